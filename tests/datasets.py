@@ -1,0 +1,115 @@
+"""Seeded input generators shared by the oracle tests, the GPU parity tests and bench.py.
+
+Own numpy code. The small designs mirror the *shapes and seeds* of the reference's test
+fixtures so that the same identities can be asserted:
+  middle_data  <- tests/conftest.py:13-45      (N=1000, 3 features, values in {-2,-1,1,2})
+  block_design <- tests/regression/test_block.py:80-113 (N=100, 1+3+2 features, 2 blocks)
+  toy          <- README.md:46-59 / examples/toy.py
+"""
+import numpy as np
+import scipy.sparse as sps
+
+STUB_W0 = -3.0
+STUB_W = np.array([1.0, 2.0, -1.0])
+STUB_V = np.array([[1.0, -1.0, 0], [0.0, 1.0, 1.0], [1.0, 1.0, 1.0], [-1.0, 0, -1.0]])  # (latent, feature)
+
+
+def fm_score(X, w0, w, V):
+    """closed form  w0 + Xw + 1/2 [ (XV)^2 . 1 - X^2 . sum V^2 ]   (V is (D, K))."""
+    X = sps.csr_matrix(X)
+    X2 = X.copy()
+    X2.data = X2.data ** 2
+    XV = X.dot(V)
+    return w0 + X.dot(w) + 0.5 * ((XV ** 2).sum(axis=1) - X2.dot((V ** 2).sum(axis=1)))
+
+
+def toy():
+    X = np.array(
+        [
+            [19.0, 0, 0, 0, 1, 1, 0, 0, 0],
+            [33.0, 0, 0, 1, 0, 0, 1, 0, 0],
+            [55.0, 0, 1, 0, 0, 0, 0, 1, 0],
+            [20.0, 1, 0, 0, 0, 0, 0, 0, 1],
+        ]
+    )
+    return sps.csr_matrix(X), np.array([0.0, 1.0, 1.0, 0.0])
+
+
+def middle_data(n_train=1000):
+    rns = np.random.RandomState(0)
+    rows, cols, data = [], [], []
+    for row in range(n_train):
+        indices = np.where(rns.random(3) > 0.5)[0]
+        for ind in indices:
+            rows.append(row)
+            cols.append(ind)
+            data.append(float(rns.choice([-2, -1, 1, 2])))
+    X = sps.csr_matrix((data, (rows, cols)), shape=(n_train, 3))
+    return X, fm_score(X, STUB_W0, STUB_W, STUB_V.T)
+
+
+def block_design(n_train=100, seed=0):
+    rns = np.random.RandomState(seed)
+    user_block = sps.csr_matrix(np.eye(3))
+    user_indices = rns.randint(0, 3, size=n_train)
+    item_block = sps.csr_matrix(np.eye(2))
+    group_shapes = [1, 3, 2]
+    item_indices = rns.randint(0, 2, size=n_train)
+    tm_column = rns.randn(n_train, 1)
+    X_flat = sps.hstack([tm_column, user_block[user_indices], item_block[item_indices]]).tocsr()
+    weights = rns.randn(3, X_flat.shape[1])
+    y = fm_score(X_flat, 0.0, np.zeros(X_flat.shape[1]), weights.T) + rns.randn(n_train)
+    blocks = [(user_indices.astype(np.int64), user_block), (item_indices.astype(np.int64), item_block)]
+    return sps.csr_matrix(tm_column), X_flat, blocks, y, group_shapes
+
+
+def multihot_block_design(n_train=400, seed=3):
+    """Blocks with multi-hot, non-unit values so that block columns conflict (several levels)."""
+    rng = np.random.default_rng(seed)
+    ub = sps.random(12, 7, density=0.4, random_state=np.random.RandomState(seed), format="csr")
+    ub.data = np.round(rng.uniform(-1.5, 1.5, size=ub.nnz), 2)
+    ib = sps.random(9, 5, density=0.5, random_state=np.random.RandomState(seed + 1), format="csr")
+    ib.data = np.round(rng.uniform(0.2, 1.0, size=ib.nnz), 2)
+    ui = rng.integers(0, 12, size=n_train)
+    ii = rng.integers(0, 9, size=n_train)
+    main = sps.random(n_train, 4, density=0.5, random_state=np.random.RandomState(seed + 2), format="csr")
+    main.data = np.round(rng.normal(size=main.nnz), 2)
+    X_flat = sps.hstack([main, ub[ui], ib[ii]]).tocsr()
+    D = X_flat.shape[1]
+    w = rng.normal(size=D) * 0.3
+    V = rng.normal(size=(D, 3)) * 0.4
+    y = fm_score(X_flat, 0.5, w, V) + rng.normal(size=n_train) * 0.5
+    blocks = [(ui.astype(np.int64), ub), (ii.astype(np.int64), ib)]
+    return main, X_flat, blocks, y, [4, 7, 5]
+
+
+def onehot_mf(n_rows, n_users, n_items, rank_true=8, seed=0, sort_by_user=True, noise=0.3, zipf=1.0):
+    """MovieLens-shaped two-field one-hot design: returns (X csr, y, group_shapes)."""
+    rng = np.random.default_rng(seed)
+    pu = 1.0 / np.arange(1, n_users + 1) ** (0.5 * zipf)
+    pi = 1.0 / np.arange(1, n_items + 1) ** zipf
+    u = rng.choice(n_users, size=n_rows, p=pu / pu.sum())
+    i = rng.choice(n_items, size=n_rows, p=pi / pi.sum())
+    # shuffle ids so that popularity is not monotone in the index
+    u = rng.permutation(n_users)[u]
+    i = rng.permutation(n_items)[i]
+    if sort_by_user:
+        order = np.argsort(u, kind="stable")
+        u, i = u[order], i[order]
+    bu = rng.normal(size=n_users) * 0.3
+    bi = rng.normal(size=n_items) * 0.3
+    U = rng.normal(size=(n_users, rank_true)) * 0.3
+    It = rng.normal(size=(n_items, rank_true)) * 0.3
+    y = 3.5 + bu[u] + bi[i] + (U[u] * It[i]).sum(axis=1) + rng.normal(size=n_rows) * noise
+    y = np.clip(np.round(y * 2) / 2, 0.5, 5.0)
+    indptr = np.arange(0, 2 * n_rows + 1, 2, dtype=np.int64)
+    indices = np.empty(2 * n_rows, dtype=np.int32)
+    indices[0::2] = u
+    indices[1::2] = n_users + i
+    data = np.ones(2 * n_rows)
+    X = sps.csr_matrix((data, indices, indptr), shape=(n_rows, n_users + n_items))
+    return X, y, [n_users, n_items]
+
+
+def group_index_from_shapes(shapes):
+    return np.concatenate([np.full(s, g, dtype=np.int32) for g, s in enumerate(shapes)])
