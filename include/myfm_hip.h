@@ -1,0 +1,166 @@
+/* myfm_hip.h -- C ABI of libmyfm_hip.so: the MI355X (gfx950) Gibbs-sampler hot path of
+ * Bayesian Factorization Machines, as the host layer behind myFM's pybind11 boundary binds it.
+ *
+ * What this replaces in the reference (paths relative to /root/reference):
+ *   the arithmetic of GibbsFMTrainer::update_all (include/myfm/BaseFMTrainer.hpp:135-152),
+ *   i.e. include/myfm/FMTrainer.hpp:127-522, the scorer FM::predict_score_write_target
+ *   (include/myfm/FM.hpp:54-136) and Predictor::predict* (include/myfm/predictor.hpp:35-147).
+ * Who calls it: myfm_amd/csrc/_myfm.cpp -- a pybind11 module with the reference's names
+ *   (cpp_source/declare_module.hpp:67-404) whose create_train_fm drives these entry points
+ *   exactly where the reference's create_train_fm (declare_module.hpp:30-45) drives Eigen.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer argument is HOST memory owned by the
+ *     caller and may be freed as soon as the call returns (the library copies / uploads);
+ *   - the ctx owns all device memory and one HIP stream; one host thread per ctx;
+ *   - matrices: CSR with int64 indptr, int32 indices, f64 data (scipy layout after
+ *     base.py:285-286); dense V is column-major (D, K) like the reference
+ *     (definitions.hpp:17), hyper matrices mu_V / lambda_V are column-major (G, K), i.e.
+ *     element (g, f) at [f * G + g] (HyperParams.hpp:18-19);
+ *   - every call returns MFM_OK or an error code; mfm_last_error() gives the message. The
+ *     host layer maps MFM_ERR_INVALID -> ValueError (std::invalid_argument in the
+ *     reference) and MFM_ERR_RUNTIME / MFM_ERR_DEVICE -> RuntimeError;
+ *   - there is NO CPU fallback: without a usable HIP device mfm_create fails with
+ *     MFM_ERR_DEVICE.
+ */
+#ifndef MYFM_HIP_H_
+#define MYFM_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFM_OK 0
+#define MFM_ERR_INVALID 1 /* std::invalid_argument in the reference -> ValueError   */
+#define MFM_ERR_RUNTIME 2 /* std::runtime_error in the reference    -> RuntimeError */
+#define MFM_ERR_DEVICE 3  /* HIP failure / no device                -> RuntimeError */
+
+/* task types: FMLearningConfig.hpp:14 (TASKTYPE) */
+#define MFM_TASK_REGRESSION 0
+#define MFM_TASK_CLASSIFICATION 1
+#define MFM_TASK_ORDERED 2
+
+typedef struct mfm_ctx mfm_ctx;       /* one training problem resident on one GPU            */
+typedef struct mfm_design mfm_design; /* a (main CSR, relation blocks) design for prediction */
+
+/* ---- library / device ---------------------------------------------------------------- */
+const char *mfm_version(void);
+/* number of visible HIP devices; 0 when there is none (never fails). */
+int mfm_device_count(void);
+/* last error of a call that had no ctx (mfm_create, mfm_design_create) on this thread. */
+const char *mfm_global_error(void);
+
+/* ---- training context: replaces the BaseFMTrainer ctor, BaseFMTrainer.hpp:58-105 ------ */
+int mfm_create(int device, mfm_ctx **out);
+void mfm_destroy(mfm_ctx *ctx);
+const char *mfm_last_error(const mfm_ctx *ctx);
+/* use an existing hipStream_t (e.g. torch's current stream) instead of the ctx's own. */
+int mfm_set_stream(mfm_ctx *ctx, void *hip_stream);
+int mfm_synchronize(mfm_ctx *ctx);
+
+/* main table X (N x D0) and targets y[N]; D0 may be 0 (base.py:230-233).                  */
+int mfm_set_main(mfm_ctx *ctx, int64_t N, int64_t D0, const int64_t *indptr, const int32_t *indices,
+                 const double *data, const double *y);
+/* RelationBlock (definitions.hpp:30-52): block CSR (B x Db) + original_to_block[N].
+ * MFM_ERR_RUNTIME "index mapping points to non-existing row." on a bad index (:38-41).    */
+int mfm_add_block(mfm_ctx *ctx, int64_t B, int64_t Db, const int64_t *indptr, const int32_t *indices,
+                  const double *data, const int64_t *original_to_block);
+/* group_index over ALL D = D0 + sum Db features (FMLearningConfig.hpp:83), G groups.      */
+int mfm_set_groups(mfm_ctx *ctx, const int32_t *group_index, int64_t D, int32_t G);
+/* Builds the device-side design: CSC (= X_t, BaseFMTrainer.hpp:61), the conflict-free level
+ * schedule of the columns, the residual/q-cache vectors. rank = n_factors (may be 0).      */
+int mfm_finalize(mfm_ctx *ctx, int32_t rank);
+
+int64_t mfm_dim_all(const mfm_ctx *ctx);
+/* schedule statistics: number of main-table levels, of main-table kernel launches per sweep */
+int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launches_per_sweep);
+
+/* ---- model state (FM.hpp:164-168) ------------------------------------------------------ */
+int mfm_set_state(mfm_ctx *ctx, double w0, const double *w, const double *V);
+int mfm_get_state(mfm_ctx *ctx, double *w0, double *w, double *V);
+int mfm_set_w0(mfm_ctx *ctx, double w0); /* scalar only; does not touch e (FMTrainer.hpp:219-222) */
+int mfm_zero_w(mfm_ctx *ctx);            /* fit_linear == false, FMTrainer.hpp:232-235            */
+/* residual e_train and per-factor cache q_train (BaseFMTrainer.hpp:46-47), for tests.      */
+int mfm_get_e(mfm_ctx *ctx, double *e);
+int mfm_get_q(mfm_ctx *ctx, double *q);
+int mfm_set_e(mfm_ctx *ctx, const double *e);
+
+/* ---- the Gibbs iteration, in update_all order (BaseFMTrainer.hpp:135-152) --------------- */
+/* sum_t e_t and sum_t e_t^2 : inputs of update_alpha (FMTrainer.hpp:138) and update_w0
+ * (:223, sum(w0 - e) = N w0 - sum e).                                                       */
+int mfm_reduce_e(mfm_ctx *ctx, double *sum_e, double *sum_e2);
+/* e += delta (FMTrainer.hpp:227).                                                           */
+int mfm_shift_e(mfm_ctx *ctx, double delta);
+/* per-group sufficient statistics of w for update_lambda_w / update_mu_w
+ * (FMTrainer.hpp:150-200): sum[g] = sum_{j in g} w_j, ssd[g] = sum_{j in g} (w_j - mu[g])^2 */
+int mfm_group_stats_w(mfm_ctx *ctx, const double *mu_w, double *sum, double *ssd);
+/* same for every factor of V (FMTrainer.hpp:202-216); all arrays (G, K) column-major.       */
+int mfm_group_stats_V(mfm_ctx *ctx, const double *mu_V, double *sum, double *ssd);
+/* update_w (FMTrainer.hpp:231-314): main table then relation blocks, feature order preserved
+ * for every pair of features that share a row. z[D] = the N(0,1) variates of the D
+ * sample_normal calls in reference order (main columns, then each block's columns).          */
+int mfm_sweep_w(mfm_ctx *ctx, double alpha, const double *lambda_w, const double *mu_w, const double *z);
+/* update_V (FMTrainer.hpp:316-486) for factors [f_begin, f_end): per factor the q-cache build
+ * (:320-340), the main-table sweep (:343-376) and the per-block sweeps (:378-482).
+ * lambda_V / mu_V: full (G, K) column-major; z: (f_end - f_begin) * D variates, factor-major. */
+int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, const double *lambda_V,
+                const double *mu_V, const double *z);
+/* update_e (FMTrainer.hpp:493-522), regression: e = predict_score(X_train) - y.             */
+int mfm_update_e_regression(mfm_ctx *ctx);
+/* update_e, probit classification (:498-512): e_t = score_t - z_t, z_t ~ TN(score_t, 1) on
+ * (0, inf) if y_t > 0 else (-inf, 0) (util.hpp:15-78). The reference consumes its mt19937 in
+ * data-dependent rejection loops; here each row draws from a Philox4x32-10 stream keyed by
+ * (seed, draw_index, row): parity is distributional.                            */
+int mfm_update_e_classification(mfm_ctx *ctx, uint64_t seed, uint64_t draw_index);
+/* e = predict_score(X_train) only (initialize_e for the ordered task, FMTrainer.hpp:100).   */
+int mfm_score_train(mfm_ctx *ctx);
+
+/* ordered probit (OProbitSampler.hpp): one cutpoint group = a row subset with n_class labels.
+ * rows == NULL means all N rows. Returns the group id in *group.                            */
+int mfm_oprobit_add_group(mfm_ctx *ctx, int32_t n_class, const int64_t *rows, int64_t n_rows, int32_t *group);
+/* log-likelihood, d/dgamma and the gamma-space Hessian accumulators of
+ * OprobitSampler::operator() (OProbitSampler.hpp:402-413, 111-236) over the group's rows at
+ * cutpoints gamma[n_class-1], on the current e (= score). H is (n_class-1)^2 row-major; pass
+ * NULL to skip it.                                                                          */
+int mfm_oprobit_eval(mfm_ctx *ctx, int32_t group, const double *gamma, double *ll, double *dgamma, double *H);
+/* sample_z_given_cutpoint (OProbitSampler.hpp:238-272): e_t -= z_t, Philox-keyed as above.  */
+int mfm_oprobit_sample_z(mfm_ctx *ctx, int32_t group, const double *gamma, uint64_t seed, uint64_t draw_index);
+
+/* ---- per-kernel timing (HIP events on the ctx stream) for bench.py's roofline block ---- */
+int mfm_timing_enable(mfm_ctx *ctx, int on);
+int mfm_timing_reset(mfm_ctx *ctx);
+int mfm_timing_n_classes(void);
+const char *mfm_timing_class_name(int cls);
+/* total milliseconds, launch count and algorithmic bytes (SURVEY 8d per-unit figures times
+ * the units each launch processed) accumulated for one kernel class since the last reset.   */
+int mfm_timing_get(mfm_ctx *ctx, int cls, double *ms_total, int64_t *launches, double *alg_bytes_total);
+
+/* ---- prediction: FM::predict_score (FM.hpp:47-136), Predictor::predict* (predictor.hpp) -- */
+int mfm_design_create(int device, int64_t N, int64_t D0, const int64_t *indptr, const int32_t *indices,
+                      const double *data, mfm_design **out);
+int mfm_design_add_block(mfm_design *d, int64_t B, int64_t Db, const int64_t *indptr, const int32_t *indices,
+                         const double *data, const int64_t *original_to_block);
+void mfm_design_destroy(mfm_design *d);
+const char *mfm_design_last_error(const mfm_design *d);
+int64_t mfm_design_dim_all(const mfm_design *d);
+/* mode 0: out[N]  = mean_s score_s                    (Predictor::predict, regression)
+ * mode 1: out[N]  = mean_s Phi(score_s)               (classification, predictor.hpp:138-143)
+ * mode 2: out[N * (n_cut + 1)] row-major = mean_s ordered-probit class probabilities with
+ *         cutpoints[s * n_cut + c]                    (FM.hpp:137-162, predictor.hpp:78-124)
+ * w0s[S], ws[S * D], Vs[S * D * K] (each sample's V column-major (D, K)).                   */
+int mfm_design_predict(mfm_design *d, int32_t rank, int32_t n_samples, const double *w0s, const double *ws,
+                       const double *Vs, int32_t mode, int32_t n_cut, const double *cutpoints, double *out);
+
+/* ---- host-only helpers (no device needed; exercised by the CPU test-suite) -------------- */
+/* Level schedule of the columns of a CSR matrix: level[j] = 0 if no earlier
+ * column shares a row with column j, else 1 + max level of those columns. Returns the number
+ * of levels in *n_levels.                                                                   */
+int mfm_host_column_levels(int64_t n_rows, int64_t n_cols, const int64_t *indptr, const int32_t *indices,
+                           int32_t *level, int32_t *n_levels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MYFM_HIP_H_ */

@@ -1,0 +1,357 @@
+"""ctypes binding of libmyfm_hip.so (include/myfm_hip.h) -- used by the parity tests and bench.py
+to reach the device path through the C ABI itself. The estimator layer goes through the pybind11
+module ``myfm_amd._myfm`` (host C++), which links the same library.
+
+There is no fallback: a missing library is an ImportError, a missing GPU is a RuntimeError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import scipy.sparse as sps
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmyfm_hip.so")
+
+MFM_OK, MFM_ERR_INVALID, MFM_ERR_RUNTIME, MFM_ERR_DEVICE = 0, 1, 2, 3
+TASK_REGRESSION, TASK_CLASSIFICATION, TASK_ORDERED = 0, 1, 2
+
+# every symbol declared in include/myfm_hip.h (tests check the library exports all of them)
+SYMBOLS = [
+    "mfm_version", "mfm_device_count", "mfm_global_error", "mfm_create", "mfm_destroy", "mfm_last_error",
+    "mfm_set_stream", "mfm_synchronize", "mfm_set_main", "mfm_add_block", "mfm_set_groups", "mfm_finalize",
+    "mfm_dim_all", "mfm_plan_info", "mfm_set_state", "mfm_get_state", "mfm_set_w0", "mfm_zero_w", "mfm_get_e",
+    "mfm_get_q", "mfm_set_e", "mfm_reduce_e", "mfm_shift_e", "mfm_group_stats_w", "mfm_group_stats_V",
+    "mfm_sweep_w", "mfm_sweep_V", "mfm_update_e_regression", "mfm_update_e_classification", "mfm_score_train",
+    "mfm_oprobit_add_group", "mfm_oprobit_eval", "mfm_oprobit_sample_z", "mfm_timing_enable", "mfm_timing_reset",
+    "mfm_timing_n_classes", "mfm_timing_class_name", "mfm_timing_get", "mfm_design_create", "mfm_design_add_block",
+    "mfm_design_destroy", "mfm_design_last_error", "mfm_design_dim_all", "mfm_design_predict",
+    "mfm_host_column_levels",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, dbl, P = C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p
+    u64 = C.c_uint64
+    L.mfm_version.restype = C.c_char_p
+    L.mfm_global_error.restype = C.c_char_p
+    L.mfm_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.mfm_destroy.argtypes = [vp]
+    L.mfm_destroy.restype = None
+    L.mfm_last_error.restype = C.c_char_p
+    L.mfm_last_error.argtypes = [vp]
+    L.mfm_set_stream.argtypes = [vp, vp]
+    L.mfm_synchronize.argtypes = [vp]
+    L.mfm_set_main.argtypes = [vp, i64, i64, P, P, P, P]
+    L.mfm_add_block.argtypes = [vp, i64, i64, P, P, P, P]
+    L.mfm_set_groups.argtypes = [vp, P, i64, i32]
+    L.mfm_finalize.argtypes = [vp, i32]
+    L.mfm_dim_all.restype = i64
+    L.mfm_dim_all.argtypes = [vp]
+    L.mfm_plan_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.mfm_set_state.argtypes = [vp, dbl, P, P]
+    L.mfm_get_state.argtypes = [vp, C.POINTER(dbl), P, P]
+    L.mfm_set_w0.argtypes = [vp, dbl]
+    L.mfm_zero_w.argtypes = [vp]
+    L.mfm_get_e.argtypes = [vp, P]
+    L.mfm_get_q.argtypes = [vp, P]
+    L.mfm_set_e.argtypes = [vp, P]
+    L.mfm_reduce_e.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl)]
+    L.mfm_shift_e.argtypes = [vp, dbl]
+    L.mfm_group_stats_w.argtypes = [vp, P, P, P]
+    L.mfm_group_stats_V.argtypes = [vp, P, P, P]
+    L.mfm_sweep_w.argtypes = [vp, dbl, P, P, P]
+    L.mfm_sweep_V.argtypes = [vp, i32, i32, dbl, P, P, P]
+    L.mfm_update_e_regression.argtypes = [vp]
+    L.mfm_update_e_classification.argtypes = [vp, u64, u64]
+    L.mfm_score_train.argtypes = [vp]
+    L.mfm_oprobit_add_group.argtypes = [vp, i32, P, i64, C.POINTER(i32)]
+    L.mfm_oprobit_eval.argtypes = [vp, i32, P, C.POINTER(dbl), P, P]
+    L.mfm_oprobit_sample_z.argtypes = [vp, i32, P, u64, u64]
+    L.mfm_timing_enable.argtypes = [vp, C.c_int]
+    L.mfm_timing_reset.argtypes = [vp]
+    L.mfm_timing_class_name.restype = C.c_char_p
+    L.mfm_timing_class_name.argtypes = [C.c_int]
+    L.mfm_timing_get.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl)]
+    L.mfm_design_create.argtypes = [C.c_int, i64, i64, P, P, P, C.POINTER(vp)]
+    L.mfm_design_add_block.argtypes = [vp, i64, i64, P, P, P, P]
+    L.mfm_design_destroy.argtypes = [vp]
+    L.mfm_design_destroy.restype = None
+    L.mfm_design_last_error.restype = C.c_char_p
+    L.mfm_design_last_error.argtypes = [vp]
+    L.mfm_design_dim_all.restype = i64
+    L.mfm_design_dim_all.argtypes = [vp]
+    L.mfm_design_predict.argtypes = [vp, i32, i32, P, P, P, i32, i32, P, P]
+    L.mfm_host_column_levels.argtypes = [i64, i64, P, P, P, C.POINTER(i32)]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def csr_parts(X):
+    X = sps.csr_matrix(X, dtype=np.float64)
+    return (
+        X,
+        np.ascontiguousarray(X.indptr, dtype=np.int64),
+        np.ascontiguousarray(X.indices, dtype=np.int32),
+        np.ascontiguousarray(X.data, dtype=np.float64),
+    )
+
+
+def _raise(code, msg):
+    msg = msg.decode() if isinstance(msg, bytes) else msg
+    if code == MFM_ERR_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def column_levels(X):
+    """Host-only: level schedule of the columns of X (no GPU needed)."""
+    X, ip, ix, _ = csr_parts(X)
+    level = np.zeros(X.shape[1], dtype=np.int32)
+    n = C.c_int32()
+    rc = lib().mfm_host_column_levels(X.shape[0], X.shape[1], _p(ip), _p(ix), _p(level), C.byref(n))
+    if rc:
+        _raise(rc, lib().mfm_global_error())
+    return level, n.value
+
+
+class Context:
+    """One training problem on one GPU: thin, explicit wrapper over the mfm_* entry points."""
+
+    def __init__(self, X, y, blocks=(), rank=4, group_index=None, device=0):
+        L = lib()
+        h = C.c_void_p()
+        rc = L.mfm_create(device, C.byref(h))
+        if rc:
+            _raise(rc, L.mfm_global_error())
+        self.h = h
+        X, ip, ix, dv = csr_parts(X)
+        y = _f64(y)
+        self.N, self.D0 = X.shape
+        self._ck(L.mfm_set_main(h, X.shape[0], X.shape[1], _p(ip), _p(ix), _p(dv), _p(y)))
+        D = X.shape[1]
+        for mp, B in blocks:
+            B, bp, bx, bv = csr_parts(B)
+            mp = np.ascontiguousarray(mp, dtype=np.int64)
+            self._ck(L.mfm_add_block(h, B.shape[0], B.shape[1], _p(bp), _p(bx), _p(bv), _p(mp)))
+            D += B.shape[1]
+        if group_index is None:
+            group_index = np.zeros(D, dtype=np.int32)
+        group_index = np.ascontiguousarray(group_index, dtype=np.int32)
+        self.G = int(group_index.max()) + 1 if D else 1
+        self._ck(L.mfm_set_groups(h, _p(group_index), group_index.shape[0], self.G))
+        self._ck(L.mfm_finalize(h, rank))
+        self.D, self.K = D, rank
+
+    def _ck(self, rc):
+        if rc:
+            _raise(rc, lib().mfm_last_error(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mfm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- state; V crosses this wrapper in the (D, K) shape of the boundary
+    def set_state(self, w0, w, V):
+        w = _f64(w)
+        Vt = _f64(np.asarray(V, dtype=np.float64).T)
+        self._ck(lib().mfm_set_state(self.h, float(w0), _p(w), _p(Vt)))
+
+    def get_state(self):
+        w0 = C.c_double()
+        w = np.empty(self.D)
+        V = np.empty((self.K, self.D))
+        self._ck(lib().mfm_get_state(self.h, C.byref(w0), _p(w), _p(V)))
+        return w0.value, w, np.ascontiguousarray(V.T)
+
+    def set_w0(self, w0):
+        self._ck(lib().mfm_set_w0(self.h, float(w0)))
+
+    def zero_w(self):
+        self._ck(lib().mfm_zero_w(self.h))
+
+    def get_e(self):
+        e = np.empty(self.N)
+        self._ck(lib().mfm_get_e(self.h, _p(e)))
+        return e
+
+    def get_q(self):
+        q = np.empty(self.N)
+        self._ck(lib().mfm_get_q(self.h, _p(q)))
+        return q
+
+    def set_e(self, e):
+        e = _f64(e)
+        self._ck(lib().mfm_set_e(self.h, _p(e)))
+
+    # --- iteration pieces
+    def reduce_e(self):
+        a, b = C.c_double(), C.c_double()
+        self._ck(lib().mfm_reduce_e(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def shift_e(self, delta):
+        self._ck(lib().mfm_shift_e(self.h, float(delta)))
+
+    def group_stats_w(self, mu_w):
+        mu_w = _f64(mu_w)
+        s, ss = np.empty(self.G), np.empty(self.G)
+        self._ck(lib().mfm_group_stats_w(self.h, _p(mu_w), _p(s), _p(ss)))
+        return s, ss
+
+    def group_stats_V(self, mu_V):
+        """mu_V: (G, K) -> (sum (G, K), ssd (G, K))"""
+        mu = _f64(np.asarray(mu_V).T)
+        s, ss = np.empty((self.K, self.G)), np.empty((self.K, self.G))
+        self._ck(lib().mfm_group_stats_V(self.h, _p(mu), _p(s), _p(ss)))
+        return s.T.copy(), ss.T.copy()
+
+    def sweep_w(self, alpha, lambda_w, mu_w, z):
+        lambda_w, mu_w, z = _f64(lambda_w), _f64(mu_w), _f64(z)
+        assert z.shape[0] == self.D
+        self._ck(lib().mfm_sweep_w(self.h, float(alpha), _p(lambda_w), _p(mu_w), _p(z)))
+
+    def sweep_V(self, f_begin, f_end, alpha, lambda_V, mu_V, z):
+        """lambda_V, mu_V: (G, K); z: ((f_end - f_begin), D)"""
+        lam, mu = _f64(np.asarray(lambda_V).T), _f64(np.asarray(mu_V).T)
+        z = _f64(z)
+        assert z.size == (f_end - f_begin) * self.D
+        self._ck(lib().mfm_sweep_V(self.h, f_begin, f_end, float(alpha), _p(lam), _p(mu), _p(z)))
+
+    def update_e_regression(self):
+        self._ck(lib().mfm_update_e_regression(self.h))
+
+    def update_e_classification(self, seed, draw_index):
+        self._ck(lib().mfm_update_e_classification(self.h, seed, draw_index))
+
+    def score_train(self):
+        self._ck(lib().mfm_score_train(self.h))
+
+    def oprobit_add_group(self, n_class, rows=None):
+        g = C.c_int32()
+        if rows is None:
+            self._ck(lib().mfm_oprobit_add_group(self.h, n_class, None, 0, C.byref(g)))
+        else:
+            rows = np.ascontiguousarray(rows, dtype=np.int64)
+            self._ck(lib().mfm_oprobit_add_group(self.h, n_class, _p(rows), rows.shape[0], C.byref(g)))
+        return g.value
+
+    def oprobit_eval(self, group, gamma, want_h=True):
+        gamma = _f64(gamma)
+        m = gamma.shape[0]
+        ll = C.c_double()
+        dg = np.empty(m)
+        H = np.empty((m, m)) if want_h else None
+        self._ck(lib().mfm_oprobit_eval(self.h, group, _p(gamma), C.byref(ll), _p(dg), _p(H)))
+        return ll.value, dg, H
+
+    def oprobit_sample_z(self, group, gamma, seed, draw_index):
+        gamma = _f64(gamma)
+        self._ck(lib().mfm_oprobit_sample_z(self.h, group, _p(gamma), seed, draw_index))
+
+    def synchronize(self):
+        self._ck(lib().mfm_synchronize(self.h))
+
+    def plan_info(self):
+        a, b = C.c_int64(), C.c_int64()
+        lib().mfm_plan_info(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    # --- timing
+    def timing_enable(self, on=True):
+        self._ck(lib().mfm_timing_enable(self.h, int(on)))
+
+    def timing_reset(self):
+        self._ck(lib().mfm_timing_reset(self.h))
+
+    def timing(self):
+        """{class name: (ms_total, launches, algorithmic_bytes_total)} for classes that ran."""
+        L = lib()
+        out = {}
+        for c in range(L.mfm_timing_n_classes()):
+            ms, n, by = C.c_double(), C.c_int64(), C.c_double()
+            self._ck(L.mfm_timing_get(self.h, c, C.byref(ms), C.byref(n), C.byref(by)))
+            if n.value:
+                out[L.mfm_timing_class_name(c).decode()] = (ms.value, n.value, by.value)
+        return out
+
+
+class Design:
+    """A prediction design (main CSR + relation blocks) resident on the GPU."""
+
+    def __init__(self, X, blocks=(), device=0):
+        L = lib()
+        h = C.c_void_p()
+        X, ip, ix, dv = csr_parts(X)
+        rc = L.mfm_design_create(device, X.shape[0], X.shape[1], _p(ip), _p(ix), _p(dv), C.byref(h))
+        if rc:
+            _raise(rc, L.mfm_global_error())
+        self.h = h
+        self.N = X.shape[0]
+        for mp, B in blocks:
+            B, bp, bx, bv = csr_parts(B)
+            mp = np.ascontiguousarray(mp, dtype=np.int64)
+            if mp.shape[0] != self.N:
+                self.close()
+                raise ValueError("Relation blocks have inconsistent mapper size with case_size")
+            rc = L.mfm_design_add_block(h, B.shape[0], B.shape[1], _p(bp), _p(bx), _p(bv), _p(mp))
+            if rc:
+                msg = L.mfm_design_last_error(h)
+                self.close()
+                _raise(rc, msg)
+        self.D = L.mfm_design_dim_all(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mfm_design_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def predict(self, samples, mode=0, cutpoints=None):
+        """samples: list of (w0, w[D], V[D, K]); mode 0 mean score, 1 mean Phi(score), 2 ordered probit."""
+        S = len(samples)
+        K = np.asarray(samples[0][2]).shape[1] if S else 0
+        w0s = _f64([s[0] for s in samples])
+        ws = _f64(np.stack([np.asarray(s[1], dtype=np.float64) for s in samples])) if S else np.empty(0)
+        Vs = _f64(np.stack([np.asarray(s[2], dtype=np.float64).T for s in samples])) if S else np.empty(0)
+        n_cut = 0
+        cp = None
+        if mode == 2:
+            cp = _f64(np.stack([np.asarray(c, dtype=np.float64) for c in cutpoints]))
+            n_cut = cp.shape[1]
+        out = np.empty((self.N, n_cut + 1) if mode == 2 else self.N)
+        rc = lib().mfm_design_predict(self.h, K, S, _p(w0s), _p(ws), _p(Vs), mode, n_cut, _p(cp), _p(out))
+        if rc:
+            _raise(rc, lib().mfm_design_last_error(self.h))
+        return out

@@ -1,0 +1,414 @@
+// mfm_block_kernels.hpp -- relation-block ("block structure", Rendle 2013) device path.
+//
+// Reference: FMTrainer.hpp:256-313 (linear weights) and :323-340, :378-482 (latent factors);
+// caches per block row are RelationWiseCache (definitions.hpp:54-84), kept here as one 64-byte
+// record rec[i] = {q, q_S, c, c_S, e, e_q, cardinality, -}.
+//
+// The O(N) passes through original_to_block are done as follows:
+//   statistics + un-sync (:268-275, :401-417): by BLOCK ROW through the inverse map
+//       (inv_ptr / inv_rows = for every block row the ascending list of training rows mapped to it),
+//       so that every sum has one owner and a fixed order -- no atomics, deterministic;
+//   re-sync (:306-311, :473-480): streaming over the training rows, gathering the block record.
+#pragma once
+#include <algorithm>
+#include <vector>
+
+#include "mfm_common.hpp"
+#include "mfm_kernels.hpp"
+#include "mfm_plan.hpp"
+
+namespace mfm {
+
+constexpr int INV_WAVE_CAP = 512;    // block rows with at most this many training rows: one wavefront
+constexpr int INV_WG_CAP = 16384;    // ... one workgroup; longer ones are chunked
+
+// rec[i].q = sum_l x_il theta_l ; optionally rec[i].q_S = sum_l x_il^2 theta_l^2 ; zero c, c_S, e, e_q.
+// FMTrainer.hpp:265-266 / :331-333 / :388-393 (+ the .array() = 0 resets at :262-263, :396-399)
+template <bool WITH_QS, bool WAVE_PER_ROW>
+__global__ __launch_bounds__(WG) void k_block_rowcache(const int32_t *__restrict__ rowptr,
+                                                       const int32_t *__restrict__ colidx,
+                                                       const double *__restrict__ val,
+                                                       const double *__restrict__ theta, double *__restrict__ rec,
+                                                       int64_t B) {
+  int64_t i;
+  int lane = 0;
+  if (WAVE_PER_ROW) {
+    i = (int64_t)blockIdx.x * (WG / WAVE) + (threadIdx.x >> 6);
+    lane = threadIdx.x & 63;
+  } else {
+    i = (int64_t)blockIdx.x * WG + threadIdx.x;
+  }
+  if (i >= B) return;
+  const int32_t b = rowptr[i], e = rowptr[i + 1];
+  double q = 0.0, qs = 0.0;
+  for (int32_t p = b + lane; p < e; p += (WAVE_PER_ROW ? WAVE : 1)) {
+    const double x = val[p], th = theta[colidx[p]];
+    q += x * th;
+    if (WITH_QS) qs += (x * x) * (th * th);
+  }
+  if (WAVE_PER_ROW) {
+    q = wave_allreduce_sum(q);
+    if (WITH_QS) qs = wave_allreduce_sum(qs);
+    if (lane != 0) return;
+  }
+  double2 *r = (double2 *)rec + i * 4;
+  r[0] = make_double2(q, qs);
+  r[1] = make_double2(0.0, 0.0);
+  r[2] = make_double2(0.0, 0.0);
+}
+
+// per-entry body of the statistics + un-sync pass for training row t mapped to a block row whose
+// (q_B, q_S) are given. Accumulates into s[4] = {c, c_S, e, e_q} (V) or s[0] = e (w).
+template <bool IS_W>
+__device__ __forceinline__ void unsync_entry(double2 *__restrict__ eq, int32_t t, double qB, double qS, double *s) {
+  double2 v = eq[t];
+  if (IS_W) {
+    s[0] += v.x;  // FMTrainer.hpp:271
+    v.x -= qB;    // :272-273
+    eq[t].x = v.x;
+  } else {
+    const double temp = v.y - qB;  // :402
+    s[0] += temp;                  // :403
+    s[1] += temp * temp;           // :404
+    s[2] += v.x;                   // :405
+    s[3] += v.x * temp;            // :406
+    v.y = temp;                    // :408
+    v.x -= (v.y * qB + 0.5 * qB * qB - 0.5 * qS);  // :412-415
+    eq[t] = v;
+  }
+}
+
+template <bool IS_W>
+__device__ __forceinline__ void unsync_store(double *__restrict__ rec, int64_t i, const double *s) {
+  double2 *r = (double2 *)rec + i * 4;
+  if (IS_W) {
+    r[2] = make_double2(s[0], 0.0);
+  } else {
+    r[1] = make_double2(s[0], s[1]);
+    r[2] = make_double2(s[2], s[3]);
+  }
+}
+
+template <bool IS_W>
+__global__ __launch_bounds__(WG) void k_unsync_wave(const int64_t *__restrict__ inv_ptr,
+                                                    const int32_t *__restrict__ inv_rows,
+                                                    const int32_t *__restrict__ brow, int n, double2 *__restrict__ eq,
+                                                    double *__restrict__ rec) {
+  const int w = blockIdx.x * (WG / WAVE) + (threadIdx.x >> 6);
+  if (w >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = brow[w];
+  const double2 qq = ((const double2 *)rec)[i * 4];
+  const int64_t b = inv_ptr[i], e = inv_ptr[i + 1];
+  double s[4] = {0, 0, 0, 0};
+  for (int64_t p = b + lane; p < e; p += WAVE) unsync_entry<IS_W>(eq, inv_rows[p], qq.x, qq.y, s);
+#pragma unroll
+  for (int k = 0; k < (IS_W ? 1 : 4); k++) s[k] = wave_allreduce_sum(s[k]);
+  if (lane == 0) unsync_store<IS_W>(rec, i, s);
+}
+
+template <bool IS_W>
+__global__ __launch_bounds__(WG) void k_unsync_wg(const int64_t *__restrict__ inv_ptr,
+                                                  const int32_t *__restrict__ inv_rows,
+                                                  const int32_t *__restrict__ brow, double2 *__restrict__ eq,
+                                                  double *__restrict__ rec) {
+  __shared__ double lds[2 * WG / WAVE];
+  const int64_t i = brow[blockIdx.x];
+  const double2 qq = ((const double2 *)rec)[i * 4];
+  const int64_t b = inv_ptr[i], e = inv_ptr[i + 1];
+  double s[4] = {0, 0, 0, 0};
+  for (int64_t p = b + threadIdx.x; p < e; p += WG) unsync_entry<IS_W>(eq, inv_rows[p], qq.x, qq.y, s);
+  wg_allreduce2<WG / WAVE>(s[0], s[1], lds);
+  if (!IS_W) wg_allreduce2<WG / WAVE>(s[2], s[3], lds);
+  if (threadIdx.x == 0) unsync_store<IS_W>(rec, i, s);
+}
+
+struct InvChunk {
+  int64_t begin;
+  int32_t len;
+  int32_t brow;
+};
+// long block rows: every chunk un-syncs its rows and leaves partial sums; k_unsync_long_fin adds them
+template <bool IS_W>
+__global__ __launch_bounds__(WG) void k_unsync_long(const InvChunk *__restrict__ chunks,
+                                                    const int32_t *__restrict__ inv_rows, double2 *__restrict__ eq,
+                                                    const double *__restrict__ rec, double *__restrict__ partial) {
+  __shared__ double lds[2 * WG / WAVE];
+  const InvChunk c = chunks[blockIdx.x];
+  const double2 qq = ((const double2 *)rec)[(int64_t)c.brow * 4];
+  double s[4] = {0, 0, 0, 0};
+  for (int p = threadIdx.x; p < c.len; p += WG) unsync_entry<IS_W>(eq, inv_rows[c.begin + p], qq.x, qq.y, s);
+  wg_allreduce2<WG / WAVE>(s[0], s[1], lds);
+  if (!IS_W) wg_allreduce2<WG / WAVE>(s[2], s[3], lds);
+  if (threadIdx.x == 0) {
+    double *o = partial + (int64_t)blockIdx.x * 4;
+    o[0] = s[0];
+    o[1] = s[1];
+    o[2] = s[2];
+    o[3] = s[3];
+  }
+}
+template <bool IS_W>
+__global__ void k_unsync_long_fin(const int32_t *__restrict__ lrows, const int32_t *__restrict__ chunk_ptr, int n,
+                                  const double *__restrict__ partial, double *__restrict__ rec) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n) return;
+  double s[4] = {0, 0, 0, 0};
+  for (int c = chunk_ptr[l]; c < chunk_ptr[l + 1]; c++)
+    for (int k = 0; k < 4; k++) s[k] += partial[(int64_t)c * 4 + k];
+  unsync_store<IS_W>(rec, lrows[l], s);
+}
+
+// re-sync, streaming over training rows: FMTrainer.hpp:473-480 (V) / :306-311 (w)
+template <bool IS_W>
+__global__ __launch_bounds__(WG) void k_resync(const int32_t *__restrict__ map, const double *__restrict__ rec,
+                                               double2 *__restrict__ eq, int64_t N) {
+  const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x;
+  if (t >= N) return;
+  const double2 qq = ((const double2 *)rec)[(int64_t)map[t] * 4];
+  if (IS_W) {
+    eq[t].x += qq.x;
+  } else {
+    double2 v = eq[t];
+    v.x += (v.y * qq.x + 0.5 * qq.x * qq.x - 0.5 * qq.y);
+    v.y += qq.x;
+    eq[t] = v;
+  }
+}
+
+// block-level caches of the fused re-score: per block row  bl = sum_l x w_l,
+// bq[s] = sum_l x v_ls, bs = sum_s sum_l x^2 v_ls^2   (FM.hpp:81, :104-106, :121-127)
+template <int GS, int SPL>
+__global__ __launch_bounds__(WG) void k_block_score_cache(const int32_t *__restrict__ rowptr,
+                                                          const int32_t *__restrict__ colidx,
+                                                          const double *__restrict__ val,
+                                                          const double *__restrict__ Vt /* block's first row */,
+                                                          const double *__restrict__ w /* block's first */, int K,
+                                                          int KS, double *__restrict__ bq, double *__restrict__ bl,
+                                                          double *__restrict__ bs, int64_t B) {
+  const int64_t i = ((int64_t)blockIdx.x * WG + threadIdx.x) / GS;
+  const int lig = threadIdx.x % GS;
+  const bool live = i < B;
+  double a[SPL], b = 0.0, lin = 0.0;
+#pragma unroll
+  for (int u = 0; u < SPL; u++) a[u] = 0.0;
+  if (live) {
+    for (int32_t p = rowptr[i]; p < rowptr[i + 1]; p++) {
+      const int32_t j = colidx[p];
+      const double x = val[p], x2 = x * x;
+      if (lig == 0) lin += x * w[j];
+      const double *row = Vt + (int64_t)j * KS;
+#pragma unroll
+      for (int u = 0; u < SPL; u++) {
+        const int s = lig + u * GS;
+        if (s < K) {
+          const double v = row[s];
+          a[u] += x * v;
+          b += x2 * (v * v);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = GS / 2; m >= 1; m >>= 1) b += __shfl_xor(b, m, WAVE);
+  if (live) {
+#pragma unroll
+    for (int u = 0; u < SPL; u++) {
+      const int s = lig + u * GS;
+      if (s < K) bq[i * KS + s] = a[u];
+    }
+    if (lig == 0) {
+      bl[i] = lin;
+      bs[i] = b;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct DevBlock {
+  int64_t B = 0, Db = 0, nnz = 0;
+  int64_t col_off = 0;  // offset of the block's features in the global feature index
+  DevSparse X;
+  DevBuf<int32_t> map;  // original_to_block (B < 2^31)
+  DevBuf<double> rec;   // [B][8]
+  DevBuf<double> bq, bl, bs;
+  StepPlan plan_V, plan_W;
+  // inverse map + bins of block rows by cardinality
+  DevBuf<int64_t> inv_ptr;
+  DevBuf<int32_t> inv_rows;
+  DevBuf<int32_t> inv_wave, inv_wg, inv_long, inv_long_chunk_ptr;
+  DevBuf<InvChunk> inv_chunks;
+  DevBuf<double> inv_partial;
+  int n_inv_wave = 0, n_inv_wg = 0, n_inv_long = 0, n_inv_chunks = 0;
+
+  void build(const HostCsr &hX, const std::vector<int64_t> &hmap, int64_t N, int KS, hipStream_t s) {
+    B = hX.rows;
+    Db = hX.cols;
+    nnz = hX.nnz();
+    HostCsr Xt = transpose_host(hX);
+    X.upload(hX, &Xt);
+    plan_V.build(Xt, WAVE * PBlockV::WAVE_R, WG * PBlockV::WG_R);
+    plan_W.build(Xt, WAVE * PBlockW::WAVE_R, WG * PBlockW::WG_R);
+    std::vector<int32_t> m32((size_t)N);
+    std::vector<int64_t> iptr((size_t)B + 1, 0);
+    for (int64_t t = 0; t < N; t++) {
+      m32[t] = (int32_t)hmap[t];
+      iptr[hmap[t] + 1]++;
+    }
+    std::vector<double> hrec((size_t)B * BLOCK_REC, 0.0);
+    for (int64_t i = 0; i < B; i++) {
+      hrec[(size_t)i * BLOCK_REC + 6] = (double)iptr[i + 1];  // cardinality, definitions.hpp:65-68
+      iptr[i + 1] += iptr[i];
+    }
+    std::vector<int32_t> irows((size_t)N);
+    {
+      std::vector<int64_t> cur(iptr.begin(), iptr.end() - 1);
+      for (int64_t t = 0; t < N; t++) irows[cur[hmap[t]]++] = (int32_t)t;
+    }
+    std::vector<int32_t> bw, bg, bl_, cptr;
+    std::vector<InvChunk> ch;
+    for (int64_t i = 0; i < B; i++) {
+      int64_t len = iptr[i + 1] - iptr[i];
+      if (len <= INV_WAVE_CAP)
+        bw.push_back((int32_t)i);
+      else if (len <= INV_WG_CAP)
+        bg.push_back((int32_t)i);
+      else {
+        cptr.push_back((int32_t)ch.size());
+        for (int64_t b = 0; b < len; b += INV_WG_CAP)
+          ch.push_back(InvChunk{iptr[i] + b, (int32_t)std::min<int64_t>(INV_WG_CAP, len - b), (int32_t)i});
+        bl_.push_back((int32_t)i);
+      }
+    }
+    cptr.push_back((int32_t)ch.size());
+    n_inv_wave = (int)bw.size();
+    n_inv_wg = (int)bg.size();
+    n_inv_long = (int)bl_.size();
+    n_inv_chunks = (int)ch.size();
+    map.upload(m32);
+    rec.upload(hrec);
+    inv_ptr.upload(iptr);
+    inv_rows.upload(irows);
+    inv_wave.upload(bw);
+    inv_wg.upload(bg);
+    inv_long.upload(bl_);
+    inv_long_chunk_ptr.upload(cptr);
+    inv_chunks.upload(ch.data(), ch.size());
+    inv_partial.alloc((size_t)std::max(n_inv_chunks, 1) * 4);
+    bq.alloc_zero((size_t)B * std::max(KS, 1), s);
+    bl.alloc_zero((size_t)B, s);
+    bs.alloc_zero((size_t)B, s);
+  }
+};
+
+static inline int cdiv_i(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// q_B (and q_S) for one coefficient vector theta (already offset to the block's first feature)
+static void block_rowcache(hipStream_t s, Timing &tm, DevBlock &B, const double *theta, bool with_qs) {
+  if (B.B == 0) return;
+  TimedLaunch t(tm, s, KC_BLOCK_ROWCACHE, 12.0 * B.nnz + 48.0 * B.B);
+  const bool wave = B.X.avg_row_nnz > 16.0;
+  dim3 grid(wave ? cdiv_i(B.B, WG / WAVE) : cdiv_i(B.B, WG)), block(WG);
+#define MFM_RC(QS, WV) \
+  hipLaunchKernelGGL((k_block_rowcache<QS, WV>), grid, block, 0, s, B.X.rowptr.p, B.X.colidx.p, B.X.rval.p, theta, B.rec.p, B.B)
+  if (with_qs) {
+    if (wave) MFM_RC(true, true); else MFM_RC(true, false);
+  } else {
+    if (wave) MFM_RC(false, true); else MFM_RC(false, false);
+  }
+#undef MFM_RC
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
+template <bool IS_W>
+static void block_unsync(hipStream_t s, Timing &tm, DevBlock &B, int64_t N, double2 *eq) {
+  TimedLaunch t(tm, s, KC_BLOCK_UNSYNC, (IS_W ? 4.0 + 8.0 + 8.0 : 4.0 + 16.0 + 16.0) * N + 32.0 * B.B);
+  if (B.n_inv_wave)
+    hipLaunchKernelGGL((k_unsync_wave<IS_W>), dim3(cdiv_i(B.n_inv_wave, WG / WAVE)), dim3(WG), 0, s, B.inv_ptr.p,
+                       B.inv_rows.p, B.inv_wave.p, B.n_inv_wave, eq, B.rec.p);
+  if (B.n_inv_wg)
+    hipLaunchKernelGGL((k_unsync_wg<IS_W>), dim3(B.n_inv_wg), dim3(WG), 0, s, B.inv_ptr.p, B.inv_rows.p, B.inv_wg.p, eq,
+                       B.rec.p);
+  if (B.n_inv_long) {
+    hipLaunchKernelGGL((k_unsync_long<IS_W>), dim3(B.n_inv_chunks), dim3(WG), 0, s, B.inv_chunks.p, B.inv_rows.p, eq,
+                       B.rec.p, B.inv_partial.p);
+    hipLaunchKernelGGL((k_unsync_long_fin<IS_W>), dim3(cdiv_i(B.n_inv_long, 64)), dim3(64), 0, s, B.inv_long.p,
+                       B.inv_long_chunk_ptr.p, B.n_inv_long, B.inv_partial.p, B.rec.p);
+  }
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
+template <bool IS_W>
+static void block_resync(hipStream_t s, Timing &tm, DevBlock &B, int64_t N, double2 *eq) {
+  if (N == 0) return;
+  TimedLaunch t(tm, s, KC_BLOCK_RESYNC, (IS_W ? 4.0 + 8.0 + 8.0 : 4.0 + 16.0 + 16.0) * N);
+  hipLaunchKernelGGL((k_resync<IS_W>), dim3(cdiv_i(N, WG)), dim3(WG), 0, s, B.map.p, B.rec.p, eq, N);
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
+static SweepArgs block_args(DevBlock &B, double *theta_all, const double *z_all, const int32_t *group_all,
+                            const double *lam, const double *mu, double alpha) {
+  SweepArgs a;
+  a.colptr = B.X.colptr.p;
+  a.rowidx = B.X.rowidx.p;
+  a.val = B.X.cval.p;
+  a.state = B.rec.p;
+  a.theta = theta_all + B.col_off;
+  a.z = z_all + B.col_off;
+  a.group = group_all + B.col_off;
+  a.lambda = lam;
+  a.mu = mu;
+  a.alpha = alpha;
+  return a;
+}
+
+// FMTrainer.hpp:256-313 for one block
+static void block_sweep_w(hipStream_t s, Timing &tm, LongScratch &ls, DevBlock &B, int64_t N, double2 *eq, double *w,
+                          const double *z, const int32_t *group, const double *lam, const double *mu, double alpha) {
+  block_rowcache(s, tm, B, w + B.col_off, false);  // :265-266
+  block_unsync<true>(s, tm, B, N, eq);             // :268-275
+  SweepArgs a = block_args(B, w, z, group, lam, mu, alpha);
+  run_plan<PBlockW>(s, tm, B.plan_W, a, ls, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP,
+                    KC_BLOCK_SWEEP);               // :276-302
+  block_rowcache(s, tm, B, w + B.col_off, false);  // :304-305
+  block_resync<true>(s, tm, B, N, eq);             // :306-311
+}
+
+// FMTrainer.hpp:378-482 for one block and one factor (q_B / q_S were filled by block_rowcache before
+// the q-cache build, :331-333 / :388-393: V_B does not change in between)
+static void block_sweep_V(hipStream_t s, Timing &tm, LongScratch &ls, DevBlock &B, int64_t N, double2 *eq, double *Vf,
+                          const double *zf, const int32_t *group, const double *lamf, const double *muf, double alpha) {
+  block_unsync<false>(s, tm, B, N, eq);  // :401-417
+  SweepArgs a = block_args(B, Vf, zf, group, lamf, muf, alpha);
+  run_plan<PBlockV>(s, tm, B.plan_V, a, ls, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP,
+                    KC_BLOCK_SWEEP);     // :419-470
+  block_resync<false>(s, tm, B, N, eq);  // :473-480
+}
+
+template <int GS, int SPL>
+static void launch_block_score_cache_t(hipStream_t s, DevBlock &B, const double *Vt, const double *w, int K, int KS) {
+  hipLaunchKernelGGL((k_block_score_cache<GS, SPL>), dim3(cdiv_i(B.B * GS, WG)), dim3(WG), 0, s, B.X.rowptr.p,
+                     B.X.colidx.p, B.X.rval.p, Vt + B.col_off * KS, w + B.col_off, K, KS, B.bq.p, B.bl.p, B.bs.p, B.B);
+}
+static void launch_block_score_cache(hipStream_t s, DevBlock &B, const double *Vt, const double *w, int K, int KS) {
+  if (B.B == 0) return;
+  if (K <= 4)
+    launch_block_score_cache_t<4, 1>(s, B, Vt, w, K, KS);
+  else if (K <= 8)
+    launch_block_score_cache_t<8, 1>(s, B, Vt, w, K, KS);
+  else if (K <= 16)
+    launch_block_score_cache_t<16, 1>(s, B, Vt, w, K, KS);
+  else if (K <= 32)
+    launch_block_score_cache_t<32, 1>(s, B, Vt, w, K, KS);
+  else if (K <= 64)
+    launch_block_score_cache_t<64, 1>(s, B, Vt, w, K, KS);
+  else if (K <= 128)
+    launch_block_score_cache_t<64, 2>(s, B, Vt, w, K, KS);
+  else if (K <= 256)
+    launch_block_score_cache_t<64, 4>(s, B, Vt, w, K, KS);
+  else
+    launch_block_score_cache_t<64, 8>(s, B, Vt, w, K, KS);
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace mfm

@@ -1,0 +1,311 @@
+// mfm_common.hpp -- host-side plumbing shared by the HIP translation units of libmyfm_hip.so:
+// error type, HIP_CHECK, RAII device buffers, pinned staging, event-based kernel timing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "myfm_hip.h"
+
+namespace mfm {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define MFM_HIP_CHECK(expr)                                                                                   \
+  do {                                                                                                        \
+    hipError_t e__ = (expr);                                                                                  \
+    if (e__ != hipSuccess)                                                                                    \
+      throw ::mfm::Error(MFM_ERR_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(e__));          \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) {
+    o.p = nullptr;
+    o.n = 0;
+  }
+  DevBuf &operator=(DevBuf &&o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p;
+      n = o.n;
+      o.p = nullptr;
+      o.n = 0;
+    }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    if (count) MFM_HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+  }
+  void alloc_zero(size_t count, hipStream_t s) {
+    alloc(count);
+    if (count) MFM_HIP_CHECK(hipMemsetAsync(p, 0, count * sizeof(T), s));
+  }
+  // synchronous upload of pageable host memory (setup path only)
+  void upload(const T *src, size_t count) {
+    alloc(count);
+    if (count) MFM_HIP_CHECK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+  }
+  void upload(const std::vector<T> &v) { upload(v.data(), v.size()); }
+};
+
+// A small ring of pinned host buffers for the per-iteration uploads (pre-drawn normals,
+// hyper-parameters): memcpy into pinned memory, hipMemcpyAsync on the ctx stream, an event
+// per slot so a slot is not overwritten while its copy is still in flight.
+struct PinnedRing {
+  static constexpr int SLOTS = 3;
+  void *buf[SLOTS] = {nullptr, nullptr, nullptr};
+  size_t cap[SLOTS] = {0, 0, 0};
+  hipEvent_t ev[SLOTS];
+  bool ev_valid[SLOTS] = {false, false, false};
+  int next = 0;
+  ~PinnedRing() {
+    for (int i = 0; i < SLOTS; i++) {
+      if (buf[i]) (void)hipHostFree(buf[i]);
+      if (ev_valid[i]) (void)hipEventDestroy(ev[i]);
+    }
+  }
+  void upload(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s) {
+    if (!bytes) return;
+    int i = next;
+    next = (next + 1) % SLOTS;
+    if (ev_valid[i]) MFM_HIP_CHECK(hipEventSynchronize(ev[i]));
+    if (cap[i] < bytes) {
+      if (buf[i]) MFM_HIP_CHECK(hipHostFree(buf[i]));
+      buf[i] = nullptr;
+      MFM_HIP_CHECK(hipHostMalloc(&buf[i], bytes, hipHostMallocDefault));
+      cap[i] = bytes;
+    }
+    std::memcpy(buf[i], src_host, bytes);
+    MFM_HIP_CHECK(hipMemcpyAsync(dst_dev, buf[i], bytes, hipMemcpyHostToDevice, s));
+    if (!ev_valid[i]) {
+      MFM_HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+      ev_valid[i] = true;
+    }
+    MFM_HIP_CHECK(hipEventRecord(ev[i], s));
+  }
+};
+
+// ---- kernel classes for the timing / roofline report --------------------------------------
+enum KernelClass {
+  KC_QBUILD = 0,       // q = X v_f (CSR SpMV)                              FMTrainer.hpp:320-340
+  KC_SWEEP_V_WAVE,     // latent sweep, one wavefront per column           FMTrainer.hpp:343-376
+  KC_SWEEP_V_WG,       // latent sweep, one workgroup per column
+  KC_SWEEP_V_LSTATS,   // latent sweep, long columns: partial statistics
+  KC_SWEEP_V_LDRAW,    //   ... draw
+  KC_SWEEP_V_LAPPLY,   //   ... apply
+  KC_SWEEP_V_CHAIN,    // latent sweep, sequential chain of tiny levels
+  KC_SWEEP_W_WAVE,     // linear sweep                                      FMTrainer.hpp:237-254
+  KC_SWEEP_W_WG,
+  KC_SWEEP_W_LSTATS,
+  KC_SWEEP_W_LDRAW,
+  KC_SWEEP_W_LAPPLY,
+  KC_SWEEP_W_CHAIN,
+  KC_UPDATE_E,         // fused rank-K re-score                             FM.hpp:54-136
+  KC_BUILD_VT,         // V -> row-major gather table for the scorer
+  KC_REDUCE_E,         // sum e, sum e^2                                    FMTrainer.hpp:138,223
+  KC_SHIFT_E,          // e += delta                                        FMTrainer.hpp:227
+  KC_GROUP_STATS,      // per-group sums of w / V                           FMTrainer.hpp:150-192
+  KC_BLOCK_ROWCACHE,   // q_B, q_S, block-level scorer caches               FMTrainer.hpp:265,331,388
+  KC_BLOCK_UNSYNC,     // statistics + un-sync pass through original_to_block  FMTrainer.hpp:268-275,401-417
+  KC_BLOCK_RESYNC,     // re-sync pass                                      FMTrainer.hpp:306-311,473-480
+  KC_BLOCK_SWEEP,      // block feature sweeps                              FMTrainer.hpp:276-302,419-470
+  KC_TN_SAMPLE,        // truncated-normal latent z                         util.hpp:15-78
+  KC_OPROBIT_EVAL,     // cutpoint likelihood / gradient / Hessian          OProbitSampler.hpp:389-413
+  KC_PREDICT,          // Predictor::predict*                               predictor.hpp:35-147
+  KC_N
+};
+
+static const char *const kKernelClassNames[KC_N] = {
+    "qbuild_spmv",        "sweep_V_wave",      "sweep_V_workgroup",  "sweep_V_long_stats", "sweep_V_long_draw",
+    "sweep_V_long_apply", "sweep_V_chain",     "sweep_w_wave",       "sweep_w_workgroup",  "sweep_w_long_stats",
+    "sweep_w_long_draw",  "sweep_w_long_apply", "sweep_w_chain",     "update_e_score",     "build_vt",
+    "reduce_e",           "shift_e",           "group_stats",        "block_rowcache",     "block_unsync",
+    "block_resync",       "block_sweep",       "tn_sample",          "oprobit_eval",       "predict"};
+
+struct Timing {
+  bool on = false;
+  struct Rec {
+    hipEvent_t a, b;
+    int cls;
+  };
+  std::vector<Rec> pending;
+  std::vector<hipEvent_t> pool;
+  double ms[KC_N] = {0};
+  int64_t launches[KC_N] = {0};
+  double bytes[KC_N] = {0};
+
+  ~Timing() {
+    for (auto &r : pending) {
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
+    }
+    for (auto e : pool) (void)hipEventDestroy(e);
+  }
+  hipEvent_t get_event() {
+    if (!pool.empty()) {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    MFM_HIP_CHECK(hipEventCreate(&e));
+    return e;
+  }
+  void resolve() {
+    for (auto &r : pending) {
+      MFM_HIP_CHECK(hipEventSynchronize(r.b));
+      float t = 0;
+      MFM_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+      ms[r.cls] += t;
+      pool.push_back(r.a);
+      pool.push_back(r.b);
+    }
+    pending.clear();
+  }
+  void reset() {
+    resolve();
+    for (int i = 0; i < KC_N; i++) {
+      ms[i] = 0;
+      launches[i] = 0;
+      bytes[i] = 0;
+    }
+  }
+};
+
+// RAII scope: brackets one kernel launch with events when timing is on.
+struct TimedLaunch {
+  Timing &t;
+  hipStream_t s;
+  int cls;
+  hipEvent_t a;
+  TimedLaunch(Timing &t_, hipStream_t s_, int cls_, double alg_bytes) : t(t_), s(s_), cls(cls_), a(nullptr) {
+    if (t.on) {
+      t.launches[cls]++;
+      t.bytes[cls] += alg_bytes;
+      a = t.get_event();
+      MFM_HIP_CHECK(hipEventRecord(a, s));
+    }
+  }
+  ~TimedLaunch() {
+    if (t.on && a) {
+      hipEvent_t b = t.get_event();
+      (void)hipEventRecord(b, s);
+      t.pending.push_back({a, b, cls});
+    }
+  }
+};
+
+// ---- host-side sparse helpers ---------------------------------------------------------------
+struct HostCsr {
+  int64_t rows = 0, cols = 0;
+  std::vector<int64_t> ptr;
+  std::vector<int32_t> idx;
+  std::vector<double> val;
+  int64_t nnz() const { return (int64_t)idx.size(); }
+};
+
+inline HostCsr make_host_csr(int64_t rows, int64_t cols, const int64_t *indptr, const int32_t *indices,
+                             const double *data) {
+  if (rows < 0 || cols < 0) throw Error(MFM_ERR_INVALID, "negative matrix shape");
+  HostCsr X;
+  X.rows = rows;
+  X.cols = cols;
+  X.ptr.assign(indptr, indptr + rows + 1);
+  if (X.ptr[0] != 0) throw Error(MFM_ERR_INVALID, "indptr[0] must be 0");
+  for (int64_t i = 0; i < rows; i++)
+    if (X.ptr[i + 1] < X.ptr[i]) throw Error(MFM_ERR_INVALID, "indptr must be non-decreasing");
+  int64_t nnz = X.ptr[rows];
+  if (nnz >= (int64_t)2147483647) throw Error(MFM_ERR_INVALID, "nnz must be < 2^31 per matrix");
+  X.idx.assign(indices, indices + nnz);
+  X.val.assign(data, data + nnz);
+  for (int64_t p = 0; p < nnz; p++)
+    if (X.idx[p] < 0 || X.idx[p] >= cols) throw Error(MFM_ERR_INVALID, "column index out of range");
+  return X;
+}
+
+// CSC of X with ascending row order inside every column (= Eigen's X.transpose() stored
+// row-major, BaseFMTrainer.hpp:61).
+inline HostCsr transpose_host(const HostCsr &X) {
+  HostCsr T;
+  T.rows = X.cols;
+  T.cols = X.rows;
+  T.ptr.assign(X.cols + 1, 0);
+  for (int64_t p = 0; p < X.nnz(); p++) T.ptr[X.idx[p] + 1]++;
+  for (int64_t j = 0; j < X.cols; j++) T.ptr[j + 1] += T.ptr[j];
+  T.idx.resize(X.nnz());
+  T.val.resize(X.nnz());
+  std::vector<int64_t> cur(T.ptr.begin(), T.ptr.end() - 1);
+  for (int64_t i = 0; i < X.rows; i++)
+    for (int64_t p = X.ptr[i]; p < X.ptr[i + 1]; p++) {
+      int64_t q = cur[X.idx[p]]++;
+      T.idx[q] = (int32_t)i;
+      T.val[q] = X.val[p];
+    }
+  return T;
+}
+
+// SURVEY A.5. csc: one "row" per column, listing the rows it touches.
+inline int32_t column_levels(const HostCsr &csc, std::vector<int32_t> &level) {
+  std::vector<int32_t> rowlevel((size_t)csc.cols, -1);
+  level.assign((size_t)csc.rows, 0);
+  int32_t n_levels = 0;
+  for (int64_t j = 0; j < csc.rows; j++) {
+    int32_t m = -1;
+    for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) m = std::max(m, rowlevel[csc.idx[p]]);
+    int32_t lv = m + 1;
+    level[j] = lv;
+    for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) rowlevel[csc.idx[p]] = lv;
+    n_levels = std::max(n_levels, lv + 1);
+  }
+  return n_levels;
+}
+
+// Device-resident sparse matrix: CSR (row passes: q-build, re-score) and CSC (column sweeps).
+struct DevSparse {
+  int64_t rows = 0, cols = 0, nnz = 0;
+  DevBuf<int32_t> rowptr, colidx;
+  DevBuf<double> rval;
+  DevBuf<int64_t> colptr;
+  DevBuf<int32_t> rowidx;
+  DevBuf<double> cval;
+  double avg_row_nnz = 0;
+  void upload(const HostCsr &X, const HostCsr *Xt /* may be null: CSR only */) {
+    rows = X.rows;
+    cols = X.cols;
+    nnz = X.nnz();
+    std::vector<int32_t> rp((size_t)rows + 1);
+    for (int64_t i = 0; i <= rows; i++) rp[i] = (int32_t)X.ptr[i];
+    rowptr.upload(rp);
+    colidx.upload(X.idx);
+    rval.upload(X.val);
+    avg_row_nnz = rows ? (double)nnz / rows : 0;
+    if (Xt) {
+      colptr.upload(Xt->ptr);
+      rowidx.upload(Xt->idx);
+      cval.upload(Xt->val);
+    }
+  }
+};
+
+}  // namespace mfm

@@ -1,0 +1,659 @@
+// mfm_hip.hip -- libmyfm_hip.so: the training context and the C ABI of include/myfm_hip.h.
+//
+// Host side of the device path: builds the device-resident design (CSR + CSC + conflict-free
+// level schedule), launches the kernels of mfm_kernels.hpp / mfm_block_kernels.hpp on one HIP
+// stream and exposes them as the entry points the pybind11 host layer (csrc/_myfm.cpp) binds.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "mfm_common.hpp"
+#include "mfm_kernels.hpp"
+#include "mfm_plan.hpp"
+#include "mfm_block_kernels.hpp"
+
+namespace mfm {
+static thread_local std::string g_global_error;
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+}  // namespace mfm
+
+using namespace mfm;
+
+struct mfm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  bool finalized = false;
+
+  // host-side staging until finalize
+  HostCsr hX;
+  std::vector<double> hy;
+  struct HostBlock {
+    HostCsr X;
+    std::vector<int64_t> map;
+  };
+  std::vector<HostBlock> hblocks;
+  std::vector<int32_t> hgroup;
+  int32_t G = 0;
+
+  // device design
+  int64_t N = 0, D0 = 0, D = 0;
+  int K = 0, KS = 0;
+  DevSparse X;
+  StepPlan plan_V, plan_W;
+  LongScratch ls;
+  std::vector<std::unique_ptr<DevBlock>> blocks;
+  DevBuf<double> y;
+  DevBuf<double2> eq;
+  DevBuf<int32_t> group;
+  DevBuf<int32_t> feat_sorted;
+  DevBuf<int64_t> group_ptr;
+
+  // model state
+  double w0 = 0;
+  DevBuf<double> w, V, Vt;
+
+  // per-iteration scratch
+  DevBuf<double> z;             // max(1, K) * D
+  DevBuf<double> lam, mu;       // (G, K) column-major (or [G] for w)
+  DevBuf<double2> red_partial;  // REDUCE_BLOCKS
+  DevBuf<double2> red_out;      // 1 + G * max(1,K)
+  DevBuf<double> scratch_n;     // N doubles (get/set e,q)
+  PinnedRing ring;
+  double2 *h_red = nullptr;  // pinned readback
+  size_t h_red_cap = 0;
+  Timing timing;
+
+  // ordered probit groups
+  struct OGroup {
+    int n_class = 0;
+    int64_t n_rows = 0;
+    DevBuf<int32_t> rows;  // empty => all rows
+  };
+  std::vector<std::unique_ptr<OGroup>> ogroups;
+  DevBuf<double> opartial;
+
+  ~mfm_ctx() {
+    if (h_red) (void)hipHostFree(h_red);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+  void use_device() { MFM_HIP_CHECK(hipSetDevice(device)); }
+  void need_final() const {
+    if (!finalized) throw Error(MFM_ERR_RUNTIME, "mfm_finalize has not been called");
+  }
+  double2 *readback(size_t n) {
+    if (h_red_cap < n) {
+      if (h_red) MFM_HIP_CHECK(hipHostFree(h_red));
+      h_red = nullptr;
+      MFM_HIP_CHECK(hipHostMalloc((void **)&h_red, n * sizeof(double2), hipHostMallocDefault));
+      h_red_cap = n;
+    }
+    return h_red;
+  }
+};
+
+#define MFM_TRY(ctx) \
+  try {              \
+    (ctx)->use_device();
+#define MFM_CATCH(ctx)                 \
+  return MFM_OK;                       \
+  }                                    \
+  catch (const mfm::Error &ex) {       \
+    (ctx)->err = ex.what();            \
+    return ex.code;                    \
+  }                                    \
+  catch (const std::bad_alloc &) {     \
+    (ctx)->err = "host out of memory"; \
+    return MFM_ERR_RUNTIME;            \
+  }                                    \
+  catch (const std::exception &ex) {   \
+    (ctx)->err = ex.what();            \
+    return MFM_ERR_RUNTIME;            \
+  }
+
+// =============================================================================================
+// launch helpers
+// =============================================================================================
+namespace mfm {
+
+static void fill_gather_args(std::vector<std::unique_ptr<DevBlock>> &blocks, BlockGatherArgs &g) {
+  std::memset(&g, 0, sizeof(g));
+  g.n_blocks = (int)blocks.size();
+  for (size_t b = 0; b < blocks.size(); b++) {
+    g.map[b] = blocks[b]->map.p;
+    g.rec[b] = blocks[b]->rec.p;
+  }
+}
+
+// q = X v_f + sum_b q_B[map_b]   (FMTrainer.hpp:320-340); the blocks' q_B must be in rec already
+static void launch_qbuild(mfm_ctx *c, const double *vf) {
+  if (c->N == 0) return;
+  hipStream_t s = c->stream;
+  BlockGatherArgs g;
+  fill_gather_args(c->blocks, g);
+  TimedLaunch t(c->timing, s, KC_QBUILD, 12.0 * c->X.nnz + 8.0 * c->N + 8.0 * c->D0 + 12.0 * c->N * g.n_blocks);
+  if (c->X.avg_row_nnz <= 16.0) {
+    hipLaunchKernelGGL(k_qbuild_rows, dim3(cdiv(c->N, WG)), dim3(WG), 0, s, c->X.rowptr.p, c->X.colidx.p, c->X.rval.p, vf,
+                       c->eq.p, c->N, g);
+  } else {
+    hipLaunchKernelGGL(k_qbuild_wave, dim3(cdiv(c->N, WG / WAVE)), dim3(WG), 0, s, c->X.rowptr.p, c->X.colidx.p,
+                       c->X.rval.p, vf, c->eq.p, c->N, g);
+  }
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
+template <int GS, int SPL>
+static void launch_score_t(hipStream_t s, int mode, const DevSparse &X, const double *Vt, const double *w, double w0, int K,
+                           int KS, const double *y, double2 *eq, double *out, const BlockScoreArgs &blk) {
+  const int64_t N = X.rows;
+  dim3 grid(cdiv(N * GS, WG)), block(WG);
+  if (mode == 0)
+    hipLaunchKernelGGL((k_score<GS, SPL, 0>), grid, block, 0, s, X.rowptr.p, X.colidx.p, X.rval.p, Vt, w, w0, K, KS, y, eq,
+                       out, N, blk);
+  else
+    hipLaunchKernelGGL((k_score<GS, SPL, 1>), grid, block, 0, s, X.rowptr.p, X.colidx.p, X.rval.p, Vt, w, w0, K, KS, y, eq,
+                       out, N, blk);
+}
+
+// mode 0: eq.x = score (- y)   mode 1: out = score
+static void launch_score(hipStream_t s, int mode, const DevSparse &X, const double *Vt, const double *w, double w0, int K,
+                         int KS, const double *y, double2 *eq, double *out, const BlockScoreArgs &blk) {
+  if (X.rows == 0) return;
+#define MFM_SCORE(GS, SPL) launch_score_t<GS, SPL>(s, mode, X, Vt, w, w0, K, KS, y, eq, out, blk)
+  if (K <= 4)
+    MFM_SCORE(4, 1);
+  else if (K <= 8)
+    MFM_SCORE(8, 1);
+  else if (K <= 16)
+    MFM_SCORE(16, 1);
+  else if (K <= 32)
+    MFM_SCORE(32, 1);
+  else if (K <= 64)
+    MFM_SCORE(64, 1);
+  else if (K <= 128)
+    MFM_SCORE(64, 2);
+  else if (K <= 256)
+    MFM_SCORE(64, 4);
+  else if (K <= 512)
+    MFM_SCORE(64, 8);
+  else
+    throw Error(MFM_ERR_INVALID, "rank > 512 is not supported");
+#undef MFM_SCORE
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
+static void build_vt(hipStream_t s, const double *V, double *Vt, int64_t D, int K, int KS) {
+  if (K == 0 || D == 0) return;
+  hipLaunchKernelGGL(k_build_vt, dim3(cdiv(D, 32), cdiv(KS, 32)), dim3(WG), 0, s, V, Vt, D, K, KS);
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
+// score of a design under (w0, w, V): builds Vt and the block-level caches, then one fused pass
+static void score_design(hipStream_t s, Timing &tm, int mode, const DevSparse &X, std::vector<std::unique_ptr<DevBlock>> &blocks,
+                         int64_t D, int K, int KS, double w0, const double *w, const double *V, double *Vt, const double *y,
+                         double2 *eq, double *out) {
+  {
+    TimedLaunch t(tm, s, KC_BUILD_VT, 16.0 * D * K);
+    build_vt(s, V, Vt, D, K, KS);
+  }
+  BlockScoreArgs blk;
+  std::memset(&blk, 0, sizeof(blk));
+  blk.n_blocks = (int)blocks.size();
+  for (size_t b = 0; b < blocks.size(); b++) {
+    DevBlock &B = *blocks[b];
+    TimedLaunch t(tm, s, KC_BLOCK_ROWCACHE, 12.0 * B.nnz + 8.0 * B.B * (K + 2));
+    launch_block_score_cache(s, B, Vt, w, K, KS);
+    blk.map[b] = B.map.p;
+    blk.bq[b] = B.bq.p;
+    blk.bl[b] = B.bl.p;
+    blk.bs[b] = B.bs.p;
+  }
+  TimedLaunch t(tm, s, KC_UPDATE_E,
+                12.0 * X.nnz + 16.0 * X.rows + 8.0 * D * (K + 1) + (4.0 + 8.0 * (K + 2)) * X.rows * blk.n_blocks);
+  launch_score(s, mode, X, Vt, w, w0, K, KS, y, eq, out, blk);
+}
+
+static void score_train(mfm_ctx *c, bool subtract_y) {
+  score_design(c->stream, c->timing, 0, c->X, c->blocks, c->D, c->K, c->KS, c->w0, c->w.p, c->V.p, c->Vt.p,
+               subtract_y ? c->y.p : nullptr, c->eq.p, nullptr);
+}
+
+static SweepArgs main_args(mfm_ctx *c, double *theta, const double *z, const double *lam, const double *mu, double alpha) {
+  SweepArgs a;
+  a.colptr = c->X.colptr.p;
+  a.rowidx = c->X.rowidx.p;
+  a.val = c->X.cval.p;
+  a.state = c->eq.p;
+  a.theta = theta;
+  a.z = z;
+  a.group = c->group.p;
+  a.lambda = lam;
+  a.mu = mu;
+  a.alpha = alpha;
+  return a;
+}
+
+}  // namespace mfm
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char *mfm_version(void) { return "myfm_hip 0.1 (gfx950)"; }
+
+int mfm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+const char *mfm_global_error(void) { return g_global_error.c_str(); }
+
+int mfm_create(int device, mfm_ctx **out) {
+  *out = nullptr;
+  try {
+    int n = mfm_device_count();
+    if (n <= 0)
+      throw Error(MFM_ERR_DEVICE,
+                  "no HIP device is visible: libmyfm_hip.so has no CPU fallback (the Gibbs hot path runs on MI355X only)");
+    if (device < 0 || device >= n) throw Error(MFM_ERR_INVALID, "device index out of range");
+    std::unique_ptr<mfm_ctx> c(new mfm_ctx());
+    c->device = device;
+    c->use_device();
+    MFM_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    *out = c.release();
+    return MFM_OK;
+  } catch (const mfm::Error &ex) {
+    g_global_error = ex.what();
+    return ex.code;
+  } catch (const std::exception &ex) {
+    g_global_error = ex.what();
+    return MFM_ERR_RUNTIME;
+  }
+}
+
+void mfm_destroy(mfm_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  delete ctx;
+}
+
+const char *mfm_last_error(const mfm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_global_error.c_str(); }
+
+int mfm_set_stream(mfm_ctx *ctx, void *hip_stream) {
+  MFM_TRY(ctx)
+  if (ctx->own_stream && ctx->stream) {
+    MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MFM_HIP_CHECK(hipStreamDestroy(ctx->stream));
+  }
+  ctx->stream = (hipStream_t)hip_stream;
+  ctx->own_stream = false;
+  MFM_CATCH(ctx)
+}
+
+int mfm_synchronize(mfm_ctx *ctx) {
+  MFM_TRY(ctx)
+  MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  MFM_CATCH(ctx)
+}
+
+int mfm_set_main(mfm_ctx *ctx, int64_t N, int64_t D0, const int64_t *indptr, const int32_t *indices, const double *data,
+                 const double *y) {
+  MFM_TRY(ctx)
+  if (ctx->finalized) throw Error(MFM_ERR_RUNTIME, "design already finalized");
+  ctx->hX = make_host_csr(N, D0, indptr, indices, data);
+  ctx->hy.assign(y, y + N);
+  MFM_CATCH(ctx)
+}
+
+int mfm_add_block(mfm_ctx *ctx, int64_t B, int64_t Db, const int64_t *indptr, const int32_t *indices, const double *data,
+                  const int64_t *original_to_block) {
+  MFM_TRY(ctx)
+  if (ctx->finalized) throw Error(MFM_ERR_RUNTIME, "design already finalized");
+  if ((int)ctx->hblocks.size() >= MAX_BLOCKS) throw Error(MFM_ERR_INVALID, "too many relation blocks (max 16)");
+  mfm_ctx::HostBlock hb;
+  hb.X = make_host_csr(B, Db, indptr, indices, data);
+  int64_t N = ctx->hX.rows;
+  hb.map.assign(original_to_block, original_to_block + N);
+  for (int64_t t = 0; t < N; t++)  // definitions.hpp:38-41
+    if (hb.map[t] < 0 || hb.map[t] >= B) throw Error(MFM_ERR_RUNTIME, "index mapping points to non-existing row.");
+  ctx->hblocks.push_back(std::move(hb));
+  MFM_CATCH(ctx)
+}
+
+int mfm_set_groups(mfm_ctx *ctx, const int32_t *group_index, int64_t D, int32_t G) {
+  MFM_TRY(ctx)
+  if (ctx->finalized) throw Error(MFM_ERR_RUNTIME, "design already finalized");
+  if (G <= 0) throw Error(MFM_ERR_INVALID, "n_groups must be positive");
+  ctx->hgroup.assign(group_index, group_index + D);
+  std::vector<char> seen((size_t)G, 0);
+  for (auto g : ctx->hgroup) {
+    if (g < 0 || g >= G) throw Error(MFM_ERR_INVALID, "group index out of range");
+    seen[g] = 1;
+  }
+  for (int g = 0; g < G; g++)  // FMLearningConfig.hpp:33-40
+    if (!seen[g]) throw Error(MFM_ERR_INVALID, "No matching index for group index " + std::to_string(g) + " found.");
+  ctx->G = G;
+  MFM_CATCH(ctx)
+}
+
+int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
+  MFM_TRY(ctx)
+  if (ctx->finalized) throw Error(MFM_ERR_RUNTIME, "design already finalized");
+  if (rank < 0) throw Error(MFM_ERR_INVALID, "rank must be non-negative");
+  mfm_ctx *c = ctx;
+  c->N = c->hX.rows;
+  c->D0 = c->hX.cols;
+  c->D = c->D0;
+  for (auto &hb : c->hblocks) c->D += hb.X.cols;
+  if (c->G == 0) throw Error(MFM_ERR_RUNTIME, "mfm_set_groups has not been called");
+  if ((int64_t)c->hgroup.size() != c->D)
+    throw Error(MFM_ERR_INVALID, "group_index has " + std::to_string(c->hgroup.size()) + " entries but the design has " +
+                                     std::to_string(c->D) + " features");
+  if (c->N >= (int64_t)2147483647) throw Error(MFM_ERR_INVALID, "N must be < 2^31 per GPU");
+  c->K = rank;
+  c->KS = (rank + 1) & ~1;
+  // main table
+  {
+    HostCsr Xt = transpose_host(c->hX);
+    c->X.upload(c->hX, &Xt);
+    c->plan_V.build(Xt, WAVE * PMainV::WAVE_R, WG * PMainV::WG_R);
+    c->plan_W.build(Xt, WAVE * PMainW::WAVE_R, WG * PMainW::WG_R);
+  }
+  c->y.upload(c->hy);
+  c->eq.alloc_zero((size_t)c->N, c->stream);
+  c->group.upload(c->hgroup);
+  // features sorted by group (FMLearningConfig.hpp:41-46 group_vs_feature_index)
+  {
+    std::vector<int64_t> gptr((size_t)c->G + 1, 0);
+    for (auto g : c->hgroup) gptr[g + 1]++;
+    for (int g = 0; g < c->G; g++) gptr[g + 1] += gptr[g];
+    std::vector<int32_t> fs((size_t)c->D);
+    std::vector<int64_t> cur(gptr.begin(), gptr.end() - 1);
+    for (int64_t j = 0; j < c->D; j++) fs[cur[c->hgroup[j]]++] = (int32_t)j;
+    c->group_ptr.upload(gptr);
+    c->feat_sorted.upload(fs);
+  }
+  // relation blocks
+  int64_t off = c->D0;
+  int max_chunks = std::max(c->plan_V.max_chunks, c->plan_W.max_chunks);
+  int max_long = std::max(c->plan_V.max_long, c->plan_W.max_long);
+  for (auto &hb : c->hblocks) {
+    std::unique_ptr<DevBlock> B(new DevBlock());
+    B->col_off = off;
+    B->build(hb.X, hb.map, c->N, c->KS, c->stream);
+    off += B->Db;
+    max_chunks = std::max({max_chunks, B->plan_V.max_chunks, B->plan_W.max_chunks});
+    max_long = std::max({max_long, B->plan_V.max_long, B->plan_W.max_long});
+    c->blocks.push_back(std::move(B));
+  }
+  c->ls.reserve(std::max(max_chunks, 1), std::max(max_long, 1));
+  // state + scratch
+  c->w.alloc_zero((size_t)c->D, c->stream);
+  c->V.alloc_zero((size_t)c->D * c->K, c->stream);
+  c->Vt.alloc_zero((size_t)c->D * c->KS, c->stream);
+  c->z.alloc((size_t)std::max<int64_t>(c->D, 1) * std::max(c->K, 1));
+  c->lam.alloc((size_t)c->G * std::max(c->K, 1));
+  c->mu.alloc((size_t)c->G * std::max(c->K, 1));
+  c->red_partial.alloc(REDUCE_BLOCKS);
+  c->red_out.alloc((size_t)1 + (size_t)c->G * std::max(c->K, 1));
+  c->scratch_n.alloc((size_t)std::max<int64_t>(c->N, 1));
+  MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
+  // host copies are no longer needed
+  c->hX = HostCsr();
+  c->hy.clear();
+  c->hy.shrink_to_fit();
+  c->hblocks.clear();
+  c->finalized = true;
+  MFM_CATCH(ctx)
+}
+
+int64_t mfm_dim_all(const mfm_ctx *ctx) { return ctx->D; }
+
+int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launches_per_sweep) {
+  if (n_levels_main) *n_levels_main = (int64_t)ctx->plan_V.n_levels;
+  if (n_launches_per_sweep) {
+    int64_t n = ctx->plan_V.launches;
+    for (auto &B : ctx->blocks) n += B->plan_V.launches + 3;
+    *n_launches_per_sweep = n;
+  }
+  return MFM_OK;
+}
+
+// ---- state ------------------------------------------------------------------------------------
+int mfm_set_state(mfm_ctx *ctx, double w0, const double *w, const double *V) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  ctx->w0 = w0;
+  ctx->ring.upload(ctx->w.p, w, (size_t)ctx->D * sizeof(double), ctx->stream);
+  if (ctx->K) ctx->ring.upload(ctx->V.p, V, (size_t)ctx->D * ctx->K * sizeof(double), ctx->stream);
+  MFM_CATCH(ctx)
+}
+
+int mfm_get_state(mfm_ctx *ctx, double *w0, double *w, double *V) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  *w0 = ctx->w0;
+  if (ctx->D)
+    MFM_HIP_CHECK(hipMemcpyAsync(w, ctx->w.p, (size_t)ctx->D * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->K && ctx->D)
+    MFM_HIP_CHECK(
+        hipMemcpyAsync(V, ctx->V.p, (size_t)ctx->D * ctx->K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  MFM_CATCH(ctx)
+}
+
+int mfm_set_w0(mfm_ctx *ctx, double w0) {
+  ctx->w0 = w0;
+  return MFM_OK;
+}
+
+int mfm_zero_w(mfm_ctx *ctx) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  if (ctx->D) MFM_HIP_CHECK(hipMemsetAsync(ctx->w.p, 0, (size_t)ctx->D * sizeof(double), ctx->stream));
+  MFM_CATCH(ctx)
+}
+
+static int get_eq(mfm_ctx *ctx, double *dst, int which) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  if (ctx->N) {
+    hipLaunchKernelGGL(k_get_eq, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq.p, ctx->scratch_n.p, ctx->N,
+                       which);
+    MFM_HIP_CHECK(
+        hipMemcpyAsync(dst, ctx->scratch_n.p, (size_t)ctx->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  MFM_CATCH(ctx)
+}
+int mfm_get_e(mfm_ctx *ctx, double *e) { return get_eq(ctx, e, 0); }
+int mfm_get_q(mfm_ctx *ctx, double *q) { return get_eq(ctx, q, 1); }
+int mfm_set_e(mfm_ctx *ctx, const double *e) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  if (ctx->N) {
+    MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MFM_HIP_CHECK(hipMemcpy(ctx->scratch_n.p, e, (size_t)ctx->N * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_set_eq, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq.p, ctx->scratch_n.p, ctx->N, 0);
+    MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  }
+  MFM_CATCH(ctx)
+}
+
+// ---- reductions / hyper statistics ------------------------------------------------------------
+int mfm_reduce_e(mfm_ctx *ctx, double *sum_e, double *sum_e2) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  hipStream_t s = ctx->stream;
+  {
+    TimedLaunch t(ctx->timing, s, KC_REDUCE_E, 8.0 * ctx->N);
+    hipLaunchKernelGGL(k_reduce_e_partial, dim3(REDUCE_BLOCKS), dim3(WG), 0, s, ctx->eq.p, ctx->N, ctx->red_partial.p);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, s, ctx->red_partial.p, REDUCE_BLOCKS, ctx->red_out.p);
+  }
+  double2 *h = ctx->readback(1);
+  MFM_HIP_CHECK(hipMemcpyAsync(h, ctx->red_out.p, sizeof(double2), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipStreamSynchronize(s));
+  *sum_e = h[0].x;
+  *sum_e2 = h[0].y;
+  MFM_CATCH(ctx)
+}
+
+int mfm_shift_e(mfm_ctx *ctx, double delta) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  if (ctx->N) {
+    TimedLaunch t(ctx->timing, ctx->stream, KC_SHIFT_E, 16.0 * ctx->N);
+    hipLaunchKernelGGL(k_shift_e, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq.p, ctx->N, delta);
+    MFM_HIP_CHECK(hipGetLastError());
+  }
+  MFM_CATCH(ctx)
+}
+
+static int group_stats(mfm_ctx *ctx, const double *theta, int nf, const double *mu_host, double *sum, double *ssd) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  hipStream_t s = ctx->stream;
+  const int G = ctx->G;
+  if (nf > 0) {
+    ctx->ring.upload(ctx->mu.p, mu_host, (size_t)G * nf * sizeof(double), s);
+    {
+      TimedLaunch t(ctx->timing, s, KC_GROUP_STATS, 12.0 * ctx->D * nf);
+      hipLaunchKernelGGL(k_group_stats, dim3(G, nf), dim3(WG), 0, s, theta, ctx->D, ctx->feat_sorted.p, ctx->group_ptr.p,
+                         ctx->mu.p, G, ctx->red_out.p + 1);
+    }
+    double2 *h = ctx->readback((size_t)G * nf + 1);
+    MFM_HIP_CHECK(hipMemcpyAsync(h, ctx->red_out.p + 1, (size_t)G * nf * sizeof(double2), hipMemcpyDeviceToHost, s));
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < G * nf; i++) {
+      sum[i] = h[i].x;
+      ssd[i] = h[i].y;
+    }
+  }
+  MFM_CATCH(ctx)
+}
+int mfm_group_stats_w(mfm_ctx *ctx, const double *mu_w, double *sum, double *ssd) {
+  return group_stats(ctx, ctx->w.p, 1, mu_w, sum, ssd);
+}
+int mfm_group_stats_V(mfm_ctx *ctx, const double *mu_V, double *sum, double *ssd) {
+  return group_stats(ctx, ctx->V.p, ctx->K, mu_V, sum, ssd);
+}
+
+// ---- sweeps -----------------------------------------------------------------------------------
+int mfm_sweep_w(mfm_ctx *ctx, double alpha, const double *lambda_w, const double *mu_w, const double *z) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  mfm_ctx *c = ctx;
+  hipStream_t s = c->stream;
+  c->ring.upload(c->lam.p, lambda_w, (size_t)c->G * sizeof(double), s);
+  c->ring.upload(c->mu.p, mu_w, (size_t)c->G * sizeof(double), s);
+  c->ring.upload(c->z.p, z, (size_t)c->D * sizeof(double), s);
+  SweepArgs a = main_args(c, c->w.p, c->z.p, c->lam.p, c->mu.p, alpha);
+  run_plan<PMainW>(s, c->timing, c->plan_W, a, c->ls, KC_SWEEP_W_WAVE, KC_SWEEP_W_WG, KC_SWEEP_W_LSTATS, KC_SWEEP_W_LDRAW,
+                   KC_SWEEP_W_LAPPLY, KC_SWEEP_W_CHAIN);
+  for (auto &B : c->blocks)
+    block_sweep_w(s, c->timing, c->ls, *B, c->N, c->eq.p, c->w.p, c->z.p, c->group.p, c->lam.p, c->mu.p, alpha);
+  MFM_CATCH(ctx)
+}
+
+int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, const double *lambda_V, const double *mu_V,
+                const double *z) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  mfm_ctx *c = ctx;
+  if (f_begin < 0 || f_end > c->K || f_begin > f_end) throw Error(MFM_ERR_INVALID, "factor range out of bounds");
+  if (f_begin == f_end) return MFM_OK;
+  hipStream_t s = c->stream;
+  c->ring.upload(c->lam.p, lambda_V, (size_t)c->G * c->K * sizeof(double), s);
+  c->ring.upload(c->mu.p, mu_V, (size_t)c->G * c->K * sizeof(double), s);
+  c->ring.upload(c->z.p, z, (size_t)c->D * (f_end - f_begin) * sizeof(double), s);
+  for (int f = f_begin; f < f_end; f++) {
+    double *Vf = c->V.p + (size_t)f * c->D;
+    const double *zf = c->z.p + (size_t)(f - f_begin) * c->D;
+    const double *lamf = c->lam.p + (size_t)f * c->G;
+    const double *muf = c->mu.p + (size_t)f * c->G;
+    for (auto &B : c->blocks) block_rowcache(s, c->timing, *B, Vf + B->col_off, true);  // :331-333, :388-393
+    launch_qbuild(c, Vf);                                                               // :320, :334-337
+    SweepArgs a = main_args(c, Vf, zf, lamf, muf, alpha);
+    run_plan<PMainV>(s, c->timing, c->plan_V, a, c->ls, KC_SWEEP_V_WAVE, KC_SWEEP_V_WG, KC_SWEEP_V_LSTATS, KC_SWEEP_V_LDRAW,
+                     KC_SWEEP_V_LAPPLY, KC_SWEEP_V_CHAIN);                              // :343-376
+    for (auto &B : c->blocks)
+      block_sweep_V(s, c->timing, c->ls, *B, c->N, c->eq.p, Vf, zf, c->group.p, lamf, muf, alpha);  // :378-482
+  }
+  MFM_CATCH(ctx)
+}
+
+int mfm_update_e_regression(mfm_ctx *ctx) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  score_train(ctx, true);
+  MFM_CATCH(ctx)
+}
+
+int mfm_score_train(mfm_ctx *ctx) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  score_train(ctx, false);
+  MFM_CATCH(ctx)
+}
+
+// ---- timing ---------------------------------------------------------------------------------------
+int mfm_timing_enable(mfm_ctx *ctx, int on) {
+  MFM_TRY(ctx)
+  if (!on) ctx->timing.resolve();
+  ctx->timing.on = on != 0;
+  MFM_CATCH(ctx)
+}
+int mfm_timing_reset(mfm_ctx *ctx) {
+  MFM_TRY(ctx)
+  MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->timing.reset();
+  MFM_CATCH(ctx)
+}
+int mfm_timing_n_classes(void) { return KC_N; }
+const char *mfm_timing_class_name(int cls) { return (cls >= 0 && cls < KC_N) ? kKernelClassNames[cls] : ""; }
+int mfm_timing_get(mfm_ctx *ctx, int cls, double *ms_total, int64_t *launches, double *alg_bytes_total) {
+  MFM_TRY(ctx)
+  if (cls < 0 || cls >= KC_N) throw Error(MFM_ERR_INVALID, "bad kernel class");
+  MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->timing.resolve();
+  *ms_total = ctx->timing.ms[cls];
+  *launches = ctx->timing.launches[cls];
+  *alg_bytes_total = ctx->timing.bytes[cls];
+  MFM_CATCH(ctx)
+}
+
+int mfm_host_column_levels(int64_t n_rows, int64_t n_cols, const int64_t *indptr, const int32_t *indices, int32_t *level,
+                           int32_t *n_levels) {
+  try {
+    HostCsr X;
+    X.rows = n_rows;
+    X.cols = n_cols;
+    X.ptr.assign(indptr, indptr + n_rows + 1);
+    X.idx.assign(indices, indices + indptr[n_rows]);
+    X.val.assign((size_t)indptr[n_rows], 1.0);
+    HostCsr Xt = transpose_host(X);
+    std::vector<int32_t> lv;
+    *n_levels = column_levels(Xt, lv);
+    std::copy(lv.begin(), lv.end(), level);
+    return MFM_OK;
+  } catch (const std::exception &ex) {
+    g_global_error = ex.what();
+    return MFM_ERR_RUNTIME;
+  }
+}
+
+}  // extern "C"
+
+#include "mfm_tasks.hpp"    // classification / ordered-probit entry points
+#include "mfm_predict.hpp"  // mfm_design_* entry points

@@ -1,0 +1,557 @@
+// mfm_kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the Gibbs hot path.
+//
+// Data layout in HBM:
+//   eq[N]      double2 {e_t, q_t}: the residual and the per-factor q-cache interleaved, so that
+//              one 16-byte access serves both vectors of the latent sweep (FMTrainer.hpp:351-374
+//              reads and writes e and q at the same rows).
+//   rec[B][8]  one 64-byte record per relation-block row: {q, q_S, c, c_S, e, e_q, cardinality, -}
+//              (RelationWiseCache, definitions.hpp:54-84) so a block-feature sweep gathers one
+//              record per entry instead of seven scattered doubles.
+//   CSC        colptr int64[D+1], rowidx int32[nnz], val f64[nnz]   (= X_t, BaseFMTrainer.hpp:61)
+//   CSR        rowptr int32[N+1], colidx int32[nnz], val f64[nnz]
+//   V          factor-major [K][D] (the reference's column-major (D,K)), w[D]
+//   Vt         row-major gather table [D][KS] for the fused re-score, KS = K rounded up to even
+//
+// All arithmetic is fp64. The path is HBM/gather bound (< 0.1 flop/byte): no MFMA here by design.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mfm {
+
+constexpr int WAVE = 64;
+constexpr int WG = 256;         // threads per workgroup
+constexpr int CHAIN_WG = 1024;  // threads of the sequential-chain kernel
+constexpr int BLOCK_REC = 8;    // doubles per relation-block row record
+
+struct SweepArgs {
+  const int64_t *colptr;
+  const int32_t *rowidx;
+  const double *val;
+  void *state;           // double2 eq[N] (main table) or double rec[B][8] (relation block)
+  double *theta;         // w or V[:, f], already offset to this matrix's first feature
+  const double *z;       // pre-drawn N(0,1) variates, same indexing
+  const int32_t *group;  // group_index, same indexing
+  const double *lambda;  // [G] for this sweep
+  const double *mu;      // [G]
+  double alpha;
+};
+
+struct ChunkDesc {
+  int64_t begin;  // first CSC entry
+  int32_t len;
+  int32_t lcol;  // index into the level's long-column list
+};
+
+__device__ __forceinline__ double wave_allreduce_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+  return v;
+}
+
+// all threads of the workgroup obtain the same totals; fixed summation tree (deterministic).
+template <int NW>
+__device__ __forceinline__ void wg_allreduce2(double &a, double &b, double *lds /* [2 * NW] */) {
+  a = wave_allreduce_sum(a);
+  b = wave_allreduce_sum(b);
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    lds[wid * 2] = a;
+    lds[wid * 2 + 1] = b;
+  }
+  __syncthreads();
+  a = 0;
+  b = 0;
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    a += lds[w * 2];
+    b += lds[w * 2 + 1];
+  }
+  __syncthreads();
+}
+
+// sample_normal (FMTrainer.hpp:122-125) with the N(0,1) variate supplied
+__device__ __forceinline__ double sample_normal_z(double quad, double first, double z) {
+  return (first / quad) + z / sqrt(quad);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sweep policies: what one coordinate's conditional needs from the entries of its column.
+//   St         per-entry state gathered from memory
+//   stats      accumulates the two sufficient statistics
+//   draw       the conditional draw from (S1, S2)
+//   apply      the scatter update of the entry's state
+// ---------------------------------------------------------------------------------------------
+// latent factors, main table: FMTrainer.hpp:343-376
+struct PMainV {
+  static constexpr int WAVE_R = 4, WG_R = 16;
+  static constexpr double BYTES = 44.0, STAT_BYTES = 28.0;  // per nnz: CSC 12 + eq 16 (+ eq 16 write)
+  typedef double2 St;
+  static __device__ __forceinline__ St load(const SweepArgs &a, int row) { return ((const double2 *)a.state)[row]; }
+  static __device__ __forceinline__ void stats(double x, const St &s, double old, double &S1, double &S2) {
+    const double h = x * (s.y - x * old);
+    S2 += h * h;
+    S1 += (-s.x) * h;
+  }
+  static __device__ __forceinline__ double draw(double S1, double S2, double old, double alpha, double lam, double mu,
+                                                double z) {
+    double lin = S1 + S2 * old;  // :358
+    double sq = S2 * alpha;      // :360
+    lin = lin * alpha;           // :361
+    sq += lam;                   // :363
+    lin += lam * mu;             // :364-365
+    return sample_normal_z(sq, lin, z);
+  }
+  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St s, double old, double fresh) {
+    const double delta = fresh - old;
+    const double h = x * (s.y - x * old);
+    s.y += x * delta;  // :373
+    s.x += h * delta;  // :374
+    ((double2 *)a.state)[row] = s;
+  }
+};
+
+// linear weights, main table: FMTrainer.hpp:237-254
+struct PMainW {
+  static constexpr int WAVE_R = 4, WG_R = 16;
+  static constexpr double BYTES = 28.0, STAT_BYTES = 20.0;
+  typedef double St;
+  static __device__ __forceinline__ St load(const SweepArgs &a, int row) { return ((const double2 *)a.state)[row].x; }
+  static __device__ __forceinline__ void stats(double x, const St &e, double old, double &S1, double &S2) {
+    const double et = e - x * old;  // :242
+    S2 += x * x;                    // :246
+    S1 += x * et;                   // :248
+  }
+  static __device__ __forceinline__ double draw(double S1, double S2, double old, double alpha, double lam, double mu,
+                                                double z) {
+    const double sq = lam + alpha * S2;
+    const double lin = -alpha * S1 + lam * mu;
+    return sample_normal_z(sq, lin, z);
+  }
+  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St e, double old, double fresh) {
+    e -= x * old;
+    e += x * fresh;  // :252
+    ((double2 *)a.state)[row].x = e;
+  }
+};
+
+struct BlockRec {
+  double2 qq;  // q, q_S
+  double2 cc;  // c, c_S
+  double2 ee;  // e, e_q
+  double2 kk;  // cardinality, unused
+};
+
+// latent factors, relation block: FMTrainer.hpp:419-470
+struct PBlockV {
+  static constexpr int WAVE_R = 4, WG_R = 4;
+  static constexpr double BYTES = 12.0 + 64.0 + 48.0, STAT_BYTES = 12.0 + 64.0;
+  typedef BlockRec St;
+  static __device__ __forceinline__ St load(const SweepArgs &a, int row) {
+    const double2 *r = (const double2 *)a.state + (int64_t)row * 4;
+    St s;
+    s.qq = r[0];
+    s.cc = r[1];
+    s.ee = r[2];
+    s.kk = r[3];
+    return s;
+  }
+  static __device__ __forceinline__ void stats(double x, const St &s, double old, double &S1, double &S2) {
+    const double h_B = s.qq.x - x * old;                                      // :432
+    double h_squared = h_B * h_B * s.kk.x + 2 * s.cc.x * h_B + s.cc.y;        // :433-436
+    h_squared = x * x * h_squared;                                            // :437
+    S2 += h_squared;                                                          // :438
+    S1 += (-s.ee.x * h_B - s.ee.y) * x;                                       // :439-441
+  }
+  static __device__ __forceinline__ double draw(double S1, double S2, double old, double alpha, double lam, double mu,
+                                                double z) {
+    return PMainV::draw(S1, S2, old, alpha, lam, mu, z);  // :443-450
+  }
+  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St s, double old, double fresh) {
+    const double delta = fresh - old;
+    const double h_B = s.qq.x - x * old;                      // :456
+    s.qq.x += delta * x;                                      // :457
+    s.qq.y += delta * (fresh + old) * x * x;                  // :458-459
+    s.ee.x += x * delta * (h_B * s.kk.x + s.cc.x);            // :461-464
+    s.ee.y += x * delta * (h_B * s.cc.x + s.cc.y);            // :465-468
+    double2 *r = (double2 *)a.state + (int64_t)row * 4;
+    r[0] = s.qq;
+    r[2] = s.ee;
+  }
+};
+
+// linear weights, relation block: FMTrainer.hpp:276-302
+struct PBlockW {
+  static constexpr int WAVE_R = 4, WG_R = 8;
+  static constexpr double BYTES = 12.0 + 32.0 + 8.0, STAT_BYTES = 12.0 + 32.0;
+  struct St {
+    double e, card;
+  };
+  static __device__ __forceinline__ St load(const SweepArgs &a, int row) {
+    const double2 *r = (const double2 *)a.state + (int64_t)row * 4;
+    St s;
+    s.e = r[2].x;
+    s.card = r[3].x;
+    return s;
+  }
+  static __device__ __forceinline__ void stats(double x, const St &s, double old, double &S1, double &S2) {
+    S2 += (x * x) * s.card;  // :285-287
+    S1 += x * s.e;           // :288-289
+  }
+  static __device__ __forceinline__ double draw(double S1, double S2, double old, double alpha, double lam, double mu,
+                                                double z) {
+    double lin = -S1;
+    lin += S2 * old;                 // :291
+    const double sq = lam + alpha * S2;  // :293
+    lin = alpha * lin + lam * mu;    // :294
+    return sample_normal_z(sq, lin, z);
+  }
+  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St s, double old, double fresh) {
+    s.e += (x * s.card) * (fresh - old);  // :298-301
+    ((double *)a.state)[(int64_t)row * BLOCK_REC + 4] = s.e;
+  }
+};
+
+// One column handled by NT cooperating threads (NT = 64: a wavefront, NT = 256: the workgroup),
+// at most NT * R entries. The column's (row, x, state) are staged in registers so that the CSC
+// column and the gathered state are read from memory exactly once: pass 1 statistics, draw,
+// pass 2 scatter (FMTrainer.hpp:351-375).
+template <class P, int R, int NT>
+__device__ __forceinline__ void column_update(const SweepArgs &a, int j, int tid, double *lds) {
+  const int64_t begin = a.colptr[j];
+  const int len = (int)(a.colptr[j + 1] - begin);
+  const double old = a.theta[j];
+  int32_t ri[R];
+  double xv[R];
+  typename P::St st[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int p = tid + r * NT;
+    ri[r] = -1;
+    xv[r] = 0.0;
+    if (p < len) {
+      ri[r] = a.rowidx[begin + p];
+      xv[r] = a.val[begin + p];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++)
+    if (ri[r] >= 0) st[r] = P::load(a, ri[r]);
+  double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; r++)
+    if (ri[r] >= 0) P::stats(xv[r], st[r], old, S1, S2);
+  if (NT == WAVE) {
+    S1 = wave_allreduce_sum(S1);
+    S2 = wave_allreduce_sum(S2);
+  } else {
+    wg_allreduce2<NT / WAVE>(S1, S2, lds);
+  }
+  const int g = a.group[j];
+  const double fresh = P::draw(S1, S2, old, a.alpha, a.lambda[g], a.mu[g], a.z[j]);
+#pragma unroll
+  for (int r = 0; r < R; r++)
+    if (ri[r] >= 0) P::apply(a, ri[r], xv[r], st[r], old, fresh);
+  if (tid == 0) a.theta[j] = fresh;
+}
+
+// one wavefront per column; 4 columns per workgroup
+template <class P>
+__global__ __launch_bounds__(WG) void k_sweep_wave(SweepArgs a, const int32_t *__restrict__ cols, int n_cols) {
+  const int w = blockIdx.x * (WG / WAVE) + (threadIdx.x >> 6);
+  if (w >= n_cols) return;
+  column_update<P, P::WAVE_R, WAVE>(a, cols[w], threadIdx.x & 63, nullptr);
+}
+
+// one workgroup per column
+template <class P>
+__global__ __launch_bounds__(WG) void k_sweep_wg(SweepArgs a, const int32_t *__restrict__ cols) {
+  __shared__ double lds[2 * WG / WAVE];
+  column_update<P, P::WG_R, WG>(a, cols[blockIdx.x], threadIdx.x, lds);
+}
+
+// ---- long columns: statistics per chunk, draw, apply ------------------------------------------
+template <class P>
+__global__ __launch_bounds__(WG) void k_long_stats(SweepArgs a, const ChunkDesc *__restrict__ chunks,
+                                                   const int32_t *__restrict__ lcols, double2 *__restrict__ partial) {
+  __shared__ double lds[2 * WG / WAVE];
+  const ChunkDesc c = chunks[blockIdx.x];
+  const double old = a.theta[lcols[c.lcol]];
+  double S1 = 0.0, S2 = 0.0;
+  for (int p = threadIdx.x; p < c.len; p += WG) {
+    const int32_t row = a.rowidx[c.begin + p];
+    const double x = a.val[c.begin + p];
+    const typename P::St s = P::load(a, row);
+    P::stats(x, s, old, S1, S2);
+  }
+  wg_allreduce2<WG / WAVE>(S1, S2, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = make_double2(S1, S2);
+}
+
+template <class P>
+__global__ void k_long_draw(SweepArgs a, const int32_t *__restrict__ lcols, const int32_t *__restrict__ chunk_ptr,
+                            int n_long, const double2 *__restrict__ partial, double2 *__restrict__ oldnew) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n_long) return;
+  const int j = lcols[l];
+  double S1 = 0.0, S2 = 0.0;
+  for (int c = chunk_ptr[l]; c < chunk_ptr[l + 1]; c++) {  // fixed order: deterministic
+    S1 += partial[c].x;
+    S2 += partial[c].y;
+  }
+  const double old = a.theta[j];
+  const int g = a.group[j];
+  const double fresh = P::draw(S1, S2, old, a.alpha, a.lambda[g], a.mu[g], a.z[j]);
+  a.theta[j] = fresh;
+  oldnew[l] = make_double2(old, fresh);
+}
+
+template <class P>
+__global__ __launch_bounds__(WG) void k_long_apply(SweepArgs a, const ChunkDesc *__restrict__ chunks,
+                                                   const double2 *__restrict__ oldnew) {
+  const ChunkDesc c = chunks[blockIdx.x];
+  const double2 on = oldnew[c.lcol];
+  for (int p = threadIdx.x; p < c.len; p += WG) {
+    const int32_t row = a.rowidx[c.begin + p];
+    const double x = a.val[c.begin + p];
+    const typename P::St s = P::load(a, row);
+    P::apply(a, row, x, s, on.x, on.y);
+  }
+}
+
+// ---- sequential chain: a run of tiny levels handled by ONE workgroup, column after column -------
+// Used where the conflict graph leaves no parallelism across columns (dense / multi-hot columns,
+// small relation blocks): a launch per level would be launch-latency bound.
+template <class P>
+__global__ __launch_bounds__(CHAIN_WG) void k_chain(SweepArgs a, const int32_t *__restrict__ cols, int n_cols) {
+  __shared__ double lds[2 * CHAIN_WG / WAVE];
+  for (int c = 0; c < n_cols; c++) {
+    const int j = cols[c];
+    const int64_t begin = a.colptr[j];
+    const int len = (int)(a.colptr[j + 1] - begin);
+    const double old = a.theta[j];
+    double S1 = 0.0, S2 = 0.0;
+    for (int p = threadIdx.x; p < len; p += CHAIN_WG) {
+      const int32_t row = a.rowidx[begin + p];
+      const double x = a.val[begin + p];
+      const typename P::St s = P::load(a, row);
+      P::stats(x, s, old, S1, S2);
+    }
+    wg_allreduce2<CHAIN_WG / WAVE>(S1, S2, lds);
+    const int g = a.group[j];
+    const double fresh = P::draw(S1, S2, old, a.alpha, a.lambda[g], a.mu[g], a.z[j]);
+    for (int p = threadIdx.x; p < len; p += CHAIN_WG) {
+      const int32_t row = a.rowidx[begin + p];
+      const double x = a.val[begin + p];
+      const typename P::St s = P::load(a, row);
+      P::apply(a, row, x, s, old, fresh);
+    }
+    if (threadIdx.x == 0) a.theta[j] = fresh;
+    __syncthreads();  // this column's stores are visible to the workgroup before the next column loads
+  }
+}
+
+// ---- q-cache build: q = X v_f (+ block contributions)  (FMTrainer.hpp:320-340), CSR SpMV --------
+constexpr int MAX_BLOCKS = 16;
+struct BlockGatherArgs {
+  int n_blocks;
+  const int32_t *map[MAX_BLOCKS];
+  const double *rec[MAX_BLOCKS];
+};
+
+// thread per row: the right shape for one-hot / few-nnz rows (coalesced over consecutive rows)
+__global__ __launch_bounds__(WG) void k_qbuild_rows(const int32_t *__restrict__ rowptr,
+                                                    const int32_t *__restrict__ colidx,
+                                                    const double *__restrict__ val, const double *__restrict__ vf,
+                                                    double2 *__restrict__ eq, int64_t N, BlockGatherArgs blk) {
+  const int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x;
+  if (i >= N) return;
+  const int32_t b = rowptr[i], e = rowptr[i + 1];
+  double s = 0.0;
+  for (int32_t p = b; p < e; p++) s += val[p] * vf[colidx[p]];
+  for (int bi = 0; bi < blk.n_blocks; bi++) s += blk.rec[bi][(int64_t)blk.map[bi][i] * BLOCK_REC];  // :335-337
+  eq[i].y = s;
+}
+// wavefront per row: long rows (dense main tables)
+__global__ __launch_bounds__(WG) void k_qbuild_wave(const int32_t *__restrict__ rowptr,
+                                                    const int32_t *__restrict__ colidx,
+                                                    const double *__restrict__ val, const double *__restrict__ vf,
+                                                    double2 *__restrict__ eq, int64_t N, BlockGatherArgs blk) {
+  const int64_t i = (int64_t)blockIdx.x * (WG / WAVE) + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const int lane = threadIdx.x & 63;
+  const int32_t b = rowptr[i], e = rowptr[i + 1];
+  double s = 0.0;
+  for (int32_t p = b + lane; p < e; p += WAVE) s += val[p] * vf[colidx[p]];
+  s = wave_allreduce_sum(s);
+  if (lane == 0) {
+    for (int bi = 0; bi < blk.n_blocks; bi++) s += blk.rec[bi][(int64_t)blk.map[bi][i] * BLOCK_REC];
+    eq[i].y = s;
+  }
+}
+
+// ---- fused re-score (update_e, FMTrainer.hpp:494 -> FM.hpp:78-135) ------------------------------
+// score_t = w0 + sum_j x w_j + 1/2 sum_f [ (sum_j x v_jf)^2 - sum_j x^2 v_jf^2 ]  (+ block terms)
+// One CSR pass instead of the reference's 2K+1 SpMVs: GS lanes cooperate on one row, lane s of the
+// group owns factor slots s, s+GS, ...; V rows are gathered from the row-major table Vt.
+// Block contributions come pre-reduced per block row (bq: [B][KS] q_B per factor, bl: [B] linear,
+// bs: [B] sum_f q_S) and are gathered through original_to_block.
+struct BlockScoreArgs {
+  int n_blocks;
+  const int32_t *map[MAX_BLOCKS];
+  const double *bq[MAX_BLOCKS];  // [B][KS]
+  const double *bl[MAX_BLOCKS];  // [B]
+  const double *bs[MAX_BLOCKS];  // [B]
+};
+
+// OUT_MODE 0: eq[t].x = score - y[t] (y may be null => score)   1: out[t] = score
+template <int GS, int SPL, int OUT_MODE>
+__global__ __launch_bounds__(WG) void k_score(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                              const double *__restrict__ val, const double *__restrict__ Vt,
+                                              const double *__restrict__ w, double w0, int K, int KS,
+                                              const double *__restrict__ y, double2 *__restrict__ eq,
+                                              double *__restrict__ out, int64_t N, BlockScoreArgs blk) {
+  const int64_t t = ((int64_t)blockIdx.x * WG + threadIdx.x) / GS;
+  const int lig = threadIdx.x % GS;
+  const bool live = t < N;
+  double a[SPL], b[SPL];
+#pragma unroll
+  for (int u = 0; u < SPL; u++) {
+    a[u] = 0.0;
+    b[u] = 0.0;
+  }
+  double lin = 0.0;
+  if (live) {
+    const int32_t pb = rowptr[t], pe = rowptr[t + 1];
+    for (int32_t p = pb; p < pe; p++) {
+      const int32_t j = colidx[p];
+      const double x = val[p];
+      const double x2 = x * x;
+      if (lig == 0) lin += x * w[j];
+      const double *row = Vt + (int64_t)j * KS;
+#pragma unroll
+      for (int u = 0; u < SPL; u++) {
+        const int s = lig + u * GS;
+        if (s < K) {
+          const double v = row[s];
+          a[u] += x * v;
+          b[u] += x2 * (v * v);
+        }
+      }
+    }
+    for (int bi = 0; bi < blk.n_blocks; bi++) {
+      const int64_t i = blk.map[bi][t];
+      if (lig == 0) lin += blk.bl[bi][i];
+      const double *row = blk.bq[bi] + i * KS;
+#pragma unroll
+      for (int u = 0; u < SPL; u++) {
+        const int s = lig + u * GS;
+        if (s < K) a[u] += row[s];
+      }
+      if (lig == 0) b[0] += blk.bs[bi][i];
+    }
+  }
+  double part = 0.0;
+#pragma unroll
+  for (int u = 0; u < SPL; u++) part += (a[u] * a[u] - b[u]);
+  part = 0.5 * part + lin;
+#pragma unroll
+  for (int m = GS / 2; m >= 1; m >>= 1) part += __shfl_xor(part, m, WAVE);
+  if (live && lig == 0) {
+    const double score = w0 + part;
+    if (OUT_MODE == 0) {
+      eq[t].x = y ? (score - y[t]) : score;
+    } else {
+      out[t] = score;
+    }
+  }
+}
+
+// Vt[j][s] = V[s][j]  (s < K), row stride KS
+__global__ __launch_bounds__(WG) void k_build_vt(const double *__restrict__ V, double *__restrict__ Vt, int64_t D, int K,
+                                                 int KS) {
+  __shared__ double tile[32][33];
+  // 32 x 32 tiles: read coalesced along j, write coalesced along s
+  const int64_t j0 = (int64_t)blockIdx.x * 32;
+  const int s0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int s = s0 + r;
+    const int64_t j = j0 + tx;
+    tile[r][tx] = (s < K && j < D) ? V[(int64_t)s * D + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t j = j0 + r;
+    const int s = s0 + tx;
+    if (j < D && s < KS) Vt[j * KS + s] = tile[tx][r];
+  }
+}
+
+// ---- reductions over the residual ------------------------------------------------------------------
+constexpr int REDUCE_BLOCKS = 1024;
+__global__ __launch_bounds__(WG) void k_reduce_e_partial(const double2 *__restrict__ eq, int64_t N,
+                                                         double2 *__restrict__ partial) {
+  __shared__ double lds[2 * WG / WAVE];
+  double s = 0.0, s2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x; i < N; i += (int64_t)gridDim.x * WG) {
+    const double e = eq[i].x;
+    s += e;
+    s2 += e * e;
+  }
+  wg_allreduce2<WG / WAVE>(s, s2, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = make_double2(s, s2);
+}
+__global__ __launch_bounds__(WG) void k_reduce_final(const double2 *__restrict__ partial, int n,
+                                                     double2 *__restrict__ out) {
+  __shared__ double lds[2 * WG / WAVE];
+  double s = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < n; i += WG) {
+    s += partial[i].x;
+    s2 += partial[i].y;
+  }
+  wg_allreduce2<WG / WAVE>(s, s2, lds);
+  if (threadIdx.x == 0) out[0] = make_double2(s, s2);
+}
+
+__global__ __launch_bounds__(WG) void k_shift_e(double2 *__restrict__ eq, int64_t N, double delta) {
+  const int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x;
+  if (i < N) eq[i].x += delta;
+}
+
+// group statistics: block (g, f) reduces theta over the features of group g (sorted list).
+// out[(f * G + g)] = { sum theta, sum (theta - mu)^2 }
+__global__ __launch_bounds__(WG) void k_group_stats(const double *__restrict__ theta, int64_t D,
+                                                    const int32_t *__restrict__ feat_sorted,
+                                                    const int64_t *__restrict__ group_ptr,
+                                                    const double *__restrict__ mu, int G, double2 *__restrict__ out) {
+  __shared__ double lds[2 * WG / WAVE];
+  const int g = blockIdx.x, f = blockIdx.y;
+  const double m = mu[f * G + g];
+  const double *th = theta + (int64_t)f * D;
+  double s = 0.0, ss = 0.0;
+  for (int64_t p = group_ptr[g] + threadIdx.x; p < group_ptr[g + 1]; p += WG) {
+    const double v = th[feat_sorted[p]];
+    s += v;
+    const double d = v - m;
+    ss += d * d;
+  }
+  wg_allreduce2<WG / WAVE>(s, ss, lds);
+  if (threadIdx.x == 0) out[f * G + g] = make_double2(s, ss);
+}
+
+__global__ void k_set_eq(double2 *__restrict__ eq, const double *__restrict__ src, int64_t N, int which) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) {
+    if (which == 0)
+      eq[i].x = src[i];
+    else
+      eq[i].y = src[i];
+  }
+}
+__global__ void k_get_eq(const double2 *__restrict__ eq, double *__restrict__ dst, int64_t N, int which) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) dst[i] = which == 0 ? eq[i].x : eq[i].y;
+}
+
+}  // namespace mfm

@@ -1,0 +1,340 @@
+// mfm_tasks.hpp -- probit classification and ordered-probit pieces of update_e
+// (FMTrainer.hpp:498-521, util.hpp:15-78, OProbitSampler.hpp). Included by mfm_hip.hip.
+//
+// Random numbers: the reference draws the latent z_t row after row from its single mt19937 inside
+// data-dependent rejection loops, which has no parallel equivalent. Here every row owns a
+// counter-based Philox4x32-10 stream keyed by (seed, draw_index, row), so results are reproducible
+// for a seed and independent of the launch geometry; parity with the reference is distributional.
+#pragma once
+
+namespace mfm {
+
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+    const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += W0;
+    k.y += W1;
+  }
+  return c;
+}
+
+struct RowRng {
+  uint2 key;
+  uint32_t row, d0, d1, n;
+  __device__ RowRng(uint64_t seed, uint64_t draw, uint32_t row_)
+      : key(make_uint2((uint32_t)seed, (uint32_t)(seed >> 32))), row(row_), d0((uint32_t)draw), d1((uint32_t)(draw >> 32)), n(0) {}
+  // two uniforms in (0, 1)
+  __device__ __forceinline__ double2 next2() {
+    const uint4 r = philox4x32_10(make_uint4(row, n++, d0, d1), key);
+    const double a = ((double)(((uint64_t)r.x << 21) | (r.y >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
+    const double b = ((double)(((uint64_t)r.z << 21) | (r.w >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
+    return make_double2(a, b);
+  }
+};
+
+constexpr int TN_MAX_TRIES = 1 << 14;
+
+// util.hpp:15-37 (Robert 2009, Prop. 2.3): z ~ N(0,1) | z > mu_minus
+__device__ __forceinline__ double tn_left(RowRng &g, double mu_minus) {
+  if (mu_minus < 0) {
+    for (int it = 0; it < TN_MAX_TRIES; it++) {
+      const double2 u = g.next2();
+      const double r = sqrt(-2.0 * log(u.x));
+      double s, c;
+      sincospi(2.0 * u.y, &s, &c);
+      if (r * c > mu_minus) return r * c;
+      if (r * s > mu_minus) return r * s;
+    }
+    return 0.0;
+  }
+  const double alpha_star = (mu_minus + sqrt(mu_minus * mu_minus + 4)) / 2;
+  for (int it = 0; it < TN_MAX_TRIES; it++) {
+    const double2 u = g.next2();
+    const double z = -log(u.x) / alpha_star + mu_minus;
+    const double rho = exp(-(z - alpha_star) * (z - alpha_star) / 2);
+    if (u.y < rho) return z;
+  }
+  return mu_minus;
+}
+__device__ __forceinline__ double tn_right(RowRng &g, double mu_plus) { return -tn_left(g, -mu_plus); }  // util.hpp:68-71
+// util.hpp:39-60
+__device__ __forceinline__ double tn_twoside(RowRng &g, double mu_minus, double mu_plus) {
+  for (int it = 0; it < TN_MAX_TRIES; it++) {
+    const double2 u = g.next2();
+    const double z = mu_minus + (mu_plus - mu_minus) * u.x;
+    double rho;
+    if (mu_minus <= 0 && mu_plus >= 0)
+      rho = exp(-z * z / 2);
+    else if (mu_plus < 0)
+      rho = exp((mu_plus * mu_plus - z * z) / 2);
+    else
+      rho = exp((mu_minus * mu_minus - z * z) / 2);
+    if (u.y < rho) return z;
+  }
+  return 0.5 * (mu_minus + mu_plus);
+}
+
+// FMTrainer.hpp:498-512: eq.x holds the score on entry, e = score - z on exit
+__global__ __launch_bounds__(WG) void k_tn_classification(double2 *__restrict__ eq, const double *__restrict__ y, int64_t N,
+                                                          uint64_t seed, uint64_t draw) {
+  const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x;
+  if (t >= N) return;
+  RowRng g(seed, draw, (uint32_t)t);
+  const double pred = eq[t].x;
+  double n;
+  if (y[t] > 0)
+    n = pred + tn_left(g, (0.0 - pred));   // util.hpp:61-66 with std = 1
+  else
+    n = pred + tn_right(g, (0.0 - pred));  // util.hpp:73-78
+  eq[t].x = pred - n;
+}
+
+// erfcx, same evaluation as the CPU oracle (libm erfc for small x, Laplace continued fraction beyond)
+__device__ __forceinline__ double d_erfcx_pos(double x) {
+  if (x < 3.0) return exp(x * x) * erfc(x);
+  if (x > 5e7) return 0.5641895835477562869 / x;
+  const int n = (x < 5) ? 90 : (x < 10 ? 50 : 25);
+  double t = x;
+  for (int k = n; k >= 1; k--) t = x + (0.5 * k) / t;
+  return 0.5641895835477562869 / t;
+}
+__device__ __forceinline__ double d_erfcx(double x) {
+  if (x >= 0) return d_erfcx_pos(x);
+  if (x < -26.7) return INFINITY;
+  return 2 * exp(x * x) - d_erfcx_pos(-x);
+}
+
+constexpr int OPROBIT_MAX_CLASS = 32;
+constexpr int OPROBIT_SLOTS = 6;  // ll, d_hi, d_lo, h_hi, h_lo, h_off per label
+constexpr int OPROBIT_BLOCKS = 512;
+
+// OProbitSampler.hpp:402-413 with safe_lcdf / safe_lccdf / safe_ldiff (:111-236), accumulated per
+// label: slot 1/3 belong to cutpoint index `label`, slot 2/4 to `label - 1`, slot 5 is the
+// off-diagonal (label, label-1).
+__global__ __launch_bounds__(WG) void k_oprobit_eval(const double2 *__restrict__ eq, const double *__restrict__ y,
+                                                     const int32_t *__restrict__ rows, int64_t n_rows, int n_class,
+                                                     const double *__restrict__ gamma, int want_h,
+                                                     double *__restrict__ partial) {
+  __shared__ double acc[OPROBIT_MAX_CLASS * OPROBIT_SLOTS];
+  __shared__ double gam[OPROBIT_MAX_CLASS];
+  for (int i = threadIdx.x; i < n_class * OPROBIT_SLOTS; i += WG) acc[i] = 0.0;
+  for (int i = threadIdx.x; i < n_class - 1; i += WG) gam[i] = gamma[i];
+  __syncthreads();
+  const double SQRT2 = 1.4142135623730951, SQRT2PI = 1.4142135623730951 * 1.7724538509055159, PI = 3.141592653589793;
+  for (int64_t p = (int64_t)blockIdx.x * WG + threadIdx.x; p < n_rows; p += (int64_t)gridDim.x * WG) {
+    const int64_t t = rows ? rows[p] : p;
+    const int label = (int)y[t];
+    const double sc = eq[t].x;
+    double ll = 0, d_hi = 0, d_lo = 0, h_hi = 0, h_lo = 0, h_off = 0;
+    if (label == 0) {  // safe_lcdf(gamma0 - score), :183-208
+      const double x = gam[0] - sc;
+      if (x > 1) {
+        const double ef = exp(-x * x / 2), den = 1 + erf(x / SQRT2);
+        d_hi += (2 / SQRT2PI) * ef / den;
+        ll += log(den / 2);
+        if (want_h) h_hi += -(SQRT2PI * x * den * ef + 2 * ef * ef) / PI / den / den;
+      } else {
+        const double den = d_erfcx(-x / SQRT2);
+        d_hi += (2 / SQRT2PI) / den;
+        ll -= x * x / 2;
+        ll += log(den / 2);
+        if (want_h) h_hi += -(SQRT2PI * x * den + 2) / PI / den / den;
+      }
+    } else if (label == n_class - 1) {  // safe_lccdf(gamma_{K-2} - score), :210-236
+      const double x = gam[n_class - 2] - sc;
+      if (x > -1) {
+        const double den = d_erfcx(x / SQRT2);
+        d_lo -= (2 / SQRT2PI) / den;
+        ll += log(den / 2);
+        ll -= x * x / 2;
+        if (want_h) h_lo += (SQRT2PI * x * den - 2) / den / den / PI;
+      } else {
+        const double den = 1 - erf(x / SQRT2);
+        d_lo -= (2 / SQRT2PI) * exp(-x * x / 2) / den;
+        ll += log(den / 2);
+        if (want_h) {
+          const double ef = exp(-(x * x) / 2);
+          h_lo += -(-SQRT2PI * x * den * ef + 2 * ef * ef) / PI / den / den;
+        }
+      }
+    } else {  // safe_ldiff(x = gamma_l - score, yv = gamma_{l-1} - score), :111-181
+      const double x = gam[label] - sc, yv = gam[label - 1] - sc;
+      if (yv > 0) {
+        const double ef = exp((yv * yv - x * x) / 2);
+        const double den = d_erfcx(yv / SQRT2) - ef * d_erfcx(x / SQRT2);
+        ll -= yv * yv / 2;
+        ll += log(den / 2);
+        d_hi += (2 / SQRT2PI) * ef / den;
+        d_lo -= (2 / SQRT2PI) / den;
+        if (want_h) {
+          h_hi += -(SQRT2PI * x * den * exp((yv * yv - x * x) / 2) + 2 * exp(yv * yv - x * x)) / den / den / PI;
+          h_lo += (SQRT2PI * yv * den - 2) / den / den / PI;
+          h_off += 2 * exp((yv * yv - x * x) / 2) / PI / den / den;
+        }
+      } else if (x < 0) {
+        ll -= x * x / 2;
+        const double ef = exp((x * x - yv * yv) / 2);
+        const double den = d_erfcx(-x / SQRT2) - ef * d_erfcx(-yv / SQRT2);
+        ll += log(den / 2);
+        d_hi += (2 / SQRT2PI) / den;
+        d_lo -= (2 / SQRT2PI) * ef / den;
+        if (want_h) {
+          h_hi += -(SQRT2PI * x * den + 2) / PI / den / den;
+          h_lo += (SQRT2PI * yv * ef * den - 2 * (ef * ef)) / PI / den / den;
+          h_off += 2 * ef / PI / den / den;
+        }
+      } else {
+        const double den = erf(x / SQRT2) - erf(yv / SQRT2);
+        const double exx = exp(-x * x / 2), eyy = exp(-yv * yv / 2);
+        d_hi += 2 * exx / den / SQRT2PI;
+        d_lo -= 2 * eyy / den / SQRT2PI;
+        ll += log(den / 2);
+        if (want_h) {
+          h_hi += -(SQRT2PI * x * den * exx + 2 * exx * exx) / PI / den / den;
+          h_lo += -(-SQRT2PI * yv * den * eyy + 2 * eyy * eyy) / PI / den / den;
+          h_off += 2 * exx * eyy / PI / den / den;
+        }
+      }
+    }
+    double *a = acc + label * OPROBIT_SLOTS;
+    atomicAdd(a + 0, ll);
+    atomicAdd(a + 1, d_hi);
+    atomicAdd(a + 2, d_lo);
+    if (want_h) {
+      atomicAdd(a + 3, h_hi);
+      atomicAdd(a + 4, h_lo);
+      atomicAdd(a + 5, h_off);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_class * OPROBIT_SLOTS; i += WG)
+    partial[(int64_t)blockIdx.x * n_class * OPROBIT_SLOTS + i] = acc[i];
+}
+
+// sample_z_given_cutpoint, OProbitSampler.hpp:238-272 (deviation = 1)
+__global__ __launch_bounds__(WG) void k_oprobit_sample_z(double2 *__restrict__ eq, const double *__restrict__ y,
+                                                         const int32_t *__restrict__ rows, int64_t n_rows, int n_class,
+                                                         const double *__restrict__ gamma, uint64_t seed, uint64_t draw) {
+  const int64_t p = (int64_t)blockIdx.x * WG + threadIdx.x;
+  if (p >= n_rows) return;
+  const int64_t t = rows ? rows[p] : p;
+  RowRng g(seed, draw, (uint32_t)t);
+  const int cls = (int)y[t];
+  const double pred = eq[t].x;
+  double z;
+  if (cls == 0)
+    z = tn_right(g, gamma[0] - pred) + pred;
+  else if (cls == n_class - 1)
+    z = tn_left(g, gamma[n_class - 2] - pred) + pred;
+  else
+    z = tn_twoside(g, gamma[cls - 1] - pred, gamma[cls] - pred) + pred;
+  eq[t].x = pred - z;
+}
+
+}  // namespace mfm
+
+extern "C" {
+
+int mfm_update_e_classification(mfm_ctx *ctx, uint64_t seed, uint64_t draw_index) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  score_train(ctx, false);
+  if (ctx->N) {
+    TimedLaunch t(ctx->timing, ctx->stream, KC_TN_SAMPLE, 24.0 * ctx->N);
+    hipLaunchKernelGGL(k_tn_classification, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq.p, ctx->y.p, ctx->N,
+                       seed, draw_index);
+    MFM_HIP_CHECK(hipGetLastError());
+  }
+  MFM_CATCH(ctx)
+}
+
+int mfm_oprobit_add_group(mfm_ctx *ctx, int32_t n_class, const int64_t *rows, int64_t n_rows, int32_t *group) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  if (n_class < 2 || n_class > OPROBIT_MAX_CLASS)
+    throw Error(MFM_ERR_INVALID, "ordered probit supports 2.." + std::to_string(OPROBIT_MAX_CLASS) + " classes");
+  std::unique_ptr<mfm_ctx::OGroup> g(new mfm_ctx::OGroup());
+  g->n_class = n_class;
+  if (rows) {
+    std::vector<int32_t> r32((size_t)n_rows);
+    for (int64_t i = 0; i < n_rows; i++) {
+      if (rows[i] < 0 || rows[i] >= ctx->N) throw Error(MFM_ERR_INVALID, "out of range for cutpoint group config.");
+      r32[i] = (int32_t)rows[i];
+    }
+    g->rows.upload(r32);
+    g->n_rows = n_rows;
+  } else {
+    g->n_rows = ctx->N;
+  }
+  *group = (int32_t)ctx->ogroups.size();
+  ctx->ogroups.push_back(std::move(g));
+  if (ctx->opartial.n == 0) ctx->opartial.alloc((size_t)OPROBIT_BLOCKS * OPROBIT_MAX_CLASS * OPROBIT_SLOTS + OPROBIT_MAX_CLASS);
+  MFM_CATCH(ctx)
+}
+
+int mfm_oprobit_eval(mfm_ctx *ctx, int32_t group, const double *gamma, double *ll, double *dgamma, double *H) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  if (group < 0 || group >= (int)ctx->ogroups.size()) throw Error(MFM_ERR_INVALID, "bad cutpoint group");
+  mfm_ctx::OGroup &g = *ctx->ogroups[group];
+  hipStream_t s = ctx->stream;
+  const int C = g.n_class, m = C - 1;
+  double *dgam = ctx->opartial.p + (size_t)OPROBIT_BLOCKS * OPROBIT_MAX_CLASS * OPROBIT_SLOTS;
+  ctx->ring.upload(dgam, gamma, (size_t)m * sizeof(double), s);
+  const int nb = (int)std::min<int64_t>(OPROBIT_BLOCKS, std::max<int64_t>(1, cdiv(g.n_rows, WG)));
+  {
+    TimedLaunch t(ctx->timing, s, KC_OPROBIT_EVAL, 16.0 * g.n_rows);
+    hipLaunchKernelGGL(k_oprobit_eval, dim3(nb), dim3(WG), 0, s, ctx->eq.p, ctx->y.p, g.rows.p, g.n_rows, C, dgam,
+                       H ? 1 : 0, ctx->opartial.p);
+    MFM_HIP_CHECK(hipGetLastError());
+  }
+  const size_t cnt = (size_t)nb * C * OPROBIT_SLOTS;
+  double *h = (double *)ctx->readback((cnt + 1) / 2 + 1);
+  MFM_HIP_CHECK(hipMemcpyAsync(h, ctx->opartial.p, cnt * sizeof(double), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipStreamSynchronize(s));
+  std::vector<double> acc((size_t)C * OPROBIT_SLOTS, 0.0);
+  for (int b = 0; b < nb; b++)
+    for (int i = 0; i < C * OPROBIT_SLOTS; i++) acc[i] += h[(size_t)b * C * OPROBIT_SLOTS + i];
+  *ll = 0;
+  for (int k = 0; k < m; k++) dgamma[k] = 0;
+  if (H)
+    for (int k = 0; k < m * m; k++) H[k] = 0;
+  for (int l = 0; l < C; l++) {
+    const double *a = acc.data() + (size_t)l * OPROBIT_SLOTS;
+    *ll += a[0];
+    if (l < m) dgamma[l] += a[1];
+    if (l >= 1) dgamma[l - 1] += a[2];
+    if (H) {
+      if (l < m) H[(size_t)l * m + l] += a[3];
+      if (l >= 1) H[(size_t)(l - 1) * m + (l - 1)] += a[4];
+      if (l >= 1 && l < m) {
+        H[(size_t)l * m + (l - 1)] += a[5];
+        H[(size_t)(l - 1) * m + l] += a[5];
+      }
+    }
+  }
+  MFM_CATCH(ctx)
+}
+
+int mfm_oprobit_sample_z(mfm_ctx *ctx, int32_t group, const double *gamma, uint64_t seed, uint64_t draw_index) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  if (group < 0 || group >= (int)ctx->ogroups.size()) throw Error(MFM_ERR_INVALID, "bad cutpoint group");
+  mfm_ctx::OGroup &g = *ctx->ogroups[group];
+  hipStream_t s = ctx->stream;
+  double *dgam = ctx->opartial.p + (size_t)OPROBIT_BLOCKS * OPROBIT_MAX_CLASS * OPROBIT_SLOTS;
+  ctx->ring.upload(dgam, gamma, (size_t)(g.n_class - 1) * sizeof(double), s);
+  if (g.n_rows) {
+    TimedLaunch t(ctx->timing, s, KC_TN_SAMPLE, 24.0 * g.n_rows);
+    hipLaunchKernelGGL(k_oprobit_sample_z, dim3(cdiv(g.n_rows, WG)), dim3(WG), 0, s, ctx->eq.p, ctx->y.p, g.rows.p,
+                       g.n_rows, g.n_class, dgam, seed, draw_index);
+    MFM_HIP_CHECK(hipGetLastError());
+  }
+  MFM_CATCH(ctx)
+}
+
+}  // extern "C"

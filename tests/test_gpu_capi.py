@@ -1,0 +1,224 @@
+"""GPU parity tests through the C ABI (libmyfm_hip.so) against the CPU oracle.
+
+Tolerances: the device sums each column's sufficient statistics with a fixed tree instead of the
+reference's sequential order, so single draws agree to ~1e-12 relative; the state after a few
+iterations to 1e-8 (SURVEY 8d asks <= 1e-9 after 1 and <= 1e-6 after 10 iterations).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from . import datasets as ds
+from .gibbs_driver import CapiGibbs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from myfm_amd import _capi
+
+    if _capi.lib().mfm_device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests need a real MI355X")
+    return _capi
+
+
+def _designs():
+    out = {}
+    X, y = ds.toy()
+    out["toy_dense_plus_onehot"] = (X, y, None, 4)
+    X, score = ds.middle_data(1000)
+    out["middle_multilevel"] = (X, score + np.random.RandomState(0).normal(size=score.shape), None, 3)
+    X, y, shapes = ds.onehot_mf(20000, 300, 40, seed=1)  # items with > 4096 ratings: long-column path
+    out["onehot_long_columns"] = (X, y, ds.group_index_from_shapes(shapes), 8)
+    X, y, shapes = ds.onehot_mf(30000, 2000, 700, seed=2, sort_by_user=False)
+    out["onehot_unsorted"] = (X, y, ds.group_index_from_shapes(shapes), 5)
+    return out
+
+
+DESIGNS = _designs()
+
+
+def _pair(oracle, capi, X, y, gi, rank, blocks=(), **kw):
+    t = oracle.OracleTrainer(X, y, blocks, rank=rank, group_index=gi, **kw)
+    n = X.shape[0]
+    D = t.D
+    if gi is None:
+        gi = np.zeros(D, dtype=np.int32)
+    c = capi.Context(X, y, blocks, rank=rank, group_index=gi)
+    c.set_state(*t.fm())
+    c.set_e(t.e(n))
+    return t, c, gi
+
+
+@pytest.mark.parametrize("name", list(DESIGNS))
+def test_sweep_V_single_factor(oracle, capi, name):
+    X, y, gi, rank = DESIGNS[name]
+    t, c, gi = _pair(oracle, capi, X, y, gi, rank)
+    n, D, G = X.shape[0], t.D, t.G
+    rng = np.random.default_rng(5)
+    lam = rng.uniform(0.5, 2.0, size=(G, rank))
+    mu = rng.normal(size=(G, rank)) * 0.1
+    h = t.hyper()
+    t.set_hyper(0.7, h["mu_w"], h["lambda_w"], mu, lam)
+    for f in range(min(rank, 2)):
+        z = t.clone().rng_sample_normals(D)
+        t.update_V_factor(f)
+        c.sweep_V(f, f + 1, 0.7, lam, mu, z)
+        w0, w, V = t.fm()
+        gw0, gw, gV = c.get_state()
+        np.testing.assert_allclose(gV[:, f], V[:, f], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(c.get_q(), t.q(n), rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("name", list(DESIGNS))
+def test_sweep_w(oracle, capi, name):
+    X, y, gi, rank = DESIGNS[name]
+    t, c, gi = _pair(oracle, capi, X, y, gi, rank)
+    n, D, G = X.shape[0], t.D, t.G
+    rng = np.random.default_rng(6)
+    lam, mu = rng.uniform(0.5, 2.0, size=G), rng.normal(size=G) * 0.1
+    h = t.hyper()
+    t.set_hyper(1.3, mu, lam, h["mu_V"], h["lambda_V"])
+    z = t.clone().rng_sample_normals(D)
+    t.substep(4)
+    c.sweep_w(1.3, lam, mu, z)
+    np.testing.assert_allclose(c.get_state()[1], t.fm()[1], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("name", list(DESIGNS))
+def test_update_e_and_reductions(oracle, capi, name):
+    X, y, gi, rank = DESIGNS[name]
+    t, c, gi = _pair(oracle, capi, X, y, gi, rank)
+    n = X.shape[0]
+    t.substep(8)
+    c.update_e_regression()
+    e = t.e(n)
+    np.testing.assert_allclose(c.get_e(), e, rtol=1e-11, atol=1e-11)
+    se, se2 = c.reduce_e()
+    np.testing.assert_allclose([se, se2], [e.sum(), (e * e).sum()], rtol=1e-11)
+    c.shift_e(0.25)
+    np.testing.assert_allclose(c.get_e(), e + 0.25, rtol=1e-14)
+    w0, w, V = t.fm()
+    G = t.G
+    mu_w = np.linspace(-0.1, 0.1, G)
+    s, ssd = c.group_stats_w(mu_w)
+    for g in range(G):
+        sel = gi == g
+        np.testing.assert_allclose(s[g], w[sel].sum(), rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(ssd[g], ((w[sel] - mu_w[g]) ** 2).sum(), rtol=1e-11)
+    mu_V = np.random.default_rng(0).normal(size=(G, rank)) * 0.05
+    s, ssd = c.group_stats_V(mu_V)
+    for g in range(G):
+        sel = gi == g
+        np.testing.assert_allclose(s[g], V[sel].sum(axis=0), rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(ssd[g], ((V[sel] - mu_V[g]) ** 2).sum(axis=0), rtol=1e-11)
+
+
+@pytest.mark.parametrize("name", list(DESIGNS))
+def test_full_iterations_match_oracle(oracle, capi, name):
+    X, y, gi, rank = DESIGNS[name]
+    t, c, gi = _pair(oracle, capi, X, y, gi, rank)
+    drv = CapiGibbs(c, t.clone(), X.shape[0], gi)
+    for it in range(5):
+        t.step()
+        drv.step()
+        tol = 1e-9 if it == 0 else 1e-7
+        w0, w, V = t.fm()
+        gw0, gw, gV = c.get_state()
+        assert abs(drv.w0 - w0) <= tol * max(1, abs(w0))
+        np.testing.assert_allclose(gw, w, rtol=tol, atol=tol)
+        np.testing.assert_allclose(gV, V, rtol=tol, atol=tol)
+        h, gh = t.hyper(), drv.hyper()
+        for k in h:
+            np.testing.assert_allclose(gh[k], h[k], rtol=tol, atol=tol)
+    np.testing.assert_allclose(c.get_e(), t.e(X.shape[0]), rtol=1e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize("design", ["onehot", "multihot"])
+def test_blocks_match_oracle_and_flat(oracle, capi, design):
+    # tests/regression/test_block.py:80-149 on the device path + against the oracle
+    if design == "onehot":
+        main, X_flat, blocks, y, shapes = ds.block_design()
+        rank = 2
+    else:
+        main, X_flat, blocks, y, shapes = ds.multihot_block_design()
+        rank = 3
+    gi = ds.group_index_from_shapes(shapes)
+    kw = dict(fit_w0=False)
+    tb, cb, _ = _pair(oracle, capi, main, y, gi, rank, blocks, **kw)
+    tf, cf, _ = _pair(oracle, capi, X_flat, y, gi, rank, (), **kw)
+    db = CapiGibbs(cb, tb.clone(), main.shape[0], gi, fit_w0=False)
+    df = CapiGibbs(cf, tf.clone(), main.shape[0], gi, fit_w0=False)
+    for it in range(6):
+        tb.step()
+        db.step()
+        df.step()
+        w0, w, V = tb.fm()
+        _, gw, gV = cb.get_state()
+        _, fw, fV = cf.get_state()
+        np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(gV, fV, rtol=1e-7, atol=1e-8)  # blocked == flat on the device
+        np.testing.assert_allclose(gw, fw, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(cb.get_e(), tb.e(main.shape[0]), rtol=1e-7, atol=1e-7)
+
+
+def test_block_only_design_no_main_columns(oracle, capi):
+    # X=None => (N, 0) main table (base.py:230-233)
+    main, X_flat, blocks, y, shapes = ds.multihot_block_design()
+    empty = sps.csr_matrix((main.shape[0], 0))
+    gi = ds.group_index_from_shapes(shapes[1:])
+    t, c, _ = _pair(oracle, capi, empty, y, gi, 3, blocks)
+    d = CapiGibbs(c, t.clone(), main.shape[0], gi)
+    for _ in range(3):
+        t.step()
+        d.step()
+    np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-7, atol=1e-8)
+
+
+def test_rank_zero(oracle, capi):
+    X, score = ds.middle_data(300)
+    y = score
+    t, c, gi = _pair(oracle, capi, X, y, None, 0)
+    d = CapiGibbs(c, t.clone(), X.shape[0], gi)
+    for _ in range(3):
+        t.step()
+        d.step()
+    np.testing.assert_allclose(c.get_state()[1], t.fm()[1], rtol=1e-8, atol=1e-9)
+
+
+def test_predict_modes(oracle, capi):
+    main, X_flat, blocks, y, shapes = ds.multihot_block_design()
+    rng = np.random.default_rng(3)
+    D = X_flat.shape[1]
+    samples = [(rng.normal(), rng.normal(size=D) * 0.3, rng.normal(size=(D, 5)) * 0.3) for _ in range(4)]
+    od = oracle.OracleDesign(main, blocks)
+    scores = np.stack([od.predict_score(*s) for s in samples])
+    dev = capi.Design(main, blocks)
+    np.testing.assert_allclose(dev.predict(samples, 0), scores.mean(axis=0), rtol=1e-11, atol=1e-11)
+    from scipy import special
+
+    phi = (1 + special.erf(scores * np.sqrt(0.5))) / 2
+    np.testing.assert_allclose(dev.predict(samples, 1), phi.mean(axis=0), rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(capi.Design(X_flat).predict(samples, 0), scores.mean(axis=0), rtol=1e-10, atol=1e-10)
+    cuts = [np.sort(rng.normal(size=3)) for _ in samples]
+    p = dev.predict(samples, 2, cuts)
+    exp = np.zeros((main.shape[0], 4))
+    for sc, cp in zip(scores, cuts):
+        cdf = (1 + special.erf((cp[None, :] - sc[:, None]) * np.sqrt(0.5))) / 2
+        full = np.hstack([np.zeros((sc.shape[0], 1)), cdf, np.ones((sc.shape[0], 1))])
+        exp += full[:, 1:] - full[:, :-1]
+    np.testing.assert_allclose(p, exp / len(samples), rtol=1e-10, atol=1e-12)
+
+
+def test_error_paths(capi):
+    X, y = ds.toy()
+    with pytest.raises(RuntimeError, match="index mapping points to non-existing row"):
+        capi.Context(X, y, [(np.array([0, 1, 2, 7]), sps.csr_matrix(np.eye(3)))], rank=2, group_index=np.zeros(12, np.int32))
+    with pytest.raises(ValueError, match="No matching index for group index"):
+        capi.Context(X, y, rank=2, group_index=np.array([0, 0, 0, 2, 2, 2, 2, 2, 2], np.int32))
+    with pytest.raises(ValueError):
+        capi.Context(X, y, rank=2, group_index=np.zeros(5, np.int32))
