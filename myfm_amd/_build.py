@@ -1,0 +1,67 @@
+"""In-tree build of the native parts: libmyfm_hip.so (hipcc, gfx950) and the pybind11 module _myfm
+(g++, linked against it). Built artefacts stay next to the package so they travel with the tree."""
+import os
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+HIP_LIB = os.path.join(HERE, "libmyfm_hip.so")
+EXT_SUFFIX = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+PYMOD = os.path.join(HERE, "_myfm" + EXT_SUFFIX)
+
+HIP_SOURCES = ["mfm_hip.hip"]
+HIP_HEADERS = ["mfm_common.hpp", "mfm_kernels.hpp", "mfm_plan.hpp", "mfm_block_kernels.hpp", "mfm_tasks.hpp",
+               "mfm_predict.hpp", "mfm_rng.hpp"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def _hipcc():
+    for c in ("/opt/rocm/bin/hipcc", "hipcc"):
+        if os.path.exists(c) or c == "hipcc":
+            return c
+
+
+def build_hip(force=False, verbose=False):
+    deps = [os.path.join(CSRC, f) for f in HIP_SOURCES + HIP_HEADERS] + [os.path.join(INCLUDE, "myfm_hip.h")]
+    if not (force or _newer(HIP_LIB, deps)):
+        return HIP_LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-I" + INCLUDE, "-I" + CSRC] + [os.path.join(CSRC, f) for f in HIP_SOURCES] + ["-o", HIP_LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HIP_LIB
+
+
+def build_pymod(force=False, verbose=False):
+    import pybind11
+
+    src = os.path.join(CSRC, "_myfm.cpp")
+    if not (force or _newer(PYMOD, [src, os.path.join(INCLUDE, "myfm_hip.h"), HIP_LIB])):
+        return PYMOD
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-I" + pybind11.get_include(),
+           "-I" + sysconfig.get_paths()["include"], "-I" + INCLUDE, src, "-o", PYMOD, "-L" + HERE, "-lmyfm_hip",
+           "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return PYMOD
+
+
+def build_all(force=False, verbose=False):
+    build_hip(force, verbose)
+    build_pymod(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,1191 @@
+// _myfm.cpp -- the drop-in boundary: a pybind11 module with the names and signatures of the
+// reference's `myfm._myfm` (cpp_source/declare_module.hpp:67-404, stubs src/myfm/_myfm.pyi), whose
+// trainer drives the MI355X device path through the C ABI of include/myfm_hip.h.
+//
+// Host side (this file): configuration, validation and error behaviour of the reference, the
+// mt19937 draw order of the Gibbs iteration (FMTrainer.hpp / BaseFMTrainer.hpp:135-152), the O(G K)
+// hyper-parameter conditionals, the (K-1)-dimensional cutpoint Newton / Metropolis step of ordered
+// probit, sample retention and pickling. Device side (libmyfm_hip.so): everything that touches
+// the N-row or nnz-sized data. There is no CPU fallback: without a GPU, training / prediction
+// raise RuntimeError.
+#include <pybind11/functional.h>
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <limits>
+#include <memory>
+#include <random>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "myfm_hip.h"
+
+namespace py = pybind11;
+using std::vector;
+typedef double Real;
+typedef py::array_t<double, py::array::c_style | py::array::forcecast> NpF64;
+
+namespace {
+
+// ---- errors: the reference's exception classes (SURVEY 8b "Errors") -------------------------------
+[[noreturn]] void throw_code(int code, const char *msg) {
+  if (code == MFM_ERR_INVALID) throw std::invalid_argument(msg);
+  throw std::runtime_error(msg);
+}
+void ck(mfm_ctx *c, int code) {
+  if (code != MFM_OK) throw_code(code, mfm_last_error(c));
+}
+
+// ---- sparse matrices crossing the boundary (pybind11/eigen.h's scipy caster, restated) -----------
+struct Csr {
+  int64_t rows = 0, cols = 0;
+  vector<int64_t> indptr;
+  vector<int32_t> indices;
+  vector<double> data;
+  int64_t nnz() const { return (int64_t)indices.size(); }
+};
+
+Csr csr_from_py(const py::handle &obj) {
+  py::object sparse = py::module_::import("scipy.sparse");
+  py::object m = py::reinterpret_borrow<py::object>(obj);
+  if (!py::isinstance(m, sparse.attr("csr_matrix"))) m = sparse.attr("csr_matrix")(m);
+  py::tuple shape = m.attr("shape");
+  Csr X;
+  X.rows = shape[0].cast<int64_t>();
+  X.cols = shape[1].cast<int64_t>();
+  auto ip = py::array_t<int64_t, py::array::c_style | py::array::forcecast>::ensure(m.attr("indptr"));
+  auto ix = py::array_t<int32_t, py::array::c_style | py::array::forcecast>::ensure(m.attr("indices"));
+  auto dv = NpF64::ensure(m.attr("data"));
+  if (!ip || !ix || !dv) throw std::invalid_argument("could not convert the sparse matrix to CSR arrays");
+  X.indptr.assign(ip.data(), ip.data() + ip.size());
+  X.indices.assign(ix.data(), ix.data() + ix.size());
+  X.data.assign(dv.data(), dv.data() + dv.size());
+  if ((int64_t)X.indptr.size() != X.rows + 1) throw std::invalid_argument("malformed CSR matrix");
+  return X;
+}
+
+py::object csr_to_py(const Csr &X) {
+  py::object sparse = py::module_::import("scipy.sparse");
+  py::array_t<double> data((py::ssize_t)X.data.size(), X.data.data());
+  py::array_t<int32_t> indices((py::ssize_t)X.indices.size(), X.indices.data());
+  py::array_t<int64_t> indptr((py::ssize_t)X.indptr.size(), X.indptr.data());
+  return sparse.attr("csr_matrix")(py::make_tuple(data, indices, indptr), py::make_tuple(X.rows, X.cols));
+}
+
+py::array_t<double> vec_to_np(const vector<double> &v) { return py::array_t<double>((py::ssize_t)v.size(), v.data()); }
+vector<double> np_to_vec(const py::handle &h) {
+  auto a = NpF64::ensure(h);
+  if (!a) throw std::invalid_argument("expected a float64 array");
+  return vector<double>(a.data(), a.data() + a.size());
+}
+// column-major (rows, cols) storage <-> numpy (rows, cols)
+py::array_t<double> colmajor_to_np(const vector<double> &v, int64_t rows, int64_t cols) {
+  py::array_t<double, py::array::f_style> a({(py::ssize_t)rows, (py::ssize_t)cols});
+  std::copy(v.begin(), v.end(), a.mutable_data());
+  return std::move(a);
+}
+vector<double> np_to_colmajor(const py::handle &h, int64_t *rows, int64_t *cols) {
+  auto a = py::array_t<double, py::array::f_style | py::array::forcecast>::ensure(h);
+  if (!a || a.ndim() != 2) throw std::invalid_argument("expected a 2-d float64 array");
+  *rows = a.shape(0);
+  *cols = a.shape(1);
+  return vector<double>(a.data(), a.data() + a.size());
+}
+
+// ---- TaskType / FMLearningConfig / ConfigBuilder (FMLearningConfig.hpp:11-203) -------------------
+enum class TaskType { REGRESSION = 0, CLASSIFICATION = 1, ORDERED = 2 };
+typedef vector<std::pair<size_t, vector<size_t>>> CutpointGroupType;
+
+struct FMLearningConfig {
+  Real alpha_0, beta_0, gamma_0, mu_0, reg_0;
+  TaskType task_type;
+  Real nu_oprobit;
+  bool fit_w0, fit_linear;
+  int n_iter, n_kept_samples;
+  Real cutpoint_scale;
+  vector<size_t> group_index;
+  size_t n_groups = 0;
+  vector<vector<size_t>> group_vs_feature_index;
+  CutpointGroupType cutpoint_groups;
+
+  // FMLearningConfig.hpp:17-57
+  FMLearningConfig(Real alpha_0, Real beta_0, Real gamma_0, Real mu_0, Real reg_0, TaskType task_type, Real nu_oprobit,
+                   bool fit_w0, bool fit_linear, const vector<size_t> &group_index, int n_iter, int n_kept_samples,
+                   Real cutpoint_scale, const CutpointGroupType &cutpoint_groups)
+      : alpha_0(alpha_0), beta_0(beta_0), gamma_0(gamma_0), mu_0(mu_0), reg_0(reg_0), task_type(task_type),
+        nu_oprobit(nu_oprobit), fit_w0(fit_w0), fit_linear(fit_linear), n_iter(n_iter), n_kept_samples(n_kept_samples),
+        cutpoint_scale(cutpoint_scale), group_index(group_index), cutpoint_groups(cutpoint_groups) {
+    std::set<size_t> all_index(group_index.begin(), group_index.end());
+    n_groups = all_index.size();
+    for (size_t i = 0; i < n_groups; i++) {
+      if (all_index.find(i) == all_index.cend()) {
+        std::ostringstream ss;
+        ss << "No matching index for group index " << i << " found.";
+        throw std::invalid_argument(ss.str());
+      }
+    }
+    group_vs_feature_index = vector<vector<size_t>>(n_groups);
+    size_t feature_index = 0;
+    for (auto g : group_index) group_vs_feature_index[g].push_back(feature_index++);
+    if (n_kept_samples < 0) throw std::invalid_argument("n_kept_samples must be non-negative,");
+    if (n_iter <= 0) throw std::invalid_argument("n_iter must be positive.");
+    if (n_iter < n_kept_samples) throw std::invalid_argument("n_kept_samples must not exceed n_iter.");
+  }
+};
+
+// FMLearningConfig.hpp:92-201
+struct ConfigBuilder {
+  Real alpha_0 = 1, beta_0 = 1, gamma_0 = 1, mu_0 = 1, reg_0 = 1;
+  int n_iter = 100, n_kept_samples = 10;
+  TaskType task_type = TaskType::REGRESSION;
+  Real nu_oprobit = 5;
+  bool fit_w0 = true, fit_linear = true;
+  vector<size_t> group_index;
+  Real cutpoint_scale = 10;
+  CutpointGroupType cutpoint_groups;
+
+  ConfigBuilder &set_alpha_0(Real a) { alpha_0 = a; return *this; }
+  ConfigBuilder &set_beta_0(Real a) { beta_0 = a; return *this; }
+  ConfigBuilder &set_gamma_0(Real a) { gamma_0 = a; return *this; }
+  ConfigBuilder &set_mu_0(Real a) { mu_0 = a; return *this; }
+  ConfigBuilder &set_reg_0(Real a) { reg_0 = a; return *this; }
+  ConfigBuilder &set_n_iter(int a) { n_iter = a; return *this; }
+  ConfigBuilder &set_n_kept_samples(int a) { n_kept_samples = a; return *this; }
+  ConfigBuilder &set_task_type(TaskType a) { task_type = a; return *this; }
+  ConfigBuilder &set_group_index(const vector<size_t> a) { group_index = a; return *this; }
+  ConfigBuilder &set_identical_groups(size_t n_features) { group_index.assign(n_features, 0); return *this; }
+  ConfigBuilder &set_nu_oprobit(size_t nu) { nu_oprobit = (Real)nu; return *this; }
+  ConfigBuilder &set_fit_w0(bool a) { fit_w0 = a; return *this; }
+  ConfigBuilder &set_fit_linear(bool a) { fit_linear = a; return *this; }
+  ConfigBuilder &set_cutpoint_scale(Real a) { cutpoint_scale = a; return *this; }
+  ConfigBuilder &set_cutpoint_groups(const CutpointGroupType &a) { cutpoint_groups = a; return *this; }
+  FMLearningConfig build() {
+    return FMLearningConfig(alpha_0, beta_0, gamma_0, mu_0, reg_0, task_type, nu_oprobit, fit_w0, fit_linear, group_index,
+                            n_iter, n_kept_samples, cutpoint_scale, cutpoint_groups);
+  }
+};
+
+// ---- RelationBlock (definitions.hpp:30-52) ---------------------------------------------------------
+struct RelationBlock {
+  vector<size_t> original_to_block;
+  size_t mapper_size;
+  Csr X;
+  size_t block_size, feature_size;
+  RelationBlock(vector<size_t> o2b, Csr X_)
+      : original_to_block(std::move(o2b)), mapper_size(original_to_block.size()), X(std::move(X_)),
+        block_size((size_t)X.rows), feature_size((size_t)X.cols) {
+    for (auto c : original_to_block)
+      if (c >= block_size) throw std::runtime_error("index mapping points to non-existing row.");
+  }
+  vector<int64_t> map64() const { return vector<int64_t>(original_to_block.begin(), original_to_block.end()); }
+};
+typedef vector<std::shared_ptr<RelationBlock>> Relations;
+
+Relations relations_from_py(const py::handle &h) {
+  Relations out;
+  for (auto item : py::reinterpret_borrow<py::sequence>(h)) out.push_back(item.cast<std::shared_ptr<RelationBlock>>());
+  return out;
+}
+
+// util.hpp:147-165
+size_t check_row_consistency_return_column(const Csr &X, const Relations &relations) {
+  size_t row = (size_t)X.rows, col = (size_t)X.cols;
+  int i = 0;
+  for (const auto &rel : relations) {
+    if (row != rel->original_to_block.size()) {
+      std::ostringstream ss;
+      ss << "main table has size " << row << " but the relation[" << i << "] has size " << rel->original_to_block.size();
+      throw std::runtime_error(ss.str());
+    }
+    col += rel->feature_size;
+    i++;
+  }
+  return col;
+}
+
+// A prediction design resident on the GPU for the duration of one call.
+struct DeviceDesign {
+  mfm_design *d = nullptr;
+  DeviceDesign(const Csr &X, const Relations &rels) {
+    int code = mfm_design_create(0, X.rows, X.cols, X.indptr.data(), X.indices.data(), X.data.data(), &d);
+    if (code != MFM_OK) throw_code(code, mfm_global_error());
+    for (auto &r : rels) {
+      auto m = r->map64();
+      code = mfm_design_add_block(d, r->X.rows, r->X.cols, r->X.indptr.data(), r->X.indices.data(), r->X.data.data(),
+                                  m.data());
+      if (code != MFM_OK) {
+        std::string msg = mfm_design_last_error(d);
+        mfm_design_destroy(d);
+        d = nullptr;
+        throw_code(code, msg.c_str());
+      }
+    }
+  }
+  ~DeviceDesign() {
+    if (d) mfm_design_destroy(d);
+  }
+  void predict(int rank, int S, const double *w0s, const double *ws, const double *Vs, int mode, int n_cut,
+               const double *cuts, double *out) {
+    int code = mfm_design_predict(d, rank, S, w0s, ws, Vs, mode, n_cut, cuts, out);
+    if (code != MFM_OK) throw_code(code, mfm_design_last_error(d));
+  }
+};
+
+// ---- FM (FM.hpp:10-172) -----------------------------------------------------------------------------
+struct FM {
+  int n_factors = 0;
+  Real w0 = 0;
+  vector<Real> w;               // (D)
+  vector<Real> V;               // column-major (D, K)
+  vector<vector<Real>> cutpoints;
+  bool initialized = false;
+  // live sample handed to callbacks: w / V stay on the GPU until somebody looks at them
+  std::function<void(FM &)> fetch;
+  bool stale = false;
+
+  FM() {}
+  explicit FM(int n_factors) : n_factors(n_factors) {}
+  FM(Real w0, vector<Real> w, vector<Real> V, int K, vector<vector<Real>> cutpoints = {})
+      : n_factors(K), w0(w0), w(std::move(w)), V(std::move(V)), cutpoints(std::move(cutpoints)), initialized(true) {}
+  // a kept sample is a plain host copy
+  FM snapshot() {
+    ensure();
+    FM s;
+    s.n_factors = n_factors;
+    s.w0 = w0;
+    s.w = w;
+    s.V = V;
+    s.cutpoints = cutpoints;
+    s.initialized = initialized;
+    return s;
+  }
+  void ensure() {
+    if (stale && fetch) {
+      stale = false;
+      fetch(*this);
+    }
+  }
+  int64_t D() const { return (int64_t)w.size(); }
+
+  // FM.hpp:34-45: one persistent normal_distribution; Eigen fills the col-major V in storage order.
+  void initialize_weight(int64_t n_features, Real init_std, std::mt19937 &gen) {
+    initialized = false;
+    std::normal_distribution<Real> nd;
+    V.resize((size_t)n_features * n_factors);
+    for (auto &v : V) v = nd(gen) * init_std;
+    w.resize((size_t)n_features);
+    for (auto &v : w) v = nd(gen) * init_std;
+    w0 = nd(gen) * init_std;
+    initialized = true;
+  }
+
+  // FM.hpp:57-77 checks, then the device scorer
+  void check(const Csr &X, const Relations &relations) {
+    size_t case_size = (size_t)X.rows, feature_size_all = (size_t)X.cols;
+    for (auto const &rel : relations) {
+      if (case_size != rel->original_to_block.size())
+        throw std::invalid_argument("Relation blocks have inconsistent mapper size with case_size");
+      feature_size_all += rel->feature_size;
+    }
+    if (feature_size_all != w.size()) {
+      std::ostringstream ss;
+      ss << "Total feature size mismatch. Should be " << w.size() << ", but got " << feature_size_all << ".";
+      throw std::invalid_argument(ss.str());
+    }
+    if (!initialized) throw std::runtime_error("get_score called before initialization");
+  }
+  py::array_t<double> predict_score(const py::object &Xo, const py::object &relso) {
+    ensure();
+    Csr X = csr_from_py(Xo);
+    Relations rels = relations_from_py(relso);
+    check(X, rels);
+    py::array_t<double> out((py::ssize_t)X.rows);
+    DeviceDesign dd(X, rels);
+    dd.predict(n_factors, 1, &w0, w.data(), V.data(), 0, 0, nullptr, out.mutable_data());
+    return out;
+  }
+  // FM.hpp:137-162
+  py::array_t<double> oprobit_predict_proba(const py::object &Xo, const py::object &relso, size_t cutpoint_index) {
+    ensure();
+    if (cutpoints.empty()) throw std::runtime_error("No cutpoint available for this FM.");
+    Csr X = csr_from_py(Xo);
+    Relations rels = relations_from_py(relso);
+    check(X, rels);
+    const vector<Real> &cp = cutpoints.at(cutpoint_index);
+    int n_cpt = (int)cp.size();
+    py::array_t<double> out({(py::ssize_t)X.rows, (py::ssize_t)(n_cpt + 1)});
+    DeviceDesign dd(X, rels);
+    dd.predict(n_factors, 1, &w0, w.data(), V.data(), 2, n_cpt, cp.data(), out.mutable_data());
+    return out;
+  }
+};
+
+// ---- FMHyperParameters (HyperParams.hpp) ------------------------------------------------------------
+struct Hyper {
+  Real alpha = 1;
+  vector<Real> mu_w, lambda_w;  // (G)
+  vector<Real> mu_V, lambda_V;  // column-major (G, K)
+  size_t G = 0, K = 0;
+  Hyper() {}
+  Hyper(size_t n_factors, size_t n_groups)
+      : mu_w(n_groups), lambda_w(n_groups), mu_V(n_groups * n_factors), lambda_V(n_groups * n_factors), G(n_groups),
+        K(n_factors) {}
+};
+
+struct LearningHistory {
+  vector<Hyper> hypers;
+  vector<size_t> n_mh_accept;
+  vector<Real> train_log_losses;
+};
+
+// ---- Predictor (predictor.hpp:14-167) ---------------------------------------------------------------
+struct Predictor {
+  size_t rank, feature_size;
+  TaskType type;
+  vector<FM> samples;
+  Predictor(size_t rank, size_t feature_size, TaskType type) : rank(rank), feature_size(feature_size), type(type) {}
+
+  void check_input(const Csr &X, const Relations &relations) const {  // predictor.hpp:24-33
+    auto given = check_row_consistency_return_column(X, relations);
+    if (feature_size != given) {
+      std::ostringstream ss;
+      ss << "Told to predict for " << given << " but this->feature_size is " << feature_size;
+      throw std::invalid_argument(ss.str());
+    }
+  }
+  void pack(vector<double> &w0s, vector<double> &ws, vector<double> &Vs) const {
+    const size_t S = samples.size(), D = feature_size;
+    w0s.resize(S);
+    ws.resize(S * D);
+    Vs.resize(S * D * rank);
+    for (size_t s = 0; s < S; s++) {
+      const FM &f = samples[s];
+      if (f.w.size() != D || f.V.size() != D * rank) throw std::invalid_argument("feature size mismatch!");
+      w0s[s] = f.w0;
+      std::copy(f.w.begin(), f.w.end(), ws.begin() + s * D);
+      std::copy(f.V.begin(), f.V.end(), Vs.begin() + s * D * rank);
+    }
+  }
+  // predictor.hpp:126-147 (and :35-76: the worker count only changes how the CPU reference splits
+  // the samples over threads; here all samples are scored on the GPU)
+  py::array_t<double> predict_impl(const py::object &Xo, const py::object &relso, const char *empty_msg) const {
+    Csr X = csr_from_py(Xo);
+    Relations rels = relations_from_py(relso);
+    check_input(X, rels);
+    if (samples.empty()) throw std::runtime_error(empty_msg);
+    vector<double> w0s, ws, Vs;
+    pack(w0s, ws, Vs);
+    py::array_t<double> out((py::ssize_t)X.rows);
+    DeviceDesign dd(X, rels);
+    // regression averages scores, classification Phi(score); ORDERED falls through both branches of
+    // predictor.hpp:136-144 and yields zeros
+    if (type == TaskType::ORDERED) {
+      std::fill(out.mutable_data(), out.mutable_data() + X.rows, 0.0);
+      return out;
+    }
+    dd.predict((int)rank, (int)samples.size(), w0s.data(), ws.data(), Vs.data(), type == TaskType::CLASSIFICATION ? 1 : 0, 0,
+               nullptr, out.mutable_data());
+    return out;
+  }
+  py::array_t<double> predict(const py::object &X, const py::object &rels) const { return predict_impl(X, rels, "Empty samples!"); }
+  py::array_t<double> predict_parallel(const py::object &Xo, const py::object &relso, size_t n_workers) const {
+    // predict_parallel applies Phi only for CLASSIFICATION and otherwise averages raw scores (:53-65)
+    if (type != TaskType::ORDERED) return predict_impl(Xo, relso, "Told to predict but no sample available.");
+    Csr X = csr_from_py(Xo);
+    Relations rels = relations_from_py(relso);
+    check_input(X, rels);
+    if (samples.empty()) throw std::runtime_error("Told to predict but no sample available.");
+    vector<double> w0s, ws, Vs;
+    pack(w0s, ws, Vs);
+    py::array_t<double> out((py::ssize_t)X.rows);
+    DeviceDesign dd(X, rels);
+    dd.predict((int)rank, (int)samples.size(), w0s.data(), ws.data(), Vs.data(), 0, 0, nullptr, out.mutable_data());
+    return out;
+  }
+  // predictor.hpp:78-124
+  py::array_t<double> predict_parallel_oprobit(const py::object &Xo, const py::object &relso, size_t n_workers,
+                                               size_t cutpoint_index) const {
+    Csr X = csr_from_py(Xo);
+    Relations rels = relations_from_py(relso);
+    check_input(X, rels);
+    if (samples.empty()) throw std::runtime_error("Told to predict but no sample available.");
+    if (type != TaskType::ORDERED) throw std::runtime_error("predict_parallel_oprobit must be called for oprobit model.");
+    int n_cpt = (int)samples.at(0).cutpoints.at(cutpoint_index).size();
+    vector<double> w0s, ws, Vs, cuts;
+    pack(w0s, ws, Vs);
+    for (auto &s : samples) {
+      const auto &cp = s.cutpoints.at(cutpoint_index);
+      if ((int)cp.size() != n_cpt) throw std::runtime_error("inconsistent cutpoint sizes among samples.");
+      cuts.insert(cuts.end(), cp.begin(), cp.end());
+    }
+    py::array_t<double> out({(py::ssize_t)X.rows, (py::ssize_t)(n_cpt + 1)});
+    DeviceDesign dd(X, rels);
+    dd.predict((int)rank, (int)samples.size(), w0s.data(), ws.data(), Vs.data(), 2, n_cpt, cuts.data(), out.mutable_data());
+    return out;
+  }
+};
+
+// ---- small dense algebra for the cutpoint sampler (Eigen LLT restated) ------------------------------
+void cholesky_lower(const vector<Real> &A, int n, vector<Real> &L) {
+  L.assign((size_t)n * n, 0);
+  for (int j = 0; j < n; j++) {
+    Real d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; k++) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+    if (!(d > 0)) d = std::numeric_limits<Real>::quiet_NaN();  // Eigen's LLT carries on with NaNs
+    Real ljj = std::sqrt(d);
+    L[(size_t)j * n + j] = ljj;
+    for (int i = j + 1; i < n; i++) {
+      Real s = A[(size_t)i * n + j];
+      for (int k = 0; k < j; k++) s -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+      L[(size_t)i * n + j] = s / ljj;
+    }
+  }
+}
+void llt_solve(const vector<Real> &L, int n, vector<Real> &b) {
+  for (int i = 0; i < n; i++) {
+    Real s = b[i];
+    for (int k = 0; k < i; k++) s -= L[(size_t)i * n + k] * b[k];
+    b[i] = s / L[(size_t)i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    Real s = b[i];
+    for (int k = i + 1; k < n; k++) s -= L[(size_t)k * n + i] * b[k];
+    b[i] = s / L[(size_t)i * n + i];
+  }
+}
+bool has_nan(const vector<Real> &v) {
+  for (Real a : v)
+    if (std::isnan(a)) return true;
+  return false;
+}
+Real norm2(const vector<Real> &v) {
+  Real s = 0;
+  for (Real a : v) s += a * a;
+  return std::sqrt(s);
+}
+
+// ---- ordered-probit cutpoint sampler, host part (OProbitSampler.hpp:15-481). The O(N) likelihood /
+// gradient / Hessian accumulation over the rows (:402-413) and the per-row latent draw (:238-272)
+// run on the device; the (K-1)-dimensional reparametrisation, damped Newton search and the
+// multivariate-t Metropolis step stay here.
+struct OprobitSampler {
+  mfm_ctx *ctx;
+  int group;  // device-side cutpoint group
+  int K;
+  Real reg, nu;
+  std::mt19937 *rng;
+  vector<Real> alpha_now, gamma_now, H;
+  size_t accept_count = 0;
+
+  OprobitSampler(mfm_ctx *ctx, int group, int K, std::mt19937 &rng, Real reg, Real nu)
+      : ctx(ctx), group(group), K(K), reg(reg), nu(nu), rng(&rng) {
+    alpha_now.assign(K - 1, 0);
+    gamma_now.assign(K - 1, 0);
+    alpha_to_gamma(gamma_now, alpha_now);
+    H.assign((size_t)(K - 1) * (K - 1), 0);
+  }
+  int n() const { return K - 1; }
+  static void alpha_to_gamma(vector<Real> &target, const vector<Real> &alpha) {  // :95-101
+    if (alpha.empty()) return;
+    target[0] = alpha[0];
+    for (size_t i = 1; i < alpha.size(); i++) target[i] = target[i - 1] + std::exp(alpha[i]);
+  }
+  static void jacobian_dgamma_dalpha(vector<Real> &J, const vector<Real> &alpha) {  // :74-93
+    int m = (int)alpha.size();
+    std::fill(J.begin(), J.end(), 0);
+    J[0] = 1;
+    for (int j = 1; j < m; j++) J[j] = 1;
+    for (int i = 1; i < m; i++) {
+      Real ed = std::exp(alpha[i]);
+      for (int j = i; j < m; j++) J[(size_t)i * m + j] = ed;
+    }
+  }
+  Real log_p_mvt(const vector<Real> &Si, const vector<Real> &mu, Real nu_, const vector<Real> &x) const {  // :49-53
+    int m = n();
+    Real lp = 0;
+    for (int i = 0; i < m; i++) {
+      Real s = 0;
+      for (int j = 0; j < m; j++) s += Si[(size_t)i * m + j] * (x[j] - mu[j]);
+      lp += (x[i] - mu[i]) * s;
+    }
+    return std::log(1 + lp / nu_) * (-nu_ - m) / 2;
+  }
+  vector<Real> sample_mvt(const vector<Real> &Si, Real nu_) {  // :55-72
+    int m = n();
+    vector<Real> result(m);
+    std::normal_distribution<Real> base_dist(0, 1);
+    std::gamma_distribution<Real> chi_gen(nu_ / 2);
+    for (int i = 0; i < m; i++) result[i] = base_dist(*rng);
+    vector<Real> L;
+    cholesky_lower(Si, m, L);
+    for (int i = m - 1; i >= 0; i--) {
+      Real s = result[i];
+      for (int k = i + 1; k < m; k++) s -= L[(size_t)k * m + i] * result[k];
+      result[i] = s / L[(size_t)i * m + i];
+    }
+    Real denom = std::sqrt(chi_gen(*rng) * 2 / nu_);
+    for (auto &r : result) r /= denom;
+    return result;
+  }
+  // operator(), :389-463 -- rows on the device, the rest here
+  Real eval(const vector<Real> &alpha, vector<Real> &dalpha, vector<Real> *Ht) {
+    int m = n();
+    vector<Real> gamma(m, 0);
+    alpha_to_gamma(gamma, alpha);
+    vector<Real> J((size_t)m * m);
+    jacobian_dgamma_dalpha(J, alpha);
+    Real ll = 0;
+    dalpha.assign(m, 0);
+    if (Ht) Ht->assign((size_t)m * m, 0);
+    ck(ctx, mfm_oprobit_eval(ctx, group, gamma.data(), &ll, dalpha.data(), Ht ? Ht->data() : nullptr));
+    if (Ht) {
+      vector<Real> &Hh = *Ht;
+      vector<Real> expAlpha(m);
+      for (int k = 0; k < m; k++) expAlpha[k] = std::exp(alpha[k]);
+      vector<Real> T((size_t)m * m, 0), R((size_t)m * m, 0);
+      for (int a = 0; a < m; a++)
+        for (int b = 0; b < m; b++) {
+          Real s = 0;
+          for (int k = 0; k < m; k++) s += J[(size_t)a * m + k] * Hh[(size_t)k * m + b];
+          T[(size_t)a * m + b] = s;
+        }
+      for (int a = 0; a < m; a++)
+        for (int b = 0; b < m; b++) {
+          Real s = 0;
+          for (int k = 0; k < m; k++) s += T[(size_t)a * m + k] * J[(size_t)b * m + k];
+          R[(size_t)a * m + b] = s;
+        }
+      Hh = R;
+      for (int mm = 1; mm < (K - 1); mm++)
+        for (int j = 1; j <= mm; j++) Hh[(size_t)j * m + j] += dalpha[mm] * expAlpha[j];
+      Hh[0] -= reg;
+      for (int mm = 1; mm < (K - 1); mm++) Hh[(size_t)mm * m + mm] -= reg;
+      for (auto &h : Hh) h *= -1;
+      if (has_nan(Hh)) throw std::runtime_error("H has NaN");
+    }
+    {
+      vector<Real> d2(m, 0);
+      for (int a = 0; a < m; a++) {
+        Real s = 0;
+        for (int k = 0; k < m; k++) s += J[(size_t)a * m + k] * dalpha[k];
+        d2[a] = -s;
+      }
+      dalpha = d2;
+    }
+    if (has_nan(dalpha)) throw std::runtime_error("dalpha has NaN");
+    dalpha[0] += reg * alpha[0];
+    ll -= 0.5 * reg * alpha[0] * alpha[0];
+    for (int mm = 1; mm < (K - 1); mm++) {
+      dalpha[mm] += reg * alpha[mm];
+      ll -= 0.5 * reg * alpha[mm] * alpha[mm];
+    }
+    return -ll;
+  }
+  void find_minimum(vector<Real> &alpha_hat) {  // :289-357
+    int max_iter = 10000;
+    Real epsilon = 1e-5, epsilon_rel = 1e-5, delta = 1e-5;
+    const int past = 3;
+    Real history[past] = {0, 0, 0};
+    int m = n();
+    vector<Real> alpha_new(alpha_hat), dalpha(alpha_hat), direction(alpha_hat);
+    Real ll_current = 0;
+    bool first = true;
+    int i = 0;
+    while (true) {
+      if (first) ll_current = eval(alpha_hat, dalpha, &H);
+      {
+        Real alpha2 = norm2(alpha_hat), dalpha2 = norm2(dalpha);
+        if (dalpha2 < epsilon || dalpha2 < epsilon_rel * alpha2) break;
+      }
+      {
+        vector<Real> L;
+        cholesky_lower(H, m, L);
+        direction = dalpha;
+        llt_solve(L, m, direction);
+        for (auto &d : direction) d = -d;
+      }
+      Real step_size = 1;
+      int lsc = 0;
+      while (true) {
+        for (int k = 0; k < m; k++) alpha_new[k] = alpha_hat[k] + step_size * direction[k];
+        Real ll_new;
+        try {
+          ll_new = eval(alpha_new, dalpha, &H);
+        } catch (std::runtime_error &) {
+          step_size /= 2;
+          if (++lsc > 1000) break;  // the reference can spin forever on a persistent NaN; bail out
+          continue;
+        }
+        if (ll_new >= (ll_current * (1 + delta))) {
+          step_size /= 2;
+        } else {
+          alpha_hat = alpha_new;
+          ll_current = ll_new;
+          break;
+        }
+        if (++lsc > 1000) break;
+      }
+      first = false;
+      if (i >= past) {
+        Real past_loss = history[i % past];
+        if (std::abs(past_loss - ll_current) <= delta * std::max(std::max(std::abs(ll_current), std::abs(past_loss)), Real(1)))
+          break;
+      }
+      history[i % past] = ll_current;
+      i++;
+      if (i >= max_iter) break;
+    }
+    if (i == max_iter) throw std::runtime_error("Failed to converge. See fail-log.txt");
+  }
+  void start_sample() {  // :274-279
+    vector<Real> alpha_hat(K - 1, 0);
+    find_minimum(alpha_hat);
+    alpha_now = alpha_hat;
+    alpha_to_gamma(gamma_now, alpha_now);
+  }
+  bool step() {  // :359-387
+    vector<Real> alpha_hat = alpha_now;
+    vector<Real> gamma(alpha_hat);
+    find_minimum(alpha_hat);
+    vector<Real> alpha_candidate = sample_mvt(H, nu);
+    for (int k = 0; k < n(); k++) alpha_candidate[k] += alpha_hat[k];
+    Real ll_candidate, ll_old;
+    try {
+      ll_candidate = -eval(alpha_candidate, gamma, nullptr);
+      ll_old = -eval(alpha_now, gamma, nullptr);
+    } catch (std::runtime_error &) {
+      return false;
+    }
+    Real lpc = log_p_mvt(H, alpha_hat, nu, alpha_candidate);
+    Real lpo = log_p_mvt(H, alpha_hat, nu, alpha_now);
+    Real test_ratio = std::exp(ll_candidate - lpc - ll_old + lpo);
+    Real u = std::uniform_real_distribution<Real>{0, 1}(*rng);
+    if (u < test_ratio) {
+      alpha_now = alpha_candidate;
+      alpha_to_gamma(gamma_now, alpha_now);
+      accept_count++;
+      return true;
+    }
+    return false;
+  }
+  void sample_z_given_cutpoint(uint64_t seed, uint64_t draw) {  // :238-272 on the device
+    ck(ctx, mfm_oprobit_sample_z(ctx, group, gamma_now.data(), seed, draw));
+  }
+};
+
+// ---- GibbsFMTrainer (BaseFMTrainer.hpp + FMTrainer.hpp) on the device path ---------------------------
+struct FMTrainer {
+  mfm_ctx *ctx = nullptr;
+  int64_t N = 0, D0 = 0;
+  size_t dim_all = 0;
+  FMLearningConfig cfg;
+  int random_seed;
+  std::mt19937 gen_;
+  vector<Real> y;
+  vector<Real> n_in_group;
+  vector<OprobitSampler> cutpoint_sampler;
+  uint64_t latent_draws = 0;  // Philox draw index of the device-side truncated-normal draws
+  int K = -1;
+  vector<Real> zbuf;
+
+  // BaseFMTrainer.hpp:58-105
+  FMTrainer(const py::object &Xo, const py::object &relso, const py::object &yo, int random_seed, FMLearningConfig config)
+      : cfg(std::move(config)), random_seed(random_seed), gen_(random_seed) {
+    X_ = csr_from_py(Xo);
+    rels_ = relations_from_py(relso);
+    dim_all = check_row_consistency_return_column(X_, rels_);
+    y = np_to_vec(yo);
+    N = X_.rows;
+    D0 = X_.cols;
+    if (X_.rows != (int64_t)y.size()) {
+      std::ostringstream ss;
+      ss << "Shape mismatch: X has size " << X_.rows << " and y has size " << y.size();
+      throw std::runtime_error(ss.str());
+    }
+    if (cfg.task_type == TaskType::ORDERED) {
+      const size_t rows = (size_t)X_.rows;
+      vector<bool> existence(rows, false);
+      for (auto &gc : cfg.cutpoint_groups)
+        for (size_t k : gc.second) {
+          if (k >= rows) throw std::invalid_argument("out of range for cutpoint group config.");
+          if (existence[k]) {
+            std::stringstream ss;
+            ss << "index " << k << " overlapping in cutpoint config.";
+            throw std::invalid_argument(ss.str());
+          }
+          existence[k] = true;
+        }
+      for (size_t i = 0; i < rows; i++)
+        if (!existence[i]) {
+          std::stringstream ss;
+          ss << "cutpoint group not specified for " << i << ".";
+          throw std::invalid_argument(ss.str());
+        }
+    }
+    if (cfg.group_index.size() != dim_all) throw std::out_of_range("group_index does not cover all features");  // .at()
+    n_in_group.assign(cfg.n_groups, 0);
+    for (auto g : cfg.group_index) n_in_group[g] += 1;
+  }
+  ~FMTrainer() {
+    if (ctx) mfm_destroy(ctx);
+  }
+  FMTrainer(const FMTrainer &) = delete;
+
+  // BaseFMTrainer.hpp:107-115
+  FM create_FM(int rank, Real init_std) {
+    FM fm(rank);
+    fm.initialize_weight((int64_t)dim_all, init_std, gen_);
+    return fm;
+  }
+  Hyper create_Hyper(size_t rank) { return Hyper(rank, cfg.n_groups); }
+
+  void build_device(int rank) {
+    if (ctx) return;
+    K = rank;
+    int code = mfm_create(0, &ctx);
+    if (code != MFM_OK) throw_code(code, mfm_global_error());
+    ck(ctx, mfm_set_main(ctx, X_.rows, X_.cols, X_.indptr.data(), X_.indices.data(), X_.data.data(), y.data()));
+    for (auto &r : rels_) {
+      auto m = r->map64();
+      ck(ctx, mfm_add_block(ctx, r->X.rows, r->X.cols, r->X.indptr.data(), r->X.indices.data(), r->X.data.data(), m.data()));
+    }
+    vector<int32_t> gi(cfg.group_index.begin(), cfg.group_index.end());
+    ck(ctx, mfm_set_groups(ctx, gi.data(), (int64_t)gi.size(), (int32_t)cfg.n_groups));
+    ck(ctx, mfm_finalize(ctx, rank));
+    X_ = Csr();  // the design now lives on the device
+  }
+  void upload(const FM &fm) { ck(ctx, mfm_set_state(ctx, fm.w0, fm.w.data(), fm.V.data())); }
+  void download(FM &fm) {
+    fm.w.resize(dim_all);
+    fm.V.resize(dim_all * (size_t)fm.n_factors);
+    ck(ctx, mfm_get_state(ctx, &fm.w0, fm.w.data(), fm.V.data()));
+  }
+
+  // FMTrainer.hpp:122-125: a fresh normal_distribution per draw
+  Real sample_normal(Real quad, Real first) { return (first / quad) + std::normal_distribution<Real>(0, 1)(gen_) / std::sqrt(quad); }
+  void draw_normals(Real *out, size_t n) {
+    for (size_t i = 0; i < n; i++) out[i] = std::normal_distribution<Real>(0, 1)(gen_);
+  }
+
+  void initialize_hyper(Hyper &hyper) {  // FMTrainer.hpp:89-97
+    hyper.alpha = 1;
+    std::fill(hyper.mu_w.begin(), hyper.mu_w.end(), 0);
+    std::fill(hyper.lambda_w.begin(), hyper.lambda_w.end(), 1e-5);
+    std::fill(hyper.mu_V.begin(), hyper.mu_V.end(), 0);
+    std::fill(hyper.lambda_V.begin(), hyper.lambda_V.end(), 1e-5);
+  }
+
+  void initialize_e(FM &fm) {  // FMTrainer.hpp:99-119
+    if (cfg.task_type == TaskType::ORDERED) {
+      ck(ctx, mfm_score_train(ctx));
+      int i = 0;
+      cutpoint_sampler.clear();
+      cutpoint_sampler.reserve(cfg.cutpoint_groups.size());
+      for (auto &c : cfg.cutpoint_groups) {
+        // label validation of the OprobitSampler ctor (OProbitSampler.hpp:33-46)
+        for (auto r : c.second) {
+          int y_label = (int)y[r];
+          if (std::abs(y_label - y[r]) > 1e-3) throw std::invalid_argument("y has a floating-point element.");
+          if (y_label < 0) throw std::invalid_argument("y has a negative element.");
+          if (y_label >= (int)c.first) {
+            std::stringstream ss;
+            ss << "y[ " << r << "] is greater than " << (c.first - 1) << ".";
+            throw std::invalid_argument(ss.str());
+          }
+        }
+        fm.cutpoints.emplace_back(c.first - 1);
+        int32_t g = 0;
+        bool all_rows = (int64_t)c.second.size() == N;
+        if (all_rows)
+          for (size_t k = 0; k < c.second.size(); k++)
+            if (c.second[k] != k) {
+              all_rows = false;
+              break;
+            }
+        vector<int64_t> rows(c.second.begin(), c.second.end());
+        ck(ctx, mfm_oprobit_add_group(ctx, (int32_t)c.first, all_rows ? nullptr : rows.data(), (int64_t)rows.size(), &g));
+        cutpoint_sampler.emplace_back(ctx, g, (int)c.first, gen_, cfg.reg_0, cfg.nu_oprobit);
+        cutpoint_sampler[i].start_sample();
+        OprobitSampler::alpha_to_gamma(fm.cutpoints[i], cutpoint_sampler[i].alpha_now);
+        cutpoint_sampler[i].sample_z_given_cutpoint((uint64_t)random_seed, latent_draws++);
+        i++;
+      }
+      return;
+    }
+    ck(ctx, mfm_update_e_regression(ctx));  // e = score - y
+  }
+
+  // ---- one Gibbs iteration, BaseFMTrainer.hpp:135-152 ----
+  void update_all(FM &fm, Hyper &hyper) {
+    const size_t G = cfg.n_groups;
+    const int Kf = fm.n_factors;
+    // update_alpha (FMTrainer.hpp:127-145) + update_w0 (:218-229) share one pass over e
+    Real sum_e = 0, sum_e2 = 0;
+    const bool need_alpha = cfg.task_type == TaskType::REGRESSION;
+    if (need_alpha || cfg.fit_w0) ck(ctx, mfm_reduce_e(ctx, &sum_e, &sum_e2));
+    if (need_alpha) {
+      Real exponent = (cfg.alpha_0 + N) / 2;
+      Real variance = (cfg.beta_0 + sum_e2) / 2;
+      hyper.alpha = std::gamma_distribution<Real>(exponent, 1 / variance)(gen_);
+    } else {
+      hyper.alpha = 1;
+    }
+    if (!cfg.fit_w0) {
+      fm.w0 = 0;
+    } else {
+      Real w0_lin_term = hyper.alpha * (N * fm.w0 - sum_e);  // sum(w0 - e)
+      Real w0_quad_term = hyper.alpha * N + cfg.reg_0;
+      Real w0_new = sample_normal(w0_quad_term, w0_lin_term);
+      ck(ctx, mfm_shift_e(ctx, w0_new - fm.w0));
+      fm.w0 = w0_new;
+    }
+    ck(ctx, mfm_set_w0(ctx, fm.w0));
+    // update_lambda_w / update_mu_w (:150-200)
+    vector<Real> sum(G * std::max(Kf, 1)), ssd(G * std::max(Kf, 1));
+    ck(ctx, mfm_group_stats_w(ctx, hyper.mu_w.data(), sum.data(), ssd.data()));
+    for (size_t g = 0; g < G; g++) {
+      Real alpha = cfg.alpha_0 + n_in_group[g];
+      Real beta = cfg.beta_0 + ssd[g];
+      hyper.lambda_w[g] = std::gamma_distribution<Real>(alpha / 2, 2 / beta)(gen_);
+    }
+    for (size_t g = 0; g < G; g++) {
+      Real square = hyper.lambda_w[g] * (cfg.gamma_0 + n_in_group[g]);
+      Real linear = cfg.gamma_0 * cfg.mu_0 + sum[g];
+      linear *= hyper.lambda_w[g];
+      hyper.mu_w[g] = sample_normal(square, linear);
+    }
+    // update_w (:231-314)
+    if (!cfg.fit_linear) {
+      ck(ctx, mfm_zero_w(ctx));
+    } else {
+      zbuf.resize(std::max<size_t>(dim_all, 1));
+      draw_normals(zbuf.data(), dim_all);
+      ck(ctx, mfm_sweep_w(ctx, hyper.alpha, hyper.lambda_w.data(), hyper.mu_w.data(), zbuf.data()));
+    }
+    if (Kf > 0) {
+      // update_lambda_V / update_mu_V (:202-216): factor outer, group inner
+      ck(ctx, mfm_group_stats_V(ctx, hyper.mu_V.data(), sum.data(), ssd.data()));
+      for (int f = 0; f < Kf; f++)
+        for (size_t g = 0; g < G; g++) {
+          Real alpha = cfg.alpha_0 + n_in_group[g];
+          Real beta = cfg.beta_0 + ssd[(size_t)f * G + g];
+          hyper.lambda_V[(size_t)f * G + g] = std::gamma_distribution<Real>(alpha / 2, 2 / beta)(gen_);
+        }
+      for (int f = 0; f < Kf; f++)
+        for (size_t g = 0; g < G; g++) {
+          Real lam = hyper.lambda_V[(size_t)f * G + g];
+          Real square = lam * (cfg.gamma_0 + n_in_group[g]);
+          Real linear = cfg.gamma_0 * cfg.mu_0 + sum[(size_t)f * G + g];
+          linear *= lam;
+          hyper.mu_V[(size_t)f * G + g] = sample_normal(square, linear);
+        }
+      // update_V (:316-486)
+      zbuf.resize(dim_all * (size_t)Kf);
+      draw_normals(zbuf.data(), dim_all * (size_t)Kf);
+      ck(ctx, mfm_sweep_V(ctx, 0, Kf, hyper.alpha, hyper.lambda_V.data(), hyper.mu_V.data(), zbuf.data()));
+    }
+    // update_e (:493-522)
+    if (cfg.task_type == TaskType::REGRESSION) {
+      ck(ctx, mfm_update_e_regression(ctx));
+    } else if (cfg.task_type == TaskType::CLASSIFICATION) {
+      ck(ctx, mfm_update_e_classification(ctx, (uint64_t)random_seed, latent_draws++));
+    } else {
+      ck(ctx, mfm_score_train(ctx));
+      int i = 0;
+      for (auto &s : cutpoint_sampler) {
+        s.step();
+        OprobitSampler::alpha_to_gamma(fm.cutpoints[i], s.alpha_now);
+        s.sample_z_given_cutpoint((uint64_t)random_seed, latent_draws++);
+        i++;
+      }
+    }
+  }
+
+  // FMTrainer.hpp:56-87
+  std::pair<Predictor, LearningHistory> learn_with_callback(
+      FM &fm, Hyper &hyper, const std::function<bool(int, FM *, Hyper *, LearningHistory *)> &cb) {
+    std::pair<Predictor, LearningHistory> result{Predictor((size_t)fm.n_factors, dim_all, cfg.task_type), LearningHistory()};
+    build_device(fm.n_factors);
+    upload(fm);
+    initialize_hyper(hyper);
+    initialize_e(fm);
+    fm.fetch = [this](FM &f) { this->download(f); };
+    result.first.samples.reserve((size_t)cfg.n_kept_samples);
+    for (int it = 0; it < cfg.n_iter; it++) {
+      update_all(fm, hyper);
+      fm.stale = true;  // w / V live on the device until somebody reads them
+      if (cfg.n_iter <= (it + cfg.n_kept_samples)) result.first.samples.emplace_back(fm.snapshot());
+      result.second.hypers.emplace_back(hyper);
+      bool should_stop = cb(it, &fm, &hyper, &(result.second));
+      if (should_stop) break;
+    }
+    fm.ensure();
+    fm.fetch = nullptr;
+    for (auto &cs : cutpoint_sampler) result.second.n_mh_accept.emplace_back(cs.accept_count);
+    return result;
+  }
+
+ private:
+  Csr X_;
+  Relations rels_;
+};
+
+// cpp_source/declare_module.hpp:30-45
+std::pair<Predictor, LearningHistory> create_train_fm(size_t n_factor, Real init_std, const py::object &X,
+                                                      const py::object &relations, const py::object &y, int random_seed,
+                                                      FMLearningConfig &config,
+                                                      std::function<bool(int, FM *, Hyper *, LearningHistory *)> cb) {
+  FMTrainer fm_trainer(X, relations, y, random_seed, config);
+  auto fm = fm_trainer.create_FM((int)n_factor, init_std);
+  auto hyper_param = fm_trainer.create_Hyper((size_t)fm.n_factors);
+  return fm_trainer.learn_with_callback(fm, hyper_param, cb);
+}
+
+// A steppable training session: not part of the reference's surface; bench.py and the parity tests
+// use it to time / inspect single Gibbs iterations of exactly the loop create_train_fm runs.
+struct GibbsSession {
+  std::unique_ptr<FMTrainer> trainer;
+  FM fm;
+  Hyper hyper;
+  int it = 0;
+  GibbsSession(size_t n_factor, Real init_std, const py::object &X, const py::object &relations, const py::object &y,
+               int random_seed, FMLearningConfig &config)
+      : trainer(new FMTrainer(X, relations, y, random_seed, config)) {
+    fm = trainer->create_FM((int)n_factor, init_std);
+    hyper = trainer->create_Hyper((size_t)fm.n_factors);
+    trainer->build_device(fm.n_factors);
+    trainer->upload(fm);
+    trainer->initialize_hyper(hyper);
+    trainer->initialize_e(fm);
+    fm.fetch = [this](FM &f) { this->trainer->download(f); };
+  }
+  void step() {
+    trainer->update_all(fm, hyper);
+    fm.stale = true;
+    it++;
+  }
+  void synchronize() { ck(trainer->ctx, mfm_synchronize(trainer->ctx)); }
+  py::array_t<double> residual() {
+    py::array_t<double> e((py::ssize_t)trainer->N);
+    ck(trainer->ctx, mfm_get_e(trainer->ctx, e.mutable_data()));
+    return e;
+  }
+  void timing_enable(bool on) { ck(trainer->ctx, mfm_timing_enable(trainer->ctx, on ? 1 : 0)); }
+  void timing_reset() { ck(trainer->ctx, mfm_timing_reset(trainer->ctx)); }
+  py::dict timing() {
+    py::dict out;
+    for (int c = 0; c < mfm_timing_n_classes(); c++) {
+      double ms = 0, by = 0;
+      int64_t n = 0;
+      ck(trainer->ctx, mfm_timing_get(trainer->ctx, c, &ms, &n, &by));
+      if (n) out[py::str(mfm_timing_class_name(c))] = py::make_tuple(ms, n, by);
+    }
+    return out;
+  }
+  py::tuple plan_info() {
+    int64_t a = 0, b = 0;
+    mfm_plan_info(trainer->ctx, &a, &b);
+    return py::make_tuple(a, b);
+  }
+};
+
+}  // namespace
+
+PYBIND11_MODULE(_myfm, m) {
+  m.doc() = "MI355X backend for myfm (same surface as the reference's myfm._myfm).";
+
+  py::enum_<TaskType>(m, "TaskType", py::arithmetic())
+      .value("REGRESSION", TaskType::REGRESSION)
+      .value("CLASSIFICATION", TaskType::CLASSIFICATION)
+      .value("ORDERED", TaskType::ORDERED);
+
+  py::class_<FMLearningConfig>(m, "FMLearningConfig");
+
+  py::class_<RelationBlock, std::shared_ptr<RelationBlock>>(m, "RelationBlock", "The RelationBlock Class.")
+      .def(py::init([](vector<size_t> o2b, const py::object &data) {
+             return std::make_shared<RelationBlock>(std::move(o2b), csr_from_py(data));
+           }),
+           py::arg("original_to_block"), py::arg("data"))
+      .def_readonly("original_to_block", &RelationBlock::original_to_block)
+      .def_property_readonly("data", [](const RelationBlock &b) { return csr_to_py(b.X); })
+      .def_readonly("mapper_size", &RelationBlock::mapper_size)
+      .def_readonly("block_size", &RelationBlock::block_size)
+      .def_readonly("feature_size", &RelationBlock::feature_size)
+      .def("__repr__",
+           [](const RelationBlock &b) {
+             std::ostringstream ss;
+             ss << "<RelationBlock with mapper size = " << b.mapper_size << ", block data size = " << b.block_size
+                << ", feature size = " << b.feature_size << ">";
+             return ss.str();
+           })
+      .def(py::pickle([](const RelationBlock &b) { return py::make_tuple(b.original_to_block, csr_to_py(b.X)); },
+                      [](py::tuple t) {
+                        if (t.size() != 2) throw std::runtime_error("invalid state for Relationblock.");
+                        return std::make_shared<RelationBlock>(t[0].cast<vector<size_t>>(), csr_from_py(t[1]));
+                      }));
+
+  py::class_<ConfigBuilder>(m, "ConfigBuilder")
+      .def(py::init<>())
+      .def("set_alpha_0", &ConfigBuilder::set_alpha_0)
+      .def("set_beta_0", &ConfigBuilder::set_beta_0)
+      .def("set_gamma_0", &ConfigBuilder::set_gamma_0)
+      .def("set_mu_0", &ConfigBuilder::set_mu_0)
+      .def("set_reg_0", &ConfigBuilder::set_reg_0)
+      .def("set_n_iter", &ConfigBuilder::set_n_iter)
+      .def("set_n_kept_samples", &ConfigBuilder::set_n_kept_samples)
+      .def("set_task_type", &ConfigBuilder::set_task_type)
+      .def("set_nu_oprobit", &ConfigBuilder::set_nu_oprobit)
+      .def("set_fit_w0", &ConfigBuilder::set_fit_w0)
+      .def("set_fit_linear", &ConfigBuilder::set_fit_linear)
+      .def("set_group_index", &ConfigBuilder::set_group_index)
+      .def("set_identical_groups", &ConfigBuilder::set_identical_groups)
+      .def("set_cutpoint_scale", &ConfigBuilder::set_cutpoint_scale)
+      .def("set_cutpoint_groups", &ConfigBuilder::set_cutpoint_groups)
+      .def("build", &ConfigBuilder::build);
+
+  py::class_<FM>(m, "FM")
+      .def_property(
+          "w0", [](FM &f) { return f.w0; }, [](FM &f, Real v) { f.w0 = v; })
+      .def_property(
+          "w",
+          [](FM &f) {
+            f.ensure();
+            return vec_to_np(f.w);
+          },
+          [](FM &f, const py::object &v) {
+            f.ensure();
+            f.w = np_to_vec(v);
+          })
+      .def_property(
+          "V",
+          [](FM &f) {
+            f.ensure();
+            return colmajor_to_np(f.V, f.D(), f.n_factors);
+          },
+          [](FM &f, const py::object &v) {
+            f.ensure();
+            int64_t r, c;
+            f.V = np_to_colmajor(v, &r, &c);
+          })
+      .def_property(
+          "cutpoints",
+          [](FM &f) {
+            py::list out;
+            for (auto &c : f.cutpoints) out.append(vec_to_np(c));
+            return out;
+          },
+          [](FM &f, const py::object &v) {
+            f.cutpoints.clear();
+            for (auto item : py::reinterpret_borrow<py::sequence>(v)) f.cutpoints.push_back(np_to_vec(item));
+          })
+      .def("predict_score", &FM::predict_score)
+      .def("oprobit_predict_proba", &FM::oprobit_predict_proba)
+      .def("__repr__",
+           [](FM &f) {
+             f.ensure();
+             std::ostringstream ss;
+             ss << "<Factorization Machine sample with feature size = " << f.w.size() << ", rank = " << f.n_factors << ">";
+             return ss.str();
+           })
+      .def(py::pickle(
+          [](FM &f) {
+            f.ensure();
+            py::list cps;
+            for (auto &c : f.cutpoints) cps.append(vec_to_np(c));
+            return py::make_tuple(f.w0, vec_to_np(f.w), colmajor_to_np(f.V, f.D(), f.n_factors), cps);
+          },
+          [](py::tuple t) {
+            if (t.size() != 3 && t.size() != 4) throw std::runtime_error("invalid state for FM.");
+            int64_t r, c;
+            vector<Real> V = np_to_colmajor(t[2], &r, &c);
+            vector<vector<Real>> cps;
+            if (t.size() == 4)
+              for (auto item : py::reinterpret_borrow<py::sequence>(t[3])) cps.push_back(np_to_vec(item));
+            return FM(t[0].cast<Real>(), np_to_vec(t[1]), std::move(V), (int)c, std::move(cps));
+          }));
+
+  py::class_<Hyper>(m, "FMHyperParameters")
+      .def_readonly("alpha", &Hyper::alpha)
+      .def_property_readonly("mu_w", [](const Hyper &h) { return vec_to_np(h.mu_w); })
+      .def_property_readonly("lambda_w", [](const Hyper &h) { return vec_to_np(h.lambda_w); })
+      .def_property_readonly("mu_V", [](const Hyper &h) { return colmajor_to_np(h.mu_V, h.G, h.K); })
+      .def_property_readonly("lambda_V", [](const Hyper &h) { return colmajor_to_np(h.lambda_V, h.G, h.K); })
+      .def(py::pickle(
+          [](const Hyper &h) {
+            return py::make_tuple(h.alpha, vec_to_np(h.mu_w), vec_to_np(h.lambda_w), colmajor_to_np(h.mu_V, h.G, h.K),
+                                  colmajor_to_np(h.lambda_V, h.G, h.K));
+          },
+          [](py::tuple t) {
+            if (t.size() != 5) throw std::runtime_error("invalid state for FMHyperParameters.");
+            Hyper h;
+            h.alpha = t[0].cast<Real>();
+            h.mu_w = np_to_vec(t[1]);
+            h.lambda_w = np_to_vec(t[2]);
+            int64_t r, c;
+            h.mu_V = np_to_colmajor(t[3], &r, &c);
+            h.lambda_V = np_to_colmajor(t[4], &r, &c);
+            h.G = (size_t)r;
+            h.K = (size_t)c;
+            return h;
+          }));
+
+  py::class_<Predictor>(m, "Predictor")
+      .def_readonly("samples", &Predictor::samples)
+      .def("predict", &Predictor::predict)
+      .def("predict_parallel", &Predictor::predict_parallel)
+      .def("predict_parallel_oprobit", &Predictor::predict_parallel_oprobit)
+      .def(py::pickle(
+          [](const Predictor &p) { return py::make_tuple(p.rank, p.feature_size, static_cast<int>(p.type), p.samples); },
+          [](py::tuple t) {
+            if (t.size() != 4) throw std::runtime_error("invalid state for FMHyperParameters.");
+            Predictor p(t[0].cast<size_t>(), t[1].cast<size_t>(), static_cast<TaskType>(t[2].cast<int>()));
+            p.samples = t[3].cast<vector<FM>>();
+            return p;
+          }));
+
+  py::class_<FMTrainer>(m, "FMTrainer")
+      .def(py::init<const py::object &, const py::object &, const py::object &, int, FMLearningConfig>())
+      .def("create_FM", &FMTrainer::create_FM)
+      .def("create_Hyper", &FMTrainer::create_Hyper);
+
+  py::class_<LearningHistory>(m, "LearningHistory")
+      .def_readonly("hypers", &LearningHistory::hypers)
+      .def_readonly("train_log_losses", &LearningHistory::train_log_losses)
+      .def_readonly("n_mh_accept", &LearningHistory::n_mh_accept)
+      .def(py::pickle([](const LearningHistory &h) { return py::make_tuple(h.hypers, h.train_log_losses, h.n_mh_accept); },
+                      [](py::tuple t) {
+                        if (t.size() != 3) throw std::runtime_error("invalid state for LearningHistory.");
+                        LearningHistory r;
+                        r.hypers = t[0].cast<vector<Hyper>>();
+                        r.train_log_losses = t[1].cast<vector<Real>>();
+                        r.n_mh_accept = t[2].cast<vector<size_t>>();
+                        return r;
+                      }));
+
+  m.def("create_train_fm", &create_train_fm, "create and train fm.", py::return_value_policy::move);
+
+  // extensions beyond the reference's surface (bench / tests)
+  py::class_<GibbsSession>(m, "GibbsSession")
+      .def(py::init<size_t, Real, const py::object &, const py::object &, const py::object &, int, FMLearningConfig &>())
+      .def("step", &GibbsSession::step)
+      .def("synchronize", &GibbsSession::synchronize)
+      .def("residual", &GibbsSession::residual)
+      .def("timing_enable", &GibbsSession::timing_enable)
+      .def("timing_reset", &GibbsSession::timing_reset)
+      .def("timing", &GibbsSession::timing)
+      .def("plan_info", &GibbsSession::plan_info)
+      .def_property_readonly("fm", [](GibbsSession &s) -> FM & { return s.fm; }, py::return_value_policy::reference_internal)
+      .def_property_readonly("hyper", [](GibbsSession &s) -> Hyper & { return s.hyper; },
+                             py::return_value_policy::reference_internal)
+      .def_readonly("iteration", &GibbsSession::it);
+  m.def("device_count", []() { return mfm_device_count(); });
+  m.def("backend_version", []() { return std::string(mfm_version()); });
+}

@@ -1,0 +1,228 @@
+"""End-to-end GPU tests through the drop-in boundary (myfm_amd estimators -> _myfm -> C ABI).
+
+They read like the reference's own tests (tests/regression/test_block.py, test_fit.py,
+tests/classification/test_classification.py, tests/oprobit/test_oprobit_1dim.py) plus draw-for-draw
+comparisons with the CPU oracle where the chain is seed-reproducible (regression).
+"""
+import pickle
+import tempfile
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from . import datasets as ds
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def myfm():
+    import myfm_amd
+    from myfm_amd import _myfm
+
+    if _myfm.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests need a real MI355X")
+    return myfm_amd
+
+
+class RunningMean:
+    """what RegressionCallback / ClassificationCallback accumulate (utils/callbacks/libfm.py:82-113)."""
+
+    def __init__(self, X, transform=lambda s: s, X_rel=()):
+        self.X, self.X_rel, self.f = X, list(X_rel), transform
+        self.sum, self.n = None, 0
+
+    def __call__(self, i, fm, hyper, history):
+        p = self.f(fm.predict_score(self.X, self.X_rel))
+        self.sum = p if self.sum is None else self.sum + p
+        self.n += 1
+        return False, None
+
+
+def test_toy_config1(myfm):
+    # BASELINE config 1 / examples/toy.py
+    X, y = ds.toy()
+    fm = myfm.MyFMRegressor(rank=4).fit(X, y, n_iter=100)
+    assert fm.predict(X).shape == (4,) and len(fm.predictor_.samples) == 95
+    clf = myfm.MyFMClassifier(rank=4).fit(X, y)
+    p = clf.predict_proba(sps.csr_matrix(np.array([[24.0, 1, 0, 0, 0, 1, 0, 0, 0]])))
+    assert p.shape == (1,) and 0 <= p[0] <= 1
+
+
+def test_regression_matches_oracle_sample_by_sample(myfm, oracle):
+    X, y, shapes = ds.onehot_mf(30000, 800, 150, seed=4)
+    fm = myfm.MyFMRegressor(6, random_seed=7).fit(X, y, group_shapes=shapes, n_iter=10, n_kept_samples=10)
+    samples, hypers, _ = oracle.fit(X, y, rank=6, seed=7, group_index=ds.group_index_from_shapes(shapes), n_iter=10,
+                                    n_kept_samples=10)
+    for it, (got, want) in enumerate(zip(fm.predictor_.samples, samples)):
+        tol = 1e-9 if it == 0 else 1e-6
+        assert abs(got.w0 - want[0]) < tol
+        np.testing.assert_allclose(got.w, want[1], rtol=tol, atol=tol)
+        np.testing.assert_allclose(got.V, want[2], rtol=tol, atol=tol)
+    trace = fm.get_hyper_trace()
+    np.testing.assert_allclose(trace["alpha"].values, [h["alpha"] for h in hypers], rtol=1e-6)
+    np.testing.assert_allclose(trace["lambda_V[1,3]"].values, [h["lambda_V"][1, 3] for h in hypers], rtol=1e-6)
+    # posterior-mean parity (north_star: RMSE <= 1e-3)
+    pred = fm.predict(X[:5000])
+    want = np.mean([oracle.OracleDesign(X[:5000]).predict_score(*s) for s in samples], axis=0)
+    assert np.sqrt(np.mean((pred - want) ** 2)) < 1e-6
+
+
+def test_block(myfm):
+    # tests/regression/test_block.py:80-149
+    main, X_flat, blocks, y, group_shapes = ds.block_design()
+    rbs = [myfm.RelationBlock(list(m), b) for m, b in blocks]
+    fm_flat = myfm.MyFMRegressor(2, fit_w0=False).fit(X_flat, y, group_shapes=group_shapes, n_iter=30, n_kept_samples=30)
+    fm_blocked = myfm.MyFMRegressor(2, fit_w0=False).fit(main, y, rbs, group_shapes=group_shapes, n_iter=30, n_kept_samples=30)
+    for a, b in zip(fm_flat.predictor_.samples, fm_blocked.predictor_.samples):
+        np.testing.assert_allclose(a.V, b.V)
+    with tempfile.TemporaryFile() as fs:
+        pickle.dump(fm_blocked, fs)
+        del fm_blocked
+        fs.seek(0)
+        fm_blocked = pickle.load(fs)
+    p1 = fm_flat.predict(main, rbs, n_workers=2)
+    p2 = fm_blocked.predict(X_flat, n_workers=None)
+    np.testing.assert_allclose(p1, p2)
+    # doc/source/relation-blocks.rst:205-210
+    assert np.abs(fm_flat.w_samples[:3] - fm_blocked.w_samples[:3]).max() < 1e-5
+
+
+def test_block_multihot_matches_oracle(myfm, oracle):
+    main, X_flat, blocks, y, shapes = ds.multihot_block_design()
+    rbs = [myfm.RelationBlock(list(m), b) for m, b in blocks]
+    fm = myfm.MyFMRegressor(3).fit(main, y, rbs, group_shapes=shapes, n_iter=12, n_kept_samples=12)
+    samples, _, _ = oracle.fit(main, y, blocks, rank=3, group_index=ds.group_index_from_shapes(shapes), n_iter=12,
+                               n_kept_samples=12)
+    for got, want in zip(fm.predictor_.samples, samples):
+        np.testing.assert_allclose(got.V, want[2], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(got.w, want[1], rtol=1e-6, atol=1e-7)
+    # X=None with blocks only (base.py:230-233)
+    fm2 = myfm.MyFMRegressor(2).fit(None, y, rbs, n_iter=5)
+    assert fm2.predict(None, rbs).shape == y.shape
+
+
+@pytest.mark.parametrize("alpha_inv", [0.3, 1.0, 3])
+def test_middle_reg(myfm, alpha_inv):
+    # tests/regression/test_fit.py:19-72
+    X, score = ds.middle_data()
+    y = score + alpha_inv * np.random.RandomState(0).normal(0, 1, size=score.shape)
+    cb = RunningMean(X)
+    init = myfm.MyFMGibbsRegressor(3)
+    assert init.w0_samples is None and init.w_samples is None and init.V_samples is None
+    fm = init.fit(X, y, X_test=X, y_test=y, n_iter=100, n_kept_samples=100, callback=cb)
+    np.testing.assert_allclose(fm.predict(X), cb.sum / 100)
+    last_alpha = fm.get_hyper_trace()["alpha"].iloc[-20:].values
+    assert np.all(last_alpha > (1 / alpha_inv ** 2) / 2) and np.all(last_alpha < (1 / alpha_inv ** 2) * 2)
+    assert np.all(np.abs(fm.w0_samples[-20:] - ds.STUB_W0) < 0.5)
+    for w_ in fm.w_samples[-20:]:
+        assert np.all(np.abs(w_ - ds.STUB_W) < 1.0)
+    for V_ in fm.V_samples[-20:]:
+        for i in range(3):
+            for j in range(i + 1, 3):
+                cross = ds.STUB_V[:, i].dot(ds.STUB_V[:, j])
+                if abs(cross) < 0.1:
+                    continue
+                sign = cross / abs(cross)
+                c = V_[i].dot(V_[j])
+                assert sign * cross * 0.5 < c < sign * cross * 2
+
+
+def test_middle_clf(myfm):
+    # tests/classification/test_classification.py:13-70
+    from myfm_amd.estimators import std_cdf
+
+    X, score = ds.middle_data()
+    sn = score + np.random.RandomState(0).normal(0, 1, size=score.shape)
+    sn -= sn.mean()
+    y = sn > 0
+    cb = RunningMean(X, std_cdf)
+    fm = myfm.MyFMGibbsClassifier(3).fit(X, y, X_test=X, y_test=y, n_iter=200, n_kept_samples=200, callback=cb)
+    np.testing.assert_allclose(fm.predict_proba(X), cb.sum / 200)
+    assert ((fm.predict(X) == y).mean()) > 0.85
+    for s in fm.predictor_.samples[-20:]:
+        for i in range(3):
+            for j in range(i + 1, 3):
+                cross = ds.STUB_V[:, i].dot(ds.STUB_V[:, j])
+                if abs(cross) < 0.5:
+                    continue
+                sign = cross / abs(cross)
+                c = np.asarray(s.V)[i].dot(np.asarray(s.V)[j])
+                assert sign * cross * 0.5 < c < sign * cross * 2
+
+
+def test_classification_posterior_mean_vs_oracle(myfm, oracle):
+    # distributional parity: the latent z are drawn from a different (Philox) stream than the
+    # reference's mt19937, so compare posterior means of P(y=1) with a Monte-Carlo tolerance
+    from myfm_amd.estimators import std_cdf
+
+    X, score = ds.middle_data()
+    sn = score + np.random.RandomState(1).normal(0, 1, size=score.shape)
+    y = sn > np.median(sn)
+    fm = myfm.MyFMGibbsClassifier(3).fit(X, y, n_iter=400, n_kept_samples=300)
+    samples, _, _ = oracle.fit(X, y.astype(float) * 2 - 1, rank=3, n_iter=400, n_kept_samples=300, task=oracle.CLASSIFICATION)
+    want = np.mean([std_cdf(oracle.OracleDesign(X).predict_score(*s)) for s in samples], axis=0)
+    got = fm.predict_proba(X)
+    assert np.sqrt(np.mean((got - want) ** 2)) < 0.03
+
+
+def test_oprobit(myfm):
+    # tests/oprobit/test_oprobit_1dim.py:10-61
+    from myfm_amd.estimators import std_cdf
+
+    n = 1000
+    cps = np.array([0.0, 0.5, 1.5])
+    rns = np.random.RandomState(0)
+    x = rns.normal(0, 2, size=n)
+    y = np.zeros(n)
+    score = x * 0.5 + rns.randn(n)
+    for c in cps:
+        y += (score > c).astype(np.int64)
+    fm = myfm.MyFMOrderedProbit(0, fit_w0=False)
+    fm.fit(x[:, None], y, n_iter=100, n_kept_samples=100)
+    for c1, c2, c3 in fm.cutpoint_samples[-10:]:
+        assert abs(c1) < 0.25 and abs(c2 - c1 - 0.5) < 0.25 and abs(c3 - c1 - 1.5) < 0.25
+    p = fm.predict_proba(x[:, None])
+    manual = np.zeros((n, 4))
+    for s in fm.predictor_.samples:
+        sc = s.predict_score(x[:, None], [])
+        cdf = std_cdf(s.cutpoints[0][None, :] - sc[:, None])
+        d = np.hstack([np.zeros((n, 1)), cdf, np.ones((n, 1))])
+        manual += d[:, 1:] - d[:, :-1]
+    np.testing.assert_allclose(manual / len(fm.predictor_.samples), p)
+    assert (fm.predict(x[:, None]) == y).mean() > 0.4
+    assert fm.history_.n_mh_accept[0] > 20
+
+
+def test_oprobit_eval_matches_oracle_cutpoints(myfm, oracle):
+    # the device likelihood/gradient/Hessian drive the same Newton start point as the oracle's
+    n = 2000
+    rns = np.random.RandomState(3)
+    x = rns.normal(0, 1.5, size=n)
+    score = 0.8 * x + rns.randn(n)
+    y = (score > -0.5).astype(float) + (score > 0.4) + (score > 1.1)
+    t = oracle.OracleTrainer(sps.csr_matrix(x[:, None]), y, rank=0, fit_w0=False, task=oracle.ORDERED)
+    fm = myfm.MyFMOrderedProbit(0, fit_w0=False).fit(x[:, None], y, n_iter=1, n_kept_samples=1)
+    # after iteration 1 both chains hold cutpoints close to the same posterior mode
+    t.step()
+    np.testing.assert_allclose(fm.cutpoint_samples[0], t.cutpoints(0), atol=0.15)
+
+
+def test_error_behaviour(myfm):
+    X, y = ds.toy()
+    with pytest.raises(RuntimeError, match="index mapping points to non-existing row"):
+        myfm.RelationBlock([0, 5], sps.csr_matrix(np.eye(2)))
+    fm = myfm.MyFMRegressor(2).fit(X, y, n_iter=6)
+    with pytest.raises(ValueError, match="Told to predict for"):
+        fm.predict(X[:, :5])
+    with pytest.raises(ValueError, match="Total feature size mismatch"):
+        fm.predictor_.samples[0].predict_score(X[:, :5], [])
+    with pytest.raises(RuntimeError, match="Shape mismatch"):
+        from myfm_amd import _myfm
+
+        cfg = _myfm.ConfigBuilder().set_identical_groups(9).build()
+        _myfm.create_train_fm(2, 0.1, X, [], np.zeros(3), 1, cfg, lambda *a: False)
+    # early stop through the callback (FMTrainer.hpp:78-81)
+    fm = myfm.MyFMRegressor(2).fit(X, y, n_iter=50, n_kept_samples=50, callback=lambda i, *a: (i == 9, None))
+    assert len(fm.history_.hypers) == 10 and len(fm.predictor_.samples) == 10
