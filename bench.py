@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py -- Gibbs iterations/sec of the MI355X sampler on BASELINE config 3:
+MovieLens-10M-shaped synthetic CSR (N = 10 M rows, 69 878 + 10 677 one-hot features, nnz = 20 M),
+MyFMRegressor rank 32, fp64, full update_all per step (BaseFMTrainer.hpp:135-152).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line (rank 0). Besides the contract's fields it carries
+  "roofline":     HBM roofline of the dominant kernel class (algorithmic bytes / HIP-event time)
+  "cpu_baseline": the CPU oracle (Eigen-free restatement, 1 thread) timed on this box's host cores
+                  on a bounded sample of the same workload (N = 1: full iterations of the same design)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def b_iter_bytes(N, nnz, D, K):
+    """algorithmic bytes per Gibbs iteration, main table, regression."""
+    return nnz * (40 + 56 * K) + N * (40 + 8 * K) + D * (16 * K + 8)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--users", type=int, default=69878)
+    ap.add_argument("--items", type=int, default=10677)
+    ap.add_argument("--rank", type=int, default=32)
+    ap.add_argument("--cpu-iters", type=int, default=2, help="CPU-oracle iterations timed (0 disables)")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if a.gpus != 1 or world != 1:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (a.gpus, world))
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the sampler has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    os.environ["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES", "")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from myfm_amd import _myfm
+    from tests import datasets as ds
+
+    # ---- workload: every rank holds one ML-10M-shaped shard of `rows` rows (weak scaling) --------
+    t0 = time.time()
+    X, y, shapes = ds.movielens_like(a.rows, a.users, a.items, rank_true=32, seed=1 + rank)
+    gi = ds.group_index_from_shapes(shapes)
+    N, D, nnz, K = X.shape[0], X.shape[1], X.nnz, a.rank
+    t_data = time.time() - t0
+
+    b = _myfm.ConfigBuilder()
+    b.set_alpha_0(1.0).set_beta_0(1.0).set_gamma_0(1.0).set_mu_0(0.0).set_reg_0(1.0)
+    b.set_group_index([int(g) for g in gi]).set_n_iter(a.steps + a.warmup).set_n_kept_samples(0)
+    b.set_task_type(_myfm.TaskType.REGRESSION)
+    t0 = time.time()
+    # the device ordinal is the process-local one: one process per GPU, HIP sees LOCAL_RANK via set_device
+    sess = _myfm.GibbsSession(K, 0.1, X, [], y, 42 + rank, b.build())
+    t_setup = time.time() - t0
+
+    def sync():
+        sess.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        sess.step()
+    if not a.no_kernel_timing:
+        sess.timing_enable(True)
+        sess.timing_reset()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        sess.step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timing = {} if a.no_kernel_timing else dict(sess.timing())
+    if not a.no_kernel_timing:
+        sess.timing_enable(False)
+
+    # sanity: the chain is alive (finite state, plausible noise precision)
+    alpha = sess.hyper.alpha
+    assert np.isfinite(alpha) and alpha > 0, alpha
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    it_per_s = world * a.steps / elapsed  # every rank runs its own shard-chain: whole-job iterations/s
+    B_iter = b_iter_bytes(N, nnz, D, K)
+
+    roofline = None
+    if timing:
+        dom = max(timing.items(), key=lambda kv: kv[1][0])
+        name, (ms, launches, alg_bytes) = dom
+        achieved = alg_bytes / (ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm",
+            "kernel": name,
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "avg_launch_us": round(ms / launches * 1e3, 2),
+            "launches": int(launches),
+            "alg_bytes_per_launch": round(alg_bytes / launches),
+            "kernel_ms_per_step": round(sum(v[0] for v in timing.values()) / a.steps, 3),
+            "iteration_alg_gbs": round(B_iter * (a.steps / elapsed) / 1e9, 1),
+            "iteration_frac": round(B_iter * (a.steps / elapsed) / 1e9 / HBM_PEAK_GBS, 4),
+            "by_kernel_ms_per_step": {k: round(v[0] / a.steps, 3) for k, v in sorted(timing.items(), key=lambda kv: -kv[1][0])},
+        }
+
+    cpu = None
+    if a.cpu_iters > 0:
+        from oracle import oracle as O
+
+        O.build()
+        ot = O.OracleTrainer(X, y, rank=K, group_index=gi, seed=42)
+        c0 = time.perf_counter()
+        for _ in range(a.cpu_iters):
+            ot.step()
+        c_el = time.perf_counter() - c0
+        cpu = {
+            "value": round(a.cpu_iters / c_el, 5),
+            "unit": "Gibbs iterations/sec",
+            "cores": 1,
+            "kind": "port",
+            "sample": "%d full update_all iterations of the same design (N=%d, nnz=%d, rank %d) by oracle/libmyfm_oracle.so, "
+                      "1 thread; the reference core itself needs Eigen and cannot be built here" % (a.cpu_iters, N, nnz, K),
+            "seconds": round(c_el, 2),
+            "host_cpus": os.cpu_count(),
+        }
+
+    out = {
+        "metric": "Gibbs iterations/sec (rank=32)",
+        "value": round(it_per_s, 3),
+        "unit": "Gibbs iterations/sec",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[2]: MovieLens-10M-shaped synthetic CSR, MyFMRegressor rank=%d fp64, full update_all" % K,
+            "rows": N, "nnz": nnz, "features": D, "users": a.users, "items": a.items, "rank": K, "groups": 2,
+            "parallelism": "1 GPU" if world == 1 else "%d independent shard-chains (replicas), no data-path collective" % world,
+            "alg_bytes_per_iteration": B_iter,
+            "setup_s": round(t_setup, 2), "datagen_s": round(t_data, 2),
+        },
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    if cpu:
+        out["speedup_vs_cpu_baseline"] = round((a.steps / elapsed) / cpu["value"], 1)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,3 +113,39 @@ def onehot_mf(n_rows, n_users, n_items, rank_true=8, seed=0, sort_by_user=True, 
 
 def group_index_from_shapes(shapes):
     return np.concatenate([np.full(s, g, dtype=np.int32) for g, s in enumerate(shapes)])
+
+
+def movielens_like(n_rows, n_users, n_items, rank_true=32, seed=1, noise=0.8, user_offset=700.0, item_offset=40.0):
+    """ML-10M-shaped two-field one-hot design (BASELINE config 3 / SURVEY 8d).
+
+    Popularity follows p(rank r) ~ 1 / (r + offset): with the defaults and 10 M rows the most active
+    user has ~3 k ratings and the least ~30 (ML-10M: 20 .. 7 359, mean 143), the most popular item
+    ~45 k and the median item ~330 (ML-10M: max 34 864). Rows are sorted by user like the MovieLens
+    files. Targets: rank-`rank_true` truth + noise on the half-star grid.
+    """
+    rng = np.random.default_rng(seed)
+    pu = 1.0 / (np.arange(1, n_users + 1) + user_offset)
+    pi = 1.0 / (np.arange(1, n_items + 1) + item_offset)
+    u = rng.choice(n_users, size=n_rows, p=pu / pu.sum()).astype(np.int32)
+    i = rng.choice(n_items, size=n_rows, p=pi / pi.sum()).astype(np.int32)
+    u = rng.permutation(n_users).astype(np.int32)[u]
+    i = rng.permutation(n_items).astype(np.int32)[i]
+    order = np.argsort(u, kind="stable")
+    u, i = u[order], i[order]
+    bu = rng.normal(size=n_users) * 0.4
+    bi = rng.normal(size=n_items) * 0.4
+    U = rng.normal(size=(n_users, rank_true)) * (0.6 / np.sqrt(rank_true))
+    It = rng.normal(size=(n_items, rank_true)) * (0.6 / np.sqrt(rank_true)) * np.sqrt(rank_true)
+    y = np.empty(n_rows)
+    step = 2_000_000
+    for s in range(0, n_rows, step):
+        e = min(n_rows, s + step)
+        y[s:e] = 3.5 + bu[u[s:e]] + bi[i[s:e]] + np.einsum("ij,ij->i", U[u[s:e]], It[i[s:e]])
+    y += rng.normal(size=n_rows) * noise
+    y = np.clip(np.round(y * 2) / 2, 0.5, 5.0)
+    indptr = np.arange(0, 2 * n_rows + 1, 2, dtype=np.int64)
+    indices = np.empty(2 * n_rows, dtype=np.int32)
+    indices[0::2] = u
+    indices[1::2] = n_users + i
+    X = sps.csr_matrix((np.ones(2 * n_rows), indices, indptr), shape=(n_rows, n_users + n_items))
+    return X, y, [n_users, n_items]
