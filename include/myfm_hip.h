@@ -100,7 +100,8 @@ int mfm_group_stats_w(mfm_ctx *ctx, const double *mu_w, double *sum, double *ssd
 int mfm_group_stats_V(mfm_ctx *ctx, const double *mu_V, double *sum, double *ssd);
 /* update_w (FMTrainer.hpp:231-314): main table then relation blocks, feature order preserved
  * for every pair of features that share a row. z[D] = the N(0,1) variates of the D
- * sample_normal calls in reference order (main columns, then each block's columns).          */
+ * sample_normal calls in reference order (main columns, then each block's columns); z == NULL uses the
+ * device-generated variates of the set acquired by mfm_rng_acquire.                          */
 int mfm_sweep_w(mfm_ctx *ctx, double alpha, const double *lambda_w, const double *mu_w, const double *z);
 /* update_V (FMTrainer.hpp:316-486) for factors [f_begin, f_end): per factor the q-cache build
  * (:320-340), the main-table sweep (:343-376) and the per-block sweeps (:378-482).
@@ -127,6 +128,37 @@ int mfm_oprobit_add_group(mfm_ctx *ctx, int32_t n_class, const int64_t *rows, in
 int mfm_oprobit_eval(mfm_ctx *ctx, int32_t group, const double *gamma, double *ll, double *dgamma, double *H);
 /* sample_z_given_cutpoint (OProbitSampler.hpp:238-272): e_t -= z_t, Philox-keyed as above.  */
 int mfm_oprobit_sample_z(mfm_ctx *ctx, int32_t group, const double *gamma, uint64_t seed, uint64_t draw_index);
+
+/* ---- device-side random stream (bit-compatible with the reference's std::mt19937 + libstdc++
+ * distributions, see csrc/mfm_rng.hpp) ----------------------------------------------------------
+ * For regression / classification the engine outputs consumed per Gibbs iteration do not depend on
+ * the model state, so the iteration's variates are produced on the GPU ahead of the sweeps:
+ *   - mfm_rng_seed_mt19937: hand over the generator (the 624 state words and the position index of
+ *     a std::mt19937, e.g. after FM::initialize_weight consumed its share, FM.hpp:34-45);
+ *   - mfm_rng_set_program: the draw order of one iteration as a list of ops (SURVEY 8a "RNG draw
+ *     order"): NORMALS(count) = that many `sample_normal` variates (FMTrainer.hpp:122-125: a fresh
+ *     normal_distribution per draw), GAMMA(shape) = the unit-scale variate of
+ *     gamma_distribution(shape, scale) (FMTrainer.hpp:142-143, :164-165; multiply by scale);
+ *     dest 0 = "hyper" variates returned to the host in program order, 1 = z of mfm_sweep_w (D),
+ *     2 = z of mfm_sweep_V (K * D, factor-major);
+ *   - mfm_rng_prefetch: start producing the NEXT iteration's variates on a side stream;
+ *   - mfm_rng_acquire: wait for the oldest prefetched set, copy its hyper variates to the host and
+ *     make its z buffers the ones mfm_sweep_w / mfm_sweep_V use when called with z == NULL.      */
+#define MFM_RNG_NORMALS 0
+#define MFM_RNG_GAMMA 1
+typedef struct mfm_rng_op {
+  int32_t kind;   /* MFM_RNG_NORMALS | MFM_RNG_GAMMA                       */
+  int32_t dest;   /* 0 hyper variates, 1 z_w, 2 z_V                        */
+  int64_t count;  /* NORMALS: number of draws; GAMMA: 1                    */
+  int64_t offset; /* first index in the destination                        */
+  double shape;   /* GAMMA: alpha                                          */
+} mfm_rng_op;
+int mfm_rng_seed_mt19937(mfm_ctx *ctx, const uint32_t *state624, int32_t position);
+int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops);
+int mfm_rng_prefetch(mfm_ctx *ctx);
+int mfm_rng_acquire(mfm_ctx *ctx, double *hyper_variates, int64_t n_hyper_variates);
+/* test hook: the z buffers of the acquired set (zw[D], zv[K*D]); either pointer may be NULL. */
+int mfm_rng_get_z(mfm_ctx *ctx, double *zw, double *zv);
 
 /* ---- per-kernel timing (HIP events on the ctx stream) for bench.py's roofline block ---- */
 int mfm_timing_enable(mfm_ctx *ctx, int on);

@@ -26,7 +26,8 @@ SYMBOLS = [
     "mfm_oprobit_add_group", "mfm_oprobit_eval", "mfm_oprobit_sample_z", "mfm_timing_enable", "mfm_timing_reset",
     "mfm_timing_n_classes", "mfm_timing_class_name", "mfm_timing_get", "mfm_design_create", "mfm_design_add_block",
     "mfm_design_destroy", "mfm_design_last_error", "mfm_design_dim_all", "mfm_design_predict",
-    "mfm_host_column_levels",
+    "mfm_host_column_levels", "mfm_rng_seed_mt19937", "mfm_rng_set_program", "mfm_rng_prefetch", "mfm_rng_acquire",
+    "mfm_rng_get_z",
 ]
 
 _lib = None
@@ -94,6 +95,11 @@ def lib():
     L.mfm_design_dim_all.argtypes = [vp]
     L.mfm_design_predict.argtypes = [vp, i32, i32, P, P, P, i32, i32, P, P]
     L.mfm_host_column_levels.argtypes = [i64, i64, P, P, P, C.POINTER(i32)]
+    L.mfm_rng_seed_mt19937.argtypes = [vp, P, i32]
+    L.mfm_rng_set_program.argtypes = [vp, P, i32]
+    L.mfm_rng_prefetch.argtypes = [vp]
+    L.mfm_rng_acquire.argtypes = [vp, P, i64]
+    L.mfm_rng_get_z.argtypes = [vp, P, P]
     _lib = L
     return L
 
@@ -233,15 +239,18 @@ class Context:
         return s.T.copy(), ss.T.copy()
 
     def sweep_w(self, alpha, lambda_w, mu_w, z):
-        lambda_w, mu_w, z = _f64(lambda_w), _f64(mu_w), _f64(z)
-        assert z.shape[0] == self.D
+        lambda_w, mu_w = _f64(lambda_w), _f64(mu_w)
+        if z is not None:
+            z = _f64(z)
+            assert z.shape[0] == self.D
         self._ck(lib().mfm_sweep_w(self.h, float(alpha), _p(lambda_w), _p(mu_w), _p(z)))
 
     def sweep_V(self, f_begin, f_end, alpha, lambda_V, mu_V, z):
         """lambda_V, mu_V: (G, K); z: ((f_end - f_begin), D)"""
         lam, mu = _f64(np.asarray(lambda_V).T), _f64(np.asarray(mu_V).T)
-        z = _f64(z)
-        assert z.size == (f_end - f_begin) * self.D
+        if z is not None:
+            z = _f64(z)
+            assert z.size == (f_end - f_begin) * self.D
         self._ck(lib().mfm_sweep_V(self.h, f_begin, f_end, float(alpha), _p(lam), _p(mu), _p(z)))
 
     def update_e_regression(self):
@@ -277,6 +286,33 @@ class Context:
 
     def synchronize(self):
         self._ck(lib().mfm_synchronize(self.h))
+
+    # --- device random stream
+    RNG_OP = np.dtype([("kind", np.int32), ("dest", np.int32), ("count", np.int64), ("offset", np.int64), ("shape", np.float64)])
+
+    def rng_seed_mt19937(self, state624, position):
+        st = np.ascontiguousarray(state624, dtype=np.uint32)
+        assert st.shape[0] == 624
+        self._ck(lib().mfm_rng_seed_mt19937(self.h, _p(st), int(position)))
+
+    def rng_set_program(self, ops):
+        """ops: list of (kind, dest, count, offset, shape)"""
+        arr = np.array([tuple(o) for o in ops], dtype=self.RNG_OP)
+        self._n_hv = int(sum(o[2] for o in ops if o[1] == 0))
+        self._ck(lib().mfm_rng_set_program(self.h, _p(arr), len(ops)))
+
+    def rng_prefetch(self):
+        self._ck(lib().mfm_rng_prefetch(self.h))
+
+    def rng_acquire(self):
+        hv = np.empty(max(self._n_hv, 1))
+        self._ck(lib().mfm_rng_acquire(self.h, _p(hv), self._n_hv))
+        return hv[: self._n_hv]
+
+    def rng_get_z(self):
+        zw, zv = np.empty(self.D), np.empty((max(self.K, 1), self.D))
+        self._ck(lib().mfm_rng_get_z(self.h, _p(zw), _p(zv)))
+        return zw, zv[: self.K]
 
     def plan_info(self):
         a, b = C.c_int64(), C.c_int64()

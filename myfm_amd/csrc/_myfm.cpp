@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <functional>
 #include <limits>
 #include <memory>
@@ -695,6 +696,11 @@ struct FMTrainer {
   uint64_t latent_draws = 0;  // Philox draw index of the device-side truncated-normal draws
   int K = -1;
   vector<Real> zbuf;
+  // device-side random stream (include/myfm_hip.h "device-side random stream"): the generator is handed
+  // to the GPU after initialize_weight; the host then only scales the pre-drawn unit variates.
+  bool device_rng = false;
+  vector<Real> hv;
+  size_t hv_pos = 0;
 
   // BaseFMTrainer.hpp:58-105
   FMTrainer(const py::object &Xo, const py::object &relso, const py::object &yo, int random_seed, FMLearningConfig config)
@@ -770,9 +776,55 @@ struct FMTrainer {
   }
 
   // FMTrainer.hpp:122-125: a fresh normal_distribution per draw
-  Real sample_normal(Real quad, Real first) { return (first / quad) + std::normal_distribution<Real>(0, 1)(gen_) / std::sqrt(quad); }
+  Real next_normal() { return device_rng ? hv.at(hv_pos++) : std::normal_distribution<Real>(0, 1)(gen_); }
+  Real sample_normal(Real quad, Real first) { return (first / quad) + next_normal() / std::sqrt(quad); }
+  // gamma_distribution(shape, scale)(gen_): libstdc++ returns (unit variate) * scale
+  Real sample_gamma(Real shape, Real scale) {
+    if (device_rng) return hv.at(hv_pos++) * scale;
+    return std::gamma_distribution<Real>(shape, scale)(gen_);
+  }
   void draw_normals(Real *out, size_t n) {
     for (size_t i = 0; i < n; i++) out[i] = std::normal_distribution<Real>(0, 1)(gen_);
+  }
+
+  // Hands gen_ to the device and registers one iteration's draw order (SURVEY 8a "RNG draw order").
+  // Only where that order is state-independent: regression and probit classification (whose latent
+  // z use their own Philox stream). Ordered probit interleaves host-side Metropolis draws.
+  void start_device_rng(int Kf) {
+    if (cfg.task_type == TaskType::ORDERED || std::getenv("MYFM_AMD_HOST_RNG")) return;
+    std::ostringstream os;
+    os << gen_;
+    std::istringstream is(os.str());
+    vector<uint32_t> st(625);
+    for (auto &v : st) {
+      unsigned long x;
+      is >> x;
+      v = (uint32_t)x;
+    }
+    ck(ctx, mfm_rng_seed_mt19937(ctx, st.data(), (int32_t)st[624]));
+    const size_t G = cfg.n_groups;
+    vector<mfm_rng_op> ops;
+    int64_t n = 0;
+    auto gamma = [&](Real shape) { ops.push_back(mfm_rng_op{MFM_RNG_GAMMA, 0, 1, n++, shape}); };
+    auto normals_hv = [&](int64_t c) {
+      ops.push_back(mfm_rng_op{MFM_RNG_NORMALS, 0, c, n, 0.0});
+      n += c;
+    };
+    if (cfg.task_type == TaskType::REGRESSION) gamma((cfg.alpha_0 + N) / 2);     // update_alpha
+    if (cfg.fit_w0) normals_hv(1);                                              // update_w0
+    for (size_t g = 0; g < G; g++) gamma((cfg.alpha_0 + n_in_group[g]) / 2);     // update_lambda_w
+    normals_hv((int64_t)G);                                                     // update_mu_w
+    if (cfg.fit_linear && dim_all) ops.push_back(mfm_rng_op{MFM_RNG_NORMALS, 1, (int64_t)dim_all, 0, 0.0});  // update_w
+    if (Kf > 0) {
+      for (int f = 0; f < Kf; f++)
+        for (size_t g = 0; g < G; g++) gamma((cfg.alpha_0 + n_in_group[g]) / 2);  // update_lambda_V
+      normals_hv((int64_t)G * Kf);                                                // update_mu_V
+      if (dim_all) ops.push_back(mfm_rng_op{MFM_RNG_NORMALS, 2, (int64_t)dim_all * Kf, 0, 0.0});  // update_V
+    }
+    ck(ctx, mfm_rng_set_program(ctx, ops.data(), (int32_t)ops.size()));
+    hv.assign((size_t)n, 0);
+    ck(ctx, mfm_rng_prefetch(ctx));
+    device_rng = true;
   }
 
   void initialize_hyper(Hyper &hyper) {  // FMTrainer.hpp:89-97
@@ -827,6 +879,11 @@ struct FMTrainer {
   void update_all(FM &fm, Hyper &hyper) {
     const size_t G = cfg.n_groups;
     const int Kf = fm.n_factors;
+    if (device_rng) {
+      ck(ctx, mfm_rng_acquire(ctx, hv.data(), (int64_t)hv.size()));  // this iteration's variates
+      hv_pos = 0;
+      ck(ctx, mfm_rng_prefetch(ctx));  // the next iteration's are produced while this one runs
+    }
     // update_alpha (FMTrainer.hpp:127-145) + update_w0 (:218-229) share one pass over e
     Real sum_e = 0, sum_e2 = 0;
     const bool need_alpha = cfg.task_type == TaskType::REGRESSION;
@@ -834,7 +891,7 @@ struct FMTrainer {
     if (need_alpha) {
       Real exponent = (cfg.alpha_0 + N) / 2;
       Real variance = (cfg.beta_0 + sum_e2) / 2;
-      hyper.alpha = std::gamma_distribution<Real>(exponent, 1 / variance)(gen_);
+      hyper.alpha = sample_gamma(exponent, 1 / variance);
     } else {
       hyper.alpha = 1;
     }
@@ -854,7 +911,7 @@ struct FMTrainer {
     for (size_t g = 0; g < G; g++) {
       Real alpha = cfg.alpha_0 + n_in_group[g];
       Real beta = cfg.beta_0 + ssd[g];
-      hyper.lambda_w[g] = std::gamma_distribution<Real>(alpha / 2, 2 / beta)(gen_);
+      hyper.lambda_w[g] = sample_gamma(alpha / 2, 2 / beta);
     }
     for (size_t g = 0; g < G; g++) {
       Real square = hyper.lambda_w[g] * (cfg.gamma_0 + n_in_group[g]);
@@ -866,9 +923,13 @@ struct FMTrainer {
     if (!cfg.fit_linear) {
       ck(ctx, mfm_zero_w(ctx));
     } else {
-      zbuf.resize(std::max<size_t>(dim_all, 1));
-      draw_normals(zbuf.data(), dim_all);
-      ck(ctx, mfm_sweep_w(ctx, hyper.alpha, hyper.lambda_w.data(), hyper.mu_w.data(), zbuf.data()));
+      if (device_rng && dim_all) {
+        ck(ctx, mfm_sweep_w(ctx, hyper.alpha, hyper.lambda_w.data(), hyper.mu_w.data(), nullptr));
+      } else {
+        zbuf.resize(std::max<size_t>(dim_all, 1));
+        draw_normals(zbuf.data(), dim_all);
+        ck(ctx, mfm_sweep_w(ctx, hyper.alpha, hyper.lambda_w.data(), hyper.mu_w.data(), zbuf.data()));
+      }
     }
     if (Kf > 0) {
       // update_lambda_V / update_mu_V (:202-216): factor outer, group inner
@@ -877,7 +938,7 @@ struct FMTrainer {
         for (size_t g = 0; g < G; g++) {
           Real alpha = cfg.alpha_0 + n_in_group[g];
           Real beta = cfg.beta_0 + ssd[(size_t)f * G + g];
-          hyper.lambda_V[(size_t)f * G + g] = std::gamma_distribution<Real>(alpha / 2, 2 / beta)(gen_);
+          hyper.lambda_V[(size_t)f * G + g] = sample_gamma(alpha / 2, 2 / beta);
         }
       for (int f = 0; f < Kf; f++)
         for (size_t g = 0; g < G; g++) {
@@ -888,9 +949,13 @@ struct FMTrainer {
           hyper.mu_V[(size_t)f * G + g] = sample_normal(square, linear);
         }
       // update_V (:316-486)
-      zbuf.resize(dim_all * (size_t)Kf);
-      draw_normals(zbuf.data(), dim_all * (size_t)Kf);
-      ck(ctx, mfm_sweep_V(ctx, 0, Kf, hyper.alpha, hyper.lambda_V.data(), hyper.mu_V.data(), zbuf.data()));
+      if (device_rng && dim_all) {
+        ck(ctx, mfm_sweep_V(ctx, 0, Kf, hyper.alpha, hyper.lambda_V.data(), hyper.mu_V.data(), nullptr));
+      } else {
+        zbuf.resize(dim_all * (size_t)Kf);
+        draw_normals(zbuf.data(), dim_all * (size_t)Kf);
+        ck(ctx, mfm_sweep_V(ctx, 0, Kf, hyper.alpha, hyper.lambda_V.data(), hyper.mu_V.data(), zbuf.data()));
+      }
     }
     // update_e (:493-522)
     if (cfg.task_type == TaskType::REGRESSION) {
@@ -917,6 +982,7 @@ struct FMTrainer {
     upload(fm);
     initialize_hyper(hyper);
     initialize_e(fm);
+    start_device_rng(fm.n_factors);
     fm.fetch = [this](FM &f) { this->download(f); };
     result.first.samples.reserve((size_t)cfg.n_kept_samples);
     for (int it = 0; it < cfg.n_iter; it++) {
@@ -965,6 +1031,7 @@ struct GibbsSession {
     trainer->upload(fm);
     trainer->initialize_hyper(hyper);
     trainer->initialize_e(fm);
+    trainer->start_device_rng(fm.n_factors);
     fm.fetch = [this](FM &f) { this->trainer->download(f); };
   }
   void step() {

@@ -14,6 +14,7 @@
 #include "mfm_kernels.hpp"
 #include "mfm_plan.hpp"
 #include "mfm_block_kernels.hpp"
+#include "mfm_rng.hpp"
 
 namespace mfm {
 static thread_local std::string g_global_error;
@@ -67,6 +68,34 @@ struct mfm_ctx {
   double2 *h_red = nullptr;  // pinned readback
   size_t h_red_cap = 0;
   Timing timing;
+
+  // device-side random stream (mfm_rng.hpp)
+  struct RngEngine {
+    bool seeded = false, programmed = false;
+    hipStream_t stream = nullptr;
+    DevBuf<RngState> state;
+    DevBuf<uint32_t> raw;
+    uint64_t mask = 0, need = 0;
+    DevBuf<RngOp> ops;
+    int n_ops = 0;
+    int64_t n_hv = 0, n_zw = 0, n_zv = 0;
+    struct Slot {
+      DevBuf<double> hv, zw, zv;
+      double *h_hv = nullptr;  // pinned: [n_hv] variates + RngState header (3 x 8 bytes)
+      hipEvent_t ready = nullptr, free_ev = nullptr;
+      bool free_valid = false;
+    } slot[2];
+    int64_t produced = 0, acquired = 0;
+    int current = -1;
+    ~RngEngine() {
+      for (auto &sl : slot) {
+        if (sl.h_hv) (void)hipHostFree(sl.h_hv);
+        if (sl.ready) (void)hipEventDestroy(sl.ready);
+        if (sl.free_ev) (void)hipEventDestroy(sl.free_ev);
+      }
+      if (stream) (void)hipStreamDestroy(stream);
+    }
+  } rng;
 
   // ordered probit groups
   struct OGroup {
@@ -557,12 +586,19 @@ int mfm_sweep_w(mfm_ctx *ctx, double alpha, const double *lambda_w, const double
   hipStream_t s = c->stream;
   c->ring.upload(c->lam.p, lambda_w, (size_t)c->G * sizeof(double), s);
   c->ring.upload(c->mu.p, mu_w, (size_t)c->G * sizeof(double), s);
-  c->ring.upload(c->z.p, z, (size_t)c->D * sizeof(double), s);
-  SweepArgs a = main_args(c, c->w.p, c->z.p, c->lam.p, c->mu.p, alpha);
+  const double *zdev = c->z.p;
+  if (z) {
+    c->ring.upload(c->z.p, z, (size_t)c->D * sizeof(double), s);
+  } else {
+    if (c->rng.current < 0 || c->rng.n_zw != c->D)
+      throw Error(MFM_ERR_RUNTIME, "mfm_sweep_w(z = NULL) needs an acquired device random set with D z_w variates");
+    zdev = c->rng.slot[c->rng.current].zw.p;
+  }
+  SweepArgs a = main_args(c, c->w.p, zdev, c->lam.p, c->mu.p, alpha);
   run_plan<PMainW>(s, c->timing, c->plan_W, a, c->ls, KC_SWEEP_W_WAVE, KC_SWEEP_W_WG, KC_SWEEP_W_LSTATS, KC_SWEEP_W_LDRAW,
                    KC_SWEEP_W_LAPPLY, KC_SWEEP_W_CHAIN);
   for (auto &B : c->blocks)
-    block_sweep_w(s, c->timing, c->ls, *B, c->N, c->eq.p, c->w.p, c->z.p, c->group.p, c->lam.p, c->mu.p, alpha);
+    block_sweep_w(s, c->timing, c->ls, *B, c->N, c->eq.p, c->w.p, zdev, c->group.p, c->lam.p, c->mu.p, alpha);
   MFM_CATCH(ctx)
 }
 
@@ -576,10 +612,17 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
   hipStream_t s = c->stream;
   c->ring.upload(c->lam.p, lambda_V, (size_t)c->G * c->K * sizeof(double), s);
   c->ring.upload(c->mu.p, mu_V, (size_t)c->G * c->K * sizeof(double), s);
-  c->ring.upload(c->z.p, z, (size_t)c->D * (f_end - f_begin) * sizeof(double), s);
+  const double *zbase = c->z.p;
+  if (z) {
+    c->ring.upload(c->z.p, z, (size_t)c->D * (f_end - f_begin) * sizeof(double), s);
+  } else {
+    if (c->rng.current < 0 || c->rng.n_zv != c->D * (int64_t)c->K)
+      throw Error(MFM_ERR_RUNTIME, "mfm_sweep_V(z = NULL) needs an acquired device random set with K*D z_V variates");
+    zbase = c->rng.slot[c->rng.current].zv.p + (size_t)f_begin * c->D;
+  }
   for (int f = f_begin; f < f_end; f++) {
     double *Vf = c->V.p + (size_t)f * c->D;
-    const double *zf = c->z.p + (size_t)(f - f_begin) * c->D;
+    const double *zf = zbase + (size_t)(f - f_begin) * c->D;
     const double *lamf = c->lam.p + (size_t)f * c->G;
     const double *muf = c->mu.p + (size_t)f * c->G;
     for (auto &B : c->blocks) block_rowcache(s, c->timing, *B, Vf + B->col_off, true);  // :331-333, :388-393
@@ -604,6 +647,135 @@ int mfm_score_train(mfm_ctx *ctx) {
   MFM_TRY(ctx)
   ctx->need_final();
   score_train(ctx, false);
+  MFM_CATCH(ctx)
+}
+
+// ---- device random stream ---------------------------------------------------------------------------
+int mfm_rng_seed_mt19937(mfm_ctx *ctx, const uint32_t *state624, int32_t position) {
+  MFM_TRY(ctx)
+  auto &r = ctx->rng;
+  if (position < 0 || position > MT_N) throw Error(MFM_ERR_INVALID, "mt19937 position out of range");
+  if (!r.stream) MFM_HIP_CHECK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+  MFM_HIP_CHECK(hipStreamSynchronize(r.stream));
+  RngState h;
+  std::memset(&h, 0, sizeof(h));
+  h.mt_pos = position;
+  std::memcpy(h.mt, state624, sizeof(uint32_t) * MT_N);
+  r.state.alloc(1);
+  MFM_HIP_CHECK(hipMemcpy(r.state.p, &h, sizeof(h), hipMemcpyHostToDevice));
+  r.seeded = true;
+  r.produced = r.acquired = 0;
+  r.current = -1;
+  for (auto &sl : r.slot) sl.free_valid = false;
+  MFM_CATCH(ctx)
+}
+
+int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops) {
+  MFM_TRY(ctx)
+  auto &r = ctx->rng;
+  if (!r.seeded) throw Error(MFM_ERR_RUNTIME, "mfm_rng_seed_mt19937 has not been called");
+  if (r.produced != r.acquired) throw Error(MFM_ERR_RUNTIME, "cannot change the draw program while a set is in flight");
+  MFM_HIP_CHECK(hipStreamSynchronize(r.stream));
+  std::vector<RngOp> h((size_t)n_ops);
+  int64_t n_dest[3] = {0, 0, 0};
+  double normals = 0, gammas = 0;
+  int n_normal_ops = 0;
+  for (int i = 0; i < n_ops; i++) {
+    const mfm_rng_op &o = ops[i];
+    if (o.kind != MFM_RNG_NORMALS && o.kind != MFM_RNG_GAMMA) throw Error(MFM_ERR_INVALID, "bad rng op kind");
+    if (o.dest < 0 || o.dest > 2 || o.count < 0 || o.offset < 0) throw Error(MFM_ERR_INVALID, "bad rng op");
+    if (o.kind == MFM_RNG_GAMMA && !(o.shape > 0)) throw Error(MFM_ERR_INVALID, "gamma shape must be positive");
+    h[i].kind = o.kind;
+    h[i].dest = o.dest;
+    h[i].count = o.kind == MFM_RNG_GAMMA ? 1 : o.count;
+    h[i].offset = o.offset;
+    h[i].shape = o.shape;
+    n_dest[o.dest] = std::max(n_dest[o.dest], o.offset + h[i].count);
+    if (o.kind == MFM_RNG_GAMMA)
+      gammas += 1;
+    else {
+      normals += (double)o.count;
+      n_normal_ops++;
+    }
+  }
+  r.n_hv = n_dest[0];
+  r.n_zw = n_dest[1];
+  r.n_zv = n_dest[2];
+  r.ops.upload(h);
+  r.n_ops = n_ops;
+  // engine outputs one iteration can consume: 4 per polar attempt, 4/pi attempts per normal on average
+  // (+2 % and a 6-sigma allowance), a batch of look-ahead per NORMALS op, 4096 per gamma draw.
+  const double per_normal = 4.0 * 4.0 / 3.14159265358979;
+  r.need = (uint64_t)(normals * per_normal * 1.02 + 6.0 * 2.4 * std::sqrt(normals + 1.0) + gammas * 4096.0 +
+                      4.0 * RNG_ATT * RNG_CONSUME_THREADS * (n_normal_ops + 1) + 65536.0);
+  uint64_t cap = 1;
+  while (cap < r.need + 2 * MT_N) cap <<= 1;
+  r.raw.alloc((size_t)cap);
+  r.mask = cap - 1;
+  for (auto &sl : r.slot) {
+    sl.hv.alloc((size_t)std::max<int64_t>(r.n_hv, 1));
+    sl.zw.alloc((size_t)std::max<int64_t>(r.n_zw, 1));
+    sl.zv.alloc((size_t)std::max<int64_t>(r.n_zv, 1));
+    if (sl.h_hv) MFM_HIP_CHECK(hipHostFree(sl.h_hv));
+    sl.h_hv = nullptr;
+    MFM_HIP_CHECK(hipHostMalloc((void **)&sl.h_hv, ((size_t)r.n_hv + 4) * sizeof(double), hipHostMallocDefault));
+    if (!sl.ready) MFM_HIP_CHECK(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+    if (!sl.free_ev) MFM_HIP_CHECK(hipEventCreateWithFlags(&sl.free_ev, hipEventDisableTiming));
+    sl.free_valid = false;
+  }
+  r.programmed = true;
+  MFM_CATCH(ctx)
+}
+
+int mfm_rng_prefetch(mfm_ctx *ctx) {
+  MFM_TRY(ctx)
+  auto &r = ctx->rng;
+  if (!r.programmed) throw Error(MFM_ERR_RUNTIME, "mfm_rng_set_program has not been called");
+  if (r.produced - r.acquired >= 2) throw Error(MFM_ERR_RUNTIME, "both random sets are in flight: acquire one first");
+  auto &sl = r.slot[r.produced % 2];
+  hipStream_t s = r.stream;
+  if (sl.free_valid) MFM_HIP_CHECK(hipStreamWaitEvent(s, sl.free_ev, 0));
+  hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(64), 0, s, r.state.p, r.raw.p, r.mask, r.need);
+  hipLaunchKernelGGL(k_rng_consume, dim3(1), dim3(RNG_CONSUME_THREADS), 0, s, r.state.p, r.raw.p, r.mask, r.ops.p, r.n_ops,
+                     sl.hv.p, sl.zw.p, sl.zv.p);
+  MFM_HIP_CHECK(hipGetLastError());
+  if (r.n_hv)
+    MFM_HIP_CHECK(hipMemcpyAsync(sl.h_hv, sl.hv.p, (size_t)r.n_hv * sizeof(double), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipMemcpyAsync(sl.h_hv + r.n_hv, r.state.p, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipEventRecord(sl.ready, s));
+  r.produced++;
+  MFM_CATCH(ctx)
+}
+
+int mfm_rng_acquire(mfm_ctx *ctx, double *hyper_variates, int64_t n_hyper_variates) {
+  MFM_TRY(ctx)
+  auto &r = ctx->rng;
+  if (r.produced <= r.acquired) throw Error(MFM_ERR_RUNTIME, "no prefetched random set: call mfm_rng_prefetch first");
+  if (n_hyper_variates != r.n_hv) throw Error(MFM_ERR_INVALID, "hyper variate count does not match the draw program");
+  // everything that used the previously acquired set has been enqueued on the main stream by now
+  if (r.current >= 0) {
+    auto &prev = r.slot[r.current];
+    MFM_HIP_CHECK(hipEventRecord(prev.free_ev, ctx->stream));
+    prev.free_valid = true;
+  }
+  auto &sl = r.slot[r.acquired % 2];
+  MFM_HIP_CHECK(hipEventSynchronize(sl.ready));
+  RngState hdr;
+  std::memcpy(&hdr, sl.h_hv + r.n_hv, 3 * sizeof(double));
+  if (hdr.error) throw Error(MFM_ERR_RUNTIME, "device random stream underflow (generated range exhausted)");
+  if (r.n_hv) std::memcpy(hyper_variates, sl.h_hv, (size_t)r.n_hv * sizeof(double));
+  r.current = (int)(r.acquired % 2);
+  r.acquired++;
+  MFM_CATCH(ctx)
+}
+
+int mfm_rng_get_z(mfm_ctx *ctx, double *zw, double *zv) {
+  MFM_TRY(ctx)
+  auto &r = ctx->rng;
+  if (r.current < 0) throw Error(MFM_ERR_RUNTIME, "no acquired random set");
+  auto &sl = r.slot[r.current];
+  if (zw && r.n_zw) MFM_HIP_CHECK(hipMemcpy(zw, sl.zw.p, (size_t)r.n_zw * sizeof(double), hipMemcpyDeviceToHost));
+  if (zv && r.n_zv) MFM_HIP_CHECK(hipMemcpy(zv, sl.zv.p, (size_t)r.n_zv * sizeof(double), hipMemcpyDeviceToHost));
   MFM_CATCH(ctx)
 }
 

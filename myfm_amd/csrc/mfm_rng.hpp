@@ -1,0 +1,255 @@
+// mfm_rng.hpp -- device-side reproduction of the reference's random stream.
+//
+// The reference draws every variate of the Gibbs iteration from ONE std::mt19937 through libstdc++
+// distribution objects (BaseFMTrainer.hpp:193; FMTrainer.hpp:122-125, :142-143, :164-165). For the
+// regression / probit-classification sweeps the sequence of engine outputs consumed per iteration
+// does not depend on the model state, so the whole stream can be produced ahead of the
+// sweeps. Drawing it on the host costs ~140 ms per iteration at the ML-10M shape (2.7 M normals);
+// here it is produced on the GPU, on a side stream, bit-compatible with libstdc++:
+//   k_mt_generate : the MT19937 recurrence + tempering (one wavefront, state in LDS) -> ring of raw
+//                   32-bit outputs in HBM;
+//   k_rng_consume : runs the iteration's "draw program" over that ring:
+//                   NORMALS(n) = n x `normal_distribution<double>(0,1)(gen)` with a FRESH distribution
+//                                each (Marsaglia polar, /usr/include/c++/11/bits/random.tcc:1802-1835:
+//                                attempts of 4 outputs, returns y*mult, discards x*mult) -- evaluated
+//                                1024 x 4 attempts at a time with a block-wide prefix sum over the
+//                                accept flags to keep the sequential semantics;
+//                   GAMMA(a)   = the unit-scale variate of `gamma_distribution<double>(a, b)(gen)`
+//                                (Marsaglia-Tsang, random.tcc:2337-2392); the caller multiplies by b.
+// generate_canonical<double,53> (random.tcc:3348-3380) takes two outputs per uniform, low word first.
+// The accept/reject decisions use only +,* and are exact; log() may differ from glibc's in the last
+// ulp, so a variate can differ from the host's by 1 ulp (tests/test_gpu_rng.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mfm {
+
+constexpr int MT_N = 624, MT_M = 397;
+constexpr int RNG_CONSUME_THREADS = 1024;
+constexpr int RNG_ATT = 4;  // attempts per thread per batch
+
+struct RngOp {
+  int32_t kind;   // 0 = NORMALS, 1 = GAMMA
+  int32_t dest;   // 0 = hyper variates, 1 = z_w, 2 = z_V
+  int64_t count;  // NORMALS: number of draws (GAMMA: 1)
+  int64_t offset; // first destination index
+  double shape;   // GAMMA: alpha
+};
+
+struct RngState {
+  uint64_t p_gen;   // absolute index of the next output to generate
+  uint64_t p_cons;  // absolute index of the next output to consume
+  int32_t error;    // 1: the consumer ran past the generated range
+  int32_t mt_pos;   // libstdc++ _M_p
+  uint32_t mt[MT_N];
+};
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+__device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// One wavefront. LDS operations of a wave execute in order, and inside one loop trip every lane
+// reads before any lane writes, which is exactly the dependency structure of the recurrence:
+// x[k] <- f(x[k], x[k+1], x[k+397 mod 624]) with the 227-wide independent fronts.
+__global__ __launch_bounds__(64) void k_mt_generate(RngState *__restrict__ st, uint32_t *__restrict__ raw, uint64_t mask,
+                                                    uint64_t need) {
+  __shared__ uint32_t mt[MT_N];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < MT_N; i += 64) mt[i] = st->mt[i];
+  int pos = st->mt_pos;
+  uint64_t p_gen = st->p_gen;
+  const uint64_t target = st->p_cons + need;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  while (p_gen < target) {
+    if (pos >= MT_N) {
+      for (int k = lane; k < MT_N - MT_M; k += 64) {  // k in [0, 227): uses old x[k+397]
+        const uint32_t v = mt_twist(mt[k], mt[k + 1], mt[k + MT_M]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        mt[k] = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      for (int k = MT_N - MT_M + lane; k < MT_N - 1; k += 64) {  // k in [227, 623): uses new x[k-227]
+        const uint32_t v = mt_twist(mt[k], mt[k + 1], mt[k - (MT_N - MT_M)]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        mt[k] = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (lane == 0) mt[MT_N - 1] = mt_twist(mt[MT_N - 1], mt[0], mt[MT_M - 1]);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      pos = 0;
+    }
+    for (int i = pos + lane; i < MT_N; i += 64) raw[(p_gen + (uint64_t)(i - pos)) & mask] = mt_temper(mt[i]);
+    p_gen += (uint64_t)(MT_N - pos);
+    pos = MT_N;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int i = lane; i < MT_N; i += 64) st->mt[i] = mt[i];
+  if (lane == 0) {
+    st->mt_pos = pos;
+    st->p_gen = p_gen;
+  }
+}
+
+// generate_canonical<double, 53>(mt19937): low word first, sum rounded to nearest, / 2^64
+__device__ __forceinline__ double canonical(uint32_t lo, uint32_t hi) {
+  const double sum = (double)lo + (double)hi * 4294967296.0;
+  double ret = sum * (1.0 / 18446744073709551616.0);
+  if (ret >= 1.0) ret = 0.99999999999999988898;  // nextafter(1, 0)
+  return ret;
+}
+
+struct RawReader {
+  const uint32_t *raw;
+  uint64_t mask, p;
+  __device__ __forceinline__ uint32_t next() { return raw[(p++) & mask]; }
+  __device__ __forceinline__ double uniform() {
+    const uint32_t lo = next();
+    const uint32_t hi = next();
+    return canonical(lo, hi);
+  }
+};
+
+// std::normal_distribution<double> object state
+struct NormalDist {
+  bool saved_available = false;
+  double saved = 0.0;
+  __device__ double operator()(RawReader &g) {
+    double ret;
+    if (saved_available) {
+      saved_available = false;
+      ret = saved;
+    } else {
+      double x, y, r2;
+      do {
+        x = 2.0 * g.uniform() - 1.0;
+        y = 2.0 * g.uniform() - 1.0;
+        r2 = x * x + y * y;
+      } while (r2 > 1.0 || r2 == 0.0);
+      const double mult = sqrt(-2 * log(r2) / r2);
+      saved = x * mult;
+      saved_available = true;
+      ret = y * mult;
+    }
+    return ret * 1.0 + 0.0;
+  }
+};
+
+// unit-scale gamma_distribution<double>(alpha, .)(gen): the caller multiplies by beta
+__device__ double gamma_unit(RawReader &g, double alpha) {
+  const double malpha = alpha < 1.0 ? alpha + 1.0 : alpha;
+  const double a1 = malpha - 1.0 / 3.0;
+  const double a2 = 1.0 / sqrt(9.0 * a1);
+  NormalDist nd;
+  double u, v, n;
+  do {
+    do {
+      n = nd(g);
+      v = 1.0 + a2 * n;
+    } while (v <= 0.0);
+    v = v * v * v;
+    u = g.uniform();
+  } while (u > 1.0 - 0.0331 * n * n * n * n && (log(u) > (0.5 * n * n + a1 * (1.0 - v + log(v)))));
+  if (alpha == malpha) return a1 * v;
+  do u = g.uniform();
+  while (u == 0.0);
+  return pow(u, 1.0 / alpha) * a1 * v;
+}
+
+__global__ __launch_bounds__(RNG_CONSUME_THREADS) void k_rng_consume(RngState *__restrict__ st,
+                                                                     const uint32_t *__restrict__ raw, uint64_t mask,
+                                                                     const RngOp *__restrict__ ops, int n_ops,
+                                                                     double *__restrict__ hv, double *__restrict__ zw,
+                                                                     double *__restrict__ zv) {
+  constexpr int NW = RNG_CONSUME_THREADS / 64;
+  __shared__ int s_tot[RNG_ATT][NW];
+  __shared__ unsigned long long s_p;
+  __shared__ int s_kstar;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  uint64_t p = st->p_cons;
+  for (int oi = 0; oi < n_ops; oi++) {
+    const RngOp op = ops[oi];
+    double *dst = (op.dest == 0 ? hv : (op.dest == 1 ? zw : zv)) + op.offset;
+    if (op.kind == 1) {
+      if (tid == 0) {
+        RawReader g{raw, mask, p};
+        dst[0] = gamma_unit(g, op.shape);
+        s_p = g.p;
+      }
+      __syncthreads();
+      p = s_p;
+      __syncthreads();
+      continue;
+    }
+    int64_t done = 0;
+    while (done < op.count) {
+      bool acc[RNG_ATT];
+      double yv[RNG_ATT], r2v[RNG_ATT];
+      unsigned long long bal[RNG_ATT];
+#pragma unroll
+      for (int r = 0; r < RNG_ATT; r++) {
+        const uint64_t base = p + 4ull * (uint64_t)(r * RNG_CONSUME_THREADS + tid);
+        const uint32_t u0 = raw[(base + 0) & mask], u1 = raw[(base + 1) & mask];
+        const uint32_t u2 = raw[(base + 2) & mask], u3 = raw[(base + 3) & mask];
+        const double x = 2.0 * canonical(u0, u1) - 1.0;
+        const double y = 2.0 * canonical(u2, u3) - 1.0;
+        const double r2 = x * x + y * y;
+        acc[r] = !(r2 > 1.0 || r2 == 0.0);
+        yv[r] = y;
+        r2v[r] = r2;
+        bal[r] = __ballot(acc[r]);
+        if (lane == 0) s_tot[r][wid] = __popcll(bal[r]);
+      }
+      __syncthreads();
+      const int64_t needed = op.count - done;
+      int64_t run = 0;  // accepted attempts before slice r
+      int64_t total = 0;
+      int rank[RNG_ATT];
+#pragma unroll
+      for (int r = 0; r < RNG_ATT; r++) {
+        int before = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          const int t = s_tot[r][w];
+          before += (w < wid) ? t : 0;
+          tot += t;
+        }
+        rank[r] = (int)run + before + __popcll(bal[r] & ((1ull << lane) - 1ull));
+        run += tot;
+      }
+      total = run;
+      const bool last_batch = total >= needed;
+#pragma unroll
+      for (int r = 0; r < RNG_ATT; r++) {
+        if (acc[r] && rank[r] < needed) {
+          const double mult = sqrt(-2 * log(r2v[r]) / r2v[r]);
+          dst[done + rank[r]] = (yv[r] * mult) * 1.0 + 0.0;
+          if (last_batch && rank[r] == needed - 1) s_kstar = r * RNG_CONSUME_THREADS + tid;
+        }
+      }
+      __syncthreads();
+      if (last_batch) {
+        p += 4ull * (uint64_t)(s_kstar + 1);
+        done = op.count;
+      } else {
+        p += 4ull * (uint64_t)(RNG_ATT * RNG_CONSUME_THREADS);
+        done += total;
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    st->p_cons = p;
+    if (p > st->p_gen) st->error = 1;
+  }
+}
+
+}  // namespace mfm

@@ -29,6 +29,7 @@
 #include <cstring>
 #include <limits>
 #include <random>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -1296,6 +1297,17 @@ void orc_rng_sample_normals(orc::Trainer *t, int64_t n, double *out) {
 }
 double orc_rng_gamma(orc::Trainer *t, double shape, double scale) { return std::gamma_distribution<double>(shape, scale)(t->gen_); }
 uint32_t orc_rng_raw(orc::Trainer *t) { return t->gen_(); }
+// the generator's 624 state words followed by its position index (libstdc++ operator<< layout)
+void orc_rng_state(const orc::Trainer *t, uint32_t *out625) {
+  std::ostringstream os;
+  os << t->gen_;
+  std::istringstream is(os.str());
+  for (int i = 0; i < 625; i++) {
+    unsigned long v;
+    is >> v;
+    out625[i] = (uint32_t)v;
+  }
+}
 
 void orc_trace_enable(orc::Trainer *t, int on) {
   t->trace_on = on != 0;

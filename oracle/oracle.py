@@ -68,6 +68,7 @@ def lib():
         L.orc_rng_gamma.argtypes = [vp, dbl, dbl]
         L.orc_rng_raw.restype = C.c_uint32
         L.orc_rng_raw.argtypes = [vp]
+        L.orc_rng_state.argtypes = [vp, P]
         L.orc_trace_enable.argtypes = [vp, C.c_int]
         L.orc_trace_size.restype = i64
         L.orc_trace_size.argtypes = [vp]
@@ -259,6 +260,12 @@ class OracleTrainer:
 
     def rng_gamma(self, shape, scale):
         return lib().orc_rng_gamma(self.h, shape, scale)
+
+    def rng_state(self):
+        """(state[624] uint32, position) of the trainer's std::mt19937"""
+        out = np.empty(625, dtype=np.uint32)
+        lib().orc_rng_state(self.h, _p(out))
+        return out[:624].copy(), int(out[624])
 
     def trace_enable(self, on=True):
         lib().orc_trace_enable(self.h, int(on))

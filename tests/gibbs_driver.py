@@ -26,14 +26,59 @@ class CapiGibbs:
         self.mu_V, self.lam_V = np.zeros((G, K)), np.full((G, K), 1e-5)
         self.w0 = ctx.get_state()[0]
 
+    # ---- random variates: host (oracle generator) or the device stream of csrc/mfm_rng.hpp ----
+    def use_device_rng(self, state624, position):
+        """hand the generator to the device and describe one iteration's draw order"""
+        c, G, K, D = self.c, self.G, self.c.K, self.c.D
+        c.rng_seed_mt19937(state624, position)
+        ops, n = [], 0
+        ops.append((1, 0, 1, n, (self.a0 + self.N) / 2)); n += 1
+        if self.fit_w0:
+            ops.append((0, 0, 1, n, 0.0)); n += 1
+        for g in range(G):
+            ops.append((1, 0, 1, n, (self.a0 + self.n_g[g]) / 2)); n += 1
+        ops.append((0, 0, G, n, 0.0)); n += G
+        if self.fit_linear:
+            ops.append((0, 1, D, 0, 0.0))
+        if K:
+            for f in range(K):
+                for g in range(G):
+                    ops.append((1, 0, 1, n, (self.a0 + self.n_g[g]) / 2)); n += 1
+            ops.append((0, 0, K * G, n, 0.0)); n += K * G
+            ops.append((0, 2, K * D, 0, 0.0))
+        c.rng_set_program(ops)
+        c.rng_prefetch()
+        self.dev = True
+        self.hv, self.hvi = None, 0
+
+    def _begin(self):
+        if getattr(self, "dev", False):
+            self.hv, self.hvi = self.c.rng_acquire(), 0
+            self.c.rng_prefetch()
+
+    def _hv(self):
+        v = self.hv[self.hvi]
+        self.hvi += 1
+        return v
+
+    def _gamma(self, shape, scale):
+        if getattr(self, "dev", False):
+            return self._hv() * scale
+        return self.rng.rng_gamma(shape, scale)
+
+    def _z(self, n):
+        return None if getattr(self, "dev", False) else self.rng.rng_sample_normals(n)
+
     def _normal(self, quad, first):
-        return first / quad + self.rng.rng_sample_normals(1)[0] / np.sqrt(quad)
+        z = self._hv() if getattr(self, "dev", False) else self.rng.rng_sample_normals(1)[0]
+        return first / quad + z / np.sqrt(quad)
 
     def step(self):
         c, K, G, D = self.c, self.c.K, self.G, self.c.D
+        self._begin()
         # update_alpha, FMTrainer.hpp:127-145
         se, se2 = c.reduce_e()
-        self.alpha = self.rng.rng_gamma((self.a0 + self.N) / 2, 1.0 / ((self.b0 + se2) / 2))
+        self.alpha = self._gamma((self.a0 + self.N) / 2, 1.0 / ((self.b0 + se2) / 2))
         # update_w0, :218-229
         if self.fit_w0:
             lin = self.alpha * (self.N * self.w0 - se)
@@ -47,14 +92,14 @@ class CapiGibbs:
         # update_lambda_w / update_mu_w, :150-200
         s, ssd = c.group_stats_w(self.mu_w)
         for g in range(G):
-            self.lam_w[g] = self.rng.rng_gamma((self.a0 + self.n_g[g]) / 2, 2.0 / (self.b0 + ssd[g]))
+            self.lam_w[g] = self._gamma((self.a0 + self.n_g[g]) / 2, 2.0 / (self.b0 + ssd[g]))
         for g in range(G):
             sq = self.lam_w[g] * (self.g0 + self.n_g[g])
             lin = (self.g0 * self.m0 + s[g]) * self.lam_w[g]
             self.mu_w[g] = self._normal(sq, lin)
         # update_w, :231-314
         if self.fit_linear:
-            c.sweep_w(self.alpha, self.lam_w, self.mu_w, self.rng.rng_sample_normals(D))
+            c.sweep_w(self.alpha, self.lam_w, self.mu_w, self._z(D))
         else:
             c.zero_w()
         # update_lambda_V / update_mu_V, :202-216 (factor outer, group inner)
@@ -62,14 +107,14 @@ class CapiGibbs:
             s, ssd = c.group_stats_V(self.mu_V)
             for f in range(K):
                 for g in range(G):
-                    self.lam_V[g, f] = self.rng.rng_gamma((self.a0 + self.n_g[g]) / 2, 2.0 / (self.b0 + ssd[g, f]))
+                    self.lam_V[g, f] = self._gamma((self.a0 + self.n_g[g]) / 2, 2.0 / (self.b0 + ssd[g, f]))
             for f in range(K):
                 for g in range(G):
                     sq = self.lam_V[g, f] * (self.g0 + self.n_g[g])
                     lin = (self.g0 * self.m0 + s[g, f]) * self.lam_V[g, f]
                     self.mu_V[g, f] = self._normal(sq, lin)
             # update_V, :316-486
-            c.sweep_V(0, K, self.alpha, self.lam_V, self.mu_V, self.rng.rng_sample_normals(K * D))
+            c.sweep_V(0, K, self.alpha, self.lam_V, self.mu_V, self._z(K * D))
         # update_e, :493-497
         c.update_e_regression()
 
