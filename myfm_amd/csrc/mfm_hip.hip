@@ -87,6 +87,17 @@ struct mfm_ctx {
     } slot[2];
     int64_t produced = 0, acquired = 0;
     int current = -1;
+    // big NORMALS ops run as eval / scan / scatter over the whole GPU
+    std::vector<RngOp> h_ops;
+    DevBuf<double> cand;
+    DevBuf<unsigned long long> masks;
+    DevBuf<int> counts;
+    DevBuf<NormScratch> nscratch;
+    static int64_t attempts_for(int64_t count) {
+      double a = (double)count * (4.0 / 3.14159265358979) * 1.01 + 8.0 * std::sqrt((double)count + 1.0) + 4096.0;
+      int64_t n = (int64_t)a;
+      return (n + NORM_CHUNK - 1) / NORM_CHUNK * NORM_CHUNK;
+    }
     ~RngEngine() {
       for (auto &sl : slot) {
         if (sl.h_hv) (void)hipHostFree(sl.h_hv);
@@ -702,12 +713,25 @@ int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops) {
   r.n_zw = n_dest[1];
   r.n_zv = n_dest[2];
   r.ops.upload(h);
+  r.h_ops = h;
   r.n_ops = n_ops;
+  {
+    int64_t amax = 0;
+    for (auto &o : h)
+      if (o.kind == MFM_RNG_NORMALS && o.count > 16384) amax = std::max(amax, mfm_ctx::RngEngine::attempts_for(o.count));
+    r.cand.alloc((size_t)std::max<int64_t>(amax, 1));
+    r.masks.alloc((size_t)std::max<int64_t>(amax / 64, 1));
+    r.counts.alloc((size_t)std::max<int64_t>(amax / NORM_CHUNK, 1));
+    r.nscratch.alloc(1);
+  }
   // engine outputs one iteration can consume: 4 per polar attempt, 4/pi attempts per normal on average
   // (+2 % and a 6-sigma allowance), a batch of look-ahead per NORMALS op, 4096 per gamma draw.
   const double per_normal = 4.0 * 4.0 / 3.14159265358979;
   r.need = (uint64_t)(normals * per_normal * 1.02 + 6.0 * 2.4 * std::sqrt(normals + 1.0) + gammas * 4096.0 +
                       4.0 * RNG_ATT * RNG_CONSUME_THREADS * (n_normal_ops + 1) + 65536.0);
+  for (auto &o : h)  // the evaluation window of a big op reaches past its last accept
+    if (o.kind == MFM_RNG_NORMALS && o.count > 16384)
+      r.need += (uint64_t)(4 * (mfm_ctx::RngEngine::attempts_for(o.count) - (int64_t)((double)o.count * 1.2732)));
   uint64_t cap = 1;
   while (cap < r.need + 2 * MT_N) cap <<= 1;
   r.raw.alloc((size_t)cap);
@@ -735,9 +759,29 @@ int mfm_rng_prefetch(mfm_ctx *ctx) {
   auto &sl = r.slot[r.produced % 2];
   hipStream_t s = r.stream;
   if (sl.free_valid) MFM_HIP_CHECK(hipStreamWaitEvent(s, sl.free_ev, 0));
-  hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(64), 0, s, r.state.p, r.raw.p, r.mask, r.need);
-  hipLaunchKernelGGL(k_rng_consume, dim3(1), dim3(RNG_CONSUME_THREADS), 0, s, r.state.p, r.raw.p, r.mask, r.ops.p, r.n_ops,
-                     sl.hv.p, sl.zw.p, sl.zv.p);
+  hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(MT_GEN_THREADS), 0, s, r.state.p, r.raw.p, r.mask, r.need);
+  // small ops (hyper draws) run in one sequential workgroup; big NORMALS ops on the whole GPU
+  int i = 0;
+  while (i < r.n_ops) {
+    int j = i;
+    while (j < r.n_ops && !(r.h_ops[j].kind == MFM_RNG_NORMALS && r.h_ops[j].count > 16384)) j++;
+    if (j > i)
+      hipLaunchKernelGGL(k_rng_consume, dim3(1), dim3(RNG_CONSUME_THREADS), 0, s, r.state.p, r.raw.p, r.mask, r.ops.p, i, j,
+                         sl.hv.p, sl.zw.p, sl.zv.p);
+    if (j < r.n_ops) {
+      const RngOp &o = r.h_ops[j];
+      const int64_t A = mfm_ctx::RngEngine::attempts_for(o.count);
+      const int n_chunks = (int)(A / NORM_CHUNK);
+      double *dst = (o.dest == 0 ? sl.hv.p : (o.dest == 1 ? sl.zw.p : sl.zv.p)) + o.offset;
+      hipLaunchKernelGGL(k_norm_eval, dim3(n_chunks), dim3(256), 0, s, r.state.p, r.raw.p, r.mask, r.cand.p, r.masks.p,
+                         r.counts.p);
+      hipLaunchKernelGGL(k_norm_scan, dim3(1), dim3(1024), 0, s, r.state.p, r.counts.p, n_chunks, o.count, r.nscratch.p);
+      hipLaunchKernelGGL(k_norm_scatter, dim3(n_chunks), dim3(256), 0, s, r.state.p, r.cand.p, r.masks.p, r.counts.p, o.count,
+                         r.nscratch.p, dst);
+      j++;
+    }
+    i = j;
+  }
   MFM_HIP_CHECK(hipGetLastError());
   if (r.n_hv)
     MFM_HIP_CHECK(hipMemcpyAsync(sl.h_hv, sl.hv.p, (size_t)r.n_hv * sizeof(double), hipMemcpyDeviceToHost, s));

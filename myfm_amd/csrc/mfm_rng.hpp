@@ -57,43 +57,59 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c)
   return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
 
-// One wavefront. LDS operations of a wave execute in order, and inside one loop trip every lane
-// reads before any lane writes, which is exactly the dependency structure of the recurrence:
-// x[k] <- f(x[k], x[k+1], x[k+397 mod 624]) with the 227-wide independent fronts.
-__global__ __launch_bounds__(64) void k_mt_generate(RngState *__restrict__ st, uint32_t *__restrict__ raw, uint64_t mask,
-                                                    uint64_t need) {
-  __shared__ uint32_t mt[MT_N];
-  const int lane = threadIdx.x;
-  for (int i = lane; i < MT_N; i += 64) mt[i] = st->mt[i];
+// The MT19937 block update in closed form. With x the old 624-word block, x' the new one and
+// G[k] = twist(x[k], x[k+1]) (k <= 622, old words only), the sequential recurrence
+//   x'[k] = x[k+397] ^ G[k] (k < 227),  x'[k] = x'[k-227] ^ G[k] (227 <= k < 623)
+// unrolls to expressions over OLD words only:
+//   k in [0,227)   : x[k+397] ^ G[k]
+//   k in [227,454) : x[k+170] ^ G[k-227] ^ G[k]
+//   k in [454,623) : x[k-57]  ^ G[k-454] ^ G[k-227] ^ G[k]
+//   k = 623        : x'[396] ^ twist(x[623], x'[0]),  x'[396] = x[566]^G[169]^G[396], x'[0] = x[397]^G[0]
+// so a whole block is ONE parallel step (624 threads, double-buffered in LDS, one barrier per block)
+// instead of three dependent 227-wide fronts.
+constexpr int MT_GEN_THREADS = 640;
+__device__ __forceinline__ uint32_t mt_G(const uint32_t *x, int k) { return mt_twist(x[k], x[k + 1], 0u); }
+
+__global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate(RngState *__restrict__ st, uint32_t *__restrict__ raw,
+                                                                uint64_t mask, uint64_t need) {
+  __shared__ uint32_t buf[2][MT_N + 1];
+  const int t = threadIdx.x;
+  if (t < MT_N) buf[0][t] = st->mt[t];
   int pos = st->mt_pos;
   uint64_t p_gen = st->p_gen;
   const uint64_t target = st->p_cons + need;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  while (p_gen < target) {
-    if (pos >= MT_N) {
-      for (int k = lane; k < MT_N - MT_M; k += 64) {  // k in [0, 227): uses old x[k+397]
-        const uint32_t v = mt_twist(mt[k], mt[k + 1], mt[k + MT_M]);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        mt[k] = v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      for (int k = MT_N - MT_M + lane; k < MT_N - 1; k += 64) {  // k in [227, 623): uses new x[k-227]
-        const uint32_t v = mt_twist(mt[k], mt[k + 1], mt[k - (MT_N - MT_M)]);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        mt[k] = v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (lane == 0) mt[MT_N - 1] = mt_twist(mt[MT_N - 1], mt[0], mt[MT_M - 1]);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      pos = 0;
-    }
-    for (int i = pos + lane; i < MT_N; i += 64) raw[(p_gen + (uint64_t)(i - pos)) & mask] = mt_temper(mt[i]);
+  __syncthreads();
+  int cur = 0;
+  if (pos < MT_N && p_gen < target) {  // the not yet emitted tail of the current block
+    if (t >= pos && t < MT_N) raw[(p_gen + (uint64_t)(t - pos)) & mask] = mt_temper(buf[0][t]);
     p_gen += (uint64_t)(MT_N - pos);
     pos = MT_N;
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  for (int i = lane; i < MT_N; i += 64) st->mt[i] = mt[i];
-  if (lane == 0) {
+  while (p_gen < target) {
+    const uint32_t *x = buf[cur];
+    uint32_t *xn = buf[cur ^ 1];
+    if (t < MT_N) {
+      uint32_t v;
+      if (t < 227) {
+        v = x[t + 397] ^ mt_G(x, t);
+      } else if (t < 454) {
+        v = x[t + 170] ^ mt_G(x, t - 227) ^ mt_G(x, t);
+      } else if (t < 623) {
+        v = x[t - 57] ^ mt_G(x, t - 454) ^ mt_G(x, t - 227) ^ mt_G(x, t);
+      } else {
+        const uint32_t x0n = x[397] ^ mt_G(x, 0);
+        const uint32_t x396n = x[566] ^ mt_G(x, 169) ^ mt_G(x, 396);
+        v = mt_twist(x[623], x0n, x396n);
+      }
+      xn[t] = v;
+      raw[(p_gen + (uint64_t)t) & mask] = mt_temper(v);
+    }
+    p_gen += MT_N;
+    cur ^= 1;
+    __syncthreads();
+  }
+  if (t < MT_N) st->mt[t] = buf[cur][t];
+  if (t == 0) {
     st->mt_pos = pos;
     st->p_gen = p_gen;
   }
@@ -166,16 +182,16 @@ __device__ double gamma_unit(RawReader &g, double alpha) {
 
 __global__ __launch_bounds__(RNG_CONSUME_THREADS) void k_rng_consume(RngState *__restrict__ st,
                                                                      const uint32_t *__restrict__ raw, uint64_t mask,
-                                                                     const RngOp *__restrict__ ops, int n_ops,
-                                                                     double *__restrict__ hv, double *__restrict__ zw,
-                                                                     double *__restrict__ zv) {
+                                                                     const RngOp *__restrict__ ops, int op_begin,
+                                                                     int op_end, double *__restrict__ hv,
+                                                                     double *__restrict__ zw, double *__restrict__ zv) {
   constexpr int NW = RNG_CONSUME_THREADS / 64;
   __shared__ int s_tot[RNG_ATT][NW];
   __shared__ unsigned long long s_p;
   __shared__ int s_kstar;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   uint64_t p = st->p_cons;
-  for (int oi = 0; oi < n_ops; oi++) {
+  for (int oi = op_begin; oi < op_end; oi++) {
     const RngOp op = ops[oi];
     double *dst = (op.dest == 0 ? hv : (op.dest == 1 ? zw : zv)) + op.offset;
     if (op.kind == 1) {
@@ -250,6 +266,116 @@ __global__ __launch_bounds__(RNG_CONSUME_THREADS) void k_rng_consume(RngState *_
     st->p_cons = p;
     if (p > st->p_gen) st->error = 1;
   }
+}
+
+
+// ---- big NORMALS ops: evaluate the attempts on the whole GPU, then compact (chunked scan) ------------
+// Attempt a of the op uses outputs [p + 4a, p + 4a + 4); the op's i-th variate is the i-th accepted
+// attempt. k_norm_eval evaluates every attempt of a window that holds >= count accepts (up to a
+// 1e-15 tail, checked), k_norm_scan prefix-sums the per-chunk accept counts, k_norm_scatter places the
+// accepted candidates by rank and moves the stream position just past the count-th accept.
+constexpr int NORM_CHUNK = 1024;  // attempts per workgroup (256 threads x 4)
+
+struct NormScratch {
+  unsigned long long p_base;  // stream position of attempt 0
+  int32_t insufficient;
+  int32_t pad;
+};
+
+__global__ __launch_bounds__(256) void k_norm_eval(const RngState *__restrict__ st, const uint32_t *__restrict__ raw,
+                                                   uint64_t mask, double *__restrict__ cand,
+                                                   unsigned long long *__restrict__ masks, int *__restrict__ counts) {
+  __shared__ int s_cnt[4];
+  const uint64_t p = st->p_cons;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int cnt = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int64_t a = (int64_t)blockIdx.x * NORM_CHUNK + r * 256 + tid;
+    const uint64_t base = p + 4ull * (uint64_t)a;
+    const uint32_t u0 = raw[(base + 0) & mask], u1 = raw[(base + 1) & mask];
+    const uint32_t u2 = raw[(base + 2) & mask], u3 = raw[(base + 3) & mask];
+    const double x = 2.0 * canonical(u0, u1) - 1.0;
+    const double y = 2.0 * canonical(u2, u3) - 1.0;
+    const double r2 = x * x + y * y;
+    const bool acc = !(r2 > 1.0 || r2 == 0.0);
+    if (acc) {
+      const double mult = sqrt(-2 * log(r2) / r2);
+      cand[a] = (y * mult) * 1.0 + 0.0;
+    }
+    const unsigned long long b = __ballot(acc);
+    if (lane == 0) {
+      masks[a >> 6] = b;
+      cnt += __popcll(b);
+    }
+  }
+  if (lane == 0) s_cnt[wid] = cnt;
+  __syncthreads();
+  if (tid == 0) counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// exclusive scan of counts[n_chunks] (in place -> offsets); single workgroup
+__global__ __launch_bounds__(1024) void k_norm_scan(const RngState *__restrict__ st, int *__restrict__ counts, int n_chunks,
+                                                    int64_t count, NormScratch *__restrict__ ns) {
+  __shared__ int s_w[16];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n_chunks; base += 1024) {
+    const int i = base + tid;
+    const int v = i < n_chunks ? counts[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_w[wid] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wid; w++) woff += s_w[w];
+    const int carry = s_carry;
+    if (i < n_chunks) counts[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (tid == 1023) s_carry = carry + woff + incl;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    ns->p_base = st->p_cons;
+    ns->insufficient = (int64_t)s_carry < count ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_norm_scatter(RngState *__restrict__ st, const double *__restrict__ cand,
+                                                      const unsigned long long *__restrict__ masks,
+                                                      const int *__restrict__ offs, int64_t count,
+                                                      const NormScratch *__restrict__ ns, double *__restrict__ dst) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // the 16 ballot words of this chunk, in attempt order: word (r * 4 + wid) covers attempts r*256 + wid*64 ..
+  const unsigned long long *m = masks + (int64_t)blockIdx.x * (NORM_CHUNK / 64);
+  int64_t before = offs[blockIdx.x];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    int wbefore = 0;
+    for (int w = 0; w < 4; w++) {
+      const int c = __popcll(m[r * 4 + w]);
+      if (w < wid) wbefore += c;
+    }
+    const unsigned long long b = m[r * 4 + wid];
+    const bool acc = (b >> lane) & 1ull;
+    const int64_t rank = before + wbefore + __popcll(b & ((1ull << lane) - 1ull));
+    const int64_t a = (int64_t)blockIdx.x * NORM_CHUNK + r * 256 + tid;
+    if (acc && rank < count) {
+      dst[rank] = cand[a];
+      if (rank == count - 1) {
+        st->p_cons = ns->p_base + 4ull * (unsigned long long)(a + 1);
+        if (ns->insufficient) st->error = 1;
+      }
+    }
+    for (int w = 0; w < 4; w++) before += __popcll(m[r * 4 + w]);
+  }
+  if (blockIdx.x == 0 && tid == 0 && ns->insufficient) st->error = 1;
 }
 
 }  // namespace mfm

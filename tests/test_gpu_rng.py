@@ -28,12 +28,14 @@ def _host_program(t, ops):
     return np.concatenate(hv), zw, zv
 
 
-@pytest.mark.parametrize("seed", [42, 7])
-def test_device_stream_matches_libstdcxx(oracle, seed):
+@pytest.mark.parametrize("seed,n_users,K", [(42, 700, 5), (7, 700, 5), (3, 9000, 7)])
+def test_device_stream_matches_libstdcxx(oracle, seed, n_users, K):
+    # (n_users=700, K=5): every op takes the single-workgroup path; (9000, 7): z_V has 63 k variates and
+    # goes through the whole-GPU eval / scan / scatter path, z_w (9 k) stays on the small path
     from myfm_amd import _capi
 
-    X, y, shapes = ds.onehot_mf(3000, 700, 90, seed=1)
-    K, D = 5, X.shape[1]
+    X, y, shapes = ds.onehot_mf(3000, n_users, 90, seed=1)
+    D = X.shape[1]
     t = oracle.OracleTrainer(X, y, rank=K, seed=seed)  # generator state after initialize_weight
     c = _capi.Context(X, y, rank=K)
     st, pos = t.rng_state()
