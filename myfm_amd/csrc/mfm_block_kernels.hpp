@@ -247,8 +247,8 @@ struct DevBlock {
     nnz = hX.nnz();
     HostCsr Xt = transpose_host(hX);
     X.upload(hX, &Xt);
-    plan_V.build(Xt, WAVE * PBlockV::WAVE_R, WG * PBlockV::WG_R);
-    plan_W.build(Xt, WAVE * PBlockW::WAVE_R, WG * PBlockW::WG_R);
+    plan_V.build(Xt, PBlockV::R_W16, PBlockV::R_WG, coop_capacity<PBlockV>());
+    plan_W.build(Xt, PBlockW::R_W16, PBlockW::R_WG, coop_capacity<PBlockW>());
     std::vector<int32_t> m32((size_t)N);
     std::vector<int64_t> iptr((size_t)B + 1, 0);
     for (int64_t t = 0; t < N; t++) {
@@ -368,8 +368,9 @@ static void block_sweep_w(hipStream_t s, Timing &tm, LongScratch &ls, DevBlock &
   block_rowcache(s, tm, B, w + B.col_off, false);  // :265-266
   block_unsync<true>(s, tm, B, N, eq);             // :268-275
   SweepArgs a = block_args(B, w, z, group, lam, mu, alpha);
-  run_plan<PBlockW>(s, tm, B.plan_W, a, ls, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP,
-                    KC_BLOCK_SWEEP);               // :276-302
+  const SweepClasses kc{KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP,
+                        KC_BLOCK_SWEEP};
+  run_plan<PBlockW>(s, tm, B.plan_W, a, ls, kc, false);  // :276-302
   block_rowcache(s, tm, B, w + B.col_off, false);  // :304-305
   block_resync<true>(s, tm, B, N, eq);             // :306-311
 }
@@ -380,8 +381,9 @@ static void block_sweep_V(hipStream_t s, Timing &tm, LongScratch &ls, DevBlock &
                           const double *zf, const int32_t *group, const double *lamf, const double *muf, double alpha) {
   block_unsync<false>(s, tm, B, N, eq);  // :401-417
   SweepArgs a = block_args(B, Vf, zf, group, lamf, muf, alpha);
-  run_plan<PBlockV>(s, tm, B.plan_V, a, ls, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP,
-                    KC_BLOCK_SWEEP);     // :419-470
+  const SweepClasses kc{KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP,
+                        KC_BLOCK_SWEEP};
+  run_plan<PBlockV>(s, tm, B.plan_V, a, ls, kc, false);  // :419-470
   block_resync<false>(s, tm, B, N, eq);  // :473-480
 }
 

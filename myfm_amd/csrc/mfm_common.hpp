@@ -109,14 +109,16 @@ struct PinnedRing {
 // ---- kernel classes for the timing / roofline report --------------------------------------
 enum KernelClass {
   KC_QBUILD = 0,       // q = X v_f (CSR SpMV)                              FMTrainer.hpp:320-340
-  KC_SWEEP_V_WAVE,     // latent sweep, one wavefront per column           FMTrainer.hpp:343-376
-  KC_SWEEP_V_WG,       // latent sweep, one workgroup per column
-  KC_SWEEP_V_LSTATS,   // latent sweep, long columns: partial statistics
+  KC_SWEEP_V_LIGHT,    // latent sweep, columns <= 256 entries (wavefront per column)  FMTrainer.hpp:343-376
+  KC_SWEEP_V_HEAVY,    // latent sweep, columns <= 4096 entries (wavefront x16 / workgroup per column)
+  KC_SWEEP_V_COOP,     // latent sweep, long columns: co-resident chunks, single pass
+  KC_SWEEP_V_LSTATS,   // latent sweep, huge columns: partial statistics
   KC_SWEEP_V_LDRAW,    //   ... draw
   KC_SWEEP_V_LAPPLY,   //   ... apply
   KC_SWEEP_V_CHAIN,    // latent sweep, sequential chain of tiny levels
-  KC_SWEEP_W_WAVE,     // linear sweep                                      FMTrainer.hpp:237-254
-  KC_SWEEP_W_WG,
+  KC_SWEEP_W_LIGHT,    // linear sweep                                      FMTrainer.hpp:237-254
+  KC_SWEEP_W_HEAVY,
+  KC_SWEEP_W_COOP,
   KC_SWEEP_W_LSTATS,
   KC_SWEEP_W_LDRAW,
   KC_SWEEP_W_LAPPLY,
@@ -137,9 +139,10 @@ enum KernelClass {
 };
 
 static const char *const kKernelClassNames[KC_N] = {
-    "qbuild_spmv",        "sweep_V_wave",      "sweep_V_workgroup",  "sweep_V_long_stats", "sweep_V_long_draw",
-    "sweep_V_long_apply", "sweep_V_chain",     "sweep_w_wave",       "sweep_w_workgroup",  "sweep_w_long_stats",
-    "sweep_w_long_draw",  "sweep_w_long_apply", "sweep_w_chain",     "update_e_score",     "build_vt",
+    "qbuild_spmv",        "sweep_V_light",     "sweep_V_heavy",      "sweep_V_coop",       "sweep_V_huge_stats",
+    "sweep_V_huge_draw",  "sweep_V_huge_apply", "sweep_V_chain",     "sweep_w_light",      "sweep_w_heavy",
+    "sweep_w_coop",       "sweep_w_huge_stats", "sweep_w_huge_draw", "sweep_w_huge_apply", "sweep_w_chain",
+    "update_e_score",     "build_vt",
     "reduce_e",           "shift_e",           "group_stats",        "block_rowcache",     "block_unsync",
     "block_resync",       "block_sweep",       "tn_sample",          "oprobit_eval",       "predict"};
 
@@ -290,10 +293,21 @@ struct DevSparse {
   DevBuf<int32_t> rowidx;
   DevBuf<double> cval;
   double avg_row_nnz = 0;
+  bool unit = false;      // every stored value is exactly 1.0 (one-hot designs): kernels skip the val arrays
+  int32_t ell_width = -1; // every row has exactly this many entries (>= 0): kernels skip rowptr
   void upload(const HostCsr &X, const HostCsr *Xt /* may be null: CSR only */) {
     rows = X.rows;
     cols = X.cols;
     nnz = X.nnz();
+    unit = nnz > 0;
+    for (double v : X.val)
+      if (v != 1.0) {
+        unit = false;
+        break;
+      }
+    ell_width = rows > 0 ? (int32_t)(X.ptr[1] - X.ptr[0]) : -1;
+    for (int64_t i = 0; i < rows && ell_width >= 0; i++)
+      if (X.ptr[i + 1] - X.ptr[i] != ell_width) ell_width = -1;
     std::vector<int32_t> rp((size_t)rows + 1);
     for (int64_t i = 0; i <= rows; i++) rp[i] = (int32_t)X.ptr[i];
     rowptr.upload(rp);

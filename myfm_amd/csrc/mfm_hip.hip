@@ -407,8 +407,8 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   {
     HostCsr Xt = transpose_host(c->hX);
     c->X.upload(c->hX, &Xt);
-    c->plan_V.build(Xt, WAVE * PMainV::WAVE_R, WG * PMainV::WG_R);
-    c->plan_W.build(Xt, WAVE * PMainW::WAVE_R, WG * PMainW::WG_R);
+    c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_capacity<PMainV>());
+    c->plan_W.build(Xt, PMainW::R_W16, PMainW::R_WG, coop_capacity<PMainW>());
   }
   c->y.upload(c->hy);
   c->eq.alloc_zero((size_t)c->N, c->stream);
@@ -426,15 +426,15 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   }
   // relation blocks
   int64_t off = c->D0;
-  int max_chunks = std::max(c->plan_V.max_chunks, c->plan_W.max_chunks);
-  int max_long = std::max(c->plan_V.max_long, c->plan_W.max_long);
+  int max_chunks = std::max(c->plan_V.max_hchunks, c->plan_W.max_hchunks);
+  int max_long = std::max(c->plan_V.max_huge, c->plan_W.max_huge);
   for (auto &hb : c->hblocks) {
     std::unique_ptr<DevBlock> B(new DevBlock());
     B->col_off = off;
     B->build(hb.X, hb.map, c->N, c->KS, c->stream);
     off += B->Db;
-    max_chunks = std::max({max_chunks, B->plan_V.max_chunks, B->plan_W.max_chunks});
-    max_long = std::max({max_long, B->plan_V.max_long, B->plan_W.max_long});
+    max_chunks = std::max({max_chunks, B->plan_V.max_hchunks, B->plan_W.max_hchunks});
+    max_long = std::max({max_long, B->plan_V.max_huge, B->plan_W.max_huge});
     c->blocks.push_back(std::move(B));
   }
   c->ls.reserve(std::max(max_chunks, 1), std::max(max_long, 1));
@@ -541,9 +541,12 @@ int mfm_reduce_e(mfm_ctx *ctx, double *sum_e, double *sum_e2) {
     hipLaunchKernelGGL(k_reduce_e_partial, dim3(REDUCE_BLOCKS), dim3(WG), 0, s, ctx->eq.p, ctx->N, ctx->red_partial.p);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, s, ctx->red_partial.p, REDUCE_BLOCKS, ctx->red_out.p);
   }
-  double2 *h = ctx->readback(1);
+  double2 *h = ctx->readback(2);
   MFM_HIP_CHECK(hipMemcpyAsync(h, ctx->red_out.p, sizeof(double2), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipMemcpyAsync(h + 1, ctx->ls.error.p, sizeof(int), hipMemcpyDeviceToHost, s));
   MFM_HIP_CHECK(hipStreamSynchronize(s));
+  if (*(const int *)(h + 1) != 0)
+    throw Error(MFM_ERR_RUNTIME, "long-column sweep: co-resident chunks timed out waiting for each other");
   *sum_e = h[0].x;
   *sum_e2 = h[0].y;
   MFM_CATCH(ctx)
@@ -606,8 +609,9 @@ int mfm_sweep_w(mfm_ctx *ctx, double alpha, const double *lambda_w, const double
     zdev = c->rng.slot[c->rng.current].zw.p;
   }
   SweepArgs a = main_args(c, c->w.p, zdev, c->lam.p, c->mu.p, alpha);
-  run_plan<PMainW>(s, c->timing, c->plan_W, a, c->ls, KC_SWEEP_W_WAVE, KC_SWEEP_W_WG, KC_SWEEP_W_LSTATS, KC_SWEEP_W_LDRAW,
-                   KC_SWEEP_W_LAPPLY, KC_SWEEP_W_CHAIN);
+  const SweepClasses kcw{KC_SWEEP_W_LIGHT, KC_SWEEP_W_HEAVY, KC_SWEEP_W_COOP, KC_SWEEP_W_LSTATS, KC_SWEEP_W_LDRAW,
+                         KC_SWEEP_W_LAPPLY, KC_SWEEP_W_CHAIN};
+  run_plan<PMainW>(s, c->timing, c->plan_W, a, c->ls, kcw, c->X.unit);
   for (auto &B : c->blocks)
     block_sweep_w(s, c->timing, c->ls, *B, c->N, c->eq.p, c->w.p, zdev, c->group.p, c->lam.p, c->mu.p, alpha);
   MFM_CATCH(ctx)
@@ -639,8 +643,9 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     for (auto &B : c->blocks) block_rowcache(s, c->timing, *B, Vf + B->col_off, true);  // :331-333, :388-393
     launch_qbuild(c, Vf);                                                               // :320, :334-337
     SweepArgs a = main_args(c, Vf, zf, lamf, muf, alpha);
-    run_plan<PMainV>(s, c->timing, c->plan_V, a, c->ls, KC_SWEEP_V_WAVE, KC_SWEEP_V_WG, KC_SWEEP_V_LSTATS, KC_SWEEP_V_LDRAW,
-                     KC_SWEEP_V_LAPPLY, KC_SWEEP_V_CHAIN);                              // :343-376
+    const SweepClasses kcv{KC_SWEEP_V_LIGHT, KC_SWEEP_V_HEAVY, KC_SWEEP_V_COOP, KC_SWEEP_V_LSTATS, KC_SWEEP_V_LDRAW,
+                           KC_SWEEP_V_LAPPLY, KC_SWEEP_V_CHAIN};
+    run_plan<PMainV>(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit);  // :343-376
     for (auto &B : c->blocks)
       block_sweep_V(s, c->timing, c->ls, *B, c->N, c->eq.p, Vf, zf, c->group.p, lamf, muf, alpha);  // :378-482
   }

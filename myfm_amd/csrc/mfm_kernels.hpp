@@ -84,7 +84,7 @@ __device__ __forceinline__ double sample_normal_z(double quad, double first, dou
 // ---------------------------------------------------------------------------------------------
 // latent factors, main table: FMTrainer.hpp:343-376
 struct PMainV {
-  static constexpr int WAVE_R = 4, WG_R = 16;
+  static constexpr int R_W16 = 16, R_WG = 16;
   static constexpr double BYTES = 44.0, STAT_BYTES = 28.0;  // per nnz: CSC 12 + eq 16 (+ eq 16 write)
   typedef double2 St;
   static __device__ __forceinline__ St load(const SweepArgs &a, int row) { return ((const double2 *)a.state)[row]; }
@@ -113,7 +113,7 @@ struct PMainV {
 
 // linear weights, main table: FMTrainer.hpp:237-254
 struct PMainW {
-  static constexpr int WAVE_R = 4, WG_R = 16;
+  static constexpr int R_W16 = 16, R_WG = 16;
   static constexpr double BYTES = 28.0, STAT_BYTES = 20.0;
   typedef double St;
   static __device__ __forceinline__ St load(const SweepArgs &a, int row) { return ((const double2 *)a.state)[row].x; }
@@ -144,7 +144,7 @@ struct BlockRec {
 
 // latent factors, relation block: FMTrainer.hpp:419-470
 struct PBlockV {
-  static constexpr int WAVE_R = 4, WG_R = 4;
+  static constexpr int R_W16 = 0, R_WG = 4;   // 64-byte records: keep the register budget bounded
   static constexpr double BYTES = 12.0 + 64.0 + 48.0, STAT_BYTES = 12.0 + 64.0;
   typedef BlockRec St;
   static __device__ __forceinline__ St load(const SweepArgs &a, int row) {
@@ -182,7 +182,7 @@ struct PBlockV {
 
 // linear weights, relation block: FMTrainer.hpp:276-302
 struct PBlockW {
-  static constexpr int WAVE_R = 4, WG_R = 8;
+  static constexpr int R_W16 = 0, R_WG = 8;
   static constexpr double BYTES = 12.0 + 32.0 + 8.0, STAT_BYTES = 12.0 + 32.0;
   struct St {
     double e, card;
@@ -215,8 +215,9 @@ struct PBlockW {
 // One column handled by NT cooperating threads (NT = 64: a wavefront, NT = 256: the workgroup),
 // at most NT * R entries. The column's (row, x, state) are staged in registers so that the CSC
 // column and the gathered state are read from memory exactly once: pass 1 statistics, draw,
-// pass 2 scatter (FMTrainer.hpp:351-375).
-template <class P, int R, int NT>
+// pass 2 scatter (FMTrainer.hpp:351-375). UNIT: every stored value of the matrix is 1.0 (one-hot
+// designs), the val array is not read at all.
+template <class P, int R, int NT, bool UNIT>
 __device__ __forceinline__ void column_update(const SweepArgs &a, int j, int tid, double *lds) {
   const int64_t begin = a.colptr[j];
   const int len = (int)(a.colptr[j + 1] - begin);
@@ -228,10 +229,10 @@ __device__ __forceinline__ void column_update(const SweepArgs &a, int j, int tid
   for (int r = 0; r < R; r++) {
     const int p = tid + r * NT;
     ri[r] = -1;
-    xv[r] = 0.0;
+    xv[r] = UNIT ? 1.0 : 0.0;
     if (p < len) {
       ri[r] = a.rowidx[begin + p];
-      xv[r] = a.val[begin + p];
+      if (!UNIT) xv[r] = a.val[begin + p];
     }
   }
 #pragma unroll
@@ -255,22 +256,119 @@ __device__ __forceinline__ void column_update(const SweepArgs &a, int j, int tid
   if (tid == 0) a.theta[j] = fresh;
 }
 
-// one wavefront per column; 4 columns per workgroup
-template <class P>
-__global__ __launch_bounds__(WG) void k_sweep_wave(SweepArgs a, const int32_t *__restrict__ cols, int n_cols) {
-  const int w = blockIdx.x * (WG / WAVE) + (threadIdx.x >> 6);
-  if (w >= n_cols) return;
-  column_update<P, P::WAVE_R, WAVE>(a, cols[w], threadIdx.x & 63, nullptr);
+// Columns of one level are binned by length (mfm_plan.hpp): W1 (<= 64 entries, wavefront, 1 entry
+// per lane), W4 (<= 256), W16 (<= 1024, wavefront, 16 per lane), WG (<= 256 * R_WG, workgroup),
+// LONG (cooperating chunks), HUGE (two-pass). One "light" and one "heavy" launch per level keep the
+// register budget of the short columns small (more waves in flight) without a launch per bin.
+template <class P, bool UNIT>
+__global__ __launch_bounds__(WG) void k_level_light(SweepArgs a, const int32_t *__restrict__ cols_w4, int n_w4,
+                                                    const int32_t *__restrict__ cols_w1, int n_w1) {
+  const int nb4 = (n_w4 + 3) >> 2;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if ((int)blockIdx.x < nb4) {
+    const int w = blockIdx.x * 4 + wv;
+    if (w < n_w4) column_update<P, 4, WAVE, UNIT>(a, cols_w4[w], lane, nullptr);
+  } else {
+    const int w = (blockIdx.x - nb4) * 4 + wv;
+    if (w < n_w1) column_update<P, 1, WAVE, UNIT>(a, cols_w1[w], lane, nullptr);
+  }
 }
 
-// one workgroup per column
-template <class P>
-__global__ __launch_bounds__(WG) void k_sweep_wg(SweepArgs a, const int32_t *__restrict__ cols) {
+template <class P, bool UNIT>
+__global__ __launch_bounds__(WG) void k_level_heavy(SweepArgs a, const int32_t *__restrict__ cols_wg, int n_wg,
+                                                    const int32_t *__restrict__ cols_w16, int n_w16) {
   __shared__ double lds[2 * WG / WAVE];
-  column_update<P, P::WG_R, WG>(a, cols[blockIdx.x], threadIdx.x, lds);
+  if ((int)blockIdx.x < n_wg) {
+    column_update<P, P::R_WG, WG, UNIT>(a, cols_wg[blockIdx.x], threadIdx.x, lds);
+  } else if (P::R_W16 > 0) {
+    const int w = (blockIdx.x - n_wg) * 4 + (threadIdx.x >> 6);
+    if (w < n_w16) column_update<P, (P::R_W16 > 0 ? P::R_W16 : 1), WAVE, UNIT>(a, cols_w16[w], threadIdx.x & 63, nullptr);
+  }
 }
 
-// ---- long columns: statistics per chunk, draw, apply ------------------------------------------
+// ---- LONG columns, single pass: one workgroup per chunk of <= 256 * R_WG entries, all chunks of a
+// column co-resident (the launch never exceeds the device's resident workgroup capacity). Every
+// chunk stages its entries in registers, publishes its partial statistics, waits until all chunks
+// of its column have arrived, sums the partials in chunk order (deterministic, identical in every
+// chunk), draws, and scatters from registers. The exchange uses 8-byte agent-scope atomics on both
+// sides (cdna_hip_programming.md G16: valid across XCDs, L1 bypassed), one arrival counter per column,
+// monotone across launches (target = epoch * n_chunks), bounded spin.
+struct CoopArgs {
+  const ChunkDesc *chunks;
+  const int32_t *lcols;
+  const int32_t *chunk_ptr;     // [n_long + 1]
+  double *partial;              // [2 * n_chunks]
+  unsigned long long *arrive;   // [n_long]
+  unsigned long long epoch;     // >= 1
+  int *error;                   // set to 1 on spin timeout
+};
+
+template <class P, bool UNIT>
+__global__ __launch_bounds__(WG) void k_long_coop(SweepArgs a, CoopArgs ca, int chunk_base) {
+  constexpr int R = P::R_WG;
+  __shared__ double lds[2 * WG / WAVE + 2];
+  const int c = chunk_base + blockIdx.x;
+  const ChunkDesc d = ca.chunks[c];
+  const int l = d.lcol;
+  const int j = ca.lcols[l];
+  const int tid = threadIdx.x;
+  const double old = a.theta[j];
+  int32_t ri[R];
+  double xv[R];
+  typename P::St st[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int p = tid + r * WG;
+    ri[r] = -1;
+    xv[r] = UNIT ? 1.0 : 0.0;
+    if (p < d.len) {
+      ri[r] = a.rowidx[d.begin + p];
+      if (!UNIT) xv[r] = a.val[d.begin + p];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++)
+    if (ri[r] >= 0) st[r] = P::load(a, ri[r]);
+  double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; r++)
+    if (ri[r] >= 0) P::stats(xv[r], st[r], old, S1, S2);
+  wg_allreduce2<WG / WAVE>(S1, S2, lds);
+  if (tid == 0) {
+    __hip_atomic_store(ca.partial + 2 * c, S1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ca.partial + 2 * c + 1, S2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(ca.arrive + l, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int c0 = ca.chunk_ptr[l], c1 = ca.chunk_ptr[l + 1];
+    const unsigned long long target = ca.epoch * (unsigned long long)(c1 - c0);
+    unsigned spins = 0;
+    while (__hip_atomic_load(ca.arrive + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 22)) {
+        *ca.error = 1;
+        break;
+      }
+    }
+    double T1 = 0.0, T2 = 0.0;
+    for (int cc = c0; cc < c1; cc++) {
+      T1 += __hip_atomic_load(ca.partial + 2 * cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      T2 += __hip_atomic_load(ca.partial + 2 * cc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    lds[2 * WG / WAVE] = T1;
+    lds[2 * WG / WAVE + 1] = T2;
+  }
+  __syncthreads();
+  S1 = lds[2 * WG / WAVE];
+  S2 = lds[2 * WG / WAVE + 1];
+  const int g = a.group[j];
+  const double fresh = P::draw(S1, S2, old, a.alpha, a.lambda[g], a.mu[g], a.z[j]);
+#pragma unroll
+  for (int r = 0; r < R; r++)
+    if (ri[r] >= 0) P::apply(a, ri[r], xv[r], st[r], old, fresh);
+  if (tid == 0 && c == ca.chunk_ptr[l]) a.theta[j] = fresh;
+}
+
+// ---- HUGE columns (more chunks than can be co-resident): statistics per chunk, draw, apply ---------
 template <class P>
 __global__ __launch_bounds__(WG) void k_long_stats(SweepArgs a, const ChunkDesc *__restrict__ chunks,
                                                    const int32_t *__restrict__ lcols, double2 *__restrict__ partial) {

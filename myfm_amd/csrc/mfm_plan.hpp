@@ -3,8 +3,12 @@
 // The reference updates the features of a table strictly in index order (FMTrainer.hpp:343, :419).
 // Two features whose columns share no row touch disjoint state and commute, so the plan assigns
 // level(j) = 1 + max level of the earlier columns sharing a row with j and runs the levels in order:
-//   PAR step   one level with enough work: its columns run concurrently, binned by length into
-//              wavefront-per-column / workgroup-per-column / chunked long columns;
+//   PAR step   one level with enough work: its columns run concurrently, binned by length
+//              W1 (<= 64 entries) / W4 (<= 256): wavefront per column, "light" launch
+//              W16 (<= 1024, wavefront) / WG (<= 256 * R_WG, workgroup): "heavy" launch
+//              LONG: chunks of 256 * R_WG entries, co-resident, single pass (k_long_coop), launched in
+//                    rounds that never exceed the device's resident-workgroup capacity
+//              HUGE: more chunks than one round can hold (e.g. a dense column): two-pass
 //   CHAIN step a run of consecutive tiny levels (dense / multi-hot columns, small blocks): one
 //              workgroup walks their columns one after the other inside a single launch.
 // The draws are identical to the sequential order given the same per-feature variates.
@@ -18,10 +22,21 @@
 namespace mfm {
 
 struct ParLevel {
-  DevBuf<int32_t> wave_cols, wg_cols, long_cols, long_chunk_ptr;
-  DevBuf<ChunkDesc> chunks;
-  int n_wave = 0, n_wg = 0, n_long = 0, n_chunks = 0;
-  int64_t nnz_wave = 0, nnz_wg = 0, nnz_long = 0;
+  DevBuf<int32_t> cols_w1, cols_w4, cols_w16, cols_wg, cols_long, cols_huge;
+  int n_w1 = 0, n_w4 = 0, n_w16 = 0, n_wg = 0, n_long = 0, n_huge = 0;
+  int64_t nnz_light = 0, nnz_heavy = 0, nnz_long = 0, nnz_huge = 0;
+  // LONG: co-resident single pass
+  DevBuf<ChunkDesc> lchunks;
+  DevBuf<int32_t> lchunk_ptr;
+  DevBuf<double> lpartial;
+  DevBuf<unsigned long long> arrive;
+  mutable unsigned long long epoch = 0;
+  std::vector<std::pair<int, int>> rounds;  // (first chunk, number of chunks)
+  std::vector<int64_t> round_nnz;
+  // HUGE: two-pass
+  DevBuf<ChunkDesc> hchunks;
+  DevBuf<int32_t> hchunk_ptr;
+  int n_hchunks = 0;
 };
 
 struct ChainRun {
@@ -39,13 +54,16 @@ struct Step {
 struct StepPlan {
   std::vector<Step> steps;
   int n_levels = 0;
-  int max_chunks = 0, max_long = 0;
+  int max_hchunks = 0, max_huge = 0;
   int64_t launches = 0;
 
   // a level is "tiny" when running it as its own launches cannot fill the device anyway
   static bool tiny(size_t n_cols, int64_t nnz) { return n_cols <= 8 && nnz <= 16384; }
 
-  void build(const HostCsr &csc, int wave_cap, int wg_cap) {
+  // r_w16: entries per lane of the 16-wide wavefront bin (0: the policy has none); r_wg: entries per
+  // thread of the workgroup bin; coop_max: workgroups that are safely co-resident on the device
+  void build(const HostCsr &csc, int r_w16, int r_wg, int coop_max) {
+    const int64_t cap_w1 = WAVE, cap_w4 = 4 * WAVE, cap_w16 = (int64_t)r_w16 * WAVE, cap_wg = (int64_t)r_wg * WG;
     std::vector<int32_t> level;
     n_levels = column_levels(csc, level);
     std::vector<std::vector<int32_t>> by_level((size_t)n_levels);
@@ -76,89 +94,177 @@ struct StepPlan {
       }
       flush_run();
       steps.emplace_back();
-      Step &s = steps.back();
-      ParLevel &L = s.par;
-      std::vector<int32_t> wv, wg, lg, cptr;
-      std::vector<ChunkDesc> ch;
+      ParLevel &L = steps.back().par;
+      std::vector<int32_t> w1, w4, w16, wg, lg, hg, lptr, hptr;
+      std::vector<ChunkDesc> lch, hch;
       for (int32_t j : by_level[l]) {
-        int64_t len = csc.ptr[j + 1] - csc.ptr[j];
-        if (len <= wave_cap) {
-          wv.push_back(j);
-          L.nnz_wave += len;
-        } else if (len <= wg_cap) {
+        const int64_t len = csc.ptr[j + 1] - csc.ptr[j];
+        if (len <= cap_w1) {
+          w1.push_back(j);
+          L.nnz_light += len;
+        } else if (len <= cap_w4) {
+          w4.push_back(j);
+          L.nnz_light += len;
+        } else if (len <= cap_w16) {
+          w16.push_back(j);
+          L.nnz_heavy += len;
+        } else if (len <= cap_wg) {
           wg.push_back(j);
-          L.nnz_wg += len;
+          L.nnz_heavy += len;
         } else {
-          cptr.push_back((int32_t)ch.size());
-          for (int64_t b = 0; b < len; b += wg_cap)
-            ch.push_back(ChunkDesc{csc.ptr[j] + b, (int32_t)std::min<int64_t>(wg_cap, len - b), (int32_t)lg.size()});
-          lg.push_back(j);
-          L.nnz_long += len;
+          const int64_t nch = (len + cap_wg - 1) / cap_wg;
+          const bool coop = nch <= coop_max;
+          std::vector<ChunkDesc> &ch = coop ? lch : hch;
+          std::vector<int32_t> &ptr = coop ? lptr : hptr;
+          std::vector<int32_t> &lst = coop ? lg : hg;
+          ptr.push_back((int32_t)ch.size());
+          for (int64_t b = 0; b < len; b += cap_wg)
+            ch.push_back(ChunkDesc{csc.ptr[j] + b, (int32_t)std::min<int64_t>(cap_wg, len - b), (int32_t)lst.size()});
+          lst.push_back(j);
+          (coop ? L.nnz_long : L.nnz_huge) += len;
         }
       }
-      cptr.push_back((int32_t)ch.size());
-      L.n_wave = (int)wv.size();
+      lptr.push_back((int32_t)lch.size());
+      hptr.push_back((int32_t)hch.size());
+      L.n_w1 = (int)w1.size();
+      L.n_w4 = (int)w4.size();
+      L.n_w16 = (int)w16.size();
       L.n_wg = (int)wg.size();
       L.n_long = (int)lg.size();
-      L.n_chunks = (int)ch.size();
-      L.wave_cols.upload(wv);
-      L.wg_cols.upload(wg);
-      L.long_cols.upload(lg);
-      L.long_chunk_ptr.upload(cptr);
-      L.chunks.upload(ch.data(), ch.size());
-      max_chunks = std::max(max_chunks, L.n_chunks);
-      max_long = std::max(max_long, L.n_long);
-      launches += (L.n_wave ? 1 : 0) + (L.n_wg ? 1 : 0) + (L.n_long ? 3 : 0);
+      L.n_huge = (int)hg.size();
+      L.cols_w1.upload(w1);
+      L.cols_w4.upload(w4);
+      L.cols_w16.upload(w16);
+      L.cols_wg.upload(wg);
+      L.cols_long.upload(lg);
+      L.cols_huge.upload(hg);
+      L.lchunks.upload(lch.data(), lch.size());
+      L.lchunk_ptr.upload(lptr);
+      L.hchunks.upload(hch.data(), hch.size());
+      L.hchunk_ptr.upload(hptr);
+      L.n_hchunks = (int)hch.size();
+      if (!lch.empty()) {
+        L.lpartial.alloc(2 * lch.size());
+        L.arrive.alloc(lg.size());
+        MFM_HIP_CHECK(hipMemset(L.arrive.p, 0, lg.size() * sizeof(unsigned long long)));
+        // rounds: whole columns, at most coop_max chunks each
+        int first = 0;
+        int64_t rn = 0;
+        for (size_t c = 0; c < lg.size(); c++) {
+          const int cb = lptr[c], ce = lptr[c + 1];
+          if (ce - first > coop_max) {
+            L.rounds.emplace_back(first, cb - first);
+            L.round_nnz.push_back(rn);
+            first = cb;
+            rn = 0;
+          }
+          rn += csc.ptr[lg[c] + 1] - csc.ptr[lg[c]];
+        }
+        L.rounds.emplace_back(first, (int)lch.size() - first);
+        L.round_nnz.push_back(rn);
+      }
+      max_hchunks = std::max(max_hchunks, L.n_hchunks);
+      max_huge = std::max(max_huge, L.n_huge);
+      launches += ((L.n_w1 + L.n_w4) ? 1 : 0) + ((L.n_w16 + L.n_wg) ? 1 : 0) + (int64_t)L.rounds.size() + (L.n_huge ? 3 : 0);
     }
     flush_run();
   }
 };
 
-// scratch shared by every long-column launch of a ctx
+// scratch shared by every sweep of a ctx
 struct LongScratch {
   DevBuf<double2> partial, oldnew;
+  DevBuf<int> error;  // set by k_long_coop on a spin timeout
   void reserve(int max_chunks, int max_long) {
     if ((size_t)max_chunks > partial.n) partial.alloc((size_t)max_chunks);
     if ((size_t)max_long > oldnew.n) oldnew.alloc((size_t)max_long);
+    if (!error.p) {
+      error.alloc(1);
+      MFM_HIP_CHECK(hipMemset(error.p, 0, sizeof(int)));
+    }
   }
 };
 
-template <class P>
-static void run_plan(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls, int kc_wave,
-                     int kc_wg, int kc_lstats, int kc_ldraw, int kc_lapply, int kc_chain) {
+struct SweepClasses {
+  int light, heavy, coop, hstats, hdraw, happly, chain;
+};
+
+template <class P, bool UNIT>
+static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls,
+                       const SweepClasses &kc) {
   for (const Step &st : plan.steps) {
     if (st.is_chain) {
-      TimedLaunch t(tm, s, kc_chain, P::BYTES * st.chain.nnz);
+      TimedLaunch t(tm, s, kc.chain, P::BYTES * st.chain.nnz);
       hipLaunchKernelGGL((k_chain<P>), dim3(1), dim3(CHAIN_WG), 0, s, a, st.chain.cols.p, st.chain.n_cols);
       continue;
     }
     const ParLevel &L = st.par;
-    if (L.n_wave) {
-      TimedLaunch t(tm, s, kc_wave, P::BYTES * L.nnz_wave);
-      hipLaunchKernelGGL((k_sweep_wave<P>), dim3((L.n_wave + WG / WAVE - 1) / (WG / WAVE)), dim3(WG), 0, s, a,
-                         L.wave_cols.p, L.n_wave);
-    }
-    if (L.n_wg) {
-      TimedLaunch t(tm, s, kc_wg, P::BYTES * L.nnz_wg);
-      hipLaunchKernelGGL((k_sweep_wg<P>), dim3(L.n_wg), dim3(WG), 0, s, a, L.wg_cols.p);
-    }
+    // the long columns first: they are the critical path of the level
     if (L.n_long) {
+      L.epoch++;
+      CoopArgs ca;
+      ca.chunks = L.lchunks.p;
+      ca.lcols = L.cols_long.p;
+      ca.chunk_ptr = L.lchunk_ptr.p;
+      ca.partial = L.lpartial.p;
+      ca.arrive = L.arrive.p;
+      ca.epoch = L.epoch;
+      ca.error = ls.error.p;
+      for (size_t r = 0; r < L.rounds.size(); r++) {
+        TimedLaunch t(tm, s, kc.coop, P::BYTES * L.round_nnz[r]);
+        hipLaunchKernelGGL((k_long_coop<P, UNIT>), dim3(L.rounds[r].second), dim3(WG), 0, s, a, ca, L.rounds[r].first);
+      }
+    }
+    if (L.n_wg + L.n_w16) {
+      TimedLaunch t(tm, s, kc.heavy, P::BYTES * L.nnz_heavy);
+      hipLaunchKernelGGL((k_level_heavy<P, UNIT>), dim3(L.n_wg + (L.n_w16 + 3) / 4), dim3(WG), 0, s, a, L.cols_wg.p, L.n_wg,
+                         L.cols_w16.p, L.n_w16);
+    }
+    if (L.n_w4 + L.n_w1) {
+      TimedLaunch t(tm, s, kc.light, P::BYTES * L.nnz_light);
+      hipLaunchKernelGGL((k_level_light<P, UNIT>), dim3((L.n_w4 + 3) / 4 + (L.n_w1 + 3) / 4), dim3(WG), 0, s, a, L.cols_w4.p,
+                         L.n_w4, L.cols_w1.p, L.n_w1);
+    }
+    if (L.n_huge) {
       {
-        TimedLaunch t(tm, s, kc_lstats, P::STAT_BYTES * L.nnz_long);
-        hipLaunchKernelGGL((k_long_stats<P>), dim3(L.n_chunks), dim3(WG), 0, s, a, L.chunks.p, L.long_cols.p, ls.partial.p);
+        TimedLaunch t(tm, s, kc.hstats, P::STAT_BYTES * L.nnz_huge);
+        hipLaunchKernelGGL((k_long_stats<P>), dim3(L.n_hchunks), dim3(WG), 0, s, a, L.hchunks.p, L.cols_huge.p, ls.partial.p);
       }
       {
-        TimedLaunch t(tm, s, kc_ldraw, 16.0 * L.n_chunks);
-        hipLaunchKernelGGL((k_long_draw<P>), dim3((L.n_long + 63) / 64), dim3(64), 0, s, a, L.long_cols.p,
-                           L.long_chunk_ptr.p, L.n_long, ls.partial.p, ls.oldnew.p);
+        TimedLaunch t(tm, s, kc.hdraw, 16.0 * L.n_hchunks);
+        hipLaunchKernelGGL((k_long_draw<P>), dim3((L.n_huge + 63) / 64), dim3(64), 0, s, a, L.cols_huge.p, L.hchunk_ptr.p,
+                           L.n_huge, ls.partial.p, ls.oldnew.p);
       }
       {
-        TimedLaunch t(tm, s, kc_lapply, P::BYTES * L.nnz_long);
-        hipLaunchKernelGGL((k_long_apply<P>), dim3(L.n_chunks), dim3(WG), 0, s, a, L.chunks.p, ls.oldnew.p);
+        TimedLaunch t(tm, s, kc.happly, P::BYTES * L.nnz_huge);
+        hipLaunchKernelGGL((k_long_apply<P>), dim3(L.n_hchunks), dim3(WG), 0, s, a, L.hchunks.p, ls.oldnew.p);
       }
     }
   }
   MFM_HIP_CHECK(hipGetLastError());
+}
+
+template <class P>
+static void run_plan(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls,
+                     const SweepClasses &kc, bool unit) {
+  if (unit)
+    run_plan_t<P, true>(s, tm, plan, a, ls, kc);
+  else
+    run_plan_t<P, false>(s, tm, plan, a, ls, kc);
+}
+
+// resident-workgroup capacity for the co-resident long-column kernel, with a safety margin
+template <class P>
+static int coop_capacity() {
+  int dev = 0, cus = 0, per_cu_a = 0, per_cu_b = 0;
+  MFM_HIP_CHECK(hipGetDevice(&dev));
+  MFM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  MFM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_long_coop<P, false>, WG, 0));
+  MFM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, k_long_coop<P, true>, WG, 0));
+  int per_cu = std::min(per_cu_a, per_cu_b);
+  // the occupancy API can over-report by one block per CU (MI355X_MICROARCH.md): take one off, cap at 3
+  per_cu = std::max(1, std::min(per_cu - 1, 3));
+  return std::max(8, cus * per_cu);
 }
 
 }  // namespace mfm
