@@ -175,10 +175,19 @@ static void launch_qbuild(mfm_ctx *c, const double *vf) {
   hipStream_t s = c->stream;
   BlockGatherArgs g;
   fill_gather_args(c->blocks, g);
-  TimedLaunch t(c->timing, s, KC_QBUILD, 12.0 * c->X.nnz + 8.0 * c->N + 8.0 * c->D0 + 12.0 * c->N * g.n_blocks);
+  TimedLaunch t(c->timing, s, KC_QBUILD, 12.0 * c->X.nnz + 8.0 * c->N + 8.0 * c->D0 + 12.0 * c->N * g.n_blocks);  // SURVEY 8d
   if (c->X.avg_row_nnz <= 16.0) {
-    hipLaunchKernelGGL(k_qbuild_rows, dim3(cdiv(c->N, WG)), dim3(WG), 0, s, c->X.rowptr.p, c->X.colidx.p, c->X.rval.p, vf,
-                       c->eq.p, c->N, g);
+    const bool ell = c->X.ell_width >= 0;
+    dim3 grid(cdiv(c->N, WG)), block(WG);
+#define MFM_QB(U, E) \
+  hipLaunchKernelGGL((k_qbuild_rows<U, E>), grid, block, 0, s, c->X.rowptr.p, c->X.colidx.p, c->X.rval.p, vf, c->eq.p, c->N, \
+                     (int)c->X.ell_width, g)
+    if (c->X.unit) {
+      if (ell) MFM_QB(true, true); else MFM_QB(true, false);
+    } else {
+      if (ell) MFM_QB(false, true); else MFM_QB(false, false);
+    }
+#undef MFM_QB
   } else {
     hipLaunchKernelGGL(k_qbuild_wave, dim3(cdiv(c->N, WG / WAVE)), dim3(WG), 0, s, c->X.rowptr.p, c->X.colidx.p,
                        c->X.rval.p, vf, c->eq.p, c->N, g);
@@ -186,40 +195,51 @@ static void launch_qbuild(mfm_ctx *c, const double *vf) {
   MFM_HIP_CHECK(hipGetLastError());
 }
 
-template <int GS, int SPL>
+template <int GS, int SPL, bool UNIT, bool ELL>
 static void launch_score_t(hipStream_t s, int mode, const DevSparse &X, const double *Vt, const double *w, double w0, int K,
                            int KS, const double *y, double2 *eq, double *out, const BlockScoreArgs &blk) {
   const int64_t N = X.rows;
-  dim3 grid(cdiv(N * GS, WG)), block(WG);
+  const int64_t groups = (N + SCORE_RU - 1) / SCORE_RU;
+  dim3 grid(cdiv(groups * GS, WG)), block(WG);
   if (mode == 0)
-    hipLaunchKernelGGL((k_score<GS, SPL, 0>), grid, block, 0, s, X.rowptr.p, X.colidx.p, X.rval.p, Vt, w, w0, K, KS, y, eq,
-                       out, N, blk);
+    hipLaunchKernelGGL((k_score<GS, SPL, 0, UNIT, ELL>), grid, block, 0, s, X.rowptr.p, X.colidx.p, X.rval.p, Vt, w, w0, K, KS,
+                       (int)X.ell_width, y, eq, out, N, blk);
   else
-    hipLaunchKernelGGL((k_score<GS, SPL, 1>), grid, block, 0, s, X.rowptr.p, X.colidx.p, X.rval.p, Vt, w, w0, K, KS, y, eq,
-                       out, N, blk);
+    hipLaunchKernelGGL((k_score<GS, SPL, 1, UNIT, ELL>), grid, block, 0, s, X.rowptr.p, X.colidx.p, X.rval.p, Vt, w, w0, K, KS,
+                       (int)X.ell_width, y, eq, out, N, blk);
 }
 
-// mode 0: eq.x = score (- y)   mode 1: out = score
+template <int GS, int SPL>
+static void launch_score_f(hipStream_t s, int mode, const DevSparse &X, const double *Vt, const double *w, double w0, int K,
+                           int KS, const double *y, double2 *eq, double *out, const BlockScoreArgs &blk) {
+  const bool ell = X.ell_width >= 0;
+  if (X.unit && ell)
+    launch_score_t<GS, SPL, true, true>(s, mode, X, Vt, w, w0, K, KS, y, eq, out, blk);
+  else if (X.unit)
+    launch_score_t<GS, SPL, true, false>(s, mode, X, Vt, w, w0, K, KS, y, eq, out, blk);
+  else
+    launch_score_t<GS, SPL, false, false>(s, mode, X, Vt, w, w0, K, KS, y, eq, out, blk);
+}
+
+// mode 0: eq.x = score (- y)   mode 1: out = score.  A lane owns factor pairs: GS lanes cover 2 GS factors.
 static void launch_score(hipStream_t s, int mode, const DevSparse &X, const double *Vt, const double *w, double w0, int K,
                          int KS, const double *y, double2 *eq, double *out, const BlockScoreArgs &blk) {
   if (X.rows == 0) return;
-#define MFM_SCORE(GS, SPL) launch_score_t<GS, SPL>(s, mode, X, Vt, w, w0, K, KS, y, eq, out, blk)
-  if (K <= 4)
+#define MFM_SCORE(GS, SPL) launch_score_f<GS, SPL>(s, mode, X, Vt, w, w0, K, KS, y, eq, out, blk)
+  if (K <= 8)
     MFM_SCORE(4, 1);
-  else if (K <= 8)
-    MFM_SCORE(8, 1);
   else if (K <= 16)
-    MFM_SCORE(16, 1);
+    MFM_SCORE(8, 1);
   else if (K <= 32)
-    MFM_SCORE(32, 1);
+    MFM_SCORE(16, 1);
   else if (K <= 64)
-    MFM_SCORE(64, 1);
+    MFM_SCORE(32, 1);
   else if (K <= 128)
-    MFM_SCORE(64, 2);
+    MFM_SCORE(64, 1);
   else if (K <= 256)
-    MFM_SCORE(64, 4);
+    MFM_SCORE(64, 2);
   else if (K <= 512)
-    MFM_SCORE(64, 8);
+    MFM_SCORE(64, 4);
   else
     throw Error(MFM_ERR_INVALID, "rank > 512 is not supported");
 #undef MFM_SCORE

@@ -260,28 +260,37 @@ __device__ __forceinline__ void column_update(const SweepArgs &a, int j, int tid
 // per lane), W4 (<= 256), W16 (<= 1024, wavefront, 16 per lane), WG (<= 256 * R_WG, workgroup),
 // LONG (cooperating chunks), HUGE (two-pass). One "light" and one "heavy" launch per level keep the
 // register budget of the short columns small (more waves in flight) without a launch per bin.
+// XCD-aware block index: workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md); map the
+// blocks of one XCD to a CONTIGUOUS range of the work list so that columns with neighbouring rows
+// share that XCD's L2. Bijective for any nb; a wrong placement guess only costs speed.
+__device__ __forceinline__ int xcd_swizzle(int b, int nb, int on) {
+  if (!on || nb < 16) return b;
+  const int q = nb >> 3, r = nb & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 template <class P, bool UNIT>
 __global__ __launch_bounds__(WG) void k_level_light(SweepArgs a, const int32_t *__restrict__ cols_w4, int n_w4,
-                                                    const int32_t *__restrict__ cols_w1, int n_w1) {
+                                                    const int32_t *__restrict__ cols_w1, int n_w1, int swz) {
   const int nb4 = (n_w4 + 3) >> 2;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if ((int)blockIdx.x < nb4) {
-    const int w = blockIdx.x * 4 + wv;
+    const int w = xcd_swizzle(blockIdx.x, nb4, swz) * 4 + wv;
     if (w < n_w4) column_update<P, 4, WAVE, UNIT>(a, cols_w4[w], lane, nullptr);
   } else {
-    const int w = (blockIdx.x - nb4) * 4 + wv;
+    const int w = xcd_swizzle(blockIdx.x - nb4, gridDim.x - nb4, swz) * 4 + wv;
     if (w < n_w1) column_update<P, 1, WAVE, UNIT>(a, cols_w1[w], lane, nullptr);
   }
 }
 
 template <class P, bool UNIT>
 __global__ __launch_bounds__(WG) void k_level_heavy(SweepArgs a, const int32_t *__restrict__ cols_wg, int n_wg,
-                                                    const int32_t *__restrict__ cols_w16, int n_w16) {
+                                                    const int32_t *__restrict__ cols_w16, int n_w16, int swz) {
   __shared__ double lds[2 * WG / WAVE];
   if ((int)blockIdx.x < n_wg) {
-    column_update<P, P::R_WG, WG, UNIT>(a, cols_wg[blockIdx.x], threadIdx.x, lds);
+    column_update<P, P::R_WG, WG, UNIT>(a, cols_wg[xcd_swizzle(blockIdx.x, n_wg, swz)], threadIdx.x, lds);
   } else if (P::R_W16 > 0) {
-    const int w = (blockIdx.x - n_wg) * 4 + (threadIdx.x >> 6);
+    const int w = xcd_swizzle(blockIdx.x - n_wg, gridDim.x - n_wg, swz) * 4 + (threadIdx.x >> 6);
     if (w < n_w16) column_update<P, (P::R_W16 > 0 ? P::R_W16 : 1), WAVE, UNIT>(a, cols_w16[w], threadIdx.x & 63, nullptr);
   }
 }
@@ -457,16 +466,26 @@ struct BlockGatherArgs {
   const double *rec[MAX_BLOCKS];
 };
 
-// thread per row: the right shape for one-hot / few-nnz rows (coalesced over consecutive rows)
+// thread per row: the right shape for one-hot / few-nnz rows (coalesced over consecutive rows).
+// UNIT: all stored values are 1.0 (val not read); ELL >= 0: every row has exactly ELL entries (rowptr
+// not read) -- one-hot designs with a fixed number of fields stream 4 bytes per entry.
+template <bool UNIT, bool ELL>
 __global__ __launch_bounds__(WG) void k_qbuild_rows(const int32_t *__restrict__ rowptr,
                                                     const int32_t *__restrict__ colidx,
                                                     const double *__restrict__ val, const double *__restrict__ vf,
-                                                    double2 *__restrict__ eq, int64_t N, BlockGatherArgs blk) {
+                                                    double2 *__restrict__ eq, int64_t N, int ell, BlockGatherArgs blk) {
   const int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x;
   if (i >= N) return;
-  const int32_t b = rowptr[i], e = rowptr[i + 1];
+  int64_t b, e;
+  if (ELL) {
+    b = i * ell;
+    e = b + ell;
+  } else {
+    b = rowptr[i];
+    e = rowptr[i + 1];
+  }
   double s = 0.0;
-  for (int32_t p = b; p < e; p++) s += val[p] * vf[colidx[p]];
+  for (int64_t p = b; p < e; p++) s += (UNIT ? 1.0 : val[p]) * vf[colidx[p]];
   for (int bi = 0; bi < blk.n_blocks; bi++) s += blk.rec[bi][(int64_t)blk.map[bi][i] * BLOCK_REC];  // :335-337
   eq[i].y = s;
 }
@@ -503,64 +522,106 @@ struct BlockScoreArgs {
 };
 
 // OUT_MODE 0: eq[t].x = score - y[t] (y may be null => score)   1: out[t] = score
-template <int GS, int SPL, int OUT_MODE>
+// Lane `lig` of a GS-lane group owns factor PAIRS (2 lig, 2 lig + 1), (2 (lig + GS), ...): V rows are
+// gathered with 16-byte loads (KS is even, rows are 16-byte aligned). Each group works on RU rows at
+// a time so that several independent gathers are in flight per lane (the pass is L2-gather bound).
+// UNIT: all values are 1.0 (val not read); ELL: every row has `ell` entries (rowptr not read).
+constexpr int SCORE_RU = 4;
+template <int GS, int SPL, int OUT_MODE, bool UNIT, bool ELL>
 __global__ __launch_bounds__(WG) void k_score(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                                               const double *__restrict__ val, const double *__restrict__ Vt,
-                                              const double *__restrict__ w, double w0, int K, int KS,
+                                              const double *__restrict__ w, double w0, int K, int KS, int ell,
                                               const double *__restrict__ y, double2 *__restrict__ eq,
                                               double *__restrict__ out, int64_t N, BlockScoreArgs blk) {
-  const int64_t t = ((int64_t)blockIdx.x * WG + threadIdx.x) / GS;
+  constexpr int RU = SCORE_RU;
   const int lig = threadIdx.x % GS;
-  const bool live = t < N;
-  double a[SPL], b[SPL];
+  const int64_t t0 = (((int64_t)blockIdx.x * WG + threadIdx.x) / GS) * RU;
+  double2 a[RU][SPL];
+  double b[RU], lin[RU];
+  int64_t pb[RU];
+  int len[RU];
+  int maxlen = 0;
 #pragma unroll
-  for (int u = 0; u < SPL; u++) {
-    a[u] = 0.0;
+  for (int u = 0; u < RU; u++) {
     b[u] = 0.0;
-  }
-  double lin = 0.0;
-  if (live) {
-    const int32_t pb = rowptr[t], pe = rowptr[t + 1];
-    for (int32_t p = pb; p < pe; p++) {
-      const int32_t j = colidx[p];
-      const double x = val[p];
-      const double x2 = x * x;
-      if (lig == 0) lin += x * w[j];
-      const double *row = Vt + (int64_t)j * KS;
+    lin[u] = 0.0;
 #pragma unroll
-      for (int u = 0; u < SPL; u++) {
-        const int s = lig + u * GS;
-        if (s < K) {
-          const double v = row[s];
-          a[u] += x * v;
-          b[u] += x2 * (v * v);
+    for (int k = 0; k < SPL; k++) a[u][k] = make_double2(0.0, 0.0);
+    const int64_t t = t0 + u;
+    if (t < N) {
+      if (ELL) {
+        pb[u] = t * ell;
+        len[u] = ell;
+      } else {
+        pb[u] = rowptr[t];
+        len[u] = rowptr[t + 1] - (int32_t)pb[u];
+      }
+    } else {
+      pb[u] = 0;
+      len[u] = 0;
+    }
+    maxlen = len[u] > maxlen ? len[u] : maxlen;
+  }
+  for (int k = 0; k < maxlen; k++) {
+#pragma unroll
+    for (int u = 0; u < RU; u++) {
+      if (k < len[u]) {
+        const int32_t j = colidx[pb[u] + k];
+        const double x = UNIT ? 1.0 : val[pb[u] + k];
+        const double x2 = x * x;
+        if (lig == 0) lin[u] += x * w[j];
+        const double2 *row = (const double2 *)(Vt + (int64_t)j * KS);
+#pragma unroll
+        for (int s = 0; s < SPL; s++) {
+          const int pr = lig + s * GS;
+          if (2 * pr < K) {
+            const double2 v = row[pr];  // pad column of an odd K is zero
+            a[u][s].x += x * v.x;
+            a[u][s].y += x * v.y;
+            b[u] += x2 * (v.x * v.x);
+            b[u] += x2 * (v.y * v.y);
+          }
         }
       }
     }
-    for (int bi = 0; bi < blk.n_blocks; bi++) {
-      const int64_t i = blk.map[bi][t];
-      if (lig == 0) lin += blk.bl[bi][i];
-      const double *row = blk.bq[bi] + i * KS;
+  }
 #pragma unroll
-      for (int u = 0; u < SPL; u++) {
-        const int s = lig + u * GS;
-        if (s < K) a[u] += row[s];
+  for (int u = 0; u < RU; u++) {
+    const int64_t t = t0 + u;
+    if (t < N) {
+      for (int bi = 0; bi < blk.n_blocks; bi++) {
+        const int64_t i = blk.map[bi][t];
+        if (lig == 0) lin[u] += blk.bl[bi][i];
+        const double2 *row = (const double2 *)(blk.bq[bi] + i * KS);
+#pragma unroll
+        for (int s = 0; s < SPL; s++) {
+          const int pr = lig + s * GS;
+          if (2 * pr < K) {
+            const double2 v = row[pr];
+            a[u][s].x += v.x;
+            a[u][s].y += v.y;
+          }
+        }
+        if (lig == 0) b[u] += blk.bs[bi][i];
       }
-      if (lig == 0) b[0] += blk.bs[bi][i];
     }
   }
-  double part = 0.0;
 #pragma unroll
-  for (int u = 0; u < SPL; u++) part += (a[u] * a[u] - b[u]);
-  part = 0.5 * part + lin;
+  for (int u = 0; u < RU; u++) {
+    double part = 0.0;
 #pragma unroll
-  for (int m = GS / 2; m >= 1; m >>= 1) part += __shfl_xor(part, m, WAVE);
-  if (live && lig == 0) {
-    const double score = w0 + part;
-    if (OUT_MODE == 0) {
-      eq[t].x = y ? (score - y[t]) : score;
-    } else {
-      out[t] = score;
+    for (int s = 0; s < SPL; s++) part += a[u][s].x * a[u][s].x + a[u][s].y * a[u][s].y;
+    part = 0.5 * (part - b[u]) + lin[u];
+#pragma unroll
+    for (int m = GS / 2; m >= 1; m >>= 1) part += __shfl_xor(part, m, WAVE);
+    const int64_t t = t0 + u;
+    if (t < N && lig == 0) {
+      const double score = w0 + part;
+      if (OUT_MODE == 0) {
+        eq[t].x = y ? (score - y[t]) : score;
+      } else {
+        out[t] = score;
+      }
     }
   }
 }

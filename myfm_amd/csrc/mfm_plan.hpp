@@ -14,6 +14,7 @@
 // The draws are identical to the sequential order given the same per-feature variates.
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "mfm_common.hpp"
@@ -185,6 +186,15 @@ struct LongScratch {
   }
 };
 
+static inline int xcd_swizzle_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = std::getenv("MFM_XCD_SWIZZLE");
+    v = e ? std::atoi(e) : 0;
+  }
+  return v;
+}
+
 struct SweepClasses {
   int light, heavy, coop, hstats, hdraw, happly, chain;
 };
@@ -218,12 +228,12 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
     if (L.n_wg + L.n_w16) {
       TimedLaunch t(tm, s, kc.heavy, P::BYTES * L.nnz_heavy);
       hipLaunchKernelGGL((k_level_heavy<P, UNIT>), dim3(L.n_wg + (L.n_w16 + 3) / 4), dim3(WG), 0, s, a, L.cols_wg.p, L.n_wg,
-                         L.cols_w16.p, L.n_w16);
+                         L.cols_w16.p, L.n_w16, xcd_swizzle_enabled());
     }
     if (L.n_w4 + L.n_w1) {
       TimedLaunch t(tm, s, kc.light, P::BYTES * L.nnz_light);
       hipLaunchKernelGGL((k_level_light<P, UNIT>), dim3((L.n_w4 + 3) / 4 + (L.n_w1 + 3) / 4), dim3(WG), 0, s, a, L.cols_w4.p,
-                         L.n_w4, L.cols_w1.p, L.n_w1);
+                         L.n_w4, L.cols_w1.p, L.n_w1, xcd_swizzle_enabled());
     }
     if (L.n_huge) {
       {
@@ -262,8 +272,12 @@ static int coop_capacity() {
   MFM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, k_long_coop<P, false>, WG, 0));
   MFM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, k_long_coop<P, true>, WG, 0));
   int per_cu = std::min(per_cu_a, per_cu_b);
-  // the occupancy API can over-report by one block per CU (MI355X_MICROARCH.md): take one off, cap at 3
-  per_cu = std::max(1, std::min(per_cu - 1, 3));
+  // The occupancy API over-reports by one block per CU only where the SGPR budget binds (7 vs 8 blocks,
+  // MI355X_MICROARCH.md "Residency"); this kernel is VGPR-bound at 2-4 blocks. Other streams' kernels can
+  // delay residency but never wait on anything, and the spin is bounded.
+  if (per_cu >= 7) per_cu -= 1;
+  per_cu = std::max(1, std::min(per_cu, 4));
+  if (const char *e = std::getenv("MFM_COOP_PER_CU")) per_cu = std::max(1, std::atoi(e));
   return std::max(8, cus * per_cu);
 }
 

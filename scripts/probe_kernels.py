@@ -18,17 +18,34 @@ ap.add_argument("--items", type=int, default=10677)
 ap.add_argument("--rank", type=int, default=32)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--unsorted", action="store_true")
+ap.add_argument("--only", default="both", choices=["both", "users", "items"])
+ap.add_argument("--ublock", type=int, default=0, help="re-sort rows by (user // ublock, item)")
+ap.add_argument("--ml", action="store_true", help="ML-10M-like popularity (bench.py data)")
 a = ap.parse_args()
 
 t0 = time.time()
-X, y, shapes = ds.onehot_mf(a.rows, a.users, a.items, rank_true=8, seed=1, sort_by_user=not a.unsorted)
+if a.ml:
+    X, y, shapes = ds.movielens_like(a.rows, a.users, a.items, seed=1)
+else:
+    X, y, shapes = ds.onehot_mf(a.rows, a.users, a.items, rank_true=8, seed=1, sort_by_user=not a.unsorted)
+if a.ublock:
+    Xc = X.tocsr()
+    u = Xc.indices[0::2].astype(np.int64)
+    it = Xc.indices[1::2].astype(np.int64)
+    order = np.lexsort((it, u // a.ublock))
+    X = Xc[order]
+    y = y[order]
+if a.only == "users":
+    X, shapes = X[:, : a.users].tocsr(), [a.users]
+elif a.only == "items":
+    X, shapes = X[:, a.users:].tocsr(), [a.items]
 gi = ds.group_index_from_shapes(shapes)
 print("data %.1fs  N=%d nnz=%d D=%d" % (time.time() - t0, X.shape[0], X.nnz, X.shape[1]), flush=True)
 t0 = time.time()
 c = _capi.Context(X, y, rank=a.rank, group_index=gi)
 print("setup %.1fs plan=%s" % (time.time() - t0, c.plan_info()), flush=True)
 rng = np.random.default_rng(0)
-D, K, G = c.D, a.rank, 2
+D, K, G = c.D, a.rank, len(shapes)
 c.set_state(0.1, rng.normal(size=D) * 0.1, rng.normal(size=(D, K)) * 0.1)
 c.update_e_regression()
 lam_w, mu_w = np.ones(G), np.zeros(G)
