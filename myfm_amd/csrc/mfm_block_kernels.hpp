@@ -369,7 +369,7 @@ static void block_sweep_w(hipStream_t s, Timing &tm, LongScratch &ls, DevBlock &
   block_unsync<true>(s, tm, B, N, eq);             // :268-275
   SweepArgs a = block_args(B, w, z, group, lam, mu, alpha);
   const SweepClasses kc{KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP,
-                        KC_BLOCK_SWEEP};
+                        KC_BLOCK_SWEEP, KC_BLOCK_SWEEP};
   run_plan<PBlockW>(s, tm, B.plan_W, a, ls, kc, false);  // :276-302
   block_rowcache(s, tm, B, w + B.col_off, false);  // :304-305
   block_resync<true>(s, tm, B, N, eq);             // :306-311
@@ -382,7 +382,7 @@ static void block_sweep_V(hipStream_t s, Timing &tm, LongScratch &ls, DevBlock &
   block_unsync<false>(s, tm, B, N, eq);  // :401-417
   SweepArgs a = block_args(B, Vf, zf, group, lamf, muf, alpha);
   const SweepClasses kc{KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP,
-                        KC_BLOCK_SWEEP};
+                        KC_BLOCK_SWEEP, KC_BLOCK_SWEEP};
   run_plan<PBlockV>(s, tm, B.plan_V, a, ls, kc, false);  // :419-470
   block_resync<false>(s, tm, B, N, eq);  // :473-480
 }

@@ -112,6 +112,7 @@ enum KernelClass {
   KC_SWEEP_V_LIGHT,    // latent sweep, columns <= 256 entries (wavefront per column)  FMTrainer.hpp:343-376
   KC_SWEEP_V_HEAVY,    // latent sweep, columns <= 4096 entries (wavefront x16 / workgroup per column)
   KC_SWEEP_V_COOP,     // latent sweep, long columns: co-resident chunks, single pass
+  KC_SWEEP_V_SCAT,     // latent sweep, scattered level: row-blocked stats / draw / apply
   KC_SWEEP_V_LSTATS,   // latent sweep, huge columns: partial statistics
   KC_SWEEP_V_LDRAW,    //   ... draw
   KC_SWEEP_V_LAPPLY,   //   ... apply
@@ -119,6 +120,7 @@ enum KernelClass {
   KC_SWEEP_W_LIGHT,    // linear sweep                                      FMTrainer.hpp:237-254
   KC_SWEEP_W_HEAVY,
   KC_SWEEP_W_COOP,
+  KC_SWEEP_W_SCAT,
   KC_SWEEP_W_LSTATS,
   KC_SWEEP_W_LDRAW,
   KC_SWEEP_W_LAPPLY,
@@ -139,9 +141,9 @@ enum KernelClass {
 };
 
 static const char *const kKernelClassNames[KC_N] = {
-    "qbuild_spmv",        "sweep_V_light",     "sweep_V_heavy",      "sweep_V_coop",       "sweep_V_huge_stats",
+    "qbuild_spmv",        "sweep_V_light",     "sweep_V_heavy",      "sweep_V_coop",       "sweep_V_scattered",  "sweep_V_huge_stats",
     "sweep_V_huge_draw",  "sweep_V_huge_apply", "sweep_V_chain",     "sweep_w_light",      "sweep_w_heavy",
-    "sweep_w_coop",       "sweep_w_huge_stats", "sweep_w_huge_draw", "sweep_w_huge_apply", "sweep_w_chain",
+    "sweep_w_coop",       "sweep_w_scattered",  "sweep_w_huge_stats", "sweep_w_huge_draw", "sweep_w_huge_apply", "sweep_w_chain",
     "update_e_score",     "build_vt",
     "reduce_e",           "shift_e",           "group_stats",        "block_rowcache",     "block_unsync",
     "block_resync",       "block_sweep",       "tn_sample",          "oprobit_eval",       "predict"};

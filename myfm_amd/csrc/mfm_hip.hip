@@ -427,8 +427,9 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   {
     HostCsr Xt = transpose_host(c->hX);
     c->X.upload(c->hX, &Xt);
-    c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_capacity<PMainV>());
-    c->plan_W.build(Xt, PMainW::R_W16, PMainW::R_WG, coop_capacity<PMainW>());
+    c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_capacity<PMainV>(), true, c->X.unit);
+    c->plan_W.build(Xt, PMainW::R_W16, PMainW::R_WG, coop_capacity<PMainW>(), true, c->X.unit);
+    c->ls.reserve_cols(std::max(c->plan_V.max_cols_scat, c->plan_W.max_cols_scat));
   }
   c->y.upload(c->hy);
   c->eq.alloc_zero((size_t)c->N, c->stream);
@@ -630,7 +631,7 @@ int mfm_sweep_w(mfm_ctx *ctx, double alpha, const double *lambda_w, const double
   }
   SweepArgs a = main_args(c, c->w.p, zdev, c->lam.p, c->mu.p, alpha);
   const SweepClasses kcw{KC_SWEEP_W_LIGHT, KC_SWEEP_W_HEAVY, KC_SWEEP_W_COOP, KC_SWEEP_W_LSTATS, KC_SWEEP_W_LDRAW,
-                         KC_SWEEP_W_LAPPLY, KC_SWEEP_W_CHAIN};
+                         KC_SWEEP_W_LAPPLY, KC_SWEEP_W_CHAIN, KC_SWEEP_W_SCAT};
   run_plan<PMainW>(s, c->timing, c->plan_W, a, c->ls, kcw, c->X.unit);
   for (auto &B : c->blocks)
     block_sweep_w(s, c->timing, c->ls, *B, c->N, c->eq.p, c->w.p, zdev, c->group.p, c->lam.p, c->mu.p, alpha);
@@ -664,7 +665,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     launch_qbuild(c, Vf);                                                               // :320, :334-337
     SweepArgs a = main_args(c, Vf, zf, lamf, muf, alpha);
     const SweepClasses kcv{KC_SWEEP_V_LIGHT, KC_SWEEP_V_HEAVY, KC_SWEEP_V_COOP, KC_SWEEP_V_LSTATS, KC_SWEEP_V_LDRAW,
-                           KC_SWEEP_V_LAPPLY, KC_SWEEP_V_CHAIN};
+                           KC_SWEEP_V_LAPPLY, KC_SWEEP_V_CHAIN, KC_SWEEP_V_SCAT};
     run_plan<PMainV>(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit);  // :343-376
     for (auto &B : c->blocks)
       block_sweep_V(s, c->timing, c->ls, *B, c->N, c->eq.p, Vf, zf, c->group.p, lamf, muf, alpha);  // :378-482

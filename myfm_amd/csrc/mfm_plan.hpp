@@ -38,6 +38,15 @@ struct ParLevel {
   DevBuf<ChunkDesc> hchunks;
   DevBuf<int32_t> hchunk_ptr;
   int n_hchunks = 0;
+  // scattered level: row-blocked two-pass path (k_scat_*); replaces all the bins above
+  bool scattered = false;
+  int64_t n_ent = 0;
+  int n_cols = 0, n_runs = 0;
+  DevBuf<int2> ent;          // (row, column), sorted by (row block, column, row)
+  DevBuf<double> ent_val;    // same order (empty when the matrix is unit-valued)
+  DevBuf<int32_t> run_base;  // per 64-entry tile: index of its first run
+  DevBuf<int32_t> scols, slot_ptr, slot_idx;
+  DevBuf<double2> slots;
 };
 
 struct ChainRun {
@@ -63,7 +72,75 @@ struct StepPlan {
 
   // r_w16: entries per lane of the 16-wide wavefront bin (0: the policy has none); r_wg: entries per
   // thread of the workgroup bin; coop_max: workgroups that are safely co-resident on the device
-  void build(const HostCsr &csc, int r_w16, int r_wg, int coop_max) {
+  int64_t max_cols_scat = 0;
+
+  // Row-blocked layout for a level whose columns jump between far-apart rows. Returns false (and leaves
+  // L untouched) when the level is small or its columns are mostly contiguous.
+  static bool build_scattered(const HostCsr &csc, const std::vector<int32_t> &cols, int64_t lnnz, bool unit, ParLevel &L) {
+    int64_t min_nnz = 1 << 20;  // below this the level is launch-bound anyway
+    if (const char *e = std::getenv("MFM_SCATTER_MIN_NNZ")) min_nnz = std::atoll(e);
+    if (lnnz < min_nnz) return false;
+    if (const char *e = std::getenv("MFM_NO_SCATTER"))
+      if (std::atoi(e)) return false;
+    int64_t far = 0;
+    for (int32_t j : cols)
+      for (int64_t p = csc.ptr[j] + 1; p < csc.ptr[j + 1]; p++) far += (csc.idx[p] - csc.idx[p - 1]) >= 8;
+    if ((double)far < 0.5 * (double)lnnz) return false;
+    const int64_t N = csc.cols;
+    const int64_t nb = (N + SCAT_RB - 1) / SCAT_RB;
+    std::vector<int64_t> bptr((size_t)nb + 1, 0);
+    for (int32_t j : cols)
+      for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) bptr[csc.idx[p] / SCAT_RB + 1]++;
+    for (int64_t b = 0; b < nb; b++) bptr[b + 1] += bptr[b];
+    std::vector<int2> ent((size_t)lnnz);
+    std::vector<double> ev;
+    if (!unit) ev.resize((size_t)lnnz);
+    {
+      std::vector<int64_t> cur(bptr.begin(), bptr.end() - 1);
+      for (int32_t j : cols)  // ascending column, ascending row inside: (block, column, row) order
+        for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) {
+          const int64_t q = cur[csc.idx[p] / SCAT_RB]++;
+          ent[q] = make_int2(csc.idx[p], j);
+          if (!unit) ev[q] = csc.val[p];
+        }
+    }
+    // runs: maximal stretches of one column inside a 64-entry tile
+    const int64_t n_tiles = (lnnz + WAVE - 1) / WAVE;
+    std::vector<int32_t> run_base((size_t)n_tiles + 1, 0);
+    std::vector<int32_t> run_col;
+    run_col.reserve((size_t)(lnnz / 4));
+    for (int64_t t = 0; t < n_tiles; t++) {
+      run_base[t] = (int32_t)run_col.size();
+      const int64_t b = t * WAVE, e = std::min<int64_t>(lnnz, b + WAVE);
+      for (int64_t p = b; p < e; p++)
+        if (p == b || ent[p].y != ent[p - 1].y) run_col.push_back(ent[p].y);
+    }
+    run_base[n_tiles] = (int32_t)run_col.size();
+    // per column: its runs in stream order
+    std::vector<int32_t> local((size_t)csc.rows, -1);
+    for (size_t c = 0; c < cols.size(); c++) local[cols[c]] = (int32_t)c;
+    std::vector<int32_t> sptr(cols.size() + 1, 0), sidx(run_col.size());
+    for (int32_t j : run_col) sptr[local[j] + 1]++;
+    for (size_t c = 0; c < cols.size(); c++) sptr[c + 1] += sptr[c];
+    {
+      std::vector<int32_t> cur(sptr.begin(), sptr.end() - 1);
+      for (size_t r = 0; r < run_col.size(); r++) sidx[cur[local[run_col[r]]]++] = (int32_t)r;
+    }
+    L.scattered = true;
+    L.n_ent = lnnz;
+    L.n_cols = (int)cols.size();
+    L.n_runs = (int)run_col.size();
+    L.ent.upload(ent.data(), ent.size());
+    if (!unit) L.ent_val.upload(ev);
+    L.run_base.upload(run_base);
+    L.scols.upload(cols);
+    L.slot_ptr.upload(sptr);
+    L.slot_idx.upload(sidx);
+    L.slots.alloc((size_t)std::max<size_t>(run_col.size(), 1));
+    return true;
+  }
+
+  void build(const HostCsr &csc, int r_w16, int r_wg, int coop_max, bool allow_scatter = false, bool unit = false) {
     const int64_t cap_w1 = WAVE, cap_w4 = 4 * WAVE, cap_w16 = (int64_t)r_w16 * WAVE, cap_wg = (int64_t)r_wg * WG;
     std::vector<int32_t> level;
     n_levels = column_levels(csc, level);
@@ -96,6 +173,11 @@ struct StepPlan {
       flush_run();
       steps.emplace_back();
       ParLevel &L = steps.back().par;
+      if (allow_scatter && build_scattered(csc, by_level[l], lnnz, unit, L)) {
+        launches += 3;
+        max_cols_scat = std::max<int64_t>(max_cols_scat, csc.rows);
+        continue;
+      }
       std::vector<int32_t> w1, w4, w16, wg, lg, hg, lptr, hptr;
       std::vector<ChunkDesc> lch, hch;
       for (int32_t j : by_level[l]) {
@@ -176,6 +258,10 @@ struct StepPlan {
 struct LongScratch {
   DevBuf<double2> partial, oldnew;
   DevBuf<int> error;  // set by k_long_coop on a spin timeout
+  DevBuf<double2> oldnew_col;  // scattered levels: (old, new) per column of the matrix
+  void reserve_cols(int64_t n_cols) {
+    if ((size_t)n_cols > oldnew_col.n) oldnew_col.alloc((size_t)n_cols);
+  }
   void reserve(int max_chunks, int max_long) {
     if ((size_t)max_chunks > partial.n) partial.alloc((size_t)max_chunks);
     if ((size_t)max_long > oldnew.n) oldnew.alloc((size_t)max_long);
@@ -190,13 +276,13 @@ static inline int xcd_swizzle_enabled() {
   static int v = -1;
   if (v < 0) {
     const char *e = std::getenv("MFM_XCD_SWIZZLE");
-    v = e ? std::atoi(e) : 0;
+    v = e ? std::atoi(e) : 1;
   }
   return v;
 }
 
 struct SweepClasses {
-  int light, heavy, coop, hstats, hdraw, happly, chain;
+  int light, heavy, coop, hstats, hdraw, happly, chain, scat;
 };
 
 template <class P, bool UNIT>
@@ -209,6 +295,18 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
       continue;
     }
     const ParLevel &L = st.par;
+    if (L.scattered) {
+      TimedLaunch t(tm, s, kc.scat, P::BYTES * L.n_ent);
+      const int swz = xcd_swizzle_enabled();
+      const int n_wg_s = (int)((L.n_ent + WG - 1) / WG);
+      hipLaunchKernelGGL((k_scat_stats<P, UNIT>), dim3(n_wg_s), dim3(WG), 0, s, a, L.ent.p, L.ent_val.p, L.n_ent, L.run_base.p,
+                         L.slots.p, n_wg_s, swz);
+      hipLaunchKernelGGL((k_scat_draw<P>), dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.slot_ptr.p,
+                         L.slot_idx.p, L.slots.p, ls.oldnew_col.p);
+      hipLaunchKernelGGL((k_scat_apply<P, UNIT>), dim3(n_wg_s), dim3(WG), 0, s, a, L.ent.p, L.ent_val.p, L.n_ent,
+                         ls.oldnew_col.p, n_wg_s, swz);
+      continue;
+    }
     // the long columns first: they are the critical path of the level
     if (L.n_long) {
       L.epoch++;

@@ -137,6 +137,36 @@ def test_full_iterations_match_oracle(oracle, capi, name):
     np.testing.assert_allclose(c.get_e(), t.e(X.shape[0]), rtol=1e-7, atol=1e-7)
 
 
+def test_scattered_level_path(oracle, capi, monkeypatch):
+    # the row-blocked two-pass path (k_scat_*) is chosen for large scattered levels only; force it on a
+    # small unsorted design (both one-hot fields jump between far-apart rows) and on non-unit values
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    X, y, shapes = ds.onehot_mf(200000, 700, 90, seed=5, sort_by_user=False)
+    gi = ds.group_index_from_shapes(shapes)
+    for scale in (None, 0.5):
+        Xs = X.copy()
+        if scale:
+            Xs.data = np.where(np.arange(Xs.nnz) % 3 == 0, scale, 1.5)
+        t, c, _ = _pair(oracle, capi, Xs, y, gi, 3)
+        drv = CapiGibbs(c, t.clone(), X.shape[0], gi)
+        for it in range(3):
+            t.step()
+            drv.step()
+        np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(c.get_state()[1], t.fm()[1], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(c.get_e(), t.e(X.shape[0]), rtol=1e-7, atol=1e-7)
+        assert "sweep_V_scattered" in _timing_classes(c, drv)  # (runs one more sweep: keep it last)
+
+
+def _timing_classes(c, drv):
+    c.timing_enable(True)
+    c.timing_reset()
+    drv.c.sweep_V(0, 1, drv.alpha, drv.lam_V, drv.mu_V, np.zeros(c.D))
+    names = set(c.timing())
+    c.timing_enable(False)
+    return names
+
+
 @pytest.mark.parametrize("design", ["onehot", "multihot"])
 def test_blocks_match_oracle_and_flat(oracle, capi, design):
     # tests/regression/test_block.py:80-149 on the device path + against the oracle
