@@ -67,47 +67,59 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c)
 //   k = 623        : x'[396] ^ twist(x[623], x'[0]),  x'[396] = x[566]^G[169]^G[396], x'[0] = x[397]^G[0]
 // so a whole block is ONE parallel step (624 threads, double-buffered in LDS, one barrier per block)
 // instead of three dependent 227-wide fronts.
-constexpr int MT_GEN_THREADS = 640;
+// The ring holds the UNTEMPERED state words; consumers apply mt_temper() when they read (they run on
+// the whole GPU, the generator is the one serial chain and is instruction-issue bound on its CU).
+// Word 623 needs two dependent twists: it is computed by lane 0 of an eleventh wave so that no wave
+// executes two code paths.
+constexpr int MT_GEN_THREADS = 704;
 __device__ __forceinline__ uint32_t mt_G(const uint32_t *x, int k) { return mt_twist(x[k], x[k + 1], 0u); }
 
 __global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate(RngState *__restrict__ st, uint32_t *__restrict__ raw,
                                                                 uint64_t mask, uint64_t need) {
   __shared__ uint32_t buf[2][MT_N + 1];
   const int t = threadIdx.x;
+  __builtin_amdgcn_s_setprio(3);
   if (t < MT_N) buf[0][t] = st->mt[t];
   int pos = st->mt_pos;
   uint64_t p_gen = st->p_gen;
   const uint64_t target = st->p_cons + need;
+  const uint32_t m32 = (uint32_t)mask;  // the ring has < 2^32 entries
   __syncthreads();
   int cur = 0;
   if (pos < MT_N && p_gen < target) {  // the not yet emitted tail of the current block
-    if (t >= pos && t < MT_N) raw[(p_gen + (uint64_t)(t - pos)) & mask] = mt_temper(buf[0][t]);
+    if (t >= pos && t < MT_N) raw[(p_gen + (uint64_t)(t - pos)) & mask] = buf[0][t];
     p_gen += (uint64_t)(MT_N - pos);
     pos = MT_N;
   }
+  // element this thread produces: threads 0..622 their own index, thread 640 (wave 10, lane 0) word 623
+  const int k = t < 623 ? t : (t == 640 ? 623 : -1);
+  uint32_t off = (uint32_t)p_gen & m32;
   while (p_gen < target) {
     const uint32_t *x = buf[cur];
     uint32_t *xn = buf[cur ^ 1];
-    if (t < MT_N) {
+    if (k >= 0) {
       uint32_t v;
-      if (t < 227) {
-        v = x[t + 397] ^ mt_G(x, t);
-      } else if (t < 454) {
-        v = x[t + 170] ^ mt_G(x, t - 227) ^ mt_G(x, t);
-      } else if (t < 623) {
-        v = x[t - 57] ^ mt_G(x, t - 454) ^ mt_G(x, t - 227) ^ mt_G(x, t);
+      if (k < 227) {
+        v = x[k + 397] ^ mt_G(x, k);
+      } else if (k < 454) {
+        v = x[k + 170] ^ mt_G(x, k - 227) ^ mt_G(x, k);
+      } else if (k < 623) {
+        v = x[k - 57] ^ mt_G(x, k - 454) ^ mt_G(x, k - 227) ^ mt_G(x, k);
       } else {
         const uint32_t x0n = x[397] ^ mt_G(x, 0);
         const uint32_t x396n = x[566] ^ mt_G(x, 169) ^ mt_G(x, 396);
         v = mt_twist(x[623], x0n, x396n);
       }
-      xn[t] = v;
-      raw[(p_gen + (uint64_t)t) & mask] = mt_temper(v);
+      xn[k] = v;
+      raw[(off + (uint32_t)k) & m32] = v;
     }
     p_gen += MT_N;
+    off += MT_N;
     cur ^= 1;
-    __syncthreads();
+    // LDS-only barrier: __syncthreads() would also drain vmcnt (wait for this block's global stores)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
+  __syncthreads();
   if (t < MT_N) st->mt[t] = buf[cur][t];
   if (t == 0) {
     st->mt_pos = pos;
@@ -126,7 +138,7 @@ __device__ __forceinline__ double canonical(uint32_t lo, uint32_t hi) {
 struct RawReader {
   const uint32_t *raw;
   uint64_t mask, p;
-  __device__ __forceinline__ uint32_t next() { return raw[(p++) & mask]; }
+  __device__ __forceinline__ uint32_t next() { return mt_temper(raw[(p++) & mask]); }
   __device__ __forceinline__ double uniform() {
     const uint32_t lo = next();
     const uint32_t hi = next();
@@ -213,8 +225,8 @@ __global__ __launch_bounds__(RNG_CONSUME_THREADS) void k_rng_consume(RngState *_
 #pragma unroll
       for (int r = 0; r < RNG_ATT; r++) {
         const uint64_t base = p + 4ull * (uint64_t)(r * RNG_CONSUME_THREADS + tid);
-        const uint32_t u0 = raw[(base + 0) & mask], u1 = raw[(base + 1) & mask];
-        const uint32_t u2 = raw[(base + 2) & mask], u3 = raw[(base + 3) & mask];
+        const uint32_t u0 = mt_temper(raw[(base + 0) & mask]), u1 = mt_temper(raw[(base + 1) & mask]);
+        const uint32_t u2 = mt_temper(raw[(base + 2) & mask]), u3 = mt_temper(raw[(base + 3) & mask]);
         const double x = 2.0 * canonical(u0, u1) - 1.0;
         const double y = 2.0 * canonical(u2, u3) - 1.0;
         const double r2 = x * x + y * y;
@@ -293,8 +305,8 @@ __global__ __launch_bounds__(256) void k_norm_eval(const RngState *__restrict__ 
   for (int r = 0; r < 4; r++) {
     const int64_t a = (int64_t)blockIdx.x * NORM_CHUNK + r * 256 + tid;
     const uint64_t base = p + 4ull * (uint64_t)a;
-    const uint32_t u0 = raw[(base + 0) & mask], u1 = raw[(base + 1) & mask];
-    const uint32_t u2 = raw[(base + 2) & mask], u3 = raw[(base + 3) & mask];
+    const uint32_t u0 = mt_temper(raw[(base + 0) & mask]), u1 = mt_temper(raw[(base + 1) & mask]);
+    const uint32_t u2 = mt_temper(raw[(base + 2) & mask]), u3 = mt_temper(raw[(base + 3) & mask]);
     const double x = 2.0 * canonical(u0, u1) - 1.0;
     const double y = 2.0 * canonical(u2, u3) - 1.0;
     const double r2 = x * x + y * y;
