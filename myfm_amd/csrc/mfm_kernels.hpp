@@ -35,6 +35,7 @@ struct SweepArgs {
   const double *lambda;  // [G] for this sweep
   const double *mu;      // [G]
   double alpha;
+  int rec2 = 4;          // stride of a relation-block record in 16-byte words (5 when staged in LDS: bank spread)
 };
 
 struct ChunkDesc {
@@ -43,10 +44,35 @@ struct ChunkDesc {
   int32_t lcol;  // index into the level's long-column list
 };
 
+// value of lane K (compile-time) broadcast to the wave through SGPRs (v_readlane), no LDS crossbar
+__device__ __forceinline__ double readlane_f64(double v, int k) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int k) {
+  const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), k);
+  const int hi = __builtin_amdgcn_readlane((int)(v >> 32), k);
+  return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// Sum over the 64 lanes, identical in every lane, fixed order. DPP data-parallel primitives (row_shr
+// 1/2/4/8 inside the 16-lane rows, row_bcast15 / row_bcast31 across rows; lanes without a source add
+// +0.0) instead of six dependent ds_bpermute round trips: the reduction sits on the critical path of
+// every conditional draw.
 __device__ __forceinline__ double wave_allreduce_sum(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
-  return v;
+  v += dpp_f64<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_f64<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_f64<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_f64<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row holds the row sum
+  v += dpp_f64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_f64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  return readlane_f64(v, 63);
 }
 
 // all threads of the workgroup obtain the same totals; fixed summation tree (deterministic).
@@ -84,7 +110,7 @@ __device__ __forceinline__ double sample_normal_z(double quad, double first, dou
 // ---------------------------------------------------------------------------------------------
 // latent factors, main table: FMTrainer.hpp:343-376
 struct PMainV {
-  static constexpr int R_W16 = 16, R_WG = 16;
+  static constexpr int R_W16 = 16, R_WG = 16, REC_DOUBLES = 2;
   static constexpr double BYTES = 44.0, STAT_BYTES = 28.0;  // per nnz: CSC 12 + eq 16 (+ eq 16 write)
   typedef double2 St;
   static __device__ __forceinline__ St load(const SweepArgs &a, int row) { return ((const double2 *)a.state)[row]; }
@@ -113,7 +139,7 @@ struct PMainV {
 
 // linear weights, main table: FMTrainer.hpp:237-254
 struct PMainW {
-  static constexpr int R_W16 = 16, R_WG = 16;
+  static constexpr int R_W16 = 16, R_WG = 16, REC_DOUBLES = 2;
   static constexpr double BYTES = 28.0, STAT_BYTES = 20.0;
   typedef double St;
   static __device__ __forceinline__ St load(const SweepArgs &a, int row) { return ((const double2 *)a.state)[row].x; }
@@ -144,11 +170,11 @@ struct BlockRec {
 
 // latent factors, relation block: FMTrainer.hpp:419-470
 struct PBlockV {
-  static constexpr int R_W16 = 0, R_WG = 4;   // 64-byte records: keep the register budget bounded
+  static constexpr int R_W16 = 0, R_WG = 4, REC_DOUBLES = 8;   // 64-byte records: keep the register budget bounded
   static constexpr double BYTES = 12.0 + 64.0 + 48.0, STAT_BYTES = 12.0 + 64.0;
   typedef BlockRec St;
   static __device__ __forceinline__ St load(const SweepArgs &a, int row) {
-    const double2 *r = (const double2 *)a.state + (int64_t)row * 4;
+    const double2 *r = (const double2 *)a.state + (int64_t)row * a.rec2;
     St s;
     s.qq = r[0];
     s.cc = r[1];
@@ -174,7 +200,7 @@ struct PBlockV {
     s.qq.y += delta * (fresh + old) * x * x;                  // :458-459
     s.ee.x += x * delta * (h_B * s.kk.x + s.cc.x);            // :461-464
     s.ee.y += x * delta * (h_B * s.cc.x + s.cc.y);            // :465-468
-    double2 *r = (double2 *)a.state + (int64_t)row * 4;
+    double2 *r = (double2 *)a.state + (int64_t)row * a.rec2;
     r[0] = s.qq;
     r[2] = s.ee;
   }
@@ -182,13 +208,13 @@ struct PBlockV {
 
 // linear weights, relation block: FMTrainer.hpp:276-302
 struct PBlockW {
-  static constexpr int R_W16 = 0, R_WG = 8;
+  static constexpr int R_W16 = 0, R_WG = 8, REC_DOUBLES = 8;
   static constexpr double BYTES = 12.0 + 32.0 + 8.0, STAT_BYTES = 12.0 + 32.0;
   struct St {
     double e, card;
   };
   static __device__ __forceinline__ St load(const SweepArgs &a, int row) {
-    const double2 *r = (const double2 *)a.state + (int64_t)row * 4;
+    const double2 *r = (const double2 *)a.state + (int64_t)row * a.rec2;
     St s;
     s.e = r[2].x;
     s.card = r[3].x;
@@ -208,7 +234,7 @@ struct PBlockW {
   }
   static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St s, double old, double fresh) {
     s.e += (x * s.card) * (fresh - old);  // :298-301
-    ((double *)a.state)[(int64_t)row * BLOCK_REC + 4] = s.e;
+    ((double *)a.state)[(int64_t)row * (2 * a.rec2) + 4] = s.e;
   }
 };
 
@@ -545,6 +571,132 @@ __global__ __launch_bounds__(CHAIN_WG) void k_chain(SweepArgs a, const int32_t *
     if (threadIdx.x == 0) a.theta[j] = fresh;
     __syncthreads();  // this column's stores are visible to the workgroup before the next column loads
   }
+}
+
+// ---- sequential chain, state resident in LDS ---------------------------------------------------------
+// When the table's per-row state fits in LDS (small relation blocks: B x 64 bytes, toy main tables),
+// ONE wavefront walks the chain with the state staged in LDS for the whole launch: a column then costs
+// LDS round trips instead of L2/HBM latency. Columns are processed in batches of CHAIN_CB; everything
+// a column needs from global memory (descriptor, old coefficient, variate, group hyper-parameters and
+// its first 64 entries) is prefetched into registers one batch ahead, descriptors two batches ahead.
+struct ChainDesc {
+  int64_t begin;
+  int32_t len;
+  int32_t col;
+};
+constexpr int CHAIN_CB = 16;
+
+template <class P>
+__global__ __launch_bounds__(WAVE) void k_chain_lds(SweepArgs a, const ChainDesc *__restrict__ desc, int n_cols,
+                                                    int64_t n_rows, int rec_doubles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CB = CHAIN_CB;
+  double2 *lst = (double2 *)smem;
+  const int lane = threadIdx.x;
+  const int w16 = rec_doubles / 2;              // 16-byte words per record in global memory
+  const int l16 = w16 > 1 ? w16 + 1 : w16;      // ... in LDS: 64-byte records are padded to 80 bytes (bank spread)
+  const int64_t n16 = n_rows * w16;
+  double2 *gst = (double2 *)a.state;
+  for (int64_t i = lane; i < n16; i += WAVE) lst[(i / w16) * l16 + (i % w16)] = gst[i];
+  SweepArgs al = a;
+  al.state = lst;
+  al.rec2 = l16;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+  // per-lane (lane < CB) column scalars and per-column entry registers: cur = batch being processed,
+  // nxt = batch in flight, dsc = descriptors two batches ahead
+  ChainDesc dsc = {0, 0, 0};
+  int32_t c_col = 0, n_col = 0, c_len = 0, n_len = 0;
+  int64_t c_begin = 0, n_begin = 0;
+  double c_old = 0, n_old = 0, c_z = 0, n_z = 0, c_lam = 0, n_lam = 0, c_mu = 0, n_mu = 0;
+  int32_t cidx[CB], nidx[CB];
+  double cval[CB], nval[CB];
+  auto load_desc = [&](int base) {
+    dsc.len = 0;
+    if (lane < CB && base + lane < n_cols) dsc = desc[base + lane];
+  };
+  auto load_batch = [&]() {  // from dsc into nxt
+    n_col = dsc.col;
+    n_len = dsc.len;
+    n_begin = dsc.begin;
+    int g = 0;
+    if (lane < CB && n_len >= 0 && n_col >= 0) {
+      n_old = a.theta[n_col];
+      n_z = a.z[n_col];
+      g = a.group[n_col];
+    }
+#pragma unroll
+    for (int k = 0; k < CB; k++) {
+      const int64_t b = readlane_i64(n_begin, k);
+      const int l = __builtin_amdgcn_readlane(n_len, k);
+      nidx[k] = -1;
+      nval[k] = 0.0;
+      if (lane < l) {
+        nidx[k] = a.rowidx[b + lane];
+        nval[k] = a.val[b + lane];
+      }
+    }
+    if (lane < CB) {
+      n_lam = a.lambda[g];
+      n_mu = a.mu[g];
+    }
+  };
+  load_desc(0);
+  load_batch();
+  load_desc(CB);
+  for (int base = 0; base < n_cols; base += CB) {
+    // rotate: nxt -> cur, start the loads of the following batch
+    c_col = n_col;
+    c_len = n_len;
+    c_begin = n_begin;
+    c_old = n_old;
+    c_z = n_z;
+    c_lam = n_lam;
+    c_mu = n_mu;
+#pragma unroll
+    for (int k = 0; k < CB; k++) {
+      cidx[k] = nidx[k];
+      cval[k] = nval[k];
+    }
+    if (base + CB < n_cols) {
+      load_batch();
+      load_desc(base + 2 * CB);
+    }
+#pragma unroll
+    for (int k = 0; k < CB; k++) {
+      if (base + k < n_cols) {
+        const int cj = __builtin_amdgcn_readlane(c_col, k);
+        const int clen = __builtin_amdgcn_readlane(c_len, k);
+        const int64_t cbegin = readlane_i64(c_begin, k);
+        const double old = readlane_f64(c_old, k);
+        double S1 = 0.0, S2 = 0.0;
+        typename P::St st0;
+        if (lane < clen) {
+          st0 = P::load(al, cidx[k]);
+          P::stats(cval[k], st0, old, S1, S2);
+        }
+        for (int p = lane + WAVE; p < clen; p += WAVE) {
+          const int32_t row = a.rowidx[cbegin + p];
+          const double x = a.val[cbegin + p];
+          const typename P::St st = P::load(al, row);
+          P::stats(x, st, old, S1, S2);
+        }
+        S1 = wave_allreduce_sum(S1);
+        S2 = wave_allreduce_sum(S2);
+        const double fresh = P::draw(S1, S2, old, a.alpha, readlane_f64(c_lam, k), readlane_f64(c_mu, k), readlane_f64(c_z, k));
+        if (lane < clen) P::apply(al, cidx[k], cval[k], st0, old, fresh);
+        for (int p = lane + WAVE; p < clen; p += WAVE) {
+          const int32_t row = a.rowidx[cbegin + p];
+          const double x = a.val[cbegin + p];
+          const typename P::St st = P::load(al, row);
+          P::apply(al, row, x, st, old, fresh);
+        }
+        if (lane == 0) a.theta[cj] = fresh;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+    }
+  }
+  for (int64_t i = lane; i < n16; i += WAVE) gst[i] = lst[(i / w16) * l16 + (i % w16)];
 }
 
 // ---- q-cache build: q = X v_f (+ block contributions)  (FMTrainer.hpp:320-340), CSR SpMV --------

@@ -50,6 +50,7 @@ struct ParLevel {
 };
 
 struct ChainRun {
+  DevBuf<ChainDesc> desc;  // (first CSC entry, length, column) per chain column, for k_chain_lds
   DevBuf<int32_t> cols;
   int n_cols = 0;
   int64_t nnz = 0;
@@ -61,9 +62,12 @@ struct Step {
   ChainRun chain;
 };
 
+constexpr size_t CHAIN_LDS_MAX = 156 * 1024;  // of the CU's 160 KiB
+
 struct StepPlan {
   std::vector<Step> steps;
   int n_levels = 0;
+  int64_t n_state_rows = 0;  // rows of the table whose state the sweeps touch (= csc.cols)
   int max_hchunks = 0, max_huge = 0;
   int64_t launches = 0;
 
@@ -141,6 +145,7 @@ struct StepPlan {
   }
 
   void build(const HostCsr &csc, int r_w16, int r_wg, int coop_max, bool allow_scatter = false, bool unit = false) {
+    n_state_rows = csc.cols;
     const int64_t cap_w1 = WAVE, cap_w4 = 4 * WAVE, cap_w16 = (int64_t)r_w16 * WAVE, cap_wg = (int64_t)r_wg * WG;
     std::vector<int32_t> level;
     n_levels = column_levels(csc, level);
@@ -158,6 +163,11 @@ struct StepPlan {
       s.chain.n_cols = (int)run.size();
       s.chain.nnz = run_nnz;
       s.chain.cols.upload(run);
+      {
+        std::vector<ChainDesc> d;
+        for (int32_t j : run) d.push_back(ChainDesc{csc.ptr[j], (int32_t)(csc.ptr[j + 1] - csc.ptr[j]), j});
+        s.chain.desc.upload(d.data(), d.size());
+      }
       launches += 1;
       run.clear();
       run_nnz = 0;
@@ -291,7 +301,13 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
   for (const Step &st : plan.steps) {
     if (st.is_chain) {
       TimedLaunch t(tm, s, kc.chain, P::BYTES * st.chain.nnz);
-      hipLaunchKernelGGL((k_chain<P>), dim3(1), dim3(CHAIN_WG), 0, s, a, st.chain.cols.p, st.chain.n_cols);
+      const size_t lds_bytes = (size_t)plan.n_state_rows * (P::REC_DOUBLES > 2 ? P::REC_DOUBLES + 2 : P::REC_DOUBLES) * sizeof(double);
+      if (plan.n_state_rows > 0 && lds_bytes <= CHAIN_LDS_MAX) {
+        hipLaunchKernelGGL((k_chain_lds<P>), dim3(1), dim3(WAVE), lds_bytes, s, a, st.chain.desc.p, st.chain.n_cols,
+                           plan.n_state_rows, (int)P::REC_DOUBLES);
+      } else {
+        hipLaunchKernelGGL((k_chain<P>), dim3(1), dim3(CHAIN_WG), 0, s, a, st.chain.cols.p, st.chain.n_cols);
+      }
       continue;
     }
     const ParLevel &L = st.par;
@@ -355,6 +371,12 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
 template <class P>
 static void run_plan(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls,
                      const SweepClasses &kc, bool unit) {
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {  // dynamic LDS above 64 KiB must be opted into
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_lds<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)CHAIN_LDS_MAX));
+    lds_attr_set = true;
+  }
   if (unit)
     run_plan_t<P, true>(s, tm, plan, a, ls, kc);
   else
