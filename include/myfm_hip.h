@@ -177,6 +177,7 @@ int mfm_design_add_block(mfm_design *d, int64_t B, int64_t Db, const int64_t *in
 void mfm_design_destroy(mfm_design *d);
 const char *mfm_design_last_error(const mfm_design *d);
 int64_t mfm_design_dim_all(const mfm_design *d);
+int64_t mfm_design_n_rows(const mfm_design *d);
 /* mode 0: out[N]  = mean_s score_s                    (Predictor::predict, regression)
  * mode 1: out[N]  = mean_s Phi(score_s)               (classification, predictor.hpp:138-143)
  * mode 2: out[N * (n_cut + 1)] row-major = mean_s ordered-probit class probabilities with
@@ -184,6 +185,11 @@ int64_t mfm_design_dim_all(const mfm_design *d);
  * w0s[S], ws[S * D], Vs[S * D * K] (each sample's V column-major (D, K)).                   */
 int mfm_design_predict(mfm_design *d, int32_t rank, int32_t n_samples, const double *w0s, const double *ws,
                        const double *Vs, int32_t mode, int32_t n_cut, const double *cutpoints, double *out);
+
+/* FM::predict_score of the LIVE sample (the FM* handed to the per-iteration callback,
+ * FMTrainer.hpp:78; utils/callbacks/libfm.py:85): scores design `d` with the (w0, w, V) currently
+ * resident in training context `ctx` -- no download / upload of the model state. Same device only.  */
+int mfm_design_score_ctx(mfm_design *d, mfm_ctx *ctx, double *out);
 
 /* ---- host-only helpers (no device needed; exercised by the CPU test-suite) -------------- */
 /* Level schedule of the columns of a CSR matrix: level[j] = 0 if no earlier

@@ -27,7 +27,7 @@ SYMBOLS = [
     "mfm_timing_n_classes", "mfm_timing_class_name", "mfm_timing_get", "mfm_design_create", "mfm_design_add_block",
     "mfm_design_destroy", "mfm_design_last_error", "mfm_design_dim_all", "mfm_design_predict",
     "mfm_host_column_levels", "mfm_rng_seed_mt19937", "mfm_rng_set_program", "mfm_rng_prefetch", "mfm_rng_acquire",
-    "mfm_rng_get_z",
+    "mfm_rng_get_z", "mfm_design_score_ctx", "mfm_design_n_rows",
 ]
 
 _lib = None
@@ -100,6 +100,9 @@ def lib():
     L.mfm_rng_prefetch.argtypes = [vp]
     L.mfm_rng_acquire.argtypes = [vp, P, i64]
     L.mfm_rng_get_z.argtypes = [vp, P, P]
+    L.mfm_design_score_ctx.argtypes = [vp, vp, P]
+    L.mfm_design_n_rows.restype = i64
+    L.mfm_design_n_rows.argtypes = [vp]
     _lib = L
     return L
 
@@ -373,6 +376,14 @@ class Design:
             self.close()
         except Exception:
             pass
+
+    def score_ctx(self, ctx):
+        """FM::predict_score with the model state resident in training context `ctx`."""
+        out = np.empty(self.N)
+        rc = lib().mfm_design_score_ctx(self.h, ctx.h, _p(out))
+        if rc:
+            _raise(rc, lib().mfm_design_last_error(self.h))
+        return out
 
     def predict(self, samples, mode=0, cutpoints=None):
         """samples: list of (w0, w[D], V[D, K]); mode 0 mean score, 1 mean Phi(score), 2 ordered probit."""

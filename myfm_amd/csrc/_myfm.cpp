@@ -251,6 +251,33 @@ struct FM {
   // live sample handed to callbacks: w / V stay on the GPU until somebody looks at them
   std::function<void(FM &)> fetch;
   bool stale = false;
+  // live sample only: the training context, and the test designs already uploaded for it (the LibFM-like
+  // callbacks score the same X_test object every iteration: libfm.py:85)
+  mfm_ctx *live_ctx = nullptr;
+  struct CachedDesign {
+    py::object X;
+    vector<py::object> rels;
+    std::shared_ptr<DeviceDesign> design;
+  };
+  std::shared_ptr<vector<CachedDesign>> design_cache;
+  std::shared_ptr<DeviceDesign> cached_design(const py::object &Xo, const py::object &relso) {
+    if (!design_cache) design_cache = std::make_shared<vector<CachedDesign>>();
+    vector<py::object> rl;
+    for (auto item : py::reinterpret_borrow<py::sequence>(relso)) rl.push_back(py::reinterpret_borrow<py::object>(item));
+    for (auto &c : *design_cache) {
+      if (c.X.ptr() != Xo.ptr() || c.rels.size() != rl.size()) continue;
+      bool same = true;
+      for (size_t i = 0; i < rl.size(); i++) same = same && c.rels[i].ptr() == rl[i].ptr();
+      if (same) return c.design;
+    }
+    Csr X = csr_from_py(Xo);
+    Relations rels = relations_from_py(relso);
+    check(X, rels);
+    auto dd = std::make_shared<DeviceDesign>(X, rels);
+    if (design_cache->size() >= 4) design_cache->erase(design_cache->begin());
+    design_cache->push_back(CachedDesign{Xo, rl, dd});
+    return dd;
+  }
 
   FM() {}
   explicit FM(int n_factors) : n_factors(n_factors) {}
@@ -265,7 +292,7 @@ struct FM {
     s.w = w;
     s.V = V;
     s.cutpoints = cutpoints;
-    s.initialized = initialized;
+    s.initialized = initialized;  // (a kept sample is detached from the training context)
     return s;
   }
   void ensure() {
@@ -304,6 +331,13 @@ struct FM {
     if (!initialized) throw std::runtime_error("get_score called before initialization");
   }
   py::array_t<double> predict_score(const py::object &Xo, const py::object &relso) {
+    if (live_ctx && stale) {  // score straight from the device-resident state
+      auto dd = cached_design(Xo, relso);
+      py::array_t<double> out((py::ssize_t)mfm_design_n_rows(dd->d));
+      int code = mfm_design_score_ctx(dd->d, live_ctx, out.mutable_data());
+      if (code != MFM_OK) throw_code(code, mfm_design_last_error(dd->d));
+      return out;
+    }
     ensure();
     Csr X = csr_from_py(Xo);
     Relations rels = relations_from_py(relso);
@@ -984,6 +1018,7 @@ struct FMTrainer {
     initialize_e(fm);
     start_device_rng(fm.n_factors);
     fm.fetch = [this](FM &f) { this->download(f); };
+    fm.live_ctx = ctx;
     result.first.samples.reserve((size_t)cfg.n_kept_samples);
     for (int it = 0; it < cfg.n_iter; it++) {
       update_all(fm, hyper);
@@ -995,6 +1030,8 @@ struct FMTrainer {
     }
     fm.ensure();
     fm.fetch = nullptr;
+    fm.live_ctx = nullptr;
+    fm.design_cache.reset();
     for (auto &cs : cutpoint_sampler) result.second.n_mh_accept.emplace_back(cs.accept_count);
     return result;
   }
@@ -1033,6 +1070,7 @@ struct GibbsSession {
     trainer->initialize_e(fm);
     trainer->start_device_rng(fm.n_factors);
     fm.fetch = [this](FM &f) { this->trainer->download(f); };
+    fm.live_ctx = trainer->ctx;
   }
   void step() {
     trainer->update_all(fm, hyper);

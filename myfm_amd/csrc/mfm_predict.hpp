@@ -121,6 +121,37 @@ void mfm_design_destroy(mfm_design *d) {
 
 const char *mfm_design_last_error(const mfm_design *d) { return d ? d->err.c_str() : g_global_error.c_str(); }
 int64_t mfm_design_dim_all(const mfm_design *d) { return d->D; }
+int64_t mfm_design_n_rows(const mfm_design *d) { return d->N; }
+
+int mfm_design_score_ctx(mfm_design *d, mfm_ctx *ctx, double *out) {
+  MFM_TRY(d)
+  ctx->need_final();
+  if (ctx->device != d->device) throw Error(MFM_ERR_INVALID, "design and training context live on different devices");
+  if (d->D != ctx->D) {  // FM.hpp:67-73
+    throw Error(MFM_ERR_INVALID, "Total feature size mismatch. Should be " + std::to_string(ctx->D) + ", but got " +
+                                     std::to_string(d->D) + ".");
+  }
+  const int rank = ctx->K;
+  hipStream_t s = ctx->stream;  // ordered after the sweeps that produced the state
+  if (d->K != rank) {
+    d->K = rank;
+    d->KS = (rank + 1) & ~1;
+    d->Vt.alloc_zero((size_t)std::max<int64_t>(d->D * d->KS, 1), s);
+    d->score.alloc((size_t)std::max<int64_t>(d->N, 1));
+    d->w.alloc((size_t)std::max<int64_t>(d->D, 1));
+    d->V.alloc((size_t)std::max<int64_t>(d->D * rank, 1));
+    for (auto &B : d->blocks) {
+      B->bq.alloc_zero((size_t)B->B * std::max(d->KS, 1), s);
+      B->bl.alloc_zero((size_t)B->B, s);
+      B->bs.alloc_zero((size_t)B->B, s);
+    }
+  }
+  score_design(s, ctx->timing, 1, d->X, d->blocks, d->D, rank, d->KS, ctx->w0, ctx->w.p, ctx->V.p, d->Vt.p, nullptr, nullptr,
+               d->score.p);
+  if (d->N) MFM_HIP_CHECK(hipMemcpyAsync(out, d->score.p, (size_t)d->N * sizeof(double), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipStreamSynchronize(s));
+  MFM_CATCH(d)
+}
 
 int mfm_design_predict(mfm_design *d, int32_t rank, int32_t n_samples, const double *w0s, const double *ws,
                        const double *Vs, int32_t mode, int32_t n_cut, const double *cutpoints, double *out) {

@@ -40,6 +40,38 @@ class RunningMean:
         return False, None
 
 
+def test_libfm_callbacks(myfm, oracle):
+    # utils/callbacks/libfm.py semantics: running means of per-iteration test scores; the live sample is
+    # scored on the device from the resident state (same numbers as scoring the downloaded sample)
+    from myfm_amd.utils import ClassificationCallback, OrderedProbitCallback, RegressionCallback
+
+    X, score = ds.middle_data()
+    y = score + np.random.RandomState(0).normal(0, 1, size=score.shape)
+    cb = RegressionCallback(40, X_test=X, y_test=y, clip_min=-50, clip_max=50)
+    fm = myfm.MyFMGibbsRegressor(3).fit(X, y, n_iter=40, n_kept_samples=40, callback=cb)
+    np.testing.assert_allclose(fm.predict(X), cb.predictions / 40)
+    assert list(cb.result_trace[-1]) == ["alpha", "rmse", "rmse_this", "rmse_all_but_5"]
+    assert np.isnan(cb.result_trace[2]["rmse_all_but_5"]) and cb.result_trace[-1]["rmse"] < 1.5
+    manual = np.mean([s.predict_score(X, []) for s in fm.predictor_.samples[5:]], axis=0)
+    np.testing.assert_allclose(cb.prediction_all_but_5 / 35, manual)
+    # relation blocks through the callback
+    main, X_flat, blocks, yb, shapes = ds.multihot_block_design()
+    rbs = [myfm.RelationBlock(list(m), b) for m, b in blocks]
+    cb = RegressionCallback(10, X_test=main, y_test=yb, X_rel_test=rbs)
+    fm = myfm.MyFMRegressor(3).fit(main, yb, rbs, group_shapes=shapes, n_iter=10, n_kept_samples=10, callback=cb)
+    np.testing.assert_allclose(fm.predict(main, rbs), cb.predictions / 10)
+    yc = y > np.median(y)
+    cb = ClassificationCallback(30, X, yc)
+    clf = myfm.MyFMGibbsClassifier(3).fit(X, yc, n_iter=30, n_kept_samples=30, callback=cb)
+    np.testing.assert_allclose(clf.predict_proba(X), cb.predictions / 30)
+    assert list(cb.result_trace[-1])[:3] == ["log_loss", "log_loss_this", "log_loss_all_but_5"]
+    yo = np.digitize(y, np.quantile(y, [0.25, 0.5, 0.75])).astype(float)
+    cb = OrderedProbitCallback(20, X_test=X, y_test=yo, n_class=4)
+    op = myfm.MyFMOrderedProbit(2).fit(X, yo, n_iter=20, n_kept_samples=20, callback=cb)
+    np.testing.assert_allclose(cb.predictions / 20, op.predict_proba(X))
+    assert cb.result_trace[-1]["accuracy"] > 0.3
+
+
 def test_toy_config1(myfm):
     # BASELINE config 1 / examples/toy.py
     X, y = ds.toy()
