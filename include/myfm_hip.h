@@ -60,6 +60,24 @@ const char *mfm_last_error(const mfm_ctx *ctx);
 int mfm_set_stream(mfm_ctx *ctx, void *hip_stream);
 int mfm_synchronize(mfm_ctx *ctx);
 
+/* ---- row-sharded multi-GPU mode (one process per GPU) ---------------------------------
+ * Every rank holds a contiguous slice of the training rows (its slice of X, y and of every
+ * original_to_block) and a full replica of the model state, hyper-parameters and random variates.
+ * `fn(user, dev_buf, count)` must sum `count` doubles at device address `dev_buf` IN PLACE over all
+ * ranks, enqueued in order on the ctx stream (e.g. torch.distributed.all_reduce on the RCCL backend with
+ * the ctx stream made current, see mfm_set_stream), and return 0. The library calls it once per level
+ * of every sweep (2 |level| doubles), once per (block, factor) for the block statistics, and for
+ * sum e / sum e^2 and the ordered-probit likelihood terms. Must be called before mfm_finalize.        */
+int mfm_set_allreduce(mfm_ctx *ctx, int (*fn)(void *user, void *dev_buf, int64_t count), void *user);
+/* The level schedule of the main table's columns (mfm_host_column_levels of the GLOBAL design): in the
+ * row-sharded mode it must be identical on every rank (a conflict may exist only in another rank's
+ * rows), so the caller computes it before sharding. Checked against the local rows at mfm_finalize.
+ * Relation-block matrices are replicated, their schedules need no hand-over.                          */
+int mfm_set_main_levels(mfm_ctx *ctx, const int32_t *level, int64_t D0);
+/* global index of this rank's first row: keys the per-row Philox streams so that the latent draws of
+ * classification / ordered probit do not depend on how the rows are sharded.                         */
+int mfm_set_row_offset(mfm_ctx *ctx, int64_t first_global_row);
+
 /* main table X (N x D0) and targets y[N]; D0 may be 0 (base.py:230-233).                  */
 int mfm_set_main(mfm_ctx *ctx, int64_t N, int64_t D0, const int64_t *indptr, const int32_t *indices,
                  const double *data, const double *y);

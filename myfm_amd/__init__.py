@@ -14,6 +14,10 @@ if not any(f.startswith("_myfm.") and f.endswith(".so") for f in _os.listdir(_he
         "The package has no pure-Python / CPU fallback."
     )
 
+from ._build import preload_hip_runtime as _preload  # noqa: E402
+
+_hip_runtime = _preload()
+
 from ._myfm import RelationBlock  # noqa: E402
 from .estimators import (  # noqa: E402
     MyFMClassifier,

@@ -65,3 +65,29 @@ def build_all(force=False, verbose=False):
 
 if __name__ == "__main__":
     build_all(force="--force" in sys.argv, verbose=True)
+
+
+def preload_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64 (same sonames as /opt/rocm's). Two HIP
+    runtimes in one process do not coexist (the second one sees no GPU), and the row-sharded mode hands this
+    library's device buffers to torch.distributed. So when torch is installed, its runtime is loaded first
+    and libmyfm_hip.so binds to it; without torch the system ROCm runtime is used. Set
+    MYFM_AMD_SYSTEM_HIP=1 to force the system runtime."""
+    import ctypes
+    import importlib.util
+
+    if os.environ.get("MYFM_AMD_SYSTEM_HIP"):
+        return None
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    lib = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(lib):
+        return None
+    try:
+        return ctypes.CDLL(lib, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        return None

@@ -27,7 +27,7 @@ SYMBOLS = [
     "mfm_timing_n_classes", "mfm_timing_class_name", "mfm_timing_get", "mfm_design_create", "mfm_design_add_block",
     "mfm_design_destroy", "mfm_design_last_error", "mfm_design_dim_all", "mfm_design_predict",
     "mfm_host_column_levels", "mfm_rng_seed_mt19937", "mfm_rng_set_program", "mfm_rng_prefetch", "mfm_rng_acquire",
-    "mfm_rng_get_z", "mfm_design_score_ctx", "mfm_design_n_rows",
+    "mfm_rng_get_z", "mfm_design_score_ctx", "mfm_design_n_rows", "mfm_set_allreduce", "mfm_set_row_offset", "mfm_set_main_levels",
 ]
 
 _lib = None
@@ -42,6 +42,9 @@ def lib():
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH
         )
+    from ._build import preload_hip_runtime
+
+    preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i64, i32, dbl, P = C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p
     u64 = C.c_uint64
@@ -103,6 +106,9 @@ def lib():
     L.mfm_design_score_ctx.argtypes = [vp, vp, P]
     L.mfm_design_n_rows.restype = i64
     L.mfm_design_n_rows.argtypes = [vp]
+    L.mfm_set_allreduce.argtypes = [vp, vp, vp]
+    L.mfm_set_row_offset.argtypes = [vp, i64]
+    L.mfm_set_main_levels.argtypes = [vp, P, i64]
     _lib = L
     return L
 

@@ -735,6 +735,22 @@ struct FMTrainer {
   bool device_rng = false;
   vector<Real> hv;
   size_t hv_pos = 0;
+  // row-sharded multi-GPU mode: this process holds rows [row_offset, row_offset + N) of
+  // N_total; `allreduce(ptr, count)` sums device doubles in place over the ranks
+  int64_t N_total = 0, row_offset = 0;
+  py::object allreduce;
+  uint64_t stream_ptr = 0;
+  vector<int32_t> main_levels;  // level schedule of the GLOBAL main table (sharded mode)
+  static int allreduce_trampoline(void *user, void *buf, int64_t count) {
+    try {
+      (*static_cast<py::object *>(user))((uintptr_t)buf, count);
+      return 0;
+    } catch (py::error_already_set &e) {
+      e.restore();
+      PyErr_Print();
+      return 1;
+    }
+  }
 
   // BaseFMTrainer.hpp:58-105
   FMTrainer(const py::object &Xo, const py::object &relso, const py::object &yo, int random_seed, FMLearningConfig config)
@@ -744,6 +760,7 @@ struct FMTrainer {
     dim_all = check_row_consistency_return_column(X_, rels_);
     y = np_to_vec(yo);
     N = X_.rows;
+    N_total = N;
     D0 = X_.cols;
     if (X_.rows != (int64_t)y.size()) {
       std::ostringstream ss;
@@ -790,8 +807,16 @@ struct FMTrainer {
   void build_device(int rank) {
     if (ctx) return;
     K = rank;
-    int code = mfm_create(0, &ctx);
+    int device = 0;
+    if (const char *e = std::getenv("MYFM_AMD_DEVICE")) device = std::atoi(e);
+    int code = mfm_create(device, &ctx);
     if (code != MFM_OK) throw_code(code, mfm_global_error());
+    if (stream_ptr) ck(ctx, mfm_set_stream(ctx, (void *)stream_ptr));
+    if (!allreduce.is_none() && allreduce.ptr() != nullptr) {
+      ck(ctx, mfm_set_allreduce(ctx, &FMTrainer::allreduce_trampoline, &allreduce));
+      ck(ctx, mfm_set_row_offset(ctx, row_offset));
+    }
+    if (!main_levels.empty()) ck(ctx, mfm_set_main_levels(ctx, main_levels.data(), (int64_t)main_levels.size()));
     ck(ctx, mfm_set_main(ctx, X_.rows, X_.cols, X_.indptr.data(), X_.indices.data(), X_.data.data(), y.data()));
     for (auto &r : rels_) {
       auto m = r->map64();
@@ -844,7 +869,7 @@ struct FMTrainer {
       ops.push_back(mfm_rng_op{MFM_RNG_NORMALS, 0, c, n, 0.0});
       n += c;
     };
-    if (cfg.task_type == TaskType::REGRESSION) gamma((cfg.alpha_0 + N) / 2);     // update_alpha
+    if (cfg.task_type == TaskType::REGRESSION) gamma((cfg.alpha_0 + N_total) / 2);  // update_alpha
     if (cfg.fit_w0) normals_hv(1);                                              // update_w0
     for (size_t g = 0; g < G; g++) gamma((cfg.alpha_0 + n_in_group[g]) / 2);     // update_lambda_w
     normals_hv((int64_t)G);                                                     // update_mu_w
@@ -923,7 +948,7 @@ struct FMTrainer {
     const bool need_alpha = cfg.task_type == TaskType::REGRESSION;
     if (need_alpha || cfg.fit_w0) ck(ctx, mfm_reduce_e(ctx, &sum_e, &sum_e2));
     if (need_alpha) {
-      Real exponent = (cfg.alpha_0 + N) / 2;
+      Real exponent = (cfg.alpha_0 + N_total) / 2;
       Real variance = (cfg.beta_0 + sum_e2) / 2;
       hyper.alpha = sample_gamma(exponent, 1 / variance);
     } else {
@@ -932,8 +957,8 @@ struct FMTrainer {
     if (!cfg.fit_w0) {
       fm.w0 = 0;
     } else {
-      Real w0_lin_term = hyper.alpha * (N * fm.w0 - sum_e);  // sum(w0 - e)
-      Real w0_quad_term = hyper.alpha * N + cfg.reg_0;
+      Real w0_lin_term = hyper.alpha * (N_total * fm.w0 - sum_e);  // sum(w0 - e) over all (ranks') rows
+      Real w0_quad_term = hyper.alpha * N_total + cfg.reg_0;
       Real w0_new = sample_normal(w0_quad_term, w0_lin_term);
       ck(ctx, mfm_shift_e(ctx, w0_new - fm.w0));
       fm.w0 = w0_new;
@@ -1060,8 +1085,18 @@ struct GibbsSession {
   Hyper hyper;
   int it = 0;
   GibbsSession(size_t n_factor, Real init_std, const py::object &X, const py::object &relations, const py::object &y,
-               int random_seed, FMLearningConfig &config)
+               int random_seed, FMLearningConfig &config, py::object allreduce, int64_t n_total_rows, int64_t row_offset,
+               uint64_t stream, py::object main_levels)
       : trainer(new FMTrainer(X, relations, y, random_seed, config)) {
+    trainer->allreduce = allreduce;
+    if (!main_levels.is_none()) {
+      auto lv = py::array_t<int32_t, py::array::c_style | py::array::forcecast>::ensure(main_levels);
+      if (!lv) throw std::invalid_argument("main_levels must be an int32 array");
+      trainer->main_levels.assign(lv.data(), lv.data() + lv.size());
+    }
+    if (n_total_rows > 0) trainer->N_total = n_total_rows;
+    trainer->row_offset = row_offset;
+    trainer->stream_ptr = stream;
     fm = trainer->create_FM((int)n_factor, init_std);
     hyper = trainer->create_Hyper((size_t)fm.n_factors);
     trainer->build_device(fm.n_factors);
@@ -1279,7 +1314,11 @@ PYBIND11_MODULE(_myfm, m) {
 
   // extensions beyond the reference's surface (bench / tests)
   py::class_<GibbsSession>(m, "GibbsSession")
-      .def(py::init<size_t, Real, const py::object &, const py::object &, const py::object &, int, FMLearningConfig &>())
+      .def(py::init<size_t, Real, const py::object &, const py::object &, const py::object &, int, FMLearningConfig &,
+                    py::object, int64_t, int64_t, uint64_t, py::object>(),
+           py::arg("rank"), py::arg("init_std"), py::arg("X"), py::arg("relations"), py::arg("y"), py::arg("random_seed"),
+           py::arg("config"), py::arg("allreduce") = py::none(), py::arg("n_total_rows") = 0, py::arg("row_offset") = 0,
+           py::arg("stream") = 0, py::arg("main_levels") = py::none())
       .def("step", &GibbsSession::step)
       .def("synchronize", &GibbsSession::synchronize)
       .def("residual", &GibbsSession::residual)

@@ -176,6 +176,19 @@ __global__ __launch_bounds__(WG) void k_resync(const int32_t *__restrict__ map, 
   }
 }
 
+// sharded mode: pack / unpack the per-block-row statistics that must be summed over the ranks
+// (V: c, c_S, e, e_q = record words 2..5; w: e = word 4; setup: cardinality = word 6)
+__global__ void k_rec_pack(const double *__restrict__ rec, double *__restrict__ buf, int64_t B, int first, int n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * n) return;
+  buf[i] = rec[(i / n) * BLOCK_REC + first + (i % n)];
+}
+__global__ void k_rec_unpack(double *__restrict__ rec, const double *__restrict__ buf, int64_t B, int first, int n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * n) return;
+  rec[(i / n) * BLOCK_REC + first + (i % n)] = buf[i];
+}
+
 // block-level caches of the fused re-score: per block row  bl = sum_l x w_l,
 // bq[s] = sum_l x v_ls, bs = sum_s sum_l x^2 v_ls^2   (FM.hpp:81, :104-106, :121-127)
 template <int GS, int SPL>
@@ -239,6 +252,7 @@ struct DevBlock {
   DevBuf<int32_t> inv_wave, inv_wg, inv_long, inv_long_chunk_ptr;
   DevBuf<InvChunk> inv_chunks;
   DevBuf<double> inv_partial;
+  DevBuf<double> comm_buf;  // [B][4] packed statistics for the all-reduce (sharded mode)
   int n_inv_wave = 0, n_inv_wg = 0, n_inv_long = 0, n_inv_chunks = 0;
 
   void build(const HostCsr &hX, const std::vector<int64_t> &hmap, int64_t N, int KS, hipStream_t s) {
@@ -298,6 +312,16 @@ struct DevBlock {
     bq.alloc_zero((size_t)B * std::max(KS, 1), s);
     bl.alloc_zero((size_t)B, s);
     bs.alloc_zero((size_t)B, s);
+    comm_buf.alloc((size_t)std::max<int64_t>(B, 1) * 4);
+  }
+  // sum record words [first, first + n) of every block row over the ranks
+  void allreduce_fields(hipStream_t s, const Comm &comm, int first, int n) {
+    if (!comm.active() || B == 0) return;
+    const int64_t cnt = B * n;
+    hipLaunchKernelGGL(k_rec_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, rec.p, comm_buf.p, B, first, n);
+    comm.allreduce(comm_buf.p, cnt);
+    hipLaunchKernelGGL(k_rec_unpack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, rec.p, comm_buf.p, B, first, n);
+    MFM_HIP_CHECK(hipGetLastError());
   }
 };
 
@@ -364,9 +388,11 @@ static SweepArgs block_args(DevBlock &B, double *theta_all, const double *z_all,
 
 // FMTrainer.hpp:256-313 for one block
 static void block_sweep_w(hipStream_t s, Timing &tm, LongScratch &ls, DevBlock &B, int64_t N, double2 *eq, double *w,
-                          const double *z, const int32_t *group, const double *lam, const double *mu, double alpha) {
+                          const double *z, const int32_t *group, const double *lam, const double *mu, double alpha,
+                          const Comm &comm) {
   block_rowcache(s, tm, B, w + B.col_off, false);  // :265-266
   block_unsync<true>(s, tm, B, N, eq);             // :268-275
+  B.allreduce_fields(s, comm, 4, 1);               // sharded rows: e_B is a sum over all ranks' rows
   SweepArgs a = block_args(B, w, z, group, lam, mu, alpha);
   const SweepClasses kc{KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP,
                         KC_BLOCK_SWEEP, KC_BLOCK_SWEEP};
@@ -378,8 +404,10 @@ static void block_sweep_w(hipStream_t s, Timing &tm, LongScratch &ls, DevBlock &
 // FMTrainer.hpp:378-482 for one block and one factor (q_B / q_S were filled by block_rowcache before
 // the q-cache build, :331-333 / :388-393: V_B does not change in between)
 static void block_sweep_V(hipStream_t s, Timing &tm, LongScratch &ls, DevBlock &B, int64_t N, double2 *eq, double *Vf,
-                          const double *zf, const int32_t *group, const double *lamf, const double *muf, double alpha) {
+                          const double *zf, const int32_t *group, const double *lamf, const double *muf, double alpha,
+                          const Comm &comm) {
   block_unsync<false>(s, tm, B, N, eq);  // :401-417
+  B.allreduce_fields(s, comm, 2, 4);     // sharded rows: c, c_S, e, e_q are sums over all ranks' rows
   SweepArgs a = block_args(B, Vf, zf, group, lamf, muf, alpha);
   const SweepClasses kc{KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP,
                         KC_BLOCK_SWEEP, KC_BLOCK_SWEEP};

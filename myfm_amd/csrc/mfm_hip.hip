@@ -39,6 +39,7 @@ struct mfm_ctx {
   };
   std::vector<HostBlock> hblocks;
   std::vector<int32_t> hgroup;
+  std::vector<int32_t> hlevels;  // optional caller-provided level schedule of the main table
   int32_t G = 0;
 
   // device design
@@ -47,6 +48,8 @@ struct mfm_ctx {
   DevSparse X;
   StepPlan plan_V, plan_W;
   LongScratch ls;
+  Comm comm;               // row-sharded multi-GPU mode: set before mfm_finalize
+  int64_t row_offset = 0;  // global index of local row 0 (keys the per-row Philox streams)
   std::vector<std::unique_ptr<DevBlock>> blocks;
   DevBuf<double> y;
   DevBuf<double2> eq;
@@ -361,6 +364,26 @@ int mfm_set_stream(mfm_ctx *ctx, void *hip_stream) {
   MFM_CATCH(ctx)
 }
 
+int mfm_set_allreduce(mfm_ctx *ctx, int (*fn)(void *user, void *dev_buf, int64_t count), void *user) {
+  MFM_TRY(ctx)
+  if (ctx->finalized) throw Error(MFM_ERR_RUNTIME, "mfm_set_allreduce must be called before mfm_finalize");
+  ctx->comm.fn = fn;
+  ctx->comm.user = user;
+  MFM_CATCH(ctx)
+}
+
+int mfm_set_main_levels(mfm_ctx *ctx, const int32_t *level, int64_t D0) {
+  MFM_TRY(ctx)
+  if (ctx->finalized) throw Error(MFM_ERR_RUNTIME, "mfm_set_main_levels must be called before mfm_finalize");
+  ctx->hlevels.assign(level, level + D0);
+  MFM_CATCH(ctx)
+}
+
+int mfm_set_row_offset(mfm_ctx *ctx, int64_t first_global_row) {
+  ctx->row_offset = first_global_row;
+  return MFM_OK;
+}
+
 int mfm_synchronize(mfm_ctx *ctx) {
   MFM_TRY(ctx)
   MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -427,9 +450,15 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   {
     HostCsr Xt = transpose_host(c->hX);
     c->X.upload(c->hX, &Xt);
+    c->plan_V.sharded = c->plan_W.sharded = c->comm.active();
+    c->plan_V.given_levels = c->plan_W.given_levels = c->hlevels;
     c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_capacity<PMainV>(), true, c->X.unit);
     c->plan_W.build(Xt, PMainW::R_W16, PMainW::R_WG, coop_capacity<PMainW>(), true, c->X.unit);
     c->ls.reserve_cols(std::max(c->plan_V.max_cols_scat, c->plan_W.max_cols_scat));
+    if (c->comm.active()) {
+      c->ls.reserve_cols(c->D0);
+      c->ls.reserve_stats(c->D0);
+    }
   }
   c->y.upload(c->hy);
   c->eq.alloc_zero((size_t)c->N, c->stream);
@@ -456,6 +485,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     off += B->Db;
     max_chunks = std::max({max_chunks, B->plan_V.max_hchunks, B->plan_W.max_hchunks});
     max_long = std::max({max_long, B->plan_V.max_huge, B->plan_W.max_huge});
+    B->allreduce_fields(c->stream, c->comm, 6, 1);  // cardinality counts the rows of ALL ranks (definitions.hpp:65-68)
     c->blocks.push_back(std::move(B));
   }
   c->ls.reserve(std::max(max_chunks, 1), std::max(max_long, 1));
@@ -562,6 +592,7 @@ int mfm_reduce_e(mfm_ctx *ctx, double *sum_e, double *sum_e2) {
     hipLaunchKernelGGL(k_reduce_e_partial, dim3(REDUCE_BLOCKS), dim3(WG), 0, s, ctx->eq.p, ctx->N, ctx->red_partial.p);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, s, ctx->red_partial.p, REDUCE_BLOCKS, ctx->red_out.p);
   }
+  ctx->comm.allreduce(ctx->red_out.p, 2);
   double2 *h = ctx->readback(2);
   MFM_HIP_CHECK(hipMemcpyAsync(h, ctx->red_out.p, sizeof(double2), hipMemcpyDeviceToHost, s));
   MFM_HIP_CHECK(hipMemcpyAsync(h + 1, ctx->ls.error.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -632,9 +663,12 @@ int mfm_sweep_w(mfm_ctx *ctx, double alpha, const double *lambda_w, const double
   SweepArgs a = main_args(c, c->w.p, zdev, c->lam.p, c->mu.p, alpha);
   const SweepClasses kcw{KC_SWEEP_W_LIGHT, KC_SWEEP_W_HEAVY, KC_SWEEP_W_COOP, KC_SWEEP_W_LSTATS, KC_SWEEP_W_LDRAW,
                          KC_SWEEP_W_LAPPLY, KC_SWEEP_W_CHAIN, KC_SWEEP_W_SCAT};
-  run_plan<PMainW>(s, c->timing, c->plan_W, a, c->ls, kcw, c->X.unit);
+  if (c->comm.active())
+    run_plan_sharded<PMainW>(s, c->timing, c->plan_W, a, c->ls, kcw, c->X.unit, c->comm);
+  else
+    run_plan<PMainW>(s, c->timing, c->plan_W, a, c->ls, kcw, c->X.unit);
   for (auto &B : c->blocks)
-    block_sweep_w(s, c->timing, c->ls, *B, c->N, c->eq.p, c->w.p, zdev, c->group.p, c->lam.p, c->mu.p, alpha);
+    block_sweep_w(s, c->timing, c->ls, *B, c->N, c->eq.p, c->w.p, zdev, c->group.p, c->lam.p, c->mu.p, alpha, c->comm);
   MFM_CATCH(ctx)
 }
 
@@ -666,9 +700,12 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     SweepArgs a = main_args(c, Vf, zf, lamf, muf, alpha);
     const SweepClasses kcv{KC_SWEEP_V_LIGHT, KC_SWEEP_V_HEAVY, KC_SWEEP_V_COOP, KC_SWEEP_V_LSTATS, KC_SWEEP_V_LDRAW,
                            KC_SWEEP_V_LAPPLY, KC_SWEEP_V_CHAIN, KC_SWEEP_V_SCAT};
-    run_plan<PMainV>(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit);  // :343-376
+    if (c->comm.active())
+      run_plan_sharded<PMainV>(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit, c->comm);
+    else
+      run_plan<PMainV>(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit);  // :343-376
     for (auto &B : c->blocks)
-      block_sweep_V(s, c->timing, c->ls, *B, c->N, c->eq.p, Vf, zf, c->group.p, lamf, muf, alpha);  // :378-482
+      block_sweep_V(s, c->timing, c->ls, *B, c->N, c->eq.p, Vf, zf, c->group.p, lamf, muf, alpha, c->comm);  // :378-482
   }
   MFM_CATCH(ctx)
 }

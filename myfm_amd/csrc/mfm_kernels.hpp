@@ -541,6 +541,149 @@ __global__ __launch_bounds__(WG) void k_scat_apply(SweepArgs a, const int2 *__re
   P::apply(a, rc.x, x, st, on.x, on.y);
 }
 
+// ---- row-sharded (multi-GPU) mode: statistics -> all-reduce -> draw -> apply -------------------------------
+// With the training rows partitioned over GPUs a column's sufficient statistics are partial
+// on every rank: each level runs as local statistics into S[col], ONE all-reduce over the level's column
+// range, an identical draw on every rank (replicated model state and variates), and an apply pass.
+template <class P, int R, int NT, bool UNIT>
+__device__ __forceinline__ void column_stats(const SweepArgs &a, int j, int tid, double *lds, double2 *__restrict__ S) {
+  const int64_t begin = a.colptr[j];
+  const int len = (int)(a.colptr[j + 1] - begin);
+  const double old = a.theta[j];
+  double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int p = tid + r * NT;
+    if (p < len) {
+      const int32_t row = a.rowidx[begin + p];
+      const double x = UNIT ? 1.0 : a.val[begin + p];
+      const typename P::St st = P::load(a, row);
+      P::stats(x, st, old, S1, S2);
+    }
+  }
+  if (NT == WAVE) {
+    S1 = wave_allreduce_sum(S1);
+    S2 = wave_allreduce_sum(S2);
+  } else {
+    wg_allreduce2<NT / WAVE>(S1, S2, lds);
+  }
+  if (tid == 0) S[j] = make_double2(S1, S2);
+}
+template <class P, int R, int NT, bool UNIT>
+__device__ __forceinline__ void column_apply(const SweepArgs &a, int j, int tid, const double2 *__restrict__ oldnew) {
+  const int64_t begin = a.colptr[j];
+  const int len = (int)(a.colptr[j + 1] - begin);
+  const double2 on = oldnew[j];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int p = tid + r * NT;
+    if (p < len) {
+      const int32_t row = a.rowidx[begin + p];
+      const double x = UNIT ? 1.0 : a.val[begin + p];
+      const typename P::St st = P::load(a, row);
+      P::apply(a, row, x, st, on.x, on.y);
+    }
+  }
+}
+// PHASE 1: statistics, PHASE 2: apply. Same binning / grid as k_level_light + k_level_heavy.
+template <class P, bool UNIT, int PHASE>
+__global__ __launch_bounds__(WG) void k_level_split(SweepArgs a, const int32_t *__restrict__ cols_w1, int n_w1,
+                                                    const int32_t *__restrict__ cols_w4, int n_w4,
+                                                    const int32_t *__restrict__ cols_w16, int n_w16,
+                                                    const int32_t *__restrict__ cols_wg, int n_wg, double2 *__restrict__ S,
+                                                    const double2 *__restrict__ oldnew) {
+  __shared__ double lds[2 * WG / WAVE];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int b = blockIdx.x;
+  if (b < n_wg) {
+    if (PHASE == 1) column_stats<P, P::R_WG, WG, UNIT>(a, cols_wg[b], threadIdx.x, lds, S);
+    else column_apply<P, P::R_WG, WG, UNIT>(a, cols_wg[b], threadIdx.x, oldnew);
+    return;
+  }
+  b -= n_wg;
+  const int nb16 = (n_w16 + 3) >> 2, nb4 = (n_w4 + 3) >> 2;
+  if (b < nb16) {
+    const int w = b * 4 + wv;
+    if (w < n_w16) {
+      constexpr int R16 = P::R_W16 > 0 ? P::R_W16 : 1;
+      if (PHASE == 1) column_stats<P, R16, WAVE, UNIT>(a, cols_w16[w], lane, nullptr, S);
+      else column_apply<P, R16, WAVE, UNIT>(a, cols_w16[w], lane, oldnew);
+    }
+    return;
+  }
+  b -= nb16;
+  if (b < nb4) {
+    const int w = b * 4 + wv;
+    if (w < n_w4) {
+      if (PHASE == 1) column_stats<P, 4, WAVE, UNIT>(a, cols_w4[w], lane, nullptr, S);
+      else column_apply<P, 4, WAVE, UNIT>(a, cols_w4[w], lane, oldnew);
+    }
+    return;
+  }
+  b -= nb4;
+  const int w = b * 4 + wv;
+  if (w < n_w1) {
+    if (PHASE == 1) column_stats<P, 1, WAVE, UNIT>(a, cols_w1[w], lane, nullptr, S);
+    else column_apply<P, 1, WAVE, UNIT>(a, cols_w1[w], lane, oldnew);
+  }
+}
+// chunk partials -> S[col] (fixed chunk order)
+__global__ void k_long_sum(const int32_t *__restrict__ lcols, const int32_t *__restrict__ chunk_ptr, int n_long,
+                           const double2 *__restrict__ partial, double2 *__restrict__ S) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n_long) return;
+  double S1 = 0.0, S2 = 0.0;
+  for (int c = chunk_ptr[l]; c < chunk_ptr[l + 1]; c++) {
+    S1 += partial[c].x;
+    S2 += partial[c].y;
+  }
+  S[lcols[l]] = make_double2(S1, S2);
+}
+// run totals of a scattered level -> S[col] (wavefront per column, stream order)
+__global__ __launch_bounds__(WG) void k_scat_sum(const int32_t *__restrict__ cols, int n_cols,
+                                                 const int32_t *__restrict__ slot_ptr, const int32_t *__restrict__ slot_idx,
+                                                 const double2 *__restrict__ slots, double2 *__restrict__ S) {
+  const int c = blockIdx.x * (WG / WAVE) + (threadIdx.x >> 6);
+  if (c >= n_cols) return;
+  const int lane = threadIdx.x & 63;
+  double S1 = 0.0, S2 = 0.0;
+  for (int k = slot_ptr[c] + lane; k < slot_ptr[c + 1]; k += WAVE) {
+    const double2 s = slots[slot_idx[k]];
+    S1 += s.x;
+    S2 += s.y;
+  }
+  S1 = wave_allreduce_sum(S1);
+  S2 = wave_allreduce_sum(S2);
+  if (lane == 0) S[cols[c]] = make_double2(S1, S2);
+}
+// the draw of every column of a level from the (all-reduced) statistics
+template <class P>
+__global__ void k_col_draw(SweepArgs a, const int32_t *__restrict__ cols, int n_cols, const double2 *__restrict__ S,
+                           double2 *__restrict__ oldnew) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cols) return;
+  const int j = cols[c];
+  const double2 s = S[j];
+  const double old = a.theta[j];
+  const int g = a.group[j];
+  const double fresh = P::draw(s.x, s.y, old, a.alpha, a.lambda[g], a.mu[g], a.z[j]);
+  a.theta[j] = fresh;
+  oldnew[j] = make_double2(old, fresh);
+}
+// apply for chunked long columns with (old, new) indexed by column
+template <class P>
+__global__ __launch_bounds__(WG) void k_long_apply_col(SweepArgs a, const ChunkDesc *__restrict__ chunks,
+                                                       const int32_t *__restrict__ lcols, const double2 *__restrict__ oldnew) {
+  const ChunkDesc c = chunks[blockIdx.x];
+  const double2 on = oldnew[lcols[c.lcol]];
+  for (int p = threadIdx.x; p < c.len; p += WG) {
+    const int32_t row = a.rowidx[c.begin + p];
+    const double x = a.val[c.begin + p];
+    const typename P::St s = P::load(a, row);
+    P::apply(a, row, x, s, on.x, on.y);
+  }
+}
+
 // ---- sequential chain: a run of tiny levels handled by ONE workgroup, column after column -------
 // Used where the conflict graph leaves no parallelism across columns (dense / multi-hot columns,
 // small relation blocks): a launch per level would be launch-latency bound.

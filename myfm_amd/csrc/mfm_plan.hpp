@@ -38,6 +38,9 @@ struct ParLevel {
   DevBuf<ChunkDesc> hchunks;
   DevBuf<int32_t> hchunk_ptr;
   int n_hchunks = 0;
+  // all columns of the level (for the sharded mode's draw kernel) and their index range
+  DevBuf<int32_t> cols_all;
+  int n_all = 0, jmin = 0, jmax = -1;
   // scattered level: row-blocked two-pass path (k_scat_*); replaces all the bins above
   bool scattered = false;
   int64_t n_ent = 0;
@@ -144,11 +147,41 @@ struct StepPlan {
     return true;
   }
 
+  bool sharded = false;  // row-sharded multi-GPU mode: no chains (every column needs an all-reduce), no coop
+
+  // Row-sharded mode: the schedule must be the same on every rank, so it is computed on the GLOBAL design
+  // by the caller and handed in; here it is only checked against the local rows.
+  std::vector<int32_t> given_levels;
+  static void check_levels(const HostCsr &csc, const std::vector<int32_t> &level) {
+    if ((int64_t)level.size() != csc.rows) throw Error(MFM_ERR_INVALID, "column level array has the wrong length");
+    std::vector<int32_t> rowlevel((size_t)csc.cols, -1);
+    for (int64_t j = 0; j < csc.rows; j++) {
+      if (level[j] < 0) throw Error(MFM_ERR_INVALID, "negative column level");
+      for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) {
+        int32_t &rl = rowlevel[csc.idx[p]];
+        if (rl >= level[j])
+          throw Error(MFM_ERR_INVALID, "column levels are not a valid schedule: column " + std::to_string(j) +
+                                           " shares a row with an earlier column of the same or a later level");
+        rl = level[j];
+      }
+    }
+  }
+
   void build(const HostCsr &csc, int r_w16, int r_wg, int coop_max, bool allow_scatter = false, bool unit = false) {
+    if (sharded) coop_max = 0;
     n_state_rows = csc.cols;
     const int64_t cap_w1 = WAVE, cap_w4 = 4 * WAVE, cap_w16 = (int64_t)r_w16 * WAVE, cap_wg = (int64_t)r_wg * WG;
     std::vector<int32_t> level;
-    n_levels = column_levels(csc, level);
+    if (!given_levels.empty() || (sharded && csc.rows > 0)) {
+      if (given_levels.empty())
+        throw Error(MFM_ERR_RUNTIME, "row-sharded mode needs the column levels of the GLOBAL design (mfm_set_main_levels)");
+      check_levels(csc, given_levels);
+      level = given_levels;
+      n_levels = 0;
+      for (auto l : level) n_levels = std::max(n_levels, l + 1);
+    } else {
+      n_levels = column_levels(csc, level);
+    }
     std::vector<std::vector<int32_t>> by_level((size_t)n_levels);
     for (int64_t j = 0; j < csc.rows; j++) by_level[level[j]].push_back((int32_t)j);
     steps.clear();
@@ -173,9 +206,10 @@ struct StepPlan {
       run_nnz = 0;
     };
     for (int32_t l = 0; l < n_levels; l++) {
+      if (by_level[l].empty()) continue;
       int64_t lnnz = 0;
       for (int32_t j : by_level[l]) lnnz += csc.ptr[j + 1] - csc.ptr[j];
-      if (tiny(by_level[l].size(), lnnz)) {
+      if (!sharded && tiny(by_level[l].size(), lnnz)) {
         for (int32_t j : by_level[l]) run.push_back(j);
         run_nnz += lnnz;
         continue;
@@ -183,6 +217,10 @@ struct StepPlan {
       flush_run();
       steps.emplace_back();
       ParLevel &L = steps.back().par;
+      L.cols_all.upload(by_level[l]);
+      L.n_all = (int)by_level[l].size();
+      L.jmin = *std::min_element(by_level[l].begin(), by_level[l].end());
+      L.jmax = *std::max_element(by_level[l].begin(), by_level[l].end());
       if (allow_scatter && build_scattered(csc, by_level[l], lnnz, unit, L)) {
         launches += 3;
         max_cols_scat = std::max<int64_t>(max_cols_scat, csc.rows);
@@ -268,9 +306,13 @@ struct StepPlan {
 struct LongScratch {
   DevBuf<double2> partial, oldnew;
   DevBuf<int> error;  // set by k_long_coop on a spin timeout
-  DevBuf<double2> oldnew_col;  // scattered levels: (old, new) per column of the matrix
+  DevBuf<double2> oldnew_col;  // scattered levels / sharded mode: (old, new) per column of the matrix
+  DevBuf<double2> S_col;       // sharded mode: per-column statistics (all-reduced over the ranks)
   void reserve_cols(int64_t n_cols) {
     if ((size_t)n_cols > oldnew_col.n) oldnew_col.alloc((size_t)n_cols);
+  }
+  void reserve_stats(int64_t n_cols) {
+    if ((size_t)n_cols > S_col.n) S_col.alloc((size_t)n_cols);
   }
   void reserve(int max_chunks, int max_long) {
     if ((size_t)max_chunks > partial.n) partial.alloc((size_t)max_chunks);
@@ -381,6 +423,81 @@ static void run_plan(hipStream_t s, Timing &tm, const StepPlan &plan, const Swee
     run_plan_t<P, true>(s, tm, plan, a, ls, kc);
   else
     run_plan_t<P, false>(s, tm, plan, a, ls, kc);
+}
+
+// In-place sum over the ranks of `count` doubles in device memory, enqueued in order on the ctx stream.
+typedef int (*mfm_allreduce_fn)(void *user, void *dev_buf, int64_t count);
+struct Comm {
+  mfm_allreduce_fn fn = nullptr;
+  void *user = nullptr;
+  bool active() const { return fn != nullptr; }
+  void allreduce(void *buf, int64_t count) const {
+    if (!fn || count <= 0) return;
+    if (fn(user, buf, count) != 0) throw Error(MFM_ERR_RUNTIME, "all-reduce callback failed");
+  }
+};
+
+// Row-sharded sweep of one table: per level  statistics -> S -> all-reduce -> draw -> apply.
+template <class P, bool UNIT>
+static void run_plan_sharded_t(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls,
+                               const SweepClasses &kc, const Comm &comm) {
+  for (const Step &st : plan.steps) {
+    if (st.is_chain) throw Error(MFM_ERR_RUNTIME, "internal: chain step in a sharded plan");
+    const ParLevel &L = st.par;
+    double2 *S = ls.S_col.p;
+    if (L.scattered) {
+      TimedLaunch t(tm, s, kc.scat, P::STAT_BYTES * L.n_ent);
+      const int n_wg_s = (int)((L.n_ent + WG - 1) / WG);
+      hipLaunchKernelGGL((k_scat_stats<P, UNIT>), dim3(n_wg_s), dim3(WG), 0, s, a, L.ent.p, L.ent_val.p, L.n_ent, L.run_base.p,
+                         L.slots.p, n_wg_s, xcd_swizzle_enabled());
+      hipLaunchKernelGGL(k_scat_sum, dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, L.scols.p, L.n_cols, L.slot_ptr.p, L.slot_idx.p,
+                         L.slots.p, S);
+    } else {
+      const int grid = L.n_wg + (L.n_w16 + 3) / 4 + (L.n_w4 + 3) / 4 + (L.n_w1 + 3) / 4;
+      if (grid) {
+        TimedLaunch t(tm, s, kc.heavy, P::STAT_BYTES * (L.nnz_heavy + L.nnz_light));
+        hipLaunchKernelGGL((k_level_split<P, UNIT, 1>), dim3(grid), dim3(WG), 0, s, a, L.cols_w1.p, L.n_w1, L.cols_w4.p, L.n_w4,
+                           L.cols_w16.p, L.n_w16, L.cols_wg.p, L.n_wg, S, (const double2 *)nullptr);
+      }
+      if (L.n_huge) {
+        TimedLaunch t(tm, s, kc.hstats, P::STAT_BYTES * L.nnz_huge);
+        hipLaunchKernelGGL((k_long_stats<P>), dim3(L.n_hchunks), dim3(WG), 0, s, a, L.hchunks.p, L.cols_huge.p, ls.partial.p);
+        hipLaunchKernelGGL(k_long_sum, dim3((L.n_huge + 63) / 64), dim3(64), 0, s, L.cols_huge.p, L.hchunk_ptr.p, L.n_huge,
+                           ls.partial.p, S);
+      }
+    }
+    MFM_HIP_CHECK(hipGetLastError());
+    comm.allreduce(S + L.jmin, 2 * (int64_t)(L.jmax - L.jmin + 1));
+    hipLaunchKernelGGL((k_col_draw<P>), dim3((L.n_all + 255) / 256), dim3(256), 0, s, a, L.cols_all.p, L.n_all, S,
+                       ls.oldnew_col.p);
+    if (L.scattered) {
+      TimedLaunch t(tm, s, kc.scat, P::BYTES * L.n_ent);
+      const int n_wg_s = (int)((L.n_ent + WG - 1) / WG);
+      hipLaunchKernelGGL((k_scat_apply<P, UNIT>), dim3(n_wg_s), dim3(WG), 0, s, a, L.ent.p, L.ent_val.p, L.n_ent,
+                         ls.oldnew_col.p, n_wg_s, xcd_swizzle_enabled());
+    } else {
+      const int grid = L.n_wg + (L.n_w16 + 3) / 4 + (L.n_w4 + 3) / 4 + (L.n_w1 + 3) / 4;
+      if (grid) {
+        TimedLaunch t(tm, s, kc.light, P::BYTES * (L.nnz_heavy + L.nnz_light));
+        hipLaunchKernelGGL((k_level_split<P, UNIT, 2>), dim3(grid), dim3(WG), 0, s, a, L.cols_w1.p, L.n_w1, L.cols_w4.p, L.n_w4,
+                           L.cols_w16.p, L.n_w16, L.cols_wg.p, L.n_wg, (double2 *)nullptr, ls.oldnew_col.p);
+      }
+      if (L.n_huge) {
+        TimedLaunch t(tm, s, kc.happly, P::BYTES * L.nnz_huge);
+        hipLaunchKernelGGL((k_long_apply_col<P>), dim3(L.n_hchunks), dim3(WG), 0, s, a, L.hchunks.p, L.cols_huge.p,
+                           ls.oldnew_col.p);
+      }
+    }
+    MFM_HIP_CHECK(hipGetLastError());
+  }
+}
+template <class P>
+static void run_plan_sharded(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls,
+                             const SweepClasses &kc, bool unit, const Comm &comm) {
+  if (unit)
+    run_plan_sharded_t<P, true>(s, tm, plan, a, ls, kc, comm);
+  else
+    run_plan_sharded_t<P, false>(s, tm, plan, a, ls, kc, comm);
 }
 
 // resident-workgroup capacity for the co-resident long-column kernel, with a safety margin

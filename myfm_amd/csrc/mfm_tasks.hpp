@@ -80,10 +80,10 @@ __device__ __forceinline__ double tn_twoside(RowRng &g, double mu_minus, double 
 
 // FMTrainer.hpp:498-512: eq.x holds the score on entry, e = score - z on exit
 __global__ __launch_bounds__(WG) void k_tn_classification(double2 *__restrict__ eq, const double *__restrict__ y, int64_t N,
-                                                          uint64_t seed, uint64_t draw) {
+                                                          uint64_t seed, uint64_t draw, int64_t row_offset) {
   const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x;
   if (t >= N) return;
-  RowRng g(seed, draw, (uint32_t)t);
+  RowRng g(seed ^ ((uint64_t)((t + row_offset) >> 32) * 0x9E3779B97F4A7C15ull), draw, (uint32_t)(t + row_offset));
   const double pred = eq[t].x;
   double n;
   if (y[t] > 0)
@@ -218,11 +218,12 @@ __global__ __launch_bounds__(WG) void k_oprobit_eval(const double2 *__restrict__
 // sample_z_given_cutpoint, OProbitSampler.hpp:238-272 (deviation = 1)
 __global__ __launch_bounds__(WG) void k_oprobit_sample_z(double2 *__restrict__ eq, const double *__restrict__ y,
                                                          const int32_t *__restrict__ rows, int64_t n_rows, int n_class,
-                                                         const double *__restrict__ gamma, uint64_t seed, uint64_t draw) {
+                                                         const double *__restrict__ gamma, uint64_t seed, uint64_t draw,
+                                                         int64_t row_offset) {
   const int64_t p = (int64_t)blockIdx.x * WG + threadIdx.x;
   if (p >= n_rows) return;
   const int64_t t = rows ? rows[p] : p;
-  RowRng g(seed, draw, (uint32_t)t);
+  RowRng g(seed ^ ((uint64_t)((t + row_offset) >> 32) * 0x9E3779B97F4A7C15ull), draw, (uint32_t)(t + row_offset));
   const int cls = (int)y[t];
   const double pred = eq[t].x;
   double z;
@@ -246,7 +247,7 @@ int mfm_update_e_classification(mfm_ctx *ctx, uint64_t seed, uint64_t draw_index
   if (ctx->N) {
     TimedLaunch t(ctx->timing, ctx->stream, KC_TN_SAMPLE, 24.0 * ctx->N);
     hipLaunchKernelGGL(k_tn_classification, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq.p, ctx->y.p, ctx->N,
-                       seed, draw_index);
+                       seed, draw_index, ctx->row_offset);
     MFM_HIP_CHECK(hipGetLastError());
   }
   MFM_CATCH(ctx)
@@ -299,6 +300,13 @@ int mfm_oprobit_eval(mfm_ctx *ctx, int32_t group, const double *gamma, double *l
   std::vector<double> acc((size_t)C * OPROBIT_SLOTS, 0.0);
   for (int b = 0; b < nb; b++)
     for (int i = 0; i < C * OPROBIT_SLOTS; i++) acc[i] += h[(size_t)b * C * OPROBIT_SLOTS + i];
+  if (ctx->comm.active()) {  // row-sharded: the likelihood terms are sums over all ranks' rows
+    ctx->ring.upload(ctx->opartial.p, acc.data(), acc.size() * sizeof(double), s);
+    ctx->comm.allreduce(ctx->opartial.p, (int64_t)acc.size());
+    MFM_HIP_CHECK(hipMemcpyAsync(h, ctx->opartial.p, acc.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < acc.size(); i++) acc[i] = h[i];
+  }
   *ll = 0;
   for (int k = 0; k < m; k++) dgamma[k] = 0;
   if (H)
@@ -331,7 +339,7 @@ int mfm_oprobit_sample_z(mfm_ctx *ctx, int32_t group, const double *gamma, uint6
   if (g.n_rows) {
     TimedLaunch t(ctx->timing, s, KC_TN_SAMPLE, 24.0 * g.n_rows);
     hipLaunchKernelGGL(k_oprobit_sample_z, dim3(cdiv(g.n_rows, WG)), dim3(WG), 0, s, ctx->eq.p, ctx->y.p, g.rows.p,
-                       g.n_rows, g.n_class, dgam, seed, draw_index);
+                       g.n_rows, g.n_class, dgam, seed, draw_index, ctx->row_offset);
     MFM_HIP_CHECK(hipGetLastError());
   }
   MFM_CATCH(ctx)

@@ -1,0 +1,138 @@
+"""Row-sharded device path on ONE GPU: (a) world = 1 with an identity all-reduce exercises the
+statistics / all-reduce / draw / apply kernels; (b) two shards in two lock-stepped threads whose
+all-reduce callback sums the two device buffers -- the same call sequence a 2-GPU RCCL run makes.
+Both must reproduce the oracle's unsharded chain (regression, same seed)."""
+import threading
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from . import datasets as ds
+
+pytestmark = pytest.mark.gpu
+
+
+def _config(gi, n_iter=8, task=None):
+    from myfm_amd import _myfm
+
+    b = _myfm.ConfigBuilder()
+    b.set_alpha_0(1.0).set_beta_0(1.0).set_gamma_0(1.0).set_mu_0(0.0).set_reg_0(1.0)
+    b.set_group_index([int(g) for g in gi]).set_n_iter(n_iter).set_n_kept_samples(0)
+    b.set_task_type(task if task is not None else _myfm.TaskType.REGRESSION)
+    return b.build()
+
+
+def _designs(myfm_mod):
+    X, y, shapes = ds.onehot_mf(30000, 400, 60, seed=3)
+    Xd = sps.hstack([X, sps.csr_matrix(np.random.default_rng(1).normal(size=(30000, 1)))]).tocsr()
+    gid = np.concatenate([ds.group_index_from_shapes(shapes), [2]])
+    main, X_flat, blocks, yb, bshapes = ds.multihot_block_design(n_train=600)
+    return {
+        "onehot_plus_dense": (Xd, y, [], gid, 4),
+        "relation_blocks": (main, yb, blocks, ds.group_index_from_shapes(bshapes), 3),
+    }
+
+
+@pytest.mark.parametrize("name", ["onehot_plus_dense", "relation_blocks"])
+def test_world1_identity_allreduce(oracle, name):
+    import myfm_amd
+    from myfm_amd import _myfm
+
+    X, y, blocks, gi, K = _designs(myfm_amd)[name]
+    calls = []
+    rbs = [_myfm.RelationBlock([int(v) for v in m], b) for m, b in blocks]
+    from myfm_amd import _capi
+
+    s = _myfm.GibbsSession(K, 0.1, X, rbs, y, 42, _config(gi), allreduce=lambda p, c: calls.append(c), n_total_rows=X.shape[0],
+                           main_levels=_capi.column_levels(X)[0])
+    t = oracle.OracleTrainer(X, y, blocks, rank=K, group_index=gi)
+    for it in range(4):
+        s.step()
+        t.step()
+    np.testing.assert_allclose(s.fm.V, t.fm()[2], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(s.fm.w, t.fm()[1], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(s.residual(), t.e(X.shape[0]), rtol=1e-7, atol=1e-7)
+    assert len(calls) > 4 * (K + 1)  # one collective per level of every sweep (+ reductions)
+
+
+class Lockstep:
+    """sums the buffers of `world` sessions living in one process (stand-in for RCCL on one GPU)"""
+
+    def __init__(self, world):
+        import torch
+
+        self.torch = torch
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.bufs = [None] * world
+        self.counts = [0] * world
+
+    def callback(self, rank):
+        from myfm_amd.distributed import _DevView
+
+        def cb(ptr, count):
+            torch = self.torch
+            torch.cuda.synchronize()
+            self.bufs[rank] = torch.as_tensor(_DevView(ptr, count), device="cuda")
+            self.counts[rank] += 1
+            self.bar.wait()
+            total = self.bufs[0].clone()
+            for b in self.bufs[1:]:
+                assert b.shape == total.shape
+                total += b
+            torch.cuda.synchronize()
+            self.bar.wait()
+            self.bufs[rank].copy_(total)
+            torch.cuda.synchronize()
+            self.bar.wait()
+
+        return cb
+
+
+@pytest.mark.parametrize("name", ["onehot_plus_dense", "relation_blocks"])
+def test_two_shards_lockstep(oracle, name):
+    import myfm_amd
+    from myfm_amd import _myfm
+    from myfm_amd.distributed import shard_rows
+
+    X, y, blocks, gi, K = _designs(myfm_amd)[name]
+    from myfm_amd import _capi
+
+    world = 2
+    ls = Lockstep(world)
+    levels = _capi.column_levels(X)[0]  # schedule of the GLOBAL design, identical on every rank
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            Xl, yl, rel, lo, n = shard_rows(X, y, blocks, rank, world)
+            rbs = [_myfm.RelationBlock([int(v) for v in m], b) for m, b in rel]
+            s = _myfm.GibbsSession(K, 0.1, Xl, rbs, yl, 42, _config(gi), allreduce=ls.callback(rank), n_total_rows=n,
+                                   row_offset=lo, main_levels=levels)
+            for it in range(4):
+                s.step()
+            out[rank] = (s.fm.w0, np.asarray(s.fm.w), np.asarray(s.fm.V), s.residual(), lo, float(s.hyper.alpha))
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            ls.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=300)
+    assert not errs, errs
+    t = oracle.OracleTrainer(X, y, blocks, rank=K, group_index=gi)
+    for it in range(4):
+        t.step()
+    w0, w, V = t.fm()
+    e = t.e(X.shape[0])
+    for rank in range(world):
+        gw0, gw, gV, ge, lo, galpha = out[rank]
+        assert abs(gw0 - w0) < 1e-7
+        np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(ge, e[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
+        assert abs(galpha - t.hyper()["alpha"]) < 1e-7 * galpha
+    assert ls.counts[0] == ls.counts[1] > 0
