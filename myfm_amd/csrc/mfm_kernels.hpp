@@ -36,6 +36,11 @@ struct SweepArgs {
   const double *mu;      // [G]
   double alpha;
   int rec2 = 4;          // stride of a relation-block record in 16-byte words (5 when staged in LDS: bank spread)
+  // CSR of the same table (PMainVq only: the q-cache entry of a row is rebuilt on the fly)
+  const int32_t *r_rowptr = nullptr;
+  const int32_t *r_colidx = nullptr;
+  const double *r_val = nullptr;
+  int r_ell = -1;
 };
 
 struct ChunkDesc {
@@ -128,12 +133,36 @@ struct PMainV {
     lin += lam * mu;             // :364-365
     return sample_normal_z(sq, lin, z);
   }
-  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St s, double old, double fresh) {
+  static __device__ __forceinline__ St updated(double x, St s, double old, double fresh) {
     const double delta = fresh - old;
     const double h = x * (s.y - x * old);
     s.y += x * delta;  // :373
     s.x += h * delta;  // :374
-    ((double2 *)a.state)[row] = s;
+    return s;
+  }
+  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St s, double old, double fresh) {
+    ((double2 *)a.state)[row] = updated(x, s, old, fresh);
+  }
+};
+
+// PMainV for the FIRST level of a factor when that level touches every row exactly once (a one-hot field):
+// instead of reading q_t from the q-cache, rebuild it from the row's CSR entries,
+// q_t = sum_j x_tj v_jf (FMTrainer.hpp:320) -- the separate q-build pass (CSR stream + a partial-line store
+// of q for every row) disappears; the level writes (e, q) back anyway.
+template <bool UNIT>
+struct PMainVq : PMainV {
+  static __device__ __forceinline__ St load(const SweepArgs &a, int row) {
+    int64_t b, e;
+    if (a.r_ell >= 0) {
+      b = (int64_t)row * a.r_ell;
+      e = b + a.r_ell;
+    } else {
+      b = a.r_rowptr[row];
+      e = a.r_rowptr[row + 1];
+    }
+    double q = 0.0;
+    for (int64_t p = b; p < e; p++) q += (UNIT ? 1.0 : a.r_val[p]) * a.theta[a.r_colidx[p]];
+    return make_double2(((const double2 *)a.state)[row].x, q);
   }
 };
 
@@ -527,6 +556,41 @@ __global__ __launch_bounds__(WG) void k_scat_draw(SweepArgs a, const int32_t *__
     a.theta[j] = fresh;
     oldnew[j] = make_double2(old, fresh);
   }
+}
+
+// q-cache build of the NEXT factor fused into the apply pass of the last level: when that level touches
+// every row exactly once (a one-hot field), the pass that writes back (e, q_f) can instead write
+// (e, q_{f+1}) with q_{f+1}[t] = sum_j x_tj V[j, f+1] (FMTrainer.hpp:320) -- V[:, f+1] cannot change before
+// its own sweep. This removes the separate q-build pass (its CSR stream and a partial-line store of q).
+struct NextQArgs {
+  const int32_t *rowptr;
+  const int32_t *colidx;
+  const double *val;
+  const double *v_next;  // V[:, f + 1]
+  int ell;               // >= 0: every row has exactly `ell` entries
+};
+template <bool UNIT>
+__global__ __launch_bounds__(WG) void k_scat_apply_nextq(SweepArgs a, const int2 *__restrict__ ent,
+                                                         const double *__restrict__ eval, int64_t n_ent,
+                                                         const double2 *__restrict__ oldnew, int n_wg, int swz, NextQArgs nq) {
+  const int64_t e = (int64_t)xcd_swizzle(blockIdx.x, n_wg, swz) * WG + threadIdx.x;
+  if (e >= n_ent) return;
+  const int2 rc = ent[e];
+  const double2 on = oldnew[rc.y];
+  const double x = UNIT ? 1.0 : eval[e];
+  int64_t b, en;
+  if (nq.ell >= 0) {
+    b = (int64_t)rc.x * nq.ell;
+    en = b + nq.ell;
+  } else {
+    b = nq.rowptr[rc.x];
+    en = nq.rowptr[rc.x + 1];
+  }
+  double qn = 0.0;
+  for (int64_t p = b; p < en; p++) qn += (UNIT ? 1.0 : nq.val[p]) * nq.v_next[nq.colidx[p]];
+  double2 st = PMainV::updated(x, PMainV::load(a, rc.x), on.x, on.y);
+  st.y = qn;
+  ((double2 *)a.state)[rc.x] = st;
 }
 
 template <class P, bool UNIT>

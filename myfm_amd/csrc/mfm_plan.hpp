@@ -50,6 +50,8 @@ struct ParLevel {
   DevBuf<int32_t> run_base;  // per 64-entry tile: index of its first run
   DevBuf<int32_t> scols, slot_ptr, slot_idx;
   DevBuf<double2> slots;
+  bool covers_rows_once = false;  // every row of the table has exactly one entry in this level
+  bool first_and_once = false;    // ... and it is the first step of the plan: the level can rebuild q itself
 };
 
 struct ChainRun {
@@ -132,6 +134,15 @@ struct StepPlan {
     {
       std::vector<int32_t> cur(sptr.begin(), sptr.end() - 1);
       for (size_t r = 0; r < run_col.size(); r++) sidx[cur[local[run_col[r]]]++] = (int32_t)r;
+    }
+    {
+      std::vector<char> seen((size_t)N, 0);
+      bool once = lnnz == N;
+      for (int64_t q = 0; once && q < lnnz; q++) {
+        once = !seen[ent[q].x];
+        seen[ent[q].x] = 1;
+      }
+      L.covers_rows_once = once;
     }
     L.scattered = true;
     L.n_ent = lnnz;
@@ -225,6 +236,16 @@ struct StepPlan {
         launches += 3;
         max_cols_scat = std::max<int64_t>(max_cols_scat, csc.rows);
         continue;
+      }
+      if (steps.size() == 1 && lnnz == csc.cols) {  // first step: does it touch every row exactly once?
+        std::vector<char> seen((size_t)csc.cols, 0);
+        bool once = true;
+        for (int32_t j : by_level[l])
+          for (int64_t p = csc.ptr[j]; once && p < csc.ptr[j + 1]; p++) {
+            once = !seen[csc.idx[p]];
+            seen[csc.idx[p]] = 1;
+          }
+        L.first_and_once = once;
       }
       std::vector<int32_t> w1, w4, w16, wg, lg, hg, lptr, hptr;
       std::vector<ChunkDesc> lch, hch;
@@ -337,9 +358,54 @@ struct SweepClasses {
   int light, heavy, coop, hstats, hdraw, happly, chain, scat;
 };
 
+// can the q-build of the next factor ride on the last step of this plan? (k_scat_apply_nextq)
+static inline bool plan_can_fuse_next_q(const StepPlan &plan) {
+  if (plan.steps.empty()) return false;
+  const Step &last = plan.steps.back();
+  return !last.is_chain && last.par.scattered && last.par.covers_rows_once;
+}
+
+// the first (non-scattered, non-chain) level can rebuild the q-cache itself (PMainVq)
+static inline bool plan_first_level_builds_q(const StepPlan &plan) {
+  if (plan.steps.empty()) return false;
+  const Step &first = plan.steps.front();
+  return !first.is_chain && !first.par.scattered && first.par.first_and_once && first.par.n_huge == 0;
+}
+
+template <class P, bool UNIT>
+static void launch_binned_level(hipStream_t s, Timing &tm, const ParLevel &L, const SweepArgs &a, LongScratch &ls,
+                                const SweepClasses &kc) {
+  // the long columns first: they are the critical path of the level
+  if (L.n_long) {
+    L.epoch++;
+    CoopArgs ca;
+    ca.chunks = L.lchunks.p;
+    ca.lcols = L.cols_long.p;
+    ca.chunk_ptr = L.lchunk_ptr.p;
+    ca.partial = L.lpartial.p;
+    ca.arrive = L.arrive.p;
+    ca.epoch = L.epoch;
+    ca.error = ls.error.p;
+    for (size_t r = 0; r < L.rounds.size(); r++) {
+      TimedLaunch t(tm, s, kc.coop, P::BYTES * L.round_nnz[r]);
+      hipLaunchKernelGGL((k_long_coop<P, UNIT>), dim3(L.rounds[r].second), dim3(WG), 0, s, a, ca, L.rounds[r].first);
+    }
+  }
+  if (L.n_wg + L.n_w16) {
+    TimedLaunch t(tm, s, kc.heavy, P::BYTES * L.nnz_heavy);
+    hipLaunchKernelGGL((k_level_heavy<P, UNIT>), dim3(L.n_wg + (L.n_w16 + 3) / 4), dim3(WG), 0, s, a, L.cols_wg.p, L.n_wg,
+                       L.cols_w16.p, L.n_w16, xcd_swizzle_enabled());
+  }
+  if (L.n_w4 + L.n_w1) {
+    TimedLaunch t(tm, s, kc.light, P::BYTES * L.nnz_light);
+    hipLaunchKernelGGL((k_level_light<P, UNIT>), dim3((L.n_w4 + 3) / 4 + (L.n_w1 + 3) / 4), dim3(WG), 0, s, a, L.cols_w4.p,
+                       L.n_w4, L.cols_w1.p, L.n_w1, xcd_swizzle_enabled());
+  }
+}
+
 template <class P, bool UNIT>
 static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls,
-                       const SweepClasses &kc) {
+                       const SweepClasses &kc, const NextQArgs *nextq = nullptr, bool first_builds_q = false) {
   for (const Step &st : plan.steps) {
     if (st.is_chain) {
       TimedLaunch t(tm, s, kc.chain, P::BYTES * st.chain.nnz);
@@ -361,36 +427,18 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
                          L.slots.p, n_wg_s, swz);
       hipLaunchKernelGGL((k_scat_draw<P>), dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.slot_ptr.p,
                          L.slot_idx.p, L.slots.p, ls.oldnew_col.p);
-      hipLaunchKernelGGL((k_scat_apply<P, UNIT>), dim3(n_wg_s), dim3(WG), 0, s, a, L.ent.p, L.ent_val.p, L.n_ent,
-                         ls.oldnew_col.p, n_wg_s, swz);
+      if (nextq && &st == &plan.steps.back())
+        hipLaunchKernelGGL((k_scat_apply_nextq<UNIT>), dim3(n_wg_s), dim3(WG), 0, s, a, L.ent.p, L.ent_val.p, L.n_ent,
+                           ls.oldnew_col.p, n_wg_s, swz, *nextq);
+      else
+        hipLaunchKernelGGL((k_scat_apply<P, UNIT>), dim3(n_wg_s), dim3(WG), 0, s, a, L.ent.p, L.ent_val.p, L.n_ent,
+                           ls.oldnew_col.p, n_wg_s, swz);
       continue;
     }
-    // the long columns first: they are the critical path of the level
-    if (L.n_long) {
-      L.epoch++;
-      CoopArgs ca;
-      ca.chunks = L.lchunks.p;
-      ca.lcols = L.cols_long.p;
-      ca.chunk_ptr = L.lchunk_ptr.p;
-      ca.partial = L.lpartial.p;
-      ca.arrive = L.arrive.p;
-      ca.epoch = L.epoch;
-      ca.error = ls.error.p;
-      for (size_t r = 0; r < L.rounds.size(); r++) {
-        TimedLaunch t(tm, s, kc.coop, P::BYTES * L.round_nnz[r]);
-        hipLaunchKernelGGL((k_long_coop<P, UNIT>), dim3(L.rounds[r].second), dim3(WG), 0, s, a, ca, L.rounds[r].first);
-      }
-    }
-    if (L.n_wg + L.n_w16) {
-      TimedLaunch t(tm, s, kc.heavy, P::BYTES * L.nnz_heavy);
-      hipLaunchKernelGGL((k_level_heavy<P, UNIT>), dim3(L.n_wg + (L.n_w16 + 3) / 4), dim3(WG), 0, s, a, L.cols_wg.p, L.n_wg,
-                         L.cols_w16.p, L.n_w16, xcd_swizzle_enabled());
-    }
-    if (L.n_w4 + L.n_w1) {
-      TimedLaunch t(tm, s, kc.light, P::BYTES * L.nnz_light);
-      hipLaunchKernelGGL((k_level_light<P, UNIT>), dim3((L.n_w4 + 3) / 4 + (L.n_w1 + 3) / 4), dim3(WG), 0, s, a, L.cols_w4.p,
-                         L.n_w4, L.cols_w1.p, L.n_w1, xcd_swizzle_enabled());
-    }
+    if (first_builds_q && &st == &plan.steps.front())
+      launch_binned_level<PMainVq<UNIT>, UNIT>(s, tm, L, a, ls, kc);  // (only instantiated use: P == PMainV)
+    else
+      launch_binned_level<P, UNIT>(s, tm, L, a, ls, kc);
     if (L.n_huge) {
       {
         TimedLaunch t(tm, s, kc.hstats, P::STAT_BYTES * L.nnz_huge);
@@ -412,7 +460,7 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
 
 template <class P>
 static void run_plan(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls,
-                     const SweepClasses &kc, bool unit) {
+                     const SweepClasses &kc, bool unit, const NextQArgs *nextq = nullptr, bool first_builds_q = false) {
   static bool lds_attr_set = false;
   if (!lds_attr_set) {  // dynamic LDS above 64 KiB must be opted into
     MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_lds<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -420,9 +468,9 @@ static void run_plan(hipStream_t s, Timing &tm, const StepPlan &plan, const Swee
     lds_attr_set = true;
   }
   if (unit)
-    run_plan_t<P, true>(s, tm, plan, a, ls, kc);
+    run_plan_t<P, true>(s, tm, plan, a, ls, kc, nextq, first_builds_q);
   else
-    run_plan_t<P, false>(s, tm, plan, a, ls, kc);
+    run_plan_t<P, false>(s, tm, plan, a, ls, kc, nextq, first_builds_q);
 }
 
 // In-place sum over the ranks of `count` doubles in device memory, enqueued in order on the ctx stream.
