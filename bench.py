@@ -143,6 +143,16 @@ def main():
         dom = max(timing.items(), key=lambda kv: kv[1][0])
         name, (ms, launches, alg_bytes) = dom
         achieved = alg_bytes / (ms * 1e-3) / 1e9
+        # HBM bytes per launch of that class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE of this same command, corrected as MI355X_MICROARCH.md prescribes; profiles/*_pmc_traffic.*)
+        traffic = None
+        default_workload = (a.rows, a.users, a.items, a.rank) == (10_000_000, 69878, 10677, 32) and world == 1
+        pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")) \
+            if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        if default_workload and pmc:
+            tr = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
+            if name in tr:
+                traffic = round(tr[name]["bytes_per_level_launch"])
         roofline = {
             "bound": "hbm",
             "kernel": name,
@@ -150,7 +160,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": pmc[-1] if traffic else None,
             "avg_launch_us": round(ms / launches * 1e3, 2),
             "launches": int(launches),
             "alg_bytes_per_launch": round(alg_bytes / launches),
