@@ -724,6 +724,7 @@ struct FMTrainer {
   FMLearningConfig cfg;
   int random_seed;
   std::mt19937 gen_;
+  std::mt19937 gen_mh_;  // cutpoint Metropolis draws once gen_ lives on the device
   vector<Real> y;
   vector<Real> n_in_group;
   vector<OprobitSampler> cutpoint_sampler;
@@ -846,11 +847,14 @@ struct FMTrainer {
     for (size_t i = 0; i < n; i++) out[i] = std::normal_distribution<Real>(0, 1)(gen_);
   }
 
-  // Hands gen_ to the device and registers one iteration's draw order (SURVEY 8a "RNG draw order").
-  // Only where that order is state-independent: regression and probit classification (whose latent
-  // z use their own Philox stream). Ordered probit interleaves host-side Metropolis draws.
+  // Hands gen_ to the device and registers one iteration's draw order (SURVEY 8a "RNG draw order"): the
+  // hyper-parameter and w / V draws consume the generator in a state-independent order for every task.
+  // The latent z of classification / ordered probit use per-row Philox streams on the device, and the
+  // cutpoint sampler's few Metropolis draws (OProbitSampler.hpp:55-72, :378) come from a second host
+  // generator (gen_mh_, forked from gen_ before the hand-over): for those tasks parity with the
+  // reference is distributional anyway.
   void start_device_rng(int Kf) {
-    if (cfg.task_type == TaskType::ORDERED || std::getenv("MYFM_AMD_HOST_RNG")) return;
+    if (std::getenv("MYFM_AMD_HOST_RNG")) return;
     std::ostringstream os;
     os << gen_;
     std::istringstream is(os.str());
@@ -896,6 +900,7 @@ struct FMTrainer {
 
   void initialize_e(FM &fm) {  // FMTrainer.hpp:99-119
     if (cfg.task_type == TaskType::ORDERED) {
+      gen_mh_.seed((uint32_t)random_seed ^ 0x9E3779B9u);
       ck(ctx, mfm_score_train(ctx));
       int i = 0;
       cutpoint_sampler.clear();
@@ -923,7 +928,8 @@ struct FMTrainer {
             }
         vector<int64_t> rows(c.second.begin(), c.second.end());
         ck(ctx, mfm_oprobit_add_group(ctx, (int32_t)c.first, all_rows ? nullptr : rows.data(), (int64_t)rows.size(), &g));
-        cutpoint_sampler.emplace_back(ctx, g, (int)c.first, gen_, cfg.reg_0, cfg.nu_oprobit);
+        cutpoint_sampler.emplace_back(ctx, g, (int)c.first, std::getenv("MYFM_AMD_HOST_RNG") ? gen_ : gen_mh_, cfg.reg_0,
+                                      cfg.nu_oprobit);
         cutpoint_sampler[i].start_sample();
         OprobitSampler::alpha_to_gamma(fm.cutpoints[i], cutpoint_sampler[i].alpha_now);
         cutpoint_sampler[i].sample_z_given_cutpoint((uint64_t)random_seed, latent_draws++);

@@ -96,10 +96,12 @@ struct StepPlan {
       for (int64_t p = csc.ptr[j] + 1; p < csc.ptr[j + 1]; p++) far += (csc.idx[p] - csc.idx[p - 1]) >= 8;
     if ((double)far < 0.5 * (double)lnnz) return false;
     const int64_t N = csc.cols;
-    const int64_t nb = (N + SCAT_RB - 1) / SCAT_RB;
+    int64_t RB = SCAT_RB;
+    if (const char *e = std::getenv("MFM_SCAT_RB")) RB = std::max<int64_t>(1024, std::atoll(e));
+    const int64_t nb = (N + RB - 1) / RB;
     std::vector<int64_t> bptr((size_t)nb + 1, 0);
     for (int32_t j : cols)
-      for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) bptr[csc.idx[p] / SCAT_RB + 1]++;
+      for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) bptr[csc.idx[p] / RB + 1]++;
     for (int64_t b = 0; b < nb; b++) bptr[b + 1] += bptr[b];
     std::vector<int2> ent((size_t)lnnz);
     std::vector<double> ev;
@@ -108,7 +110,7 @@ struct StepPlan {
       std::vector<int64_t> cur(bptr.begin(), bptr.end() - 1);
       for (int32_t j : cols)  // ascending column, ascending row inside: (block, column, row) order
         for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) {
-          const int64_t q = cur[csc.idx[p] / SCAT_RB]++;
+          const int64_t q = cur[csc.idx[p] / RB]++;
           ent[q] = make_int2(csc.idx[p], j);
           if (!unit) ev[q] = csc.val[p];
         }
