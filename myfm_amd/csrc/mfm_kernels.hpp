@@ -21,7 +21,7 @@ namespace mfm {
 
 constexpr int WAVE = 64;
 constexpr int WG = 256;         // threads per workgroup
-constexpr int CHAIN_WG = 1024;  // threads of the sequential-chain kernel
+constexpr int CHAIN_WG = 256;   // threads of the sequential-chain kernel (global-state variant)
 constexpr int BLOCK_REC = 8;    // doubles per relation-block row record
 
 struct SweepArgs {
@@ -750,33 +750,88 @@ __global__ __launch_bounds__(WG) void k_long_apply_col(SweepArgs a, const ChunkD
 
 // ---- sequential chain: a run of tiny levels handled by ONE workgroup, column after column -------
 // Used where the conflict graph leaves no parallelism across columns (dense / multi-hot columns,
-// small relation blocks): a launch per level would be launch-latency bound.
+// relation blocks): a launch per level would be launch-latency bound. This is the variant for tables
+// whose state does not fit in LDS (k_chain_lds otherwise). Software pipeline, one column ahead: while
+// column c is processed, the descriptor of c+2 and the entries / old coefficient / variate / group
+// hyper-parameters of c+1 are already in flight; the first CHAIN_WG * CHAIN_R entries of a column are
+// staged in registers together with their gathered state (read once, like column_update).
+struct ChainDesc {
+  int64_t begin;
+  int32_t len;
+  int32_t col;
+};
+constexpr int CHAIN_R = 4;
+
 template <class P>
-__global__ __launch_bounds__(CHAIN_WG) void k_chain(SweepArgs a, const int32_t *__restrict__ cols, int n_cols) {
+__global__ __launch_bounds__(CHAIN_WG) void k_chain(SweepArgs a, const ChainDesc *__restrict__ desc, int n_cols) {
   __shared__ double lds[2 * CHAIN_WG / WAVE];
+  constexpr int R = CHAIN_R, NT = CHAIN_WG;
+  const int tid = threadIdx.x;
+  ChainDesc d_next = {0, 0, 0}, d_next2 = {0, 0, 0};
+  int32_t nidx[R];
+  double nval[R];
+  double n_old = 0, n_z = 0, n_lam = 0, n_mu = 0;
+  auto issue = [&](const ChainDesc &d) {  // stage B for the column described by d
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int p = tid + r * NT;
+      nidx[r] = -1;
+      nval[r] = 0.0;
+      if (p < d.len) {
+        nidx[r] = a.rowidx[d.begin + p];
+        nval[r] = a.val[d.begin + p];
+      }
+    }
+    n_old = a.theta[d.col];
+    n_z = a.z[d.col];
+    const int g = a.group[d.col];
+    n_lam = a.lambda[g];
+    n_mu = a.mu[g];
+  };
+  if (n_cols > 0) d_next = desc[0];
+  if (n_cols > 1) d_next2 = desc[1];
+  if (n_cols > 0) issue(d_next);
   for (int c = 0; c < n_cols; c++) {
-    const int j = cols[c];
-    const int64_t begin = a.colptr[j];
-    const int len = (int)(a.colptr[j + 1] - begin);
-    const double old = a.theta[j];
+    const ChainDesc d = d_next;
+    int32_t cidx[R];
+    double cval[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      cidx[r] = nidx[r];
+      cval[r] = nval[r];
+    }
+    const double old = n_old, zc = n_z, lam = n_lam, mu = n_mu;
+    d_next = d_next2;
+    if (c + 2 < n_cols) d_next2 = desc[c + 2];
+    if (c + 1 < n_cols) issue(d_next);
+    // ---- column c ----
+    typename P::St st[R];
     double S1 = 0.0, S2 = 0.0;
-    for (int p = threadIdx.x; p < len; p += CHAIN_WG) {
-      const int32_t row = a.rowidx[begin + p];
-      const double x = a.val[begin + p];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if (cidx[r] >= 0) {
+        st[r] = P::load(a, cidx[r]);
+        P::stats(cval[r], st[r], old, S1, S2);
+      }
+    for (int p = tid + R * NT; p < d.len; p += NT) {
+      const int32_t row = a.rowidx[d.begin + p];
+      const double x = a.val[d.begin + p];
       const typename P::St s = P::load(a, row);
       P::stats(x, s, old, S1, S2);
     }
-    wg_allreduce2<CHAIN_WG / WAVE>(S1, S2, lds);
-    const int g = a.group[j];
-    const double fresh = P::draw(S1, S2, old, a.alpha, a.lambda[g], a.mu[g], a.z[j]);
-    for (int p = threadIdx.x; p < len; p += CHAIN_WG) {
-      const int32_t row = a.rowidx[begin + p];
-      const double x = a.val[begin + p];
+    wg_allreduce2<NT / WAVE>(S1, S2, lds);
+    const double fresh = P::draw(S1, S2, old, a.alpha, lam, mu, zc);
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if (cidx[r] >= 0) P::apply(a, cidx[r], cval[r], st[r], old, fresh);
+    for (int p = tid + R * NT; p < d.len; p += NT) {
+      const int32_t row = a.rowidx[d.begin + p];
+      const double x = a.val[d.begin + p];
       const typename P::St s = P::load(a, row);
       P::apply(a, row, x, s, old, fresh);
     }
-    if (threadIdx.x == 0) a.theta[j] = fresh;
-    __syncthreads();  // this column's stores are visible to the workgroup before the next column loads
+    if (tid == 0) a.theta[d.col] = fresh;
+    __syncthreads();  // this column's stores are visible to the workgroup before the next column's gathers
   }
 }
 
@@ -786,11 +841,6 @@ __global__ __launch_bounds__(CHAIN_WG) void k_chain(SweepArgs a, const int32_t *
 // LDS round trips instead of L2/HBM latency. Columns are processed in batches of CHAIN_CB; everything
 // a column needs from global memory (descriptor, old coefficient, variate, group hyper-parameters and
 // its first 64 entries) is prefetched into registers one batch ahead, descriptors two batches ahead.
-struct ChainDesc {
-  int64_t begin;
-  int32_t len;
-  int32_t col;
-};
 constexpr int CHAIN_CB = 16;
 
 template <class P>

@@ -416,7 +416,7 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
         hipLaunchKernelGGL((k_chain_lds<P>), dim3(1), dim3(WAVE), lds_bytes, s, a, st.chain.desc.p, st.chain.n_cols,
                            plan.n_state_rows, (int)P::REC_DOUBLES);
       } else {
-        hipLaunchKernelGGL((k_chain<P>), dim3(1), dim3(CHAIN_WG), 0, s, a, st.chain.cols.p, st.chain.n_cols);
+        hipLaunchKernelGGL((k_chain<P>), dim3(1), dim3(CHAIN_WG), 0, s, a, st.chain.desc.p, st.chain.n_cols);
       }
       continue;
     }
