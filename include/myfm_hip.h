@@ -94,6 +94,11 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank);
 int64_t mfm_dim_all(const mfm_ctx *ctx);
 /* schedule statistics: number of main-table levels, of main-table kernel launches per sweep */
 int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launches_per_sweep);
+/* Which fast paths mfm_finalize selected for the main table (diagnostics / tests):
+ * bit 0 = q-free latent sweep (short rows: q_train is recomputed, not stored, during update_V),
+ * bit 1 = all stored values are 1.0 (values never read), bit 2 = uniform row length (rowptr never read),
+ * bit 3 = row-sharded (mfm_set_allreduce). */
+int mfm_plan_flags(const mfm_ctx *ctx);
 
 /* ---- model state (FM.hpp:164-168) ------------------------------------------------------ */
 int mfm_set_state(mfm_ctx *ctx, double w0, const double *w, const double *V);

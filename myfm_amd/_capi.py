@@ -20,7 +20,7 @@ TASK_REGRESSION, TASK_CLASSIFICATION, TASK_ORDERED = 0, 1, 2
 SYMBOLS = [
     "mfm_version", "mfm_device_count", "mfm_global_error", "mfm_create", "mfm_destroy", "mfm_last_error",
     "mfm_set_stream", "mfm_synchronize", "mfm_set_main", "mfm_add_block", "mfm_set_groups", "mfm_finalize",
-    "mfm_dim_all", "mfm_plan_info", "mfm_set_state", "mfm_get_state", "mfm_set_w0", "mfm_zero_w", "mfm_get_e",
+    "mfm_dim_all", "mfm_plan_info", "mfm_plan_flags", "mfm_set_state", "mfm_get_state", "mfm_set_w0", "mfm_zero_w", "mfm_get_e",
     "mfm_get_q", "mfm_set_e", "mfm_reduce_e", "mfm_shift_e", "mfm_group_stats_w", "mfm_group_stats_V",
     "mfm_sweep_w", "mfm_sweep_V", "mfm_update_e_regression", "mfm_update_e_classification", "mfm_score_train",
     "mfm_oprobit_add_group", "mfm_oprobit_eval", "mfm_oprobit_sample_z", "mfm_timing_enable", "mfm_timing_reset",
@@ -64,6 +64,7 @@ def lib():
     L.mfm_dim_all.restype = i64
     L.mfm_dim_all.argtypes = [vp]
     L.mfm_plan_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.mfm_plan_flags.argtypes = [vp]
     L.mfm_set_state.argtypes = [vp, dbl, P, P]
     L.mfm_get_state.argtypes = [vp, C.POINTER(dbl), P, P]
     L.mfm_set_w0.argtypes = [vp, dbl]
@@ -322,6 +323,10 @@ class Context:
         zw, zv = np.empty(self.D), np.empty((max(self.K, 1), self.D))
         self._ck(lib().mfm_rng_get_z(self.h, _p(zw), _p(zv)))
         return zw, zv[: self.K]
+
+    def plan_flags(self):
+        f = lib().mfm_plan_flags(self.h)
+        return {"qfree": bool(f & 1), "unit": bool(f & 2), "ell": bool(f & 4), "sharded": bool(f & 8)}
 
     def plan_info(self):
         a, b = C.c_int64(), C.c_int64()

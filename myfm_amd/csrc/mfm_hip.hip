@@ -67,6 +67,8 @@ struct mfm_ctx {
   DevBuf<double2> red_partial;  // REDUCE_BLOCKS
   DevBuf<double2> red_out;      // 1 + G * max(1,K)
   DevBuf<double> scratch_n;     // N doubles (get/set e,q)
+  DevBuf<double> ec;            // compact residual for the q-free latent sweep
+  bool qfree = false;
   PinnedRing ring;
   double2 *h_red = nullptr;  // pinned readback
   size_t h_red_cap = 0;
@@ -452,7 +454,14 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     c->X.upload(c->hX, &Xt);
     c->plan_V.sharded = c->plan_W.sharded = c->comm.active();
     c->plan_V.given_levels = c->plan_W.given_levels = c->hlevels;
-    c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_capacity<PMainV>(), true, c->X.unit);
+    // scattered levels: LDS row tiles of 2^tile_bits {e, q} records (64 KiB by default: two workgroups per CU)
+    int tile_bits = 12;
+    if (const char *e = std::getenv("MFM_TILE_BITS")) tile_bits = std::atoi(e);
+    if (tile_bits < 9 || tile_bits > 13) tile_bits = 0;  // 0: L2-window path (k_scat_*)
+    c->plan_V.tile_bits = c->plan_W.tile_bits = tile_bits;
+    // one plan serves the three latent policies of the main table: size the co-resident launch for all of them
+    const int coop_v = std::min({coop_capacity<PMainV>(), coop_capacity<PMainVe<false, false>>(), coop_capacity<PMainVe<true, false>>()});
+    c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_v, true, c->X.unit);
     c->plan_W.build(Xt, PMainW::R_W16, PMainW::R_WG, coop_capacity<PMainW>(), true, c->X.unit);
     c->ls.reserve_cols(std::max(c->plan_V.max_cols_scat, c->plan_W.max_cols_scat));
     if (c->comm.active()) {
@@ -499,6 +508,11 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   c->red_partial.alloc(REDUCE_BLOCKS);
   c->red_out.alloc((size_t)1 + (size_t)c->G * std::max(c->K, 1));
   c->scratch_n.alloc((size_t)std::max<int64_t>(c->N, 1));
+  // q-free latent sweep (PMainVe), opt-in (MFM_QFREE=1): pays off when the levels' rows are contiguous; needs
+  // short rows, no relation blocks, no sharding, single-pass PAR levels, no row-tile levels
+  c->qfree = !c->comm.active() && c->blocks.empty() && c->X.rows > 0 && c->X.avg_row_nnz <= 4.0 &&
+             plan_is_single_pass_par(c->plan_V) && std::getenv("MFM_QFREE") && std::atoi(std::getenv("MFM_QFREE"));
+  if (c->qfree) c->ec.alloc((size_t)c->N);
   MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
   // host copies are no longer needed
   c->hX = HostCsr();
@@ -519,6 +533,10 @@ int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launche
     *n_launches_per_sweep = n;
   }
   return MFM_OK;
+}
+
+int mfm_plan_flags(const mfm_ctx *ctx) {
+  return (ctx->qfree ? 1 : 0) | (ctx->X.unit ? 2 : 0) | (ctx->X.ell_width >= 0 ? 4 : 0) | (ctx->comm.active() ? 8 : 0);
 }
 
 // ---- state ------------------------------------------------------------------------------------
@@ -699,6 +717,27 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
   const bool first_q = !c->comm.active() && c->blocks.empty() && plan_first_level_builds_q(c->plan_V) &&
                        !std::getenv("MFM_NO_FUSED_QBUILD");
   bool q_ready = false;
+  if (c->qfree) {
+    // compact e for the duration of the factor loop; q is never materialised inside it
+    hipLaunchKernelGGL(k_e_pack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
+    const SweepClasses kcv{KC_SWEEP_V_LIGHT, KC_SWEEP_V_HEAVY, KC_SWEEP_V_COOP, KC_SWEEP_V_LSTATS, KC_SWEEP_V_LDRAW,
+                           KC_SWEEP_V_LAPPLY, KC_SWEEP_V_CHAIN, KC_SWEEP_V_SCAT};
+    for (int f = f_begin; f < f_end; f++) {
+      double *Vf = c->V.p + (size_t)f * c->D;
+      SweepArgs a = main_args(c, Vf, zbase + (size_t)(f - f_begin) * c->D, c->lam.p + (size_t)f * c->G,
+                              c->mu.p + (size_t)f * c->G, alpha);
+      a.state = c->ec.p;
+      a.r_rowptr = c->X.rowptr.p;
+      a.r_colidx = c->X.colidx.p;
+      a.r_val = c->X.rval.p;
+      a.r_ell = (int)c->X.ell_width;
+      run_plan_qfree(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit);
+    }
+    hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
+    launch_qbuild(c, c->V.p + (size_t)(f_end - 1) * c->D);  // leave q_train as the reference would (FMTrainer.hpp:373)
+    MFM_HIP_CHECK(hipGetLastError());
+    return MFM_OK;
+  }
   for (int f = f_begin; f < f_end; f++) {
     double *Vf = c->V.p + (size_t)f * c->D;
     const double *zf = zbase + (size_t)(f - f_begin) * c->D;

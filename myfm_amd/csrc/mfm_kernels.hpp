@@ -80,6 +80,55 @@ __device__ __forceinline__ double wave_allreduce_sum(double v) {
   return readlane_f64(v, 63);
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v, int fill) {
+  return __builtin_amdgcn_update_dpp(fill, v, CTRL, ROW_MASK, 0xf, false);
+}
+// Inclusive segmented sum scan over the wave, entirely in the VALU (DPP): (s1, s2) are summed over the
+// lanes of a segment up to and including this lane; f != 0 marks "a segment head lies in [row start or
+// wave start .. this lane]" and is 1 at heads on entry. In-row steps row_shr 1/2/4/8, then row_bcast15 /
+// row_bcast31 carry the running totals across the 16-lane rows. Fixed association: deterministic.
+__device__ __forceinline__ void wave_segscan2(double &s1, double &s2, int &f) {
+  // lanes without a source (row start / masked rows) read u = 0 and fu = 0: unchanged
+  {
+    const double u1 = dpp_f64<0x111, 0xf>(s1), u2 = dpp_f64<0x111, 0xf>(s2);
+    const int fu = dpp_i32<0x111, 0xf>(f, 0);
+    if (!f) { s1 += u1; s2 += u2; }
+    f |= fu;
+  }
+  {
+    const double u1 = dpp_f64<0x112, 0xf>(s1), u2 = dpp_f64<0x112, 0xf>(s2);
+    const int fu = dpp_i32<0x112, 0xf>(f, 0);
+    if (!f) { s1 += u1; s2 += u2; }
+    f |= fu;
+  }
+  {
+    const double u1 = dpp_f64<0x114, 0xf>(s1), u2 = dpp_f64<0x114, 0xf>(s2);
+    const int fu = dpp_i32<0x114, 0xf>(f, 0);
+    if (!f) { s1 += u1; s2 += u2; }
+    f |= fu;
+  }
+  {
+    const double u1 = dpp_f64<0x118, 0xf>(s1), u2 = dpp_f64<0x118, 0xf>(s2);
+    const int fu = dpp_i32<0x118, 0xf>(f, 0);
+    if (!f) { s1 += u1; s2 += u2; }
+    f |= fu;
+  }
+  // rows 1 and 3 take lane 15 of the row before; then rows 2 and 3 take lane 31 (rows 0-1 complete)
+  {
+    const double u1 = dpp_f64<0x142, 0xa>(s1), u2 = dpp_f64<0x142, 0xa>(s2);
+    const int fu = dpp_i32<0x142, 0xa>(f, 0);
+    if (!f) { s1 += u1; s2 += u2; }
+    f |= fu;
+  }
+  {
+    const double u1 = dpp_f64<0x143, 0xc>(s1), u2 = dpp_f64<0x143, 0xc>(s2);
+    const int fu = dpp_i32<0x143, 0xc>(f, 0);
+    if (!f) { s1 += u1; s2 += u2; }
+    f |= fu;
+  }
+}
+
 // all threads of the workgroup obtain the same totals; fixed summation tree (deterministic).
 template <int NW>
 __device__ __forceinline__ void wg_allreduce2(double &a, double &b, double *lds /* [2 * NW] */) {
@@ -116,6 +165,7 @@ __device__ __forceinline__ double sample_normal_z(double quad, double first, dou
 // latent factors, main table: FMTrainer.hpp:343-376
 struct PMainV {
   static constexpr int R_W16 = 16, R_WG = 16, REC_DOUBLES = 2;
+  static constexpr bool QFREE = false;
   static constexpr double BYTES = 44.0, STAT_BYTES = 28.0;  // per nnz: CSC 12 + eq 16 (+ eq 16 write)
   typedef double2 St;
   static __device__ __forceinline__ St load(const SweepArgs &a, int row) { return ((const double2 *)a.state)[row]; }
@@ -143,6 +193,9 @@ struct PMainV {
   static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St s, double old, double fresh) {
     ((double2 *)a.state)[row] = updated(x, s, old, fresh);
   }
+  // row-tile path: the {e, q} record staged in LDS
+  static __device__ __forceinline__ St from_rec(double2 r) { return r; }
+  static __device__ __forceinline__ double2 to_rec(double2, St s) { return s; }
 };
 
 // PMainV for the FIRST level of a factor when that level touches every row exactly once (a one-hot field):
@@ -166,9 +219,48 @@ struct PMainVq : PMainV {
   }
 };
 
+// "q-free" latent sweep for tables with short rows (one-hot designs): the q-cache entry of a row is never
+// stored -- it is recomputed from the row's few CSR entries and the current V[:, f] wherever it is needed
+// (q_t = sum_j x_tj v_jf, FMTrainer.hpp:320; the increments of :373 are implicit because v is updated in
+// place). The sweep then streams a compact residual array e[N] (8 bytes per row instead of the 16-byte
+// {e, q} pair), which halves the state traffic of both levels, and the separate q-build pass disappears.
+// AFTER = the load happens after the column's new coefficient was written (apply pass of the two-pass
+// scattered path): q already contains x * v_new, so h = x (q - x v_new) = x (q_old - x v_old).
+template <bool UNIT, bool AFTER>
+struct PMainVe : PMainV {
+  static constexpr bool QFREE = true;
+  static constexpr double BYTES = 28.0, STAT_BYTES = 20.0;  // CSC 4(+8) + row CSR 8 + e 8 (+ e 8 write)
+  static __device__ __forceinline__ St load(const SweepArgs &a, int row) {
+    int64_t b, e;
+    if (a.r_ell >= 0) {
+      b = (int64_t)row * a.r_ell;
+      e = b + a.r_ell;
+    } else {
+      b = a.r_rowptr[row];
+      e = a.r_rowptr[row + 1];
+    }
+    double q = 0.0;
+    for (int64_t p = b; p < e; p++) q += (UNIT ? 1.0 : a.r_val[p]) * a.theta[a.r_colidx[p]];
+    return make_double2(((const double *)a.state)[row], q);
+  }
+  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St s, double old, double fresh) {
+    const double h = x * (s.y - x * (AFTER ? fresh : old));
+    ((double *)a.state)[row] = s.x + h * (fresh - old);  // :374
+  }
+};
+__global__ void k_e_pack(const double2 *__restrict__ eq, double *__restrict__ ec, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) ec[i] = eq[i].x;
+}
+__global__ void k_e_unpack(double2 *__restrict__ eq, const double *__restrict__ ec, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) eq[i].x = ec[i];
+}
+
 // linear weights, main table: FMTrainer.hpp:237-254
 struct PMainW {
   static constexpr int R_W16 = 16, R_WG = 16, REC_DOUBLES = 2;
+  static constexpr bool QFREE = false;
   static constexpr double BYTES = 28.0, STAT_BYTES = 20.0;
   typedef double St;
   static __device__ __forceinline__ St load(const SweepArgs &a, int row) { return ((const double2 *)a.state)[row].x; }
@@ -183,11 +275,16 @@ struct PMainW {
     const double lin = -alpha * S1 + lam * mu;
     return sample_normal_z(sq, lin, z);
   }
-  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St e, double old, double fresh) {
+  static __device__ __forceinline__ St updated(double x, St e, double old, double fresh) {
     e -= x * old;
     e += x * fresh;  // :252
-    ((double2 *)a.state)[row].x = e;
+    return e;
   }
+  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St e, double old, double fresh) {
+    ((double2 *)a.state)[row].x = updated(x, e, old, fresh);
+  }
+  static __device__ __forceinline__ St from_rec(double2 r) { return r.x; }
+  static __device__ __forceinline__ double2 to_rec(double2 r, St e) { return make_double2(e, r.y); }
 };
 
 struct BlockRec {
@@ -200,6 +297,7 @@ struct BlockRec {
 // latent factors, relation block: FMTrainer.hpp:419-470
 struct PBlockV {
   static constexpr int R_W16 = 0, R_WG = 4, REC_DOUBLES = 8;   // 64-byte records: keep the register budget bounded
+  static constexpr bool QFREE = false;
   static constexpr double BYTES = 12.0 + 64.0 + 48.0, STAT_BYTES = 12.0 + 64.0;
   typedef BlockRec St;
   static __device__ __forceinline__ St load(const SweepArgs &a, int row) {
@@ -238,6 +336,7 @@ struct PBlockV {
 // linear weights, relation block: FMTrainer.hpp:276-302
 struct PBlockW {
   static constexpr int R_W16 = 0, R_WG = 8, REC_DOUBLES = 8;
+  static constexpr bool QFREE = false;
   static constexpr double BYTES = 12.0 + 32.0 + 8.0, STAT_BYTES = 12.0 + 32.0;
   struct St {
     double e, card;
@@ -603,6 +702,174 @@ __global__ __launch_bounds__(WG) void k_scat_apply(SweepArgs a, const int2 *__re
   const double x = UNIT ? 1.0 : eval[e];
   const typename P::St st = P::load(a, rc.x);
   P::apply(a, rc.x, x, st, on.x, on.y);
+}
+
+// ---- scattered levels, row-tile path --------------------------------------------------------------------
+// The L2-window kernels above still issue one divergent 16-byte global access per entry and pass (a full
+// cache-line transaction in the CU's vector memory pipeline each), which is what bounds them (~2 TB/s
+// algorithmic). Here a workgroup owns a tile of 2^tile_bits rows whose {e, q} records fit in LDS: it loads
+// the tile with coalesced 16-byte accesses, gathers / updates the records in LDS, and (apply pass) writes
+// the tile back coalesced -- global memory only sees streams. The entries of the level are sorted by
+// (tile, column, row) and packed to 4 bytes, (index of the column in the level) << tile_bits | (row - tile
+// start); every tile's entry range is padded to whole 64-entry wave tiles with 0xffffffff.
+//   k_tile_stats : tile -> LDS; per wave tile: segmented reduction over runs of equal column -> slots
+//   k_tile_draw  : wavefront per column: sums its slots in fixed order, draws, writes (old, new)[column]
+//   k_tile_apply : tile -> LDS; updates in LDS (rows of one level are disjoint); LDS -> tile
+constexpr uint32_t TILE_PAD = 0xffffffffu;
+constexpr int TILE_K = 8;  // rows (and at most entries: a level has <= 1 entry per row) per thread of a tile
+typedef double d2_t __attribute__((ext_vector_type(2)));  // register-resident 16-byte record (native vector)
+
+// before the statistics pass: (old, .) per column of the level, so that the entry loop needs one gather
+__global__ void k_tile_old(const double *__restrict__ theta, const int32_t *__restrict__ cols, int n_cols,
+                           double2 *__restrict__ oldnew) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n_cols) oldnew[c].x = theta[cols[c]];
+}
+
+// blockDim.x = 2^tile_bits / TILE_K. All global loads of the workgroup (its tile of records, its <= TILE_K
+// wave tiles of entries per wave, the gathered old coefficients) are issued before the barrier.
+template <class P, bool UNIT>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_tile_stats(SweepArgs a, const uint32_t *__restrict__ tent,
+                                                     const double *__restrict__ tval, const int32_t *__restrict__ tile_ptr,
+                                                     const double2 *__restrict__ oldnew, const int32_t *__restrict__ run_base,
+                                                     const int32_t *__restrict__ slot_pos, double2 *__restrict__ slots,
+                                                     int tile_bits, int64_t n_rows, int n_tiles, int swz) {
+  extern __shared__ double2 lds_rec[];
+  const int b = xcd_swizzle(blockIdx.x, n_tiles, swz);
+  const int64_t row0 = (int64_t)b << tile_bits;
+  const int nr = (int)min((int64_t)1 << tile_bits, n_rows - row0);
+  const int nt = blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = nt >> 6;
+  const d2_t *src = (const d2_t *)a.state + row0;
+  d2_t rec[TILE_K];
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    rec[k] = d2_t{0.0, 0.0};
+    if (tid + k * nt < nr) rec[k] = src[tid + k * nt];
+  }
+  const int t0 = tile_ptr[b] + (tid >> 6), t1 = tile_ptr[b + 1];
+  uint32_t u[TILE_K];
+  int rb[TILE_K];
+  double x[TILE_K], old[TILE_K];
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    const int t = t0 + k * nw;
+    u[k] = TILE_PAD;
+    x[k] = 1.0;
+    rb[k] = 0;
+    if (t < t1) {
+      rb[k] = run_base[t];
+      u[k] = tent[(int64_t)t * WAVE + lane];
+      if (!UNIT) x[k] = tval[(int64_t)t * WAVE + lane];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) old[k] = u[k] != TILE_PAD ? oldnew[u[k] >> tile_bits].x : 0.0;
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++)
+    if (tid + k * nt < nr) ((d2_t *)lds_rec)[tid + k * nt] = rec[k];
+  __syncthreads();
+  const uint32_t rmask = (1u << tile_bits) - 1u;
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    const int t = t0 + k * nw;
+    if (t >= t1) continue;  // wave-uniform
+    const bool valid = u[k] != TILE_PAD;
+    int c = -1 - lane;  // padding lanes: distinct keys, never stored
+    double s1 = 0.0, s2 = 0.0;
+    if (valid) {
+      c = (int)(u[k] >> tile_bits);
+      P::stats(x[k], P::from_rec(lds_rec[u[k] & rmask]), old[k], s1, s2);
+    }
+    const int cp = dpp_i32<0x138, 0xf>(c, 0), cn = dpp_i32<0x130, 0xf>(c, 0);  // wave_shr:1 / wave_shl:1
+    const bool head = lane == 0 || cp != c;
+    const bool tail = lane == 63 || cn != c;
+    const unsigned long long hb = __ballot(head);
+    int pos = 0;
+    if (valid && tail) pos = slot_pos[rb[k] + __popcll(hb & ((2ull << lane) - 1ull)) - 1];
+    int f = head ? 1 : 0;
+    wave_segscan2(s1, s2, f);
+    if (valid && tail) slots[pos] = make_double2(s1, s2);  // column-major slot order: the draw streams
+  }
+}
+
+// (old, new) indexed by the column's position in the level; a column's slots are contiguous
+template <class P>
+__global__ __launch_bounds__(WG) void k_tile_draw(SweepArgs a, const int32_t *__restrict__ cols, int n_cols,
+                                                  const int32_t *__restrict__ slot_ptr, const double2 *__restrict__ slots,
+                                                  double2 *__restrict__ oldnew) {
+  const int c = blockIdx.x * (WG / WAVE) + (threadIdx.x >> 6);
+  if (c >= n_cols) return;
+  const int lane = threadIdx.x & 63;
+  double S1 = 0.0, S2 = 0.0;
+  for (int k = slot_ptr[c] + lane; k < slot_ptr[c + 1]; k += WAVE) {
+    const double2 s = slots[k];
+    S1 += s.x;
+    S2 += s.y;
+  }
+  S1 = wave_allreduce_sum(S1);
+  S2 = wave_allreduce_sum(S2);
+  if (lane == 0) {
+    const int j = cols[c];
+    const double old = a.theta[j];
+    const int g = a.group[j];
+    const double fresh = P::draw(S1, S2, old, a.alpha, a.lambda[g], a.mu[g], a.z[j]);
+    a.theta[j] = fresh;
+    oldnew[c] = make_double2(old, fresh);
+  }
+}
+
+template <class P, bool UNIT>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_tile_apply(SweepArgs a, const uint32_t *__restrict__ tent,
+                                                     const double *__restrict__ tval, const int32_t *__restrict__ tile_ptr,
+                                                     const double2 *__restrict__ oldnew, int tile_bits, int64_t n_rows,
+                                                     int n_tiles, int swz) {
+  extern __shared__ double2 lds_rec[];
+  const int b = xcd_swizzle(blockIdx.x, n_tiles, swz);
+  const int64_t row0 = (int64_t)b << tile_bits;
+  const int nr = (int)min((int64_t)1 << tile_bits, n_rows - row0);
+  const int nt = blockDim.x, tid = threadIdx.x;
+  d2_t *dst = (d2_t *)a.state + row0;
+  d2_t rec[TILE_K];
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    rec[k] = d2_t{0.0, 0.0};
+    if (tid + k * nt < nr) rec[k] = dst[tid + k * nt];
+  }
+  const int64_t p0 = (int64_t)tile_ptr[b] * WAVE + tid, p1 = (int64_t)tile_ptr[b + 1] * WAVE;
+  uint32_t u[TILE_K];
+  double x[TILE_K];
+  d2_t on[TILE_K];
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    const int64_t p = p0 + (int64_t)k * nt;
+    u[k] = TILE_PAD;
+    x[k] = 1.0;
+    if (p < p1) {
+      u[k] = tent[p];
+      if (!UNIT) x[k] = tval[p];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    on[k] = d2_t{0.0, 0.0};
+    if (u[k] != TILE_PAD) on[k] = ((const d2_t *)oldnew)[u[k] >> tile_bits];
+  }
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++)
+    if (tid + k * nt < nr) ((d2_t *)lds_rec)[tid + k * nt] = rec[k];
+  __syncthreads();
+  const uint32_t rmask = (1u << tile_bits) - 1u;
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    if (u[k] == TILE_PAD) continue;
+    const uint32_t r = u[k] & rmask;
+    const double2 old_rec = lds_rec[r];
+    lds_rec[r] = P::to_rec(old_rec, P::updated(x[k], P::from_rec(old_rec), on[k][0], on[k][1]));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++)
+    if (tid + k * nt < nr) dst[tid + k * nt] = ((const d2_t *)lds_rec)[tid + k * nt];
 }
 
 // ---- row-sharded (multi-GPU) mode: statistics -> all-reduce -> draw -> apply -------------------------------

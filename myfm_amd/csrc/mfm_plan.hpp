@@ -49,7 +49,13 @@ struct ParLevel {
   DevBuf<double> ent_val;    // same order (empty when the matrix is unit-valued)
   DevBuf<int32_t> run_base;  // per 64-entry tile: index of its first run
   DevBuf<int32_t> scols, slot_ptr, slot_idx;
+  DevBuf<int32_t> slot_pos;  // row-tile variant: run (stream order) -> slot (column-major)
   DevBuf<double2> slots;
+  // row-tile variant (k_tile_*): LDS-staged {e, q} tiles, 4-byte packed entries
+  bool tiled = false;
+  int tile_bits = 0, n_tiles = 0;
+  DevBuf<uint32_t> tent;      // padded per tile to whole 64-entry wave tiles
+  DevBuf<int32_t> tile_ptr;   // [n_tiles + 1], in wave tiles
   bool covers_rows_once = false;  // every row of the table has exactly one entry in this level
   bool first_and_once = false;    // ... and it is the first step of the plan: the level can rebuild q itself
 };
@@ -85,7 +91,9 @@ struct StepPlan {
 
   // Row-blocked layout for a level whose columns jump between far-apart rows. Returns false (and leaves
   // L untouched) when the level is small or its columns are mostly contiguous.
-  static bool build_scattered(const HostCsr &csc, const std::vector<int32_t> &cols, int64_t lnnz, bool unit, ParLevel &L) {
+  // tile_bits > 0: row-tile variant (tiles of 2^tile_bits rows staged in LDS, packed + padded entries)
+  static bool build_scattered(const HostCsr &csc, const std::vector<int32_t> &cols, int64_t lnnz, bool unit, ParLevel &L,
+                              int tile_bits = 0) {
     int64_t min_nnz = 1 << 20;  // below this the level is launch-bound anyway
     if (const char *e = std::getenv("MFM_SCATTER_MIN_NNZ")) min_nnz = std::atoll(e);
     if (lnnz < min_nnz) return false;
@@ -96,6 +104,12 @@ struct StepPlan {
       for (int64_t p = csc.ptr[j] + 1; p < csc.ptr[j + 1]; p++) far += (csc.idx[p] - csc.idx[p - 1]) >= 8;
     if ((double)far < 0.5 * (double)lnnz) return false;
     const int64_t N = csc.cols;
+    if (tile_bits > 0) {
+      // worthwhile only when the level touches most rows (the apply pass rewrites whole tiles), and the
+      // packed entry must hold the column's position in the level
+      if (2 * lnnz < N || (int64_t)cols.size() >= ((int64_t)1 << (32 - tile_bits)) - 1) tile_bits = 0;
+    }
+    if (tile_bits > 0) return build_tiled(csc, cols, lnnz, unit, L, tile_bits);
     int64_t RB = SCAT_RB;
     if (const char *e = std::getenv("MFM_SCAT_RB")) RB = std::max<int64_t>(1024, std::atoll(e));
     const int64_t nb = (N + RB - 1) / RB;
@@ -160,6 +174,89 @@ struct StepPlan {
     return true;
   }
 
+  static bool build_tiled(const HostCsr &csc, const std::vector<int32_t> &cols, int64_t lnnz, bool unit, ParLevel &L,
+                          int tile_bits) {
+    const int64_t N = csc.cols, RB = (int64_t)1 << tile_bits;
+    const int64_t nb = (N + RB - 1) / RB;
+    std::vector<int64_t> cnt((size_t)nb + 1, 0);
+    for (int32_t j : cols)
+      for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) cnt[csc.idx[p] / RB + 1]++;
+    std::vector<int32_t> tptr((size_t)nb + 1, 0);  // in wave tiles
+    for (int64_t b = 0; b < nb; b++) {
+      const int64_t t = (int64_t)tptr[b] + (cnt[b + 1] + WAVE - 1) / WAVE;
+      if (t >= (int64_t)1 << 30) return false;
+      tptr[b + 1] = (int32_t)t;
+    }
+    const int64_t n_wt = tptr[nb], n_pad = n_wt * WAVE;
+    std::vector<uint32_t> ent((size_t)n_pad, TILE_PAD);
+    std::vector<double> ev;
+    if (!unit) ev.assign((size_t)n_pad, 0.0);
+    {
+      std::vector<int64_t> cur((size_t)nb);
+      for (int64_t b = 0; b < nb; b++) cur[b] = (int64_t)tptr[b] * WAVE;
+      for (size_t c = 0; c < cols.size(); c++) {  // ascending column, ascending row inside: (tile, column, row)
+        const int32_t j = cols[c];
+        for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) {
+          const int64_t r = csc.idx[p], q = cur[r / RB]++;
+          ent[q] = ((uint32_t)c << tile_bits) | (uint32_t)(r & (RB - 1));
+          if (!unit) ev[q] = csc.val[p];
+        }
+      }
+    }
+    // runs: maximal stretches of one column inside a wave tile
+    std::vector<int32_t> run_base((size_t)n_wt + 1, 0), run_col;
+    run_col.reserve((size_t)(lnnz / 4));
+    for (int64_t t = 0; t < n_wt; t++) {
+      run_base[t] = (int32_t)run_col.size();
+      for (int64_t p = t * WAVE; p < (t + 1) * WAVE && ent[p] != TILE_PAD; p++) {
+        const int32_t c = (int32_t)(ent[p] >> tile_bits);
+        if (p == t * WAVE || (int32_t)(ent[p - 1] >> tile_bits) != c) run_col.push_back(c);
+      }
+    }
+    run_base[n_wt] = (int32_t)run_col.size();
+    std::vector<int32_t> sptr(cols.size() + 1, 0), sidx(run_col.size());
+    for (int32_t c : run_col) sptr[c + 1]++;
+    for (size_t c = 0; c < cols.size(); c++) sptr[c + 1] += sptr[c];
+    {
+      std::vector<int32_t> cur(sptr.begin(), sptr.end() - 1);
+      for (size_t r = 0; r < run_col.size(); r++) sidx[cur[run_col[r]]++] = (int32_t)r;
+    }
+    {
+      std::vector<char> seen((size_t)N, 0);
+      bool once = lnnz == N;
+      for (int32_t j : cols)
+        for (int64_t p = csc.ptr[j]; once && p < csc.ptr[j + 1]; p++) {
+          once = !seen[csc.idx[p]];
+          seen[csc.idx[p]] = 1;
+        }
+      L.covers_rows_once = once;
+    }
+    L.scattered = true;
+    L.tiled = true;
+    L.tile_bits = tile_bits;
+    L.n_tiles = (int)nb;
+    L.n_ent = lnnz;
+    L.n_cols = (int)cols.size();
+    L.n_runs = (int)run_col.size();
+    L.tent.upload(ent);
+    if (!unit) L.ent_val.upload(ev);
+    L.tile_ptr.upload(tptr);
+    L.run_base.upload(run_base);
+    L.scols.upload(cols);
+    L.slot_ptr.upload(sptr);
+    {
+      // slots in column-major order (a column's slots contiguous, in stream order): the statistics pass
+      // scatters one 16-byte store per run, the draw streams. (Measured alternatives on config 3: stream-order
+      // slots + gathering draw 84 + 109 us, tile-group-major slots 99 + 52 us, this layout 103 + 30 us.)
+      std::vector<int32_t> pos(sidx.size());
+      for (size_t k = 0; k < sidx.size(); k++) pos[sidx[k]] = (int32_t)k;
+      L.slot_pos.upload(pos);
+    }
+    L.slots.alloc((size_t)std::max<size_t>(run_col.size(), 1));
+    return true;
+  }
+
+  int tile_bits = 0;     // > 0: scattered levels use the row-tile path with tiles of 2^tile_bits rows
   bool sharded = false;  // row-sharded multi-GPU mode: no chains (every column needs an all-reduce), no coop
 
   // Row-sharded mode: the schedule must be the same on every rank, so it is computed on the GLOBAL design
@@ -234,7 +331,7 @@ struct StepPlan {
       L.n_all = (int)by_level[l].size();
       L.jmin = *std::min_element(by_level[l].begin(), by_level[l].end());
       L.jmax = *std::max_element(by_level[l].begin(), by_level[l].end());
-      if (allow_scatter && build_scattered(csc, by_level[l], lnnz, unit, L)) {
+      if (allow_scatter && build_scattered(csc, by_level[l], lnnz, unit, L, sharded ? 0 : tile_bits)) {
         launches += 3;
         max_cols_scat = std::max<int64_t>(max_cols_scat, csc.rows);
         continue;
@@ -364,7 +461,7 @@ struct SweepClasses {
 static inline bool plan_can_fuse_next_q(const StepPlan &plan) {
   if (plan.steps.empty()) return false;
   const Step &last = plan.steps.back();
-  return !last.is_chain && last.par.scattered && last.par.covers_rows_once;
+  return !last.is_chain && last.par.scattered && !last.par.tiled && last.par.covers_rows_once;
 }
 
 // the first (non-scattered, non-chain) level can rebuild the q-cache itself (PMainVq)
@@ -405,7 +502,18 @@ static void launch_binned_level(hipStream_t s, Timing &tm, const ParLevel &L, co
   }
 }
 
-template <class P, bool UNIT>
+// threads of a row-tile workgroup: TILE_K rows per thread (tile_bits 9..13: 64..1024 threads)
+static inline int tile_threads(int tile_bits) { return (1 << tile_bits) / TILE_K; }
+
+// every step is a PAR level without two-pass (huge) columns: what the q-free policy (PMainVe) supports
+static inline bool plan_is_single_pass_par(const StepPlan &plan) {
+  for (const Step &st : plan.steps)
+    if (st.is_chain || (!st.par.scattered && st.par.n_huge > 0) || st.par.tiled) return false;
+  return !plan.steps.empty();
+}
+
+// PA: policy of the apply pass of scattered levels (differs from P only for the q-free policy)
+template <class P, bool UNIT, class PA = P>
 static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls,
                        const SweepClasses &kc, const NextQArgs *nextq = nullptr, bool first_builds_q = false) {
   for (const Step &st : plan.steps) {
@@ -421,6 +529,34 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
       continue;
     }
     const ParLevel &L = st.par;
+    if (L.scattered && L.tiled) {
+      if constexpr (P::REC_DOUBLES == 2 && !P::QFREE) {
+        TimedLaunch t(tm, s, kc.scat, P::BYTES * L.n_ent);
+        const int swz = xcd_swizzle_enabled();
+        const size_t lds = sizeof(double2) << L.tile_bits;
+        const int nt = tile_threads(L.tile_bits);
+        if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit: opt in once per kernel
+          static bool raised = false;
+          if (!raised) {
+            MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_stats<P, UNIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)CHAIN_LDS_MAX));
+            MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply<P, UNIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)CHAIN_LDS_MAX));
+            raised = true;
+          }
+        }
+        hipLaunchKernelGGL(k_tile_old, dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a.theta, L.scols.p, L.n_cols,
+                           ls.oldnew_col.p);
+        hipLaunchKernelGGL((k_tile_stats<P, UNIT>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p, L.tile_ptr.p,
+                           ls.oldnew_col.p, L.run_base.p, L.slot_pos.p, L.slots.p, L.tile_bits, plan.n_state_rows, L.n_tiles,
+                           swz);
+        hipLaunchKernelGGL((k_tile_draw<P>), dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.slot_ptr.p,
+                           L.slots.p, ls.oldnew_col.p);
+        hipLaunchKernelGGL((k_tile_apply<P, UNIT>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p,
+                           L.tile_ptr.p, ls.oldnew_col.p, L.tile_bits, plan.n_state_rows, L.n_tiles, swz);
+      }
+      continue;
+    }
     if (L.scattered) {
       TimedLaunch t(tm, s, kc.scat, P::BYTES * L.n_ent);
       const int swz = xcd_swizzle_enabled();
@@ -433,7 +569,7 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
         hipLaunchKernelGGL((k_scat_apply_nextq<UNIT>), dim3(n_wg_s), dim3(WG), 0, s, a, L.ent.p, L.ent_val.p, L.n_ent,
                            ls.oldnew_col.p, n_wg_s, swz, *nextq);
       else
-        hipLaunchKernelGGL((k_scat_apply<P, UNIT>), dim3(n_wg_s), dim3(WG), 0, s, a, L.ent.p, L.ent_val.p, L.n_ent,
+        hipLaunchKernelGGL((k_scat_apply<PA, UNIT>), dim3(n_wg_s), dim3(WG), 0, s, a, L.ent.p, L.ent_val.p, L.n_ent,
                            ls.oldnew_col.p, n_wg_s, swz);
       continue;
     }
@@ -548,6 +684,15 @@ static void run_plan_sharded(hipStream_t s, Timing &tm, const StepPlan &plan, co
     run_plan_sharded_t<P, true>(s, tm, plan, a, ls, kc, comm);
   else
     run_plan_sharded_t<P, false>(s, tm, plan, a, ls, kc, comm);
+}
+
+// latent sweep of the main table with the q-free policy (compact residual array in a.state)
+static void run_plan_qfree(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls,
+                           const SweepClasses &kc, bool unit) {
+  if (unit)
+    run_plan_t<PMainVe<true, false>, true, PMainVe<true, true>>(s, tm, plan, a, ls, kc);
+  else
+    run_plan_t<PMainVe<false, false>, false, PMainVe<false, true>>(s, tm, plan, a, ls, kc);
 }
 
 // resident-workgroup capacity for the co-resident long-column kernel, with a safety margin

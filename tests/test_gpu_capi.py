@@ -137,11 +137,41 @@ def test_full_iterations_match_oracle(oracle, capi, name):
     np.testing.assert_allclose(c.get_e(), t.e(X.shape[0]), rtol=1e-7, atol=1e-7)
 
 
-def test_scattered_level_path(oracle, capi, monkeypatch):
+@pytest.mark.parametrize("qfree", [True, False])
+def test_scattered_level_path(oracle, capi, monkeypatch, qfree):
     # the row-blocked two-pass path (k_scat_*) is chosen for large scattered levels only; force it on a
-    # small unsorted design (both one-hot fields jump between far-apart rows) and on non-unit values
+    # small unsorted design (both one-hot fields jump between far-apart rows) and on non-unit values.
+    # qfree: short-row tables recompute q_train on the fly (PMainVe) instead of keeping the q-cache
     monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    monkeypatch.setenv("MFM_TILE_BITS", "0")  # the L2-window kernels (k_scat_*); the row-tile path has its own test
+    if qfree:
+        monkeypatch.setenv("MFM_QFREE", "1")
     X, y, shapes = ds.onehot_mf(200000, 700, 90, seed=5, sort_by_user=False)
+    gi = ds.group_index_from_shapes(shapes)
+    for scale in (None, 0.5):
+        Xs = X.copy()
+        if scale:
+            Xs.data = np.where(np.arange(Xs.nnz) % 3 == 0, scale, 1.5)
+        t, c, _ = _pair(oracle, capi, Xs, y, gi, 3)
+        assert c.plan_flags()["qfree"] == qfree
+        drv = CapiGibbs(c, t.clone(), X.shape[0], gi)
+        for it in range(3):
+            t.step()
+            drv.step()
+        np.testing.assert_allclose(c.get_q(), t.q(X.shape[0]), rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(c.get_state()[1], t.fm()[1], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(c.get_e(), t.e(X.shape[0]), rtol=1e-7, atol=1e-7)
+        assert "sweep_V_scattered" in _timing_classes(c, drv)  # (runs one more sweep: keep it last)
+
+
+@pytest.mark.parametrize("tile_bits", [9, 12, 13])
+def test_row_tile_level_path(oracle, capi, monkeypatch, tile_bits):
+    # scattered levels through LDS-staged row tiles (k_tile_*): packed entries, padded tiles, a last partial
+    # tile (N not a multiple of the tile), unit and non-unit values, both sweeps (w and V)
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    monkeypatch.setenv("MFM_TILE_BITS", str(tile_bits))
+    X, y, shapes = ds.onehot_mf(200003, 700, 90, seed=6, sort_by_user=False)
     gi = ds.group_index_from_shapes(shapes)
     for scale in (None, 0.5):
         Xs = X.copy()
@@ -152,10 +182,33 @@ def test_scattered_level_path(oracle, capi, monkeypatch):
         for it in range(3):
             t.step()
             drv.step()
+        np.testing.assert_allclose(c.get_q(), t.q(X.shape[0]), rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(c.get_state()[1], t.fm()[1], rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(c.get_e(), t.e(X.shape[0]), rtol=1e-7, atol=1e-7)
-        assert "sweep_V_scattered" in _timing_classes(c, drv)  # (runs one more sweep: keep it last)
+        assert "sweep_V_scattered" in _timing_classes(c, drv)
+
+
+@pytest.mark.parametrize("qfree", [True, False])
+def test_sorted_onehot_binned_and_coop_levels(oracle, capi, monkeypatch, qfree):
+    # user-sorted one-hot table: level 1 goes through the binned single-pass kernels (wave / workgroup /
+    # co-resident long columns), in q-free and in q-cache form; a few users are long enough for k_long_coop
+    if qfree:
+        monkeypatch.setenv("MFM_QFREE", "1")
+    monkeypatch.setenv("MFM_NO_SCATTER", "1")
+    X, y, shapes = ds.onehot_mf(120000, 40, 300, seed=11, sort_by_user=True)
+    gi = ds.group_index_from_shapes(shapes)
+    t, c, _ = _pair(oracle, capi, X, y, gi, 4)
+    assert c.plan_flags()["qfree"] == qfree
+    drv = CapiGibbs(c, t.clone(), X.shape[0], gi)
+    for it in range(3):
+        t.step()
+        drv.step()
+    np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(c.get_state()[1], t.fm()[1], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(c.get_e(), t.e(X.shape[0]), rtol=1e-7, atol=1e-7)
+    names = _timing_classes(c, drv)
+    assert "sweep_V_coop" in names or "sweep_V_heavy" in names
 
 
 def _timing_classes(c, drv):
