@@ -41,6 +41,9 @@ struct SweepArgs {
   const int32_t *r_colidx = nullptr;
   const double *r_val = nullptr;
   int r_ell = -1;
+  // level whose columns each cover a contiguous row range (a table sorted by this field): first row per
+  // column; the row index array is not read and the state loads issue one round trip earlier
+  const int32_t *row0 = nullptr;
 };
 
 struct ChunkDesc {
@@ -213,9 +216,17 @@ struct PMainVq : PMainV {
       b = a.r_rowptr[row];
       e = a.r_rowptr[row + 1];
     }
+    const double ev = ((const double2 *)a.state)[row].x;
     double q = 0.0;
-    for (int64_t p = b; p < e; p++) q += (UNIT ? 1.0 : a.r_val[p]) * a.theta[a.r_colidx[p]];
-    return make_double2(((const double2 *)a.state)[row].x, q);
+    if (a.r_ell == 2) {  // two one-hot fields: one 8-byte index load, both gathers in flight together
+      const int2 ci = *(const int2 *)(a.r_colidx + b);
+      const double v0 = a.theta[ci.x], v1 = a.theta[ci.y];
+      q = (UNIT ? 1.0 : a.r_val[b]) * v0;
+      q += (UNIT ? 1.0 : a.r_val[b + 1]) * v1;
+    } else {
+      for (int64_t p = b; p < e; p++) q += (UNIT ? 1.0 : a.r_val[p]) * a.theta[a.r_colidx[p]];
+    }
+    return make_double2(ev, q);
   }
 };
 
@@ -376,6 +387,10 @@ __device__ __forceinline__ void column_update(const SweepArgs &a, int j, int tid
   const int64_t begin = a.colptr[j];
   const int len = (int)(a.colptr[j + 1] - begin);
   const double old = a.theta[j];
+  // everything the draw needs is requested now, not after the reduction
+  const int g = a.group[j];
+  const double zj = a.z[j];
+  const int rbase = a.row0 ? a.row0[j] : 0;
   int32_t ri[R];
   double xv[R];
   typename P::St st[R];
@@ -385,13 +400,14 @@ __device__ __forceinline__ void column_update(const SweepArgs &a, int j, int tid
     ri[r] = -1;
     xv[r] = UNIT ? 1.0 : 0.0;
     if (p < len) {
-      ri[r] = a.rowidx[begin + p];
+      ri[r] = a.row0 ? rbase + p : a.rowidx[begin + p];
       if (!UNIT) xv[r] = a.val[begin + p];
     }
   }
 #pragma unroll
   for (int r = 0; r < R; r++)
     if (ri[r] >= 0) st[r] = P::load(a, ri[r]);
+  const double lam = a.lambda[g], mu = a.mu[g];
   double S1 = 0.0, S2 = 0.0;
 #pragma unroll
   for (int r = 0; r < R; r++)
@@ -402,8 +418,7 @@ __device__ __forceinline__ void column_update(const SweepArgs &a, int j, int tid
   } else {
     wg_allreduce2<NT / WAVE>(S1, S2, lds);
   }
-  const int g = a.group[j];
-  const double fresh = P::draw(S1, S2, old, a.alpha, a.lambda[g], a.mu[g], a.z[j]);
+  const double fresh = P::draw(S1, S2, old, a.alpha, lam, mu, zj);
 #pragma unroll
   for (int r = 0; r < R; r++)
     if (ri[r] >= 0) P::apply(a, ri[r], xv[r], st[r], old, fresh);
@@ -476,6 +491,7 @@ __global__ __launch_bounds__(WG) void k_long_coop(SweepArgs a, CoopArgs ca, int 
   const int j = ca.lcols[l];
   const int tid = threadIdx.x;
   const double old = a.theta[j];
+  const int rbase = a.row0 ? a.row0[j] + (int)(d.begin - a.colptr[j]) : 0;
   int32_t ri[R];
   double xv[R];
   typename P::St st[R];
@@ -485,7 +501,7 @@ __global__ __launch_bounds__(WG) void k_long_coop(SweepArgs a, CoopArgs ca, int 
     ri[r] = -1;
     xv[r] = UNIT ? 1.0 : 0.0;
     if (p < d.len) {
-      ri[r] = a.rowidx[d.begin + p];
+      ri[r] = a.row0 ? rbase + p : a.rowidx[d.begin + p];
       if (!UNIT) xv[r] = a.val[d.begin + p];
     }
   }

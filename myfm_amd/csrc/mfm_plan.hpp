@@ -58,6 +58,7 @@ struct ParLevel {
   DevBuf<int32_t> tile_ptr;   // [n_tiles + 1], in wave tiles
   bool covers_rows_once = false;  // every row of the table has exactly one entry in this level
   bool first_and_once = false;    // ... and it is the first step of the plan: the level can rebuild q itself
+  bool contig = false;            // every column of the level covers a contiguous row range (StepPlan::col_row0)
 };
 
 struct ChainRun {
@@ -81,6 +82,7 @@ struct StepPlan {
   int64_t n_state_rows = 0;  // rows of the table whose state the sweeps touch (= csc.cols)
   int max_hchunks = 0, max_huge = 0;
   int64_t launches = 0;
+  DevBuf<int32_t> col_row0;  // first row of every column (used by levels with contiguous columns)
 
   // a level is "tiny" when running it as its own launches cannot fill the device anyway
   static bool tiny(size_t n_cols, int64_t nnz) { return n_cols <= 8 && nnz <= 16384; }
@@ -280,6 +282,12 @@ struct StepPlan {
   void build(const HostCsr &csc, int r_w16, int r_wg, int coop_max, bool allow_scatter = false, bool unit = false) {
     if (sharded) coop_max = 0;
     n_state_rows = csc.cols;
+    {
+      std::vector<int32_t> r0((size_t)csc.rows, 0);
+      for (int64_t j = 0; j < csc.rows; j++)
+        if (csc.ptr[j + 1] > csc.ptr[j]) r0[j] = csc.idx[csc.ptr[j]];
+      col_row0.upload(r0);
+    }
     const int64_t cap_w1 = WAVE, cap_w4 = 4 * WAVE, cap_w16 = (int64_t)r_w16 * WAVE, cap_wg = (int64_t)r_wg * WG;
     std::vector<int32_t> level;
     if (!given_levels.empty() || (sharded && csc.rows > 0)) {
@@ -377,6 +385,14 @@ struct StepPlan {
       }
       lptr.push_back((int32_t)lch.size());
       hptr.push_back((int32_t)hch.size());
+      {
+        bool contig = !std::getenv("MFM_NO_CONTIG");
+        for (size_t c = 0; contig && c < by_level[l].size(); c++) {
+          const int32_t j = by_level[l][c];
+          for (int64_t p = csc.ptr[j] + 1; contig && p < csc.ptr[j + 1]; p++) contig = csc.idx[p] == csc.idx[p - 1] + 1;
+        }
+        L.contig = contig;
+      }
       L.n_w1 = (int)w1.size();
       L.n_w4 = (int)w4.size();
       L.n_w16 = (int)w16.size();
@@ -472,8 +488,10 @@ static inline bool plan_first_level_builds_q(const StepPlan &plan) {
 }
 
 template <class P, bool UNIT>
-static void launch_binned_level(hipStream_t s, Timing &tm, const ParLevel &L, const SweepArgs &a, LongScratch &ls,
-                                const SweepClasses &kc) {
+static void launch_binned_level(hipStream_t s, Timing &tm, const ParLevel &L, const SweepArgs &a_in, LongScratch &ls,
+                                const SweepClasses &kc, const int32_t *col_row0) {
+  SweepArgs a = a_in;
+  a.row0 = L.contig ? col_row0 : nullptr;
   // the long columns first: they are the critical path of the level
   if (L.n_long) {
     L.epoch++;
@@ -574,9 +592,9 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
       continue;
     }
     if (first_builds_q && &st == &plan.steps.front())
-      launch_binned_level<PMainVq<UNIT>, UNIT>(s, tm, L, a, ls, kc);  // (only instantiated use: P == PMainV)
+      launch_binned_level<PMainVq<UNIT>, UNIT>(s, tm, L, a, ls, kc, plan.col_row0.p);  // (only instantiated use: P == PMainV)
     else
-      launch_binned_level<P, UNIT>(s, tm, L, a, ls, kc);
+      launch_binned_level<P, UNIT>(s, tm, L, a, ls, kc, plan.col_row0.p);
     if (L.n_huge) {
       {
         TimedLaunch t(tm, s, kc.hstats, P::STAT_BYTES * L.nnz_huge);
