@@ -67,8 +67,8 @@ struct mfm_ctx {
   DevBuf<double2> red_partial;  // REDUCE_BLOCKS
   DevBuf<double2> red_out;      // 1 + G * max(1,K)
   DevBuf<double> scratch_n;     // N doubles (get/set e,q)
-  DevBuf<double> ec;            // compact residual for the q-free latent sweep
-  bool qfree = false;
+  DevBuf<double> ec, qc;        // split e / q arrays of the latent sweep (soa), compact residual (qfree)
+  bool qfree = false, soa = false;
   PinnedRing ring;
   double2 *h_red = nullptr;  // pinned readback
   size_t h_red_cap = 0;
@@ -460,7 +460,8 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     if (tile_bits < 9 || tile_bits > 13) tile_bits = 0;  // 0: L2-window path (k_scat_*)
     c->plan_V.tile_bits = c->plan_W.tile_bits = tile_bits;
     // one plan serves the three latent policies of the main table: size the co-resident launch for all of them
-    const int coop_v = std::min({coop_capacity<PMainV>(), coop_capacity<PMainVe<false, false>>(), coop_capacity<PMainVe<true, false>>()});
+    const int coop_v = std::min({coop_capacity<PMainV>(), coop_capacity<PMainVe<false, false>>(), coop_capacity<PMainVe<true, false>>(),
+                                 coop_capacity<PMainVsq<false>>(), coop_capacity<PMainVsq<true>>(), coop_capacity<PMainVs>()});
     c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_v, true, c->X.unit);
     c->plan_W.build(Xt, PMainW::R_W16, PMainW::R_WG, coop_capacity<PMainW>(), true, c->X.unit);
     c->ls.reserve_cols(std::max(c->plan_V.max_cols_scat, c->plan_W.max_cols_scat));
@@ -513,6 +514,13 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   c->qfree = !c->comm.active() && c->blocks.empty() && c->X.rows > 0 && c->X.avg_row_nnz <= 4.0 &&
              plan_is_single_pass_par(c->plan_V) && std::getenv("MFM_QFREE") && std::atoi(std::getenv("MFM_QFREE"));
   if (c->qfree) c->ec.alloc((size_t)c->N);
+  // split e / q layout for update_V (run_plan_soa)
+  c->soa = !c->qfree && !c->comm.active() && c->blocks.empty() && c->N > 0 && plan_supports_soa(c->plan_V) &&
+           !std::getenv("MFM_NO_SOA") && !std::getenv("MFM_NO_FUSED_QBUILD");
+  if (c->soa) {
+    c->ec.alloc((size_t)c->N);
+    c->qc.alloc((size_t)c->N);
+  }
   MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
   // host copies are no longer needed
   c->hX = HostCsr();
@@ -536,7 +544,8 @@ int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launche
 }
 
 int mfm_plan_flags(const mfm_ctx *ctx) {
-  return (ctx->qfree ? 1 : 0) | (ctx->X.unit ? 2 : 0) | (ctx->X.ell_width >= 0 ? 4 : 0) | (ctx->comm.active() ? 8 : 0);
+  return (ctx->qfree ? 1 : 0) | (ctx->X.unit ? 2 : 0) | (ctx->X.ell_width >= 0 ? 4 : 0) | (ctx->comm.active() ? 8 : 0) |
+         (ctx->soa ? 16 : 0);
 }
 
 // ---- state ------------------------------------------------------------------------------------
@@ -732,6 +741,30 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       a.r_val = c->X.rval.p;
       a.r_ell = (int)c->X.ell_width;
       run_plan_qfree(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit);
+    }
+    hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
+    launch_qbuild(c, c->V.p + (size_t)(f_end - 1) * c->D);  // leave q_train as the reference would (FMTrainer.hpp:373)
+    MFM_HIP_CHECK(hipGetLastError());
+    return MFM_OK;
+  }
+  if (c->soa) {
+    hipLaunchKernelGGL(k_e_pack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
+    const SweepClasses kcv{KC_SWEEP_V_LIGHT, KC_SWEEP_V_HEAVY, KC_SWEEP_V_COOP, KC_SWEEP_V_LSTATS, KC_SWEEP_V_LDRAW,
+                           KC_SWEEP_V_LAPPLY, KC_SWEEP_V_CHAIN, KC_SWEEP_V_SCAT};
+    for (int f = f_begin; f < f_end; f++) {
+      double *Vf = c->V.p + (size_t)f * c->D;
+      SweepArgs a = main_args(c, Vf, zbase + (size_t)(f - f_begin) * c->D, c->lam.p + (size_t)f * c->G,
+                              c->mu.p + (size_t)f * c->G, alpha);
+      a.state = c->ec.p;
+      a.state2 = c->qc.p;
+      a.r_rowptr = c->X.rowptr.p;
+      a.r_colidx = c->X.colidx.p;
+      a.r_val = c->X.rval.p;
+      a.r_ell = (int)c->X.ell_width;
+      if (c->X.unit)
+        run_plan_soa<true>(s, c->timing, c->plan_V, a, c->ls, kcv);
+      else
+        run_plan_soa<false>(s, c->timing, c->plan_V, a, c->ls, kcv);
     }
     hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
     launch_qbuild(c, c->V.p + (size_t)(f_end - 1) * c->D);  // leave q_train as the reference would (FMTrainer.hpp:373)

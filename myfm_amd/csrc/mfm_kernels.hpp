@@ -44,6 +44,8 @@ struct SweepArgs {
   // level whose columns each cover a contiguous row range (a table sorted by this field): first row per
   // column; the row index array is not read and the state loads issue one round trip earlier
   const int32_t *row0 = nullptr;
+  // split layout of the latent sweep (PMainVs*): state = e[N], state2 = q[N]
+  double *state2 = nullptr;
 };
 
 struct ChunkDesc {
@@ -219,6 +221,50 @@ struct PMainVq : PMainV {
     const double ev = ((const double2 *)a.state)[row].x;
     double q = 0.0;
     if (a.r_ell == 2) {  // two one-hot fields: one 8-byte index load, both gathers in flight together
+      const int2 ci = *(const int2 *)(a.r_colidx + b);
+      const double v0 = a.theta[ci.x], v1 = a.theta[ci.y];
+      q = (UNIT ? 1.0 : a.r_val[b]) * v0;
+      q += (UNIT ? 1.0 : a.r_val[b + 1]) * v1;
+    } else {
+      for (int64_t p = b; p < e; p++) q += (UNIT ? 1.0 : a.r_val[p]) * a.theta[a.r_colidx[p]];
+    }
+    return make_double2(ev, q);
+  }
+};
+
+// Split ("SoA") layout for the latent sweep of a main table without relation blocks: e[N] and q[N] as two
+// arrays for the duration of update_V. With the first level rebuilding q (PMainVsq) and nothing reading q
+// after a factor's last level (PMainVsl / k_tile_apply<.., WRITE_Q = false>), the sweep moves 8 bytes per row
+// where the interleaved {e, q} layout moves 16: the first level reads only e, the last level writes only e.
+struct PMainVs : PMainV {
+  static __device__ __forceinline__ St load(const SweepArgs &a, int row) {
+    return make_double2(((const double *)a.state)[row], a.state2[row]);
+  }
+  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St s, double old, double fresh) {
+    const St n = updated(x, s, old, fresh);
+    ((double *)a.state)[row] = n.x;
+    a.state2[row] = n.y;
+  }
+};
+struct PMainVsl : PMainVs {  // last level of the factor: q is dead
+  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St s, double old, double fresh) {
+    ((double *)a.state)[row] = updated(x, s, old, fresh).x;
+  }
+};
+template <bool UNIT>
+struct PMainVsq : PMainVs {  // first level: q rebuilt from the row (see PMainVq)
+  static __device__ __forceinline__ St load(const SweepArgs &a, int row) {
+    int64_t b, e;
+    if (a.r_ell >= 0) {
+      b = (int64_t)row * a.r_ell;
+      e = b + a.r_ell;
+    } else {
+      b = a.r_rowptr[row];
+      e = a.r_rowptr[row + 1];
+    }
+    const double ev = ((const double *)a.state)[row];
+    double q = 0.0;
+    if (a.r_ell == 2) {
       const int2 ci = *(const int2 *)(a.r_colidx + b);
       const double v0 = a.theta[ci.x], v1 = a.theta[ci.y];
       q = (UNIT ? 1.0 : a.r_val[b]) * v0;
@@ -744,7 +790,7 @@ __global__ void k_tile_old(const double *__restrict__ theta, const int32_t *__re
 
 // blockDim.x = 2^tile_bits / TILE_K. All global loads of the workgroup (its tile of records, its <= TILE_K
 // wave tiles of entries per wave, the gathered old coefficients) are issued before the barrier.
-template <class P, bool UNIT>
+template <class P, bool UNIT, bool SOA = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_tile_stats(SweepArgs a, const uint32_t *__restrict__ tent,
                                                      const double *__restrict__ tval, const int32_t *__restrict__ tile_ptr,
                                                      const double2 *__restrict__ oldnew, const int32_t *__restrict__ run_base,
@@ -755,12 +801,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
   const int64_t row0 = (int64_t)b << tile_bits;
   const int nr = (int)min((int64_t)1 << tile_bits, n_rows - row0);
   const int nt = blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = nt >> 6;
-  const d2_t *src = (const d2_t *)a.state + row0;
   d2_t rec[TILE_K];
 #pragma unroll
   for (int k = 0; k < TILE_K; k++) {
     rec[k] = d2_t{0.0, 0.0};
-    if (tid + k * nt < nr) rec[k] = src[tid + k * nt];
+    if (tid + k * nt < nr) {
+      if (SOA)
+        rec[k] = d2_t{((const double *)a.state)[row0 + tid + k * nt], a.state2[row0 + tid + k * nt]};
+      else
+        rec[k] = ((const d2_t *)a.state)[row0 + tid + k * nt];
+    }
   }
   const int t0 = tile_ptr[b] + (tid >> 6), t1 = tile_ptr[b + 1];
   uint32_t u[TILE_K];
@@ -834,7 +884,7 @@ __global__ __launch_bounds__(WG) void k_tile_draw(SweepArgs a, const int32_t *__
   }
 }
 
-template <class P, bool UNIT>
+template <class P, bool UNIT, bool SOA = false, bool WRITE_Q = true>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_tile_apply(SweepArgs a, const uint32_t *__restrict__ tent,
                                                      const double *__restrict__ tval, const int32_t *__restrict__ tile_ptr,
                                                      const double2 *__restrict__ oldnew, int tile_bits, int64_t n_rows,
@@ -844,12 +894,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
   const int64_t row0 = (int64_t)b << tile_bits;
   const int nr = (int)min((int64_t)1 << tile_bits, n_rows - row0);
   const int nt = blockDim.x, tid = threadIdx.x;
-  d2_t *dst = (d2_t *)a.state + row0;
   d2_t rec[TILE_K];
 #pragma unroll
   for (int k = 0; k < TILE_K; k++) {
     rec[k] = d2_t{0.0, 0.0};
-    if (tid + k * nt < nr) rec[k] = dst[tid + k * nt];
+    if (tid + k * nt < nr) {
+      if (SOA)
+        rec[k] = d2_t{((const double *)a.state)[row0 + tid + k * nt], a.state2[row0 + tid + k * nt]};
+      else
+        rec[k] = ((const d2_t *)a.state)[row0 + tid + k * nt];
+    }
   }
   const int64_t p0 = (int64_t)tile_ptr[b] * WAVE + tid, p1 = (int64_t)tile_ptr[b + 1] * WAVE;
   uint32_t u[TILE_K];
@@ -885,7 +939,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < TILE_K; k++)
-    if (tid + k * nt < nr) dst[tid + k * nt] = ((const d2_t *)lds_rec)[tid + k * nt];
+    if (tid + k * nt < nr) {
+      const d2_t r = ((const d2_t *)lds_rec)[tid + k * nt];
+      if (SOA) {
+        ((double *)a.state)[row0 + tid + k * nt] = r[0];
+        if (WRITE_Q) a.state2[row0 + tid + k * nt] = r[1];
+      } else {
+        ((d2_t *)a.state)[row0 + tid + k * nt] = r;
+      }
+    }
 }
 
 // ---- row-sharded (multi-GPU) mode: statistics -> all-reduce -> draw -> apply -------------------------------

@@ -704,6 +704,88 @@ static void run_plan_sharded(hipStream_t s, Timing &tm, const StepPlan &plan, co
     run_plan_sharded_t<P, false>(s, tm, plan, a, ls, kc, comm);
 }
 
+// Can the latent sweep of this table run in the split layout (run_plan_soa)? PAR levels only, every
+// scattered level on the row-tile path, and a first level that rebuilds q (so q never has to be packed).
+static inline bool plan_supports_soa(const StepPlan &plan) {
+  if (plan.steps.size() < 2) return false;
+  for (const Step &st : plan.steps)
+    if (st.is_chain || (st.par.scattered && !st.par.tiled)) return false;
+  const ParLevel &first = plan.steps.front().par;
+  return !first.scattered && first.first_and_once;
+}
+
+template <class P, bool UNIT>
+static void launch_huge(hipStream_t s, Timing &tm, const ParLevel &L, const SweepArgs &a, LongScratch &ls,
+                        const SweepClasses &kc) {
+  if (!L.n_huge) return;
+  {
+    TimedLaunch t(tm, s, kc.hstats, P::STAT_BYTES * L.nnz_huge);
+    hipLaunchKernelGGL((k_long_stats<P>), dim3(L.n_hchunks), dim3(WG), 0, s, a, L.hchunks.p, L.cols_huge.p, ls.partial.p);
+  }
+  {
+    TimedLaunch t(tm, s, kc.hdraw, 16.0 * L.n_hchunks);
+    hipLaunchKernelGGL((k_long_draw<P>), dim3((L.n_huge + 63) / 64), dim3(64), 0, s, a, L.cols_huge.p, L.hchunk_ptr.p,
+                       L.n_huge, ls.partial.p, ls.oldnew.p);
+  }
+  {
+    TimedLaunch t(tm, s, kc.happly, P::BYTES * L.nnz_huge);
+    hipLaunchKernelGGL((k_long_apply<P>), dim3(L.n_hchunks), dim3(WG), 0, s, a, L.hchunks.p, ls.oldnew.p);
+  }
+}
+
+// latent sweep of one factor in the split layout: a.state = e[N], a.state2 = q[N]
+template <bool UNIT>
+static void run_plan_soa(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls,
+                         const SweepClasses &kc) {
+  for (const Step &st : plan.steps) {
+    const ParLevel &L = st.par;
+    const bool first = &st == &plan.steps.front(), last = &st == &plan.steps.back();
+    if (L.scattered) {  // (tiled: plan_supports_soa)
+      TimedLaunch t(tm, s, kc.scat, (last ? 48.0 : 56.0) * L.n_ent);
+      const int swz = xcd_swizzle_enabled();
+      const size_t lds = sizeof(double2) << L.tile_bits;
+      const int nt = tile_threads(L.tile_bits);
+      if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_stats<PMainV, UNIT, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_MAX));
+          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply<PMainV, UNIT, true, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_MAX));
+          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply<PMainV, UNIT, true, false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_MAX));
+          raised = true;
+        }
+      }
+      hipLaunchKernelGGL(k_tile_old, dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a.theta, L.scols.p, L.n_cols,
+                         ls.oldnew_col.p);
+      hipLaunchKernelGGL((k_tile_stats<PMainV, UNIT, true>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p,
+                         L.tile_ptr.p, ls.oldnew_col.p, L.run_base.p, L.slot_pos.p, L.slots.p, L.tile_bits, plan.n_state_rows,
+                         L.n_tiles, swz);
+      hipLaunchKernelGGL((k_tile_draw<PMainV>), dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols,
+                         L.slot_ptr.p, L.slots.p, ls.oldnew_col.p);
+      if (last)
+        hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, false>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p,
+                           L.ent_val.p, L.tile_ptr.p, ls.oldnew_col.p, L.tile_bits, plan.n_state_rows, L.n_tiles, swz);
+      else
+        hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, true>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p,
+                           L.ent_val.p, L.tile_ptr.p, ls.oldnew_col.p, L.tile_bits, plan.n_state_rows, L.n_tiles, swz);
+      continue;
+    }
+    if (first) {
+      launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, L, a, ls, kc, plan.col_row0.p);
+      launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, L, a, ls, kc);
+    } else if (last) {
+      launch_binned_level<PMainVsl, UNIT>(s, tm, L, a, ls, kc, plan.col_row0.p);
+      launch_huge<PMainVsl, UNIT>(s, tm, L, a, ls, kc);
+    } else {
+      launch_binned_level<PMainVs, UNIT>(s, tm, L, a, ls, kc, plan.col_row0.p);
+      launch_huge<PMainVs, UNIT>(s, tm, L, a, ls, kc);
+    }
+  }
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
 // latent sweep of the main table with the q-free policy (compact residual array in a.state)
 static void run_plan_qfree(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls,
                            const SweepClasses &kc, bool unit) {

@@ -189,6 +189,38 @@ def test_row_tile_level_path(oracle, capi, monkeypatch, tile_bits):
         assert "sweep_V_scattered" in _timing_classes(c, drv)
 
 
+@pytest.mark.parametrize("n_fields", [2, 3])
+def test_split_layout_latent_sweep(oracle, capi, monkeypatch, n_fields):
+    # update_V with e and q as separate arrays (run_plan_soa): first level (user-sorted, contiguous columns)
+    # rebuilds q, middle levels read and write both, the last level writes only e; q_train is restored after
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    import scipy.sparse as sps
+    n = 150001
+    X, y, shapes = ds.onehot_mf(n, 500, 120, seed=21, sort_by_user=True)
+    if n_fields == 3:
+        rng = np.random.default_rng(3)
+        ctx = rng.integers(0, 37, size=n)
+        extra = sps.csr_matrix((np.ones(n), ctx, np.arange(n + 1)), shape=(n, 37))
+        X = sps.hstack([X, extra]).tocsr()
+        X.sort_indices()
+        shapes = shapes + [37]
+    gi = ds.group_index_from_shapes(shapes)
+    for scale in (None, 0.5):
+        Xs = X.copy()
+        if scale:
+            Xs.data = np.where(np.arange(Xs.nnz) % 3 == 0, scale, 1.5)
+        t, c, _ = _pair(oracle, capi, Xs, y, gi, 3)
+        assert c.plan_flags()["soa"]
+        drv = CapiGibbs(c, t.clone(), n, gi)
+        for it in range(3):
+            t.step()
+            drv.step()
+        np.testing.assert_allclose(c.get_q(), t.q(n), rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(c.get_state()[1], t.fm()[1], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-7, atol=1e-7)
+
+
 @pytest.mark.parametrize("qfree", [True, False])
 def test_sorted_onehot_binned_and_coop_levels(oracle, capi, monkeypatch, qfree):
     # user-sorted one-hot table: level 1 goes through the binned single-pass kernels (wave / workgroup /
