@@ -137,6 +137,7 @@ enum KernelClass {
   KC_TN_SAMPLE,        // truncated-normal latent z                         util.hpp:15-78
   KC_OPROBIT_EVAL,     // cutpoint likelihood / gradient / Hessian          OProbitSampler.hpp:389-413
   KC_PREDICT,          // Predictor::predict*                               predictor.hpp:35-147
+  KC_SWEEP_V_FUSED,    // latent sweep: last level's apply pass + next factor's first level on the LDS tile
   KC_N
 };
 
@@ -146,7 +147,8 @@ static const char *const kKernelClassNames[KC_N] = {
     "sweep_w_coop",       "sweep_w_scattered",  "sweep_w_huge_stats", "sweep_w_huge_draw", "sweep_w_huge_apply", "sweep_w_chain",
     "update_e_score",     "build_vt",
     "reduce_e",           "shift_e",           "group_stats",        "block_rowcache",     "block_unsync",
-    "block_resync",       "block_sweep",       "tn_sample",          "oprobit_eval",       "predict"};
+    "block_resync",       "block_sweep",       "tn_sample",          "oprobit_eval",       "predict",
+    "sweep_V_fused_next"};
 
 struct Timing {
   bool on = false;

@@ -68,7 +68,7 @@ struct mfm_ctx {
   DevBuf<double2> red_out;      // 1 + G * max(1,K)
   DevBuf<double> scratch_n;     // N doubles (get/set e,q)
   DevBuf<double> ec, qc;        // split e / q arrays of the latent sweep (soa), compact residual (qfree)
-  bool qfree = false, soa = false;
+  bool qfree = false, soa = false, fuse_next = false;
   PinnedRing ring;
   double2 *h_red = nullptr;  // pinned readback
   size_t h_red_cap = 0;
@@ -520,6 +520,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   if (c->soa) {
     c->ec.alloc((size_t)c->N);
     c->qc.alloc((size_t)c->N);
+    c->fuse_next = plan_supports_fused_next(c->plan_V) && !std::getenv("MFM_NO_FUSED_NEXT");
   }
   MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
   // host copies are no longer needed
@@ -545,7 +546,7 @@ int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launche
 
 int mfm_plan_flags(const mfm_ctx *ctx) {
   return (ctx->qfree ? 1 : 0) | (ctx->X.unit ? 2 : 0) | (ctx->X.ell_width >= 0 ? 4 : 0) | (ctx->comm.active() ? 8 : 0) |
-         (ctx->soa ? 16 : 0);
+         (ctx->soa ? 16 : 0) | (ctx->fuse_next ? 32 : 0);
 }
 
 // ---- state ------------------------------------------------------------------------------------
@@ -751,21 +752,22 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     hipLaunchKernelGGL(k_e_pack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
     const SweepClasses kcv{KC_SWEEP_V_LIGHT, KC_SWEEP_V_HEAVY, KC_SWEEP_V_COOP, KC_SWEEP_V_LSTATS, KC_SWEEP_V_LDRAW,
                            KC_SWEEP_V_LAPPLY, KC_SWEEP_V_CHAIN, KC_SWEEP_V_SCAT};
-    for (int f = f_begin; f < f_end; f++) {
-      double *Vf = c->V.p + (size_t)f * c->D;
-      SweepArgs a = main_args(c, Vf, zbase + (size_t)(f - f_begin) * c->D, c->lam.p + (size_t)f * c->G,
-                              c->mu.p + (size_t)f * c->G, alpha);
+    auto args = [&](int f) {
+      SweepArgs a = main_args(c, c->V.p + (size_t)f * c->D, zbase + (size_t)(f - f_begin) * c->D,
+                              c->lam.p + (size_t)f * c->G, c->mu.p + (size_t)f * c->G, alpha);
       a.state = c->ec.p;
       a.state2 = c->qc.p;
       a.r_rowptr = c->X.rowptr.p;
       a.r_colidx = c->X.colidx.p;
       a.r_val = c->X.rval.p;
       a.r_ell = (int)c->X.ell_width;
-      if (c->X.unit)
-        run_plan_soa<true>(s, c->timing, c->plan_V, a, c->ls, kcv);
-      else
-        run_plan_soa<false>(s, c->timing, c->plan_V, a, c->ls, kcv);
-    }
+      return a;
+    };
+    const bool fuse = c->fuse_next;
+    if (c->X.unit)
+      run_sweep_soa<true>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, fuse);
+    else
+      run_sweep_soa<false>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, fuse);
     hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
     launch_qbuild(c, c->V.p + (size_t)(f_end - 1) * c->D);  // leave q_train as the reference would (FMTrainer.hpp:373)
     MFM_HIP_CHECK(hipGetLastError());

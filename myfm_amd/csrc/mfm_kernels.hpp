@@ -793,13 +793,14 @@ __global__ void k_tile_old(const double *__restrict__ theta, const int32_t *__re
 template <class P, bool UNIT, bool SOA = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_tile_stats(SweepArgs a, const uint32_t *__restrict__ tent,
                                                      const double *__restrict__ tval, const int32_t *__restrict__ tile_ptr,
+                                                     const int32_t *__restrict__ tile_row0,
                                                      const double2 *__restrict__ oldnew, const int32_t *__restrict__ run_base,
                                                      const int32_t *__restrict__ slot_pos, double2 *__restrict__ slots,
-                                                     int tile_bits, int64_t n_rows, int n_tiles, int swz) {
+                                                     int tile_bits, int n_tiles, int swz) {
   extern __shared__ double2 lds_rec[];
   const int b = xcd_swizzle(blockIdx.x, n_tiles, swz);
-  const int64_t row0 = (int64_t)b << tile_bits;
-  const int nr = (int)min((int64_t)1 << tile_bits, n_rows - row0);
+  const int64_t row0 = tile_row0[b];
+  const int nr = tile_row0[b + 1] - (int)row0;
   const int nt = blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = nt >> 6;
   d2_t rec[TILE_K];
 #pragma unroll
@@ -887,12 +888,12 @@ __global__ __launch_bounds__(WG) void k_tile_draw(SweepArgs a, const int32_t *__
 template <class P, bool UNIT, bool SOA = false, bool WRITE_Q = true>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_tile_apply(SweepArgs a, const uint32_t *__restrict__ tent,
                                                      const double *__restrict__ tval, const int32_t *__restrict__ tile_ptr,
-                                                     const double2 *__restrict__ oldnew, int tile_bits, int64_t n_rows,
-                                                     int n_tiles, int swz) {
+                                                     const int32_t *__restrict__ tile_row0,
+                                                     const double2 *__restrict__ oldnew, int tile_bits, int n_tiles, int swz) {
   extern __shared__ double2 lds_rec[];
   const int b = xcd_swizzle(blockIdx.x, n_tiles, swz);
-  const int64_t row0 = (int64_t)b << tile_bits;
-  const int nr = (int)min((int64_t)1 << tile_bits, n_rows - row0);
+  const int64_t row0 = tile_row0[b];
+  const int nr = tile_row0[b + 1] - (int)row0;
   const int nt = blockDim.x, tid = threadIdx.x;
   d2_t rec[TILE_K];
 #pragma unroll
@@ -947,6 +948,155 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
       } else {
         ((d2_t *)a.state)[row0 + tid + k * nt] = r;
       }
+    }
+}
+
+// Apply pass of a factor's LAST level fused with the FIRST level of the next factor (split e / q layout,
+// tiles aligned to the first level's contiguous columns, StepPlan::build_aligned_tiles). While the tile is in
+// LDS with the final e of factor f, the workgroup
+//   1. rebuilds q for factor f + 1 from the rows' CSR entries and V[:, f + 1] (FMTrainer.hpp:320),
+//   2. runs the conditional of every first-level column lying inside the tile: statistics over the column's
+//      (contiguous) rows from LDS, draw, update of e and q in LDS (FMTrainer.hpp:343-376) -- a wavefront per
+//      column, the columns' scalars prefetched 64 at a time,
+//   3. writes e and the new q back.
+// The tile's rows cross HBM once for both levels, and the latency-bound column kernels of the first level
+// are left with only the columns longer than a tile (k_long_coop, launched afterwards).
+struct FuseArgs {
+  double *theta_next;       // V[:, f + 1]
+  const double *z_next;
+  const double *lam_next;   // [G]
+  const double *mu_next;
+  const int32_t *fuse_cols;     // first-level columns inside the tiles, row order
+  const int32_t *fuse_col_ptr;  // [n_tiles + 1]
+};
+
+template <bool UNIT>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_tile_apply_next(
+    SweepArgs a, const uint32_t *__restrict__ tent, const double *__restrict__ tval, const int32_t *__restrict__ tile_ptr,
+    const int32_t *__restrict__ tile_row0, const double2 *__restrict__ oldnew, int tile_bits, int n_tiles, int swz,
+    FuseArgs fa) {
+  extern __shared__ double2 lds_rec[];
+  const int b = xcd_swizzle(blockIdx.x, n_tiles, swz);
+  const int64_t row0 = tile_row0[b];
+  const int nr = tile_row0[b + 1] - (int)row0;
+  const int nt = blockDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+  double *E = (double *)a.state, *Q = a.state2;
+  d2_t rec[TILE_K];
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    rec[k] = d2_t{0.0, 0.0};
+    if (tid + k * nt < nr) rec[k] = d2_t{E[row0 + tid + k * nt], Q[row0 + tid + k * nt]};
+  }
+  const int64_t p0 = (int64_t)tile_ptr[b] * WAVE + tid, p1 = (int64_t)tile_ptr[b + 1] * WAVE;
+  uint32_t u[TILE_K];
+  double x[TILE_K];
+  d2_t on[TILE_K];
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    const int64_t p = p0 + (int64_t)k * nt;
+    u[k] = TILE_PAD;
+    x[k] = 1.0;
+    if (p < p1) {
+      u[k] = tent[p];
+      if (!UNIT) x[k] = tval[p];
+    }
+  }
+  // q of the next factor for this thread's rows
+  double qn[TILE_K];
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    qn[k] = 0.0;
+    if (tid + k * nt < nr) {
+      const int64_t row = row0 + tid + k * nt;
+      if (a.r_ell == 2) {
+        const int2 ci = *(const int2 *)(a.r_colidx + row * 2);
+        const double v0 = fa.theta_next[ci.x], v1 = fa.theta_next[ci.y];
+        qn[k] = (UNIT ? 1.0 : a.r_val[row * 2]) * v0;
+        qn[k] += (UNIT ? 1.0 : a.r_val[row * 2 + 1]) * v1;
+      } else {
+        int64_t pb, pe;
+        if (a.r_ell >= 0) {
+          pb = row * a.r_ell;
+          pe = pb + a.r_ell;
+        } else {
+          pb = a.r_rowptr[row];
+          pe = a.r_rowptr[row + 1];
+        }
+        double q = 0.0;
+        for (int64_t p = pb; p < pe; p++) q += (UNIT ? 1.0 : a.r_val[p]) * fa.theta_next[a.r_colidx[p]];
+        qn[k] = q;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    on[k] = d2_t{0.0, 0.0};
+    if (u[k] != TILE_PAD) on[k] = ((const d2_t *)oldnew)[u[k] >> tile_bits];
+  }
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++)
+    if (tid + k * nt < nr) ((d2_t *)lds_rec)[tid + k * nt] = rec[k];
+  __syncthreads();
+  // last level of factor f: only e matters from here on
+  const uint32_t rmask = (1u << tile_bits) - 1u;
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    if (u[k] == TILE_PAD) continue;
+    const uint32_t r = u[k] & rmask;
+    lds_rec[r].x = PMainV::updated(x[k], lds_rec[r], on[k][0], on[k][1]).x;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++)
+    if (tid + k * nt < nr) lds_rec[tid + k * nt].y = qn[k];
+  __syncthreads();
+  // first level of factor f + 1: one wavefront per column, lane m of a batch prefetches column m's scalars
+  const int c0 = fa.fuse_col_ptr[b], c1 = fa.fuse_col_ptr[b + 1];
+  for (int cb = c0 + wv; cb < c1; cb += nw * WAVE) {
+    const int cm = cb + lane * nw;
+    int pj = 0, plen = 0, plr0 = 0;
+    int64_t pbeg = 0;
+    double pold = 0.0, pz = 0.0, plam = 0.0, pmu = 0.0;
+    if (cm < c1) {
+      pj = fa.fuse_cols[cm];
+      pbeg = a.colptr[pj];
+      plen = (int)(a.colptr[pj + 1] - pbeg);
+      plr0 = a.row0[pj] - (int)row0;
+      pold = fa.theta_next[pj];
+      pz = fa.z_next[pj];
+      const int g = a.group[pj];
+      plam = fa.lam_next[g];
+      pmu = fa.mu_next[g];
+    }
+    const int nb_cols = min(WAVE, (c1 - cb + nw - 1) / nw);
+    for (int m = 0; m < nb_cols; m++) {
+      const int j = __builtin_amdgcn_readlane(pj, m), len = __builtin_amdgcn_readlane(plen, m);
+      const int lr0 = __builtin_amdgcn_readlane(plr0, m);
+      const int64_t beg = readlane_i64(pbeg, m);
+      const double old = readlane_f64(pold, m), zj = readlane_f64(pz, m);
+      const double lam = readlane_f64(plam, m), mu = readlane_f64(pmu, m);
+      double S1 = 0.0, S2 = 0.0;
+      for (int i = lane; i < len; i += WAVE) {
+        const double xv = UNIT ? 1.0 : a.val[beg + i];
+        PMainV::stats(xv, lds_rec[lr0 + i], old, S1, S2);
+      }
+      S1 = wave_allreduce_sum(S1);
+      S2 = wave_allreduce_sum(S2);
+      const double fresh = PMainV::draw(S1, S2, old, a.alpha, lam, mu, zj);
+      for (int i = lane; i < len; i += WAVE) {
+        const double xv = UNIT ? 1.0 : a.val[beg + i];
+        lds_rec[lr0 + i] = PMainV::updated(xv, lds_rec[lr0 + i], old, fresh);
+      }
+      if (lane == 0) fa.theta_next[j] = fresh;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++)
+    if (tid + k * nt < nr) {
+      const d2_t r = ((const d2_t *)lds_rec)[tid + k * nt];
+      E[row0 + tid + k * nt] = r[0];
+      Q[row0 + tid + k * nt] = r[1];
     }
 }
 

@@ -56,6 +56,7 @@ struct ParLevel {
   int tile_bits = 0, n_tiles = 0;
   DevBuf<uint32_t> tent;      // padded per tile to whole 64-entry wave tiles
   DevBuf<int32_t> tile_ptr;   // [n_tiles + 1], in wave tiles
+  DevBuf<int32_t> tile_row0;  // [n_tiles + 1] first row of every tile (fixed 2^tile_bits grid, or StepPlan::h_tile_start)
   bool covers_rows_once = false;  // every row of the table has exactly one entry in this level
   bool first_and_once = false;    // ... and it is the first step of the plan: the level can rebuild q itself
   bool contig = false;            // every column of the level covers a contiguous row range (StepPlan::col_row0)
@@ -83,6 +84,12 @@ struct StepPlan {
   int max_hchunks = 0, max_huge = 0;
   int64_t launches = 0;
   DevBuf<int32_t> col_row0;  // first row of every column (used by levels with contiguous columns)
+  // Row tiles aligned to the columns of a contiguous first level (every such column of <= 2^tile_bits rows lies
+  // inside one tile; longer columns get tiles of their own): lets the apply pass of the last level run the
+  // first level of the NEXT factor on the tile while it is in LDS (k_tile_apply_next).
+  std::vector<int32_t> h_tile_start;
+  DevBuf<int32_t> fuse_cols, fuse_col_ptr;  // first-level columns inside each tile, in row order
+  bool aligned_tiles = false;
 
   // a level is "tiny" when running it as its own launches cannot fill the device anyway
   static bool tiny(size_t n_cols, int64_t nnz) { return n_cols <= 8 && nnz <= 16384; }
@@ -95,7 +102,7 @@ struct StepPlan {
   // L untouched) when the level is small or its columns are mostly contiguous.
   // tile_bits > 0: row-tile variant (tiles of 2^tile_bits rows staged in LDS, packed + padded entries)
   static bool build_scattered(const HostCsr &csc, const std::vector<int32_t> &cols, int64_t lnnz, bool unit, ParLevel &L,
-                              int tile_bits = 0) {
+                              int tile_bits = 0, const std::vector<int32_t> *bounds = nullptr) {
     int64_t min_nnz = 1 << 20;  // below this the level is launch-bound anyway
     if (const char *e = std::getenv("MFM_SCATTER_MIN_NNZ")) min_nnz = std::atoll(e);
     if (lnnz < min_nnz) return false;
@@ -111,7 +118,7 @@ struct StepPlan {
       // packed entry must hold the column's position in the level
       if (2 * lnnz < N || (int64_t)cols.size() >= ((int64_t)1 << (32 - tile_bits)) - 1) tile_bits = 0;
     }
-    if (tile_bits > 0) return build_tiled(csc, cols, lnnz, unit, L, tile_bits);
+    if (tile_bits > 0) return build_tiled(csc, cols, lnnz, unit, L, tile_bits, bounds);
     int64_t RB = SCAT_RB;
     if (const char *e = std::getenv("MFM_SCAT_RB")) RB = std::max<int64_t>(1024, std::atoll(e));
     const int64_t nb = (N + RB - 1) / RB;
@@ -176,13 +183,24 @@ struct StepPlan {
     return true;
   }
 
+  // bounds: tile boundaries (row starts, last = N), every tile at most 2^tile_bits rows; null: fixed grid
   static bool build_tiled(const HostCsr &csc, const std::vector<int32_t> &cols, int64_t lnnz, bool unit, ParLevel &L,
-                          int tile_bits) {
+                          int tile_bits, const std::vector<int32_t> *bounds = nullptr) {
     const int64_t N = csc.cols, RB = (int64_t)1 << tile_bits;
-    const int64_t nb = (N + RB - 1) / RB;
+    std::vector<int32_t> grid;
+    if (!bounds || bounds->size() < 2) {
+      for (int64_t r = 0; r < N; r += RB) grid.push_back((int32_t)r);
+      grid.push_back((int32_t)N);
+      bounds = &grid;
+    }
+    const std::vector<int32_t> &tstart = *bounds;
+    const int64_t nb = (int64_t)tstart.size() - 1;
+    std::vector<int32_t> row_tile((size_t)N);
+    for (int64_t b = 0; b < nb; b++)
+      for (int64_t r = tstart[b]; r < tstart[b + 1]; r++) row_tile[r] = (int32_t)b;
     std::vector<int64_t> cnt((size_t)nb + 1, 0);
     for (int32_t j : cols)
-      for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) cnt[csc.idx[p] / RB + 1]++;
+      for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) cnt[row_tile[csc.idx[p]] + 1]++;
     std::vector<int32_t> tptr((size_t)nb + 1, 0);  // in wave tiles
     for (int64_t b = 0; b < nb; b++) {
       const int64_t t = (int64_t)tptr[b] + (cnt[b + 1] + WAVE - 1) / WAVE;
@@ -199,8 +217,8 @@ struct StepPlan {
       for (size_t c = 0; c < cols.size(); c++) {  // ascending column, ascending row inside: (tile, column, row)
         const int32_t j = cols[c];
         for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) {
-          const int64_t r = csc.idx[p], q = cur[r / RB]++;
-          ent[q] = ((uint32_t)c << tile_bits) | (uint32_t)(r & (RB - 1));
+          const int64_t r = csc.idx[p], b = row_tile[r], q = cur[b]++;
+          ent[q] = ((uint32_t)c << tile_bits) | (uint32_t)(r - tstart[b]);
           if (!unit) ev[q] = csc.val[p];
         }
       }
@@ -243,6 +261,7 @@ struct StepPlan {
     L.tent.upload(ent);
     if (!unit) L.ent_val.upload(ev);
     L.tile_ptr.upload(tptr);
+    L.tile_row0.upload(tstart);
     L.run_base.upload(run_base);
     L.scols.upload(cols);
     L.slot_ptr.upload(sptr);
@@ -256,6 +275,44 @@ struct StepPlan {
     }
     L.slots.alloc((size_t)std::max<size_t>(run_col.size(), 1));
     return true;
+  }
+
+  void build_aligned_tiles(const HostCsr &csc, const std::vector<int32_t> &cols, int64_t RB) {
+    std::vector<int32_t> order(cols);
+    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return csc.idx[csc.ptr[x]] < csc.idx[csc.ptr[y]]; });
+    std::vector<int32_t> fcols, fptr;
+    h_tile_start.clear();
+    int64_t cur_rows = 0, next_row = 0;
+    auto open_tile = [&](int64_t row) {
+      h_tile_start.push_back((int32_t)row);
+      fptr.push_back((int32_t)fcols.size());
+      cur_rows = 0;
+    };
+    for (int32_t j : order) {
+      const int64_t r0 = csc.idx[csc.ptr[j]], len = csc.ptr[j + 1] - csc.ptr[j];
+      if (r0 != next_row) {  // (cannot happen: the level covers every row once with contiguous columns)
+        h_tile_start.clear();
+        return;
+      }
+      if (len > RB) {
+        for (int64_t r = r0; r < r0 + len; r += RB) open_tile(r);
+        cur_rows = RB;  // closed
+      } else {
+        if (h_tile_start.empty() || cur_rows + len > RB) open_tile(r0);
+        fcols.push_back(j);
+        cur_rows += len;
+      }
+      next_row = r0 + len;
+    }
+    h_tile_start.push_back((int32_t)next_row);
+    fptr.push_back((int32_t)fcols.size());
+    if (next_row != csc.cols) {
+      h_tile_start.clear();
+      return;
+    }
+    fuse_cols.upload(fcols);
+    fuse_col_ptr.upload(fptr);
+    aligned_tiles = true;
   }
 
   int tile_bits = 0;     // > 0: scattered levels use the row-tile path with tiles of 2^tile_bits rows
@@ -339,7 +396,8 @@ struct StepPlan {
       L.n_all = (int)by_level[l].size();
       L.jmin = *std::min_element(by_level[l].begin(), by_level[l].end());
       L.jmax = *std::max_element(by_level[l].begin(), by_level[l].end());
-      if (allow_scatter && build_scattered(csc, by_level[l], lnnz, unit, L, sharded ? 0 : tile_bits)) {
+      if (allow_scatter && build_scattered(csc, by_level[l], lnnz, unit, L, sharded ? 0 : tile_bits,
+                                           aligned_tiles ? &h_tile_start : nullptr)) {
         launches += 3;
         max_cols_scat = std::max<int64_t>(max_cols_scat, csc.rows);
         continue;
@@ -393,6 +451,9 @@ struct StepPlan {
         }
         L.contig = contig;
       }
+      if (steps.size() == 1 && L.contig && L.first_and_once && allow_scatter && !sharded && tile_bits > 0 &&
+          ((int64_t)1 << tile_bits) == cap_wg && hg.empty() && !std::getenv("MFM_NO_ALIGNED_TILES"))
+        build_aligned_tiles(csc, by_level[l], (int64_t)1 << tile_bits);
       L.n_w1 = (int)w1.size();
       L.n_w4 = (int)w4.size();
       L.n_w16 = (int)w16.size();
@@ -489,11 +550,12 @@ static inline bool plan_first_level_builds_q(const StepPlan &plan) {
 
 template <class P, bool UNIT>
 static void launch_binned_level(hipStream_t s, Timing &tm, const ParLevel &L, const SweepArgs &a_in, LongScratch &ls,
-                                const SweepClasses &kc, const int32_t *col_row0) {
+                                const SweepClasses &kc, const int32_t *col_row0, int parts = 3) {
+  // parts: bit 0 = the long (co-resident) columns, bit 1 = the wavefront / workgroup bins
   SweepArgs a = a_in;
   a.row0 = L.contig ? col_row0 : nullptr;
   // the long columns first: they are the critical path of the level
-  if (L.n_long) {
+  if (L.n_long && (parts & 1)) {
     L.epoch++;
     CoopArgs ca;
     ca.chunks = L.lchunks.p;
@@ -508,6 +570,7 @@ static void launch_binned_level(hipStream_t s, Timing &tm, const ParLevel &L, co
       hipLaunchKernelGGL((k_long_coop<P, UNIT>), dim3(L.rounds[r].second), dim3(WG), 0, s, a, ca, L.rounds[r].first);
     }
   }
+  if (!(parts & 2)) return;
   if (L.n_wg + L.n_w16) {
     TimedLaunch t(tm, s, kc.heavy, P::BYTES * L.nnz_heavy);
     hipLaunchKernelGGL((k_level_heavy<P, UNIT>), dim3(L.n_wg + (L.n_w16 + 3) / 4), dim3(WG), 0, s, a, L.cols_wg.p, L.n_wg,
@@ -566,12 +629,11 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
         hipLaunchKernelGGL(k_tile_old, dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a.theta, L.scols.p, L.n_cols,
                            ls.oldnew_col.p);
         hipLaunchKernelGGL((k_tile_stats<P, UNIT>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p, L.tile_ptr.p,
-                           ls.oldnew_col.p, L.run_base.p, L.slot_pos.p, L.slots.p, L.tile_bits, plan.n_state_rows, L.n_tiles,
-                           swz);
+                           L.tile_row0.p, ls.oldnew_col.p, L.run_base.p, L.slot_pos.p, L.slots.p, L.tile_bits, L.n_tiles, swz);
         hipLaunchKernelGGL((k_tile_draw<P>), dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.slot_ptr.p,
                            L.slots.p, ls.oldnew_col.p);
         hipLaunchKernelGGL((k_tile_apply<P, UNIT>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p,
-                           L.tile_ptr.p, ls.oldnew_col.p, L.tile_bits, plan.n_state_rows, L.n_tiles, swz);
+                           L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz);
       }
       continue;
     }
@@ -733,54 +795,91 @@ static void launch_huge(hipStream_t s, Timing &tm, const ParLevel &L, const Swee
   }
 }
 
-// latent sweep of one factor in the split layout: a.state = e[N], a.state2 = q[N]
-template <bool UNIT>
-static void run_plan_soa(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls,
-                         const SweepClasses &kc) {
-  for (const Step &st : plan.steps) {
-    const ParLevel &L = st.par;
-    const bool first = &st == &plan.steps.front(), last = &st == &plan.steps.back();
-    if (L.scattered) {  // (tiled: plan_supports_soa)
-      TimedLaunch t(tm, s, kc.scat, (last ? 48.0 : 56.0) * L.n_ent);
-      const int swz = xcd_swizzle_enabled();
-      const size_t lds = sizeof(double2) << L.tile_bits;
-      const int nt = tile_threads(L.tile_bits);
-      if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_stats<PMainV, UNIT, true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_MAX));
-          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply<PMainV, UNIT, true, true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_MAX));
-          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply<PMainV, UNIT, true, false>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_MAX));
-          raised = true;
-        }
-      }
-      hipLaunchKernelGGL(k_tile_old, dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a.theta, L.scols.p, L.n_cols,
-                         ls.oldnew_col.p);
-      hipLaunchKernelGGL((k_tile_stats<PMainV, UNIT, true>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p,
-                         L.tile_ptr.p, ls.oldnew_col.p, L.run_base.p, L.slot_pos.p, L.slots.p, L.tile_bits, plan.n_state_rows,
-                         L.n_tiles, swz);
-      hipLaunchKernelGGL((k_tile_draw<PMainV>), dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols,
-                         L.slot_ptr.p, L.slots.p, ls.oldnew_col.p);
-      if (last)
-        hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, false>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p,
-                           L.ent_val.p, L.tile_ptr.p, ls.oldnew_col.p, L.tile_bits, plan.n_state_rows, L.n_tiles, swz);
-      else
-        hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, true>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p,
-                           L.ent_val.p, L.tile_ptr.p, ls.oldnew_col.p, L.tile_bits, plan.n_state_rows, L.n_tiles, swz);
-      continue;
+// Is the last level's apply pass fusable with the next factor's first level (k_tile_apply_next)?
+static inline bool plan_supports_fused_next(const StepPlan &plan) {
+  if (!plan_supports_soa(plan) || !plan.aligned_tiles) return false;
+  const ParLevel &first = plan.steps.front().par, &last = plan.steps.back().par;
+  return first.contig && first.n_huge == 0 && last.scattered && last.tiled;
+}
+
+template <class P, bool UNIT>
+static void launch_tile_head(hipStream_t s, const ParLevel &L, const SweepArgs &a, LongScratch &ls, int swz) {
+  const size_t lds = sizeof(double2) << L.tile_bits;
+  const int nt = tile_threads(L.tile_bits);
+  hipLaunchKernelGGL(k_tile_old, dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a.theta, L.scols.p, L.n_cols, ls.oldnew_col.p);
+  hipLaunchKernelGGL((k_tile_stats<P, UNIT, true>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p, L.tile_ptr.p,
+                     L.tile_row0.p, ls.oldnew_col.p, L.run_base.p, L.slot_pos.p, L.slots.p, L.tile_bits, L.n_tiles, swz);
+  hipLaunchKernelGGL((k_tile_draw<P>), dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.slot_ptr.p,
+                     L.slots.p, ls.oldnew_col.p);
+}
+
+// Latent sweep of factors [f_begin, f_end) in the split layout: args(f).state = e[N], .state2 = q[N].
+// fuse: the last level's apply pass also runs the next factor's first level (short columns) on the tile.
+template <bool UNIT, class ArgsOf>
+static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf args, int f_begin, int f_end,
+                          LongScratch &ls, const SweepClasses &kc, bool fuse) {
+  const int swz = xcd_swizzle_enabled();
+  {
+    static bool raised = false;  // tiles beyond the default dynamic-LDS limit: opt in once
+    if (!raised && plan.tile_bits > 12) {
+      const int lim = (int)CHAIN_LDS_MAX;
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_stats<PMainV, UNIT, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply<PMainV, UNIT, true, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply<PMainV, UNIT, true, false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      raised = true;
     }
-    if (first) {
-      launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, L, a, ls, kc, plan.col_row0.p);
-      launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, L, a, ls, kc);
-    } else if (last) {
-      launch_binned_level<PMainVsl, UNIT>(s, tm, L, a, ls, kc, plan.col_row0.p);
-      launch_huge<PMainVsl, UNIT>(s, tm, L, a, ls, kc);
-    } else {
-      launch_binned_level<PMainVs, UNIT>(s, tm, L, a, ls, kc, plan.col_row0.p);
-      launch_huge<PMainVs, UNIT>(s, tm, L, a, ls, kc);
+  }
+  for (int f = f_begin; f < f_end; f++) {
+    const SweepArgs a = args(f);
+    for (const Step &st : plan.steps) {
+      const ParLevel &L = st.par;
+      const bool first = &st == &plan.steps.front(), last = &st == &plan.steps.back();
+      if (L.scattered) {  // (tiled: plan_supports_soa)
+        const size_t lds = sizeof(double2) << L.tile_bits;
+        const int nt = tile_threads(L.tile_bits);
+        if (last && fuse && f + 1 < f_end) {
+          {
+            TimedLaunch t(tm, s, kc.scat, 20.0 * L.n_ent);
+            launch_tile_head<PMainV, UNIT>(s, L, a, ls, swz);
+          }
+          SweepArgs an = args(f + 1);
+          an.row0 = plan.col_row0.p;
+          {
+            TimedLaunch t(tm, s, KC_SWEEP_V_FUSED, 44.0 * plan.n_state_rows);
+            SweepArgs af = a;
+            af.row0 = plan.col_row0.p;
+            FuseArgs fa{an.theta, an.z, an.lambda, an.mu, plan.fuse_cols.p, plan.fuse_col_ptr.p};
+            hipLaunchKernelGGL((k_tile_apply_next<UNIT>), dim3(L.n_tiles), dim3(nt), lds, s, af, L.tent.p, L.ent_val.p,
+                               L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
+          }
+          // first-level columns longer than a tile
+          launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, plan.steps.front().par, an, ls, kc, plan.col_row0.p, 1);
+          continue;
+        }
+        TimedLaunch t(tm, s, kc.scat, (last ? 48.0 : 56.0) * L.n_ent);
+        launch_tile_head<PMainV, UNIT>(s, L, a, ls, swz);
+        if (last)
+          hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, false>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p,
+                             L.ent_val.p, L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz);
+        else
+          hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, true>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p,
+                             L.ent_val.p, L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz);
+        continue;
+      }
+      if (first) {
+        if (fuse && f > f_begin) continue;  // done by the previous factor's fused apply pass
+        launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, L, a, ls, kc, plan.col_row0.p);
+        launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, L, a, ls, kc);
+      } else if (last) {
+        launch_binned_level<PMainVsl, UNIT>(s, tm, L, a, ls, kc, plan.col_row0.p);
+        launch_huge<PMainVsl, UNIT>(s, tm, L, a, ls, kc);
+      } else {
+        launch_binned_level<PMainVs, UNIT>(s, tm, L, a, ls, kc, plan.col_row0.p);
+        launch_huge<PMainVs, UNIT>(s, tm, L, a, ls, kc);
+      }
     }
   }
   MFM_HIP_CHECK(hipGetLastError());

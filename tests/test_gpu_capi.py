@@ -189,14 +189,19 @@ def test_row_tile_level_path(oracle, capi, monkeypatch, tile_bits):
         assert "sweep_V_scattered" in _timing_classes(c, drv)
 
 
-@pytest.mark.parametrize("n_fields", [2, 3])
-def test_split_layout_latent_sweep(oracle, capi, monkeypatch, n_fields):
+@pytest.mark.parametrize("n_fields,fused", [(2, True), (3, True), (2, False)])
+def test_split_layout_latent_sweep(oracle, capi, monkeypatch, n_fields, fused):
     # update_V with e and q as separate arrays (run_plan_soa): first level (user-sorted, contiguous columns)
     # rebuilds q, middle levels read and write both, the last level writes only e; q_train is restored after
+    # fused: the last level's apply pass also runs the next factor's first level on the LDS tile
+    # (k_tile_apply_next; tiles aligned to the users' row ranges, a few users longer than a tile)
     monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    if not fused:
+        monkeypatch.setenv("MFM_NO_FUSED_NEXT", "1")
     import scipy.sparse as sps
     n = 150001
-    X, y, shapes = ds.onehot_mf(n, 500, 120, seed=21, sort_by_user=True)
+    X, y, shapes = ds.onehot_mf(n, 200, 120, seed=21, sort_by_user=True)
+    assert np.diff(X.tocsc().indptr)[:200].max() > 4096
     if n_fields == 3:
         rng = np.random.default_rng(3)
         ctx = rng.integers(0, 37, size=n)
@@ -210,7 +215,7 @@ def test_split_layout_latent_sweep(oracle, capi, monkeypatch, n_fields):
         if scale:
             Xs.data = np.where(np.arange(Xs.nnz) % 3 == 0, scale, 1.5)
         t, c, _ = _pair(oracle, capi, Xs, y, gi, 3)
-        assert c.plan_flags()["soa"]
+        assert c.plan_flags()["soa"] and c.plan_flags()["fused_next"] == fused
         drv = CapiGibbs(c, t.clone(), n, gi)
         for it in range(3):
             t.step()
