@@ -863,10 +863,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
 template <class P>
 __global__ __launch_bounds__(WG) void k_tile_draw(SweepArgs a, const int32_t *__restrict__ cols, int n_cols,
                                                   const int32_t *__restrict__ slot_ptr, const double2 *__restrict__ slots,
-                                                  double2 *__restrict__ oldnew) {
+                                                  double2 *__restrict__ oldnew, const double *__restrict__ theta_next = nullptr,
+                                                  double *__restrict__ vnext_col = nullptr) {
   const int c = blockIdx.x * (WG / WAVE) + (threadIdx.x >> 6);
   if (c >= n_cols) return;
   const int lane = threadIdx.x & 63;
+  if (theta_next && lane == 1) vnext_col[c] = theta_next[cols[c]];  // for k_tile_apply_next<.., TWO>
   double S1 = 0.0, S2 = 0.0;
   for (int k = slot_ptr[c] + lane; k < slot_ptr[c + 1]; k += WAVE) {
     const double2 s = slots[k];
@@ -968,9 +970,14 @@ struct FuseArgs {
   const double *mu_next;
   const int32_t *fuse_cols;     // first-level columns inside the tiles, row order
   const int32_t *fuse_col_ptr;  // [n_tiles + 1]
+  const double *vnext_col;      // TWO: V[col, f + 1] per column of the last level (k_tile_draw)
 };
 
-template <bool UNIT>
+// TWO: the plan has exactly these two levels and the last one covers every row once (a two-field one-hot
+// table): q of the next factor is x_last * V[last col, f + 1] (gathered per ENTRY from the compact vnext_col,
+// entries are sorted by column) + x_first * V[first col, f + 1] (uniform per first-level column) -- no CSR
+// read and no per-row gather; with two terms the sum is the same in either order.
+template <bool UNIT, bool TWO>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_tile_apply_next(
     SweepArgs a, const uint32_t *__restrict__ tent, const double *__restrict__ tval, const int32_t *__restrict__ tile_ptr,
     const int32_t *__restrict__ tile_row0, const double2 *__restrict__ oldnew, int tile_bits, int n_tiles, int swz,
@@ -1001,12 +1008,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
       if (!UNIT) x[k] = tval[p];
     }
   }
-  // q of the next factor for this thread's rows
+  // q of the next factor for this thread's rows (TWO: the last level's term, per entry)
   double qn[TILE_K];
 #pragma unroll
   for (int k = 0; k < TILE_K; k++) {
     qn[k] = 0.0;
-    if (tid + k * nt < nr) {
+    if (TWO) {
+      if (u[k] != TILE_PAD) qn[k] = x[k] * fa.vnext_col[u[k] >> tile_bits];
+    } else if (tid + k * nt < nr) {
       const int64_t row = row0 + tid + k * nt;
       if (a.r_ell == 2) {
         const int2 ci = *(const int2 *)(a.r_colidx + row * 2);
@@ -1043,13 +1052,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
   for (int k = 0; k < TILE_K; k++) {
     if (u[k] == TILE_PAD) continue;
     const uint32_t r = u[k] & rmask;
-    lds_rec[r].x = PMainV::updated(x[k], lds_rec[r], on[k][0], on[k][1]).x;
+    const double en = PMainV::updated(x[k], lds_rec[r], on[k][0], on[k][1]).x;
+    if (TWO)
+      lds_rec[r] = make_double2(en, qn[k]);  // q_f of this row is dead now
+    else
+      lds_rec[r].x = en;
   }
   __syncthreads();
+  if (!TWO) {
 #pragma unroll
-  for (int k = 0; k < TILE_K; k++)
-    if (tid + k * nt < nr) lds_rec[tid + k * nt].y = qn[k];
-  __syncthreads();
+    for (int k = 0; k < TILE_K; k++)
+      if (tid + k * nt < nr) lds_rec[tid + k * nt].y = qn[k];
+    __syncthreads();
+  }
   // first level of factor f + 1: one wavefront per column, lane m of a batch prefetches column m's scalars
   const int c0 = fa.fuse_col_ptr[b], c1 = fa.fuse_col_ptr[b + 1];
   for (int cb = c0 + wv; cb < c1; cb += nw * WAVE) {
@@ -1078,14 +1093,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
       double S1 = 0.0, S2 = 0.0;
       for (int i = lane; i < len; i += WAVE) {
         const double xv = UNIT ? 1.0 : a.val[beg + i];
-        PMainV::stats(xv, lds_rec[lr0 + i], old, S1, S2);
+        double2 st = lds_rec[lr0 + i];
+        if (TWO) st.y += xv * old;
+        PMainV::stats(xv, st, old, S1, S2);
       }
       S1 = wave_allreduce_sum(S1);
       S2 = wave_allreduce_sum(S2);
       const double fresh = PMainV::draw(S1, S2, old, a.alpha, lam, mu, zj);
       for (int i = lane; i < len; i += WAVE) {
         const double xv = UNIT ? 1.0 : a.val[beg + i];
-        lds_rec[lr0 + i] = PMainV::updated(xv, lds_rec[lr0 + i], old, fresh);
+        double2 st = lds_rec[lr0 + i];
+        if (TWO) st.y += xv * old;
+        lds_rec[lr0 + i] = PMainV::updated(xv, st, old, fresh);
       }
       if (lane == 0) fa.theta_next[j] = fresh;
     }

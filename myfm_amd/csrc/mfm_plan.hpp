@@ -505,8 +505,12 @@ struct LongScratch {
   DevBuf<int> error;  // set by k_long_coop on a spin timeout
   DevBuf<double2> oldnew_col;  // scattered levels / sharded mode: (old, new) per column of the matrix
   DevBuf<double2> S_col;       // sharded mode: per-column statistics (all-reduced over the ranks)
+  DevBuf<double> vnext_col;    // fused apply pass: next factor's coefficient per column of the last level
   void reserve_cols(int64_t n_cols) {
-    if ((size_t)n_cols > oldnew_col.n) oldnew_col.alloc((size_t)n_cols);
+    if ((size_t)n_cols > oldnew_col.n) {
+      oldnew_col.alloc((size_t)n_cols);
+      vnext_col.alloc((size_t)n_cols);
+    }
   }
   void reserve_stats(int64_t n_cols) {
     if ((size_t)n_cols > S_col.n) S_col.alloc((size_t)n_cols);
@@ -803,14 +807,15 @@ static inline bool plan_supports_fused_next(const StepPlan &plan) {
 }
 
 template <class P, bool UNIT>
-static void launch_tile_head(hipStream_t s, const ParLevel &L, const SweepArgs &a, LongScratch &ls, int swz) {
+static void launch_tile_head(hipStream_t s, const ParLevel &L, const SweepArgs &a, LongScratch &ls, int swz,
+                             const double *theta_next = nullptr) {
   const size_t lds = sizeof(double2) << L.tile_bits;
   const int nt = tile_threads(L.tile_bits);
   hipLaunchKernelGGL(k_tile_old, dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a.theta, L.scols.p, L.n_cols, ls.oldnew_col.p);
   hipLaunchKernelGGL((k_tile_stats<P, UNIT, true>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p, L.tile_ptr.p,
                      L.tile_row0.p, ls.oldnew_col.p, L.run_base.p, L.slot_pos.p, L.slots.p, L.tile_bits, L.n_tiles, swz);
   hipLaunchKernelGGL((k_tile_draw<P>), dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.slot_ptr.p,
-                     L.slots.p, ls.oldnew_col.p);
+                     L.slots.p, ls.oldnew_col.p, theta_next, ls.vnext_col.p);
 }
 
 // Latent sweep of factors [f_begin, f_end) in the split layout: args(f).state = e[N], .state2 = q[N].
@@ -841,19 +846,24 @@ static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsO
         const size_t lds = sizeof(double2) << L.tile_bits;
         const int nt = tile_threads(L.tile_bits);
         if (last && fuse && f + 1 < f_end) {
-          {
-            TimedLaunch t(tm, s, kc.scat, 20.0 * L.n_ent);
-            launch_tile_head<PMainV, UNIT>(s, L, a, ls, swz);
-          }
           SweepArgs an = args(f + 1);
           an.row0 = plan.col_row0.p;
+          const bool two = plan.steps.size() == 2 && L.covers_rows_once && !std::getenv("MFM_NO_FUSED_TWO");
+          {
+            TimedLaunch t(tm, s, kc.scat, 20.0 * L.n_ent);
+            launch_tile_head<PMainV, UNIT>(s, L, a, ls, swz, two ? an.theta : nullptr);
+          }
           {
             TimedLaunch t(tm, s, KC_SWEEP_V_FUSED, 44.0 * plan.n_state_rows);
             SweepArgs af = a;
             af.row0 = plan.col_row0.p;
-            FuseArgs fa{an.theta, an.z, an.lambda, an.mu, plan.fuse_cols.p, plan.fuse_col_ptr.p};
-            hipLaunchKernelGGL((k_tile_apply_next<UNIT>), dim3(L.n_tiles), dim3(nt), lds, s, af, L.tent.p, L.ent_val.p,
-                               L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
+            FuseArgs fa{an.theta, an.z, an.lambda, an.mu, plan.fuse_cols.p, plan.fuse_col_ptr.p, ls.vnext_col.p};
+            if (two)
+              hipLaunchKernelGGL((k_tile_apply_next<UNIT, true>), dim3(L.n_tiles), dim3(nt), lds, s, af, L.tent.p, L.ent_val.p,
+                                 L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
+            else
+              hipLaunchKernelGGL((k_tile_apply_next<UNIT, false>), dim3(L.n_tiles), dim3(nt), lds, s, af, L.tent.p,
+                                 L.ent_val.p, L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
           }
           // first-level columns longer than a tile
           launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, plan.steps.front().par, an, ls, kc, plan.col_row0.p, 1);
