@@ -781,24 +781,55 @@ constexpr uint32_t TILE_PAD = 0xffffffffu;
 constexpr int TILE_K = 8;  // rows (and at most entries: a level has <= 1 entry per row) per thread of a tile
 typedef double d2_t __attribute__((ext_vector_type(2)));  // register-resident 16-byte record (native vector)
 
-// before the statistics pass: (old, .) per column of the level, so that the entry loop needs one gather
+// before the statistics pass: the current coefficient per column of the level as a compact array, so that the
+// entry loop needs one gather (in the fused flow k_tile_draw of the previous factor fills it instead)
 __global__ void k_tile_old(const double *__restrict__ theta, const int32_t *__restrict__ cols, int n_cols,
-                           double2 *__restrict__ oldnew) {
+                           double *__restrict__ told) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < n_cols) oldnew[c].x = theta[cols[c]];
+  if (c < n_cols) told[c] = theta[cols[c]];
+}
+
+// statistics of the <= TILE_K wave tiles of entries a wave holds in registers, from the tile in LDS:
+// segmented reduction over runs of equal column, one slot per run (column-major slot order: the draw streams)
+template <class P>
+__device__ __forceinline__ void tile_entry_stats(const double2 *lds_rec, const uint32_t (&u)[TILE_K], const double (&x)[TILE_K],
+                                                 const double (&old)[TILE_K], const int (&rb)[TILE_K], int t0, int t1, int nw,
+                                                 int lane, int tile_bits, const int32_t *__restrict__ slot_pos,
+                                                 double2 *__restrict__ slots) {
+  const uint32_t rmask = (1u << tile_bits) - 1u;
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    const int t = t0 + k * nw;
+    if (t >= t1) continue;  // wave-uniform
+    const bool valid = u[k] != TILE_PAD;
+    int c = -1 - lane;  // padding lanes: distinct keys, never stored
+    double s1 = 0.0, s2 = 0.0;
+    if (valid) {
+      c = (int)(u[k] >> tile_bits);
+      P::stats(x[k], P::from_rec(lds_rec[u[k] & rmask]), old[k], s1, s2);
+    }
+    const int cp = dpp_i32<0x138, 0xf>(c, 0), cn = dpp_i32<0x130, 0xf>(c, 0);  // wave_shr:1 / wave_shl:1
+    const bool head = lane == 0 || cp != c;
+    const bool tail = lane == 63 || cn != c;
+    const unsigned long long hb = __ballot(head);
+    int pos = 0;
+    if (valid && tail) pos = slot_pos[rb[k] + __popcll(hb & ((2ull << lane) - 1ull)) - 1];
+    int f = head ? 1 : 0;
+    wave_segscan2(s1, s2, f);
+    if (valid && tail) slots[pos] = make_double2(s1, s2);
+  }
 }
 
 // blockDim.x = 2^tile_bits / TILE_K. All global loads of the workgroup (its tile of records, its <= TILE_K
 // wave tiles of entries per wave, the gathered old coefficients) are issued before the barrier.
 template <class P, bool UNIT, bool SOA = false>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_tile_stats(SweepArgs a, const uint32_t *__restrict__ tent,
-                                                     const double *__restrict__ tval, const int32_t *__restrict__ tile_ptr,
-                                                     const int32_t *__restrict__ tile_row0,
-                                                     const double2 *__restrict__ oldnew, const int32_t *__restrict__ run_base,
-                                                     const int32_t *__restrict__ slot_pos, double2 *__restrict__ slots,
-                                                     int tile_bits, int n_tiles, int swz) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_tile_stats(
+    SweepArgs a, const uint32_t *__restrict__ tent, const double *__restrict__ tval, const int32_t *__restrict__ tile_ptr,
+    const int32_t *__restrict__ tile_row0, const double *__restrict__ told, const int32_t *__restrict__ run_base,
+    const int32_t *__restrict__ slot_pos, double2 *__restrict__ slots, int tile_bits, int n_tiles, int swz,
+    const int32_t *__restrict__ tile_list) {
   extern __shared__ double2 lds_rec[];
-  const int b = xcd_swizzle(blockIdx.x, n_tiles, swz);
+  const int b = tile_list ? tile_list[blockIdx.x] : xcd_swizzle(blockIdx.x, n_tiles, swz);
   const int64_t row0 = tile_row0[b];
   const int nr = tile_row0[b + 1] - (int)row0;
   const int nt = blockDim.x, tid = threadIdx.x, lane = tid & 63, nw = nt >> 6;
@@ -830,33 +861,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
     }
   }
 #pragma unroll
-  for (int k = 0; k < TILE_K; k++) old[k] = u[k] != TILE_PAD ? oldnew[u[k] >> tile_bits].x : 0.0;
+  for (int k = 0; k < TILE_K; k++) old[k] = u[k] != TILE_PAD ? told[u[k] >> tile_bits] : 0.0;
 #pragma unroll
   for (int k = 0; k < TILE_K; k++)
     if (tid + k * nt < nr) ((d2_t *)lds_rec)[tid + k * nt] = rec[k];
   __syncthreads();
-  const uint32_t rmask = (1u << tile_bits) - 1u;
-#pragma unroll
-  for (int k = 0; k < TILE_K; k++) {
-    const int t = t0 + k * nw;
-    if (t >= t1) continue;  // wave-uniform
-    const bool valid = u[k] != TILE_PAD;
-    int c = -1 - lane;  // padding lanes: distinct keys, never stored
-    double s1 = 0.0, s2 = 0.0;
-    if (valid) {
-      c = (int)(u[k] >> tile_bits);
-      P::stats(x[k], P::from_rec(lds_rec[u[k] & rmask]), old[k], s1, s2);
-    }
-    const int cp = dpp_i32<0x138, 0xf>(c, 0), cn = dpp_i32<0x130, 0xf>(c, 0);  // wave_shr:1 / wave_shl:1
-    const bool head = lane == 0 || cp != c;
-    const bool tail = lane == 63 || cn != c;
-    const unsigned long long hb = __ballot(head);
-    int pos = 0;
-    if (valid && tail) pos = slot_pos[rb[k] + __popcll(hb & ((2ull << lane) - 1ull)) - 1];
-    int f = head ? 1 : 0;
-    wave_segscan2(s1, s2, f);
-    if (valid && tail) slots[pos] = make_double2(s1, s2);  // column-major slot order: the draw streams
-  }
+  tile_entry_stats<P>(lds_rec, u, x, old, rb, t0, t1, nw, lane, tile_bits, slot_pos, slots);
 }
 
 // (old, new) indexed by the column's position in the level; a column's slots are contiguous
@@ -970,7 +980,11 @@ struct FuseArgs {
   const double *mu_next;
   const int32_t *fuse_cols;     // first-level columns inside the tiles, row order
   const int32_t *fuse_col_ptr;  // [n_tiles + 1]
-  const double *vnext_col;      // TWO: V[col, f + 1] per column of the last level (k_tile_draw)
+  const double *vnext_col;      // V[col, f + 1] per column of the last level (k_tile_draw)
+  // stats != 0 (two-level plans): the pass also computes the last level's statistics of factor f + 1
+  int stats;
+  const int32_t *run_base, *slot_pos;
+  double2 *slots;
 };
 
 // TWO: the plan has exactly these two levels and the last one covers every row once (a two-field one-hot
@@ -1008,13 +1022,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
       if (!UNIT) x[k] = tval[p];
     }
   }
+  // next factor's coefficient of each entry's column (TWO: its term of the next q; stats: the "old" value)
+  double vn[TILE_K];
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) vn[k] = (TWO || fa.stats) && u[k] != TILE_PAD ? fa.vnext_col[u[k] >> tile_bits] : 0.0;
   // q of the next factor for this thread's rows (TWO: the last level's term, per entry)
   double qn[TILE_K];
 #pragma unroll
   for (int k = 0; k < TILE_K; k++) {
     qn[k] = 0.0;
     if (TWO) {
-      if (u[k] != TILE_PAD) qn[k] = x[k] * fa.vnext_col[u[k] >> tile_bits];
+      qn[k] = x[k] * vn[k];
     } else if (tid + k * nt < nr) {
       const int64_t row = row0 + tid + k * nt;
       if (a.r_ell == 2) {
@@ -1117,6 +1135,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
       E[row0 + tid + k * nt] = r[0];
       Q[row0 + tid + k * nt] = r[1];
     }
+  // The tile now holds the state the last level of factor f + 1 starts from (two-level plan): its statistics
+  // from LDS, same entries. Tiles of a first-level column longer than a tile (no columns of their own here)
+  // are finished by k_long_coop and get their statistics from k_tile_stats afterwards.
+  if (fa.stats && c1 > c0) {
+    const int t0 = tile_ptr[b] + wv, t1 = tile_ptr[b + 1];
+    int rb[TILE_K];
+#pragma unroll
+    for (int k = 0; k < TILE_K; k++) rb[k] = t0 + k * nw < t1 ? fa.run_base[t0 + k * nw] : 0;
+    tile_entry_stats<PMainV>(lds_rec, u, x, vn, rb, t0, t1, nw, lane, tile_bits, fa.slot_pos, fa.slots);
+  }
 }
 
 // ---- row-sharded (multi-GPU) mode: statistics -> all-reduce -> draw -> apply -------------------------------

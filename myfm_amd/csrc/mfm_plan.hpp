@@ -89,6 +89,8 @@ struct StepPlan {
   // first level of the NEXT factor on the tile while it is in LDS (k_tile_apply_next).
   std::vector<int32_t> h_tile_start;
   DevBuf<int32_t> fuse_cols, fuse_col_ptr;  // first-level columns inside each tile, in row order
+  DevBuf<int32_t> solo_tiles;               // tiles inside a first-level column longer than a tile
+  int n_solo_tiles = 0;
   bool aligned_tiles = false;
 
   // a level is "tiny" when running it as its own launches cannot fill the device anyway
@@ -312,6 +314,13 @@ struct StepPlan {
     }
     fuse_cols.upload(fcols);
     fuse_col_ptr.upload(fptr);
+    {
+      std::vector<int32_t> solo;
+      for (size_t b = 0; b + 1 < fptr.size(); b++)
+        if (fptr[b + 1] == fptr[b]) solo.push_back((int32_t)b);
+      n_solo_tiles = (int)solo.size();
+      solo_tiles.upload(solo);
+    }
     aligned_tiles = true;
   }
 
@@ -631,9 +640,10 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
           }
         }
         hipLaunchKernelGGL(k_tile_old, dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a.theta, L.scols.p, L.n_cols,
-                           ls.oldnew_col.p);
+                           ls.vnext_col.p);
         hipLaunchKernelGGL((k_tile_stats<P, UNIT>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p, L.tile_ptr.p,
-                           L.tile_row0.p, ls.oldnew_col.p, L.run_base.p, L.slot_pos.p, L.slots.p, L.tile_bits, L.n_tiles, swz);
+                           L.tile_row0.p, ls.vnext_col.p, L.run_base.p, L.slot_pos.p, L.slots.p, L.tile_bits, L.n_tiles, swz,
+                           (const int32_t *)nullptr);
         hipLaunchKernelGGL((k_tile_draw<P>), dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.slot_ptr.p,
                            L.slots.p, ls.oldnew_col.p);
         hipLaunchKernelGGL((k_tile_apply<P, UNIT>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p,
@@ -806,14 +816,18 @@ static inline bool plan_supports_fused_next(const StepPlan &plan) {
   return first.contig && first.n_huge == 0 && last.scattered && last.tiled;
 }
 
+// statistics (unless already produced by the previous factor's fused pass) and draw of a row-tile level
 template <class P, bool UNIT>
 static void launch_tile_head(hipStream_t s, const ParLevel &L, const SweepArgs &a, LongScratch &ls, int swz,
-                             const double *theta_next = nullptr) {
+                             const double *theta_next = nullptr, bool have_stats = false) {
   const size_t lds = sizeof(double2) << L.tile_bits;
   const int nt = tile_threads(L.tile_bits);
-  hipLaunchKernelGGL(k_tile_old, dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a.theta, L.scols.p, L.n_cols, ls.oldnew_col.p);
-  hipLaunchKernelGGL((k_tile_stats<P, UNIT, true>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p, L.tile_ptr.p,
-                     L.tile_row0.p, ls.oldnew_col.p, L.run_base.p, L.slot_pos.p, L.slots.p, L.tile_bits, L.n_tiles, swz);
+  if (!have_stats) {
+    hipLaunchKernelGGL(k_tile_old, dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a.theta, L.scols.p, L.n_cols, ls.vnext_col.p);
+    hipLaunchKernelGGL((k_tile_stats<P, UNIT, true>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p,
+                       L.tile_ptr.p, L.tile_row0.p, ls.vnext_col.p, L.run_base.p, L.slot_pos.p, L.slots.p, L.tile_bits,
+                       L.n_tiles, swz, (const int32_t *)nullptr);
+  }
   hipLaunchKernelGGL((k_tile_draw<P>), dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.slot_ptr.p,
                      L.slots.p, ls.oldnew_col.p, theta_next, ls.vnext_col.p);
 }
@@ -824,6 +838,8 @@ template <bool UNIT, class ArgsOf>
 static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf args, int f_begin, int f_end,
                           LongScratch &ls, const SweepClasses &kc, bool fuse) {
   const int swz = xcd_swizzle_enabled();
+  // two-level plan: the fused pass also produces the next factor's last-level statistics
+  const int fuse_stats = fuse && plan.steps.size() == 2 && !std::getenv("MFM_NO_FUSED_STATS") ? 1 : 0;
   {
     static bool raised = false;  // tiles beyond the default dynamic-LDS limit: opt in once
     if (!raised && plan.tile_bits > 12) {
@@ -851,13 +867,14 @@ static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsO
           const bool two = plan.steps.size() == 2 && L.covers_rows_once && !std::getenv("MFM_NO_FUSED_TWO");
           {
             TimedLaunch t(tm, s, kc.scat, 20.0 * L.n_ent);
-            launch_tile_head<PMainV, UNIT>(s, L, a, ls, swz, two ? an.theta : nullptr);
+            launch_tile_head<PMainV, UNIT>(s, L, a, ls, swz, an.theta, fuse_stats && f > f_begin);
           }
           {
             TimedLaunch t(tm, s, KC_SWEEP_V_FUSED, 44.0 * plan.n_state_rows);
             SweepArgs af = a;
             af.row0 = plan.col_row0.p;
-            FuseArgs fa{an.theta, an.z, an.lambda, an.mu, plan.fuse_cols.p, plan.fuse_col_ptr.p, ls.vnext_col.p};
+            FuseArgs fa{an.theta,  an.z,          an.lambda,    an.mu,        plan.fuse_cols.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
+                        fuse_stats, L.run_base.p, L.slot_pos.p, L.slots.p};
             if (two)
               hipLaunchKernelGGL((k_tile_apply_next<UNIT, true>), dim3(L.n_tiles), dim3(nt), lds, s, af, L.tent.p, L.ent_val.p,
                                  L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
@@ -865,12 +882,18 @@ static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsO
               hipLaunchKernelGGL((k_tile_apply_next<UNIT, false>), dim3(L.n_tiles), dim3(nt), lds, s, af, L.tent.p,
                                  L.ent_val.p, L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
           }
-          // first-level columns longer than a tile
+          // first-level columns longer than a tile, then (fuse_stats) the statistics of their tiles
           launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, plan.steps.front().par, an, ls, kc, plan.col_row0.p, 1);
+          if (fuse_stats && plan.n_solo_tiles) {
+            TimedLaunch t(tm, s, kc.scat, 20.0 * plan.n_solo_tiles * (1 << L.tile_bits));
+            hipLaunchKernelGGL((k_tile_stats<PMainV, UNIT, true>), dim3(plan.n_solo_tiles), dim3(nt), lds, s, an, L.tent.p,
+                               L.ent_val.p, L.tile_ptr.p, L.tile_row0.p, ls.vnext_col.p, L.run_base.p, L.slot_pos.p,
+                               L.slots.p, L.tile_bits, L.n_tiles, swz, plan.solo_tiles.p);
+          }
           continue;
         }
         TimedLaunch t(tm, s, kc.scat, (last ? 48.0 : 56.0) * L.n_ent);
-        launch_tile_head<PMainV, UNIT>(s, L, a, ls, swz);
+        launch_tile_head<PMainV, UNIT>(s, L, a, ls, swz, nullptr, last && fuse && fuse_stats && f > f_begin);
         if (last)
           hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, false>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p,
                              L.ent_val.p, L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz);
