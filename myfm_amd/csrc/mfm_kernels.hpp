@@ -797,26 +797,34 @@ __device__ __forceinline__ void tile_entry_stats(const double2 *lds_rec, const u
                                                  int lane, int tile_bits, const int32_t *__restrict__ slot_pos,
                                                  double2 *__restrict__ slots) {
   const uint32_t rmask = (1u << tile_bits) - 1u;
+  // pass 1: run structure and slot addresses of all wave tiles (the slot-position loads are in flight together)
+  int pos[TILE_K];
+  unsigned flags[TILE_K];  // bit 0 head, bit 1 store (valid tail)
 #pragma unroll
   for (int k = 0; k < TILE_K; k++) {
     const int t = t0 + k * nw;
+    pos[k] = 0;
+    flags[k] = 0;
     if (t >= t1) continue;  // wave-uniform
     const bool valid = u[k] != TILE_PAD;
-    int c = -1 - lane;  // padding lanes: distinct keys, never stored
-    double s1 = 0.0, s2 = 0.0;
-    if (valid) {
-      c = (int)(u[k] >> tile_bits);
-      P::stats(x[k], P::from_rec(lds_rec[u[k] & rmask]), old[k], s1, s2);
-    }
+    const int c = valid ? (int)(u[k] >> tile_bits) : -1 - lane;  // padding lanes: distinct keys, never stored
     const int cp = dpp_i32<0x138, 0xf>(c, 0), cn = dpp_i32<0x130, 0xf>(c, 0);  // wave_shr:1 / wave_shl:1
     const bool head = lane == 0 || cp != c;
     const bool tail = lane == 63 || cn != c;
     const unsigned long long hb = __ballot(head);
-    int pos = 0;
-    if (valid && tail) pos = slot_pos[rb[k] + __popcll(hb & ((2ull << lane) - 1ull)) - 1];
-    int f = head ? 1 : 0;
+    if (valid && tail) pos[k] = slot_pos[rb[k] + __popcll(hb & ((2ull << lane) - 1ull)) - 1];
+    flags[k] = (head ? 1u : 0u) | (valid && tail ? 2u : 0u);
+  }
+  // pass 2: statistics from LDS, segmented scan, one store per run
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    const int t = t0 + k * nw;
+    if (t >= t1) continue;
+    double s1 = 0.0, s2 = 0.0;
+    if (u[k] != TILE_PAD) P::stats(x[k], P::from_rec(lds_rec[u[k] & rmask]), old[k], s1, s2);
+    int f = (int)(flags[k] & 1u);
     wave_segscan2(s1, s2, f);
-    if (valid && tail) slots[pos] = make_double2(s1, s2);
+    if (flags[k] & 2u) slots[pos[k]] = make_double2(s1, s2);
   }
 }
 

@@ -60,6 +60,7 @@ struct ParLevel {
   bool covers_rows_once = false;  // every row of the table has exactly one entry in this level
   bool first_and_once = false;    // ... and it is the first step of the plan: the level can rebuild q itself
   bool contig = false;            // every column of the level covers a contiguous row range (StepPlan::col_row0)
+  int64_t nnz_total() const { return nnz_light + nnz_heavy + nnz_long + nnz_huge; }
 };
 
 struct ChainRun {
@@ -870,7 +871,12 @@ static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsO
             launch_tile_head<PMainV, UNIT>(s, L, a, ls, swz, an.theta, fuse_stats && f > f_begin);
           }
           {
-            TimedLaunch t(tm, s, KC_SWEEP_V_FUSED, 44.0 * plan.n_state_rows);
+            // SURVEY 8d per-factor figure for what this launch does (one factor's q-build + both passes of the
+            // first level + the apply pass of this factor's last level and the statistics pass of the next one's)
+            const double nnz_f = (double)plan.steps.front().par.nnz_total() + (double)L.n_ent;
+            TimedLaunch t(tm, s, KC_SWEEP_V_FUSED,
+                          fuse_stats ? 56.0 * nnz_f + 8.0 * plan.n_state_rows + 8.0 * (plan.steps.front().par.n_all + L.n_cols)
+                                     : 44.0 * plan.n_state_rows + 16.0 * L.n_ent);
             SweepArgs af = a;
             af.row0 = plan.col_row0.p;
             FuseArgs fa{an.theta,  an.z,          an.lambda,    an.mu,        plan.fuse_cols.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
