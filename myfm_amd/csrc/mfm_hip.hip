@@ -67,6 +67,8 @@ struct mfm_ctx {
   DevBuf<double2> red_partial;  // REDUCE_BLOCKS
   DevBuf<double2> red_out;      // 1 + G * max(1,K)
   DevBuf<double> scratch_n;     // N doubles (get/set e,q)
+  DevBuf<double2> gs_partial;   // group statistics: per-chunk partials
+  int gs_chunks = 1;            // chunks of the largest group
   DevBuf<double> ec, qc;        // split e / q arrays of the latent sweep (soa), compact residual (qfree)
   bool qfree = false, soa = false, fuse_next = false;
   PinnedRing ring;
@@ -483,6 +485,9 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     for (int64_t j = 0; j < c->D; j++) fs[cur[c->hgroup[j]]++] = (int32_t)j;
     c->group_ptr.upload(gptr);
     c->feat_sorted.upload(fs);
+    int64_t big = 1;
+    for (int g = 0; g < c->G; g++) big = std::max(big, gptr[g + 1] - gptr[g]);
+    c->gs_chunks = (int)((big + GS_CHUNK - 1) / GS_CHUNK);
   }
   // relation blocks
   int64_t off = c->D0;
@@ -652,8 +657,12 @@ static int group_stats(mfm_ctx *ctx, const double *theta, int nf, const double *
     ctx->ring.upload(ctx->mu.p, mu_host, (size_t)G * nf * sizeof(double), s);
     {
       TimedLaunch t(ctx->timing, s, KC_GROUP_STATS, 12.0 * ctx->D * nf);
-      hipLaunchKernelGGL(k_group_stats, dim3(G, nf), dim3(WG), 0, s, theta, ctx->D, ctx->feat_sorted.p, ctx->group_ptr.p,
-                         ctx->mu.p, G, ctx->red_out.p + 1);
+      const int n_ch = std::max(1, ctx->gs_chunks);
+      if (ctx->gs_partial.n < (size_t)G * nf * n_ch) ctx->gs_partial.alloc((size_t)G * nf * n_ch);
+      hipLaunchKernelGGL(k_group_stats, dim3(G, nf, n_ch), dim3(WG), 0, s, theta, ctx->D, ctx->feat_sorted.p,
+                         ctx->group_ptr.p, ctx->mu.p, G, ctx->gs_partial.p);
+      hipLaunchKernelGGL(k_group_stats_final, dim3(cdiv(G * nf, 64)), dim3(64), 0, s, ctx->gs_partial.p, G * nf, n_ch,
+                         ctx->red_out.p + 1);
     }
     double2 *h = ctx->readback((size_t)G * nf + 1);
     MFM_HIP_CHECK(hipMemcpyAsync(h, ctx->red_out.p + 1, (size_t)G * nf * sizeof(double2), hipMemcpyDeviceToHost, s));

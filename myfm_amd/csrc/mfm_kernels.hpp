@@ -888,10 +888,20 @@ __global__ __launch_bounds__(WG) void k_tile_draw(SweepArgs a, const int32_t *__
   const int lane = threadIdx.x & 63;
   if (theta_next && lane == 1) vnext_col[c] = theta_next[cols[c]];  // for k_tile_apply_next<.., TWO>
   double S1 = 0.0, S2 = 0.0;
-  for (int k = slot_ptr[c] + lane; k < slot_ptr[c + 1]; k += WAVE) {
-    const double2 s = slots[k];
-    S1 += s.x;
-    S2 += s.y;
+  {
+    // four loads in flight per lane (a popular column has one slot per tile: thousands); fixed order
+    const int k1 = slot_ptr[c + 1];
+    int k = slot_ptr[c] + lane;
+    for (; k + 3 * WAVE < k1; k += 4 * WAVE) {
+      const double2 s0 = slots[k], s1 = slots[k + WAVE], s2 = slots[k + 2 * WAVE], s3 = slots[k + 3 * WAVE];
+      S1 += (s0.x + s1.x) + (s2.x + s3.x);
+      S2 += (s0.y + s1.y) + (s2.y + s3.y);
+    }
+    for (; k < k1; k += WAVE) {
+      const double2 s = slots[k];
+      S1 += s.x;
+      S2 += s.y;
+    }
   }
   S1 = wave_allreduce_sum(S1);
   S2 = wave_allreduce_sum(S2);
@@ -1726,25 +1736,47 @@ __global__ __launch_bounds__(WG) void k_shift_e(double2 *__restrict__ eq, int64_
   if (i < N) eq[i].x += delta;
 }
 
-// group statistics: block (g, f) reduces theta over the features of group g (sorted list).
+// group statistics: block (g, f, chunk) reduces theta over a chunk of GS_CHUNK features of group g (sorted
+// list); k_group_stats_final adds a (g, f)'s chunk partials in chunk order (deterministic).
 // out[(f * G + g)] = { sum theta, sum (theta - mu)^2 }
+constexpr int GS_CHUNK = 4096;
 __global__ __launch_bounds__(WG) void k_group_stats(const double *__restrict__ theta, int64_t D,
                                                     const int32_t *__restrict__ feat_sorted,
                                                     const int64_t *__restrict__ group_ptr,
-                                                    const double *__restrict__ mu, int G, double2 *__restrict__ out) {
+                                                    const double *__restrict__ mu, int G, double2 *__restrict__ partial) {
   __shared__ double lds[2 * WG / WAVE];
-  const int g = blockIdx.x, f = blockIdx.y;
+  const int g = blockIdx.x, f = blockIdx.y, ch = blockIdx.z;
   const double m = mu[f * G + g];
   const double *th = theta + (int64_t)f * D;
+  const int64_t b = group_ptr[g] + (int64_t)ch * GS_CHUNK, e = min(group_ptr[g + 1], b + GS_CHUNK);
   double s = 0.0, ss = 0.0;
-  for (int64_t p = group_ptr[g] + threadIdx.x; p < group_ptr[g + 1]; p += WG) {
-    const double v = th[feat_sorted[p]];
-    s += v;
-    const double d = v - m;
+  constexpr int U = GS_CHUNK / WG;
+  double v[U];
+#pragma unroll
+  for (int r = 0; r < U; r++) {
+    const int64_t p = b + threadIdx.x + r * WG;
+    v[r] = p < e ? th[feat_sorted[p]] : m;  // (m: contributes 0 to ss; s is masked below)
+  }
+#pragma unroll
+  for (int r = 0; r < U; r++) {
+    const int64_t p = b + threadIdx.x + r * WG;
+    if (p < e) s += v[r];
+    const double d = v[r] - m;
     ss += d * d;
   }
   wg_allreduce2<WG / WAVE>(s, ss, lds);
-  if (threadIdx.x == 0) out[f * G + g] = make_double2(s, ss);
+  if (threadIdx.x == 0) partial[((int64_t)f * G + g) * gridDim.z + ch] = make_double2(s, ss);
+}
+__global__ void k_group_stats_final(const double2 *__restrict__ partial, int n, int n_chunks, double2 *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0, ss = 0.0;
+  for (int c = 0; c < n_chunks; c++) {
+    const double2 p = partial[(int64_t)i * n_chunks + c];
+    s += p.x;
+    ss += p.y;
+  }
+  out[i] = make_double2(s, ss);
 }
 
 __global__ void k_set_eq(double2 *__restrict__ eq, const double *__restrict__ src, int64_t N, int which) {
