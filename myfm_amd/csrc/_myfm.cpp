@@ -1332,6 +1332,7 @@ PYBIND11_MODULE(_myfm, m) {
       .def("timing_reset", &GibbsSession::timing_reset)
       .def("timing", &GibbsSession::timing)
       .def("plan_info", &GibbsSession::plan_info)
+      .def("plan_flags", [](GibbsSession &s) { return mfm_plan_flags(s.trainer->ctx); })
       .def_property_readonly("fm", [](GibbsSession &s) -> FM & { return s.fm; }, py::return_value_policy::reference_internal)
       .def_property_readonly("hyper", [](GibbsSession &s) -> Hyper & { return s.hyper; },
                              py::return_value_policy::reference_internal)

@@ -71,6 +71,8 @@ struct mfm_ctx {
   int gs_chunks = 1;            // chunks of the largest group
   DevBuf<double> ec, qc;        // split e / q arrays of the latent sweep (soa), compact residual (qfree)
   bool qfree = false, soa = false, fuse_next = false;
+  bool sharded_fused = false;   // row-sharded + fused tile path (run_sweep_soa_sharded)
+  DevBuf<double> sync_mask;     // [D] 1: this rank contributes the column to the model synchronisation
   PinnedRing ring;
   double2 *h_red = nullptr;  // pinned readback
   size_t h_red_cap = 0;
@@ -464,7 +466,63 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     // one plan serves the three latent policies of the main table: size the co-resident launch for all of them
     const int coop_v = std::min({coop_capacity<PMainV>(), coop_capacity<PMainVe<false, false>>(), coop_capacity<PMainVe<true, false>>(),
                                  coop_capacity<PMainVsq<false>>(), coop_capacity<PMainVsq<true>>(), coop_capacity<PMainVs>()});
+    // Row-sharded fused tile path: which first-level columns need an all-reduce of their statistics? Those
+    // with rows on more than one rank, those longer than a tile on some rank, and those empty everywhere --
+    // the same ("special") set on every rank, from two all-reduces of per-column indicators.
+    bool try_fused = c->comm.active() && c->hblocks.empty() && !c->hlevels.empty() && tile_bits == 12 && c->N > 0 &&
+                     !std::getenv("MFM_NO_SHARDED_FUSED") && !std::getenv("MFM_NO_SOA");
+    std::vector<double> col_cnt;
+    if (try_fused) {
+      const int64_t D0 = c->D0, RB = (int64_t)1 << tile_bits;
+      std::vector<double> h((size_t)2 * D0, 0.0);
+      col_cnt.resize((size_t)D0);
+      for (int64_t j = 0; j < D0; j++) {
+        col_cnt[j] = h[j] = (double)(Xt.ptr[j + 1] - Xt.ptr[j]);
+        h[D0 + j] = h[j] > (double)RB ? 1.0 : 0.0;
+      }
+      DevBuf<double> d;
+      d.upload(h);
+      c->comm.allreduce(d.p, 2 * D0);
+      MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
+      std::vector<double> g((size_t)2 * D0);
+      MFM_HIP_CHECK(hipMemcpy(g.data(), d.p, g.size() * sizeof(double), hipMemcpyDeviceToHost));
+      std::vector<double> sh((size_t)D0);
+      for (int64_t j = 0; j < D0; j++) sh[j] = (h[j] > 0 && h[j] < g[j]) ? 1.0 : 0.0;
+      d.upload(sh);
+      c->comm.allreduce(d.p, D0);
+      MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
+      MFM_HIP_CHECK(hipMemcpy(sh.data(), d.p, sh.size() * sizeof(double), hipMemcpyDeviceToHost));
+      std::vector<char> special((size_t)D0, 0);
+      for (int64_t j = 0; j < D0; j++)
+        special[j] = c->hlevels[j] == 0 && (g[j] == 0 || g[D0 + j] > 0 || sh[j] > 0);
+      c->plan_V.sharded_tiles = true;
+      c->plan_V.special = std::move(special);
+    }
     c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_v, true, c->X.unit);
+    if (try_fused) {
+      // every rank must take the same path: agree
+      double bad = plan_supports_sharded_fused(c->plan_V) ? 0.0 : 1.0;
+      DevBuf<double> d;
+      d.upload(&bad, 1);
+      c->comm.allreduce(d.p, 1);
+      MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
+      MFM_HIP_CHECK(hipMemcpy(&bad, d.p, sizeof(double), hipMemcpyDeviceToHost));
+      if (bad > 0) {
+        c->plan_V = StepPlan();
+        c->plan_V.sharded = true;
+        c->plan_V.given_levels = c->hlevels;
+        c->plan_V.tile_bits = tile_bits;
+        c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_v, true, c->X.unit);
+      } else {
+        c->sharded_fused = true;
+        // model synchronisation after the sweep: a non-special first-level column is contributed by the rank
+        // that holds its rows, every other column (identical on all ranks) by the rank holding global row 0
+        std::vector<double> mask((size_t)c->D, c->row_offset == 0 ? 1.0 : 0.0);
+        for (int64_t j = 0; j < c->D0; j++)
+          if (c->hlevels[j] == 0 && !c->plan_V.special[j]) mask[j] = col_cnt[j] > 0 ? 1.0 : 0.0;
+        c->sync_mask.upload(mask);
+      }
+    }
     c->plan_W.build(Xt, PMainW::R_W16, PMainW::R_WG, coop_capacity<PMainW>(), true, c->X.unit);
     c->ls.reserve_cols(std::max(c->plan_V.max_cols_scat, c->plan_W.max_cols_scat));
     if (c->comm.active()) {
@@ -522,6 +580,10 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   // split e / q layout for update_V (run_plan_soa)
   c->soa = !c->qfree && !c->comm.active() && c->blocks.empty() && c->N > 0 && plan_supports_soa(c->plan_V) &&
            !std::getenv("MFM_NO_SOA") && !std::getenv("MFM_NO_FUSED_QBUILD");
+  if (c->sharded_fused) {
+    c->ec.alloc((size_t)c->N);
+    c->qc.alloc((size_t)c->N);
+  }
   if (c->soa) {
     c->ec.alloc((size_t)c->N);
     c->qc.alloc((size_t)c->N);
@@ -551,7 +613,7 @@ int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launche
 
 int mfm_plan_flags(const mfm_ctx *ctx) {
   return (ctx->qfree ? 1 : 0) | (ctx->X.unit ? 2 : 0) | (ctx->X.ell_width >= 0 ? 4 : 0) | (ctx->comm.active() ? 8 : 0) |
-         (ctx->soa ? 16 : 0) | (ctx->fuse_next ? 32 : 0);
+         (ctx->soa ? 16 : 0) | (ctx->fuse_next ? 32 : 0) | (ctx->sharded_fused ? 64 : 0);
 }
 
 // ---- state ------------------------------------------------------------------------------------
@@ -751,6 +813,37 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       a.r_val = c->X.rval.p;
       a.r_ell = (int)c->X.ell_width;
       run_plan_qfree(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit);
+    }
+    hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
+    launch_qbuild(c, c->V.p + (size_t)(f_end - 1) * c->D);  // leave q_train as the reference would (FMTrainer.hpp:373)
+    MFM_HIP_CHECK(hipGetLastError());
+    return MFM_OK;
+  }
+  if (c->sharded_fused) {
+    hipLaunchKernelGGL(k_e_pack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
+    const SweepClasses kcv{KC_SWEEP_V_LIGHT, KC_SWEEP_V_HEAVY, KC_SWEEP_V_COOP, KC_SWEEP_V_LSTATS, KC_SWEEP_V_LDRAW,
+                           KC_SWEEP_V_LAPPLY, KC_SWEEP_V_CHAIN, KC_SWEEP_V_SCAT};
+    auto args = [&](int f) {
+      SweepArgs a = main_args(c, c->V.p + (size_t)f * c->D, zbase + (size_t)(f - f_begin) * c->D,
+                              c->lam.p + (size_t)f * c->G, c->mu.p + (size_t)f * c->G, alpha);
+      a.state = c->ec.p;
+      a.state2 = c->qc.p;
+      a.r_rowptr = c->X.rowptr.p;
+      a.r_colidx = c->X.colidx.p;
+      a.r_val = c->X.rval.p;
+      a.r_ell = (int)c->X.ell_width;
+      return a;
+    };
+    if (c->X.unit)
+      run_sweep_soa_sharded<true>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, c->comm);
+    else
+      run_sweep_soa_sharded<false>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, c->comm);
+    // make the first-level coefficients identical on every rank again (each was drawn where its rows live)
+    {
+      const int64_t n = (int64_t)(f_end - f_begin) * c->D;
+      double *Vb = c->V.p + (size_t)f_begin * c->D;
+      hipLaunchKernelGGL(k_mask_rows, dim3(cdiv(n, 256)), dim3(256), 0, s, Vb, c->sync_mask.p, c->D, n);
+      c->comm.allreduce(Vb, n);
     }
     hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
     launch_qbuild(c, c->V.p + (size_t)(f_end - 1) * c->D);  // leave q_train as the reference would (FMTrainer.hpp:373)

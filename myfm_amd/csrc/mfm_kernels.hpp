@@ -276,6 +276,18 @@ struct PMainVsq : PMainVs {  // first level: q rebuilt from the row (see PMainVq
   }
 };
 
+// PMainVsq for an apply pass that runs AFTER the column's new coefficient was stored (row-sharded mode:
+// statistics -> all-reduce -> draw -> apply): the rebuilt q already contains x * v_new.
+template <bool UNIT>
+struct PMainVsqA : PMainVsq<UNIT> {
+  typedef double2 St;
+  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St s, double old, double fresh) {
+    const double h = x * (s.y - x * fresh);  // = x (q_old - x v_old)
+    ((double *)a.state)[row] = s.x + h * (fresh - old);
+    a.state2[row] = s.y;
+  }
+};
+
 // "q-free" latent sweep for tables with short rows (one-hot designs): the q-cache entry of a row is never
 // stored -- it is recomputed from the row's few CSR entries and the current V[:, f] wherever it is needed
 // (q_t = sum_j x_tj v_jf, FMTrainer.hpp:320; the increments of :373 are implicit because v is updated in
@@ -979,6 +991,61 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
         ((d2_t *)a.state)[row0 + tid + k * nt] = r;
       }
     }
+}
+
+// row-sharded mode: the slot sums of a tile level per column (position in the level), to be all-reduced ...
+__global__ __launch_bounds__(WG) void k_tile_sum(int n_cols, const int32_t *__restrict__ slot_ptr,
+                                                 const double2 *__restrict__ slots, double2 *__restrict__ S) {
+  const int c = blockIdx.x * (WG / WAVE) + (threadIdx.x >> 6);
+  if (c >= n_cols) return;
+  const int lane = threadIdx.x & 63;
+  double S1 = 0.0, S2 = 0.0;
+  const int k1 = slot_ptr[c + 1];
+  int k = slot_ptr[c] + lane;
+  for (; k + 3 * WAVE < k1; k += 4 * WAVE) {
+    const double2 s0 = slots[k], s1 = slots[k + WAVE], s2 = slots[k + 2 * WAVE], s3 = slots[k + 3 * WAVE];
+    S1 += (s0.x + s1.x) + (s2.x + s3.x);
+    S2 += (s0.y + s1.y) + (s2.y + s3.y);
+  }
+  for (; k < k1; k += WAVE) {
+    const double2 s = slots[k];
+    S1 += s.x;
+    S2 += s.y;
+  }
+  S1 = wave_allreduce_sum(S1);
+  S2 = wave_allreduce_sum(S2);
+  if (lane == 0) S[c] = make_double2(S1, S2);
+}
+// ... and the draw from the reduced statistics (same outputs as k_tile_draw)
+template <class P>
+__global__ void k_tile_draw_S(SweepArgs a, const int32_t *__restrict__ cols, int n_cols, const double2 *__restrict__ S,
+                              double2 *__restrict__ oldnew, const double *__restrict__ theta_next,
+                              double *__restrict__ vnext_col) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cols) return;
+  const int j = cols[c];
+  if (theta_next) vnext_col[c] = theta_next[j];
+  const double2 s = S[c];
+  const double old = a.theta[j];
+  const int g = a.group[j];
+  const double fresh = P::draw(s.x, s.y, old, a.alpha, a.lambda[g], a.mu[g], a.z[j]);
+  a.theta[j] = fresh;
+  oldnew[c] = make_double2(old, fresh);
+}
+// statistics of a few columns <-> a compact buffer (the all-reduce of the special first-level columns)
+__global__ void k_gather_S(const int32_t *__restrict__ cols, int n, const double2 *__restrict__ S, double2 *__restrict__ Sc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n) Sc[c] = S[cols[c]];
+}
+__global__ void k_scatter_S(const int32_t *__restrict__ cols, int n, const double2 *__restrict__ Sc, double2 *__restrict__ S) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n) S[cols[c]] = Sc[c];
+}
+// model synchronisation after a row-sharded latent sweep: every rank keeps the columns it contributes
+// (mask 1) and zeroes the rest; the all-reduce that follows leaves the same V on every rank
+__global__ void k_mask_rows(double *__restrict__ V, const double *__restrict__ mask, int64_t D, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) V[i] *= mask[i % D];
 }
 
 // Apply pass of a factor's LAST level fused with the FIRST level of the next factor (split e / q layout,

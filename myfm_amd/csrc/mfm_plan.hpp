@@ -280,9 +280,86 @@ struct StepPlan {
     return true;
   }
 
+  // bins the columns `cols` of one level by length into L (see the file header)
+  void bin_columns(const HostCsr &csc, const std::vector<int32_t> &cols, ParLevel &L, int64_t cap_w1, int64_t cap_w4,
+                   int64_t cap_w16, int64_t cap_wg, int coop_max) {
+    std::vector<int32_t> w1, w4, w16, wg, lg, hg, lptr, hptr;
+    std::vector<ChunkDesc> lch, hch;
+    for (int32_t j : cols) {
+      const int64_t len = csc.ptr[j + 1] - csc.ptr[j];
+      if (len <= cap_w1) {
+        w1.push_back(j);
+        L.nnz_light += len;
+      } else if (len <= cap_w4) {
+        w4.push_back(j);
+        L.nnz_light += len;
+      } else if (len <= cap_w16) {
+        w16.push_back(j);
+        L.nnz_heavy += len;
+      } else if (len <= cap_wg) {
+        wg.push_back(j);
+        L.nnz_heavy += len;
+      } else {
+        const int64_t nch = (len + cap_wg - 1) / cap_wg;
+        const bool coop = nch <= coop_max;
+        std::vector<ChunkDesc> &ch = coop ? lch : hch;
+        std::vector<int32_t> &ptr = coop ? lptr : hptr;
+        std::vector<int32_t> &lst = coop ? lg : hg;
+        ptr.push_back((int32_t)ch.size());
+        for (int64_t b = 0; b < len; b += cap_wg)
+          ch.push_back(ChunkDesc{csc.ptr[j] + b, (int32_t)std::min<int64_t>(cap_wg, len - b), (int32_t)lst.size()});
+        lst.push_back(j);
+        (coop ? L.nnz_long : L.nnz_huge) += len;
+      }
+    }
+    lptr.push_back((int32_t)lch.size());
+    hptr.push_back((int32_t)hch.size());
+    L.n_w1 = (int)w1.size();
+    L.n_w4 = (int)w4.size();
+    L.n_w16 = (int)w16.size();
+    L.n_wg = (int)wg.size();
+    L.n_long = (int)lg.size();
+    L.n_huge = (int)hg.size();
+    L.cols_w1.upload(w1);
+    L.cols_w4.upload(w4);
+    L.cols_w16.upload(w16);
+    L.cols_wg.upload(wg);
+    L.cols_long.upload(lg);
+    L.cols_huge.upload(hg);
+    L.lchunks.upload(lch.data(), lch.size());
+    L.lchunk_ptr.upload(lptr);
+    L.hchunks.upload(hch.data(), hch.size());
+    L.hchunk_ptr.upload(hptr);
+    L.n_hchunks = (int)hch.size();
+    if (!lch.empty()) {
+      L.lpartial.alloc(2 * lch.size());
+      L.arrive.alloc(lg.size());
+      MFM_HIP_CHECK(hipMemset(L.arrive.p, 0, lg.size() * sizeof(unsigned long long)));
+      // rounds: whole columns, at most coop_max chunks each
+      int first = 0;
+      int64_t rn = 0;
+      for (size_t c = 0; c < lg.size(); c++) {
+        const int cb = lptr[c], ce = lptr[c + 1];
+        if (ce - first > coop_max) {
+          L.rounds.emplace_back(first, cb - first);
+          L.round_nnz.push_back(rn);
+          first = cb;
+          rn = 0;
+        }
+        rn += csc.ptr[lg[c] + 1] - csc.ptr[lg[c]];
+      }
+      L.rounds.emplace_back(first, (int)lch.size() - first);
+      L.round_nnz.push_back(rn);
+    }
+  }
+
   void build_aligned_tiles(const HostCsr &csc, const std::vector<int32_t> &cols, int64_t RB) {
     std::vector<int32_t> order(cols);
-    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return csc.idx[csc.ptr[x]] < csc.idx[csc.ptr[y]]; });
+    const int64_t nnz_all = csc.ptr[csc.rows];
+    auto first_row = [&](int32_t x) { return csc.ptr[x] < csc.ptr[x + 1] ? (int64_t)csc.idx[csc.ptr[x]] : (int64_t)-1; };
+    // empty columns sort first: they join the first tile as zero-length columns (drawn from the prior there)
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return first_row(x) < first_row(y); });
+    (void)nnz_all;
     std::vector<int32_t> fcols, fptr;
     h_tile_start.clear();
     int64_t cur_rows = 0, next_row = 0;
@@ -292,12 +369,21 @@ struct StepPlan {
       cur_rows = 0;
     };
     for (int32_t j : order) {
-      const int64_t r0 = csc.idx[csc.ptr[j]], len = csc.ptr[j + 1] - csc.ptr[j];
+      const int64_t len = csc.ptr[j + 1] - csc.ptr[j];
+      const bool is_special = !special.empty() && special[j];
+      if (len == 0) {
+        // special: swept through special_level on every rank; sharded and not special: its rows live on another rank
+        if (is_special || sharded_tiles) continue;
+        if (h_tile_start.empty()) open_tile(0);
+        fcols.push_back(j);
+        continue;
+      }
+      const int64_t r0 = csc.idx[csc.ptr[j]];
       if (r0 != next_row) {  // (cannot happen: the level covers every row once with contiguous columns)
         h_tile_start.clear();
         return;
       }
-      if (len > RB) {
+      if (len > RB || is_special) {
         for (int64_t r = r0; r < r0 + len; r += RB) open_tile(r);
         cur_rows = RB;  // closed
       } else {
@@ -324,6 +410,16 @@ struct StepPlan {
     }
     aligned_tiles = true;
   }
+
+  // Row-sharded mode with the fused tile path (run_sweep_soa_sharded): the plan may use row tiles; first-level
+  // columns flagged `special` (rows on more than one rank, longer than a tile on some rank, or empty on every
+  // rank -- the same set on every rank) get tiles of their own and are swept through `special_level` with an
+  // all-reduce of their statistics; all other first-level columns with local rows are complete on this rank.
+  bool sharded_tiles = false;
+  std::vector<char> special;  // per column of the table (sharded_tiles only)
+  ParLevel special_level;
+  DevBuf<int32_t> special_cols;
+  int n_special = 0;
 
   int tile_bits = 0;     // > 0: scattered levels use the row-tile path with tiles of 2^tile_bits rows
   bool sharded = false;  // row-sharded multi-GPU mode: no chains (every column needs an all-reduce), no coop
@@ -406,7 +502,7 @@ struct StepPlan {
       L.n_all = (int)by_level[l].size();
       L.jmin = *std::min_element(by_level[l].begin(), by_level[l].end());
       L.jmax = *std::max_element(by_level[l].begin(), by_level[l].end());
-      if (allow_scatter && build_scattered(csc, by_level[l], lnnz, unit, L, sharded ? 0 : tile_bits,
+      if (allow_scatter && build_scattered(csc, by_level[l], lnnz, unit, L, (sharded && !sharded_tiles) ? 0 : tile_bits,
                                            aligned_tiles ? &h_tile_start : nullptr)) {
         launches += 3;
         max_cols_scat = std::max<int64_t>(max_cols_scat, csc.rows);
@@ -422,37 +518,7 @@ struct StepPlan {
           }
         L.first_and_once = once;
       }
-      std::vector<int32_t> w1, w4, w16, wg, lg, hg, lptr, hptr;
-      std::vector<ChunkDesc> lch, hch;
-      for (int32_t j : by_level[l]) {
-        const int64_t len = csc.ptr[j + 1] - csc.ptr[j];
-        if (len <= cap_w1) {
-          w1.push_back(j);
-          L.nnz_light += len;
-        } else if (len <= cap_w4) {
-          w4.push_back(j);
-          L.nnz_light += len;
-        } else if (len <= cap_w16) {
-          w16.push_back(j);
-          L.nnz_heavy += len;
-        } else if (len <= cap_wg) {
-          wg.push_back(j);
-          L.nnz_heavy += len;
-        } else {
-          const int64_t nch = (len + cap_wg - 1) / cap_wg;
-          const bool coop = nch <= coop_max;
-          std::vector<ChunkDesc> &ch = coop ? lch : hch;
-          std::vector<int32_t> &ptr = coop ? lptr : hptr;
-          std::vector<int32_t> &lst = coop ? lg : hg;
-          ptr.push_back((int32_t)ch.size());
-          for (int64_t b = 0; b < len; b += cap_wg)
-            ch.push_back(ChunkDesc{csc.ptr[j] + b, (int32_t)std::min<int64_t>(cap_wg, len - b), (int32_t)lst.size()});
-          lst.push_back(j);
-          (coop ? L.nnz_long : L.nnz_huge) += len;
-        }
-      }
-      lptr.push_back((int32_t)lch.size());
-      hptr.push_back((int32_t)hch.size());
+      bin_columns(csc, by_level[l], L, cap_w1, cap_w4, cap_w16, cap_wg, coop_max);
       {
         bool contig = !std::getenv("MFM_NO_CONTIG");
         for (size_t c = 0; contig && c < by_level[l].size(); c++) {
@@ -461,45 +527,25 @@ struct StepPlan {
         }
         L.contig = contig;
       }
-      if (steps.size() == 1 && L.contig && L.first_and_once && allow_scatter && !sharded && tile_bits > 0 &&
-          ((int64_t)1 << tile_bits) == cap_wg && hg.empty() && !std::getenv("MFM_NO_ALIGNED_TILES"))
+      if (steps.size() == 1 && L.contig && L.first_and_once && allow_scatter && (!sharded || sharded_tiles) && tile_bits > 0 &&
+          ((int64_t)1 << tile_bits) == cap_wg && (L.n_huge == 0 || sharded_tiles) && !std::getenv("MFM_NO_ALIGNED_TILES"))
         build_aligned_tiles(csc, by_level[l], (int64_t)1 << tile_bits);
-      L.n_w1 = (int)w1.size();
-      L.n_w4 = (int)w4.size();
-      L.n_w16 = (int)w16.size();
-      L.n_wg = (int)wg.size();
-      L.n_long = (int)lg.size();
-      L.n_huge = (int)hg.size();
-      L.cols_w1.upload(w1);
-      L.cols_w4.upload(w4);
-      L.cols_w16.upload(w16);
-      L.cols_wg.upload(wg);
-      L.cols_long.upload(lg);
-      L.cols_huge.upload(hg);
-      L.lchunks.upload(lch.data(), lch.size());
-      L.lchunk_ptr.upload(lptr);
-      L.hchunks.upload(hch.data(), hch.size());
-      L.hchunk_ptr.upload(hptr);
-      L.n_hchunks = (int)hch.size();
-      if (!lch.empty()) {
-        L.lpartial.alloc(2 * lch.size());
-        L.arrive.alloc(lg.size());
-        MFM_HIP_CHECK(hipMemset(L.arrive.p, 0, lg.size() * sizeof(unsigned long long)));
-        // rounds: whole columns, at most coop_max chunks each
-        int first = 0;
-        int64_t rn = 0;
-        for (size_t c = 0; c < lg.size(); c++) {
-          const int cb = lptr[c], ce = lptr[c + 1];
-          if (ce - first > coop_max) {
-            L.rounds.emplace_back(first, cb - first);
-            L.round_nnz.push_back(rn);
-            first = cb;
-            rn = 0;
-          }
-          rn += csc.ptr[lg[c] + 1] - csc.ptr[lg[c]];
+      if (steps.size() == 1 && sharded_tiles && aligned_tiles) {
+        std::vector<int32_t> sp;
+        for (int32_t j : by_level[l])
+          if (!special.empty() && special[j]) sp.push_back(j);
+        n_special = (int)sp.size();
+        special_cols.upload(sp);
+        special_level.cols_all.upload(sp);
+        special_level.n_all = n_special;
+        special_level.contig = L.contig;
+        if (n_special) {
+          special_level.jmin = sp.front();
+          special_level.jmax = sp.back();
+          bin_columns(csc, sp, special_level, cap_w1, cap_w4, cap_w16, cap_wg, 0);
+          max_hchunks = std::max(max_hchunks, special_level.n_hchunks);
+          max_huge = std::max(max_huge, special_level.n_huge);
         }
-        L.rounds.emplace_back(first, (int)lch.size() - first);
-        L.round_nnz.push_back(rn);
       }
       max_hchunks = std::max(max_hchunks, L.n_hchunks);
       max_huge = std::max(max_huge, L.n_huge);
@@ -516,6 +562,7 @@ struct LongScratch {
   DevBuf<double2> oldnew_col;  // scattered levels / sharded mode: (old, new) per column of the matrix
   DevBuf<double2> S_col;       // sharded mode: per-column statistics (all-reduced over the ranks)
   DevBuf<double> vnext_col;    // fused apply pass: next factor's coefficient per column of the last level
+  DevBuf<double2> S_compact;   // sharded fused path: statistics of the special first-level columns
   void reserve_cols(int64_t n_cols) {
     if ((size_t)n_cols > oldnew_col.n) {
       oldnew_col.alloc((size_t)n_cols);
@@ -919,6 +966,132 @@ static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsO
         launch_binned_level<PMainVs, UNIT>(s, tm, L, a, ls, kc, plan.col_row0.p);
         launch_huge<PMainVs, UNIT>(s, tm, L, a, ls, kc);
       }
+    }
+  }
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
+// ---- row-sharded fused path -------------------------------------------------------------------------------
+// One non-scattered level, row-sharded: statistics -> S -> all-reduce -> draw -> apply. PS: statistics / draw
+// policy, PA: apply policy (its load runs after the new coefficient was stored). ccols != null: only these
+// n_c columns take part and their statistics travel in a compact buffer.
+template <class PS, class PA, bool UNIT>
+static void run_level_sharded(hipStream_t s, Timing &tm, const ParLevel &L, const SweepArgs &a, LongScratch &ls,
+                              const SweepClasses &kc, const Comm &comm, const int32_t *ccols, int n_c) {
+  double2 *S = ls.S_col.p;
+  const int grid = L.n_wg + (L.n_w16 + 3) / 4 + (L.n_w4 + 3) / 4 + (L.n_w1 + 3) / 4;
+  if (grid) {
+    TimedLaunch t(tm, s, kc.heavy, PS::STAT_BYTES * (L.nnz_heavy + L.nnz_light));
+    hipLaunchKernelGGL((k_level_split<PS, UNIT, 1>), dim3(grid), dim3(WG), 0, s, a, L.cols_w1.p, L.n_w1, L.cols_w4.p, L.n_w4,
+                       L.cols_w16.p, L.n_w16, L.cols_wg.p, L.n_wg, S, (const double2 *)nullptr);
+  }
+  if (L.n_huge) {
+    TimedLaunch t(tm, s, kc.hstats, PS::STAT_BYTES * L.nnz_huge);
+    hipLaunchKernelGGL((k_long_stats<PS>), dim3(L.n_hchunks), dim3(WG), 0, s, a, L.hchunks.p, L.cols_huge.p, ls.partial.p);
+    hipLaunchKernelGGL(k_long_sum, dim3((L.n_huge + 63) / 64), dim3(64), 0, s, L.cols_huge.p, L.hchunk_ptr.p, L.n_huge,
+                       ls.partial.p, S);
+  }
+  MFM_HIP_CHECK(hipGetLastError());
+  if (ccols) {
+    if (ls.S_compact.n < (size_t)n_c) ls.S_compact.alloc((size_t)n_c);
+    hipLaunchKernelGGL(k_gather_S, dim3((n_c + 255) / 256), dim3(256), 0, s, ccols, n_c, S, ls.S_compact.p);
+    comm.allreduce(ls.S_compact.p, 2 * (int64_t)n_c);
+    hipLaunchKernelGGL(k_scatter_S, dim3((n_c + 255) / 256), dim3(256), 0, s, ccols, n_c, ls.S_compact.p, S);
+  } else {
+    comm.allreduce(S + L.jmin, 2 * (int64_t)(L.jmax - L.jmin + 1));
+  }
+  hipLaunchKernelGGL((k_col_draw<PS>), dim3((L.n_all + 255) / 256), dim3(256), 0, s, a, L.cols_all.p, L.n_all, S,
+                     ls.oldnew_col.p);
+  if (grid) {
+    TimedLaunch t(tm, s, kc.light, PA::BYTES * (L.nnz_heavy + L.nnz_light));
+    hipLaunchKernelGGL((k_level_split<PA, UNIT, 2>), dim3(grid), dim3(WG), 0, s, a, L.cols_w1.p, L.n_w1, L.cols_w4.p, L.n_w4,
+                       L.cols_w16.p, L.n_w16, L.cols_wg.p, L.n_wg, (double2 *)nullptr, ls.oldnew_col.p);
+  }
+  if (L.n_huge) {
+    TimedLaunch t(tm, s, kc.happly, PA::BYTES * L.nnz_huge);
+    hipLaunchKernelGGL((k_long_apply_col<PA>), dim3(L.n_hchunks), dim3(WG), 0, s, a, L.hchunks.p, L.cols_huge.p,
+                       ls.oldnew_col.p);
+  }
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
+// can the row-sharded latent sweep of this (local) table run the fused tile path? Two PAR levels: a contiguous
+// first level covering every local row once, a row-tile last level, tiles aligned to the first level.
+static inline bool plan_supports_sharded_fused(const StepPlan &plan) {
+  if (!plan.sharded_tiles || plan.steps.size() != 2 || !plan.aligned_tiles) return false;
+  const Step &f = plan.steps.front(), &l = plan.steps.back();
+  if (f.is_chain || l.is_chain) return false;
+  return !f.par.scattered && f.par.first_and_once && f.par.contig && l.par.scattered && l.par.tiled;
+}
+
+// Row-sharded latent sweep, split e / q layout, fused tile pass (args(f).state = e, .state2 = q). The
+// first-level columns that are complete on this rank go through k_tile_apply_next without any communication;
+// per factor the ranks exchange the last level's statistics (2 n_cols doubles) and those of the few special
+// first-level columns; the first-level coefficients are made identical on every rank once, after the sweep
+// (sync_model in mfm_sweep_V).
+template <bool UNIT, class ArgsOf>
+static void run_sweep_soa_sharded(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf args, int f_begin, int f_end,
+                                  LongScratch &ls, const SweepClasses &kc, const Comm &comm) {
+  const ParLevel &L1 = plan.steps.front().par, &L = plan.steps.back().par;
+  const int swz = xcd_swizzle_enabled();
+  const size_t lds = sizeof(double2) << L.tile_bits;
+  const int nt = tile_threads(L.tile_bits);
+  const bool two = L.covers_rows_once && !std::getenv("MFM_NO_FUSED_TWO");
+  {
+    // first factor's first level: every column, with an all-reduce over the level's column range
+    const SweepArgs a = args(f_begin);
+    run_level_sharded<PMainVsq<UNIT>, PMainVsqA<UNIT>, UNIT>(s, tm, L1, a, ls, kc, comm, nullptr, 0);
+  }
+  for (int f = f_begin; f < f_end; f++) {
+    const SweepArgs a = args(f);
+    const bool next = f + 1 < f_end;
+    {
+      TimedLaunch t(tm, s, kc.scat, 20.0 * L.n_ent);
+      if (f == f_begin) {
+        hipLaunchKernelGGL(k_tile_old, dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a.theta, L.scols.p, L.n_cols,
+                           ls.vnext_col.p);
+        hipLaunchKernelGGL((k_tile_stats<PMainV, UNIT, true>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p,
+                           L.tile_ptr.p, L.tile_row0.p, ls.vnext_col.p, L.run_base.p, L.slot_pos.p, L.slots.p, L.tile_bits,
+                           L.n_tiles, swz, (const int32_t *)nullptr);
+      }
+      hipLaunchKernelGGL(k_tile_sum, dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, L.n_cols, L.slot_ptr.p, L.slots.p, ls.S_col.p);
+    }
+    MFM_HIP_CHECK(hipGetLastError());
+    comm.allreduce(ls.S_col.p, 2 * (int64_t)L.n_cols);
+    SweepArgs an = next ? args(f + 1) : a;
+    hipLaunchKernelGGL((k_tile_draw_S<PMainV>), dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a, L.scols.p, L.n_cols,
+                       ls.S_col.p, ls.oldnew_col.p, next ? (const double *)an.theta : (const double *)nullptr, ls.vnext_col.p);
+    if (!next) {
+      TimedLaunch t(tm, s, kc.scat, 28.0 * L.n_ent);
+      hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, false>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p,
+                         L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz);
+      continue;
+    }
+    an.row0 = plan.col_row0.p;
+    {
+      const double nnz_f = (double)L1.nnz_total() + (double)L.n_ent;
+      TimedLaunch t(tm, s, KC_SWEEP_V_FUSED, 56.0 * nnz_f + 8.0 * plan.n_state_rows + 8.0 * (L1.n_all + L.n_cols));
+      SweepArgs af = a;
+      af.row0 = plan.col_row0.p;
+      FuseArgs fa{an.theta,  an.z,          an.lambda,    an.mu,        plan.fuse_cols.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
+                  1,         L.run_base.p,  L.slot_pos.p, L.slots.p};
+      if (two)
+        hipLaunchKernelGGL((k_tile_apply_next<UNIT, true>), dim3(L.n_tiles), dim3(nt), lds, s, af, L.tent.p, L.ent_val.p,
+                           L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
+      else
+        hipLaunchKernelGGL((k_tile_apply_next<UNIT, false>), dim3(L.n_tiles), dim3(nt), lds, s, af, L.tent.p, L.ent_val.p,
+                           L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
+    }
+    MFM_HIP_CHECK(hipGetLastError());
+    // special first-level columns of factor f + 1 (rows on several ranks / longer than a tile / empty)
+    if (plan.n_special)
+      run_level_sharded<PMainVsq<UNIT>, PMainVsqA<UNIT>, UNIT>(s, tm, plan.special_level, an, ls, kc, comm,
+                                                               plan.special_cols.p, plan.n_special);
+    if (plan.n_solo_tiles) {
+      TimedLaunch t(tm, s, kc.scat, 20.0 * plan.n_solo_tiles * (1 << L.tile_bits));
+      hipLaunchKernelGGL((k_tile_stats<PMainV, UNIT, true>), dim3(plan.n_solo_tiles), dim3(nt), lds, s, an, L.tent.p,
+                         L.ent_val.p, L.tile_ptr.p, L.tile_row0.p, ls.vnext_col.p, L.run_base.p, L.slot_pos.p, L.slots.p,
+                         L.tile_bits, L.n_tiles, swz, plan.solo_tiles.p);
     }
   }
   MFM_HIP_CHECK(hipGetLastError());

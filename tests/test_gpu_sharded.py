@@ -136,3 +136,58 @@ def test_two_shards_lockstep(oracle, name):
         np.testing.assert_allclose(ge, e[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
         assert abs(galpha - t.hyper()["alpha"]) < 1e-7 * galpha
     assert ls.counts[0] == ls.counts[1] > 0
+
+
+@pytest.mark.parametrize("world,values", [(2, False), (3, True)])
+def test_sharded_fused_tile_path(oracle, world, values, monkeypatch):
+    """user-sorted two-field table, row-sharded: first-level columns complete on one rank are swept locally inside
+    the fused tile pass, the users straddling a rank boundary (and one longer than a tile) go through the
+    all-reduced path, the model is synchronised after the sweep -- must reproduce the unsharded oracle chain"""
+    from myfm_amd import _capi, _myfm
+    from myfm_amd.distributed import shard_rows
+
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    n = 90001
+    X, y, shapes = ds.onehot_mf(n, 80, 70, seed=9, sort_by_user=True)
+    if values:
+        X = X.copy()
+        X.data = np.where(np.arange(X.nnz) % 3 == 0, 0.5, 1.5)
+    assert np.diff(X.tocsc().indptr)[:80].max() > 4096
+    gi = ds.group_index_from_shapes(shapes)
+    K = 3
+    ls = Lockstep(world)
+    levels = _capi.column_levels(X)[0]
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            Xl, yl, rel, lo, ntot = shard_rows(X, y, [], rank, world)
+            s = _myfm.GibbsSession(K, 0.1, Xl, [], yl, 42, _config(gi), allreduce=ls.callback(rank), n_total_rows=ntot,
+                                   row_offset=lo, main_levels=levels)
+            flags = s.plan_flags()
+            for it in range(3):
+                s.step()
+            out[rank] = (s.fm.w0, np.asarray(s.fm.w), np.asarray(s.fm.V), s.residual(), lo, float(s.hyper.alpha), flags)
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            ls.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=300)
+    assert not errs, errs
+    t = oracle.OracleTrainer(X, y, rank=K, group_index=gi)
+    for it in range(3):
+        t.step()
+    w0, w, V = t.fm()
+    e = t.e(n)
+    for rank in range(world):
+        gw0, gw, gV, ge, lo, galpha, flags = out[rank]
+        assert flags & 64, flags  # the fused sharded path was taken
+        assert abs(gw0 - w0) < 1e-7
+        np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(ge, e[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
+        assert abs(galpha - t.hyper()["alpha"]) < 1e-7 * galpha
