@@ -71,7 +71,11 @@ def main():
 
     # ---- workload: every rank holds one ML-10M-shaped shard of `rows` rows (weak scaling) --------
     t0 = time.time()
-    X, y, shapes = ds.movielens_like(a.rows, a.users, a.items, rank_true=32, seed=1 + rank)
+    if world == 1:
+        X, y, shapes = ds.movielens_like(a.rows, a.users, a.items, rank_true=32, seed=1)
+    else:
+        # rank r holds rows [r * rows, (r + 1) * rows) of ONE user-sorted table of world * rows rows (same users / items)
+        X, y, shapes = ds.movielens_like_shard(a.rows, rank, world, a.users, a.items, rank_true=32, seed=1)
     gi = ds.group_index_from_shapes(shapes)
     N, D, nnz, K = X.shape[0], X.shape[1], X.nnz, a.rank
     t_data = time.time() - t0
@@ -94,7 +98,9 @@ def main():
         levels = np.concatenate([np.zeros(a.users, np.int32), np.ones(a.items, np.int32)])  # two one-hot fields
         sess = _myfm.GibbsSession(K, 0.1, X, [], y, 42, b.build(), allreduce=ar, n_total_rows=world * N, row_offset=rank * N,
                                   stream=ar.stream_ptr, main_levels=levels)
-        parallelism = "rows sharded over %d GPUs (weak: %d rows/GPU), RCCL all-reduce of 2|level| doubles per level" % (world, N)
+        parallelism = ("one chain over %d rows, user-sorted, rows sharded over %d GPUs (weak: %d rows/GPU); per factor one "
+                       "RCCL all-reduce of the item level's statistics (+ the users shared by two ranks), "
+                       "one model all-reduce per sweep" % (world * N, world, N))
     t_setup = time.time() - t0
 
     def sync():

@@ -412,12 +412,12 @@ struct StepPlan {
   }
 
   // Row-sharded mode with the fused tile path (run_sweep_soa_sharded): the plan may use row tiles; first-level
-  // columns flagged `special` (rows on more than one rank, longer than a tile on some rank, or empty on every
-  // rank -- the same set on every rank) get tiles of their own and are swept through `special_level` with an
+  // columns flagged `special` (rows on more than one rank, or empty on every rank -- the same set on every rank) get tiles of their own and are swept through `special_level` with an
   // all-reduce of their statistics; all other first-level columns with local rows are complete on this rank.
   bool sharded_tiles = false;
   std::vector<char> special;  // per column of the table (sharded_tiles only)
   ParLevel special_level;
+  ParLevel local_level;       // the other first-level columns with local rows: complete here, swept without communication
   DevBuf<int32_t> special_cols;
   int n_special = 0;
 
@@ -443,6 +443,7 @@ struct StepPlan {
   }
 
   void build(const HostCsr &csc, int r_w16, int r_wg, int coop_max, bool allow_scatter = false, bool unit = false) {
+    const int coop_local = coop_max;  // (sharded_tiles: locally complete long columns still run co-resident)
     if (sharded) coop_max = 0;
     n_state_rows = csc.cols;
     {
@@ -531,9 +532,19 @@ struct StepPlan {
           ((int64_t)1 << tile_bits) == cap_wg && (L.n_huge == 0 || sharded_tiles) && !std::getenv("MFM_NO_ALIGNED_TILES"))
         build_aligned_tiles(csc, by_level[l], (int64_t)1 << tile_bits);
       if (steps.size() == 1 && sharded_tiles && aligned_tiles) {
-        std::vector<int32_t> sp;
-        for (int32_t j : by_level[l])
-          if (!special.empty() && special[j]) sp.push_back(j);
+        std::vector<int32_t> sp, loc;
+        for (int32_t j : by_level[l]) {
+          if (!special.empty() && special[j])
+            sp.push_back(j);
+          else if (csc.ptr[j + 1] > csc.ptr[j])
+            loc.push_back(j);
+        }
+        local_level.cols_all.upload(loc);
+        local_level.n_all = (int)loc.size();
+        local_level.contig = L.contig;
+        bin_columns(csc, loc, local_level, cap_w1, cap_w4, cap_w16, cap_wg, coop_local);
+        max_hchunks = std::max(max_hchunks, local_level.n_hchunks);
+        max_huge = std::max(max_huge, local_level.n_huge);
         n_special = (int)sp.size();
         special_cols.upload(sp);
         special_level.cols_all.upload(sp);
@@ -1038,9 +1049,13 @@ static void run_sweep_soa_sharded(hipStream_t s, Timing &tm, const StepPlan &pla
   const int nt = tile_threads(L.tile_bits);
   const bool two = L.covers_rows_once && !std::getenv("MFM_NO_FUSED_TWO");
   {
-    // first factor's first level: every column, with an all-reduce over the level's column range
+    // first factor's first level: the locally complete columns in one pass, the special ones all-reduced
     const SweepArgs a = args(f_begin);
-    run_level_sharded<PMainVsq<UNIT>, PMainVsqA<UNIT>, UNIT>(s, tm, L1, a, ls, kc, comm, nullptr, 0);
+    launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, plan.local_level, a, ls, kc, plan.col_row0.p);
+    launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, plan.local_level, a, ls, kc);
+    if (plan.n_special)
+      run_level_sharded<PMainVsq<UNIT>, PMainVsqA<UNIT>, UNIT>(s, tm, plan.special_level, a, ls, kc, comm,
+                                                               plan.special_cols.p, plan.n_special);
   }
   for (int f = f_begin; f < f_end; f++) {
     const SweepArgs a = args(f);
@@ -1083,7 +1098,10 @@ static void run_sweep_soa_sharded(hipStream_t s, Timing &tm, const StepPlan &pla
                            L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
     }
     MFM_HIP_CHECK(hipGetLastError());
-    // special first-level columns of factor f + 1 (rows on several ranks / longer than a tile / empty)
+    // first-level columns of factor f + 1 longer than a tile (complete here: co-resident single pass), then the
+    // special ones (rows on several ranks / empty everywhere: all-reduced statistics)
+    launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, plan.local_level, an, ls, kc, plan.col_row0.p, 1);
+    launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, plan.local_level, an, ls, kc);
     if (plan.n_special)
       run_level_sharded<PMainVsq<UNIT>, PMainVsqA<UNIT>, UNIT>(s, tm, plan.special_level, an, ls, kc, comm,
                                                                plan.special_cols.p, plan.n_special);

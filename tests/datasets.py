@@ -149,3 +149,42 @@ def movielens_like(n_rows, n_users, n_items, rank_true=32, seed=1, noise=0.8, us
     indices[1::2] = n_users + i
     X = sps.csr_matrix((np.ones(2 * n_rows), indices, indptr), shape=(n_rows, n_users + n_items))
     return X, y, [n_users, n_items]
+
+
+def movielens_like_shard(rows_per_rank, rank, world, n_users, n_items, rank_true=32, seed=1, noise=0.8, user_offset=700.0,
+                         item_offset=40.0):
+    """Rows [rank * rows_per_rank, (rank + 1) * rows_per_rank) of ONE user-sorted table of world * rows_per_rank
+    rows with the popularity profile of movielens_like (the layout a row-sharded multi-GPU run sees: every
+    rank holds a contiguous range of users, at most two of them shared with its neighbours). Every rank
+    derives the same global user boundaries and truth parameters from `seed`; items and noise are per rank.
+    Returns (X csr local rows x all features, y, group_shapes)."""
+    total = world * rows_per_rank
+    g = np.random.default_rng(seed)
+    pu = 1.0 / (np.arange(1, n_users + 1) + user_offset)
+    pu = pu[g.permutation(n_users)]
+    bounds = np.floor(np.cumsum(pu / pu.sum()) * total + 0.5).astype(np.int64)  # user u owns rows [bounds[u-1], bounds[u])
+    bounds[-1] = total
+    iperm = g.permutation(n_items).astype(np.int32)
+    bu = g.normal(size=n_users) * 0.4
+    bi = g.normal(size=n_items) * 0.4
+    U = g.normal(size=(n_users, rank_true)) * (0.6 / np.sqrt(rank_true))
+    It = g.normal(size=(n_items, rank_true)) * 0.6
+    lo = rank * rows_per_rank
+    rows = np.arange(lo, lo + rows_per_rank, dtype=np.int64)
+    u = np.searchsorted(bounds, rows, side="right").astype(np.int32)
+    r = np.random.default_rng([seed, 1000 + rank])
+    pi = 1.0 / (np.arange(1, n_items + 1) + item_offset)
+    i = iperm[r.choice(n_items, size=rows_per_rank, p=pi / pi.sum())]
+    y = np.empty(rows_per_rank)
+    step = 2_000_000
+    for s0 in range(0, rows_per_rank, step):
+        e = min(rows_per_rank, s0 + step)
+        y[s0:e] = 3.5 + bu[u[s0:e]] + bi[i[s0:e]] + np.einsum("ij,ij->i", U[u[s0:e]], It[i[s0:e]])
+    y += r.normal(size=rows_per_rank) * noise
+    y = np.clip(np.round(y * 2) / 2, 0.5, 5.0)
+    indptr = np.arange(0, 2 * rows_per_rank + 1, 2, dtype=np.int64)
+    indices = np.empty(2 * rows_per_rank, dtype=np.int32)
+    indices[0::2] = u
+    indices[1::2] = n_users + i
+    X = sps.csr_matrix((np.ones(2 * rows_per_rank), indices, indptr), shape=(rows_per_rank, n_users + n_items))
+    return X, y, [n_users, n_items]
