@@ -55,6 +55,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the sampler has no CPU fallback")
+    if os.environ.get("MYFM_BENCH_DEVICE"):  # debugging: several ranks on one GPU (with MYFM_BENCH_BACKEND=gloo)
+        local_rank = int(os.environ["MYFM_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     os.environ["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES", "")
     dist = None
@@ -64,18 +66,23 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MYFM_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from myfm_amd import _myfm
     from tests import datasets as ds
 
     # ---- workload: every rank holds one ML-10M-shaped shard of `rows` rows (weak scaling) --------
     t0 = time.time()
+    row_lo, rows_total = 0, a.rows
     if world == 1:
         X, y, shapes = ds.movielens_like(a.rows, a.users, a.items, rank_true=32, seed=1)
     else:
         # rank r holds rows [r * rows, (r + 1) * rows) of ONE user-sorted table of world * rows rows (same users / items)
-        X, y, shapes = ds.movielens_like_shard(a.rows, rank, world, a.users, a.items, rank_true=32, seed=1)
+        X, y, shapes, row_lo, rows_total = ds.movielens_like_shard(a.rows, rank, world, a.users, a.items, rank_true=32, seed=1)
     gi = ds.group_index_from_shapes(shapes)
     N, D, nnz, K = X.shape[0], X.shape[1], X.nnz, a.rank
     t_data = time.time() - t0
@@ -96,11 +103,11 @@ def main():
 
         ar = TorchAllReduce()
         levels = np.concatenate([np.zeros(a.users, np.int32), np.ones(a.items, np.int32)])  # two one-hot fields
-        sess = _myfm.GibbsSession(K, 0.1, X, [], y, 42, b.build(), allreduce=ar, n_total_rows=world * N, row_offset=rank * N,
+        sess = _myfm.GibbsSession(K, 0.1, X, [], y, 42, b.build(), allreduce=ar, n_total_rows=rows_total, row_offset=row_lo,
                                   stream=ar.stream_ptr, main_levels=levels)
-        parallelism = ("one chain over %d rows, user-sorted, rows sharded over %d GPUs (weak: %d rows/GPU); per factor one "
-                       "RCCL all-reduce of the item level's statistics (+ the users shared by two ranks), "
-                       "one model all-reduce per sweep" % (world * N, world, N))
+        parallelism = ("one chain over %d rows, user-sorted, rows sharded over %d GPUs at user boundaries (weak: ~%d rows/GPU); "
+                       "per factor one RCCL all-reduce of the item level's statistics (+ one for users split between "
+                       "two ranks, if any), one model all-reduce per sweep" % (rows_total, world, a.rows))
     t_setup = time.time() - t0
 
     def sync():
@@ -128,9 +135,18 @@ def main():
     if not a.no_kernel_timing:
         sess.timing_enable(False)
 
-    # sanity: the chain is alive (finite state, plausible noise precision)
+    # sanity: the chain is alive (finite state, plausible noise precision) and, when sharded, the replicated
+    # model is the same on every rank (w0, alpha and a checksum of V)
     alpha = sess.hyper.alpha
     assert np.isfinite(alpha) and alpha > 0, alpha
+    if dist is not None and world > 1:
+        fm = sess.fm
+        mine = torch.tensor([float(fm.w0), float(alpha), float(np.abs(np.asarray(fm.V)).sum()), float(np.asarray(fm.w).sum())],
+                            dtype=torch.float64, device="cuda")
+        allv = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        for v in allv[1:]:
+            assert torch.allclose(v, allv[0], rtol=1e-12, atol=0), ("replicas diverged", [x.tolist() for x in allv])
 
     if rank != 0:
         if dist is not None:
@@ -215,7 +231,7 @@ def main():
             "workload": "BASELINE configs[2]: MovieLens-10M-shaped synthetic CSR, MyFMRegressor rank=%d fp64, full update_all" % K,
             "rows": N, "nnz": nnz, "features": D, "users": a.users, "items": a.items, "rank": K, "groups": 2,
             "parallelism": parallelism,
-            "row_iterations_per_s": round(world * N * a.steps / elapsed),
+            "row_iterations_per_s": round((rows_total if world > 1 else N) * a.steps / elapsed),
             "chain_iterations_per_s": round(a.steps / elapsed, 3),
             "alg_bytes_per_iteration": B_iter,
             "setup_s": round(t_setup, 2), "datagen_s": round(t_data, 2),

@@ -467,8 +467,8 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     const int coop_v = std::min({coop_capacity<PMainV>(), coop_capacity<PMainVe<false, false>>(), coop_capacity<PMainVe<true, false>>(),
                                  coop_capacity<PMainVsq<false>>(), coop_capacity<PMainVsq<true>>(), coop_capacity<PMainVs>()});
     // Row-sharded fused tile path: which first-level columns need an all-reduce of their statistics? Those
-    // with rows on more than one rank and those empty everywhere -- the same ("special") set on every rank,
-    // from two all-reduces of per-column indicators.
+    // with rows on more than one rank -- the same ("special") set on every rank, from two all-reduces of
+    // per-column indicators (columns empty on every rank are drawn from the prior by every rank itself).
     bool try_fused = c->comm.active() && c->hblocks.empty() && !c->hlevels.empty() && tile_bits == 12 && c->N > 0 &&
                      !std::getenv("MFM_NO_SHARDED_FUSED") && !std::getenv("MFM_NO_SOA");
     std::vector<double> col_cnt;
@@ -494,7 +494,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
       MFM_HIP_CHECK(hipMemcpy(sh.data(), d.p, sh.size() * sizeof(double), hipMemcpyDeviceToHost));
       std::vector<char> special((size_t)D0, 0);
       for (int64_t j = 0; j < D0; j++)
-        special[j] = c->hlevels[j] == 0 && (g[j] == 0 || sh[j] > 0);
+        special[j] = c->hlevels[j] != 0 ? 0 : sh[j] > 0 ? 1 : g[j] == 0 ? 2 : 0;
       c->plan_V.sharded_tiles = true;
       c->plan_V.special = std::move(special);
     }
@@ -519,7 +519,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
         // that holds its rows, every other column (identical on all ranks) by the rank holding global row 0
         std::vector<double> mask((size_t)c->D, c->row_offset == 0 ? 1.0 : 0.0);
         for (int64_t j = 0; j < c->D0; j++)
-          if (c->hlevels[j] == 0 && !c->plan_V.special[j]) mask[j] = col_cnt[j] > 0 ? 1.0 : 0.0;
+          if (c->hlevels[j] == 0 && c->plan_V.special[j] == 0) mask[j] = col_cnt[j] > 0 ? 1.0 : 0.0;
         c->sync_mask.upload(mask);
       }
     }

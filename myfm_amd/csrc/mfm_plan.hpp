@@ -370,10 +370,11 @@ struct StepPlan {
     };
     for (int32_t j : order) {
       const int64_t len = csc.ptr[j + 1] - csc.ptr[j];
-      const bool is_special = !special.empty() && special[j];
+      const bool is_special = !special.empty() && special[j] == 1;
       if (len == 0) {
-        // special: swept through special_level on every rank; sharded and not special: its rows live on another rank
-        if (is_special || sharded_tiles) continue;
+        // special: swept through special_level on every rank; sharded and not empty everywhere: its rows live on
+        // another rank
+        if (is_special || (sharded_tiles && special[j] != 2)) continue;
         if (h_tile_start.empty()) open_tile(0);
         fcols.push_back(j);
         continue;
@@ -412,10 +413,11 @@ struct StepPlan {
   }
 
   // Row-sharded mode with the fused tile path (run_sweep_soa_sharded): the plan may use row tiles; first-level
-  // columns flagged `special` (rows on more than one rank, or empty on every rank -- the same set on every rank) get tiles of their own and are swept through `special_level` with an
+  // columns flagged `special` (rows on more than one rank -- the same set on every rank) get tiles of their own and are swept through `special_level` with an
   // all-reduce of their statistics; all other first-level columns with local rows are complete on this rank.
   bool sharded_tiles = false;
-  std::vector<char> special;  // per column of the table (sharded_tiles only)
+  std::vector<char> special;  // per column of the table (sharded_tiles only): 1 = special, 2 = empty on every rank
+                              // (drawn from the prior by every rank itself, like a locally complete column)
   ParLevel special_level;
   ParLevel local_level;       // the other first-level columns with local rows: complete here, swept without communication
   DevBuf<int32_t> special_cols;
@@ -534,9 +536,9 @@ struct StepPlan {
       if (steps.size() == 1 && sharded_tiles && aligned_tiles) {
         std::vector<int32_t> sp, loc;
         for (int32_t j : by_level[l]) {
-          if (!special.empty() && special[j])
+          if (!special.empty() && special[j] == 1)
             sp.push_back(j);
-          else if (csc.ptr[j + 1] > csc.ptr[j])
+          else if (csc.ptr[j + 1] > csc.ptr[j] || (!special.empty() && special[j] == 2))
             loc.push_back(j);
         }
         local_level.cols_all.upload(loc);

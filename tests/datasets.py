@@ -153,11 +153,11 @@ def movielens_like(n_rows, n_users, n_items, rank_true=32, seed=1, noise=0.8, us
 
 def movielens_like_shard(rows_per_rank, rank, world, n_users, n_items, rank_true=32, seed=1, noise=0.8, user_offset=700.0,
                          item_offset=40.0):
-    """Rows [rank * rows_per_rank, (rank + 1) * rows_per_rank) of ONE user-sorted table of world * rows_per_rank
-    rows with the popularity profile of movielens_like (the layout a row-sharded multi-GPU run sees: every
-    rank holds a contiguous range of users, at most two of them shared with its neighbours). Every rank
-    derives the same global user boundaries and truth parameters from `seed`; items and noise are per rank.
-    Returns (X csr local rows x all features, y, group_shapes)."""
+    """This rank's contiguous slice (about rows_per_rank rows, cut at user boundaries) of ONE user-sorted table
+    of world * rows_per_rank rows with the popularity profile of movielens_like -- the layout a row-sharded
+    multi-GPU run sees: every rank holds a contiguous range of users. Every rank derives the same global user
+    boundaries and truth parameters from `seed`; items and noise are per rank.
+    Returns (X csr local rows x all features, y, group_shapes, first global row, total rows)."""
     total = world * rows_per_rank
     g = np.random.default_rng(seed)
     pu = 1.0 / (np.arange(1, n_users + 1) + user_offset)
@@ -169,7 +169,12 @@ def movielens_like_shard(rows_per_rank, rank, world, n_users, n_items, rank_true
     bi = g.normal(size=n_items) * 0.4
     U = g.normal(size=(n_users, rank_true)) * (0.6 / np.sqrt(rank_true))
     It = g.normal(size=(n_items, rank_true)) * 0.6
-    lo = rank * rows_per_rank
+    # shard boundaries snapped to user boundaries (a loader sharding a user-sorted table by users): the ranks'
+    # row counts differ by at most one user's rows and no user is split between two ranks
+    edges = np.concatenate([[0], bounds])
+    cut = [int(edges[np.argmin(np.abs(edges - r * rows_per_rank))]) for r in range(world + 1)]
+    cut[0], cut[-1] = 0, total
+    lo, rows_per_rank = cut[rank], cut[rank + 1] - cut[rank]
     rows = np.arange(lo, lo + rows_per_rank, dtype=np.int64)
     u = np.searchsorted(bounds, rows, side="right").astype(np.int32)
     r = np.random.default_rng([seed, 1000 + rank])
@@ -187,4 +192,4 @@ def movielens_like_shard(rows_per_rank, rank, world, n_users, n_items, rank_true
     indices[0::2] = u
     indices[1::2] = n_users + i
     X = sps.csr_matrix((np.ones(2 * rows_per_rank), indices, indptr), shape=(rows_per_rank, n_users + n_items))
-    return X, y, [n_users, n_items]
+    return X, y, [n_users, n_items], lo, total
