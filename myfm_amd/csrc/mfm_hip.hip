@@ -14,6 +14,7 @@
 #include "mfm_kernels.hpp"
 #include "mfm_plan.hpp"
 #include "mfm_block_kernels.hpp"
+#include "mfm_mtjump.hpp"
 #include "mfm_rng.hpp"
 
 namespace mfm {
@@ -82,8 +83,10 @@ struct mfm_ctx {
   struct RngEngine {
     bool seeded = false, programmed = false;
     hipStream_t stream = nullptr;
-    DevBuf<RngState> state;
+    DevBuf<RngState> state, state_next;
     DevBuf<uint32_t> raw;
+    DevBuf<uint32_t> jump;  // jump-ahead polynomials of the parallel generator (mfm_mtjump.hpp)
+    int par_wgs = 1;        // workgroups of k_mt_generate_par (1: the serial generator)
     uint64_t mask = 0, need = 0;
     DevBuf<RngOp> ops;
     int n_ops = 0;
@@ -996,6 +999,22 @@ int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops) {
   for (auto &o : h)  // the evaluation window of a big op reaches past its last accept
     if (o.kind == MFM_RNG_NORMALS && o.count > 16384)
       r.need += (uint64_t)(4 * (mfm_ctx::RngEngine::attempts_for(o.count) - (int64_t)((double)o.count * 1.2732)));
+  // more than one workgroup's worth of blocks per iteration: generate in parallel with jump-ahead
+  r.par_wgs = 1;
+  {
+    const int64_t blocks = (int64_t)(r.need / MT_N) + 2;
+    if (blocks > MT_PAR_BLOCKS && !std::getenv("MFM_RNG_SERIAL")) {
+      const int wgs = (int)((blocks + MT_PAR_BLOCKS - 1) / MT_PAR_BLOCKS);
+      std::vector<uint32_t> tab;
+      if (mtjump::build_jump_table(MT_PAR_BLOCKS, wgs - 1, tab)) {
+        r.jump.upload(tab);
+        r.state_next.alloc(1);
+        r.par_wgs = wgs;
+        MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mt_generate_par, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)((MT_JUMP_SPAN * MT_N + 2 * (MT_N + 1)) * sizeof(uint32_t))));
+      }
+    }
+  }
   uint64_t cap = 1;
   while (cap < r.need + 2 * MT_N) cap <<= 1;
   r.raw.alloc((size_t)cap);
@@ -1023,7 +1042,14 @@ int mfm_rng_prefetch(mfm_ctx *ctx) {
   auto &sl = r.slot[r.produced % 2];
   hipStream_t s = r.stream;
   if (sl.free_valid) MFM_HIP_CHECK(hipStreamWaitEvent(s, sl.free_ev, 0));
-  hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(MT_GEN_THREADS), 0, s, r.state.p, r.raw.p, r.mask, r.need);
+  if (r.par_wgs > 1) {
+    hipLaunchKernelGGL(k_mt_generate_par, dim3(r.par_wgs), dim3(MT_GEN_THREADS),
+                       (MT_JUMP_SPAN * MT_N + 2 * (MT_N + 1)) * sizeof(uint32_t), s, r.state.p, r.state_next.p, r.raw.p, r.mask,
+                       r.need, r.jump.p);
+    hipLaunchKernelGGL(k_mt_commit, dim3(1), dim3(MT_GEN_THREADS), 0, s, r.state.p, r.state_next.p);
+  } else {
+    hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(MT_GEN_THREADS), 0, s, r.state.p, r.raw.p, r.mask, r.need);
+  }
   // small ops (hyper draws) run in one sequential workgroup; big NORMALS ops on the whole GPU
   int i = 0;
   while (i < r.n_ops) {

@@ -127,6 +127,122 @@ __global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate(RngState *__rest
   }
 }
 
+// ---- parallel generation with jump-ahead ----------------------------------------------------------------
+// One workgroup is a serial chain (~0.33 us per 624-word block: 7.4 ms for the 13.5 M words of an iteration at
+// the ML-10M shape -- the wall once the sweeps dropped below that). Here workgroup p produces blocks
+// [p * MT_PAR_BLOCKS, (p + 1) * MT_PAR_BLOCKS) of the request. To start there it needs the block before its
+// first one: it walks 33 blocks from the stored state (20 592 words, in LDS) and applies the jump polynomial
+// g_p = x^((p * MT_PAR_BLOCKS - 1) * 624) mod phi (mfm_mtjump.hpp): word l of the target block is the XOR of
+// x[l + i] over the set bits i of g_p -- ~10 k conflict-free LDS reads per lane, no barriers. The new state is
+// written to a staging copy (late workgroups must still see the old one) and committed by k_mt_commit.
+constexpr int MT_PAR_BLOCKS = 512;
+constexpr int MT_JUMP_SPAN = 33;  // blocks covering 19937 + 624 words
+
+__global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate_par(const RngState *__restrict__ st, RngState *__restrict__ st_next,
+                                                                    uint32_t *__restrict__ raw, uint64_t mask, uint64_t need,
+                                                                    const uint32_t *__restrict__ jump_tab) {
+  extern __shared__ uint32_t lds_seq[];  // [MT_JUMP_SPAN * 624] sequence, then 2 x 625 generation buffers
+  uint32_t *seq = lds_seq;
+  uint32_t(*buf)[MT_N + 1] = (uint32_t(*)[MT_N + 1])(lds_seq + MT_JUMP_SPAN * MT_N);
+  const int t = threadIdx.x, p = blockIdx.x;
+  __builtin_amdgcn_s_setprio(3);
+  int pos = st->mt_pos;
+  uint64_t p_gen = st->p_gen;
+  const uint64_t target = st->p_cons + need;
+  if (t < MT_N) buf[0][t] = st->mt[t];
+  __syncthreads();
+  if (pos < MT_N && p_gen < target) {  // the not yet emitted tail of the current block
+    if (p == 0 && t >= pos && t < MT_N) raw[(p_gen + (uint64_t)(t - pos)) & mask] = buf[0][t];
+    p_gen += (uint64_t)(MT_N - pos);
+    pos = MT_N;
+  }
+  const int64_t nblk = p_gen < target ? (int64_t)((target - p_gen + MT_N - 1) / MT_N) : 0;
+  const int64_t b0 = (int64_t)p * MT_PAR_BLOCKS, b1 = min(nblk, b0 + MT_PAR_BLOCKS);
+  if (nblk == 0) {  // nothing to generate: only the position may have moved
+    if (p == 0) {
+      if (t < MT_N) st_next->mt[t] = buf[0][t];
+      if (t == 0) {
+        st_next->mt_pos = pos;
+        st_next->p_gen = p_gen;
+      }
+    }
+    return;
+  }
+  if (b0 >= nblk) return;
+  const int k = t < 623 ? t : (t == 640 ? 623 : -1);
+  auto step = [&](const uint32_t *x, uint32_t *xn) -> uint32_t {
+    uint32_t v = 0;
+    if (k >= 0) {
+      if (k < 227) {
+        v = x[k + 397] ^ mt_G(x, k);
+      } else if (k < 454) {
+        v = x[k + 170] ^ mt_G(x, k - 227) ^ mt_G(x, k);
+      } else if (k < 623) {
+        v = x[k - 57] ^ mt_G(x, k - 454) ^ mt_G(x, k - 227) ^ mt_G(x, k);
+      } else {
+        const uint32_t x0n = x[397] ^ mt_G(x, 0);
+        const uint32_t x396n = x[566] ^ mt_G(x, 169) ^ mt_G(x, 396);
+        v = mt_twist(x[623], x0n, x396n);
+      }
+      xn[k] = v;
+    }
+    return v;
+  };
+  int cur = 0;
+  if (p > 0) {
+    // blocks r = 0 .. 32 after the stored state (all of them generated words: the relation holds for every bit)
+    step(buf[0], seq);
+    __syncthreads();
+    for (int r = 1; r < MT_JUMP_SPAN; r++) {
+      step(seq + (r - 1) * MT_N, seq + r * MT_N);
+      __syncthreads();
+    }
+    // block b0 - 1 = block 0 advanced by (p * MT_PAR_BLOCKS - 1) blocks
+    if (t < MT_N) {
+      const uint32_t *g = jump_tab + (size_t)p * MT_N;
+      uint32_t y = 0;
+      for (int w = 0; w < MT_N; w++) {
+        uint32_t gw = g[w];  // wave-uniform
+        const uint32_t *xs = seq + t + 32 * w;
+        while (gw) {
+          const int b = __builtin_ctz(gw);
+          y ^= xs[b];
+          gw &= gw - 1;
+        }
+      }
+      buf[0][t] = y;
+    }
+    __syncthreads();
+  }
+  const uint32_t m32 = (uint32_t)mask;
+  uint32_t off = (uint32_t)((p_gen + (uint64_t)b0 * MT_N) & mask);
+  for (int64_t b = b0; b < b1; b++) {
+    const uint32_t *x = buf[cur];
+    uint32_t *xn = buf[cur ^ 1];
+    const uint32_t v = step(x, xn);
+    if (k >= 0) raw[(off + (uint32_t)k) & m32] = v;
+    off += MT_N;
+    cur ^= 1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  if (b1 == nblk) {  // this workgroup holds the last block: the new generator state
+    __syncthreads();
+    if (t < MT_N) st_next->mt[t] = buf[cur][t];
+    if (t == 0) {
+      st_next->mt_pos = MT_N;
+      st_next->p_gen = p_gen + (uint64_t)nblk * MT_N;
+    }
+  }
+}
+__global__ void k_mt_commit(RngState *__restrict__ st, const RngState *__restrict__ st_next) {
+  const int t = threadIdx.x;
+  if (t < MT_N) st->mt[t] = st_next->mt[t];
+  if (t == 0) {
+    st->mt_pos = st_next->mt_pos;
+    st->p_gen = st_next->p_gen;
+  }
+}
+
 // generate_canonical<double, 53>(mt19937): low word first, sum rounded to nearest, / 2^64
 __device__ __forceinline__ double canonical(uint32_t lo, uint32_t hi) {
   const double sum = (double)lo + (double)hi * 4294967296.0;

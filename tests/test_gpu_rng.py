@@ -28,10 +28,11 @@ def _host_program(t, ops):
     return np.concatenate(hv), zw, zv
 
 
-@pytest.mark.parametrize("seed,n_users,K", [(42, 700, 5), (7, 700, 5), (3, 9000, 7)])
+@pytest.mark.parametrize("seed,n_users,K", [(42, 700, 5), (7, 700, 5), (3, 9000, 7), (11, 60000, 8)])
 def test_device_stream_matches_libstdcxx(oracle, seed, n_users, K):
     # (n_users=700, K=5): every op takes the single-workgroup path; (9000, 7): z_V has 63 k variates and
-    # goes through the whole-GPU eval / scan / scatter path, z_w (9 k) stays on the small path
+    # goes through the whole-GPU eval / scan / scatter path, z_w (9 k) stays on the small path;
+    # (60000, 8): ~2.5 M engine outputs per iteration -> the parallel generator with jump-ahead (8 workgroups)
     from myfm_amd import _capi
 
     X, y, shapes = ds.onehot_mf(3000, n_users, 90, seed=1)
