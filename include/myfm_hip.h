@@ -187,6 +187,9 @@ int mfm_rng_get_z(mfm_ctx *ctx, double *zw, double *zv);
 
 /* ---- per-kernel timing (HIP events on the ctx stream) for bench.py's roofline block ---- */
 int mfm_timing_enable(mfm_ctx *ctx, int on);
+/* Restrict the event bracketing to one kernel class (index as in mfm_timing_class_name; < 0: all classes).
+ * Bracketing every launch costs ~10 % at config 3; one class is cheap enough for a timed benchmark region. */
+int mfm_timing_select(mfm_ctx *ctx, int32_t kernel_class);
 int mfm_timing_reset(mfm_ctx *ctx);
 int mfm_timing_n_classes(void);
 const char *mfm_timing_class_name(int cls);

@@ -1125,6 +1125,16 @@ struct GibbsSession {
     return e;
   }
   void timing_enable(bool on) { ck(trainer->ctx, mfm_timing_enable(trainer->ctx, on ? 1 : 0)); }
+  // only this kernel class is bracketed with events ("" : all)
+  void timing_select(const std::string &name) {
+    int idx = -1;
+    if (!name.empty()) {
+      for (int i = 0; i < mfm_timing_n_classes(); i++)
+        if (name == mfm_timing_class_name(i)) idx = i;
+      if (idx < 0) throw std::invalid_argument("unknown kernel class " + name);
+    }
+    ck(trainer->ctx, mfm_timing_select(trainer->ctx, idx));
+  }
   void timing_reset() { ck(trainer->ctx, mfm_timing_reset(trainer->ctx)); }
   py::dict timing() {
     py::dict out;
@@ -1329,6 +1339,7 @@ PYBIND11_MODULE(_myfm, m) {
       .def("synchronize", &GibbsSession::synchronize)
       .def("residual", &GibbsSession::residual)
       .def("timing_enable", &GibbsSession::timing_enable)
+      .def("timing_select", &GibbsSession::timing_select)
       .def("timing_reset", &GibbsSession::timing_reset)
       .def("timing", &GibbsSession::timing)
       .def("plan_info", &GibbsSession::plan_info)

@@ -152,6 +152,7 @@ static const char *const kKernelClassNames[KC_N] = {
 
 struct Timing {
   bool on = false;
+  int only = -1;  // >= 0: only this kernel class is bracketed with events (cheap enough for a timed benchmark region)
   struct Rec {
     hipEvent_t a, b;
     int cls;
@@ -207,7 +208,7 @@ struct TimedLaunch {
   int cls;
   hipEvent_t a;
   TimedLaunch(Timing &t_, hipStream_t s_, int cls_, double alg_bytes) : t(t_), s(s_), cls(cls_), a(nullptr) {
-    if (t.on) {
+    if (t.on && (t.only < 0 || t.only == cls)) {
       t.launches[cls]++;
       t.bytes[cls] += alg_bytes;
       a = t.get_event();

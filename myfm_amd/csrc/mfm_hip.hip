@@ -1120,6 +1120,13 @@ int mfm_timing_enable(mfm_ctx *ctx, int on) {
   ctx->timing.on = on != 0;
   MFM_CATCH(ctx)
 }
+
+int mfm_timing_select(mfm_ctx *ctx, int32_t kernel_class) {
+  MFM_TRY(ctx)
+  if (kernel_class >= KC_N) throw Error(MFM_ERR_INVALID, "kernel class index out of range");
+  ctx->timing.only = kernel_class < 0 ? -1 : kernel_class;
+  MFM_CATCH(ctx)
+}
 int mfm_timing_reset(mfm_ctx *ctx) {
   MFM_TRY(ctx)
   MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
