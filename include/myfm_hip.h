@@ -123,6 +123,11 @@ int mfm_shift_e(mfm_ctx *ctx, double delta);
 int mfm_group_stats_w(mfm_ctx *ctx, const double *mu_w, double *sum, double *ssd);
 /* same for every factor of V (FMTrainer.hpp:202-216); all arrays (G, K) column-major.       */
 int mfm_group_stats_V(mfm_ctx *ctx, const double *mu_V, double *sum, double *ssd);
+/* reduce_e + group_stats_w + group_stats_V with one host synchronisation (same outputs; need_e = 0 skips the
+ * residual sums). All three only read state the iteration has not touched yet when it needs them
+ * (FMTrainer.hpp:138, :150-216, :223). (G) and (G, K) arrays are column-major like the reference's. */
+int mfm_hyper_stats(mfm_ctx *ctx, int32_t need_e, const double *mu_w, const double *mu_V, double *sum_e, double *sum_e2,
+                    double *sum_w, double *ssd_w, double *sum_V, double *ssd_V);
 /* update_w (FMTrainer.hpp:231-314): main table then relation blocks, feature order preserved
  * for every pair of features that share a row. z[D] = the N(0,1) variates of the D
  * sample_normal calls in reference order (main columns, then each block's columns); z == NULL uses the

@@ -23,7 +23,7 @@ SYMBOLS = [
     "mfm_dim_all", "mfm_plan_info", "mfm_plan_flags", "mfm_set_state", "mfm_get_state", "mfm_set_w0", "mfm_zero_w", "mfm_get_e",
     "mfm_get_q", "mfm_set_e", "mfm_reduce_e", "mfm_shift_e", "mfm_group_stats_w", "mfm_group_stats_V",
     "mfm_sweep_w", "mfm_sweep_V", "mfm_update_e_regression", "mfm_update_e_classification", "mfm_score_train",
-    "mfm_oprobit_add_group", "mfm_oprobit_eval", "mfm_oprobit_sample_z", "mfm_timing_enable", "mfm_timing_select", "mfm_timing_reset",
+    "mfm_oprobit_add_group", "mfm_oprobit_eval", "mfm_oprobit_sample_z", "mfm_hyper_stats", "mfm_timing_enable", "mfm_timing_select", "mfm_timing_reset",
     "mfm_timing_n_classes", "mfm_timing_class_name", "mfm_timing_get", "mfm_design_create", "mfm_design_add_block",
     "mfm_design_destroy", "mfm_design_last_error", "mfm_design_dim_all", "mfm_design_predict",
     "mfm_host_column_levels", "mfm_rng_seed_mt19937", "mfm_rng_set_program", "mfm_rng_prefetch", "mfm_rng_acquire",
@@ -76,6 +76,7 @@ def lib():
     L.mfm_shift_e.argtypes = [vp, dbl]
     L.mfm_group_stats_w.argtypes = [vp, P, P, P]
     L.mfm_group_stats_V.argtypes = [vp, P, P, P]
+    L.mfm_hyper_stats.argtypes = [vp, C.c_int32, P, P, P, P, P, P, P, P]
     L.mfm_sweep_w.argtypes = [vp, dbl, P, P, P]
     L.mfm_sweep_V.argtypes = [vp, i32, i32, dbl, P, P, P]
     L.mfm_update_e_regression.argtypes = [vp]

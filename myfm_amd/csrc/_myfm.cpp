@@ -949,10 +949,14 @@ struct FMTrainer {
       hv_pos = 0;
       ck(ctx, mfm_rng_prefetch(ctx));  // the next iteration's are produced while this one runs
     }
-    // update_alpha (FMTrainer.hpp:127-145) + update_w0 (:218-229) share one pass over e
+    // every reduction the hyper-parameter updates need, one host synchronisation: sum e / sum e^2 (update_alpha,
+    // FMTrainer.hpp:127-145, update_w0 :218-229) and the group sums of w and V (:150-216) -- the latter are taken
+    // before update_w / update_V touch w / V, which is where the reference takes them too
     Real sum_e = 0, sum_e2 = 0;
     const bool need_alpha = cfg.task_type == TaskType::REGRESSION;
-    if (need_alpha || cfg.fit_w0) ck(ctx, mfm_reduce_e(ctx, &sum_e, &sum_e2));
+    vector<Real> sum(G), ssd(G), sumV(G * std::max(Kf, 1)), ssdV(G * std::max(Kf, 1));
+    ck(ctx, mfm_hyper_stats(ctx, (need_alpha || cfg.fit_w0) ? 1 : 0, hyper.mu_w.data(), hyper.mu_V.data(), &sum_e, &sum_e2,
+                            sum.data(), ssd.data(), sumV.data(), ssdV.data()));
     if (need_alpha) {
       Real exponent = (cfg.alpha_0 + N_total) / 2;
       Real variance = (cfg.beta_0 + sum_e2) / 2;
@@ -971,8 +975,6 @@ struct FMTrainer {
     }
     ck(ctx, mfm_set_w0(ctx, fm.w0));
     // update_lambda_w / update_mu_w (:150-200)
-    vector<Real> sum(G * std::max(Kf, 1)), ssd(G * std::max(Kf, 1));
-    ck(ctx, mfm_group_stats_w(ctx, hyper.mu_w.data(), sum.data(), ssd.data()));
     for (size_t g = 0; g < G; g++) {
       Real alpha = cfg.alpha_0 + n_in_group[g];
       Real beta = cfg.beta_0 + ssd[g];
@@ -998,18 +1000,17 @@ struct FMTrainer {
     }
     if (Kf > 0) {
       // update_lambda_V / update_mu_V (:202-216): factor outer, group inner
-      ck(ctx, mfm_group_stats_V(ctx, hyper.mu_V.data(), sum.data(), ssd.data()));
       for (int f = 0; f < Kf; f++)
         for (size_t g = 0; g < G; g++) {
           Real alpha = cfg.alpha_0 + n_in_group[g];
-          Real beta = cfg.beta_0 + ssd[(size_t)f * G + g];
+          Real beta = cfg.beta_0 + ssdV[(size_t)f * G + g];
           hyper.lambda_V[(size_t)f * G + g] = sample_gamma(alpha / 2, 2 / beta);
         }
       for (int f = 0; f < Kf; f++)
         for (size_t g = 0; g < G; g++) {
           Real lam = hyper.lambda_V[(size_t)f * G + g];
           Real square = lam * (cfg.gamma_0 + n_in_group[g]);
-          Real linear = cfg.gamma_0 * cfg.mu_0 + sum[(size_t)f * G + g];
+          Real linear = cfg.gamma_0 * cfg.mu_0 + sumV[(size_t)f * G + g];
           linear *= lam;
           hyper.mu_V[(size_t)f * G + g] = sample_normal(square, linear);
         }

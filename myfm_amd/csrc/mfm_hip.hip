@@ -69,6 +69,8 @@ struct mfm_ctx {
   DevBuf<double2> red_out;      // 1 + G * max(1,K)
   DevBuf<double> scratch_n;     // N doubles (get/set e,q)
   DevBuf<double2> gs_partial;   // group statistics: per-chunk partials
+  DevBuf<double2> hs_out;       // mfm_hyper_stats: [sum e | w groups | V groups]
+  DevBuf<double> hs_mu;         // mfm_hyper_stats: [mu_w | mu_V]
   int gs_chunks = 1;            // chunks of the largest group
   DevBuf<double> ec, qc;        // split e / q arrays of the latent sweep (soa), compact residual (qfree)
   bool qfree = false, soa = false, fuse_next = false;
@@ -744,6 +746,62 @@ int mfm_group_stats_w(mfm_ctx *ctx, const double *mu_w, double *sum, double *ssd
 }
 int mfm_group_stats_V(mfm_ctx *ctx, const double *mu_V, double *sum, double *ssd) {
   return group_stats(ctx, ctx->V.p, ctx->K, mu_V, sum, ssd);
+}
+
+// All the reductions the hyper-parameter updates of one iteration need, with ONE host synchronisation: sum e /
+// sum e^2 (update_alpha, update_w0: FMTrainer.hpp:138, :223), the per-group sums of w and of every factor of V
+// (update_lambda / update_mu: :150-216). None of them depends on what the iteration does before it uses them
+// (the w statistics are taken before update_w, the V statistics before update_V, both with the previous
+// iteration's mu), so they can all be taken up front.
+int mfm_hyper_stats(mfm_ctx *ctx, int32_t need_e, const double *mu_w, const double *mu_V, double *sum_e, double *sum_e2,
+                    double *sum_w, double *ssd_w, double *sum_V, double *ssd_V) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  mfm_ctx *c = ctx;
+  hipStream_t s = c->stream;
+  const int G = c->G, K = c->K, n_ch = std::max(1, c->gs_chunks);
+  const size_t n_out = 1 + (size_t)G * (K + 1);
+  if (c->hs_out.n < n_out) c->hs_out.alloc(n_out);
+  if (c->hs_mu.n < (size_t)G * (K + 1)) c->hs_mu.alloc((size_t)G * (K + 1));
+  if (c->gs_partial.n < (size_t)G * (K + 1) * n_ch) c->gs_partial.alloc((size_t)G * (K + 1) * n_ch);
+  if (need_e) {
+    TimedLaunch t(c->timing, s, KC_REDUCE_E, 8.0 * c->N);
+    hipLaunchKernelGGL(k_reduce_e_partial, dim3(REDUCE_BLOCKS), dim3(WG), 0, s, c->eq.p, c->N, c->red_partial.p);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, s, c->red_partial.p, REDUCE_BLOCKS, c->hs_out.p);
+    c->comm.allreduce(c->hs_out.p, 2);
+  }
+  c->ring.upload(c->hs_mu.p, mu_w, (size_t)G * sizeof(double), s);
+  if (K) c->ring.upload(c->hs_mu.p + G, mu_V, (size_t)G * K * sizeof(double), s);
+  {
+    TimedLaunch t(c->timing, s, KC_GROUP_STATS, 12.0 * c->D * (K + 1));
+    hipLaunchKernelGGL(k_group_stats, dim3(G, 1, n_ch), dim3(WG), 0, s, c->w.p, c->D, c->feat_sorted.p, c->group_ptr.p,
+                       c->hs_mu.p, G, c->gs_partial.p);
+    if (K)
+      hipLaunchKernelGGL(k_group_stats, dim3(G, K, n_ch), dim3(WG), 0, s, c->V.p, c->D, c->feat_sorted.p, c->group_ptr.p,
+                         c->hs_mu.p + G, G, c->gs_partial.p + (size_t)G * n_ch);
+    hipLaunchKernelGGL(k_group_stats_final, dim3(cdiv(G * (K + 1), 64)), dim3(64), 0, s, c->gs_partial.p, G * (K + 1), n_ch,
+                       c->hs_out.p + 1);
+  }
+  MFM_HIP_CHECK(hipGetLastError());
+  double2 *h = c->readback(n_out + 1);
+  MFM_HIP_CHECK(hipMemcpyAsync(h, c->hs_out.p, n_out * sizeof(double2), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipMemcpyAsync(h + n_out, c->ls.error.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipStreamSynchronize(s));
+  if (*(const int *)(h + n_out) != 0)
+    throw Error(MFM_ERR_RUNTIME, "long-column sweep: co-resident chunks timed out waiting for each other");
+  if (need_e) {
+    *sum_e = h[0].x;
+    *sum_e2 = h[0].y;
+  }
+  for (int g = 0; g < G; g++) {
+    sum_w[g] = h[1 + g].x;
+    ssd_w[g] = h[1 + g].y;
+  }
+  for (int i = 0; i < G * K; i++) {
+    sum_V[i] = h[1 + G + i].x;
+    ssd_V[i] = h[1 + G + i].y;
+  }
+  MFM_CATCH(ctx)
 }
 
 // ---- sweeps -----------------------------------------------------------------------------------
