@@ -75,6 +75,7 @@ struct mfm_ctx {
   DevBuf<double> ec, qc;        // split e / q arrays of the latent sweep (soa), compact residual (qfree)
   bool qfree = false, soa = false, fuse_next = false;
   bool sharded_fused = false;   // row-sharded + fused tile path (run_sweep_soa_sharded)
+  int q_stale_factor = -1;      // >= 0: the stored q column is stale, mfm_get_q rebuilds it for this factor first
   DevBuf<double> sync_mask;     // [D] 1: this rank contributes the column to the model synchronisation
   PinnedRing ring;
   double2 *h_red = nullptr;  // pinned readback
@@ -669,7 +670,19 @@ static int get_eq(mfm_ctx *ctx, double *dst, int which) {
   MFM_CATCH(ctx)
 }
 int mfm_get_e(mfm_ctx *ctx, double *e) { return get_eq(ctx, e, 0); }
-int mfm_get_q(mfm_ctx *ctx, double *q) { return get_eq(ctx, q, 1); }
+int mfm_get_q(mfm_ctx *ctx, double *q) {
+  if (ctx->finalized && ctx->q_stale_factor >= 0) {
+    // the split-layout sweeps never store q during update_V; nothing on the device path reads it afterwards
+    try {
+      launch_qbuild(ctx, ctx->V.p + (size_t)ctx->q_stale_factor * ctx->D);
+      ctx->q_stale_factor = -1;
+    } catch (const std::exception &ex) {
+      ctx->err = ex.what();
+      return MFM_ERR_RUNTIME;
+    }
+  }
+  return get_eq(ctx, q, 1);
+}
 int mfm_set_e(mfm_ctx *ctx, const double *e) {
   MFM_TRY(ctx)
   ctx->need_final();
@@ -876,7 +889,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       run_plan_qfree(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit);
     }
     hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
-    launch_qbuild(c, c->V.p + (size_t)(f_end - 1) * c->D);  // leave q_train as the reference would (FMTrainer.hpp:373)
+    c->q_stale_factor = f_end - 1;  // q_train as the reference leaves it (FMTrainer.hpp:373): rebuilt when asked for
     MFM_HIP_CHECK(hipGetLastError());
     return MFM_OK;
   }
@@ -907,7 +920,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       c->comm.allreduce(Vb, n);
     }
     hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
-    launch_qbuild(c, c->V.p + (size_t)(f_end - 1) * c->D);  // leave q_train as the reference would (FMTrainer.hpp:373)
+    c->q_stale_factor = f_end - 1;  // q_train as the reference leaves it (FMTrainer.hpp:373): rebuilt when asked for
     MFM_HIP_CHECK(hipGetLastError());
     return MFM_OK;
   }
@@ -932,7 +945,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     else
       run_sweep_soa<false>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, fuse);
     hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
-    launch_qbuild(c, c->V.p + (size_t)(f_end - 1) * c->D);  // leave q_train as the reference would (FMTrainer.hpp:373)
+    c->q_stale_factor = f_end - 1;  // q_train as the reference leaves it (FMTrainer.hpp:373): rebuilt when asked for
     MFM_HIP_CHECK(hipGetLastError());
     return MFM_OK;
   }
