@@ -27,6 +27,7 @@
 #include <string>
 #include <vector>
 
+#include "mfm_mtjump.hpp"
 #include "myfm_hip.h"
 
 namespace py = pybind11;
@@ -1351,4 +1352,25 @@ PYBIND11_MODULE(_myfm, m) {
       .def_readonly("iteration", &GibbsSession::it);
   m.def("device_count", []() { return mfm_device_count(); });
   m.def("backend_version", []() { return std::string(mfm_version()); });
+  // host-only self-test of the jump-ahead polynomials the parallel generator uses (csrc/mfm_mtjump.hpp) against
+  // std::mt19937 itself: tempering is linear, so the relation x_{m+J} = XOR_{g_i = 1} x_{m+i} holds for the
+  // engine's outputs too. Returns the number of mismatching outputs among 624 (0 = correct).
+  m.def("mt_jump_selftest", [](int blocks_per_wg, int p, unsigned seed) {
+    std::vector<uint32_t> tab;
+    if (!mfm::mtjump::build_jump_table(blocks_per_wg, p, tab)) return -1;
+    const uint64_t J = (uint64_t)((int64_t)p * blocks_per_wg - 1) * 624u;
+    std::mt19937 gen(seed);
+    std::vector<uint32_t> x((size_t)J + 19937 + 2 * 624);
+    for (auto &v : x) v = (uint32_t)gen();
+    const uint32_t *g = tab.data() + (size_t)p * mfm::mtjump::JUMP_WORDS32;
+    const size_t m0 = 624;  // past the seeded block
+    int bad = 0;
+    for (int l = 0; l < 624; l++) {
+      uint32_t yv = 0;
+      for (int i = 0; i < 19937; i++)
+        if ((g[i >> 5] >> (i & 31)) & 1u) yv ^= x[m0 + l + i];
+      bad += yv != x[m0 + l + J];
+    }
+    return bad;
+  });
 }

@@ -186,3 +186,12 @@ def test_level_schedule_matches_definition(built, seed):
     assert n == 2 and (level[:40] == 0).all() and (level[40:] == 1).all()
     Xt, _ = ds.toy()
     assert list(_capi.column_levels(Xt)[0]) == [0, 1, 1, 1, 1, 2, 2, 2, 2]
+
+
+def test_mt19937_jump_ahead_polynomials():
+    """csrc/mfm_mtjump.hpp (Berlekamp-Massey characteristic polynomial, x^J mod phi) against std::mt19937 itself:
+    the parallel device generator starts its workgroups from these polynomials"""
+    from myfm_amd import _myfm
+
+    assert _myfm.mt_jump_selftest(64, 3, 12345) == 0
+    assert _myfm.mt_jump_selftest(512, 2, 7) == 0
