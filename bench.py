@@ -218,7 +218,7 @@ def main():
         }
 
     cpu = None
-    if a.cpu_iters > 0:
+    if a.cpu_iters > 0 and world == 1:  # (rank 0, N = 1 only)
         from oracle import oracle as O
 
         O.build()
