@@ -863,15 +863,9 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       throw Error(MFM_ERR_RUNTIME, "mfm_sweep_V(z = NULL) needs an acquired device random set with K*D z_V variates");
     zbase = c->rng.slot[c->rng.current].zv.p + (size_t)f_begin * c->D;
   }
-  // the q-cache of factor f + 1 can be produced by factor f's last apply pass (k_scat_apply_nextq)
-  // (measured slower than the separate q-build on config 3: the row-blocked order makes the CSR row reads
-  // random; opt-in)
-  const bool fuse_q = !c->comm.active() && c->blocks.empty() && plan_can_fuse_next_q(c->plan_V) &&
-                      std::getenv("MFM_FUSED_QBUILD_NEXT") != nullptr;
   // the first level rebuilds q from the CSR rows itself when it touches every row exactly once
   const bool first_q = !c->comm.active() && c->blocks.empty() && plan_first_level_builds_q(c->plan_V) &&
                        !std::getenv("MFM_NO_FUSED_QBUILD");
-  bool q_ready = false;
   if (c->qfree) {
     // compact e for the duration of the factor loop; q is never materialised inside it
     hipLaunchKernelGGL(k_e_pack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
@@ -955,17 +949,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     const double *lamf = c->lam.p + (size_t)f * c->G;
     const double *muf = c->mu.p + (size_t)f * c->G;
     for (auto &B : c->blocks) block_rowcache(s, c->timing, *B, Vf + B->col_off, true);  // :331-333, :388-393
-    if (!q_ready && !first_q) launch_qbuild(c, Vf);                                     // :320, :334-337
-    NextQArgs nq;
-    const bool fuse_now = fuse_q && f + 1 < f_end;
-    if (fuse_now) {
-      nq.rowptr = c->X.rowptr.p;
-      nq.colidx = c->X.colidx.p;
-      nq.val = c->X.rval.p;
-      nq.v_next = c->V.p + (size_t)(f + 1) * c->D;
-      nq.ell = (int)c->X.ell_width;
-    }
-    q_ready = fuse_now;
+    if (!first_q) launch_qbuild(c, Vf);                                                 // :320, :334-337
     SweepArgs a = main_args(c, Vf, zf, lamf, muf, alpha);
     if (first_q) {
       a.r_rowptr = c->X.rowptr.p;
@@ -978,7 +962,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     if (c->comm.active())
       run_plan_sharded<PMainV>(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit, c->comm);
     else
-      run_plan<PMainV>(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit, fuse_now ? &nq : nullptr, first_q);  // :343-376
+      run_plan<PMainV>(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit, first_q);  // :343-376
     for (auto &B : c->blocks)
       block_sweep_V(s, c->timing, c->ls, *B, c->N, c->eq.p, Vf, zf, c->group.p, lamf, muf, alpha, c->comm);  // :378-482
   }

@@ -731,41 +731,6 @@ __global__ __launch_bounds__(WG) void k_scat_draw(SweepArgs a, const int32_t *__
   }
 }
 
-// q-cache build of the NEXT factor fused into the apply pass of the last level: when that level touches
-// every row exactly once (a one-hot field), the pass that writes back (e, q_f) can instead write
-// (e, q_{f+1}) with q_{f+1}[t] = sum_j x_tj V[j, f+1] (FMTrainer.hpp:320) -- V[:, f+1] cannot change before
-// its own sweep. This removes the separate q-build pass (its CSR stream and a partial-line store of q).
-struct NextQArgs {
-  const int32_t *rowptr;
-  const int32_t *colidx;
-  const double *val;
-  const double *v_next;  // V[:, f + 1]
-  int ell;               // >= 0: every row has exactly `ell` entries
-};
-template <bool UNIT>
-__global__ __launch_bounds__(WG) void k_scat_apply_nextq(SweepArgs a, const int2 *__restrict__ ent,
-                                                         const double *__restrict__ eval, int64_t n_ent,
-                                                         const double2 *__restrict__ oldnew, int n_wg, int swz, NextQArgs nq) {
-  const int64_t e = (int64_t)xcd_swizzle(blockIdx.x, n_wg, swz) * WG + threadIdx.x;
-  if (e >= n_ent) return;
-  const int2 rc = ent[e];
-  const double2 on = oldnew[rc.y];
-  const double x = UNIT ? 1.0 : eval[e];
-  int64_t b, en;
-  if (nq.ell >= 0) {
-    b = (int64_t)rc.x * nq.ell;
-    en = b + nq.ell;
-  } else {
-    b = nq.rowptr[rc.x];
-    en = nq.rowptr[rc.x + 1];
-  }
-  double qn = 0.0;
-  for (int64_t p = b; p < en; p++) qn += (UNIT ? 1.0 : nq.val[p]) * nq.v_next[nq.colidx[p]];
-  double2 st = PMainV::updated(x, PMainV::load(a, rc.x), on.x, on.y);
-  st.y = qn;
-  ((double2 *)a.state)[rc.x] = st;
-}
-
 template <class P, bool UNIT>
 __global__ __launch_bounds__(WG) void k_scat_apply(SweepArgs a, const int2 *__restrict__ ent, const double *__restrict__ eval,
                                                    int64_t n_ent, const double2 *__restrict__ oldnew, int n_wg, int swz) {

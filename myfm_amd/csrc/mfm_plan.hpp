@@ -608,13 +608,6 @@ struct SweepClasses {
   int light, heavy, coop, hstats, hdraw, happly, chain, scat;
 };
 
-// can the q-build of the next factor ride on the last step of this plan? (k_scat_apply_nextq)
-static inline bool plan_can_fuse_next_q(const StepPlan &plan) {
-  if (plan.steps.empty()) return false;
-  const Step &last = plan.steps.back();
-  return !last.is_chain && last.par.scattered && !last.par.tiled && last.par.covers_rows_once;
-}
-
 // the first (non-scattered, non-chain) level can rebuild the q-cache itself (PMainVq)
 static inline bool plan_first_level_builds_q(const StepPlan &plan) {
   if (plan.steps.empty()) return false;
@@ -670,7 +663,7 @@ static inline bool plan_is_single_pass_par(const StepPlan &plan) {
 // PA: policy of the apply pass of scattered levels (differs from P only for the q-free policy)
 template <class P, bool UNIT, class PA = P>
 static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls,
-                       const SweepClasses &kc, const NextQArgs *nextq = nullptr, bool first_builds_q = false) {
+                       const SweepClasses &kc, bool first_builds_q = false) {
   for (const Step &st : plan.steps) {
     if (st.is_chain) {
       TimedLaunch t(tm, s, kc.chain, P::BYTES * st.chain.nnz);
@@ -720,11 +713,7 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
                          L.slots.p, n_wg_s, swz);
       hipLaunchKernelGGL((k_scat_draw<P>), dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.slot_ptr.p,
                          L.slot_idx.p, L.slots.p, ls.oldnew_col.p);
-      if (nextq && &st == &plan.steps.back())
-        hipLaunchKernelGGL((k_scat_apply_nextq<UNIT>), dim3(n_wg_s), dim3(WG), 0, s, a, L.ent.p, L.ent_val.p, L.n_ent,
-                           ls.oldnew_col.p, n_wg_s, swz, *nextq);
-      else
-        hipLaunchKernelGGL((k_scat_apply<PA, UNIT>), dim3(n_wg_s), dim3(WG), 0, s, a, L.ent.p, L.ent_val.p, L.n_ent,
+      hipLaunchKernelGGL((k_scat_apply<PA, UNIT>), dim3(n_wg_s), dim3(WG), 0, s, a, L.ent.p, L.ent_val.p, L.n_ent,
                            ls.oldnew_col.p, n_wg_s, swz);
       continue;
     }
@@ -753,7 +742,7 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
 
 template <class P>
 static void run_plan(hipStream_t s, Timing &tm, const StepPlan &plan, const SweepArgs &a, LongScratch &ls,
-                     const SweepClasses &kc, bool unit, const NextQArgs *nextq = nullptr, bool first_builds_q = false) {
+                     const SweepClasses &kc, bool unit, bool first_builds_q = false) {
   static bool lds_attr_set = false;
   if (!lds_attr_set) {  // dynamic LDS above 64 KiB must be opted into
     MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_lds<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -761,9 +750,9 @@ static void run_plan(hipStream_t s, Timing &tm, const StepPlan &plan, const Swee
     lds_attr_set = true;
   }
   if (unit)
-    run_plan_t<P, true>(s, tm, plan, a, ls, kc, nextq, first_builds_q);
+    run_plan_t<P, true>(s, tm, plan, a, ls, kc, first_builds_q);
   else
-    run_plan_t<P, false>(s, tm, plan, a, ls, kc, nextq, first_builds_q);
+    run_plan_t<P, false>(s, tm, plan, a, ls, kc, first_builds_q);
 }
 
 // In-place sum over the ranks of `count` doubles in device memory, enqueued in order on the ctx stream.

@@ -226,6 +226,31 @@ def test_split_layout_latent_sweep(oracle, capi, monkeypatch, n_fields, fused):
         np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-7, atol=1e-7)
 
 
+def test_split_layout_factor_subranges(oracle, capi, monkeypatch):
+    # mfm_sweep_V over [0, 2), [2, 3), [3, 5): every call starts with an unfused first level, ends with an unfused
+    # apply pass and picks its variates / hyper columns by absolute factor index
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    n, K = 60001, 5
+    X, y, shapes = ds.onehot_mf(n, 300, 90, seed=31, sort_by_user=True)
+    gi = ds.group_index_from_shapes(shapes)
+    t, c, _ = _pair(oracle, capi, X, y, gi, K)
+    assert c.plan_flags()["fused_next"]
+    G, D = t.G, t.D
+    rng = np.random.default_rng(8)
+    lam = rng.uniform(0.5, 2.0, size=(G, K))
+    mu = rng.normal(size=(G, K)) * 0.1
+    h = t.hyper()
+    t.set_hyper(0.9, h["mu_w"], h["lambda_w"], mu, lam)
+    for f0, f1 in ((0, 2), (2, 3), (3, 5)):
+        z = t.clone().rng_sample_normals(D * (f1 - f0)).reshape(f1 - f0, D)
+        for f in range(f0, f1):
+            t.update_V_factor(f)
+        c.sweep_V(f0, f1, 0.9, lam, mu, z)
+        np.testing.assert_allclose(c.get_state()[2][:, f0:f1], t.fm()[2][:, f0:f1], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(c.get_q(), t.q(n), rtol=1e-8, atol=1e-9)
+
+
 @pytest.mark.parametrize("qfree", [True, False])
 def test_sorted_onehot_binned_and_coop_levels(oracle, capi, monkeypatch, qfree):
     # user-sorted one-hot table: level 1 goes through the binned single-pass kernels (wave / workgroup /
