@@ -1035,6 +1035,10 @@ struct FuseArgs {
   int stats;
   const int32_t *run_base, *slot_pos;
   double2 *slots;
+  // tiles inside a first-level column longer than a tile (complete on this rank): owner column per tile (-1: none)
+  // and the tile's partial statistics of that column for factor f + 1 (k_long_tile_draw, k_tile_long_finish)
+  const int32_t *solo_col;
+  double2 *long_partial;
 };
 
 // TWO: the plan has exactly these two levels and the last one covers every row once (a two-field one-hot
@@ -1137,6 +1141,44 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
       if (tid + k * nt < nr) lds_rec[tid + k * nt].y = qn[k];
     __syncthreads();
   }
+  // A tile inside a first-level column longer than a tile: the column's statistics for factor f + 1 are summed
+  // over its tiles (this tile's part goes to long_partial), the draw follows in k_long_tile_draw and the column's
+  // apply pass + the last level's statistics in k_tile_long_finish. The tile leaves with e and the FULL new q.
+  const int solo_j = fa.solo_col ? fa.solo_col[b] : -1;
+  if (solo_j >= 0) {  // (workgroup-uniform)
+    const double old = fa.theta_next[solo_j];
+    const int64_t vbase = a.colptr[solo_j] + (row0 - a.row0[solo_j]);
+    double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < TILE_K; k++) {
+      const int i = tid + k * nt;
+      if (i < nr) {
+        double2 st = lds_rec[i];
+        const double xv = UNIT ? 1.0 : a.val[vbase + i];
+        if (TWO) st.y += xv * old;
+        PMainV::stats(xv, st, old, S1, S2);
+        __builtin_nontemporal_store(st.x, &E[row0 + i]);
+        __builtin_nontemporal_store(st.y, &Q[row0 + i]);
+      }
+    }
+    S1 = wave_allreduce_sum(S1);
+    S2 = wave_allreduce_sum(S2);
+    double *scr = (double *)(lds_rec + ((size_t)1 << tile_bits));
+    if (lane == 0) {
+      scr[2 * wv] = S1;
+      scr[2 * wv + 1] = S2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double T1 = 0.0, T2 = 0.0;
+      for (int w = 0; w < nw; w++) {  // wave order: deterministic
+        T1 += scr[2 * w];
+        T2 += scr[2 * w + 1];
+      }
+      fa.long_partial[b] = make_double2(T1, T2);
+    }
+    return;
+  }
   // first level of factor f + 1: one wavefront per column, lane m of a batch prefetches column m's scalars
   const int c0 = fa.fuse_col_ptr[b], c1 = fa.fuse_col_ptr[b + 1];
   for (int cb = c0 + wv; cb < c1; cb += nw * WAVE) {
@@ -1199,6 +1241,81 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
     for (int k = 0; k < TILE_K; k++) rb[k] = t0 + k * nw < t1 ? fa.run_base[t0 + k * nw] : 0;
     tile_entry_stats<PMainV>(lds_rec, u, x, vn, rb, t0, t1, nw, lane, tile_bits, fa.slot_pos, fa.slots);
   }
+}
+
+// long first-level columns of the fused flow: sum the tiles' partial statistics (tile order), draw
+template <class P>
+__global__ void k_long_tile_draw(SweepArgs an, const int32_t *__restrict__ long_cols, const int32_t *__restrict__ long_tile_ptr,
+                                 const int32_t *__restrict__ long_tiles, int n_long, const double2 *__restrict__ partial,
+                                 double2 *__restrict__ oldnew_long) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n_long) return;
+  double S1 = 0.0, S2 = 0.0;
+  for (int t = long_tile_ptr[l]; t < long_tile_ptr[l + 1]; t++) {
+    const double2 p = partial[long_tiles[t]];
+    S1 += p.x;
+    S2 += p.y;
+  }
+  const int j = long_cols[l];
+  const double old = an.theta[j];
+  const int g = an.group[j];
+  const double fresh = P::draw(S1, S2, old, an.alpha, an.lambda[g], an.mu[g], an.z[j]);
+  an.theta[j] = fresh;
+  oldnew_long[l] = make_double2(old, fresh);
+}
+
+// ... and their second pass over the column's tiles: the column's apply (FMTrainer.hpp:371-375) on the tile in LDS,
+// then the last level's statistics of the same factor on the tile's entries (two-level plans), write-back.
+template <bool UNIT>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_tile_long_finish(
+    SweepArgs an, const uint32_t *__restrict__ tent, const double *__restrict__ tval, const int32_t *__restrict__ tile_ptr,
+    const int32_t *__restrict__ tile_row0, int tile_bits, const int32_t *__restrict__ long_tiles,
+    const int32_t *__restrict__ tile_long_idx, const double2 *__restrict__ oldnew_long, const int32_t *__restrict__ long_cols,
+    const double *__restrict__ vnext_col, int stats, const int32_t *__restrict__ run_base, const int32_t *__restrict__ slot_pos,
+    double2 *__restrict__ slots) {
+  extern __shared__ double2 lds_rec[];
+  const int b = long_tiles[blockIdx.x];
+  const int64_t row0 = tile_row0[b];
+  const int nr = tile_row0[b + 1] - (int)row0;
+  const int nt = blockDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+  double *E = (double *)an.state, *Q = an.state2;
+  const int l = tile_long_idx[b];
+  const int j = long_cols[l];
+  const d2_t on = ((const d2_t *)oldnew_long)[l];
+  const int64_t vbase = an.colptr[j] + (row0 - an.row0[j]);
+  const int t0 = tile_ptr[b] + wv, t1 = tile_ptr[b + 1];
+  uint32_t u[TILE_K];
+  int rb[TILE_K];
+  double x[TILE_K], vn[TILE_K];
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    const int t = t0 + k * nw;
+    u[k] = TILE_PAD;
+    x[k] = 1.0;
+    rb[k] = 0;
+    if (stats && t < t1) {
+      rb[k] = run_base[t];
+      u[k] = __builtin_nontemporal_load(&tent[(int64_t)t * WAVE + lane]);
+      if (!UNIT) x[k] = __builtin_nontemporal_load(&tval[(int64_t)t * WAVE + lane]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) vn[k] = u[k] != TILE_PAD ? vnext_col[u[k] >> tile_bits] : 0.0;
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    const int i = tid + k * nt;
+    if (i < nr) {
+      const double xv = UNIT ? 1.0 : an.val[vbase + i];
+      const double2 st = make_double2(__builtin_nontemporal_load(&E[row0 + i]), __builtin_nontemporal_load(&Q[row0 + i]));
+      const double2 nw2 = PMainV::updated(xv, st, on[0], on[1]);
+      lds_rec[i] = nw2;
+      __builtin_nontemporal_store(nw2.x, &E[row0 + i]);
+      __builtin_nontemporal_store(nw2.y, &Q[row0 + i]);
+    }
+  }
+  if (!stats) return;
+  __syncthreads();
+  tile_entry_stats<PMainV>(lds_rec, u, x, vn, rb, t0, t1, nw, lane, tile_bits, slot_pos, slots);
 }
 
 // ---- row-sharded (multi-GPU) mode: statistics -> all-reduce -> draw -> apply -------------------------------

@@ -90,8 +90,12 @@ struct StepPlan {
   // first level of the NEXT factor on the tile while it is in LDS (k_tile_apply_next).
   std::vector<int32_t> h_tile_start;
   DevBuf<int32_t> fuse_cols, fuse_col_ptr;  // first-level columns inside each tile, in row order
-  DevBuf<int32_t> solo_tiles;               // tiles inside a first-level column longer than a tile
-  int n_solo_tiles = 0;
+  DevBuf<int32_t> solo_tiles;               // tiles of special first-level columns (row-sharded mode): swept by
+  int n_solo_tiles = 0;                     // run_level_sharded, statistics by k_tile_stats on this list
+  // first-level columns longer than a tile (complete on this rank): two passes over their tiles
+  DevBuf<int32_t> long_cols, long_tile_ptr, long_tiles, solo_col, tile_long_idx;
+  DevBuf<double2> long_partial, oldnew_long;
+  int n_long_cols = 0, n_long_tiles = 0;
   bool aligned_tiles = false;
 
   // a level is "tiny" when running it as its own launches cannot fill the device anyway
@@ -360,7 +364,7 @@ struct StepPlan {
     // empty columns sort first: they join the first tile as zero-length columns (drawn from the prior there)
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return first_row(x) < first_row(y); });
     (void)nnz_all;
-    std::vector<int32_t> fcols, fptr;
+    std::vector<int32_t> fcols, fptr, lcols, lptr, ltiles, solo;
     h_tile_start.clear();
     int64_t cur_rows = 0, next_row = 0;
     auto open_tile = [&](int64_t row) {
@@ -385,7 +389,19 @@ struct StepPlan {
         return;
       }
       if (len > RB || is_special) {
-        for (int64_t r = r0; r < r0 + len; r += RB) open_tile(r);
+        if (!is_special) {
+          lcols.push_back(j);
+          lptr.push_back((int32_t)ltiles.size());
+        }
+        for (int64_t r = r0; r < r0 + len; r += RB) {
+          const int32_t tile_id = (int32_t)h_tile_start.size();
+          open_tile(r);
+          if (is_special) {
+            solo.push_back(tile_id);
+          } else {
+            ltiles.push_back(tile_id);
+          }
+        }
         cur_rows = RB;  // closed
       } else {
         if (h_tile_start.empty() || cur_rows + len > RB) open_tile(r0);
@@ -396,6 +412,7 @@ struct StepPlan {
     }
     h_tile_start.push_back((int32_t)next_row);
     fptr.push_back((int32_t)fcols.size());
+    lptr.push_back((int32_t)ltiles.size());
     if (next_row != csc.cols) {
       h_tile_start.clear();
       return;
@@ -403,11 +420,24 @@ struct StepPlan {
     fuse_cols.upload(fcols);
     fuse_col_ptr.upload(fptr);
     {
-      std::vector<int32_t> solo;
-      for (size_t b = 0; b + 1 < fptr.size(); b++)
-        if (fptr[b + 1] == fptr[b]) solo.push_back((int32_t)b);
+      const size_t nt = h_tile_start.size() - 1;
+      std::vector<int32_t> sc(nt, -1), tl(nt, -1);
+      for (size_t l = 0; l < lcols.size(); l++)
+        for (int32_t t = lptr[l]; t < lptr[l + 1]; t++) {
+          sc[ltiles[t]] = lcols[l];
+          tl[ltiles[t]] = (int32_t)l;
+        }
       n_solo_tiles = (int)solo.size();
       solo_tiles.upload(solo);
+      n_long_cols = (int)lcols.size();
+      n_long_tiles = (int)ltiles.size();
+      long_cols.upload(lcols);
+      long_tile_ptr.upload(lptr);
+      long_tiles.upload(ltiles);
+      solo_col.upload(sc);
+      tile_long_idx.upload(tl);
+      long_partial.alloc(std::max<size_t>(nt, 1));
+      oldnew_long.alloc(std::max<size_t>(lcols.size(), 1));
     }
     aligned_tiles = true;
   }
@@ -882,12 +912,38 @@ static void launch_tile_head(hipStream_t s, const ParLevel &L, const SweepArgs &
                      L.slots.p, ls.oldnew_col.p, theta_next, ls.vnext_col.p);
 }
 
+// the fused pass keeps 256 bytes of reduction scratch behind its tile: above the default dynamic-LDS limit
+template <bool UNIT>
+static void raise_fused_lds_limit() {
+  static bool raised = false;
+  if (raised) return;
+  const int lim = (int)CHAIN_LDS_MAX;
+  MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply_next<UNIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+  MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply_next<UNIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+  raised = true;
+}
+
+// fused flow, first-level columns longer than a tile: k_tile_apply_next left their tiles' partial statistics
+template <bool UNIT>
+static void launch_long_finish(hipStream_t s, Timing &tm, const StepPlan &plan, const ParLevel &L, const SweepArgs &an,
+                               LongScratch &ls, const SweepClasses &kc, int stats, size_t lds, int nt) {
+  if (!plan.n_long_cols) return;
+  TimedLaunch t(tm, s, kc.coop, 52.0 * plan.n_long_tiles * (double)(1 << L.tile_bits));
+  hipLaunchKernelGGL((k_long_tile_draw<PMainV>), dim3((plan.n_long_cols + 63) / 64), dim3(64), 0, s, an, plan.long_cols.p,
+                     plan.long_tile_ptr.p, plan.long_tiles.p, plan.n_long_cols, plan.long_partial.p, plan.oldnew_long.p);
+  hipLaunchKernelGGL((k_tile_long_finish<UNIT>), dim3(plan.n_long_tiles), dim3(nt), lds, s, an, L.tent.p, L.ent_val.p,
+                     L.tile_ptr.p, L.tile_row0.p, L.tile_bits, plan.long_tiles.p, plan.tile_long_idx.p, plan.oldnew_long.p,
+                     plan.long_cols.p, ls.vnext_col.p, stats, L.run_base.p, L.slot_pos.p, L.slots.p);
+  (void)ls;
+}
+
 // Latent sweep of factors [f_begin, f_end) in the split layout: args(f).state = e[N], .state2 = q[N].
 // fuse: the last level's apply pass also runs the next factor's first level (short columns) on the tile.
 template <bool UNIT, class ArgsOf>
 static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf args, int f_begin, int f_end,
                           LongScratch &ls, const SweepClasses &kc, bool fuse) {
   const int swz = xcd_swizzle_enabled();
+  if (fuse) raise_fused_lds_limit<UNIT>();
   // two-level plan: the fused pass also produces the next factor's last-level statistics
   const int fuse_stats = fuse && plan.steps.size() == 2 && !std::getenv("MFM_NO_FUSED_STATS") ? 1 : 0;
   {
@@ -928,17 +984,17 @@ static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsO
                                      : 44.0 * plan.n_state_rows + 16.0 * L.n_ent);
             SweepArgs af = a;
             af.row0 = plan.col_row0.p;
-            FuseArgs fa{an.theta,  an.z,          an.lambda,    an.mu,        plan.fuse_cols.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
-                        fuse_stats, L.run_base.p, L.slot_pos.p, L.slots.p};
+            FuseArgs fa{an.theta,   an.z,         an.lambda,    an.mu,     plan.fuse_cols.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
+                        fuse_stats, L.run_base.p, L.slot_pos.p, L.slots.p, plan.solo_col.p,  plan.long_partial.p};
             if (two)
-              hipLaunchKernelGGL((k_tile_apply_next<UNIT, true>), dim3(L.n_tiles), dim3(nt), lds, s, af, L.tent.p, L.ent_val.p,
-                                 L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
+              hipLaunchKernelGGL((k_tile_apply_next<UNIT, true>), dim3(L.n_tiles), dim3(nt), lds + 256, s, af, L.tent.p,
+                                 L.ent_val.p, L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
             else
-              hipLaunchKernelGGL((k_tile_apply_next<UNIT, false>), dim3(L.n_tiles), dim3(nt), lds, s, af, L.tent.p,
+              hipLaunchKernelGGL((k_tile_apply_next<UNIT, false>), dim3(L.n_tiles), dim3(nt), lds + 256, s, af, L.tent.p,
                                  L.ent_val.p, L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
           }
-          // first-level columns longer than a tile, then (fuse_stats) the statistics of their tiles
-          launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, plan.steps.front().par, an, ls, kc, plan.col_row0.p, 1);
+          // first-level columns longer than a tile: draw from their tiles' partial statistics, second pass
+          launch_long_finish<UNIT>(s, tm, plan, L, an, ls, kc, fuse_stats, lds, nt);
           if (fuse_stats && plan.n_solo_tiles) {
             TimedLaunch t(tm, s, kc.scat, 20.0 * plan.n_solo_tiles * (1 << L.tile_bits));
             hipLaunchKernelGGL((k_tile_stats<PMainV, UNIT, true>), dim3(plan.n_solo_tiles), dim3(nt), lds, s, an, L.tent.p,
@@ -1039,6 +1095,7 @@ static void run_sweep_soa_sharded(hipStream_t s, Timing &tm, const StepPlan &pla
   const size_t lds = sizeof(double2) << L.tile_bits;
   const int nt = tile_threads(L.tile_bits);
   const bool two = L.covers_rows_once && !std::getenv("MFM_NO_FUSED_TWO");
+  raise_fused_lds_limit<UNIT>();
   {
     // first factor's first level: the locally complete columns in one pass, the special ones all-reduced
     const SweepArgs a = args(f_begin);
@@ -1079,20 +1136,19 @@ static void run_sweep_soa_sharded(hipStream_t s, Timing &tm, const StepPlan &pla
       TimedLaunch t(tm, s, KC_SWEEP_V_FUSED, 56.0 * nnz_f + 8.0 * plan.n_state_rows + 8.0 * (L1.n_all + L.n_cols));
       SweepArgs af = a;
       af.row0 = plan.col_row0.p;
-      FuseArgs fa{an.theta,  an.z,          an.lambda,    an.mu,        plan.fuse_cols.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
-                  1,         L.run_base.p,  L.slot_pos.p, L.slots.p};
+      FuseArgs fa{an.theta, an.z,         an.lambda,    an.mu,     plan.fuse_cols.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
+                  1,        L.run_base.p, L.slot_pos.p, L.slots.p, plan.solo_col.p,  plan.long_partial.p};
       if (two)
-        hipLaunchKernelGGL((k_tile_apply_next<UNIT, true>), dim3(L.n_tiles), dim3(nt), lds, s, af, L.tent.p, L.ent_val.p,
+        hipLaunchKernelGGL((k_tile_apply_next<UNIT, true>), dim3(L.n_tiles), dim3(nt), lds + 256, s, af, L.tent.p, L.ent_val.p,
                            L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
       else
-        hipLaunchKernelGGL((k_tile_apply_next<UNIT, false>), dim3(L.n_tiles), dim3(nt), lds, s, af, L.tent.p, L.ent_val.p,
-                           L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
+        hipLaunchKernelGGL((k_tile_apply_next<UNIT, false>), dim3(L.n_tiles), dim3(nt), lds + 256, s, af, L.tent.p,
+                           L.ent_val.p, L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
     }
     MFM_HIP_CHECK(hipGetLastError());
-    // first-level columns of factor f + 1 longer than a tile (complete here: co-resident single pass), then the
-    // special ones (rows on several ranks / empty everywhere: all-reduced statistics)
-    launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, plan.local_level, an, ls, kc, plan.col_row0.p, 1);
-    launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, plan.local_level, an, ls, kc);
+    // first-level columns of factor f + 1 longer than a tile (complete here: second pass over their tiles), then
+    // the special ones (rows on several ranks: all-reduced statistics)
+    launch_long_finish<UNIT>(s, tm, plan, L, an, ls, kc, 1, lds, nt);
     if (plan.n_special)
       run_level_sharded<PMainVsq<UNIT>, PMainVsqA<UNIT>, UNIT>(s, tm, plan.special_level, an, ls, kc, comm,
                                                                plan.special_cols.p, plan.n_special);
