@@ -364,7 +364,7 @@ struct StepPlan {
     // empty columns sort first: they join the first tile as zero-length columns (drawn from the prior there)
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return first_row(x) < first_row(y); });
     (void)nnz_all;
-    std::vector<int32_t> fcols, fptr, lcols, lptr, ltiles, solo;
+    std::vector<int32_t> fcols, fptr, lcols, lptr, ltiles, solo, empties;
     h_tile_start.clear();
     int64_t cur_rows = 0, next_row = 0;
     auto open_tile = [&](int64_t row) {
@@ -377,10 +377,8 @@ struct StepPlan {
       const bool is_special = !special.empty() && special[j] == 1;
       if (len == 0) {
         // special: swept through special_level on every rank; sharded and not empty everywhere: its rows live on
-        // another rank
-        if (is_special || (sharded_tiles && special[j] != 2)) continue;
-        if (h_tile_start.empty()) open_tile(0);
-        fcols.push_back(j);
+        // another rank; otherwise it is drawn from the prior by whichever tile it is handed to below
+        if (!(is_special || (sharded_tiles && special[j] != 2))) empties.push_back(j);
         continue;
       }
       const int64_t r0 = csc.idx[csc.ptr[j]];
@@ -416,6 +414,29 @@ struct StepPlan {
     if (next_row != csc.cols) {
       h_tile_start.clear();
       return;
+    }
+    if (!empties.empty()) {
+      // columns without entries (features that never occur): spread evenly over the tiles that run first-level
+      // columns (a tile without any stays a tile of a long / special column)
+      const size_t nt = h_tile_start.size() - 1;
+      std::vector<size_t> hosts;
+      for (size_t b = 0; b < nt; b++)
+        if (fptr[b + 1] > fptr[b]) hosts.push_back(b);
+      if (hosts.empty()) {  // (only long / special columns: no fused pass to ride on)
+        h_tile_start.clear();
+        return;
+      }
+      std::vector<std::vector<int32_t>> extra(nt);
+      for (size_t k = 0; k < empties.size(); k++) extra[hosts[k % hosts.size()]].push_back(empties[k]);
+      std::vector<int32_t> f2, p2;
+      for (size_t b = 0; b < nt; b++) {
+        p2.push_back((int32_t)f2.size());
+        f2.insert(f2.end(), fcols.begin() + fptr[b], fcols.begin() + fptr[b + 1]);
+        f2.insert(f2.end(), extra[b].begin(), extra[b].end());
+      }
+      p2.push_back((int32_t)f2.size());
+      fcols.swap(f2);
+      fptr.swap(p2);
     }
     fuse_cols.upload(fcols);
     fuse_col_ptr.upload(fptr);
