@@ -196,6 +196,14 @@ class MyFMGibbsBase:
 
         config_builder.set_n_iter(n_iter).set_n_kept_samples(n_kept_samples)
         y = self._process_y(y)
+        # The sampler does not depend on the order of the training rows (every conditional is a sum over rows), the
+        # device path does: a table sorted by its first one-hot field runs the fused tile pass. Rows that
+        # arrive in another order are sorted by the first stored column here, together with y and the relation maps.
+        perm = _device_row_order(X)
+        if perm is not None:
+            X = X[perm]
+            y = np.asarray(y)[perm]
+            X_rel = [RelationBlock([int(v) for v in np.asarray(r.original_to_block)[perm]], r.data) for r in X_rel]
         config_builder.set_task_type(self._task_type)
         config = config_builder.build()
 
@@ -336,6 +344,23 @@ class MyFMGibbsClassifier(MyFMGibbsBase):
 
     def predict(self, X, X_rel=[], n_workers: Optional[int] = None):
         return self.predict_proba(X, X_rel, n_workers=n_workers) > 0.5
+
+
+def _device_row_order(X):
+    """stable order of the rows by their first stored column, or None when they already are (or it does not apply)"""
+    import os
+
+    if os.environ.get("MYFM_AMD_KEEP_ROW_ORDER") or X.shape[0] < 2 or X.shape[1] == 0:
+        return None
+    lens = np.diff(X.indptr)
+    if lens.min() < 1:
+        return None
+    if not X.has_sorted_indices:
+        X.sort_indices()
+    first = X.indices[X.indptr[:-1]]
+    if np.all(first[1:] >= first[:-1]):
+        return None
+    return np.argsort(first, kind="stable")
 
 
 class MyFMOrderedProbit(MyFMGibbsBase):

@@ -101,6 +101,26 @@ def test_regression_matches_oracle_sample_by_sample(myfm, oracle):
     assert np.sqrt(np.mean((pred - want) ** 2)) < 1e-6
 
 
+def test_rows_in_any_order(myfm, monkeypatch):
+    # fit() sorts the rows by their first stored column for the device (the sampler is invariant to the row order);
+    # a shuffled table, with a relation block riding along, gives the chain of the sorted one
+    X, y, shapes = ds.onehot_mf(20000, 300, 60, seed=12, sort_by_user=True)
+    rng = np.random.default_rng(0)
+    side = sps.csr_matrix(rng.normal(size=(60, 2)))
+    item = X.indices[1::2] - 300
+    p = rng.permutation(X.shape[0])
+    gs = shapes + [2]
+    kw = dict(group_shapes=gs, n_iter=6, n_kept_samples=6)
+    a = myfm.MyFMRegressor(4, random_seed=3).fit(X, y, [myfm.RelationBlock([int(v) for v in item], side)], **kw)
+    b = myfm.MyFMRegressor(4, random_seed=3).fit(X[p], y[p], [myfm.RelationBlock([int(v) for v in item[p]], side)], **kw)
+    monkeypatch.setenv("MYFM_AMD_KEEP_ROW_ORDER", "1")
+    c = myfm.MyFMRegressor(4, random_seed=3).fit(X[p], y[p], [myfm.RelationBlock([int(v) for v in item[p]], side)], **kw)
+    for sa, sb, sc in zip(a.predictor_.samples, b.predictor_.samples, c.predictor_.samples):
+        np.testing.assert_allclose(sb.V, sa.V, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(sc.V, sa.V, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(sb.w, sa.w, rtol=1e-7, atol=1e-9)
+
+
 def test_block(myfm):
     # tests/regression/test_block.py:80-149
     main, X_flat, blocks, y, group_shapes = ds.block_design()
