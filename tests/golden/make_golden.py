@@ -93,6 +93,10 @@ def main():
     X = X.copy()
     X.data = np.where(np.arange(X.nnz) % 3 == 0, 0.5, 1.5)
     chain("chain_onehot_values", X, y, ds.group_index_from_shapes(shapes), 3)
+    X, y = ds.toy()  # README.md:46-59 (BASELINE configs[0])
+    chain("chain_toy", X, y, np.zeros(X.shape[1], dtype=np.int32), 4, iters=(1, 2, 10))
+    X, y = ds.middle_data()[:2]
+    chain("chain_middle", X, y, np.zeros(X.shape[1], dtype=np.int32), 3, iters=(1, 10, 30))
     main_X, _, blocks, y, shapes = ds.block_design()
     chain("chain_blocks", main_X, y, ds.group_index_from_shapes(shapes), 2, blocks=blocks, fit_w0=False)
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))
