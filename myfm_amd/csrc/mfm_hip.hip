@@ -504,6 +504,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
       c->plan_V.sharded_tiles = true;
       c->plan_V.special = std::move(special);
     }
+    c->plan_V.group_of = &c->hgroup;
     c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_v, true, c->X.unit);
     if (try_fused) {
       // every rank must take the same path: agree
@@ -518,6 +519,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
         c->plan_V.sharded = true;
         c->plan_V.given_levels = c->hlevels;
         c->plan_V.tile_bits = tile_bits;
+        c->plan_V.group_of = &c->hgroup;
         c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_v, true, c->X.unit);
       } else {
         c->sharded_fused = true;

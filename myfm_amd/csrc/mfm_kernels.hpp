@@ -1028,7 +1028,7 @@ struct FuseArgs {
   const double *z_next;
   const double *lam_next;   // [G]
   const double *mu_next;
-  const int32_t *fuse_cols;     // first-level columns inside the tiles, row order
+  const int4 *fuse_desc;        // first-level columns inside the tiles, row order: {column, length, row offset, group}
   const int32_t *fuse_col_ptr;  // [n_tiles + 1]
   const double *vnext_col;      // V[col, f + 1] per column of the last level (k_tile_draw)
   // stats != 0 (two-level plans): the pass also computes the last level's statistics of factor f + 1
@@ -1187,15 +1187,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
     int64_t pbeg = 0;
     double pold = 0.0, pz = 0.0, plam = 0.0, pmu = 0.0;
     if (cm < c1) {
-      pj = fa.fuse_cols[cm];
-      pbeg = a.colptr[pj];
-      plen = (int)(a.colptr[pj + 1] - pbeg);
-      plr0 = a.row0[pj] - (int)row0;
+      const int4 d = fa.fuse_desc[cm];  // one coalesced load, then four independent gathers
+      pj = d.x;
+      plen = d.y;
+      plr0 = d.z;
       pold = fa.theta_next[pj];
       pz = fa.z_next[pj];
-      const int g = a.group[pj];
-      plam = fa.lam_next[g];
-      pmu = fa.mu_next[g];
+      plam = fa.lam_next[d.w];
+      pmu = fa.mu_next[d.w];
+      if (!UNIT) pbeg = a.colptr[pj];
     }
     const int nb_cols = min(WAVE, (c1 - cb + nw - 1) / nw);
     for (int m = 0; m < nb_cols; m++) {

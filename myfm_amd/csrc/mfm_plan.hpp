@@ -90,6 +90,8 @@ struct StepPlan {
   // first level of the NEXT factor on the tile while it is in LDS (k_tile_apply_next).
   std::vector<int32_t> h_tile_start;
   DevBuf<int32_t> fuse_cols, fuse_col_ptr;  // first-level columns inside each tile, in row order
+  DevBuf<int4> fuse_desc;                   // per entry of fuse_cols: {column, length, first row - tile start, group}
+  const std::vector<int32_t> *group_of = nullptr;  // (set by the owner before build: group index per column)
   DevBuf<int32_t> solo_tiles;               // tiles of special first-level columns (row-sharded mode): swept by
   int n_solo_tiles = 0;                     // run_level_sharded, statistics by k_tile_stats on this list
   // first-level columns longer than a tile (complete on this rank): two passes over their tiles
@@ -440,6 +442,17 @@ struct StepPlan {
     }
     fuse_cols.upload(fcols);
     fuse_col_ptr.upload(fptr);
+    {
+      std::vector<int4> desc(fcols.size());
+      for (size_t b = 0; b + 1 < fptr.size(); b++)
+        for (int32_t k = fptr[b]; k < fptr[b + 1]; k++) {
+          const int32_t j = fcols[k];
+          const int64_t len = csc.ptr[j + 1] - csc.ptr[j];
+          desc[k] = make_int4(j, (int)len, len ? (int)(csc.idx[csc.ptr[j]] - h_tile_start[b]) : 0,
+                              group_of && (size_t)j < group_of->size() ? (*group_of)[j] : 0);
+        }
+      fuse_desc.upload(desc.data(), desc.size());
+    }
     {
       const size_t nt = h_tile_start.size() - 1;
       std::vector<int32_t> sc(nt, -1), tl(nt, -1);
@@ -1005,7 +1018,7 @@ static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsO
                                      : 44.0 * plan.n_state_rows + 16.0 * L.n_ent);
             SweepArgs af = a;
             af.row0 = plan.col_row0.p;
-            FuseArgs fa{an.theta,   an.z,         an.lambda,    an.mu,     plan.fuse_cols.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
+            FuseArgs fa{an.theta,   an.z,         an.lambda,    an.mu,     plan.fuse_desc.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
                         fuse_stats, L.run_base.p, L.slot_pos.p, L.slots.p, plan.solo_col.p,  plan.long_partial.p};
             if (two)
               hipLaunchKernelGGL((k_tile_apply_next<UNIT, true>), dim3(L.n_tiles), dim3(nt), lds + 256, s, af, L.tent.p,
@@ -1157,7 +1170,7 @@ static void run_sweep_soa_sharded(hipStream_t s, Timing &tm, const StepPlan &pla
       TimedLaunch t(tm, s, KC_SWEEP_V_FUSED, 56.0 * nnz_f + 8.0 * plan.n_state_rows + 8.0 * (L1.n_all + L.n_cols));
       SweepArgs af = a;
       af.row0 = plan.col_row0.p;
-      FuseArgs fa{an.theta, an.z,         an.lambda,    an.mu,     plan.fuse_cols.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
+      FuseArgs fa{an.theta, an.z,         an.lambda,    an.mu,     plan.fuse_desc.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
                   1,        L.run_base.p, L.slot_pos.p, L.slots.p, plan.solo_col.p,  plan.long_partial.p};
       if (two)
         hipLaunchKernelGGL((k_tile_apply_next<UNIT, true>), dim3(L.n_tiles), dim3(nt), lds + 256, s, af, L.tent.p, L.ent_val.p,
