@@ -1080,6 +1080,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
       if (!UNIT) x[k] = __builtin_nontemporal_load(&tval[p]);
     }
   }
+  // first run of each of this wave's wave tiles (wave-uniform: scalar loads, issued here so that the statistics
+  // phase starts with its slot-position gathers)
+  const int ts0 = __builtin_amdgcn_readfirstlane(tile_ptr[b] + wv), ts1 = tile_ptr[b + 1];
+  int rb[TILE_K];
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) rb[k] = fa.stats && ts0 + k * nw < ts1 ? fa.run_base[ts0 + k * nw] : 0;
   // next factor's coefficient of each entry's column (TWO: its term of the next q; stats: the "old" value)
   double vn[TILE_K];
 #pragma unroll
@@ -1234,13 +1240,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
   // The tile now holds the state the last level of factor f + 1 starts from (two-level plan): its statistics
   // from LDS, same entries. Tiles of a first-level column longer than a tile (no columns of their own here)
   // are finished by k_long_coop and get their statistics from k_tile_stats afterwards.
-  if (fa.stats && c1 > c0) {
-    const int t0 = tile_ptr[b] + wv, t1 = tile_ptr[b + 1];
-    int rb[TILE_K];
-#pragma unroll
-    for (int k = 0; k < TILE_K; k++) rb[k] = t0 + k * nw < t1 ? fa.run_base[t0 + k * nw] : 0;
-    tile_entry_stats<PMainV>(lds_rec, u, x, vn, rb, t0, t1, nw, lane, tile_bits, fa.slot_pos, fa.slots);
-  }
+  if (fa.stats && c1 > c0) tile_entry_stats<PMainV>(lds_rec, u, x, vn, rb, ts0, ts1, nw, lane, tile_bits, fa.slot_pos, fa.slots);
 }
 
 // long first-level columns of the fused flow: sum the tiles' partial statistics (tile order), draw
