@@ -182,6 +182,7 @@ def main():
         dom = max(timing.items(), key=lambda kv: kv[1][0])
         name, (ms, launches, alg_bytes) = dom
         achieved = alg_bytes / (ms * 1e-3) / 1e9
+        unfused_bytes = 56.0 * nnz + 8.0 * N + 8.0 * D  # SURVEY 8d, one factor of update_V
         # HBM bytes per launch of that class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE of this same command, corrected as MI355X_MICROARCH.md prescribes; profiles/*_pmc_traffic.*)
         traffic = None
@@ -203,9 +204,16 @@ def main():
             "traffic_source": pmc[-1] if traffic else None,
             "traffic_gbs": round(traffic / (ms / launches * 1e-3) / 1e9, 1) if traffic else None,
             "traffic_frac": round(traffic / (ms / launches * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-            "note": "achieved = SURVEY 8d algorithmic bytes of the UNFUSED algorithm for the work of one launch "
-                    "((56 nnz + 8 N + 8 D) per factor: q-build + both passes of both levels) / event time; the fused pass "
-                    "moves fewer bytes than that (traffic, PMC) -- traffic_gbs is the real HBM rate of the kernel",
+            "unfused_equivalent_gbs": round(unfused_bytes / (ms / launches * 1e-3) / 1e9, 1) if name == "sweep_V_fused_next" else None,
+            "note": "achieved = algorithmic bytes of the FUSED pass (e, q read + written once, 4-byte entries, one 16-byte "
+                    "slot per run) / event time; traffic = PMC-measured HBM bytes of the same launch (above the algorithmic "
+                    "figure: the scattered 16-byte slot stores cost whole lines); unfused_equivalent_gbs = SURVEY 8d bytes of "
+                    "the unfused algorithm for the same work ((56 nnz + 8 N + 8 D) per factor) / time: what the fusion saves",
+            # SURVEY 8d's figure for the "q-cache / e-update sweep": (56 nnz + 8 N + 8 D) K / t_updateV, t_updateV = all
+            # update_V kernel classes of one step (diagnostic steps); can exceed what any unfused implementation could
+            # reach because the fused pass moves fewer bytes than that formula assumes
+            "updateV_survey_gbs": round(unfused_bytes * K / (sum(v[0] for k2, v in breakdown.items() if k2.startswith("sweep_V")) * 1e-3) / 1e9, 1)
+            if breakdown else None,
             "avg_launch_us": round(ms / launches * 1e3, 2),
             "launches": int(launches),
             "alg_bytes_per_launch": round(alg_bytes / launches),

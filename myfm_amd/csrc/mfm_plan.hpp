@@ -1010,12 +1010,10 @@ static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsO
             launch_tile_head<PMainV, UNIT>(s, L, a, ls, swz, an.theta, fuse_stats && f > f_begin);
           }
           {
-            // SURVEY 8d per-factor figure for what this launch does (one factor's q-build + both passes of the
-            // first level + the apply pass of this factor's last level and the statistics pass of the next one's)
-            const double nnz_f = (double)plan.steps.front().par.nnz_total() + (double)L.n_ent;
+            // algorithmic bytes of the FUSED pass: e, q read + written once (32 B / row), the 4-byte entry stream
+            // (+ 8-byte values when the table is not unit-valued), one 16-byte statistics slot per run
             TimedLaunch t(tm, s, KC_SWEEP_V_FUSED,
-                          fuse_stats ? 56.0 * nnz_f + 8.0 * plan.n_state_rows + 8.0 * (plan.steps.front().par.n_all + L.n_cols)
-                                     : 44.0 * plan.n_state_rows + 16.0 * L.n_ent);
+                          32.0 * plan.n_state_rows + (UNIT ? 4.0 : 12.0) * L.n_ent + (fuse_stats ? 16.0 * L.n_runs : 0.0));
             SweepArgs af = a;
             af.row0 = plan.col_row0.p;
             FuseArgs fa{an.theta,   an.z,         an.lambda,    an.mu,     plan.fuse_desc.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
@@ -1166,8 +1164,7 @@ static void run_sweep_soa_sharded(hipStream_t s, Timing &tm, const StepPlan &pla
     }
     an.row0 = plan.col_row0.p;
     {
-      const double nnz_f = (double)L1.nnz_total() + (double)L.n_ent;
-      TimedLaunch t(tm, s, KC_SWEEP_V_FUSED, 56.0 * nnz_f + 8.0 * plan.n_state_rows + 8.0 * (L1.n_all + L.n_cols));
+      TimedLaunch t(tm, s, KC_SWEEP_V_FUSED, 32.0 * plan.n_state_rows + (UNIT ? 4.0 : 12.0) * L.n_ent + 16.0 * L.n_runs);
       SweepArgs af = a;
       af.row0 = plan.col_row0.p;
       FuseArgs fa{an.theta, an.z,         an.lambda,    an.mu,     plan.fuse_desc.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
