@@ -356,11 +356,13 @@ struct PMainW {
   static __device__ __forceinline__ double2 to_rec(double2 r, St e) { return make_double2(e, r.y); }
 };
 
+typedef double d2_t __attribute__((ext_vector_type(2)));  // register-resident 16-byte record: native vector type
+                                                          // (arrays of HIP's double2 struct end up in scratch)
 struct BlockRec {
-  double2 qq;  // q, q_S
-  double2 cc;  // c, c_S
-  double2 ee;  // e, e_q
-  double2 kk;  // cardinality, unused
+  d2_t qq;  // q, q_S
+  d2_t cc;  // c, c_S
+  d2_t ee;  // e, e_q
+  d2_t kk;  // cardinality, unused
 };
 
 // latent factors, relation block: FMTrainer.hpp:419-470
@@ -370,7 +372,7 @@ struct PBlockV {
   static constexpr double BYTES = 12.0 + 64.0 + 48.0, STAT_BYTES = 12.0 + 64.0;
   typedef BlockRec St;
   static __device__ __forceinline__ St load(const SweepArgs &a, int row) {
-    const double2 *r = (const double2 *)a.state + (int64_t)row * a.rec2;
+    const d2_t *r = (const d2_t *)a.state + (int64_t)row * a.rec2;
     St s;
     s.qq = r[0];
     s.cc = r[1];
@@ -396,7 +398,7 @@ struct PBlockV {
     s.qq.y += delta * (fresh + old) * x * x;                  // :458-459
     s.ee.x += x * delta * (h_B * s.kk.x + s.cc.x);            // :461-464
     s.ee.y += x * delta * (h_B * s.cc.x + s.cc.y);            // :465-468
-    double2 *r = (double2 *)a.state + (int64_t)row * a.rec2;
+    d2_t *r = (d2_t *)a.state + (int64_t)row * a.rec2;
     r[0] = s.qq;
     r[2] = s.ee;
   }
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(WG) void k_scat_apply(SweepArgs a, const int2 *__re
 //   k_tile_apply : tile -> LDS; updates in LDS (rows of one level are disjoint); LDS -> tile
 constexpr uint32_t TILE_PAD = 0xffffffffu;
 constexpr int TILE_K = 8;  // rows (and at most entries: a level has <= 1 entry per row) per thread of a tile
-typedef double d2_t __attribute__((ext_vector_type(2)));  // register-resident 16-byte record (native vector)
+
 
 // before the statistics pass: the current coefficient per column of the level as a compact array, so that the
 // entry loop needs one gather (in the fused flow k_tile_draw of the previous factor fills it instead)
@@ -1667,6 +1669,177 @@ __global__ __launch_bounds__(WAVE) void k_chain_lds(SweepArgs a, const ChainDesc
     }
   }
   for (int64_t i = lane; i < n16; i += WAVE) gst[i] = lst[(i / w16) * l16 + (i % w16)];
+}
+
+// ---- sequential chains, conflict-batched ------------------------------------------------------------------
+// A chain walks columns that pairwise share rows, one after the other; over state in global memory every column
+// costs the full dependent round trip gather -> reduce -> draw -> scatter -> visible (~1.9 us). Consecutive
+// columns of a multi-hot table share only FEW rows, though. For a batch of B consecutive columns call a row HOT
+// if more than one column of the batch touches it, COLD otherwise. A cold row's state is read and written by
+// exactly one column of the batch, so, exactly as in the sequential order,
+//   A  (all threads) every column's statistics over its COLD entries are taken from the state at batch start,
+//   B  (one wavefront) the columns are walked in order over their HOT entries only, on the hot rows' records
+//      staged in LDS: S = S_cold + S_hot -> draw -> update of the hot records -- a ~0.25 us step,
+//   C  (all threads) the cold entries are updated with their column's (old, new); the hot records go back.
+// The draws are those of the sequential sweep (only the order of the floating-point sums differs).
+struct ChainBatch {
+  int32_t col0, ncols;      // columns [col0, col0 + ncols) of the run
+  int32_t hot_row0, n_hot;  // hot rows: hot_rows[hot_row0 ..)
+};
+constexpr int CHAINB_NT = 512;
+constexpr int CHAINB_MAXCOLS = 64;
+
+template <class P>
+__global__ __launch_bounds__(CHAINB_NT) void k_chain_batched(SweepArgs a, const ChainBatch *__restrict__ batches, int n_batches,
+                                                             const int32_t *__restrict__ cols,
+                                                             const int32_t *__restrict__ cold_ptr,
+                                                             const int32_t *__restrict__ cold_row,
+                                                             const int32_t *__restrict__ cold_lcol,
+                                                             const double *__restrict__ cold_x,
+                                                             const int32_t *__restrict__ hot_ptr,
+                                                             const int32_t *__restrict__ hot_slot,
+                                                             const double *__restrict__ hot_x,
+                                                             const int32_t *__restrict__ hot_rows, int max_hot,
+                                                             int max_hot_ent) {
+  extern __shared__ double2 lds_hot[];  // [max_hot * rec2_lds] records, then the per-batch arrays
+  constexpr int NT = CHAINB_NT, NW = NT / WAVE, MC = CHAINB_MAXCOLS;
+  constexpr int U = 4;  // wave tiles of cold entries in flight per wave
+  constexpr int rec2_g = P::REC_DOUBLES / 2;                          // 16-byte words of a record in global memory
+  constexpr int rec2_l = P::REC_DOUBLES > 2 ? rec2_g + 1 : rec2_g;    // ... in LDS (bank spread for 64-byte records)
+  double *c_old = (double *)(lds_hot + (size_t)max_hot * rec2_l);
+  double *c_z = c_old + MC, *c_lam = c_z + MC, *c_mu = c_lam + MC, *c_new = c_mu + MC;
+  double2 *part = (double2 *)(c_new + MC);       // [MC][NW]
+  double *h_x = (double *)(part + MC * NW);      // [max_hot_ent] the batch's hot entries: value ...
+  int *h_slot = (int *)(h_x + max_hot_ent);      // ... and slot
+  int *h_ptr = h_slot + max_hot_ent;             // [MC + 1] per column, relative to the batch
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  SweepArgs al = a;  // the hot records in LDS, addressed by slot
+  al.state = lds_hot;
+  al.rec2 = rec2_l;
+  const int rec2_global = P::REC_DOUBLES > 2 ? a.rec2 : 1;
+  ChainBatch B_next = batches[0];
+  for (int bi = 0; bi < n_batches; bi++) {
+    const ChainBatch B = B_next;
+    if (bi + 1 < n_batches) B_next = batches[bi + 1];  // (in flight during this batch)
+    // ---- stage the hot records, the hot entries and the columns' scalars ----------------------------------------
+    for (int i = tid; i < B.n_hot * rec2_g; i += NT) {
+      const int slot = i / rec2_g, w = i - slot * rec2_g;
+      lds_hot[(size_t)slot * rec2_l + w] = ((const double2 *)a.state)[(int64_t)hot_rows[B.hot_row0 + slot] * rec2_global + w];
+    }
+    const int hb0 = hot_ptr[B.col0], hb1 = hot_ptr[B.col0 + B.ncols];
+    for (int i = tid; i < hb1 - hb0; i += NT) {
+      h_x[i] = hot_x[hb0 + i];
+      h_slot[i] = hot_slot[hb0 + i];
+    }
+    if (tid <= B.ncols) h_ptr[tid] = hot_ptr[B.col0 + tid] - hb0;
+    if (tid < B.ncols) {
+      const int j = cols[B.col0 + tid];
+      c_old[tid] = a.theta[j];
+      c_z[tid] = a.z[j];
+      const int g = a.group[j];
+      c_lam[tid] = a.lambda[g];
+      c_mu[tid] = a.mu[g];
+    }
+    for (int i = tid; i < MC * NW; i += NT) part[i] = make_double2(0.0, 0.0);
+    __syncthreads();
+    // ---- A: statistics of the cold entries: wave tiles of 64 consecutive entries (sorted by column), U in flight ----
+    const int cb = cold_ptr[B.col0], ce = cold_ptr[B.col0 + B.ncols];
+    for (int base = cb + wv * WAVE * U; base < ce; base += NW * WAVE * U) {
+      int lc[U], row[U];
+      double xv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int p = base + u * WAVE + lane;
+        lc[u] = -1 - lane;
+        row[u] = -1;
+        xv[u] = 0.0;
+        if (p < ce) {
+          lc[u] = cold_lcol[p];
+          row[u] = cold_row[p];
+          xv[u] = cold_x[p];
+        }
+      }
+      typename P::St st[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (row[u] >= 0) st[u] = P::load(a, row[u]);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (base + u * WAVE >= ce) break;  // wave-uniform
+        double s1 = 0.0, s2 = 0.0;
+        if (row[u] >= 0) P::stats(xv[u], st[u], c_old[lc[u]], s1, s2);
+        const int lp = dpp_i32<0x138, 0xf>(lc[u], 0), ln = dpp_i32<0x130, 0xf>(lc[u], 0);
+        const bool head = lane == 0 || lp != lc[u], tail = lane == 63 || ln != lc[u];
+        int f = head ? 1 : 0;
+        wave_segscan2(s1, s2, f);
+        if (row[u] >= 0 && tail) {  // one lane per column of this tile; a wave adds its tiles in program order
+          double2 &q = part[lc[u] * NW + wv];
+          q.x += s1;
+          q.y += s2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < B.ncols) {  // a column's cold statistics: its waves' partials in wave order
+      double S1 = 0.0, S2 = 0.0;
+      for (int w = 0; w < NW; w++) {
+        S1 += part[tid * NW + w].x;
+        S2 += part[tid * NW + w].y;
+      }
+      part[tid * NW] = make_double2(S1, S2);
+    }
+    __syncthreads();
+    // ---- B: the columns in order, hot entries only (one wavefront, LDS only) -----------------------------------------
+    if (wv == 0) {
+      for (int c = 0; c < B.ncols; c++) {
+        const double S1 = part[c * NW].x, S2 = part[c * NW].y;
+        const double old = c_old[c];
+        const int hb = h_ptr[c], he = h_ptr[c + 1];
+        double h1 = 0.0, h2 = 0.0;
+        for (int h = hb + lane; h < he; h += WAVE) P::stats(h_x[h], P::load(al, h_slot[h]), old, h1, h2);
+        h1 = wave_allreduce_sum(h1);
+        h2 = wave_allreduce_sum(h2);
+        const double fresh = P::draw(S1 + h1, S2 + h2, old, a.alpha, c_lam[c], c_mu[c], c_z[c]);
+        for (int h = hb + lane; h < he; h += WAVE) {
+          const int slot = h_slot[h];
+          P::apply(al, slot, h_x[h], P::load(al, slot), old, fresh);
+        }
+        if (lane == 0) c_new[c] = fresh;
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this column's LDS updates before the next column's loads
+      }
+    }
+    __syncthreads();
+    // ---- C: cold entries take their column's update; the hot records and the coefficients go back -------------------
+    for (int base = cb + tid; base < ce; base += NT * U) {
+      int lc[U], row[U];
+      double xv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int p = base + u * NT;
+        row[u] = -1;
+        lc[u] = 0;
+        xv[u] = 0.0;
+        if (p < ce) {
+          lc[u] = cold_lcol[p];
+          row[u] = cold_row[p];
+          xv[u] = cold_x[p];
+        }
+      }
+      typename P::St st[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (row[u] >= 0) st[u] = P::load(a, row[u]);
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (row[u] >= 0) P::apply(a, row[u], xv[u], st[u], c_old[lc[u]], c_new[lc[u]]);
+    }
+    for (int i = tid; i < B.n_hot * rec2_g; i += NT) {
+      const int slot = i / rec2_g, w = i - slot * rec2_g;
+      ((double2 *)a.state)[(int64_t)hot_rows[B.hot_row0 + slot] * rec2_global + w] = lds_hot[(size_t)slot * rec2_l + w];
+    }
+    if (tid < B.ncols) a.theta[cols[B.col0 + tid]] = c_new[tid];
+    __syncthreads();  // visible to the workgroup before the next batch's gathers
+  }
 }
 
 // ---- q-cache build: q = X v_f (+ block contributions)  (FMTrainer.hpp:320-340), CSR SpMV --------

@@ -68,6 +68,95 @@ struct ChainRun {
   DevBuf<int32_t> cols;
   int n_cols = 0;
   int64_t nnz = 0;
+  // conflict-batched form (k_chain_batched): per batch the rows touched by more than one of its columns ("hot")
+  // are staged in LDS; entries are split into cold (sorted by column) and hot (slot into the batch's hot rows)
+  bool batched = false;
+  int n_batches = 0, max_hot = 0, max_hot_ent = 0;
+  DevBuf<ChainBatch> batches;
+  DevBuf<int32_t> cold_ptr, cold_row, cold_lcol, hot_ptr, hot_slot, hot_rows;
+  DevBuf<double> cold_x, hot_x;
+
+  void build_batched(const HostCsr &csc, const std::vector<int32_t> &run, int hot_cap) {
+    const int64_t n_rows = csc.cols;
+    std::vector<int32_t> cnt((size_t)n_rows, 0), slot_of((size_t)n_rows, -1);
+    std::vector<ChainBatch> bt;
+    std::vector<int32_t> cptr{0}, crow, clcol, hptr{0}, hslot, hrows;
+    std::vector<double> cx, hx;
+    size_t c = 0;
+    while (c < run.size()) {
+      // grow the batch while the number of hot rows stays within the LDS budget
+      size_t e = c;
+      int n_hot = 0, n_hot_ent = 0;
+      std::vector<int32_t> touched;
+      while (e < run.size() && (int)(e - c) < CHAINB_MAXCOLS) {
+        const int32_t j = run[e];
+        int add = 0, add_ent = 0;
+        for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) {
+          const int k = cnt[csc.idx[p]];
+          add += k == 1;
+          add_ent += k == 1 ? 2 : (k > 1 ? 1 : 0);
+        }
+        if (e > c && (n_hot + add > hot_cap || n_hot_ent + add_ent > (5 * hot_cap) / 2)) break;
+        for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) {
+          if (cnt[csc.idx[p]]++ == 0) touched.push_back(csc.idx[p]);
+        }
+        n_hot += add;
+        n_hot_ent += add_ent;
+        e++;
+      }
+      ChainBatch B;
+      B.col0 = (int32_t)c;
+      B.ncols = (int32_t)(e - c);
+      B.hot_row0 = (int32_t)hrows.size();
+      int ns = 0;
+      for (size_t k = c; k < e; k++) {  // hot slots in order of first appearance
+        const int32_t j = run[k];
+        for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) {
+          const int32_t r = csc.idx[p];
+          if (cnt[r] > 1 && slot_of[r] < 0) {
+            slot_of[r] = ns++;
+            hrows.push_back(r);
+          }
+        }
+      }
+      B.n_hot = ns;
+      for (size_t k = c; k < e; k++) {
+        const int32_t j = run[k];
+        for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) {
+          const int32_t r = csc.idx[p];
+          if (cnt[r] > 1) {
+            hslot.push_back(slot_of[r]);
+            hx.push_back(csc.val[p]);
+          } else {
+            crow.push_back(r);
+            clcol.push_back((int32_t)(k - c));
+            cx.push_back(csc.val[p]);
+          }
+        }
+        cptr.push_back((int32_t)crow.size());
+        hptr.push_back((int32_t)hslot.size());
+      }
+      for (int32_t r : touched) {
+        cnt[r] = 0;
+        slot_of[r] = -1;
+      }
+      max_hot = std::max(max_hot, ns);
+      max_hot_ent = std::max(max_hot_ent, hptr.back() - hptr[hptr.size() - 1 - (e - c)]);
+      bt.push_back(B);
+      c = e;
+    }
+    n_batches = (int)bt.size();
+    batches.upload(bt.data(), bt.size());
+    cold_ptr.upload(cptr);
+    cold_row.upload(crow);
+    cold_lcol.upload(clcol);
+    cold_x.upload(cx);
+    hot_ptr.upload(hptr);
+    hot_slot.upload(hslot);
+    hot_x.upload(hx);
+    hot_rows.upload(hrows);
+    batched = true;
+  }
 };
 
 struct Step {
@@ -549,6 +638,9 @@ struct StepPlan {
         for (int32_t j : run) d.push_back(ChainDesc{csc.ptr[j], (int32_t)(csc.ptr[j + 1] - csc.ptr[j]), j});
         s.chain.desc.upload(d.data(), d.size());
       }
+      // state too large for the LDS chain of any policy: also keep the conflict-batched form
+      if ((csc.cols > 1900 || std::getenv("MFM_CHAIN_FORCE_BATCHED")) && run.size() >= 2 && !std::getenv("MFM_NO_CHAIN_BATCHED"))
+        s.chain.build_batched(csc, run, 1200);
       launches += 1;
       run.clear();
       run_nnz = 0;
@@ -732,9 +824,26 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
     if (st.is_chain) {
       TimedLaunch t(tm, s, kc.chain, P::BYTES * st.chain.nnz);
       const size_t lds_bytes = (size_t)plan.n_state_rows * (P::REC_DOUBLES > 2 ? P::REC_DOUBLES + 2 : P::REC_DOUBLES) * sizeof(double);
-      if (plan.n_state_rows > 0 && lds_bytes <= CHAIN_LDS_MAX) {
+      const bool force_batched = st.chain.batched && std::getenv("MFM_CHAIN_FORCE_BATCHED");
+      if (plan.n_state_rows > 0 && lds_bytes <= CHAIN_LDS_MAX && !force_batched) {
         hipLaunchKernelGGL((k_chain_lds<P>), dim3(1), dim3(WAVE), lds_bytes, s, a, st.chain.desc.p, st.chain.n_cols,
                            plan.n_state_rows, (int)P::REC_DOUBLES);
+      } else if (st.chain.batched) {
+        const ChainRun &C = st.chain;
+        constexpr int rec2_l = P::REC_DOUBLES > 2 ? P::REC_DOUBLES / 2 + 1 : P::REC_DOUBLES / 2;
+        const int mhe = std::max(C.max_hot_ent, 1);
+        const size_t lds_b = (size_t)std::max(C.max_hot, 1) * rec2_l * sizeof(double2) + 5 * CHAINB_MAXCOLS * sizeof(double) +
+                             (size_t)CHAINB_MAXCOLS * (CHAINB_NT / WAVE) * sizeof(double2) + (size_t)mhe * 12 +
+                             (CHAINB_MAXCOLS + 2) * sizeof(int);
+        static bool raised = false;
+        if (!raised) {
+          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_batched<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)CHAIN_LDS_MAX));
+          raised = true;
+        }
+        hipLaunchKernelGGL((k_chain_batched<P>), dim3(1), dim3(CHAINB_NT), lds_b, s, a, C.batches.p, C.n_batches, C.cols.p,
+                           C.cold_ptr.p, C.cold_row.p, C.cold_lcol.p, C.cold_x.p, C.hot_ptr.p, C.hot_slot.p, C.hot_x.p,
+                           C.hot_rows.p, std::max(C.max_hot, 1), mhe);
       } else {
         hipLaunchKernelGGL((k_chain<P>), dim3(1), dim3(CHAIN_WG), 0, s, a, st.chain.desc.p, st.chain.n_cols);
       }

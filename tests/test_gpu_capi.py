@@ -311,6 +311,28 @@ def test_blocks_match_oracle_and_flat(oracle, capi, design):
     np.testing.assert_allclose(cb.get_e(), tb.e(main.shape[0]), rtol=1e-7, atol=1e-7)
 
 
+@pytest.mark.parametrize("design", ["onehot", "multihot", "dense_main"])
+def test_conflict_batched_chain(oracle, capi, monkeypatch, design):
+    # chains over state too large for LDS run conflict-batched (k_chain_batched: cold entries in parallel, hot rows
+    # staged in LDS and walked in order); forced here on small designs: relation-block sweeps (64-byte records, w and
+    # V) and a main table with dense columns (16-byte records)
+    monkeypatch.setenv("MFM_CHAIN_FORCE_BATCHED", "1")
+    if design == "dense_main":
+        X, y = ds.middle_data()
+        gi, blocks, rank, kw = np.zeros(X.shape[1], dtype=np.int32), (), 3, {}
+    else:
+        main, X_flat, blocks, y, shapes = ds.block_design() if design == "onehot" else ds.multihot_block_design()
+        X, gi, rank, kw = main, ds.group_index_from_shapes(shapes), 3, dict(fit_w0=False)
+    t, c, _ = _pair(oracle, capi, X, y, gi, rank, blocks, **kw)
+    drv = CapiGibbs(c, t.clone(), X.shape[0], gi, **kw)
+    for it in range(5):
+        t.step()
+        drv.step()
+        np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(c.get_state()[1], t.fm()[1], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(c.get_e(), t.e(X.shape[0]), rtol=1e-7, atol=1e-7)
+
+
 def test_block_only_design_no_main_columns(oracle, capi):
     # X=None => (N, 0) main table (base.py:230-233)
     main, X_flat, blocks, y, shapes = ds.multihot_block_design()
