@@ -1041,13 +1041,18 @@ struct FuseArgs {
   // and the tile's partial statistics of that column for factor f + 1 (k_long_tile_draw, k_tile_long_finish)
   const int32_t *solo_col;
   double2 *long_partial;
+  // SPLIT (plans with more than two levels): the statistics are those of ANOTHER tile level (the second level of
+  // the next factor) than the one applied (this factor's last level): its entry stream
+  const uint32_t *tentS;
+  const double *tvalS;
+  const int32_t *tile_ptrS;
 };
 
 // TWO: the plan has exactly these two levels and the last one covers every row once (a two-field one-hot
 // table): q of the next factor is x_last * V[last col, f + 1] (gathered per ENTRY from the compact vnext_col,
 // entries are sorted by column) + x_first * V[first col, f + 1] (uniform per first-level column) -- no CSR
 // read and no per-row gather; with two terms the sum is the same in either order.
-template <bool UNIT, bool TWO>
+template <bool UNIT, bool TWO, bool SPLIT = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_tile_apply_next(
     SweepArgs a, const uint32_t *__restrict__ tent, const double *__restrict__ tval, const int32_t *__restrict__ tile_ptr,
     const int32_t *__restrict__ tile_row0, const double2 *__restrict__ oldnew, int tile_bits, int n_tiles, int swz,
@@ -1087,11 +1092,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
   const int ts0 = __builtin_amdgcn_readfirstlane(tile_ptr[b] + wv), ts1 = tile_ptr[b + 1];
   int rb[TILE_K];
 #pragma unroll
-  for (int k = 0; k < TILE_K; k++) rb[k] = fa.stats && ts0 + k * nw < ts1 ? fa.run_base[ts0 + k * nw] : 0;
+  for (int k = 0; k < TILE_K; k++) rb[k] = !SPLIT && fa.stats && ts0 + k * nw < ts1 ? fa.run_base[ts0 + k * nw] : 0;
   // next factor's coefficient of each entry's column (TWO: its term of the next q; stats: the "old" value)
   double vn[TILE_K];
 #pragma unroll
-  for (int k = 0; k < TILE_K; k++) vn[k] = (TWO || fa.stats) && u[k] != TILE_PAD ? fa.vnext_col[u[k] >> tile_bits] : 0.0;
+  for (int k = 0; k < TILE_K; k++)
+    vn[k] = (TWO || (fa.stats && !SPLIT)) && u[k] != TILE_PAD ? fa.vnext_col[u[k] >> tile_bits] : 0.0;
   // q of the next factor for this thread's rows (TWO: the last level's term, per entry)
   double qn[TILE_K];
 #pragma unroll
@@ -1242,7 +1248,114 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
   // The tile now holds the state the last level of factor f + 1 starts from (two-level plan): its statistics
   // from LDS, same entries. Tiles of a first-level column longer than a tile (no columns of their own here)
   // are finished by k_long_coop and get their statistics from k_tile_stats afterwards.
-  if (fa.stats && c1 > c0) tile_entry_stats<PMainV>(lds_rec, u, x, vn, rb, ts0, ts1, nw, lane, tile_bits, fa.slot_pos, fa.slots);
+  if (fa.stats && c1 > c0) {
+    if (!SPLIT) {
+      tile_entry_stats<PMainV>(lds_rec, u, x, vn, rb, ts0, ts1, nw, lane, tile_bits, fa.slot_pos, fa.slots);
+    } else {  // the statistics level's own entries (loaded here: the registers of the applied level's are free again)
+      const int s0 = __builtin_amdgcn_readfirstlane(fa.tile_ptrS[b] + wv), s1 = fa.tile_ptrS[b + 1];
+      uint32_t u2[TILE_K];
+      int rb2[TILE_K];
+      double x2[TILE_K], v2[TILE_K];
+#pragma unroll
+      for (int k = 0; k < TILE_K; k++) {
+        const int t = s0 + k * nw;
+        u2[k] = TILE_PAD;
+        x2[k] = 1.0;
+        rb2[k] = 0;
+        if (t < s1) {
+          rb2[k] = fa.run_base[t];
+          u2[k] = __builtin_nontemporal_load(&fa.tentS[(int64_t)t * WAVE + lane]);
+          if (!UNIT) x2[k] = __builtin_nontemporal_load(&fa.tvalS[(int64_t)t * WAVE + lane]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < TILE_K; k++) v2[k] = u2[k] != TILE_PAD ? fa.vnext_col[u2[k] >> tile_bits] : 0.0;
+      tile_entry_stats<PMainV>(lds_rec, u2, x2, v2, rb2, s0, s1, nw, lane, tile_bits, fa.slot_pos, fa.slots);
+    }
+  }
+}
+
+// Plans with more than two levels, between two tile levels of one factor: ONE pass applies the level just drawn
+// (entries A, (old, new) per column) and takes the statistics of the next level (entries S, current coefficient per
+// column in told) on the tile in LDS.
+template <bool UNIT>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_tile_apply_stats(
+    SweepArgs a, const uint32_t *__restrict__ tentA, const double *__restrict__ tvalA, const int32_t *__restrict__ tile_ptrA,
+    const double2 *__restrict__ oldnewA, const uint32_t *__restrict__ tentS, const double *__restrict__ tvalS,
+    const int32_t *__restrict__ tile_ptrS, const double *__restrict__ told, const int32_t *__restrict__ run_base,
+    const int32_t *__restrict__ slot_pos, double2 *__restrict__ slots, const int32_t *__restrict__ tile_row0, int tile_bits,
+    int n_tiles, int swz) {
+  extern __shared__ double2 lds_rec[];
+  const int b = xcd_swizzle(blockIdx.x, n_tiles, swz);
+  const int64_t row0 = tile_row0[b];
+  const int nr = tile_row0[b + 1] - (int)row0;
+  const int nt = blockDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+  double *E = (double *)a.state, *Q = a.state2;
+  d2_t rec[TILE_K];
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    rec[k] = d2_t{0.0, 0.0};
+    if (tid + k * nt < nr)
+      rec[k] = d2_t{__builtin_nontemporal_load(&E[row0 + tid + k * nt]), __builtin_nontemporal_load(&Q[row0 + tid + k * nt])};
+  }
+  const int64_t p0 = (int64_t)tile_ptrA[b] * WAVE + tid, p1 = (int64_t)tile_ptrA[b + 1] * WAVE;
+  uint32_t u[TILE_K];
+  double x[TILE_K];
+  d2_t on[TILE_K];
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    const int64_t p = p0 + (int64_t)k * nt;
+    u[k] = TILE_PAD;
+    x[k] = 1.0;
+    if (p < p1) {
+      u[k] = __builtin_nontemporal_load(&tentA[p]);
+      if (!UNIT) x[k] = __builtin_nontemporal_load(&tvalA[p]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    on[k] = d2_t{0.0, 0.0};
+    if (u[k] != TILE_PAD) on[k] = ((const d2_t *)oldnewA)[u[k] >> tile_bits];
+  }
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++)
+    if (tid + k * nt < nr) ((d2_t *)lds_rec)[tid + k * nt] = rec[k];
+  __syncthreads();
+  const uint32_t rmask = (1u << tile_bits) - 1u;
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    if (u[k] == TILE_PAD) continue;
+    const uint32_t r = u[k] & rmask;
+    lds_rec[r] = PMainV::updated(x[k], lds_rec[r], on[k][0], on[k][1]);
+  }
+  // the next level's entries
+  const int s0 = __builtin_amdgcn_readfirstlane(tile_ptrS[b] + wv), s1 = tile_ptrS[b + 1];
+  uint32_t u2[TILE_K];
+  int rb2[TILE_K];
+  double x2[TILE_K], v2[TILE_K];
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) {
+    const int t = s0 + k * nw;
+    u2[k] = TILE_PAD;
+    x2[k] = 1.0;
+    rb2[k] = 0;
+    if (t < s1) {
+      rb2[k] = run_base[t];
+      u2[k] = __builtin_nontemporal_load(&tentS[(int64_t)t * WAVE + lane]);
+      if (!UNIT) x2[k] = __builtin_nontemporal_load(&tvalS[(int64_t)t * WAVE + lane]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++) v2[k] = u2[k] != TILE_PAD ? told[u2[k] >> tile_bits] : 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < TILE_K; k++)
+    if (tid + k * nt < nr) {
+      const d2_t r = ((const d2_t *)lds_rec)[tid + k * nt];
+      __builtin_nontemporal_store(r[0], &E[row0 + tid + k * nt]);
+      __builtin_nontemporal_store(r[1], &Q[row0 + tid + k * nt]);
+    }
+  tile_entry_stats<PMainV>(lds_rec, u2, x2, v2, rb2, s0, s1, nw, lane, tile_bits, slot_pos, slots);
 }
 
 // long first-level columns of the fused flow: sum the tiles' partial statistics (tile order), draw

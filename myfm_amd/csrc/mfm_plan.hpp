@@ -732,10 +732,12 @@ struct LongScratch {
   DevBuf<double2> S_col;       // sharded mode: per-column statistics (all-reduced over the ranks)
   DevBuf<double> vnext_col;    // fused apply pass: next factor's coefficient per column of the last level
   DevBuf<double2> S_compact;   // sharded fused path: statistics of the special first-level columns
+  DevBuf<double> told_col;     // multi-level fused flow: current coefficient per column of the level whose statistics are taken
   void reserve_cols(int64_t n_cols) {
     if ((size_t)n_cols > oldnew_col.n) {
       oldnew_col.alloc((size_t)n_cols);
       vnext_col.alloc((size_t)n_cols);
+      told_col.alloc((size_t)n_cols);
     }
   }
   void reserve_stats(int64_t n_cols) {
@@ -1080,11 +1082,97 @@ static void launch_long_finish(hipStream_t s, Timing &tm, const StepPlan &plan, 
   (void)ls;
 }
 
+// Split-layout sweep of a plan with MORE than two levels, all but the first on row tiles (several one-hot fields,
+// table sorted by the first): per factor L - 1 passes over the tiles instead of 3 (L - 1) + 1 --
+//   draw T1 | [apply T_l + statistics T_(l+1) | draw T_(l+1)] for l = 1 .. L-2 | apply T_(L-1) + q rebuild + the whole
+//   first level of the next factor + statistics T1 of the next factor (k_tile_apply_next<.., SPLIT>).
+static inline bool plan_supports_fused_multi(const StepPlan &plan) {
+  if (!plan_supports_fused_next(plan) || plan.steps.size() < 3) return false;
+  for (size_t i = 1; i < plan.steps.size(); i++)
+    if (plan.steps[i].is_chain || !plan.steps[i].par.scattered || !plan.steps[i].par.tiled) return false;
+  return true;
+}
+
+template <bool UNIT, class ArgsOf>
+static void run_sweep_soa_multi(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf args, int f_begin, int f_end,
+                                LongScratch &ls, const SweepClasses &kc) {
+  const int swz = xcd_swizzle_enabled();
+  raise_fused_lds_limit<UNIT>();
+  {
+    static bool raised = false;
+    if (!raised) {
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply_next<UNIT, false, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_MAX));
+      raised = true;
+    }
+  }
+  const int nl = (int)plan.steps.size();
+  const ParLevel &L1 = plan.steps.front().par, &T1 = plan.steps[1].par, &TL = plan.steps.back().par;
+  const size_t lds = sizeof(double2) << T1.tile_bits;
+  const int nt = tile_threads(T1.tile_bits);
+  auto draw = [&](const ParLevel &T, const SweepArgs &a, const double *theta_next) {
+    hipLaunchKernelGGL((k_tile_draw<PMainV>), dim3((T.n_cols + 3) / 4), dim3(WG), 0, s, a, T.scols.p, T.n_cols, T.slot_ptr.p,
+                       T.slots.p, ls.oldnew_col.p, theta_next, ls.vnext_col.p);
+  };
+  for (int f = f_begin; f < f_end; f++) {
+    const SweepArgs a = args(f);
+    const bool next = f + 1 < f_end;
+    SweepArgs an = next ? args(f + 1) : a;
+    an.row0 = plan.col_row0.p;
+    if (f == f_begin) {
+      launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, L1, a, ls, kc, plan.col_row0.p);
+      launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, L1, a, ls, kc);
+      TimedLaunch t(tm, s, kc.scat, 20.0 * T1.n_ent);
+      hipLaunchKernelGGL(k_tile_old, dim3((T1.n_cols + 255) / 256), dim3(256), 0, s, a.theta, T1.scols.p, T1.n_cols,
+                         ls.vnext_col.p);
+      hipLaunchKernelGGL((k_tile_stats<PMainV, UNIT, true>), dim3(T1.n_tiles), dim3(nt), lds, s, a, T1.tent.p, T1.ent_val.p,
+                         T1.tile_ptr.p, T1.tile_row0.p, ls.vnext_col.p, T1.run_base.p, T1.slot_pos.p, T1.slots.p, T1.tile_bits,
+                         T1.n_tiles, swz, (const int32_t *)nullptr);
+    }
+    {
+      TimedLaunch t(tm, s, kc.scat, 16.0 * T1.n_runs);
+      draw(T1, a, next ? (const double *)an.theta : (const double *)nullptr);
+    }
+    for (int l = 1; l + 1 < nl; l++) {
+      const ParLevel &A = plan.steps[l].par, &S = plan.steps[l + 1].par;
+      TimedLaunch t(tm, s, kc.scat, 32.0 * plan.n_state_rows + (UNIT ? 4.0 : 12.0) * (A.n_ent + S.n_ent) + 32.0 * S.n_runs);
+      hipLaunchKernelGGL(k_tile_old, dim3((S.n_cols + 255) / 256), dim3(256), 0, s, a.theta, S.scols.p, S.n_cols, ls.told_col.p);
+      hipLaunchKernelGGL((k_tile_apply_stats<UNIT>), dim3(A.n_tiles), dim3(nt), lds, s, a, A.tent.p, A.ent_val.p, A.tile_ptr.p,
+                         ls.oldnew_col.p, S.tent.p, S.ent_val.p, S.tile_ptr.p, ls.told_col.p, S.run_base.p, S.slot_pos.p,
+                         S.slots.p, A.tile_row0.p, A.tile_bits, A.n_tiles, swz);
+      draw(S, a, nullptr);
+    }
+    if (!next) {
+      TimedLaunch t(tm, s, kc.scat, 28.0 * TL.n_ent);
+      hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, false>), dim3(TL.n_tiles), dim3(nt), lds, s, a, TL.tent.p, TL.ent_val.p,
+                         TL.tile_ptr.p, TL.tile_row0.p, ls.oldnew_col.p, TL.tile_bits, TL.n_tiles, swz);
+      continue;
+    }
+    {
+      TimedLaunch t(tm, s, KC_SWEEP_V_FUSED,
+                    32.0 * plan.n_state_rows + (UNIT ? 4.0 : 12.0) * (TL.n_ent + T1.n_ent) + 16.0 * T1.n_runs);
+      SweepArgs af = a;
+      af.row0 = plan.col_row0.p;
+      FuseArgs fa{an.theta,     an.z,          an.lambda,     an.mu,        plan.fuse_desc.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
+                  1,            T1.run_base.p, T1.slot_pos.p, T1.slots.p,   plan.solo_col.p,  plan.long_partial.p,
+                  T1.tent.p,    T1.ent_val.p,  T1.tile_ptr.p};
+      hipLaunchKernelGGL((k_tile_apply_next<UNIT, false, true>), dim3(TL.n_tiles), dim3(nt), lds + 256, s, af, TL.tent.p,
+                         TL.ent_val.p, TL.tile_ptr.p, TL.tile_row0.p, ls.oldnew_col.p, TL.tile_bits, TL.n_tiles, swz, fa);
+    }
+    launch_long_finish<UNIT>(s, tm, plan, T1, an, ls, kc, 1, lds, nt);
+  }
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
 // Latent sweep of factors [f_begin, f_end) in the split layout: args(f).state = e[N], .state2 = q[N].
 // fuse: the last level's apply pass also runs the next factor's first level (short columns) on the tile.
 template <bool UNIT, class ArgsOf>
 static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf args, int f_begin, int f_end,
                           LongScratch &ls, const SweepClasses &kc, bool fuse) {
+  if (fuse && plan_supports_fused_multi(plan) && !std::getenv("MFM_NO_FUSED_MULTI")) {
+    run_sweep_soa_multi<UNIT>(s, tm, plan, args, f_begin, f_end, ls, kc);
+    return;
+  }
   const int swz = xcd_swizzle_enabled();
   if (fuse) raise_fused_lds_limit<UNIT>();
   // two-level plan: the fused pass also produces the next factor's last-level statistics
@@ -1126,7 +1214,8 @@ static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsO
             SweepArgs af = a;
             af.row0 = plan.col_row0.p;
             FuseArgs fa{an.theta,   an.z,         an.lambda,    an.mu,     plan.fuse_desc.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
-                        fuse_stats, L.run_base.p, L.slot_pos.p, L.slots.p, plan.solo_col.p,  plan.long_partial.p};
+                        fuse_stats, L.run_base.p, L.slot_pos.p, L.slots.p, plan.solo_col.p,  plan.long_partial.p,
+                        nullptr,    nullptr,      nullptr};
             if (two)
               hipLaunchKernelGGL((k_tile_apply_next<UNIT, true>), dim3(L.n_tiles), dim3(nt), lds + 256, s, af, L.tent.p,
                                  L.ent_val.p, L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
@@ -1277,7 +1366,8 @@ static void run_sweep_soa_sharded(hipStream_t s, Timing &tm, const StepPlan &pla
       SweepArgs af = a;
       af.row0 = plan.col_row0.p;
       FuseArgs fa{an.theta, an.z,         an.lambda,    an.mu,     plan.fuse_desc.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
-                  1,        L.run_base.p, L.slot_pos.p, L.slots.p, plan.solo_col.p,  plan.long_partial.p};
+                  1,        L.run_base.p, L.slot_pos.p, L.slots.p, plan.solo_col.p,  plan.long_partial.p,
+                  nullptr,  nullptr,      nullptr};
       if (two)
         hipLaunchKernelGGL((k_tile_apply_next<UNIT, true>), dim3(L.n_tiles), dim3(nt), lds + 256, s, af, L.tent.p, L.ent_val.p,
                            L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz, fa);
