@@ -1046,13 +1046,22 @@ struct FuseArgs {
   const uint32_t *tentS;
   const double *tvalS;
   const int32_t *tile_ptrS;
+  // MULTIQ (every tile level covers every row once: one-hot fields): the next factor's q from the levels' entry
+  // streams -- x * V[col, f + 1] per entry, gathered from a compact per-level array the level's draw leaves behind --
+  // instead of from the CSR rows: vnextA for the applied level, ex_* for the other tile levels
+  const double *vnextA;
+  int n_extra;
+  const uint32_t *ex_tent[6];
+  const double *ex_tval[6];
+  const int32_t *ex_tile_ptr[6];
+  const double *ex_vnext[6];
 };
 
 // TWO: the plan has exactly these two levels and the last one covers every row once (a two-field one-hot
 // table): q of the next factor is x_last * V[last col, f + 1] (gathered per ENTRY from the compact vnext_col,
 // entries are sorted by column) + x_first * V[first col, f + 1] (uniform per first-level column) -- no CSR
 // read and no per-row gather; with two terms the sum is the same in either order.
-template <bool UNIT, bool TWO, bool SPLIT = false>
+template <bool UNIT, bool TWO, bool SPLIT = false, bool MULTIQ = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_tile_apply_next(
     SweepArgs a, const uint32_t *__restrict__ tent, const double *__restrict__ tval, const int32_t *__restrict__ tile_ptr,
     const int32_t *__restrict__ tile_row0, const double2 *__restrict__ oldnew, int tile_bits, int n_tiles, int swz,
@@ -1097,13 +1106,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
   double vn[TILE_K];
 #pragma unroll
   for (int k = 0; k < TILE_K; k++)
-    vn[k] = (TWO || (fa.stats && !SPLIT)) && u[k] != TILE_PAD ? fa.vnext_col[u[k] >> tile_bits] : 0.0;
+    vn[k] = u[k] == TILE_PAD ? 0.0
+            : MULTIQ ? fa.vnextA[u[k] >> tile_bits]
+            : (TWO || (fa.stats && !SPLIT)) ? fa.vnext_col[u[k] >> tile_bits] : 0.0;
   // q of the next factor for this thread's rows (TWO: the last level's term, per entry)
   double qn[TILE_K];
 #pragma unroll
   for (int k = 0; k < TILE_K; k++) {
     qn[k] = 0.0;
-    if (TWO) {
+    if (TWO || MULTIQ) {
       qn[k] = x[k] * vn[k];
     } else if (tid + k * nt < nr) {
       const int64_t row = row0 + tid + k * nt;
@@ -1143,13 +1154,36 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
     if (u[k] == TILE_PAD) continue;
     const uint32_t r = u[k] & rmask;
     const double en = PMainV::updated(x[k], lds_rec[r], on[k][0], on[k][1]).x;
-    if (TWO)
+    if (TWO || MULTIQ)
       lds_rec[r] = make_double2(en, qn[k]);  // q_f of this row is dead now
     else
       lds_rec[r].x = en;
   }
   __syncthreads();
-  if (!TWO) {
+  if (MULTIQ) {  // the other tile levels' terms of the next q (a level has one entry per row: no two threads meet)
+    for (int e = 0; e < fa.n_extra; e++) {
+      const int64_t q0 = (int64_t)fa.ex_tile_ptr[e][b] * WAVE + tid, q1 = (int64_t)fa.ex_tile_ptr[e][b + 1] * WAVE;
+      uint32_t ue[TILE_K];
+      double xe[TILE_K], ve[TILE_K];
+#pragma unroll
+      for (int k = 0; k < TILE_K; k++) {
+        const int64_t p = q0 + (int64_t)k * nt;
+        ue[k] = TILE_PAD;
+        xe[k] = 1.0;
+        if (p < q1) {
+          ue[k] = __builtin_nontemporal_load(&fa.ex_tent[e][p]);
+          if (!UNIT) xe[k] = __builtin_nontemporal_load(&fa.ex_tval[e][p]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < TILE_K; k++) ve[k] = ue[k] != TILE_PAD ? fa.ex_vnext[e][ue[k] >> tile_bits] : 0.0;
+#pragma unroll
+      for (int k = 0; k < TILE_K; k++)
+        if (ue[k] != TILE_PAD) lds_rec[ue[k] & rmask].y += xe[k] * ve[k];
+      __syncthreads();
+    }
+  }
+  if (!TWO && !MULTIQ) {
 #pragma unroll
     for (int k = 0; k < TILE_K; k++)
       if (tid + k * nt < nr) lds_rec[tid + k * nt].y = qn[k];
@@ -1169,7 +1203,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
       if (i < nr) {
         double2 st = lds_rec[i];
         const double xv = UNIT ? 1.0 : a.val[vbase + i];
-        if (TWO) st.y += xv * old;
+        if (TWO || MULTIQ) st.y += xv * old;
         PMainV::stats(xv, st, old, S1, S2);
         __builtin_nontemporal_store(st.x, &E[row0 + i]);
         __builtin_nontemporal_store(st.y, &Q[row0 + i]);
@@ -1222,7 +1256,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
       for (int i = lane; i < len; i += WAVE) {
         const double xv = UNIT ? 1.0 : a.val[beg + i];
         double2 st = lds_rec[lr0 + i];
-        if (TWO) st.y += xv * old;
+        if (TWO || MULTIQ) st.y += xv * old;
         PMainV::stats(xv, st, old, S1, S2);
       }
       S1 = wave_allreduce_sum(S1);
@@ -1231,7 +1265,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
       for (int i = lane; i < len; i += WAVE) {
         const double xv = UNIT ? 1.0 : a.val[beg + i];
         double2 st = lds_rec[lr0 + i];
-        if (TWO) st.y += xv * old;
+        if (TWO || MULTIQ) st.y += xv * old;
         lds_rec[lr0 + i] = PMainV::updated(xv, st, old, fresh);
       }
       if (lane == 0) fa.theta_next[j] = fresh;

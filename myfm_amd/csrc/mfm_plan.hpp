@@ -733,6 +733,7 @@ struct LongScratch {
   DevBuf<double> vnext_col;    // fused apply pass: next factor's coefficient per column of the last level
   DevBuf<double2> S_compact;   // sharded fused path: statistics of the special first-level columns
   DevBuf<double> told_col;     // multi-level fused flow: current coefficient per column of the level whose statistics are taken
+  std::vector<DevBuf<double>> vnext_lvl;  // ... and per tile level: next factor's coefficient per column (MULTIQ)
   void reserve_cols(int64_t n_cols) {
     if ((size_t)n_cols > oldnew_col.n) {
       oldnew_col.alloc((size_t)n_cols);
@@ -1071,15 +1072,16 @@ static void raise_fused_lds_limit() {
 // fused flow, first-level columns longer than a tile: k_tile_apply_next left their tiles' partial statistics
 template <bool UNIT>
 static void launch_long_finish(hipStream_t s, Timing &tm, const StepPlan &plan, const ParLevel &L, const SweepArgs &an,
-                               LongScratch &ls, const SweepClasses &kc, int stats, size_t lds, int nt) {
+                               LongScratch &ls, const SweepClasses &kc, int stats, size_t lds, int nt,
+                               const double *vnext = nullptr) {
   if (!plan.n_long_cols) return;
+  if (!vnext) vnext = ls.vnext_col.p;
   TimedLaunch t(tm, s, kc.coop, 52.0 * plan.n_long_tiles * (double)(1 << L.tile_bits));
   hipLaunchKernelGGL((k_long_tile_draw<PMainV>), dim3((plan.n_long_cols + 63) / 64), dim3(64), 0, s, an, plan.long_cols.p,
                      plan.long_tile_ptr.p, plan.long_tiles.p, plan.n_long_cols, plan.long_partial.p, plan.oldnew_long.p);
   hipLaunchKernelGGL((k_tile_long_finish<UNIT>), dim3(plan.n_long_tiles), dim3(nt), lds, s, an, L.tent.p, L.ent_val.p,
                      L.tile_ptr.p, L.tile_row0.p, L.tile_bits, plan.long_tiles.p, plan.tile_long_idx.p, plan.oldnew_long.p,
-                     plan.long_cols.p, ls.vnext_col.p, stats, L.run_base.p, L.slot_pos.p, L.slots.p);
-  (void)ls;
+                     plan.long_cols.p, vnext, stats, L.run_base.p, L.slot_pos.p, L.slots.p);
 }
 
 // Split-layout sweep of a plan with MORE than two levels, all but the first on row tiles (several one-hot fields,
@@ -1110,9 +1112,24 @@ static void run_sweep_soa_multi(hipStream_t s, Timing &tm, const StepPlan &plan,
   const ParLevel &L1 = plan.steps.front().par, &T1 = plan.steps[1].par, &TL = plan.steps.back().par;
   const size_t lds = sizeof(double2) << T1.tile_bits;
   const int nt = tile_threads(T1.tile_bits);
-  auto draw = [&](const ParLevel &T, const SweepArgs &a, const double *theta_next) {
+  // every tile level a one-hot field (one entry per row): the next q comes from the entry streams (MULTIQ)
+  bool multiq = nl - 1 <= 7 && !std::getenv("MFM_NO_FUSED_MULTIQ");
+  for (int l = 1; l < nl; l++) multiq = multiq && plan.steps[l].par.covers_rows_once;
+  if (ls.vnext_lvl.size() < (size_t)nl) ls.vnext_lvl.resize((size_t)nl);
+  for (int l = 1; l < nl; l++)
+    if (ls.vnext_lvl[l].n < (size_t)plan.steps[l].par.n_cols) ls.vnext_lvl[l].alloc((size_t)plan.steps[l].par.n_cols);
+  {
+    static bool raised2 = false;
+    if (!raised2) {
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply_next<UNIT, false, true, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_MAX));
+      raised2 = true;
+    }
+  }
+  auto draw = [&](int l, const SweepArgs &a, const double *theta_next) {
+    const ParLevel &T = plan.steps[l].par;
     hipLaunchKernelGGL((k_tile_draw<PMainV>), dim3((T.n_cols + 3) / 4), dim3(WG), 0, s, a, T.scols.p, T.n_cols, T.slot_ptr.p,
-                       T.slots.p, ls.oldnew_col.p, theta_next, ls.vnext_col.p);
+                       T.slots.p, ls.oldnew_col.p, theta_next, ls.vnext_lvl[l].p);
   };
   for (int f = f_begin; f < f_end; f++) {
     const SweepArgs a = args(f);
@@ -1124,14 +1141,15 @@ static void run_sweep_soa_multi(hipStream_t s, Timing &tm, const StepPlan &plan,
       launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, L1, a, ls, kc);
       TimedLaunch t(tm, s, kc.scat, 20.0 * T1.n_ent);
       hipLaunchKernelGGL(k_tile_old, dim3((T1.n_cols + 255) / 256), dim3(256), 0, s, a.theta, T1.scols.p, T1.n_cols,
-                         ls.vnext_col.p);
+                         ls.told_col.p);
       hipLaunchKernelGGL((k_tile_stats<PMainV, UNIT, true>), dim3(T1.n_tiles), dim3(nt), lds, s, a, T1.tent.p, T1.ent_val.p,
-                         T1.tile_ptr.p, T1.tile_row0.p, ls.vnext_col.p, T1.run_base.p, T1.slot_pos.p, T1.slots.p, T1.tile_bits,
+                         T1.tile_ptr.p, T1.tile_row0.p, ls.told_col.p, T1.run_base.p, T1.slot_pos.p, T1.slots.p, T1.tile_bits,
                          T1.n_tiles, swz, (const int32_t *)nullptr);
     }
+    const double *tn = next ? (const double *)an.theta : (const double *)nullptr;
     {
       TimedLaunch t(tm, s, kc.scat, 16.0 * T1.n_runs);
-      draw(T1, a, next ? (const double *)an.theta : (const double *)nullptr);
+      draw(1, a, tn);
     }
     for (int l = 1; l + 1 < nl; l++) {
       const ParLevel &A = plan.steps[l].par, &S = plan.steps[l + 1].par;
@@ -1140,7 +1158,7 @@ static void run_sweep_soa_multi(hipStream_t s, Timing &tm, const StepPlan &plan,
       hipLaunchKernelGGL((k_tile_apply_stats<UNIT>), dim3(A.n_tiles), dim3(nt), lds, s, a, A.tent.p, A.ent_val.p, A.tile_ptr.p,
                          ls.oldnew_col.p, S.tent.p, S.ent_val.p, S.tile_ptr.p, ls.told_col.p, S.run_base.p, S.slot_pos.p,
                          S.slots.p, A.tile_row0.p, A.tile_bits, A.n_tiles, swz);
-      draw(S, a, nullptr);
+      draw(l + 1, a, tn);
     }
     if (!next) {
       TimedLaunch t(tm, s, kc.scat, 28.0 * TL.n_ent);
@@ -1153,13 +1171,27 @@ static void run_sweep_soa_multi(hipStream_t s, Timing &tm, const StepPlan &plan,
                     32.0 * plan.n_state_rows + (UNIT ? 4.0 : 12.0) * (TL.n_ent + T1.n_ent) + 16.0 * T1.n_runs);
       SweepArgs af = a;
       af.row0 = plan.col_row0.p;
-      FuseArgs fa{an.theta,     an.z,          an.lambda,     an.mu,        plan.fuse_desc.p, plan.fuse_col_ptr.p, ls.vnext_col.p,
-                  1,            T1.run_base.p, T1.slot_pos.p, T1.slots.p,   plan.solo_col.p,  plan.long_partial.p,
-                  T1.tent.p,    T1.ent_val.p,  T1.tile_ptr.p};
-      hipLaunchKernelGGL((k_tile_apply_next<UNIT, false, true>), dim3(TL.n_tiles), dim3(nt), lds + 256, s, af, TL.tent.p,
-                         TL.ent_val.p, TL.tile_ptr.p, TL.tile_row0.p, ls.oldnew_col.p, TL.tile_bits, TL.n_tiles, swz, fa);
+      FuseArgs fa{an.theta,  an.z,          an.lambda,     an.mu,      plan.fuse_desc.p, plan.fuse_col_ptr.p, ls.vnext_lvl[1].p,
+                  1,         T1.run_base.p, T1.slot_pos.p, T1.slots.p, plan.solo_col.p,  plan.long_partial.p,
+                  T1.tent.p, T1.ent_val.p,  T1.tile_ptr.p};
+      fa.vnextA = ls.vnext_lvl[nl - 1].p;
+      fa.n_extra = 0;
+      for (int l = 1; l + 1 < nl && multiq; l++) {
+        const ParLevel &E = plan.steps[l].par;
+        fa.ex_tent[fa.n_extra] = E.tent.p;
+        fa.ex_tval[fa.n_extra] = E.ent_val.p;
+        fa.ex_tile_ptr[fa.n_extra] = E.tile_ptr.p;
+        fa.ex_vnext[fa.n_extra] = ls.vnext_lvl[l].p;
+        fa.n_extra++;
+      }
+      if (multiq)
+        hipLaunchKernelGGL((k_tile_apply_next<UNIT, false, true, true>), dim3(TL.n_tiles), dim3(nt), lds + 256, s, af, TL.tent.p,
+                           TL.ent_val.p, TL.tile_ptr.p, TL.tile_row0.p, ls.oldnew_col.p, TL.tile_bits, TL.n_tiles, swz, fa);
+      else
+        hipLaunchKernelGGL((k_tile_apply_next<UNIT, false, true>), dim3(TL.n_tiles), dim3(nt), lds + 256, s, af, TL.tent.p,
+                           TL.ent_val.p, TL.tile_ptr.p, TL.tile_row0.p, ls.oldnew_col.p, TL.tile_bits, TL.n_tiles, swz, fa);
     }
-    launch_long_finish<UNIT>(s, tm, plan, T1, an, ls, kc, 1, lds, nt);
+    launch_long_finish<UNIT>(s, tm, plan, T1, an, ls, kc, 1, lds, nt, ls.vnext_lvl[1].p);
   }
   MFM_HIP_CHECK(hipGetLastError());
 }

@@ -189,15 +189,22 @@ def test_row_tile_level_path(oracle, capi, monkeypatch, tile_bits):
         assert "sweep_V_scattered" in _timing_classes(c, drv)
 
 
-@pytest.mark.parametrize("n_fields,fused", [(2, True), (3, True), (2, False)])
+@pytest.mark.parametrize("n_fields,fused", [(2, True), (3, True), (2, False), (3, "csr_q"), (3, "no_multi")])
 def test_split_layout_latent_sweep(oracle, capi, monkeypatch, n_fields, fused):
     # update_V with e and q as separate arrays (run_plan_soa): first level (user-sorted, contiguous columns)
     # rebuilds q, middle levels read and write both, the last level writes only e; q_train is restored after
     # fused: the last level's apply pass also runs the next factor's first level on the LDS tile
     # (k_tile_apply_next; tiles aligned to the users' row ranges, a few users longer than a tile)
+    # three fields: apply + next-level statistics in one pass, wrap-around pass with the next q from the entry streams
+    # ("csr_q": from the CSR rows instead; "no_multi": the per-level passes)
     monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
     if not fused:
         monkeypatch.setenv("MFM_NO_FUSED_NEXT", "1")
+    if fused == "csr_q":
+        monkeypatch.setenv("MFM_NO_FUSED_MULTIQ", "1")
+    if fused == "no_multi":
+        monkeypatch.setenv("MFM_NO_FUSED_MULTI", "1")
+    fused = bool(fused)
     import scipy.sparse as sps
     n = 150001
     X, y, shapes = ds.onehot_mf(n, 200, 120, seed=21, sort_by_user=True)
