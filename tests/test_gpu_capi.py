@@ -233,12 +233,20 @@ def test_split_layout_latent_sweep(oracle, capi, monkeypatch, n_fields, fused):
         np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-7, atol=1e-7)
 
 
-def test_split_layout_factor_subranges(oracle, capi, monkeypatch):
+@pytest.mark.parametrize("n_fields", [2, 3])
+def test_split_layout_factor_subranges(oracle, capi, monkeypatch, n_fields):
     # mfm_sweep_V over [0, 2), [2, 3), [3, 5): every call starts with an unfused first level, ends with an unfused
     # apply pass and picks its variates / hyper columns by absolute factor index
     monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
     n, K = 60001, 5
     X, y, shapes = ds.onehot_mf(n, 300, 90, seed=31, sort_by_user=True)
+    if n_fields == 3:
+        import scipy.sparse as sps
+
+        ctx = np.random.default_rng(4).integers(0, 23, size=n)
+        X = sps.hstack([X, sps.csr_matrix((np.ones(n), ctx, np.arange(n + 1)), shape=(n, 23))]).tocsr()
+        X.sort_indices()
+        shapes = shapes + [23]
     gi = ds.group_index_from_shapes(shapes)
     t, c, _ = _pair(oracle, capi, X, y, gi, K)
     assert c.plan_flags()["fused_next"]
