@@ -475,7 +475,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     // Row-sharded fused tile path: which first-level columns need an all-reduce of their statistics? Those
     // with rows on more than one rank -- the same ("special") set on every rank, from two all-reduces of
     // per-column indicators (columns empty on every rank are drawn from the prior by every rank itself).
-    bool try_fused = c->comm.active() && c->hblocks.empty() && !c->hlevels.empty() && tile_bits == 12 && c->N > 0 &&
+    bool try_fused = c->comm.active() && c->hblocks.empty() && !c->hlevels.empty() && tile_bits > 0 && c->N > 0 &&
                      !std::getenv("MFM_NO_SHARDED_FUSED") && !std::getenv("MFM_NO_SOA");
     std::vector<double> col_cnt;
     if (try_fused) {

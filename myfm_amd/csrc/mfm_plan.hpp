@@ -687,7 +687,7 @@ struct StepPlan {
         L.contig = contig;
       }
       if (steps.size() == 1 && L.contig && L.first_and_once && allow_scatter && (!sharded || sharded_tiles) && tile_bits > 0 &&
-          ((int64_t)1 << tile_bits) == cap_wg && (L.n_huge == 0 || sharded_tiles) && !std::getenv("MFM_NO_ALIGNED_TILES"))
+          !std::getenv("MFM_NO_ALIGNED_TILES"))
         build_aligned_tiles(csc, by_level[l], (int64_t)1 << tile_bits);
       if (steps.size() == 1 && sharded_tiles && aligned_tiles) {
         std::vector<int32_t> sp, loc;
@@ -1039,7 +1039,7 @@ static void launch_huge(hipStream_t s, Timing &tm, const ParLevel &L, const Swee
 static inline bool plan_supports_fused_next(const StepPlan &plan) {
   if (!plan_supports_soa(plan) || !plan.aligned_tiles) return false;
   const ParLevel &first = plan.steps.front().par, &last = plan.steps.back().par;
-  return first.contig && first.n_huge == 0 && last.scattered && last.tiled;
+  return first.contig && last.scattered && last.tiled;
 }
 
 // statistics (unless already produced by the previous factor's fused pass) and draw of a row-tile level
