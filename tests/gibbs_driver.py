@@ -73,7 +73,7 @@ class CapiGibbs:
         z = self._hv() if getattr(self, "dev", False) else self.rng.rng_sample_normals(1)[0]
         return first / quad + z / np.sqrt(quad)
 
-    def step(self):
+    def step(self, before_update_e=None):
         c, K, G, D = self.c, self.c.K, self.G, self.c.D
         self._begin()
         # update_alpha, FMTrainer.hpp:127-145
@@ -116,6 +116,8 @@ class CapiGibbs:
             # update_V, :316-486
             c.sweep_V(0, K, self.alpha, self.lam_V, self.mu_V, self._z(K * D))
         # update_e, :493-497
+        if before_update_e is not None:
+            before_update_e()
         c.update_e_regression()
 
     def hyper(self):
