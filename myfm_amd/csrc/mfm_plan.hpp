@@ -201,7 +201,7 @@ struct StepPlan {
   // tile_bits > 0: row-tile variant (tiles of 2^tile_bits rows staged in LDS, packed + padded entries)
   static bool build_scattered(const HostCsr &csc, const std::vector<int32_t> &cols, int64_t lnnz, bool unit, ParLevel &L,
                               int tile_bits = 0, const std::vector<int32_t> *bounds = nullptr) {
-    int64_t min_nnz = 1 << 20;  // below this the level is launch-bound anyway
+    int64_t min_nnz = 1 << 16;  // (measured: the tile path and the fusions it enables win from ~10^5 entries per level on)
     if (const char *e = std::getenv("MFM_SCATTER_MIN_NNZ")) min_nnz = std::atoll(e);
     if (lnnz < min_nnz) return false;
     if (const char *e = std::getenv("MFM_NO_SCATTER"))
