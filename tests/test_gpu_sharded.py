@@ -191,3 +191,50 @@ def test_sharded_fused_tile_path(oracle, world, values, monkeypatch):
         np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(ge, e[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
         assert abs(galpha - t.hyper()["alpha"]) < 1e-7 * galpha
+
+
+@pytest.mark.parametrize("seed,world", [(1, 2), (6, 3), (9, 2), (4, 2), (0, 3)])
+def test_random_designs_sharded(oracle, seed, world, monkeypatch):
+    """the seeded random one-hot designs of test_gpu_random_designs.py, row-sharded over lock-stepped ranks (two-field
+    sorted tables take the fused sharded path, the others the generic per-level all-reduce path)"""
+    from myfm_amd import _capi, _myfm
+    from myfm_amd.distributed import shard_rows
+
+    from .test_gpu_random_designs import _random_design
+
+    X, y, gi, K, env = _random_design(seed)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ls = Lockstep(world)
+    levels = _capi.column_levels(X)[0]
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            Xl, yl, rel, lo, ntot = shard_rows(X, y, [], rank, world)
+            s = _myfm.GibbsSession(K, 0.1, Xl, [], yl, 42, _config(gi), allreduce=ls.callback(rank), n_total_rows=ntot,
+                                   row_offset=lo, main_levels=levels)
+            for it in range(3):
+                s.step()
+            out[rank] = (s.fm.w0, np.asarray(s.fm.w), np.asarray(s.fm.V), s.residual(), lo, s.plan_flags())
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            ls.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=300)
+    assert not errs, errs
+    t = oracle.OracleTrainer(X, y, rank=K, group_index=gi)
+    for it in range(3):
+        t.step()
+    w0, w, V = t.fm()
+    e = t.e(X.shape[0])
+    for rank in range(world):
+        gw0, gw, gV, ge, lo, flags = out[rank]
+        assert abs(gw0 - w0) < 1e-7, flags
+        np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8, err_msg=str(flags))
+        np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(ge, e[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
