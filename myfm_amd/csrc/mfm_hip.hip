@@ -904,10 +904,16 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       a.r_ell = (int)c->X.ell_width;
       return a;
     };
-    if (c->X.unit)
+    if (c->plan_V.steps.size() > 2) {
+      if (c->X.unit)
+        run_sweep_soa_multi<true>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, &c->comm);
+      else
+        run_sweep_soa_multi<false>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, &c->comm);
+    } else if (c->X.unit) {
       run_sweep_soa_sharded<true>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, c->comm);
-    else
+    } else {
       run_sweep_soa_sharded<false>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, c->comm);
+    }
     // make the first-level coefficients identical on every rank again (each was drawn where its rows live)
     {
       const int64_t n = (int64_t)(f_end - f_begin) * c->D;

@@ -1097,7 +1097,10 @@ static inline bool plan_supports_fused_multi(const StepPlan &plan) {
 
 template <bool UNIT, class ArgsOf>
 static void run_sweep_soa_multi(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf args, int f_begin, int f_end,
-                                LongScratch &ls, const SweepClasses &kc) {
+                                LongScratch &ls, const SweepClasses &kc, const Comm *comm = nullptr) {
+  // comm != null: row-sharded (plan.sharded_tiles): every tile level's slot sums are all-reduced before its draw, the
+  // special first-level columns go through run_level_sharded, the locally complete ones stay local (see
+  // run_sweep_soa_sharded)
   const int swz = xcd_swizzle_enabled();
   raise_fused_lds_limit<UNIT>();
   {
@@ -1128,8 +1131,22 @@ static void run_sweep_soa_multi(hipStream_t s, Timing &tm, const StepPlan &plan,
   }
   auto draw = [&](int l, const SweepArgs &a, const double *theta_next) {
     const ParLevel &T = plan.steps[l].par;
-    hipLaunchKernelGGL((k_tile_draw<PMainV>), dim3((T.n_cols + 3) / 4), dim3(WG), 0, s, a, T.scols.p, T.n_cols, T.slot_ptr.p,
-                       T.slots.p, ls.oldnew_col.p, theta_next, ls.vnext_lvl[l].p);
+    if (!comm) {
+      hipLaunchKernelGGL((k_tile_draw<PMainV>), dim3((T.n_cols + 3) / 4), dim3(WG), 0, s, a, T.scols.p, T.n_cols, T.slot_ptr.p,
+                         T.slots.p, ls.oldnew_col.p, theta_next, ls.vnext_lvl[l].p);
+      return;
+    }
+    hipLaunchKernelGGL(k_tile_sum, dim3((T.n_cols + 3) / 4), dim3(WG), 0, s, T.n_cols, T.slot_ptr.p, T.slots.p, ls.S_col.p);
+    MFM_HIP_CHECK(hipGetLastError());
+    comm->allreduce(ls.S_col.p, 2 * (int64_t)T.n_cols);
+    hipLaunchKernelGGL((k_tile_draw_S<PMainV>), dim3((T.n_cols + 255) / 256), dim3(256), 0, s, a, T.scols.p, T.n_cols, ls.S_col.p,
+                       ls.oldnew_col.p, theta_next, ls.vnext_lvl[l].p);
+  };
+  auto first_level_rest = [&](const SweepArgs &ax) {  // (sharded) special first-level columns, then their tiles' statistics
+    if (!comm) return;
+    if (plan.n_special)
+      run_level_sharded<PMainVsq<UNIT>, PMainVsqA<UNIT>, UNIT>(s, tm, plan.special_level, ax, ls, kc, *comm, plan.special_cols.p,
+                                                               plan.n_special);
   };
   for (int f = f_begin; f < f_end; f++) {
     const SweepArgs a = args(f);
@@ -1137,8 +1154,10 @@ static void run_sweep_soa_multi(hipStream_t s, Timing &tm, const StepPlan &plan,
     SweepArgs an = next ? args(f + 1) : a;
     an.row0 = plan.col_row0.p;
     if (f == f_begin) {
-      launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, L1, a, ls, kc, plan.col_row0.p);
-      launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, L1, a, ls, kc);
+      const ParLevel &Lf = comm ? plan.local_level : L1;  // (sharded: the columns complete on this rank)
+      launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, Lf, a, ls, kc, plan.col_row0.p);
+      launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, Lf, a, ls, kc);
+      first_level_rest(a);
       TimedLaunch t(tm, s, kc.scat, 20.0 * T1.n_ent);
       hipLaunchKernelGGL(k_tile_old, dim3((T1.n_cols + 255) / 256), dim3(256), 0, s, a.theta, T1.scols.p, T1.n_cols,
                          ls.told_col.p);
@@ -1192,6 +1211,13 @@ static void run_sweep_soa_multi(hipStream_t s, Timing &tm, const StepPlan &plan,
                            TL.ent_val.p, TL.tile_ptr.p, TL.tile_row0.p, ls.oldnew_col.p, TL.tile_bits, TL.n_tiles, swz, fa);
     }
     launch_long_finish<UNIT>(s, tm, plan, T1, an, ls, kc, 1, lds, nt, ls.vnext_lvl[1].p);
+    first_level_rest(an);
+    if (comm && plan.n_solo_tiles) {
+      TimedLaunch t(tm, s, kc.scat, 20.0 * plan.n_solo_tiles * (1 << T1.tile_bits));
+      hipLaunchKernelGGL((k_tile_stats<PMainV, UNIT, true>), dim3(plan.n_solo_tiles), dim3(nt), lds, s, an, T1.tent.p,
+                         T1.ent_val.p, T1.tile_ptr.p, T1.tile_row0.p, ls.vnext_lvl[1].p, T1.run_base.p, T1.slot_pos.p,
+                         T1.slots.p, T1.tile_bits, T1.n_tiles, swz, plan.solo_tiles.p);
+    }
   }
   MFM_HIP_CHECK(hipGetLastError());
 }
@@ -1335,13 +1361,16 @@ static void run_level_sharded(hipStream_t s, Timing &tm, const ParLevel &L, cons
   MFM_HIP_CHECK(hipGetLastError());
 }
 
-// can the row-sharded latent sweep of this (local) table run the fused tile path? Two PAR levels: a contiguous
-// first level covering every local row once, a row-tile last level, tiles aligned to the first level.
+// can the row-sharded latent sweep of this (local) table run the fused tile path? A contiguous first level covering
+// every local row once, every other level on row tiles aligned to it (two levels: run_sweep_soa_sharded, more:
+// run_sweep_soa_multi with the communicator).
 static inline bool plan_supports_sharded_fused(const StepPlan &plan) {
-  if (!plan.sharded_tiles || plan.steps.size() != 2 || !plan.aligned_tiles) return false;
-  const Step &f = plan.steps.front(), &l = plan.steps.back();
-  if (f.is_chain || l.is_chain) return false;
-  return !f.par.scattered && f.par.first_and_once && f.par.contig && l.par.scattered && l.par.tiled;
+  if (!plan.sharded_tiles || plan.steps.size() < 2 || !plan.aligned_tiles) return false;
+  const Step &f = plan.steps.front();
+  if (f.is_chain || f.par.scattered || !f.par.first_and_once || !f.par.contig) return false;
+  for (size_t i = 1; i < plan.steps.size(); i++)
+    if (plan.steps[i].is_chain || !plan.steps[i].par.scattered || !plan.steps[i].par.tiled) return false;
+  return true;
 }
 
 // Row-sharded latent sweep, split e / q layout, fused tile pass (args(f).state = e, .state2 = q). The

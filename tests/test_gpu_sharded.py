@@ -138,8 +138,8 @@ def test_two_shards_lockstep(oracle, name):
     assert ls.counts[0] == ls.counts[1] > 0
 
 
-@pytest.mark.parametrize("world,values", [(2, False), (3, True)])
-def test_sharded_fused_tile_path(oracle, world, values, monkeypatch):
+@pytest.mark.parametrize("world,values,n_fields", [(2, False, 2), (3, True, 2), (2, True, 3), (3, False, 4)])
+def test_sharded_fused_tile_path(oracle, world, values, n_fields, monkeypatch):
     """user-sorted two-field table, row-sharded: first-level columns complete on one rank are swept locally inside
     the fused tile pass, the users straddling a rank boundary (and one longer than a tile) go through the
     all-reduced path, the model is synchronised after the sweep -- must reproduce the unsharded oracle chain"""
@@ -149,6 +149,12 @@ def test_sharded_fused_tile_path(oracle, world, values, monkeypatch):
     monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
     n = 90001
     X, y, shapes = ds.onehot_mf(n, 80, 70, seed=9, sort_by_user=True)
+    for extra in range(n_fields - 2):  # more one-hot fields: the multi-level form of the fused pass, sharded
+        k = 11 + 6 * extra
+        ctx = np.random.default_rng(50 + extra).integers(0, k, size=n)
+        X = sps.hstack([X, sps.csr_matrix((np.ones(n), ctx, np.arange(n + 1)), shape=(n, k))]).tocsr()
+        X.sort_indices()
+        shapes = shapes + [k]
     if values:
         X = X.copy()
         X.data = np.where(np.arange(X.nnz) % 3 == 0, 0.5, 1.5)
