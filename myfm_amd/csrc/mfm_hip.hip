@@ -890,7 +890,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     return MFM_OK;
   }
   if (c->sharded_fused) {
-    hipLaunchKernelGGL(k_e_pack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
+    // (no pack / unpack passes: the first level reads e from the interleaved array, the final apply pass writes it back)
     const SweepClasses kcv{KC_SWEEP_V_LIGHT, KC_SWEEP_V_HEAVY, KC_SWEEP_V_COOP, KC_SWEEP_V_LSTATS, KC_SWEEP_V_LDRAW,
                            KC_SWEEP_V_LAPPLY, KC_SWEEP_V_CHAIN, KC_SWEEP_V_SCAT};
     auto args = [&](int f) {
@@ -898,6 +898,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
                               c->lam.p + (size_t)f * c->G, c->mu.p + (size_t)f * c->G, alpha);
       a.state = c->ec.p;
       a.state2 = c->qc.p;
+      a.aos = c->eq.p;
       a.r_rowptr = c->X.rowptr.p;
       a.r_colidx = c->X.colidx.p;
       a.r_val = c->X.rval.p;
@@ -921,13 +922,13 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       hipLaunchKernelGGL(k_mask_rows, dim3(cdiv(n, 256)), dim3(256), 0, s, Vb, c->sync_mask.p, c->D, n);
       c->comm.allreduce(Vb, n);
     }
-    hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
     c->q_stale_factor = f_end - 1;  // q_train as the reference leaves it (FMTrainer.hpp:373): rebuilt when asked for
     MFM_HIP_CHECK(hipGetLastError());
     return MFM_OK;
   }
   if (c->soa) {
-    hipLaunchKernelGGL(k_e_pack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
+    // (no pack pass: the first level reads e from the interleaved array; no unpack pass when the last level runs on
+    // row tiles: its final apply pass writes e back there)
     const SweepClasses kcv{KC_SWEEP_V_LIGHT, KC_SWEEP_V_HEAVY, KC_SWEEP_V_COOP, KC_SWEEP_V_LSTATS, KC_SWEEP_V_LDRAW,
                            KC_SWEEP_V_LAPPLY, KC_SWEEP_V_CHAIN, KC_SWEEP_V_SCAT};
     auto args = [&](int f) {
@@ -935,6 +936,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
                               c->lam.p + (size_t)f * c->G, c->mu.p + (size_t)f * c->G, alpha);
       a.state = c->ec.p;
       a.state2 = c->qc.p;
+      a.aos = c->eq.p;
       a.r_rowptr = c->X.rowptr.p;
       a.r_colidx = c->X.colidx.p;
       a.r_val = c->X.rval.p;
@@ -946,7 +948,8 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       run_sweep_soa<true>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, fuse);
     else
       run_sweep_soa<false>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, fuse);
-    hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
+    if (!c->plan_V.steps.back().par.tiled)
+      hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
     c->q_stale_factor = f_end - 1;  // q_train as the reference leaves it (FMTrainer.hpp:373): rebuilt when asked for
     MFM_HIP_CHECK(hipGetLastError());
     return MFM_OK;

@@ -46,6 +46,11 @@ struct SweepArgs {
   const int32_t *row0 = nullptr;
   // split layout of the latent sweep (PMainVs*): state = e[N], state2 = q[N]
   double *state2 = nullptr;
+  // ... its first pass reads e straight from the interleaved {e, q} array (aos, stride 2) and its last pass writes
+  // it back there, so that no separate pack / unpack passes are needed
+  double2 *aos = nullptr;
+  const double *e_src = nullptr;  // PMainVsq: where e is read from (null: state), in units of e_src_stride doubles
+  int e_src_stride = 1;
 };
 
 struct ChunkDesc {
@@ -262,7 +267,7 @@ struct PMainVsq : PMainVs {  // first level: q rebuilt from the row (see PMainVq
       b = a.r_rowptr[row];
       e = a.r_rowptr[row + 1];
     }
-    const double ev = ((const double *)a.state)[row];
+    const double ev = a.e_src ? a.e_src[(int64_t)row * a.e_src_stride] : ((const double *)a.state)[row];
     double q = 0.0;
     if (a.r_ell == 2) {
       const int2 ci = *(const int2 *)(a.r_colidx + b);
@@ -952,7 +957,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
     if (tid + k * nt < nr) {
       const d2_t r = ((const d2_t *)lds_rec)[tid + k * nt];
       if (SOA) {
-        ((double *)a.state)[row0 + tid + k * nt] = r[0];
+        if (!WRITE_Q && a.aos)  // the sweep's last pass: e goes back to the interleaved array
+          a.aos[row0 + tid + k * nt].x = r[0];
+        else
+          ((double *)a.state)[row0 + tid + k * nt] = r[0];
         if (WRITE_Q) a.state2[row0 + tid + k * nt] = r[1];
       } else {
         ((d2_t *)a.state)[row0 + tid + k * nt] = r;

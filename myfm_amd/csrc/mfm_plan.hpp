@@ -1035,6 +1035,22 @@ static void launch_huge(hipStream_t s, Timing &tm, const ParLevel &L, const Swee
   }
 }
 
+// split-layout sweeps: the first factor's first level reads e from the interleaved array, the last factor's final
+// apply pass writes it back there (SweepArgs::aos is set by the caller for the whole sweep)
+static inline SweepArgs soa_first_args(const SweepArgs &a) {
+  SweepArgs r = a;
+  if (a.aos) {
+    r.e_src = (const double *)a.aos;
+    r.e_src_stride = 2;
+  }
+  return r;
+}
+static inline SweepArgs soa_final_args(const SweepArgs &a, bool is_final_factor) {
+  SweepArgs r = a;
+  if (!is_final_factor) r.aos = nullptr;
+  return r;
+}
+
 // Is the last level's apply pass fusable with the next factor's first level (k_tile_apply_next)?
 static inline bool plan_supports_fused_next(const StepPlan &plan) {
   if (!plan_supports_soa(plan) || !plan.aligned_tiles) return false;
@@ -1155,9 +1171,10 @@ static void run_sweep_soa_multi(hipStream_t s, Timing &tm, const StepPlan &plan,
     an.row0 = plan.col_row0.p;
     if (f == f_begin) {
       const ParLevel &Lf = comm ? plan.local_level : L1;  // (sharded: the columns complete on this rank)
-      launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, Lf, a, ls, kc, plan.col_row0.p);
-      launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, Lf, a, ls, kc);
-      first_level_rest(a);
+      const SweepArgs a0 = soa_first_args(a);
+      launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, Lf, a0, ls, kc, plan.col_row0.p);
+      launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, Lf, a0, ls, kc);
+      first_level_rest(a0);
       TimedLaunch t(tm, s, kc.scat, 20.0 * T1.n_ent);
       hipLaunchKernelGGL(k_tile_old, dim3((T1.n_cols + 255) / 256), dim3(256), 0, s, a.theta, T1.scols.p, T1.n_cols,
                          ls.told_col.p);
@@ -1181,8 +1198,8 @@ static void run_sweep_soa_multi(hipStream_t s, Timing &tm, const StepPlan &plan,
     }
     if (!next) {
       TimedLaunch t(tm, s, kc.scat, 28.0 * TL.n_ent);
-      hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, false>), dim3(TL.n_tiles), dim3(nt), lds, s, a, TL.tent.p, TL.ent_val.p,
-                         TL.tile_ptr.p, TL.tile_row0.p, ls.oldnew_col.p, TL.tile_bits, TL.n_tiles, swz);
+      hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, false>), dim3(TL.n_tiles), dim3(nt), lds, s, soa_final_args(a, true),
+                         TL.tent.p, TL.ent_val.p, TL.tile_ptr.p, TL.tile_row0.p, ls.oldnew_col.p, TL.tile_bits, TL.n_tiles, swz);
       continue;
     }
     {
@@ -1294,8 +1311,9 @@ static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsO
         TimedLaunch t(tm, s, kc.scat, (last ? 48.0 : 56.0) * L.n_ent);
         launch_tile_head<PMainV, UNIT>(s, L, a, ls, swz, nullptr, last && fuse && fuse_stats && f > f_begin);
         if (last)
-          hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, false>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p,
-                             L.ent_val.p, L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz);
+          hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, false>), dim3(L.n_tiles), dim3(nt), lds, s,
+                             soa_final_args(a, f + 1 == f_end), L.tent.p, L.ent_val.p, L.tile_ptr.p, L.tile_row0.p,
+                             ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz);
         else
           hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, true>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p,
                              L.ent_val.p, L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz);
@@ -1303,8 +1321,9 @@ static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsO
       }
       if (first) {
         if (fuse && f > f_begin) continue;  // done by the previous factor's fused apply pass
-        launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, L, a, ls, kc, plan.col_row0.p);
-        launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, L, a, ls, kc);
+        const SweepArgs a0 = f == f_begin ? soa_first_args(a) : a;
+        launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, L, a0, ls, kc, plan.col_row0.p);
+        launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, L, a0, ls, kc);
       } else if (last) {
         launch_binned_level<PMainVsl, UNIT>(s, tm, L, a, ls, kc, plan.col_row0.p);
         launch_huge<PMainVsl, UNIT>(s, tm, L, a, ls, kc);
@@ -1389,7 +1408,7 @@ static void run_sweep_soa_sharded(hipStream_t s, Timing &tm, const StepPlan &pla
   raise_fused_lds_limit<UNIT>();
   {
     // first factor's first level: the locally complete columns in one pass, the special ones all-reduced
-    const SweepArgs a = args(f_begin);
+    const SweepArgs a = soa_first_args(args(f_begin));
     launch_binned_level<PMainVsq<UNIT>, UNIT>(s, tm, plan.local_level, a, ls, kc, plan.col_row0.p);
     launch_huge<PMainVsq<UNIT>, UNIT>(s, tm, plan.local_level, a, ls, kc);
     if (plan.n_special)
@@ -1417,8 +1436,8 @@ static void run_sweep_soa_sharded(hipStream_t s, Timing &tm, const StepPlan &pla
                        ls.S_col.p, ls.oldnew_col.p, next ? (const double *)an.theta : (const double *)nullptr, ls.vnext_col.p);
     if (!next) {
       TimedLaunch t(tm, s, kc.scat, 28.0 * L.n_ent);
-      hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, false>), dim3(L.n_tiles), dim3(nt), lds, s, a, L.tent.p, L.ent_val.p,
-                         L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz);
+      hipLaunchKernelGGL((k_tile_apply<PMainV, UNIT, true, false>), dim3(L.n_tiles), dim3(nt), lds, s, soa_final_args(a, true),
+                         L.tent.p, L.ent_val.p, L.tile_ptr.p, L.tile_row0.p, ls.oldnew_col.p, L.tile_bits, L.n_tiles, swz);
       continue;
     }
     an.row0 = plan.col_row0.p;
