@@ -1736,8 +1736,10 @@ __global__ __launch_bounds__(WAVE) void k_chain_lds(SweepArgs a, const ChainDesc
   int32_t c_col = 0, n_col = 0, c_len = 0, n_len = 0;
   int64_t c_begin = 0, n_begin = 0;
   double c_old = 0, n_old = 0, c_z = 0, n_z = 0, c_lam = 0, n_lam = 0, c_mu = 0, n_mu = 0;
-  int32_t cidx[CB], nidx[CB];
-  double cval[CB], nval[CB];
+  // two entries per lane and column are staged ahead (columns of up to 128 entries never touch global memory inside
+  // the chain: a load there costs the chain a full memory round trip per column)
+  int32_t cidx[CB], nidx[CB], cidx2[CB], nidx2[CB];
+  double cval[CB], nval[CB], cval2[CB], nval2[CB];
   auto load_desc = [&](int base) {
     dsc.len = 0;
     if (lane < CB && base + lane < n_cols) dsc = desc[base + lane];
@@ -1758,9 +1760,15 @@ __global__ __launch_bounds__(WAVE) void k_chain_lds(SweepArgs a, const ChainDesc
       const int l = __builtin_amdgcn_readlane(n_len, k);
       nidx[k] = -1;
       nval[k] = 0.0;
+      nidx2[k] = -1;
+      nval2[k] = 0.0;
       if (lane < l) {
         nidx[k] = a.rowidx[b + lane];
         nval[k] = a.val[b + lane];
+      }
+      if (lane + WAVE < l) {
+        nidx2[k] = a.rowidx[b + lane + WAVE];
+        nval2[k] = a.val[b + lane + WAVE];
       }
     }
     if (lane < CB) {
@@ -1784,6 +1792,8 @@ __global__ __launch_bounds__(WAVE) void k_chain_lds(SweepArgs a, const ChainDesc
     for (int k = 0; k < CB; k++) {
       cidx[k] = nidx[k];
       cval[k] = nval[k];
+      cidx2[k] = nidx2[k];
+      cval2[k] = nval2[k];
     }
     if (base + CB < n_cols) {
       load_batch();
@@ -1797,12 +1807,16 @@ __global__ __launch_bounds__(WAVE) void k_chain_lds(SweepArgs a, const ChainDesc
         const int64_t cbegin = readlane_i64(c_begin, k);
         const double old = readlane_f64(c_old, k);
         double S1 = 0.0, S2 = 0.0;
-        typename P::St st0;
+        typename P::St st0, st1;
         if (lane < clen) {
           st0 = P::load(al, cidx[k]);
           P::stats(cval[k], st0, old, S1, S2);
         }
-        for (int p = lane + WAVE; p < clen; p += WAVE) {
+        if (lane + WAVE < clen) {
+          st1 = P::load(al, cidx2[k]);
+          P::stats(cval2[k], st1, old, S1, S2);
+        }
+        for (int p = lane + 2 * WAVE; p < clen; p += WAVE) {
           const int32_t row = a.rowidx[cbegin + p];
           const double x = a.val[cbegin + p];
           const typename P::St st = P::load(al, row);
@@ -1812,7 +1826,8 @@ __global__ __launch_bounds__(WAVE) void k_chain_lds(SweepArgs a, const ChainDesc
         S2 = wave_allreduce_sum(S2);
         const double fresh = P::draw(S1, S2, old, a.alpha, readlane_f64(c_lam, k), readlane_f64(c_mu, k), readlane_f64(c_z, k));
         if (lane < clen) P::apply(al, cidx[k], cval[k], st0, old, fresh);
-        for (int p = lane + WAVE; p < clen; p += WAVE) {
+        if (lane + WAVE < clen) P::apply(al, cidx2[k], cval2[k], st1, old, fresh);
+        for (int p = lane + 2 * WAVE; p < clen; p += WAVE) {
           const int32_t row = a.rowidx[cbegin + p];
           const double x = a.val[cbegin + p];
           const typename P::St st = P::load(al, row);
