@@ -56,6 +56,7 @@ const char *mfm_global_error(void);
 int mfm_create(int device, mfm_ctx **out);
 void mfm_destroy(mfm_ctx *ctx);
 const char *mfm_last_error(const mfm_ctx *ctx);
+int mfm_get_device(const mfm_ctx *ctx); /* the HIP device index the context lives on */
 /* use an existing hipStream_t (e.g. torch's current stream) instead of the ctx's own. */
 int mfm_set_stream(mfm_ctx *ctx, void *hip_stream);
 int mfm_synchronize(mfm_ctx *ctx);
@@ -223,6 +224,17 @@ int mfm_design_predict(mfm_design *d, int32_t rank, int32_t n_samples, const dou
  * FMTrainer.hpp:78; utils/callbacks/libfm.py:85): scores design `d` with the (w0, w, V) currently
  * resident in training context `ctx` -- no download / upload of the model state. Same device only.  */
 int mfm_design_score_ctx(mfm_design *d, mfm_ctx *ctx, double *out);
+
+/* ---- test hooks: kernel-level access to the special functions / samplers of the classification and
+ * ordered-probit tasks, so that parity tests can hold them against the reference's own code ----------- */
+/* out[i] = the device erfcx(x[i]) used by mfm_oprobit_eval (reference: cpp_source/Faddeeva.cc erfcx, called from
+ * OProbitSampler.hpp:111-236).                                                                           */
+int mfm_test_erfcx(int device, const double *x, int64_t n, double *out);
+/* n draws of the device truncated-normal samplers (util.hpp:15-78) with unit deviation: kind 0 = left
+ * (z > lo, sample_truncated_normal_left), 1 = right (z < hi, :68-71), 2 = two-sided (lo < z < hi, :39-60). Draw i
+ * uses the Philox stream keyed (seed, draw_index, row = i) -- the keying of mfm_update_e_classification.        */
+int mfm_test_truncated_normal(int device, int32_t kind, double lo, double hi, uint64_t seed, uint64_t draw_index,
+                              int64_t n, double *out);
 
 /* ---- host-only helpers (no device needed; exercised by the CPU test-suite) -------------- */
 /* Level schedule of the columns of a CSR matrix: level[j] = 0 if no earlier

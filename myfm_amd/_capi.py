@@ -28,6 +28,7 @@ SYMBOLS = [
     "mfm_design_destroy", "mfm_design_last_error", "mfm_design_dim_all", "mfm_design_predict",
     "mfm_host_column_levels", "mfm_rng_seed_mt19937", "mfm_rng_set_program", "mfm_rng_prefetch", "mfm_rng_acquire",
     "mfm_rng_get_z", "mfm_design_score_ctx", "mfm_design_n_rows", "mfm_set_allreduce", "mfm_set_row_offset", "mfm_set_main_levels",
+    "mfm_test_erfcx", "mfm_test_truncated_normal", "mfm_get_device",
 ]
 
 _lib = None
@@ -112,6 +113,9 @@ def lib():
     L.mfm_set_allreduce.argtypes = [vp, vp, vp]
     L.mfm_set_row_offset.argtypes = [vp, i64]
     L.mfm_set_main_levels.argtypes = [vp, P, i64]
+    L.mfm_get_device.argtypes = [vp]
+    L.mfm_test_erfcx.argtypes = [C.c_int, P, i64, P]
+    L.mfm_test_truncated_normal.argtypes = [C.c_int, i32, dbl, dbl, u64, u64, i64, P]
     _lib = L
     return L
 
@@ -150,6 +154,26 @@ def column_levels(X):
     if rc:
         _raise(rc, lib().mfm_global_error())
     return level, n.value
+
+
+def device_erfcx(x, device=0):
+    """the device erfcx of mfm_oprobit_eval on x (test hook)"""
+    x = _f64(x)
+    out = np.empty_like(x)
+    rc = lib().mfm_test_erfcx(device, _p(x), x.size, _p(out))
+    if rc:
+        _raise(rc, lib().mfm_global_error())
+    return out
+
+
+def device_truncated_normal(kind, lo, hi, n, seed=1, draw_index=0, device=0):
+    """n draws of the device truncated-normal samplers (test hook): kind 'left' (z > lo), 'right' (z < hi), 'twoside'"""
+    k = {"left": 0, "right": 1, "twoside": 2}[kind]
+    out = np.empty(n)
+    rc = lib().mfm_test_truncated_normal(device, k, float(lo), float(hi), seed, draw_index, n, _p(out))
+    if rc:
+        _raise(rc, lib().mfm_global_error())
+    return out
 
 
 class Context:

@@ -213,11 +213,19 @@ size_t check_row_consistency_return_column(const Csr &X, const Relations &relati
   return col;
 }
 
+// The GPU this process works on: MYFM_AMD_DEVICE (one process per GPU sets it to its local rank), default 0.
+// Training contexts and prediction designs are created on the same device.
+int selected_device() {
+  if (const char *e = std::getenv("MYFM_AMD_DEVICE")) return std::atoi(e);
+  return 0;
+}
+
 // A prediction design resident on the GPU for the duration of one call.
 struct DeviceDesign {
   mfm_design *d = nullptr;
-  DeviceDesign(const Csr &X, const Relations &rels) {
-    int code = mfm_design_create(0, X.rows, X.cols, X.indptr.data(), X.indices.data(), X.data.data(), &d);
+  DeviceDesign(const Csr &X, const Relations &rels, int device = -1) {
+    if (device < 0) device = selected_device();
+    int code = mfm_design_create(device, X.rows, X.cols, X.indptr.data(), X.indices.data(), X.data.data(), &d);
     if (code != MFM_OK) throw_code(code, mfm_global_error());
     for (auto &r : rels) {
       auto m = r->map64();
@@ -274,7 +282,7 @@ struct FM {
     Csr X = csr_from_py(Xo);
     Relations rels = relations_from_py(relso);
     check(X, rels);
-    auto dd = std::make_shared<DeviceDesign>(X, rels);
+    auto dd = std::make_shared<DeviceDesign>(X, rels, live_ctx ? mfm_get_device(live_ctx) : -1);
     if (design_cache->size() >= 4) design_cache->erase(design_cache->begin());
     design_cache->push_back(CachedDesign{Xo, rl, dd});
     return dd;
@@ -286,12 +294,17 @@ struct FM {
       : n_factors(K), w0(w0), w(std::move(w)), V(std::move(V)), cutpoints(std::move(cutpoints)), initialized(true) {}
   // a kept sample is a plain host copy
   FM snapshot() {
-    ensure();
     FM s;
     s.n_factors = n_factors;
     s.w0 = w0;
-    s.w = w;
-    s.V = V;
+    if (stale && fetch) {
+      // straight into the copy: the live sample stays device-resident, so callbacks that score it afterwards keep
+      // the cached-design path (predict_score) instead of re-uploading the test design every iteration
+      fetch(s);
+    } else {
+      s.w = w;
+      s.V = V;
+    }
     s.cutpoints = cutpoints;
     s.initialized = initialized;  // (a kept sample is detached from the training context)
     return s;
@@ -809,9 +822,7 @@ struct FMTrainer {
   void build_device(int rank) {
     if (ctx) return;
     K = rank;
-    int device = 0;
-    if (const char *e = std::getenv("MYFM_AMD_DEVICE")) device = std::atoi(e);
-    int code = mfm_create(device, &ctx);
+    int code = mfm_create(selected_device(), &ctx);
     if (code != MFM_OK) throw_code(code, mfm_global_error());
     if (stream_ptr) ck(ctx, mfm_set_stream(ctx, (void *)stream_ptr));
     if (!allreduce.is_none() && allreduce.ptr() != nullptr) {

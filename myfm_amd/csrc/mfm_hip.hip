@@ -363,6 +363,8 @@ void mfm_destroy(mfm_ctx *ctx) {
   delete ctx;
 }
 
+int mfm_get_device(const mfm_ctx *ctx) { return ctx ? ctx->device : -1; }
+
 const char *mfm_last_error(const mfm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_global_error.c_str(); }
 
 int mfm_set_stream(mfm_ctx *ctx, void *hip_stream) {

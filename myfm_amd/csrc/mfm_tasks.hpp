@@ -245,9 +245,64 @@ __global__ __launch_bounds__(WG) void k_oprobit_sample_z(double2 *__restrict__ e
   eq[t].x = pred - z;
 }
 
+// ---- kernel-level test hooks (include/myfm_hip.h "test hooks"): the device erfcx and the truncated-normal samplers on
+// caller-supplied arguments, so that the parity tests can hold them against Faddeeva.cc / util.hpp directly
+__global__ void k_test_erfcx(const double *__restrict__ x, double *__restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = d_erfcx(x[i]);
+}
+// kind 0: left (z > lo), 1: right (z < hi), 2: two-sided (lo < z < hi); draw i uses the stream of row i
+__global__ void k_test_tn(int kind, double lo, double hi, uint64_t seed, uint64_t draw, int64_t n, double *__restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  RowRng g(seed ^ ((uint64_t)(t >> 32) * 0x9E3779B97F4A7C15ull), draw, (uint32_t)t);
+  out[t] = kind == 0 ? tn_left(g, lo) : (kind == 1 ? tn_right(g, hi) : tn_twoside(g, lo, hi));
+}
+
 }  // namespace mfm
 
 extern "C" {
+
+static int test_hook_run(int device, int64_t n, const double *in, double *out, int kind, double lo, double hi, uint64_t seed,
+                         uint64_t draw) {
+  try {
+    if (mfm_device_count() <= 0) throw Error(MFM_ERR_DEVICE, "no HIP device is visible (no CPU fallback)");
+    if (n < 0) throw Error(MFM_ERR_INVALID, "negative count");
+    MFM_HIP_CHECK(hipSetDevice(device));
+    if (n == 0) return MFM_OK;
+    DevBuf<double> din, dout;
+    dout.alloc((size_t)n);
+    if (in) {
+      din.alloc((size_t)n);
+      MFM_HIP_CHECK(hipMemcpy(din.p, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(k_test_erfcx, dim3(cdiv(n, 256)), dim3(256), 0, 0, din.p, dout.p, n);
+    } else {
+      hipLaunchKernelGGL(k_test_tn, dim3(cdiv(n, 256)), dim3(256), 0, 0, kind, lo, hi, seed, draw, n, dout.p);
+    }
+    MFM_HIP_CHECK(hipGetLastError());
+    MFM_HIP_CHECK(hipMemcpy(out, dout.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return MFM_OK;
+  } catch (const mfm::Error &ex) {
+    g_global_error = ex.what();
+    return ex.code;
+  } catch (const std::exception &ex) {
+    g_global_error = ex.what();
+    return MFM_ERR_RUNTIME;
+  }
+}
+
+int mfm_test_erfcx(int device, const double *x, int64_t n, double *out) {
+  return test_hook_run(device, n, x, out, 0, 0.0, 0.0, 0, 0);
+}
+
+int mfm_test_truncated_normal(int device, int32_t kind, double lo, double hi, uint64_t seed, uint64_t draw_index, int64_t n,
+                              double *out) {
+  if (kind < 0 || kind > 2) {
+    g_global_error = "kind must be 0 (left), 1 (right) or 2 (two-sided)";
+    return MFM_ERR_INVALID;
+  }
+  return test_hook_run(device, n, nullptr, out, kind, lo, hi, seed, draw_index);
+}
 
 int mfm_update_e_classification(mfm_ctx *ctx, uint64_t seed, uint64_t draw_index) {
   MFM_TRY(ctx)

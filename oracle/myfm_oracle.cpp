@@ -646,6 +646,23 @@ struct OprobitSampler {
     return false;
   }
 
+  // the row loop of operator() (OProbitSampler.hpp:402-413): log-likelihood, d/dgamma and the gamma-space Hessian
+  // accumulated over the group's rows in index order (what the device's mfm_oprobit_eval returns)
+  void eval_rows(const vector<Real> &gamma, Real &ll, vector<Real> &dgamma, vector<Real> *Ht) const {
+    const vector<Real> &x = *x_;
+    const vector<Real> &y = *y_;
+    for (auto i : indices_) {
+      int label = (int)y[i];
+      if (label == 0) {
+        safe_lcdf(gamma[0] - x[i], ll, dgamma[0], Ht, label);
+      } else if (label == (K - 1)) {
+        safe_lccdf(gamma[K - 2] - x[i], ll, dgamma[K - 2], Ht, label);
+      } else {
+        safe_ldiff(gamma[label] - x[i], gamma[label - 1] - x[i], ll, dgamma[label], dgamma[label - 1], Ht, label);
+      }
+    }
+  }
+
   // OProbitSampler.hpp:389-463 (operator())
   Real eval(const vector<Real> &alpha, vector<Real> &dalpha, vector<Real> *Ht) {
     int m = n();
@@ -656,18 +673,7 @@ struct OprobitSampler {
     jacobian_dgamma_dalpha(J, alpha);
     Real ll = 0;
     if (Ht) std::fill(Ht->begin(), Ht->end(), 0);
-    const vector<Real> &x = *x_;
-    const vector<Real> &y = *y_;
-    for (auto i : indices_) {
-      int label = (int)y[i];
-      if (label == 0) {
-        safe_lcdf(gamma[0] - x[i], ll, dalpha[0], Ht, label);
-      } else if (label == (K - 1)) {
-        safe_lccdf(gamma[K - 2] - x[i], ll, dalpha[K - 2], Ht, label);
-      } else {
-        safe_ldiff(gamma[label] - x[i], gamma[label - 1] - x[i], ll, dalpha[label], dalpha[label - 1], Ht, label);
-      }
-    }
+    eval_rows(gamma, ll, dalpha, Ht);
     if (Ht) {
       vector<Real> &Hh = *Ht;
       vector<Real> expAlpha(m);
@@ -1350,5 +1356,33 @@ void orc_tn_twoside_many(uint32_t seed, double lo, double hi, int64_t n, double 
   for (int64_t i = 0; i < n; i++) out[i] = orc::sample_truncated_normal_twoside(g, lo, hi);
 }
 double orc_erfcx(double x) { return orc::erfcx(x); }
+
+// OprobitSampler::operator() (OProbitSampler.hpp:389-463) on given scores x[n] and labels y[n], rows[n_rows] of one
+// cutpoint group. gamma-space part (the row loop, :402-413): ll, dgamma[K-1], Hg[(K-1)^2]; and the full
+// alpha-space result of operator(): returns -ll (with the prior), dalpha[K-1], Ha[(K-1)^2]. Any output may be NULL.
+int orc_oprobit_eval(int n_class, const double *alpha, double reg, const double *x, const double *y, int64_t n,
+                     const int64_t *rows, int64_t n_rows, double *ll_rows, double *dgamma, double *Hg, double *neg_ll,
+                     double *dalpha, double *Ha) {
+  ORC_TRY
+  std::vector<double> xv(x, x + n), yv(y, y + n);
+  std::vector<int64_t> idx(rows, rows + n_rows);
+  std::mt19937 gen(0);
+  orc::OprobitSampler s(xv, yv, n_class, idx, gen, reg, 5.0);
+  const int m = n_class - 1;
+  std::vector<double> a(alpha, alpha + m), gamma(m, 0.0), dg(m, 0.0), H((size_t)m * m, 0.0);
+  orc::OprobitSampler::alpha_to_gamma(gamma, a);
+  double ll = 0;
+  s.eval_rows(gamma, ll, dg, &H);
+  if (ll_rows) *ll_rows = ll;
+  if (dgamma) std::copy(dg.begin(), dg.end(), dgamma);
+  if (Hg) std::copy(H.begin(), H.end(), Hg);
+  std::vector<double> da(m, 0.0), Hh((size_t)m * m, 0.0);
+  double v = s.eval(a, da, &Hh);
+  if (neg_ll) *neg_ll = v;
+  if (dalpha) std::copy(da.begin(), da.end(), dalpha);
+  if (Ha) std::copy(Hh.begin(), Hh.end(), Ha);
+  return 0;
+  ORC_CATCH(0)
+}
 
 }  // extern "C"

@@ -82,6 +82,7 @@ def lib():
         L.orc_tn_twoside_many.argtypes = [C.c_uint32, dbl, dbl, i64, P]
         L.orc_erfcx.restype = dbl
         L.orc_erfcx.argtypes = [dbl]
+        L.orc_oprobit_eval.argtypes = [C.c_int, P, dbl, P, P, i64, P, i64, C.POINTER(dbl), P, P, C.POINTER(dbl), P, P]
         _lib = L
     return _lib
 
@@ -276,6 +277,36 @@ class OracleTrainer:
         if n:
             lib().orc_trace_get(self.h, _p(out))
         return out.reshape(-1, 5)
+
+
+def oprobit_eval(n_class, alpha, scores, y, rows=None, reg=1.0):
+    """OprobitSampler::operator() (OProbitSampler.hpp:389-463) on given scores / labels for the rows of one cutpoint
+    group: dict(ll, dgamma, Hg) = the row loop in gamma space (:402-413), (neg_ll, dalpha, Ha) = the full result."""
+    alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+    m = n_class - 1
+    assert alpha.shape[0] == m
+    x = np.ascontiguousarray(scores, dtype=np.float64)
+    yv = np.ascontiguousarray(y, dtype=np.float64)
+    rows = np.arange(x.shape[0], dtype=np.int64) if rows is None else np.ascontiguousarray(rows, dtype=np.int64)
+    ll, nll = C.c_double(), C.c_double()
+    dg, Hg, da, Ha = np.empty(m), np.empty((m, m)), np.empty(m), np.empty((m, m))
+    _check(lib().orc_oprobit_eval(n_class, _p(alpha), float(reg), _p(x), _p(yv), x.shape[0], _p(rows), rows.shape[0],
+                                  C.byref(ll), _p(dg), _p(Hg), C.byref(nll), _p(da), _p(Ha)))
+    return dict(ll=ll.value, dgamma=dg, Hg=Hg, neg_ll=nll.value, dalpha=da, Ha=Ha)
+
+
+def tn_left_many(seed, mu_minus, n):
+    """util.hpp:15-37 on a std::mt19937(seed): n draws of z ~ N(0,1) | z > mu_minus"""
+    out = np.empty(n)
+    lib().orc_tn_left_many(seed, float(mu_minus), n, _p(out))
+    return out
+
+
+def tn_twoside_many(seed, lo, hi, n):
+    """util.hpp:39-60: n draws of z ~ N(0,1) | lo < z < hi"""
+    out = np.empty(n)
+    lib().orc_tn_twoside_many(seed, float(lo), float(hi), n, _p(out))
+    return out
 
 
 class OracleDesign:

@@ -193,3 +193,78 @@ def movielens_like_shard(rows_per_rank, rank, world, n_users, n_items, rank_true
     indices[1::2] = n_users + i
     X = sps.csr_matrix((np.ones(2 * rows_per_rank), indices, indptr), shape=(rows_per_rank, n_users + n_items))
     return X, y, [n_users, n_items], lo, total
+
+
+def _onehot(idx, n):
+    idx = np.asarray(idx)
+    return sps.csr_matrix((np.ones(len(idx)), (np.arange(len(idx)), idx)), shape=(len(idx), n))
+
+
+def _multihot(rng, n_rows, n_cols, mean):
+    """multi-hot rows with Poisson(mean) distinct columns, values 1 / sqrt(n) (utils/encoders/multi_value.py:51-82)"""
+    rows, cols, vals = [], [], []
+    for r in range(n_rows):
+        k = min(max(1, rng.poisson(mean)), n_cols)
+        c = np.sort(rng.choice(n_cols, size=k, replace=False))
+        rows += [r] * k
+        cols += list(c)
+        vals += [1.0 / np.sqrt(k)] * k
+    return sps.csr_matrix((vals, (rows, cols)), shape=(n_rows, n_cols))
+
+
+def ml100k_extended_like(n_rows=80000, n_users=943, n_items=1682, seed=0, implicit_user=85, implicit_item=48):
+    """BASELINE configs[3] / SURVEY 8d config 4: ML-100k-extended-shaped relation blocks (examples/ml-100k-extended.ipynb
+    cells 2-10): main table = one-hot date (212 columns); user block = [id 944 | age bin 10 | occupation 21 | zip 10 |
+    implicit movies 1683 multi-hot]; movie block = [id 1683 | year bin 10 | genres 19 multi-hot | implicit users 944
+    multi-hot]; maps drawn with the popularity profile of config 2.
+    Returns (main csr, [(map, block csr), ...], y, group_shapes)."""
+    rng = np.random.default_rng(seed)
+    pu = 1.0 / (np.arange(1, n_users + 1) + 30.0)
+    pi = 1.0 / (np.arange(1, n_items + 1) + 20.0)
+    u = rng.choice(n_users, size=n_rows, p=pu / pu.sum())
+    it = rng.choice(n_items, size=n_rows, p=pi / pi.sum())
+    date = rng.integers(0, 212, size=n_rows)
+    main = _onehot(date, 212)
+    ub = sps.hstack([_onehot(np.arange(n_users), n_users + 1), _onehot(rng.integers(0, 10, n_users), 10),
+                     _onehot(rng.integers(0, 21, n_users), 21), _onehot(rng.integers(0, 10, n_users), 10),
+                     _multihot(rng, n_users, n_items + 1, implicit_user)]).tocsr()
+    ib = sps.hstack([_onehot(np.arange(n_items), n_items + 1), _onehot(rng.integers(0, 10, n_items), 10),
+                     _multihot(rng, n_items, 19, 2), _multihot(rng, n_items, n_users + 1, implicit_item)]).tocsr()
+    shapes = [212, n_users + 1, 10, 21, 10, n_items + 1, n_items + 1, 10, 19, n_users + 1]
+    bu, bi = rng.normal(size=n_users) * 0.4, rng.normal(size=n_items) * 0.4
+    y = np.clip(np.round(3.5 + bu[u] + bi[it] + rng.normal(size=n_rows)), 1, 5)
+    return main, [(u.astype(np.int64), ub), (it.astype(np.int64), ib)], y, shapes
+
+
+def config5_like(scale=0.01, seed=2, ordered=True):
+    """BASELINE configs[4] / SURVEY 8d config 5 at `scale` (1.0: N = 50 M rows, main table = two one-hot fields
+    500 000 + 50 000, four relation blocks: user-side 500 000 x 2000 (10 nnz / row), item-side 50 000 x 1000 (10),
+    two context blocks 1000 x 200 (5)); targets 0..4 cut at the 20/40/60/80 % quantiles of a latent score (ordered)
+    or the latent score itself. Returns (main csr sorted by user, blocks, y, group_shapes)."""
+    rng = np.random.default_rng(seed)
+    N = int(50_000_000 * scale)
+    nu, ni = max(1000, int(500_000 * scale)), max(200, int(50_000 * scale))
+    u = np.sort(rng.integers(0, nu, size=N)).astype(np.int32)
+    it = rng.integers(0, ni, size=N).astype(np.int32)
+    indices = np.empty(2 * N, dtype=np.int32)
+    indices[0::2] = u
+    indices[1::2] = nu + it
+    main = sps.csr_matrix((np.ones(2 * N), indices, np.arange(0, 2 * N + 1, 2, dtype=np.int64)), shape=(N, nu + ni))
+
+    def block(n_rows, n_cols, per_row):
+        cols = rng.integers(0, n_cols, size=(n_rows, per_row))
+        cols.sort(axis=1)
+        keep = np.ones_like(cols, dtype=bool)
+        keep[:, 1:] = cols[:, 1:] != cols[:, :-1]  # drop duplicate columns inside a row
+        rows = np.repeat(np.arange(n_rows), per_row).reshape(n_rows, per_row)
+        return sps.csr_matrix((np.full(keep.sum(), 1.0 / np.sqrt(per_row)), (rows[keep], cols[keep])), shape=(n_rows, n_cols))
+
+    blocks = [(u.astype(np.int64), block(nu, 2000, 10)), (it.astype(np.int64), block(ni, 1000, 10)),
+              (rng.integers(0, 1000, size=N), block(1000, 200, 5)), (rng.integers(0, 1000, size=N), block(1000, 200, 5))]
+    score = rng.normal(size=N) + 0.5 * np.sin(u * 0.01) + 0.3 * np.cos(it * 0.1)
+    if ordered:
+        y = np.digitize(score, np.quantile(score[: min(N, 1_000_000)], [0.2, 0.4, 0.6, 0.8])).astype(np.float64)
+    else:
+        y = score
+    shapes = [nu, ni] + [b.shape[1] for _, b in blocks]
+    return main, blocks, y, shapes

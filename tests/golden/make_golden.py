@@ -6,6 +6,7 @@ What the fixtures are anchored on:
                                place into oracle/_ref/libfaddeeva_ref.so (oracle/Makefile), called on a fixed grid.
                                erfcx is what the truncated-normal samplers and the ordered-probit likelihood of
                                the reference rest on (util.hpp:15-78, OProbitSampler.hpp:29-60).
+  * faddeeva_erfcx_wide.npz -- same source, the large-|x| ranges (continued-fraction branch, overflow threshold).
   * libstdcxx_stream.npz    -- std::mt19937 + libstdc++ normal_distribution / gamma_distribution (the engine and
                                distributions the reference draws from, FMTrainer.hpp:122-125,142-143,164-165),
                                produced by the oracle's extern "C" wrappers around the real libstdc++ classes.
@@ -43,6 +44,17 @@ def faddeeva():
                         np.array([1e-12, -1e-12, 1e-3, 0.49999, 0.5, 2.99999, 3.0, 3.00001])])
     np.savez(os.path.join(OUT, "faddeeva_erfcx.npz"), x=x, erfcx=np.array([R.ref_erfcx(float(v)) for v in x]),
              erfc=np.array([R.ref_erfc(float(v)) for v in x]), erf=np.array([R.ref_erf(float(v)) for v in x]))
+
+
+def faddeeva_wide():
+    """the ranges the first grid is thin on: the continued-fraction branch of the device / oracle erfcx (x >= 3,
+    three depth classes, the asymptotic tail) and large negative arguments up to the overflow threshold."""
+    R = O.ref_faddeeva()
+    if R is None:
+        raise SystemExit("oracle/_ref/libfaddeeva_ref.so missing: run `make -C oracle ref` where /root/reference exists")
+    x = np.concatenate([np.geomspace(3.0, 1e8, 97), np.array([4.99999, 5.0, 5.00001, 9.99999, 10.0, 10.00001, 4.9e7, 5.1e7]),
+                        -np.geomspace(1e-6, 26.6, 64), np.linspace(-26.7, -6.0, 32)])
+    np.savez(os.path.join(OUT, "faddeeva_erfcx_wide.npz"), x=x, erfcx=np.array([R.ref_erfcx(float(v)) for v in x]))
 
 
 def stream():
@@ -103,4 +115,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--only-wide" in sys.argv:  # added later: leaves the other (already committed) fixtures untouched
+        O.build()
+        faddeeva_wide()
+    else:
+        main()
+        faddeeva_wide()
