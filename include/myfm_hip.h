@@ -100,7 +100,8 @@ int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launche
  * bit 1 = all stored values are 1.0 (values never read), bit 2 = uniform row length (rowptr never read),
  * bit 3 = row-sharded (mfm_set_allreduce), bit 4 = split e / q arrays during update_V,
  * bit 5 = the last level's apply pass also runs the next factor's first level (k_tile_apply_next),
- * bit 6 = row-sharded with the fused tile path (first-level columns swept where their rows live). */
+ * bit 6 = row-sharded with the fused tile path (first-level columns swept where their rows live),
+ * bit 7 = two-field pass (two one-hot-like levels: one pass over the residual per factor, no q-cache in HBM). */
 int mfm_plan_flags(const mfm_ctx *ctx);
 
 /* ---- model state (FM.hpp:164-168) ------------------------------------------------------ */

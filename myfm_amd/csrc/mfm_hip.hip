@@ -74,6 +74,7 @@ struct mfm_ctx {
   int gs_chunks = 1;            // chunks of the largest group
   DevBuf<double> ec, qc;        // split e / q arrays of the latent sweep (soa), compact residual (qfree)
   bool qfree = false, soa = false, fuse_next = false;
+  bool mf = false;              // two-field pass (run_sweep_mf): no q-cache in HBM during update_V
   bool sharded_fused = false;   // row-sharded + fused tile path (run_sweep_soa_sharded)
   int q_stale_factor = -1;      // >= 0: the stored q column is stale, mfm_get_q rebuilds it for this factor first
   DevBuf<double> sync_mask;     // [D] 1: this rank contributes the column to the model synchronisation
@@ -598,6 +599,8 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     c->ec.alloc((size_t)c->N);
     c->qc.alloc((size_t)c->N);
     c->fuse_next = plan_supports_fused_next(c->plan_V) && !std::getenv("MFM_NO_FUSED_NEXT");
+    c->mf = c->fuse_next && plan_supports_mf(c->plan_V) && !std::getenv("MFM_NO_MF") && !std::getenv("MFM_NO_FUSED_TWO") &&
+            !std::getenv("MFM_NO_FUSED_STATS");
   }
   MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
   // host copies are no longer needed
@@ -623,7 +626,7 @@ int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launche
 
 int mfm_plan_flags(const mfm_ctx *ctx) {
   return (ctx->qfree ? 1 : 0) | (ctx->X.unit ? 2 : 0) | (ctx->X.ell_width >= 0 ? 4 : 0) | (ctx->comm.active() ? 8 : 0) |
-         (ctx->soa ? 16 : 0) | (ctx->fuse_next ? 32 : 0) | (ctx->sharded_fused ? 64 : 0);
+         (ctx->soa ? 16 : 0) | (ctx->fuse_next ? 32 : 0) | (ctx->sharded_fused ? 64 : 0) | (ctx->mf ? 128 : 0);
 }
 
 // ---- state ------------------------------------------------------------------------------------
@@ -946,7 +949,12 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       return a;
     };
     const bool fuse = c->fuse_next;
-    if (c->X.unit)
+    if (c->mf) {
+      if (c->X.unit)
+        run_sweep_mf<true>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv);
+      else
+        run_sweep_mf<false>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv);
+    } else if (c->X.unit)
       run_sweep_soa<true>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, fuse);
     else
       run_sweep_soa<false>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, fuse);

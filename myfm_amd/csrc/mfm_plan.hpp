@@ -19,6 +19,7 @@
 
 #include "mfm_common.hpp"
 #include "mfm_kernels.hpp"
+#include "mfm_mf_kernels.hpp"
 
 namespace mfm {
 
@@ -188,6 +189,12 @@ struct StepPlan {
   DevBuf<double2> long_partial, oldnew_long;
   int n_long_cols = 0, n_long_tiles = 0;
   bool aligned_tiles = false;
+  // two-field pass (mfm_mf_kernels.hpp): per 64-row chunk of every tile the first-level column heads, per column of
+  // fuse_desc its partials
+  DevBuf<MfChunk> mf_chunk;
+  DevBuf<int32_t> mf_chunk_ptr;
+  DevBuf<int2> mf_upart;
+  bool mf_ready = false;
 
   // a level is "tiny" when running it as its own launches cannot fill the device anyway
   static bool tiny(size_t n_cols, int64_t nnz) { return n_cols <= 8 && nnz <= 16384; }
@@ -457,11 +464,15 @@ struct StepPlan {
     (void)nnz_all;
     std::vector<int32_t> fcols, fptr, lcols, lptr, ltiles, solo, empties;
     h_tile_start.clear();
-    int64_t cur_rows = 0, next_row = 0;
+    int64_t cur_rows = 0, next_row = 0, cur_cols = 0;
+    int tb = 0;
+    while (((int64_t)1 << tb) < RB) tb++;
+    const int64_t col_cap = mf_user_cap(tb);  // columns with rows per tile (k_mf_pass keeps their scalars in LDS)
     auto open_tile = [&](int64_t row) {
       h_tile_start.push_back((int32_t)row);
       fptr.push_back((int32_t)fcols.size());
       cur_rows = 0;
+      cur_cols = 0;
     };
     for (int32_t j : order) {
       const int64_t len = csc.ptr[j + 1] - csc.ptr[j];
@@ -493,9 +504,10 @@ struct StepPlan {
         }
         cur_rows = RB;  // closed
       } else {
-        if (h_tile_start.empty() || cur_rows + len > RB) open_tile(r0);
+        if (h_tile_start.empty() || cur_rows + len > RB || cur_cols + 1 > col_cap) open_tile(r0);
         fcols.push_back(j);
         cur_rows += len;
+        cur_cols += 1;
       }
       next_row = r0 + len;
     }
@@ -541,6 +553,41 @@ struct StepPlan {
                               group_of && (size_t)j < group_of->size() ? (*group_of)[j] : 0);
         }
       fuse_desc.upload(desc.data(), desc.size());
+      // chunk heads / partial indices for the two-field pass
+      const size_t nt_ = h_tile_start.size() - 1;
+      std::vector<int32_t> cptr(nt_ + 1, 0);
+      for (size_t b = 0; b < nt_; b++) cptr[b + 1] = cptr[b] + (h_tile_start[b + 1] - h_tile_start[b] + WAVE - 1) / WAVE;
+      std::vector<MfChunk> chunks((size_t)cptr[nt_], MfChunk{1ull, 0, 0});
+      std::vector<int2> upart(fcols.size(), make_int2(0, 0));
+      for (size_t b = 0; b < nt_; b++) {
+        MfChunk *C = chunks.data() + cptr[b];
+        const int nch = cptr[b + 1] - cptr[b];
+        if (fptr[b + 1] == fptr[b]) continue;  // tile of a long / special column
+        for (int c = 0; c < nch; c++) C[c].heads = 0ull;
+        int ul = 0;
+        for (int32_t k = fptr[b]; k < fptr[b + 1]; k++, ul++) {
+          if (desc[k].y == 0) continue;  // (never-occurring columns follow the ones with rows)
+          const int lr0 = desc[k].z;
+          C[lr0 >> 6].heads |= 1ull << (lr0 & 63);
+          for (int c = lr0 >> 6; c <= (lr0 + desc[k].y - 1) >> 6; c++)
+            if (c > (lr0 >> 6) || (lr0 & 63) == 0) C[c].ubase = ul;  // owner of the chunk's first row
+        }
+        int pidx = 0;
+        for (int c = 0; c < nch; c++) {
+          C[c].pbase = pidx;
+          pidx += __builtin_popcountll(C[c].heads | 1ull);
+        }
+        for (int32_t k = fptr[b]; k < fptr[b + 1]; k++) {
+          if (desc[k].y == 0) continue;
+          const int lr0 = desc[k].z, ca = lr0 >> 6, cb = (lr0 + desc[k].y - 1) >> 6;
+          const int seg = __builtin_popcountll(C[ca].heads & ((2ull << (lr0 & 63)) - 2ull));
+          upart[k] = make_int2(C[ca].pbase + seg, cb - ca + 1);
+        }
+      }
+      mf_chunk.upload(chunks.data(), chunks.size());
+      mf_chunk_ptr.upload(cptr);
+      mf_upart.upload(upart.data(), upart.size());
+      mf_ready = true;
     }
     {
       const size_t nt = h_tile_start.size() - 1;
@@ -734,6 +781,7 @@ struct LongScratch {
   DevBuf<double2> S_compact;   // sharded fused path: statistics of the special first-level columns
   DevBuf<double> told_col;     // multi-level fused flow: current coefficient per column of the level whose statistics are taken
   std::vector<DevBuf<double>> vnext_lvl;  // ... and per tile level: next factor's coefficient per column (MULTIQ)
+  DevBuf<double2> dv_col;      // two-field pass: (delta of this factor, coefficient of the next) per second-level column
   void reserve_cols(int64_t n_cols) {
     if ((size_t)n_cols > oldnew_col.n) {
       oldnew_col.alloc((size_t)n_cols);
@@ -1332,6 +1380,129 @@ static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsO
         launch_huge<PMainVs, UNIT>(s, tm, L, a, ls, kc);
       }
     }
+  }
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
+// ---- two-field pass (mfm_mf_kernels.hpp) --------------------------------------------------------------------
+// Two levels, each covering every row once; the first contiguous (table sorted by it) with tiles aligned to it, the
+// second on those row tiles.
+static inline bool plan_supports_mf(const StepPlan &plan) {
+  if (!plan_supports_fused_next(plan) || plan.steps.size() != 2 || !plan.mf_ready || plan.n_solo_tiles) return false;
+  const ParLevel &first = plan.steps.front().par, &last = plan.steps.back().par;
+  return first.first_and_once && last.covers_rows_once && last.tile_bits >= 9 && last.tile_bits <= 13;
+}
+
+static inline int mf_rows_per_thread() {
+  const char *e = std::getenv("MFM_MF_K");  // (read per sweep: the tests switch it inside one process)
+  return e && std::atoi(e) == 4 ? 4 : 8;
+}
+
+// Latent sweep of factors [f_begin, f_end): args(f).state = e[N] (split array), .aos = the interleaved {e, q} array the
+// residual is read from at the start and written back to at the end. K + 1 passes over the residual for K factors.
+template <bool UNIT, class ArgsOf>
+static void run_sweep_mf(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf args, int f_begin, int f_end, LongScratch &ls,
+                         const SweepClasses &kc) {
+  const ParLevel &L = plan.steps.back().par;
+  const int swz = xcd_swizzle_enabled();
+  const int KR = mf_rows_per_thread();
+  const int nt = (1 << L.tile_bits) / KR;
+  const size_t lds = mf_lds_bytes(L.tile_bits, UNIT);
+  {
+    static bool raised = false;
+    if (!raised) {
+      const int lim = (int)CHAIN_LDS_MAX;
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_pass<UNIT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_pass<UNIT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_long_finish<UNIT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_long_finish<UNIT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      raised = true;
+    }
+  }
+  if (ls.dv_col.n < (size_t)L.n_cols) ls.dv_col.alloc((size_t)std::max(L.n_cols, 1));
+  const SweepArgs a0 = args(f_begin);
+  MfArgs m;
+  std::memset(&m, 0, sizeof(m));
+  m.E = (double *)a0.state;
+  m.tile_row0 = L.tile_row0.p;
+  m.tile_ptr = L.tile_ptr.p;
+  m.tent = L.tent.p;
+  m.tval = L.ent_val.p;
+  m.tile_bits = L.tile_bits;
+  m.n_tiles = L.n_tiles;
+  m.swz = swz;
+  m.ucap = mf_user_cap(L.tile_bits);
+  m.dv = ls.dv_col.p;
+  m.udesc = plan.fuse_desc.p;
+  m.ucol_ptr = plan.fuse_col_ptr.p;
+  m.upart = plan.mf_upart.p;
+  m.chunk = plan.mf_chunk.p;
+  m.chunk_ptr = plan.mf_chunk_ptr.p;
+  m.alpha = a0.alpha;
+  m.dbg = std::getenv("MFM_MF_DBG") ? std::atoi(std::getenv("MFM_MF_DBG")) : 0;
+  m.colptr = a0.colptr;
+  m.cval = a0.val;
+  m.col_row0 = plan.col_row0.p;
+  m.run_base = L.run_base.p;
+  m.slot_pos = L.slot_pos.p;
+  m.slots = L.slots.p;
+  m.solo_col = plan.n_long_cols ? plan.solo_col.p : nullptr;
+  m.long_partial = plan.long_partial.p;
+  // algorithmic bytes of one pass: e read + written once (16 B / row), the entry stream (4 B, + 8 B values and 8 B of
+  // first-level values per row when the table is not unit-valued), one 16-byte statistics slot per run
+  const double pass_bytes = 16.0 * plan.n_state_rows + (UNIT ? 4.0 : 20.0) * L.n_ent;
+  auto pass = [&](const SweepArgs *cur, const SweepArgs *next, bool first, bool last) {
+    m.e_in = first && a0.aos ? (const double *)a0.aos : m.E;
+    m.e_in_stride = first && a0.aos ? 2 : 1;
+    m.e_out = last && a0.aos ? (double *)a0.aos : m.E;
+    m.e_out_stride = last && a0.aos ? 2 : 1;
+    m.do_apply = cur ? 1 : 0;
+    m.do_next = next ? 1 : 0;
+    m.theta_cur = cur ? cur->theta : nullptr;
+    m.theta_next = next ? next->theta : nullptr;
+    m.z_next = next ? next->z : nullptr;
+    m.lam_next = next ? next->lambda : nullptr;
+    m.mu_next = next ? next->mu : nullptr;
+    {
+      TimedLaunch t(tm, s, KC_SWEEP_V_FUSED, pass_bytes + (next ? 16.0 * L.n_runs : 0.0));
+      if (KR == 8)
+        hipLaunchKernelGGL((k_mf_pass<UNIT, 8>), dim3(L.n_tiles), dim3(nt), lds, s, m);
+      else
+        hipLaunchKernelGGL((k_mf_pass<UNIT, 4>), dim3(L.n_tiles), dim3(nt), lds, s, m);
+    }
+    if (next && plan.n_long_cols) {
+      // first-level columns longer than a tile: draw from their tiles' partial statistics, second pass over those tiles
+      TimedLaunch t(tm, s, kc.coop, 36.0 * plan.n_long_tiles * (double)(1 << L.tile_bits));
+      SweepArgs an = *next;
+      hipLaunchKernelGGL((k_long_tile_draw<PMainV>), dim3((plan.n_long_cols + 63) / 64), dim3(64), 0, s, an, plan.long_cols.p,
+                         plan.long_tile_ptr.p, plan.long_tiles.p, plan.n_long_cols, plan.long_partial.p, plan.oldnew_long.p);
+      MfArgs mf = m;
+      mf.e_out = m.E;  // (a pass with a next factor never is the sweep's last)
+      mf.e_out_stride = 1;
+      if (KR == 8)
+        hipLaunchKernelGGL((k_mf_long_finish<UNIT, 8>), dim3(plan.n_long_tiles), dim3(nt), lds, s, mf, plan.long_tiles.p,
+                           plan.tile_long_idx.p, plan.oldnew_long.p, plan.long_cols.p);
+      else
+        hipLaunchKernelGGL((k_mf_long_finish<UNIT, 4>), dim3(plan.n_long_tiles), dim3(nt), lds, s, mf, plan.long_tiles.p,
+                           plan.tile_long_idx.p, plan.oldnew_long.p, plan.long_cols.p);
+    }
+  };
+  {
+    TimedLaunch t(tm, s, kc.scat, 24.0 * L.n_cols);
+    hipLaunchKernelGGL(k_mf_gather, dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a0.theta, L.scols.p, L.n_cols, ls.dv_col.p);
+  }
+  pass(nullptr, &a0, true, false);
+  for (int f = f_begin; f < f_end; f++) {
+    const SweepArgs a = args(f);
+    const bool more = f + 1 < f_end;
+    SweepArgs an;
+    if (more) an = args(f + 1);
+    {
+      TimedLaunch t(tm, s, kc.scat, 16.0 * L.n_runs + 56.0 * L.n_cols);
+      hipLaunchKernelGGL(k_mf_draw, dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.slot_ptr.p, L.slots.p,
+                         more ? an.theta : (const double *)nullptr, ls.dv_col.p);
+    }
+    pass(&a, more ? &an : nullptr, false, !more);
   }
   MFM_HIP_CHECK(hipGetLastError());
 }

@@ -189,7 +189,8 @@ def test_row_tile_level_path(oracle, capi, monkeypatch, tile_bits):
         assert "sweep_V_scattered" in _timing_classes(c, drv)
 
 
-@pytest.mark.parametrize("n_fields,fused", [(2, True), (3, True), (2, False), (3, "csr_q"), (3, "no_multi")])
+@pytest.mark.parametrize("n_fields,fused", [(2, True), (2, "mf_k4"), (2, "tile_fused"), (3, True), (2, False), (3, "csr_q"),
+                                            (3, "no_multi")])
 def test_split_layout_latent_sweep(oracle, capi, monkeypatch, n_fields, fused):
     # update_V with e and q as separate arrays (run_plan_soa): first level (user-sorted, contiguous columns)
     # rebuilds q, middle levels read and write both, the last level writes only e; q_train is restored after
@@ -204,6 +205,11 @@ def test_split_layout_latent_sweep(oracle, capi, monkeypatch, n_fields, fused):
         monkeypatch.setenv("MFM_NO_FUSED_MULTIQ", "1")
     if fused == "no_multi":
         monkeypatch.setenv("MFM_NO_FUSED_MULTI", "1")
+    if fused == "tile_fused":  # two fields without the two-field pass: k_tile_apply_next with the q-cache in HBM
+        monkeypatch.setenv("MFM_NO_MF", "1")
+    if fused == "mf_k4":  # the two-field pass with 4 rows per thread
+        monkeypatch.setenv("MFM_MF_K", "4")
+    want_mf = n_fields == 2 and fused in (True, "mf_k4")
     fused = bool(fused)
     import scipy.sparse as sps
     n = 150001
@@ -222,7 +228,7 @@ def test_split_layout_latent_sweep(oracle, capi, monkeypatch, n_fields, fused):
         if scale:
             Xs.data = np.where(np.arange(Xs.nnz) % 3 == 0, scale, 1.5)
         t, c, _ = _pair(oracle, capi, Xs, y, gi, 3)
-        assert c.plan_flags()["soa"] and c.plan_flags()["fused_next"] == fused
+        assert c.plan_flags()["soa"] and c.plan_flags()["fused_next"] == fused and c.plan_flags()["mf"] == want_mf
         drv = CapiGibbs(c, t.clone(), n, gi)
         for it in range(3):
             t.step()

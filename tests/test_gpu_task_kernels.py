@@ -43,13 +43,14 @@ def test_device_erfcx_matches_reference_faddeeva_vectors(capi, name):
     assert np.all(np.isinf(got[~fin]))
 
 
-def _ordered_problem(n, n_class, seed, spread=3.0):
+def _ordered_problem(n, n_class, seed):
     rng = np.random.default_rng(seed)
     X = sps.csr_matrix(rng.normal(size=(n, 1)))
     y = rng.integers(0, n_class, size=n).astype(np.float64)
-    # scores far on both sides of every cutpoint: all three branches of safe_ldiff (y > 0 | x < 0 | straddling 0) and
-    # both branches of safe_lcdf (x > 1) / safe_lccdf (x > -1) occur
-    scores = rng.normal(size=n) * spread
+    # cutpoints about 0.7 apart; scores reach 5 beyond the outermost ones, so that every label meets arguments on both
+    # sides of zero: all three branches of safe_ldiff (y > 0 | x < 0 | straddling 0) and both branches of safe_lcdf
+    # (x > 1) / safe_lccdf (x > -1) occur
+    scores = rng.uniform(-5.0, 0.7 * (n_class - 2) + 5.0, size=n)
     return X, y, scores
 
 
@@ -62,11 +63,8 @@ def test_oprobit_eval_matches_oracle(capi, oracle, n_class):
     g_all = c.oprobit_add_group(n_class)
     rng = np.random.default_rng(1)
     for trial in range(3):
-        alpha = rng.normal(size=n_class - 1) * (0.3 + 0.5 * trial)
-        gamma = np.empty(n_class - 1)
-        gamma[0] = alpha[0]
-        for i in range(1, n_class - 1):
-            gamma[i] = gamma[i - 1] + np.exp(alpha[i])
+        alpha = np.concatenate([[rng.normal() * 0.3], np.log(0.7) + rng.normal(size=n_class - 2) * 0.2 * trial])
+        gamma = np.concatenate([[alpha[0]], alpha[0] + np.cumsum(np.exp(alpha[1:]))])  # OProbitSampler.hpp:95-101
         want = oracle.oprobit_eval(n_class, alpha, scores, y)
         ll, dg, H = c.oprobit_eval(g_all, gamma)
         # sums of 20 000 terms in a different (fixed) order, device libm vs glibc: 1e-10 relative to the term scale
@@ -75,13 +73,15 @@ def test_oprobit_eval_matches_oracle(capi, oracle, n_class):
         np.testing.assert_allclose(H, want["Hg"], rtol=1e-10, atol=1e-10 * np.abs(want["Hg"]).max())
         ll2, dg2, _ = c.oprobit_eval(g_all, gamma, want_h=False)
         assert ll2 == ll and np.array_equal(dg2, dg)
-    # every branch was exercised
-    x_hi = gamma[np.minimum(y.astype(int), n_class - 2)] - scores
-    mid = (y > 0) & (y < n_class - 1)
-    if mid.any():
-        x_lo = gamma[np.maximum(y.astype(int) - 1, 0)] - scores
-        assert (x_lo[mid] > 0).any() and (x_hi[mid] < 0).any() and ((x_lo[mid] <= 0) & (x_hi[mid] >= 0)).any()
-    assert (x_hi[y == 0] > 1).any() and (x_hi[y == 0] <= 1).any()
+        # every branch was exercised
+        x_hi = gamma[np.minimum(y.astype(int), n_class - 2)] - scores
+        mid = (y > 0) & (y < n_class - 1)
+        if mid.any():
+            x_lo = gamma[np.maximum(y.astype(int) - 1, 0)] - scores
+            assert (x_lo[mid] > 0).any() and (x_hi[mid] < 0).any() and ((x_lo[mid] <= 0) & (x_hi[mid] >= 0)).any()
+        assert (x_hi[y == 0] > 1).any() and (x_hi[y == 0] <= 1).any()
+        top = y == n_class - 1
+        assert (x_hi[top] > -1).any() and (x_hi[top] <= -1).any()
 
 
 def test_oprobit_eval_row_subsets(capi, oracle):
