@@ -293,11 +293,6 @@ static void score_design(hipStream_t s, Timing &tm, int mode, const DevSparse &X
   launch_score(s, mode, X, Vt, w, w0, K, KS, y, eq, out, blk);
 }
 
-static void score_train(mfm_ctx *c, bool subtract_y) {
-  score_design(c->stream, c->timing, 0, c->X, c->blocks, c->D, c->K, c->KS, c->w0, c->w.p, c->V.p, c->Vt.p,
-               subtract_y ? c->y.p : nullptr, c->eq.p, nullptr);
-}
-
 static SweepArgs main_args(mfm_ctx *c, double *theta, const double *z, const double *lam, const double *mu, double alpha) {
   SweepArgs a;
   a.colptr = c->X.colptr.p;
@@ -311,6 +306,26 @@ static SweepArgs main_args(mfm_ctx *c, double *theta, const double *z, const dou
   a.mu = mu;
   a.alpha = alpha;
   return a;
+}
+
+static void score_train(mfm_ctx *c, bool subtract_y) {
+  if (c->mf && !std::getenv("MFM_NO_MF_SCORE")) {
+    // two-field table: scorer on the row tiles of the latent sweep (item rows gathered once per run, not once per row)
+    hipStream_t s = c->stream;
+    {
+      TimedLaunch t(c->timing, s, KC_BUILD_VT, 16.0 * c->D * c->K);
+      build_vt(s, c->V.p, c->Vt.p, c->D, c->K, c->KS);
+    }
+    TimedLaunch t(c->timing, s, KC_UPDATE_E, 12.0 * c->X.nnz + 16.0 * c->X.rows + 8.0 * c->D * (c->K + 1));
+    SweepArgs a = main_args(c, c->w.p, nullptr, nullptr, nullptr, 0.0);
+    const bool done = c->X.unit ? launch_mf_score<true>(s, c->plan_V, a, c->Vt.p, c->w.p, c->w0, c->K, c->KS,
+                                                        subtract_y ? c->y.p : nullptr, c->eq.p)
+                                : launch_mf_score<false>(s, c->plan_V, a, c->Vt.p, c->w.p, c->w0, c->K, c->KS,
+                                                         subtract_y ? c->y.p : nullptr, c->eq.p);
+    if (done) return;
+  }
+  score_design(c->stream, c->timing, 0, c->X, c->blocks, c->D, c->K, c->KS, c->w0, c->w.p, c->V.p, c->Vt.p,
+               subtract_y ? c->y.p : nullptr, c->eq.p, nullptr);
 }
 
 }  // namespace mfm
@@ -1114,7 +1129,10 @@ int mfm_rng_prefetch(mfm_ctx *ctx) {
   MFM_TRY(ctx)
   auto &r = ctx->rng;
   if (!r.programmed) throw Error(MFM_ERR_RUNTIME, "mfm_rng_set_program has not been called");
-  if (r.produced - r.acquired >= 2) throw Error(MFM_ERR_RUNTIME, "both random sets are in flight: acquire one first");
+  // two slots: the acquired set stays valid until the next acquire, so at most one further set may be in flight (two
+  // before the first acquire)
+  if (r.produced - r.acquired >= (r.current >= 0 ? 1 : 2))
+    throw Error(MFM_ERR_RUNTIME, "both random sets are in use (one acquired / in flight): acquire the next one first");
   auto &sl = r.slot[r.produced % 2];
   hipStream_t s = r.stream;
   if (sl.free_valid) MFM_HIP_CHECK(hipStreamWaitEvent(s, sl.free_ev, 0));

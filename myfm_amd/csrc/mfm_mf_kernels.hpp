@@ -27,13 +27,17 @@
 
 namespace mfm {
 
+// Workgroup barrier that orders LDS traffic only (__syncthreads() is a workgroup-scope release: it also waits for the
+// wave's outstanding global stores). Global data written before such a barrier is never read by another thread of the launch.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct MfChunk {            // one per 64 consecutive rows of a tile
   unsigned long long heads; // bit l: row 64 c + l is the first row of a first-level column
   int32_t ubase;            // index (within the tile) of the column owning the chunk's first row
   int32_t pbase;            // index (within the tile) of the chunk's first partial
 };
 
-static inline int mf_user_cap(int tile_bits) {
+__host__ __device__ static inline int mf_user_cap(int tile_bits) {
   const int r = (1 << tile_bits) / 16;
   return r < 64 ? 64 : r;
 }
@@ -95,7 +99,11 @@ __device__ __forceinline__ void mf_run_structure(const uint32_t (&u)[K], const i
     const bool head = lane == 0 || cp != c;
     const bool tail = lane == 63 || cn != c;
     const unsigned long long hb = __ballot(head);
-    if (valid && tail) pos[k] = slot_pos[rb[k] + __popcll(hb & ((2ull << lane) - 1ull)) - 1];
+    // slot_pos == null: slots in stream ("tile-major") order -- a wave's stores are contiguous, whole lines
+    if (valid && tail) {
+      const int run = rb[k] + __popcll(hb & ((2ull << lane) - 1ull)) - 1;
+      pos[k] = slot_pos ? slot_pos[run] : run;
+    }
     flags[k] = (head ? 1u : 0u) | (valid && tail ? 2u : 0u);
   }
 }
@@ -146,11 +154,26 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
   for (int k = 0; k < K; k++) dv[k] = u[k] != TILE_PAD ? ((const d2_t *)a.dv)[u[k] >> a.tile_bits] : d2_t{0.0, 0.0};
   const int solo_j = a.solo_col ? a.solo_col[b] : -1;
   const int c0 = a.ucol_ptr[b], nu = a.ucol_ptr[b + 1] - c0;
+  // the row chunks' descriptors (wave-uniform) and the slot of every statistics run: every global load of the pass is
+  // issued before the first barrier
+  const int cbase = a.chunk_ptr[b];
+  MfChunk CH[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    CH[k] = MfChunk{0ull, 0, 0};
+    if ((k * nw + wv) * WAVE < nr) CH[k] = a.chunk[cbase + k * nw + wv];
+  }
+  int pos[K];
+  unsigned flags[K];
+  if (do_next) mf_run_structure<K>(u, rb, ts0, tp1, nw, lane, a.tile_bits, a.slot_pos, pos, flags);
   // this thread's first-level column (thread u <-> column u of the tile)
-  int uj = 0, ulen = 0;
+  int uj = 0, ulen = 0, upf = 0, upc = 0;
   double uold = 0.0, uz = 0.0, ulam = 0.0, umu = 0.0;
   if (solo_j < 0 && tid < nu) {
     const int4 d = a.udesc[c0 + tid];
+    const int2 pp0 = a.upart[c0 + tid];
+    upf = pp0.x;
+    upc = pp0.y;
     uj = d.x;
     ulen = d.y;
     const double vcur = do_apply ? a.theta_cur[uj] : 0.0;
@@ -222,7 +245,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
   }
 
   // ---- P2: row order
-  const int cbase = a.chunk_ptr[b];
   int ul[K];
   double h[K], ar[K];
 #pragma unroll
@@ -232,7 +254,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
     h[k] = 0.0;
     ar[k] = 1.0;
     if (ch * WAVE >= nr) continue;  // wave-uniform
-    const MfChunk C = a.chunk[cbase + ch];
+    const MfChunk C = CH[k];
     const int cnt = __popcll(C.heads & ((2ull << lane) - 2ull));  // column heads in rows (chunk start, this row]
     ul[k] = C.ubase + cnt;
     const bool valid = r < nr;
@@ -253,13 +275,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
     }
   }
   if (!do_next) return;
-  __syncthreads();
+  lds_barrier();
 
   if (a.dbg & 4) return;
   // ---- P3: one thread per first-level column: partials in row order, draw
   for (int uu = tid; uu < nu; uu += nt) {
     if (uu != tid) {  // (more columns than threads: a tile that hosts many never-occurring columns)
       const int4 d = a.udesc[c0 + uu];
+      const int2 pp = a.upart[c0 + uu];
+      upf = pp.x;
+      upc = pp.y;
       uj = d.x;
       ulen = d.y;
       uold = a.theta_next[uj];
@@ -267,9 +292,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
       ulam = a.lam_next[d.w];
       umu = a.mu_next[d.w];
     }
-    const int2 pp = a.upart[c0 + uu];
     double S1 = 0.0, S2 = 0.0;
-    for (int p = pp.x; p < pp.x + pp.y; p++) {
+    for (int p = upf; p < upf + upc; p++) {
       const d2_t s = part[p];
       S1 += s[0];
       S2 += s[1];
@@ -278,7 +302,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
     a.theta_next[uj] = fresh;
     if (ulen > 0) uval[uu] = d2_t{fresh, fresh - uold};
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- P4: the user level's update; the row's state for the item level's statistics
 #pragma unroll
@@ -292,13 +316,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
       rowbuf[r] = d2_t{e2, UNIT ? uv[0] : ar[k] * uv[0]};
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   if (a.dbg & 2) return;
   // ---- P5: item order
-  int pos[K];
-  unsigned flags[K];
-  mf_run_structure<K>(u, rb, ts0, tp1, nw, lane, a.tile_bits, a.slot_pos, pos, flags);
 #pragma unroll
   for (int k = 0; k < K; k++) {
     if (ts0 + k * nw >= tp1) continue;
@@ -398,6 +419,30 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
   }
 }
 
+// The statistics slots arrive in stream order (tile after tile, columns ascending inside a tile). Transpose-reduce: lane q
+// takes the q-th slot in COLUMN-major order (inv[q]: its stream index, bit 31 = first slot of a column; a random 16-byte read
+// of a buffer the pass has just written), a wave-level segmented scan sums each column's stretch, one partial per
+// (column, wavefront) goes to gp[] -- whose per-column ranges k_mf_draw then sums exactly like slot ranges.
+__global__ __launch_bounds__(WG) void k_mf_gather_reduce(const uint32_t *__restrict__ inv, int n_slots,
+                                                         const int32_t *__restrict__ wbase, const double2 *__restrict__ slots,
+                                                         double2 *__restrict__ gp) {
+  const int q = blockIdx.x * WG + threadIdx.x, lane = threadIdx.x & 63;
+  const bool valid = q < n_slots;
+  const uint32_t v = valid ? inv[q] : 0x80000000u;
+  int f = (int)(v >> 31) | (lane == 0 ? 1 : 0);
+  const int head = f;
+  double s1 = 0.0, s2 = 0.0;
+  if (valid) {
+    const double2 s = slots[v & 0x7fffffffu];
+    s1 = s.x;
+    s2 = s.y;
+  }
+  const int nh = dpp_i32<0x130, 0xf>(head, 1);  // wave_shl:1 (lane 63 reads the fill: a head follows)
+  const unsigned long long hb = __ballot(head != 0);
+  wave_segscan2(s1, s2, f);
+  if (valid && (lane == 63 || nh)) gp[wbase[q >> 6] + __popcll(hb & ((2ull << lane) - 1ull)) - 1] = make_double2(s1, s2);
+}
+
 // item level: a wavefront per column sums the column's slots (contiguous, fixed order), draws (FMTrainer.hpp:357-369) and
 // leaves dv[c] = (v' - v, the column's coefficient of the NEXT factor) for the pass that applies the update.
 __global__ __launch_bounds__(WG) void k_mf_draw(SweepArgs a, const int32_t *__restrict__ cols, int n_cols,
@@ -417,8 +462,20 @@ __global__ __launch_bounds__(WG) void k_mf_draw(SweepArgs a, const int32_t *__re
   }
   double S1 = 0.0, S2 = 0.0;
   {
+    // a popular column has one slot per tile (thousands): 16 loads in flight per lane, so that its wavefront is not a chain
+    // of dependent round trips (the kernel's duration is that of the longest column); fixed association
     const int k1 = slot_ptr[c + 1];
     int k = slot_ptr[c] + lane;
+    for (; k + 15 * WAVE < k1; k += 16 * WAVE) {
+      double2 t[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) t[i] = slots[k + i * WAVE];
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) {
+        S1 += (t[i].x + t[i + 1].x) + (t[i + 2].x + t[i + 3].x);
+        S2 += (t[i].y + t[i + 1].y) + (t[i + 2].y + t[i + 3].y);
+      }
+    }
     for (; k + 3 * WAVE < k1; k += 4 * WAVE) {
       const double2 s0 = slots[k], s1 = slots[k + WAVE], s2 = slots[k + 2 * WAVE], s3 = slots[k + 3 * WAVE];
       S1 += (s0.x + s1.x) + (s2.x + s3.x);
@@ -436,6 +493,114 @@ __global__ __launch_bounds__(WG) void k_mf_draw(SweepArgs a, const int32_t *__re
     const double fresh = PMainV::draw(S1, S2, old, a.alpha, a.lambda[g], a.mu[g], zj);
     a.theta[j] = fresh;
     dv[c] = make_double2(fresh - old, vn);
+  }
+}
+
+// update_e (FMTrainer.hpp:493-497 -> FM.hpp:54-136) of a two-field table, on the same row tiles: with one entry of each
+// level per row the FM score is  w0 + a w_u + b w_i + a b <V_u, V_i>  (1/2 [(a v_u + b v_i)^2 - a^2 v_u^2 - b^2 v_i^2]
+// summed over the factors). The entries are walked in ITEM order: GS lanes per entry (a lane owns a factor pair, 16-byte
+// gathers from the row-major table Vt), adjacent lane groups take adjacent entries, so an item's row is fetched once per
+// run of that item inside a tile instead of once per training row, and the tile's few users stay in L1. Scores go through
+// LDS to be written back in row order (coalesced), minus y.
+struct MfScoreArgs {
+  const int32_t *tile_row0, *tile_ptr;
+  const uint32_t *tent;
+  const double *tval;
+  int tile_bits, n_tiles, swz;
+  const int32_t *scols;      // second-level column (position in the level) -> feature
+  const int4 *udesc;
+  const int32_t *ucol_ptr;
+  const MfChunk *chunk;
+  const int32_t *chunk_ptr;
+  const int32_t *solo_col;
+  const int64_t *colptr;
+  const double *cval;
+  const int32_t *col_row0;
+  const double *Vt, *w;
+  double w0;
+  int K, KS;
+  const double *y;  // may be null
+  double2 *eq;
+};
+
+template <int GS, bool UNIT>
+__global__ __launch_bounds__(512) void k_mf_score(MfScoreArgs a) {
+  extern __shared__ double2 mf_lds[];
+  const int R = 1 << a.tile_bits;
+  double *sc = (double *)mf_lds;                  // [R]
+  int *ucol = (int *)(sc + R);                    // [ucap] feature of the tile's u-th first-level column
+  long long *uvb = (long long *)(ucol + mf_user_cap(a.tile_bits));  // [ucap] (!UNIT) value offset
+  const int b = xcd_swizzle(blockIdx.x, a.n_tiles, a.swz);
+  const int row0 = a.tile_row0[b];
+  const int nr = a.tile_row0[b + 1] - row0;
+  const int nt = blockDim.x, tid = threadIdx.x;
+  const int lig = tid % GS, grp = tid / GS, ngrp = nt / GS;
+  const int solo_j = a.solo_col ? a.solo_col[b] : -1;
+  const int c0 = a.ucol_ptr[b], nu = a.ucol_ptr[b + 1] - c0;
+  const int cbase = a.chunk_ptr[b];
+  const uint32_t rmask = (uint32_t)R - 1u;
+  for (int uu = tid; uu < nu; uu += nt) {
+    const int4 d = a.udesc[c0 + uu];
+    if (d.y > 0) {
+      ucol[uu] = d.x;
+      if (!UNIT) uvb[uu] = (long long)a.colptr[d.x] - d.z;
+    }
+  }
+  __syncthreads();
+  const int64_t p0 = (int64_t)a.tile_ptr[b] * WAVE, p1 = (int64_t)a.tile_ptr[b + 1] * WAVE;
+  const bool own = 2 * lig < a.K;  // (the pad column of an odd K is zero in Vt)
+  constexpr int RU = 4;
+  for (int64_t pb = p0 + grp; pb < p1; pb += (int64_t)ngrp * RU) {
+    uint32_t u[RU];
+    int ju[RU], ji[RU];
+    double xa[RU], xb[RU];
+#pragma unroll
+    for (int q = 0; q < RU; q++) {
+      const int64_t p = pb + (int64_t)q * ngrp;
+      u[q] = p < p1 ? __builtin_nontemporal_load(&a.tent[p]) : TILE_PAD;  // (streams: keep the L2 for the Vt rows)
+      xb[q] = !UNIT && p < p1 ? __builtin_nontemporal_load(&a.tval[p]) : 1.0;
+    }
+#pragma unroll
+    for (int q = 0; q < RU; q++) {
+      ju[q] = 0;
+      ji[q] = 0;
+      xa[q] = 1.0;
+      if (u[q] == TILE_PAD) continue;
+      const int r = (int)(u[q] & rmask);
+      ji[q] = a.scols[u[q] >> a.tile_bits];
+      if (solo_j >= 0) {
+        ju[q] = solo_j;
+        if (!UNIT) xa[q] = a.cval[a.colptr[solo_j] + (row0 - a.col_row0[solo_j]) + r];
+      } else {
+        const MfChunk C = a.chunk[cbase + (r >> 6)];
+        const int ul = C.ubase + __popcll(C.heads & ((2ull << (r & 63)) - 2ull));
+        ju[q] = ucol[ul];
+        if (!UNIT) xa[q] = a.cval[uvb[ul] + r];
+      }
+    }
+    double dot[RU];
+#pragma unroll
+    for (int q = 0; q < RU; q++) {
+      dot[q] = 0.0;
+      if (u[q] != TILE_PAD && own) {
+        const double2 vu = ((const double2 *)(a.Vt + (int64_t)ju[q] * a.KS))[lig];
+        const double2 vi = ((const double2 *)(a.Vt + (int64_t)ji[q] * a.KS))[lig];
+        dot[q] = vu.x * vi.x + vu.y * vi.y;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RU; q++) {
+      double part = dot[q];
+#pragma unroll
+      for (int m = GS / 2; m >= 1; m >>= 1) part += __shfl_xor(part, m, WAVE);
+      if (lig == 0 && u[q] != TILE_PAD)
+        sc[u[q] & rmask] = a.w0 + (xa[q] * a.w[ju[q]] + xb[q] * a.w[ji[q]]) + (xa[q] * xb[q]) * part;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < nr; i += nt) {
+    const double yv = a.y ? __builtin_nontemporal_load(&a.y[row0 + i]) : 0.0;
+    a.eq[row0 + i].x = sc[i] - yv;
   }
 }
 

@@ -58,6 +58,11 @@ struct ParLevel {
   DevBuf<uint32_t> tent;      // padded per tile to whole 64-entry wave tiles
   DevBuf<int32_t> tile_ptr;   // [n_tiles + 1], in wave tiles
   DevBuf<int32_t> tile_row0;  // [n_tiles + 1] first row of every tile (fixed 2^tile_bits grid, or StepPlan::h_tile_start)
+  // transpose-reduce of stream-ordered slots (k_mf_gather_reduce): column-major list of stream indices (bit 31: first of
+  // its column), first partial of every wavefront, partial range per column, the partials
+  DevBuf<uint32_t> g_inv;
+  DevBuf<int32_t> g_wbase, g_ptr;
+  DevBuf<double2> g_part;
   bool covers_rows_once = false;  // every row of the table has exactly one entry in this level
   bool first_and_once = false;    // ... and it is the first step of the plan: the level can rebuild q itself
   bool contig = false;            // every column of the level covers a contiguous row range (StepPlan::col_row0)
@@ -379,6 +384,31 @@ struct StepPlan {
       L.slot_pos.upload(pos);
     }
     L.slots.alloc((size_t)std::max<size_t>(run_col.size(), 1));
+    MFM_HIP_CHECK(hipMemset(L.slots.p, 0, std::max<size_t>(run_col.size(), 1) * sizeof(double2)));
+    {
+      const size_t ns = sidx.size(), nwv = (ns + WAVE - 1) / WAVE;
+      std::vector<uint32_t> inv(ns);
+      std::vector<int32_t> wbase(nwv + 1, 0), gptr(cols.size() + 1, 0);
+      size_t c = 0;
+      int32_t seg = 0;
+      for (size_t q = 0; q < ns; q++) {
+        while (c < cols.size() && (size_t)sptr[c + 1] <= q) c++;  // column of position q
+        const bool first = (size_t)sptr[c] == q;
+        inv[q] = (uint32_t)sidx[q] | (first ? 0x80000000u : 0u);
+        if (q % WAVE == 0) wbase[q / WAVE] = seg;
+        if (first || q % WAVE == 0) seg++;
+        if (first) gptr[c] = seg - 1;
+      }
+      // columns without any slot: empty ranges
+      wbase[nwv] = seg;
+      gptr[cols.size()] = seg;
+      for (size_t k = cols.size(); k-- > 0;)
+        if (sptr[k + 1] == sptr[k]) gptr[k] = gptr[k + 1];
+      L.g_inv.upload(inv);
+      L.g_wbase.upload(wbase);
+      L.g_ptr.upload(gptr);
+      L.g_part.alloc((size_t)std::max<int32_t>(seg, 1));
+    }
     return true;
   }
 
@@ -1444,7 +1474,11 @@ static void run_sweep_mf(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf
   m.cval = a0.val;
   m.col_row0 = plan.col_row0.p;
   m.run_base = L.run_base.p;
-  m.slot_pos = L.slot_pos.p;
+  // MFM_MF_STREAM_SLOTS=1: slots in stream order (whole-line stores) + a transpose-reduce before the draw. Measured at
+  // config 3: the pass 116 -> 100 us, but the 4.6 M random 16-byte reads of the transpose cost 59 us (the column-major
+  // scatter costs ~28 us on the store side): random 16-byte accesses run at ~80 G/s chip-wide either way. Default off.
+  const bool stream_slots = std::getenv("MFM_MF_STREAM_SLOTS") != nullptr;
+  m.slot_pos = stream_slots ? nullptr : L.slot_pos.p;
   m.slots = L.slots.p;
   m.solo_col = plan.n_long_cols ? plan.solo_col.p : nullptr;
   m.long_partial = plan.long_partial.p;
@@ -1498,13 +1532,79 @@ static void run_sweep_mf(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf
     SweepArgs an;
     if (more) an = args(f + 1);
     {
-      TimedLaunch t(tm, s, kc.scat, 16.0 * L.n_runs + 56.0 * L.n_cols);
-      hipLaunchKernelGGL(k_mf_draw, dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.slot_ptr.p, L.slots.p,
-                         more ? an.theta : (const double *)nullptr, ls.dv_col.p);
+      TimedLaunch t(tm, s, kc.scat, (stream_slots ? 20.0 : 16.0) * L.n_runs + 56.0 * L.n_cols);
+      if (stream_slots) {
+        hipLaunchKernelGGL(k_mf_gather_reduce, dim3((L.n_runs + WG - 1) / WG), dim3(WG), 0, s, L.g_inv.p, L.n_runs, L.g_wbase.p,
+                           L.slots.p, L.g_part.p);
+        hipLaunchKernelGGL(k_mf_draw, dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.g_ptr.p, L.g_part.p,
+                           more ? an.theta : (const double *)nullptr, ls.dv_col.p);
+      } else {
+        hipLaunchKernelGGL(k_mf_draw, dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.slot_ptr.p, L.slots.p,
+                           more ? an.theta : (const double *)nullptr, ls.dv_col.p);
+      }
     }
     pass(&a, more ? &an : nullptr, false, !more);
   }
   MFM_HIP_CHECK(hipGetLastError());
+}
+
+// update_e of a two-field table on the row tiles of its latent sweep (k_mf_score); false: not applicable (rank)
+template <bool UNIT>
+static bool launch_mf_score(hipStream_t s, const StepPlan &plan, const SweepArgs &a, const double *Vt, const double *w, double w0,
+                            int K, int KS, const double *y, double2 *eq) {
+  if (K < 1 || KS > 128) return false;
+  const ParLevel &L = plan.steps.back().par;
+  MfScoreArgs m;
+  std::memset(&m, 0, sizeof(m));
+  m.tile_row0 = L.tile_row0.p;
+  m.tile_ptr = L.tile_ptr.p;
+  m.tent = L.tent.p;
+  m.tval = L.ent_val.p;
+  m.tile_bits = L.tile_bits;
+  m.n_tiles = L.n_tiles;
+  m.swz = xcd_swizzle_enabled();
+  m.scols = L.scols.p;
+  m.udesc = plan.fuse_desc.p;
+  m.ucol_ptr = plan.fuse_col_ptr.p;
+  m.chunk = plan.mf_chunk.p;
+  m.chunk_ptr = plan.mf_chunk_ptr.p;
+  m.solo_col = plan.n_long_cols ? plan.solo_col.p : nullptr;
+  m.colptr = a.colptr;
+  m.cval = a.val;
+  m.col_row0 = plan.col_row0.p;
+  m.Vt = Vt;
+  m.w = w;
+  m.w0 = w0;
+  m.K = K;
+  m.KS = KS;
+  m.y = y;
+  m.eq = eq;
+  const size_t lds = ((size_t)8 << L.tile_bits) + (size_t)mf_user_cap(L.tile_bits) * 12 + 16;
+  const int gs = KS / 2;
+  const int nt = 512;
+#define MFM_MFS(G)                                                                                                        \
+  do {                                                                                                                    \
+    static bool raised = false;                                                                                           \
+    if (!raised) {                                                                                                        \
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_score<G, UNIT>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                        (int)CHAIN_LDS_MAX));                                                             \
+      raised = true;                                                                                                      \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((k_mf_score<G, UNIT>), dim3(L.n_tiles), dim3(nt), lds, s, m);                                        \
+  } while (0)
+  if (gs <= 4)
+    MFM_MFS(4);
+  else if (gs <= 8)
+    MFM_MFS(8);
+  else if (gs <= 16)
+    MFM_MFS(16);
+  else if (gs <= 32)
+    MFM_MFS(32);
+  else
+    MFM_MFS(64);
+#undef MFM_MFS
+  MFM_HIP_CHECK(hipGetLastError());
+  return true;
 }
 
 // ---- row-sharded fused path -------------------------------------------------------------------------------

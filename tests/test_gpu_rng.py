@@ -55,11 +55,16 @@ def test_device_stream_matches_libstdcxx(oracle, seed, n_users, K):
     ]
     c.rng_set_program(ops)
     c.rng_prefetch()
-    c.rng_prefetch()  # two sets in flight
+    c.rng_prefetch()  # two sets in flight before the first acquire
+    with pytest.raises(RuntimeError):
+        c.rng_prefetch()
     for it in range(3):
         hv = c.rng_acquire()
-        if it < 1:
-            c.rng_prefetch()
+        if it == 0:
+            with pytest.raises(RuntimeError):  # the acquired set and the one in flight occupy both slots
+                c.rng_prefetch()
+        else:
+            c.rng_prefetch()  # the Gibbs loop's pattern: acquire, then produce the next set while this one is used
         zw, zv = c.rng_get_z()
         want_hv, want_zw, want_zv = _host_program(t, ops)
         for got, want in ((hv, want_hv), (zw, want_zw[0]), (zv.ravel(), want_zv[0])):
