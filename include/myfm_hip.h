@@ -44,6 +44,7 @@ extern "C" {
 
 typedef struct mfm_ctx mfm_ctx;       /* one training problem resident on one GPU            */
 typedef struct mfm_design mfm_design; /* a (main CSR, relation blocks) design for prediction */
+typedef struct mfm_store mfm_store;   /* posterior samples kept resident in HBM                */
 
 /* ---- library / device ---------------------------------------------------------------- */
 const char *mfm_version(void);
@@ -70,6 +71,17 @@ int mfm_synchronize(mfm_ctx *ctx);
  * of every sweep (2 |level| doubles), once per (block, factor) for the block statistics, and for
  * sum e / sum e^2 and the ordered-probit likelihood terms. Must be called before mfm_finalize.        */
 int mfm_set_allreduce(mfm_ctx *ctx, int (*fn)(void *user, void *dev_buf, int64_t count), void *user);
+/* ... with the callback provider: this rank's index and the number of ranks (rank 0 contributes the replicated columns
+ * to the model synchronisation; default rank 0 of 1).                                                                */
+int mfm_set_shard(mfm_ctx *ctx, int32_t rank, int32_t world);
+/* Native provider: RCCL called from this library on the ctx stream (ncclAllReduce, fp64 sum, in place) -- no callback,
+ * no interpreter in the loop. One rank obtains the 128-byte id (ncclGetUniqueId) and hands it to the others by any
+ * out-of-band means (e.g. a torch.distributed / MPI broadcast); every rank then calls mfm_comm_init (collective:
+ * ncclCommInitRank on the ctx's device) before mfm_finalize. librccl.so is bound at run time.                          */
+int mfm_comm_unique_id(void *out128);
+int mfm_comm_init(mfm_ctx *ctx, const void *id128, int32_t rank, int32_t world);
+/* collectives issued so far and doubles they carried (either provider) */
+int mfm_comm_stats(const mfm_ctx *ctx, int64_t *calls, int64_t *doubles);
 /* The level schedule of the main table's columns (mfm_host_column_levels of the GLOBAL design): in the
  * row-sharded mode it must be identical on every rank (a conflict may exist only in another rank's
  * rows), so the caller computes it before sharding. Checked against the local rows at mfm_finalize.
@@ -220,6 +232,21 @@ int64_t mfm_design_n_rows(const mfm_design *d);
  * w0s[S], ws[S * D], Vs[S * D * K] (each sample's V column-major (D, K)).                   */
 int mfm_design_predict(mfm_design *d, int32_t rank, int32_t n_samples, const double *w0s, const double *ws,
                        const double *Vs, int32_t mode, int32_t n_cut, const double *cutpoints, double *out);
+
+/* ---- device-resident posterior samples: the Predictor's `samples` (FMTrainer.hpp:71-74, predictor.hpp:35-147) ------
+ * mfm_store_push_ctx appends the live (w0, w, V) of a training context with a device-to-device copy on its stream (no
+ * host transfer inside the Gibbs loop); mfm_store_get materialises one sample on the host (w[D], V column-major (D, K));
+ * mfm_design_predict_store = mfm_design_predict over samples [first, first + count) read in place (cutpoints[count *
+ * n_cut] for mode 2).                                                                                                */
+int mfm_store_create(int device, int64_t D, int32_t rank, mfm_store **out);
+void mfm_store_destroy(mfm_store *st);
+const char *mfm_store_last_error(const mfm_store *st);
+int32_t mfm_store_size(const mfm_store *st);
+int mfm_store_push_ctx(mfm_store *st, mfm_ctx *ctx);
+int mfm_store_push_host(mfm_store *st, double w0, const double *w, const double *V);
+int mfm_store_get(mfm_store *st, int32_t idx, double *w0, double *w, double *V);
+int mfm_design_predict_store(mfm_design *d, mfm_store *st, int32_t first, int32_t count, int32_t mode, int32_t n_cut,
+                             const double *cutpoints, double *out);
 
 /* FM::predict_score of the LIVE sample (the FM* handed to the per-iteration callback,
  * FMTrainer.hpp:78; utils/callbacks/libfm.py:85): scores design `d` with the (w0, w, V) currently

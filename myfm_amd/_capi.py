@@ -28,7 +28,9 @@ SYMBOLS = [
     "mfm_design_destroy", "mfm_design_last_error", "mfm_design_dim_all", "mfm_design_predict",
     "mfm_host_column_levels", "mfm_rng_seed_mt19937", "mfm_rng_set_program", "mfm_rng_prefetch", "mfm_rng_acquire",
     "mfm_rng_get_z", "mfm_design_score_ctx", "mfm_design_n_rows", "mfm_set_allreduce", "mfm_set_row_offset", "mfm_set_main_levels",
-    "mfm_test_erfcx", "mfm_test_truncated_normal", "mfm_get_device",
+    "mfm_test_erfcx", "mfm_test_truncated_normal", "mfm_get_device", "mfm_set_shard", "mfm_comm_unique_id", "mfm_comm_init",
+    "mfm_comm_stats", "mfm_store_create", "mfm_store_destroy", "mfm_store_last_error", "mfm_store_size", "mfm_store_push_ctx",
+    "mfm_store_push_host", "mfm_store_get", "mfm_design_predict_store",
 ]
 
 _lib = None
@@ -114,6 +116,20 @@ def lib():
     L.mfm_set_row_offset.argtypes = [vp, i64]
     L.mfm_set_main_levels.argtypes = [vp, P, i64]
     L.mfm_get_device.argtypes = [vp]
+    L.mfm_set_shard.argtypes = [vp, i32, i32]
+    L.mfm_comm_unique_id.argtypes = [P]
+    L.mfm_comm_init.argtypes = [vp, P, i32, i32]
+    L.mfm_comm_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.mfm_store_create.argtypes = [C.c_int, i64, i32, C.POINTER(vp)]
+    L.mfm_store_destroy.argtypes = [vp]
+    L.mfm_store_destroy.restype = None
+    L.mfm_store_last_error.restype = C.c_char_p
+    L.mfm_store_last_error.argtypes = [vp]
+    L.mfm_store_size.argtypes = [vp]
+    L.mfm_store_push_ctx.argtypes = [vp, vp]
+    L.mfm_store_push_host.argtypes = [vp, dbl, P, P]
+    L.mfm_store_get.argtypes = [vp, i32, C.POINTER(dbl), P, P]
+    L.mfm_design_predict_store.argtypes = [vp, vp, i32, i32, i32, i32, P, P]
     L.mfm_test_erfcx.argtypes = [C.c_int, P, i64, P]
     L.mfm_test_truncated_normal.argtypes = [C.c_int, i32, dbl, dbl, u64, u64, i64, P]
     _lib = L
@@ -439,4 +455,57 @@ class Design:
         rc = lib().mfm_design_predict(self.h, K, S, _p(w0s), _p(ws), _p(Vs), mode, n_cut, _p(cp), _p(out))
         if rc:
             _raise(rc, lib().mfm_design_last_error(self.h))
+        return out
+
+
+class Store:
+    """posterior samples resident on the GPU (mfm_store_*)"""
+
+    def __init__(self, D, K, device=0):
+        h = C.c_void_p()
+        rc = lib().mfm_store_create(device, D, K, C.byref(h))
+        if rc:
+            _raise(rc, lib().mfm_global_error())
+        self.h, self.D, self.K = h, D, K
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mfm_store_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            _raise(rc, lib().mfm_store_last_error(self.h))
+
+    def __len__(self):
+        return lib().mfm_store_size(self.h)
+
+    def push_ctx(self, ctx):
+        self._ck(lib().mfm_store_push_ctx(self.h, ctx.h))
+
+    def push(self, w0, w, V):
+        w, Vt = _f64(w), _f64(np.asarray(V, dtype=np.float64).T)
+        self._ck(lib().mfm_store_push_host(self.h, float(w0), _p(w), _p(Vt)))
+
+    def get(self, idx):
+        w0, w, V = C.c_double(), np.empty(self.D), np.empty((self.K, self.D))
+        self._ck(lib().mfm_store_get(self.h, idx, C.byref(w0), _p(w), _p(V)))
+        return w0.value, w, np.ascontiguousarray(V.T)
+
+    def predict(self, design, mode=0, cutpoints=None, first=0, count=None):
+        count = len(self) - first if count is None else count
+        n_cut, cp = 0, None
+        if mode == 2:
+            cp = _f64(np.stack([np.asarray(c, dtype=np.float64) for c in cutpoints]))
+            n_cut = cp.shape[1]
+        out = np.empty((design.N, n_cut + 1) if mode == 2 else design.N)
+        rc = lib().mfm_design_predict_store(design.h, self.h, first, count, mode, n_cut, _p(cp), _p(out))
+        if rc:
+            _raise(rc, lib().mfm_design_last_error(design.h))
         return out

@@ -249,9 +249,26 @@ struct DeviceDesign {
   }
 };
 
+// Kept posterior samples resident on the GPU (include/myfm_hip.h "device-resident posterior samples").
+struct DeviceStore {
+  mfm_store *st = nullptr;
+  DeviceStore(int64_t D, int K) {
+    int code = mfm_store_create(selected_device(), D, K, &st);
+    if (code != MFM_OK) throw_code(code, mfm_global_error());
+  }
+  ~DeviceStore() {
+    if (st) mfm_store_destroy(st);
+  }
+  DeviceStore(const DeviceStore &) = delete;
+  int size() const { return mfm_store_size(st); }
+};
+
 // ---- FM (FM.hpp:10-172) -----------------------------------------------------------------------------
 struct FM {
   int n_factors = 0;
+  // a kept sample that still lives in the device store (index), untouched by the user since training
+  std::shared_ptr<DeviceStore> store;
+  int store_idx = -1;
   Real w0 = 0;
   vector<Real> w;               // (D)
   vector<Real> V;               // column-major (D, K)
@@ -402,6 +419,29 @@ struct Predictor {
   vector<FM> samples;
   Predictor(size_t rank, size_t feature_size, TaskType type) : rank(rank), feature_size(feature_size), type(type) {}
 
+  // all samples are the consecutive, unmodified entries [first, first + S) of one device store: predict in place
+  std::shared_ptr<DeviceStore> resident(int *first) const {
+    if (samples.empty() || !samples[0].store || samples[0].store_idx < 0) return nullptr;
+    auto st = samples[0].store;
+    *first = samples[0].store_idx;
+    for (size_t k = 0; k < samples.size(); k++)
+      if (samples[k].store != st || samples[k].store_idx != *first + (int)k) return nullptr;
+    return st;
+  }
+  // mode / cutpoints as mfm_design_predict
+  void run_predict(const Csr &X, const Relations &rels, int mode, int n_cut, const vector<double> &cuts, double *out) const {
+    DeviceDesign dd(X, rels);
+    int first = 0;
+    if (auto st = resident(&first)) {
+      int code = mfm_design_predict_store(dd.d, st->st, first, (int)samples.size(), mode, n_cut, cuts.data(), out);
+      if (code != MFM_OK) throw_code(code, mfm_design_last_error(dd.d));
+      return;
+    }
+    vector<double> w0s, ws, Vs;
+    pack(w0s, ws, Vs);
+    dd.predict((int)rank, (int)samples.size(), w0s.data(), ws.data(), Vs.data(), mode, n_cut, cuts.data(), out);
+  }
+
   void check_input(const Csr &X, const Relations &relations) const {  // predictor.hpp:24-33
     auto given = check_row_consistency_return_column(X, relations);
     if (feature_size != given) {
@@ -416,6 +456,7 @@ struct Predictor {
     ws.resize(S * D);
     Vs.resize(S * D * rank);
     for (size_t s = 0; s < S; s++) {
+      const_cast<FM &>(samples[s]).ensure();
       const FM &f = samples[s];
       if (f.w.size() != D || f.V.size() != D * rank) throw std::invalid_argument("feature size mismatch!");
       w0s[s] = f.w0;
@@ -430,18 +471,14 @@ struct Predictor {
     Relations rels = relations_from_py(relso);
     check_input(X, rels);
     if (samples.empty()) throw std::runtime_error(empty_msg);
-    vector<double> w0s, ws, Vs;
-    pack(w0s, ws, Vs);
     py::array_t<double> out((py::ssize_t)X.rows);
-    DeviceDesign dd(X, rels);
     // regression averages scores, classification Phi(score); ORDERED falls through both branches of
     // predictor.hpp:136-144 and yields zeros
     if (type == TaskType::ORDERED) {
       std::fill(out.mutable_data(), out.mutable_data() + X.rows, 0.0);
       return out;
     }
-    dd.predict((int)rank, (int)samples.size(), w0s.data(), ws.data(), Vs.data(), type == TaskType::CLASSIFICATION ? 1 : 0, 0,
-               nullptr, out.mutable_data());
+    run_predict(X, rels, type == TaskType::CLASSIFICATION ? 1 : 0, 0, {}, out.mutable_data());
     return out;
   }
   py::array_t<double> predict(const py::object &X, const py::object &rels) const { return predict_impl(X, rels, "Empty samples!"); }
@@ -452,11 +489,8 @@ struct Predictor {
     Relations rels = relations_from_py(relso);
     check_input(X, rels);
     if (samples.empty()) throw std::runtime_error("Told to predict but no sample available.");
-    vector<double> w0s, ws, Vs;
-    pack(w0s, ws, Vs);
     py::array_t<double> out((py::ssize_t)X.rows);
-    DeviceDesign dd(X, rels);
-    dd.predict((int)rank, (int)samples.size(), w0s.data(), ws.data(), Vs.data(), 0, 0, nullptr, out.mutable_data());
+    run_predict(X, rels, 0, 0, {}, out.mutable_data());
     return out;
   }
   // predictor.hpp:78-124
@@ -468,16 +502,14 @@ struct Predictor {
     if (samples.empty()) throw std::runtime_error("Told to predict but no sample available.");
     if (type != TaskType::ORDERED) throw std::runtime_error("predict_parallel_oprobit must be called for oprobit model.");
     int n_cpt = (int)samples.at(0).cutpoints.at(cutpoint_index).size();
-    vector<double> w0s, ws, Vs, cuts;
-    pack(w0s, ws, Vs);
+    vector<double> cuts;
     for (auto &s : samples) {
       const auto &cp = s.cutpoints.at(cutpoint_index);
       if ((int)cp.size() != n_cpt) throw std::runtime_error("inconsistent cutpoint sizes among samples.");
       cuts.insert(cuts.end(), cp.begin(), cp.end());
     }
     py::array_t<double> out({(py::ssize_t)X.rows, (py::ssize_t)(n_cpt + 1)});
-    DeviceDesign dd(X, rels);
-    dd.predict((int)rank, (int)samples.size(), w0s.data(), ws.data(), Vs.data(), 2, n_cpt, cuts.data(), out.mutable_data());
+    run_predict(X, rels, 2, n_cpt, cuts, out.mutable_data());
     return out;
   }
 };
@@ -753,6 +785,8 @@ struct FMTrainer {
   // row-sharded multi-GPU mode: this process holds rows [row_offset, row_offset + N) of
   // N_total; `allreduce(ptr, count)` sums device doubles in place over the ranks
   int64_t N_total = 0, row_offset = 0;
+  int shard_rank = 0, shard_world = 1;
+  std::string comm_id;  // 128-byte RCCL unique id: the library calls ncclAllReduce itself (mfm_comm_init)
   py::object allreduce;
   uint64_t stream_ptr = 0;
   vector<int32_t> main_levels;  // level schedule of the GLOBAL main table (sharded mode)
@@ -810,6 +844,7 @@ struct FMTrainer {
     if (ctx) mfm_destroy(ctx);
   }
   FMTrainer(const FMTrainer &) = delete;
+  bool comm_active() const { return !comm_id.empty() || (allreduce.ptr() != nullptr && !allreduce.is_none()); }
 
   // BaseFMTrainer.hpp:107-115
   FM create_FM(int rank, Real init_std) {
@@ -825,8 +860,13 @@ struct FMTrainer {
     int code = mfm_create(selected_device(), &ctx);
     if (code != MFM_OK) throw_code(code, mfm_global_error());
     if (stream_ptr) ck(ctx, mfm_set_stream(ctx, (void *)stream_ptr));
-    if (!allreduce.is_none() && allreduce.ptr() != nullptr) {
+    if (!comm_id.empty()) {
+      if (comm_id.size() != 128) throw std::invalid_argument("comm_id must be the 128 bytes of comm_unique_id()");
+      ck(ctx, mfm_comm_init(ctx, comm_id.data(), shard_rank, shard_world));
+      ck(ctx, mfm_set_row_offset(ctx, row_offset));
+    } else if (allreduce.ptr() != nullptr && !allreduce.is_none()) {
       ck(ctx, mfm_set_allreduce(ctx, &FMTrainer::allreduce_trampoline, &allreduce));
+      ck(ctx, mfm_set_shard(ctx, shard_rank, shard_world));
       ck(ctx, mfm_set_row_offset(ctx, row_offset));
     }
     if (!main_levels.empty()) ck(ctx, mfm_set_main_levels(ctx, main_levels.data(), (int64_t)main_levels.size()));
@@ -1064,10 +1104,37 @@ struct FMTrainer {
     fm.fetch = [this](FM &f) { this->download(f); };
     fm.live_ctx = ctx;
     result.first.samples.reserve((size_t)cfg.n_kept_samples);
+    // kept samples stay on the GPU (device-to-device copy on the training stream, no host transfer inside the loop);
+    // MYFM_AMD_HOST_SAMPLES=1 or a store that does not fit: plain host copies as before
+    std::shared_ptr<DeviceStore> store;
+    if (cfg.n_kept_samples > 0 && !std::getenv("MYFM_AMD_HOST_SAMPLES") && !comm_active())
+      store = std::make_shared<DeviceStore>((int64_t)dim_all, fm.n_factors);
     for (int it = 0; it < cfg.n_iter; it++) {
       update_all(fm, hyper);
       fm.stale = true;  // w / V live on the device until somebody reads them
-      if (cfg.n_iter <= (it + cfg.n_kept_samples)) result.first.samples.emplace_back(fm.snapshot());
+      if (cfg.n_iter <= (it + cfg.n_kept_samples)) {
+        if (store && mfm_store_push_ctx(store->st, ctx) == MFM_OK) {
+          FM k;
+          k.n_factors = fm.n_factors;
+          k.w0 = fm.w0;
+          k.cutpoints = fm.cutpoints;
+          k.initialized = fm.initialized;
+          k.store = store;
+          k.store_idx = store->size() - 1;
+          k.stale = true;
+          const size_t D = dim_all;
+          k.fetch = [store, D](FM &f) {  // materialise on the host on first access
+            f.w.resize(D);
+            f.V.resize(D * (size_t)f.n_factors);
+            int code = mfm_store_get(store->st, f.store_idx, &f.w0, f.w.data(), f.V.data());
+            if (code != MFM_OK) throw_code(code, mfm_store_last_error(store->st));
+          };
+          result.first.samples.emplace_back(std::move(k));
+        } else {
+          store.reset();  // (out of device memory: fall back to host copies from here on)
+          result.first.samples.emplace_back(fm.snapshot());
+        }
+      }
       result.second.hypers.emplace_back(hyper);
       bool should_stop = cb(it, &fm, &hyper, &(result.second));
       if (should_stop) break;
@@ -1096,6 +1163,32 @@ std::pair<Predictor, LearningHistory> create_train_fm(size_t n_factor, Real init
   return fm_trainer.learn_with_callback(fm, hyper_param, cb);
 }
 
+// create_train_fm over row shards (not part of the reference's surface): every rank passes its contiguous slice
+// of the rows (X, y, every original_to_block), the level schedule of the GLOBAL main table, and either the RCCL id
+// (comm_id, native all-reduce) or an all-reduce callable. Every rank returns the same Predictor / history.
+std::pair<Predictor, LearningHistory> create_train_fm_sharded(size_t n_factor, Real init_std, const py::object &X,
+                                                              const py::object &relations, const py::object &y, int random_seed,
+                                                              FMLearningConfig &config,
+                                                              std::function<bool(int, FM *, Hyper *, LearningHistory *)> cb,
+                                                              int rank, int world, int64_t n_total_rows, int64_t row_offset,
+                                                              const py::object &main_levels, const std::string &comm_id,
+                                                              py::object allreduce, uint64_t stream) {
+  FMTrainer t(X, relations, y, random_seed, config);
+  t.allreduce = allreduce;
+  t.comm_id = comm_id;
+  t.shard_rank = rank;
+  t.shard_world = world;
+  t.N_total = n_total_rows;
+  t.row_offset = row_offset;
+  t.stream_ptr = stream;
+  auto lv = py::array_t<int32_t, py::array::c_style | py::array::forcecast>::ensure(main_levels);
+  if (!lv) throw std::invalid_argument("main_levels must be an int32 array");
+  t.main_levels.assign(lv.data(), lv.data() + lv.size());
+  auto fm = t.create_FM((int)n_factor, init_std);
+  auto hyper_param = t.create_Hyper((size_t)fm.n_factors);
+  return t.learn_with_callback(fm, hyper_param, cb);
+}
+
 // A steppable training session: not part of the reference's surface; bench.py and the parity tests
 // use it to time / inspect single Gibbs iterations of exactly the loop create_train_fm runs.
 struct GibbsSession {
@@ -1105,9 +1198,12 @@ struct GibbsSession {
   int it = 0;
   GibbsSession(size_t n_factor, Real init_std, const py::object &X, const py::object &relations, const py::object &y,
                int random_seed, FMLearningConfig &config, py::object allreduce, int64_t n_total_rows, int64_t row_offset,
-               uint64_t stream, py::object main_levels)
+               uint64_t stream, py::object main_levels, const std::string &comm_id, int rank, int world)
       : trainer(new FMTrainer(X, relations, y, random_seed, config)) {
     trainer->allreduce = allreduce;
+    trainer->comm_id = comm_id;
+    trainer->shard_rank = rank;
+    trainer->shard_world = world;
     if (!main_levels.is_none()) {
       auto lv = py::array_t<int32_t, py::array::c_style | py::array::forcecast>::ensure(main_levels);
       if (!lv) throw std::invalid_argument("main_levels must be an int32 array");
@@ -1179,11 +1275,30 @@ PYBIND11_MODULE(_myfm, m) {
   py::class_<FMLearningConfig>(m, "FMLearningConfig");
 
   py::class_<RelationBlock, std::shared_ptr<RelationBlock>>(m, "RelationBlock", "The RelationBlock Class.")
-      .def(py::init([](vector<size_t> o2b, const py::object &data) {
-             return std::make_shared<RelationBlock>(std::move(o2b), csr_from_py(data));
+      .def(py::init([](const py::object &o2b, const py::object &data) {
+             // (an integer numpy array is taken without a per-element Python conversion: maps of 10^7..10^8 rows)
+             if (py::isinstance<py::array>(o2b)) {
+               auto arr = py::array_t<int64_t, py::array::c_style | py::array::forcecast>::ensure(o2b);
+               if (!arr || arr.ndim() != 1) throw std::invalid_argument("original_to_block must be a 1-d integer array");
+               vector<size_t> v((size_t)arr.size());
+               const int64_t *p = arr.data();
+               for (py::ssize_t i = 0; i < arr.size(); i++) {
+                 if (p[i] < 0) throw std::runtime_error("index mapping points to non-existing row.");
+                 v[(size_t)i] = (size_t)p[i];
+               }
+               return std::make_shared<RelationBlock>(std::move(v), csr_from_py(data));
+             }
+             return std::make_shared<RelationBlock>(o2b.cast<vector<size_t>>(), csr_from_py(data));
            }),
            py::arg("original_to_block"), py::arg("data"))
       .def_readonly("original_to_block", &RelationBlock::original_to_block)
+      .def_property_readonly("original_to_block_array",  // (extension: the map as an int64 array, no Python list)
+                             [](const RelationBlock &b) {
+                               py::array_t<int64_t> a((py::ssize_t)b.original_to_block.size());
+                               int64_t *p = a.mutable_data();
+                               for (size_t i = 0; i < b.original_to_block.size(); i++) p[i] = (int64_t)b.original_to_block[i];
+                               return a;
+                             })
       .def_property_readonly("data", [](const RelationBlock &b) { return csr_to_py(b.X); })
       .def_readonly("mapper_size", &RelationBlock::mapper_size)
       .def_readonly("block_size", &RelationBlock::block_size)
@@ -1222,7 +1337,12 @@ PYBIND11_MODULE(_myfm, m) {
 
   py::class_<FM>(m, "FM")
       .def_property(
-          "w0", [](FM &f) { return f.w0; }, [](FM &f, Real v) { f.w0 = v; })
+          "w0", [](FM &f) { return f.w0; },
+          [](FM &f, Real v) {
+            f.ensure();
+            f.store_idx = -1;
+            f.w0 = v;
+          })
       .def_property(
           "w",
           [](FM &f) {
@@ -1231,6 +1351,7 @@ PYBIND11_MODULE(_myfm, m) {
           },
           [](FM &f, const py::object &v) {
             f.ensure();
+            f.store_idx = -1;
             f.w = np_to_vec(v);
           })
       .def_property(
@@ -1241,6 +1362,7 @@ PYBIND11_MODULE(_myfm, m) {
           },
           [](FM &f, const py::object &v) {
             f.ensure();
+            f.store_idx = -1;
             int64_t r, c;
             f.V = np_to_colmajor(v, &r, &c);
           })
@@ -1344,10 +1466,17 @@ PYBIND11_MODULE(_myfm, m) {
   // extensions beyond the reference's surface (bench / tests)
   py::class_<GibbsSession>(m, "GibbsSession")
       .def(py::init<size_t, Real, const py::object &, const py::object &, const py::object &, int, FMLearningConfig &,
-                    py::object, int64_t, int64_t, uint64_t, py::object>(),
+                    py::object, int64_t, int64_t, uint64_t, py::object, const std::string &, int, int>(),
            py::arg("rank"), py::arg("init_std"), py::arg("X"), py::arg("relations"), py::arg("y"), py::arg("random_seed"),
            py::arg("config"), py::arg("allreduce") = py::none(), py::arg("n_total_rows") = 0, py::arg("row_offset") = 0,
-           py::arg("stream") = 0, py::arg("main_levels") = py::none())
+           py::arg("stream") = 0, py::arg("main_levels") = py::none(), py::arg("comm_id") = py::bytes(""),
+           py::arg("shard_rank") = 0, py::arg("shard_world") = 1)
+      .def("comm_stats",
+           [](GibbsSession &s) {
+             int64_t c = 0, d = 0;
+             mfm_comm_stats(s.trainer->ctx, &c, &d);
+             return py::make_tuple(c, d);
+           })
       .def("step", &GibbsSession::step)
       .def("synchronize", &GibbsSession::synchronize)
       .def("residual", &GibbsSession::residual)
@@ -1361,6 +1490,16 @@ PYBIND11_MODULE(_myfm, m) {
       .def_property_readonly("hyper", [](GibbsSession &s) -> Hyper & { return s.hyper; },
                              py::return_value_policy::reference_internal)
       .def_readonly("iteration", &GibbsSession::it);
+  m.def("create_train_fm_sharded", &create_train_fm_sharded, "create_train_fm over row shards (one process per GPU).",
+        py::arg("rank"), py::arg("init_std"), py::arg("X"), py::arg("relations"), py::arg("y"), py::arg("random_seed"),
+        py::arg("config"), py::arg("callback"), py::arg("shard_rank"), py::arg("shard_world"), py::arg("n_total_rows"),
+        py::arg("row_offset"), py::arg("main_levels"), py::arg("comm_id") = py::bytes(""), py::arg("allreduce") = py::none(),
+        py::arg("stream") = 0, py::return_value_policy::move);
+  m.def("comm_unique_id", []() {
+    char id[128];
+    if (mfm_comm_unique_id(id) != MFM_OK) throw std::runtime_error(mfm_global_error());
+    return py::bytes(id, 128);
+  });
   m.def("device_count", []() { return mfm_device_count(); });
   m.def("backend_version", []() { return std::string(mfm_version()); });
   // host-only self-test of the jump-ahead polynomials the parallel generator uses (csrc/mfm_mtjump.hpp) against

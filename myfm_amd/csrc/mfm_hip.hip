@@ -391,6 +391,7 @@ int mfm_set_stream(mfm_ctx *ctx, void *hip_stream) {
   }
   ctx->stream = (hipStream_t)hip_stream;
   ctx->own_stream = false;
+  ctx->comm.stream = ctx->stream;
   MFM_CATCH(ctx)
 }
 
@@ -400,6 +401,48 @@ int mfm_set_allreduce(mfm_ctx *ctx, int (*fn)(void *user, void *dev_buf, int64_t
   ctx->comm.fn = fn;
   ctx->comm.user = user;
   MFM_CATCH(ctx)
+}
+
+int mfm_comm_unique_id(void *out128) {
+  try {
+    Rccl &r = Rccl::get();
+    r.check(r.GetUniqueId(out128), "ncclGetUniqueId");
+    return MFM_OK;
+  } catch (const std::exception &ex) {
+    g_global_error = ex.what();
+    return MFM_ERR_RUNTIME;
+  }
+}
+
+int mfm_comm_init(mfm_ctx *ctx, const void *id128, int32_t rank, int32_t world) {
+  MFM_TRY(ctx)
+  if (ctx->finalized) throw Error(MFM_ERR_RUNTIME, "mfm_comm_init must be called before mfm_finalize");
+  if (world < 1 || rank < 0 || rank >= world) throw Error(MFM_ERR_INVALID, "bad rank / world size");
+  if (ctx->comm.nccl) throw Error(MFM_ERR_RUNTIME, "communicator already initialised");
+  Rccl &r = Rccl::get();
+  mfm_nccl_id id;
+  std::memcpy(&id, id128, sizeof(id));
+  void *comm = nullptr;
+  r.check(r.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+  ctx->comm.nccl = comm;
+  ctx->comm.stream = ctx->stream;
+  ctx->comm.rank = rank;
+  ctx->comm.world = world;
+  MFM_CATCH(ctx)
+}
+
+int mfm_set_shard(mfm_ctx *ctx, int32_t rank, int32_t world) {
+  MFM_TRY(ctx)
+  if (world < 1 || rank < 0 || rank >= world) throw Error(MFM_ERR_INVALID, "bad rank / world size");
+  ctx->comm.rank = rank;
+  ctx->comm.world = world;
+  MFM_CATCH(ctx)
+}
+
+int mfm_comm_stats(const mfm_ctx *ctx, int64_t *calls, int64_t *doubles) {
+  if (calls) *calls = ctx->comm.calls;
+  if (doubles) *doubles = ctx->comm.doubles;
+  return MFM_OK;
 }
 
 int mfm_set_main_levels(mfm_ctx *ctx, const int32_t *level, int64_t D0) {
@@ -495,6 +538,17 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     // per-column indicators (columns empty on every rank are drawn from the prior by every rank itself).
     bool try_fused = c->comm.active() && c->hblocks.empty() && !c->hlevels.empty() && tile_bits > 0 && c->N > 0 &&
                      !std::getenv("MFM_NO_SHARDED_FUSED") && !std::getenv("MFM_NO_SOA");
+    if (c->comm.active()) {
+      // the predicate has rank-local inputs (an empty shard, the environment): every rank must enter the collectives
+      // below or none -- agree first
+      double no = try_fused ? 0.0 : 1.0;
+      DevBuf<double> d;
+      d.upload(&no, 1);
+      c->comm.allreduce(d.p, 1);
+      MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
+      MFM_HIP_CHECK(hipMemcpy(&no, d.p, sizeof(double), hipMemcpyDeviceToHost));
+      try_fused = no == 0.0;
+    }
     std::vector<double> col_cnt;
     if (try_fused) {
       const int64_t D0 = c->D0, RB = (int64_t)1 << tile_bits;
@@ -542,8 +596,8 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
       } else {
         c->sharded_fused = true;
         // model synchronisation after the sweep: a non-special first-level column is contributed by the rank
-        // that holds its rows, every other column (identical on all ranks) by the rank holding global row 0
-        std::vector<double> mask((size_t)c->D, c->row_offset == 0 ? 1.0 : 0.0);
+        // that holds its rows, every other column (identical on all ranks) by rank 0 of the communicator
+        std::vector<double> mask((size_t)c->D, c->comm.rank == 0 ? 1.0 : 0.0);
         for (int64_t j = 0; j < c->D0; j++)
           if (c->hlevels[j] == 0 && c->plan_V.special[j] == 0) mask[j] = col_cnt[j] > 0 ? 1.0 : 0.0;
         c->sync_mask.upload(mask);

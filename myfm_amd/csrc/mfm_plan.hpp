@@ -17,9 +17,15 @@
 #include <cstdlib>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "mfm_common.hpp"
 #include "mfm_kernels.hpp"
 #include "mfm_mf_kernels.hpp"
+
+struct mfm_nccl_id {
+  char internal[128];  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES)
+};
 
 namespace mfm {
 
@@ -1011,13 +1017,61 @@ static void run_plan(hipStream_t s, Timing &tm, const StepPlan &plan, const Swee
 
 // In-place sum over the ranks of `count` doubles in device memory, enqueued in order on the ctx stream.
 typedef int (*mfm_allreduce_fn)(void *user, void *dev_buf, int64_t count);
+// Two providers: a caller-supplied callback (mfm_set_allreduce: e.g. torch.distributed on the ctx stream), or RCCL called
+// from this library on the ctx stream (mfm_comm_init: ncclAllReduce over xGMI, no interpreter in the loop). librccl is
+// bound at run time (dlopen) so that single-GPU use does not depend on it.
+struct Rccl {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, mfm_nccl_id, int) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  static Rccl &get() {
+    static Rccl r;
+    if (!r.lib) {
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+      }
+      if (!r.lib) throw Error(MFM_ERR_RUNTIME, std::string("cannot load librccl.so: ") + dlerror());
+      r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+      r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+      r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+      r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+      r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+      if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy)
+        throw Error(MFM_ERR_RUNTIME, "librccl.so lacks the expected entry points");
+    }
+    return r;
+  }
+  void check(int rc, const char *what) const {
+    if (rc != 0)
+      throw Error(MFM_ERR_RUNTIME, std::string(what) + " failed: " + (GetErrorString ? GetErrorString(rc) : "rccl error"));
+  }
+};
+
 struct Comm {
   mfm_allreduce_fn fn = nullptr;
   void *user = nullptr;
-  bool active() const { return fn != nullptr; }
+  void *nccl = nullptr;        // ncclComm_t (mfm_comm_init)
+  hipStream_t stream = nullptr;  // the ctx stream the native collective is enqueued on
+  int rank = 0, world = 1;
+  mutable int64_t calls = 0, doubles = 0;
+  bool active() const { return fn != nullptr || nccl != nullptr; }
   void allreduce(void *buf, int64_t count) const {
-    if (!fn || count <= 0) return;
+    if (count <= 0 || !active()) return;
+    calls++;
+    doubles += count;
+    if (nccl) {
+      Rccl &r = Rccl::get();
+      r.check(r.AllReduce(buf, buf, (size_t)count, /*ncclDouble*/ 8, /*ncclSum*/ 0, nccl, stream), "ncclAllReduce");
+      return;
+    }
     if (fn(user, buf, count) != 0) throw Error(MFM_ERR_RUNTIME, "all-reduce callback failed");
+  }
+  ~Comm() {
+    if (nccl) (void)Rccl::get().CommDestroy(nccl);
   }
 };
 

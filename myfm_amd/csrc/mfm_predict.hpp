@@ -57,7 +57,86 @@ struct mfm_design {
   void use_device() { MFM_HIP_CHECK(hipSetDevice(device)); }
 };
 
+// Posterior-sample store (FMTrainer.hpp:71-74 keeps the last n_kept_samples FM copies): the kept samples stay in HBM --
+// retention is a device-to-device copy on the training stream, prediction reads them in place, the host sees a sample
+// only when somebody asks for its arrays (pickling, w_samples / V_samples).
+struct mfm_store {
+  int device = 0;
+  int64_t D = 0;
+  int K = 0;
+  std::string err;
+  std::vector<double> w0;
+  std::vector<std::unique_ptr<DevBuf<double>>> wv;  // per sample: w[D] then V[K][D] (factor-major, the ctx layout)
+  void use_device() { MFM_HIP_CHECK(hipSetDevice(device)); }
+};
+
 extern "C" {
+
+int mfm_store_create(int device, int64_t D, int32_t rank, mfm_store **out) {
+  *out = nullptr;
+  try {
+    if (mfm_device_count() <= 0) throw Error(MFM_ERR_DEVICE, "no HIP device is visible (no CPU fallback)");
+    if (D < 0 || rank < 0) throw Error(MFM_ERR_INVALID, "negative size");
+    std::unique_ptr<mfm_store> st(new mfm_store());
+    st->device = device;
+    st->D = D;
+    st->K = rank;
+    *out = st.release();
+    return MFM_OK;
+  } catch (const mfm::Error &ex) {
+    g_global_error = ex.what();
+    return ex.code;
+  }
+}
+void mfm_store_destroy(mfm_store *st) {
+  if (!st) return;
+  (void)hipSetDevice(st->device);
+  delete st;
+}
+const char *mfm_store_last_error(const mfm_store *st) { return st ? st->err.c_str() : g_global_error.c_str(); }
+int32_t mfm_store_size(const mfm_store *st) { return (int32_t)st->wv.size(); }
+
+static DevBuf<double> *store_new_sample(mfm_store *st) {
+  std::unique_ptr<DevBuf<double>> b(new DevBuf<double>());
+  b->alloc((size_t)std::max<int64_t>(st->D * (st->K + 1), 1));
+  st->wv.push_back(std::move(b));
+  return st->wv.back().get();
+}
+
+int mfm_store_push_ctx(mfm_store *st, mfm_ctx *ctx) {
+  MFM_TRY(st)
+  ctx->need_final();
+  if (ctx->device != st->device) throw Error(MFM_ERR_INVALID, "store and training context live on different devices");
+  if (ctx->D != st->D || ctx->K != st->K) throw Error(MFM_ERR_INVALID, "store and training context differ in size");
+  DevBuf<double> *b = store_new_sample(st);
+  const size_t D = (size_t)st->D;
+  if (D) MFM_HIP_CHECK(hipMemcpyAsync(b->p, ctx->w.p, D * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  if (D && st->K)
+    MFM_HIP_CHECK(hipMemcpyAsync(b->p + D, ctx->V.p, D * st->K * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  st->w0.push_back(ctx->w0);
+  MFM_CATCH(st)
+}
+
+int mfm_store_push_host(mfm_store *st, double w0, const double *w, const double *V) {
+  MFM_TRY(st)
+  DevBuf<double> *b = store_new_sample(st);
+  const size_t D = (size_t)st->D;
+  if (D) MFM_HIP_CHECK(hipMemcpy(b->p, w, D * sizeof(double), hipMemcpyHostToDevice));
+  if (D && st->K) MFM_HIP_CHECK(hipMemcpy(b->p + D, V, D * st->K * sizeof(double), hipMemcpyHostToDevice));
+  st->w0.push_back(w0);
+  MFM_CATCH(st)
+}
+
+int mfm_store_get(mfm_store *st, int32_t idx, double *w0, double *w, double *V) {
+  MFM_TRY(st)
+  if (idx < 0 || idx >= (int)st->wv.size()) throw Error(MFM_ERR_INVALID, "sample index out of range");
+  const size_t D = (size_t)st->D;
+  MFM_HIP_CHECK(hipDeviceSynchronize());  // (a push_ctx copy may still be in flight on a training stream)
+  if (w0) *w0 = st->w0[idx];
+  if (w && D) MFM_HIP_CHECK(hipMemcpy(w, st->wv[idx]->p, D * sizeof(double), hipMemcpyDeviceToHost));
+  if (V && D && st->K) MFM_HIP_CHECK(hipMemcpy(V, st->wv[idx]->p + D, D * st->K * sizeof(double), hipMemcpyDeviceToHost));
+  MFM_CATCH(st)
+}
 
 int mfm_design_create(int device, int64_t N, int64_t D0, const int64_t *indptr, const int32_t *indices, const double *data,
                       mfm_design **out) {
@@ -149,6 +228,61 @@ int mfm_design_score_ctx(mfm_design *d, mfm_ctx *ctx, double *out) {
   score_design(s, ctx->timing, 1, d->X, d->blocks, d->D, rank, d->KS, ctx->w0, ctx->w.p, ctx->V.p, d->Vt.p, nullptr, nullptr,
                d->score.p);
   if (d->N) MFM_HIP_CHECK(hipMemcpyAsync(out, d->score.p, (size_t)d->N * sizeof(double), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipStreamSynchronize(s));
+  MFM_CATCH(d)
+}
+
+// Predictor::predict* over samples resident in a store (no per-sample upload, no host synchronisation inside the loop):
+// samples [first, first + count).
+int mfm_design_predict_store(mfm_design *d, mfm_store *st, int32_t first, int32_t count, int32_t mode, int32_t n_cut,
+                             const double *cutpoints, double *out) {
+  MFM_TRY(d)
+  if (count <= 0) throw Error(MFM_ERR_RUNTIME, "Told to predict but no sample available.");  // predictor.hpp:39-41
+  if (first < 0 || first + count > (int)st->wv.size()) throw Error(MFM_ERR_INVALID, "sample range out of bounds");
+  if (st->device != d->device) throw Error(MFM_ERR_INVALID, "design and sample store live on different devices");
+  if (st->D != d->D) throw Error(MFM_ERR_INVALID, "feature size mismatch!");
+  if (mode < 0 || mode > 2) throw Error(MFM_ERR_INVALID, "bad prediction mode");
+  if (mode == 2 && n_cut < 1) throw Error(MFM_ERR_RUNTIME, "No cutpoint available for this FM.");
+  hipStream_t s = d->stream;
+  const int rank = st->K;
+  const int64_t N = d->N, D = d->D;
+  if (d->K != rank) {
+    d->K = rank;
+    d->KS = (rank + 1) & ~1;
+    d->w.alloc((size_t)std::max<int64_t>(D, 1));
+    d->V.alloc((size_t)std::max<int64_t>(D * rank, 1));
+    d->Vt.alloc_zero((size_t)std::max<int64_t>(D * d->KS, 1), s);
+    d->score.alloc((size_t)std::max<int64_t>(N, 1));
+    for (auto &B : d->blocks) {
+      B->bq.alloc_zero((size_t)B->B * std::max(d->KS, 1), s);
+      B->bl.alloc_zero((size_t)B->B, s);
+      B->bs.alloc_zero((size_t)B->B, s);
+    }
+  }
+  const int64_t out_n = mode == 2 ? N * (n_cut + 1) : N;
+  if (d->out.n < (size_t)std::max<int64_t>(out_n, 1)) d->out.alloc((size_t)std::max<int64_t>(out_n, 1));
+  MFM_HIP_CHECK(hipDeviceSynchronize());  // the samples' device-to-device copies (training stream) are complete
+  if (mode == 2) {
+    if (d->cut.n < (size_t)n_cut * count) d->cut.alloc((size_t)n_cut * count);
+    MFM_HIP_CHECK(hipMemcpyAsync(d->cut.p, cutpoints, (size_t)n_cut * count * sizeof(double), hipMemcpyHostToDevice, s));
+  }
+  for (int k = 0; k < count; k++) {
+    const double *w = st->wv[first + k]->p, *V = w + D;
+    score_design(s, d->timing, 1, d->X, d->blocks, D, rank, d->KS, st->w0[first + k], w, V, d->Vt.p, nullptr, nullptr,
+                 d->score.p);
+    if (N) {
+      if (mode == 2)
+        hipLaunchKernelGGL(k_accumulate_oprobit, dim3(cdiv(N, WG)), dim3(WG), 0, s, d->score.p, d->cut.p + (size_t)k * n_cut, n_cut,
+                           d->out.p, N, k == 0);
+      else
+        hipLaunchKernelGGL(k_accumulate_pred, dim3(cdiv(N, WG)), dim3(WG), 0, s, d->score.p, d->out.p, N, mode, k == 0);
+      MFM_HIP_CHECK(hipGetLastError());
+    }
+  }
+  if (out_n) {
+    hipLaunchKernelGGL(k_scale, dim3(cdiv(out_n, WG)), dim3(WG), 0, s, d->out.p, out_n, 1.0 / count);
+    MFM_HIP_CHECK(hipMemcpyAsync(out, d->out.p, (size_t)out_n * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
   MFM_HIP_CHECK(hipStreamSynchronize(s));
   MFM_CATCH(d)
 }

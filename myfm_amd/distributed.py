@@ -68,3 +68,70 @@ class TorchAllReduce:
             self.dist.all_reduce(t, group=self.group)
         self.calls += 1
         self.doubles += int(count)
+
+
+# ---- native provider: the library calls RCCL itself (mfm_comm_init) -------------------------------------------------
+_STATE = {"on": False, "group": None}
+
+
+def enable(group=None, set_device=True):
+    """Make `MyFM*.fit()` row-sharded over the ranks of `group` (default: the world group of an initialised
+    torch.distributed): every rank calls fit() with the SAME full data, trains on its contiguous slice of the rows on its
+    own GPU (LOCAL_RANK) with the all-reduces issued by libmyfm_hip.so through RCCL, and ends with the same samples."""
+    import os
+
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        raise RuntimeError("torch.distributed is not initialised (init_process_group first)")
+    _STATE.update(on=True, group=group)
+    if set_device and "MYFM_AMD_DEVICE" not in os.environ:
+        os.environ["MYFM_AMD_DEVICE"] = os.environ.get("LOCAL_RANK", "0")
+
+
+def disable():
+    _STATE.update(on=False, group=None)
+
+
+def active():
+    if not _STATE["on"]:
+        return False
+    import torch.distributed as dist
+
+    return dist.is_initialized() and dist.get_world_size(_STATE["group"]) > 1
+
+
+def rank_world():
+    import torch.distributed as dist
+
+    return dist.get_rank(_STATE["group"]), dist.get_world_size(_STATE["group"])
+
+
+def native_comm_id(group=None):
+    """The 128-byte RCCL id of a new communicator: created on rank 0 (ncclGetUniqueId through the library), broadcast over
+    the process group (any backend)."""
+    import torch.distributed as dist
+
+    from . import _myfm
+
+    box = [_myfm.comm_unique_id() if dist.get_rank(group) == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return box[0]
+
+
+def shard_cuts(first_col, world):
+    """Row boundaries of `world` contiguous shards of a table whose rows are sorted by their first stored column
+    (`first_col[t]`): balanced, snapped to the nearest boundary between two first-level columns so that (almost) every
+    such column has all its rows on one rank. Returns world + 1 ascending row indices."""
+    first_col = np.asarray(first_col)
+    n = first_col.shape[0]
+    edges = np.concatenate([[0], np.flatnonzero(first_col[1:] != first_col[:-1]) + 1, [n]])
+    cuts = [0]
+    for r in range(1, world):
+        want = (n * r) // world
+        k = int(np.searchsorted(edges, want))
+        cand = [edges[max(k - 1, 0)], edges[min(k, len(edges) - 1)]]
+        best = min(cand, key=lambda e: abs(int(e) - want))
+        cuts.append(max(int(best), cuts[-1]))
+    cuts.append(n)
+    return cuts

@@ -203,7 +203,7 @@ class MyFMGibbsBase:
         if perm is not None:
             X = X[perm]
             y = np.asarray(y)[perm]
-            X_rel = [RelationBlock([int(v) for v in np.asarray(r.original_to_block)[perm]], r.data) for r in X_rel]
+            X_rel = [RelationBlock(r.original_to_block_array[perm], r.data) for r in X_rel]
         config_builder.set_task_type(self._task_type)
         config = config_builder.build()
 
@@ -217,9 +217,32 @@ class MyFMGibbsBase:
                 bar.update(message)
                 return bool(should_stop)
 
-            self.predictor_, self.history_ = _myfm.create_train_fm(
-                self.rank, self.init_stdev, X, list(X_rel), np.ascontiguousarray(y, dtype=REAL), self.random_seed, config, wrapped
-            )
+            from . import distributed as _dist
+
+            if _dist.active():
+                # row-sharded over the process group: same data on every rank, each trains on its slice
+                from . import _capi
+
+                rank, world = _dist.rank_world()
+                n = X.shape[0]
+                levels, _ = _capi.column_levels(X) if X.shape[1] else (np.zeros(0, np.int32), 0)
+                if X.shape[1] and np.diff(X.indptr).min() >= 1:
+                    cuts = _dist.shard_cuts(X.indices[X.indptr[:-1]], world)
+                else:
+                    cuts = [(n * r) // world for r in range(world + 1)]
+                lo, hi = cuts[rank], cuts[rank + 1]
+                if self._task_type == TaskType.ORDERED:  # the cutpoint group lists LOCAL rows
+                    config_builder.set_cutpoint_groups([(int(np.asarray(y).max()) + 1, list(range(hi - lo)))])
+                    config = config_builder.build()
+                rel_l = [RelationBlock(r.original_to_block_array[lo:hi], r.data) for r in X_rel]
+                y_l = np.ascontiguousarray(np.asarray(y, dtype=REAL)[lo:hi])
+                self.predictor_, self.history_ = _myfm.create_train_fm_sharded(
+                    self.rank, self.init_stdev, X[lo:hi], rel_l, y_l, self.random_seed, config, wrapped, rank, world, n, lo,
+                    np.ascontiguousarray(levels, dtype=np.int32), comm_id=_dist.native_comm_id(_dist._STATE["group"]))
+            else:
+                self.predictor_, self.history_ = _myfm.create_train_fm(
+                    self.rank, self.init_stdev, X, list(X_rel), np.ascontiguousarray(y, dtype=REAL), self.random_seed, config,
+                    wrapped)
 
     # ---- posterior access ---------------------------------------------------------------------------
     def _fetch_predictor(self):

@@ -30,9 +30,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        path = os.environ.get("MYFM_ORACLE_LIB") or _LIB_PATH  # (bench.py's CPU leg: a -march=native build of the same source)
+        if path == _LIB_PATH and not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(path)
         vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
         P = C.c_void_p  # raw data pointers
         L.orc_last_error.restype = C.c_char_p

@@ -402,6 +402,37 @@ def test_predict_modes(oracle, capi):
     np.testing.assert_allclose(p, exp / len(samples), rtol=1e-10, atol=1e-12)
 
 
+def test_sample_store_predicts_like_host_samples(oracle, capi):
+    # device-resident posterior samples (mfm_store_*): pushed from the host and snapshotted from a training context;
+    # Predictor::predict* over the store == over host copies of the same samples (all three modes), == the oracle
+    main, X_flat, blocks, y, shapes = ds.multihot_block_design()
+    rng = np.random.default_rng(4)
+    D, K = X_flat.shape[1], 4
+    samples = [(rng.normal(), rng.normal(size=D) * 0.3, rng.normal(size=(D, K)) * 0.3) for _ in range(5)]
+    st = capi.Store(D, K)
+    for s in samples[:3]:
+        st.push(*s)
+    c = capi.Context(main, y, blocks, rank=K, group_index=ds.group_index_from_shapes(shapes))
+    for s in samples[3:]:
+        c.set_state(*s)
+        st.push_ctx(c)  # device-to-device snapshot of the live state
+    assert len(st) == 5
+    for k, s in enumerate(samples):
+        w0, w, V = st.get(k)
+        assert w0 == s[0] and np.array_equal(w, s[1]) and np.array_equal(V, s[2])
+    dev = capi.Design(main, blocks)
+    cuts = [np.sort(rng.normal(size=2)) for _ in samples]
+    for mode in (0, 1, 2):
+        a = st.predict(dev, mode, cuts if mode == 2 else None)
+        b = dev.predict(samples, mode, cuts if mode == 2 else None)
+        assert np.array_equal(a, b)
+    od = oracle.OracleDesign(main, blocks)
+    want = np.mean([od.predict_score(*s) for s in samples[1:4]], axis=0)
+    np.testing.assert_allclose(st.predict(dev, 0, first=1, count=3), want, rtol=1e-11, atol=1e-11)
+    with pytest.raises(ValueError):
+        st.predict(dev, 0, first=3, count=5)
+
+
 def test_error_paths(capi):
     X, y = ds.toy()
     with pytest.raises(RuntimeError, match="index mapping points to non-existing row"):

@@ -72,6 +72,29 @@ def test_libfm_callbacks(myfm, oracle):
     assert cb.result_trace[-1]["accuracy"] > 0.3
 
 
+def test_kept_samples_stay_on_device_until_asked_for(myfm, oracle, monkeypatch):
+    # FMTrainer.hpp:71-74 retention without host copies: predict() reads the samples in place; w_samples / V_samples,
+    # pickling and per-sample predict_score materialise them; a sample the user edits detaches from the store
+    X, y, shapes = ds.onehot_mf(20000, 300, 60, seed=8)
+    gi = ds.group_index_from_shapes(shapes)
+    fm = myfm.MyFMRegressor(5).fit(X, y, group_shapes=shapes, n_iter=8, n_kept_samples=6)
+    Xt = X[::7]
+    p_dev = fm.predict(Xt)
+    samples, _, _ = oracle.fit(X, y, rank=5, group_index=gi, n_iter=8, n_kept_samples=6)
+    want = np.mean([oracle.OracleDesign(Xt).predict_score(*s) for s in samples], axis=0)
+    np.testing.assert_allclose(p_dev, want, rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(fm.V_samples[-1], samples[-1][2], rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(fm.w0_samples, [s[0] for s in samples], rtol=1e-9)
+    blob = pickle.dumps(fm.predictor_)
+    p2 = pickle.loads(blob)
+    np.testing.assert_allclose(p2.predict(Xt, []), p_dev, rtol=1e-12, atol=1e-12)
+    # host-sample mode gives the same numbers
+    monkeypatch.setenv("MYFM_AMD_HOST_SAMPLES", "1")
+    fm_h = myfm.MyFMRegressor(5).fit(X, y, group_shapes=shapes, n_iter=8, n_kept_samples=6)
+    assert np.array_equal(fm_h.predict(Xt), p_dev)
+    assert np.array_equal(fm_h.V_samples, fm.V_samples)
+
+
 def test_toy_config1(myfm):
     # BASELINE config 1 / examples/toy.py
     X, y = ds.toy()

@@ -109,7 +109,7 @@ def test_two_shards_lockstep(oracle, name):
             Xl, yl, rel, lo, n = shard_rows(X, y, blocks, rank, world)
             rbs = [_myfm.RelationBlock([int(v) for v in m], b) for m, b in rel]
             s = _myfm.GibbsSession(K, 0.1, Xl, rbs, yl, 42, _config(gi), allreduce=ls.callback(rank), n_total_rows=n,
-                                   row_offset=lo, main_levels=levels)
+                                   row_offset=lo, main_levels=levels, shard_rank=rank, shard_world=world)
             for it in range(4):
                 s.step()
             out[rank] = (s.fm.w0, np.asarray(s.fm.w), np.asarray(s.fm.V), s.residual(), lo, float(s.hyper.alpha))
@@ -169,7 +169,7 @@ def test_sharded_fused_tile_path(oracle, world, values, n_fields, monkeypatch):
         try:
             Xl, yl, rel, lo, ntot = shard_rows(X, y, [], rank, world)
             s = _myfm.GibbsSession(K, 0.1, Xl, [], yl, 42, _config(gi), allreduce=ls.callback(rank), n_total_rows=ntot,
-                                   row_offset=lo, main_levels=levels)
+                                   row_offset=lo, main_levels=levels, shard_rank=rank, shard_world=world)
             flags = s.plan_flags()
             for it in range(3):
                 s.step()
@@ -219,7 +219,7 @@ def test_random_designs_sharded(oracle, seed, world, monkeypatch):
         try:
             Xl, yl, rel, lo, ntot = shard_rows(X, y, [], rank, world)
             s = _myfm.GibbsSession(K, 0.1, Xl, [], yl, 42, _config(gi), allreduce=ls.callback(rank), n_total_rows=ntot,
-                                   row_offset=lo, main_levels=levels)
+                                   row_offset=lo, main_levels=levels, shard_rank=rank, shard_world=world)
             for it in range(3):
                 s.step()
             out[rank] = (s.fm.w0, np.asarray(s.fm.w), np.asarray(s.fm.V), s.residual(), lo, s.plan_flags())
@@ -244,3 +244,89 @@ def test_random_designs_sharded(oracle, seed, world, monkeypatch):
         np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8, err_msg=str(flags))
         np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(ge, e[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
+
+
+def test_world1_native_rccl(oracle):
+    # the library's own RCCL all-reduce (mfm_comm_init: ncclCommInitRank + ncclAllReduce on the ctx stream), world = 1:
+    # the communicator, the per-level call sequence and the fused sharded tile path, against the oracle's chain
+    from myfm_amd import _capi, _myfm
+
+    X, y, shapes = ds.onehot_mf(30000, 400, 60, seed=3)
+    gi = ds.group_index_from_shapes(shapes)
+    cid = _myfm.comm_unique_id()
+    assert len(cid) == 128
+    s = _myfm.GibbsSession(4, 0.1, X, [], y, 42, _config(gi), n_total_rows=X.shape[0], main_levels=_capi.column_levels(X)[0],
+                           comm_id=cid, shard_rank=0, shard_world=1)
+    t = oracle.OracleTrainer(X, y, rank=4, group_index=gi)
+    for it in range(4):
+        s.step()
+        t.step()
+    np.testing.assert_allclose(s.fm.V, t.fm()[2], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(s.residual(), t.e(X.shape[0]), rtol=1e-7, atol=1e-7)
+    calls, doubles = s.comm_stats()
+    assert calls > 4 * 5 and doubles > 0
+    assert s.plan_flags() & 8
+
+
+def test_multi_gpu_sharded_fit():
+    # real multi-GPU run (one process per GPU, RCCL over xGMI): needs >= 2 visible GPUs, skipped otherwise
+    import os
+    import subprocess
+    import sys
+
+    from myfm_amd import _myfm
+
+    n = _myfm.device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (this box has %d)" % n)
+    world = 2 if n < 4 else 4
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", "29631", os.path.join(root, "tests", "mp_fit_worker.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "mp_fit_worker ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_empty_shard_does_not_hang_or_corrupt(oracle, monkeypatch):
+    # a rank without rows must take part in every collective of mfm_finalize and of the sweeps, and the owner of
+    # the replicated columns is rank 0 of the communicator, not "the rank whose first row is global row 0"
+    from myfm_amd import _capi, _myfm
+
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    n = 30000
+    X, y, shapes = ds.onehot_mf(n, 50, 40, seed=12, sort_by_user=True)
+    gi = ds.group_index_from_shapes(shapes)
+    K, world = 3, 3
+    cuts = [0, 0, 14000, n]  # rank 0 holds no rows (and rank 1 starts at global row 0 too)
+    ls = Lockstep(world)
+    levels = _capi.column_levels(X)[0]
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            lo, hi = cuts[rank], cuts[rank + 1]
+            s = _myfm.GibbsSession(K, 0.1, X[lo:hi], [], y[lo:hi], 42, _config(gi), allreduce=ls.callback(rank), n_total_rows=n,
+                                   row_offset=lo, main_levels=levels, shard_rank=rank, shard_world=world)
+            for it in range(3):
+                s.step()
+            out[rank] = (np.asarray(s.fm.w), np.asarray(s.fm.V), s.residual(), lo)
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            ls.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=300)
+    assert not errs, errs
+    t = oracle.OracleTrainer(X, y, rank=K, group_index=gi)
+    for it in range(3):
+        t.step()
+    _, w, V = t.fm()
+    for rank in range(world):
+        gw, gV, ge, lo = out[rank]
+        np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(ge, t.e(n)[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)

@@ -102,3 +102,47 @@ def test_row_range_partition():
     blocks = [(np.arange(10) % 3, sps.csr_matrix(np.eye(3)))]
     Xl, yl, rel, lo, n = shard_rows(X, y, blocks, 1, 3)
     assert (lo, n) == (4, 10) and Xl.shape[0] == 3 and (yl == [4, 5, 6]).all() and (rel[0][0] == [1, 2, 0]).all()
+
+
+def _cuts_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from myfm_amd import distributed as D
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    D.enable(set_device=False)
+    assert D.active() and D.rank_world() == (rank, world)
+    X, y, shapes = ds.onehot_mf(5000, 70, 30, seed=4)
+    cuts = D.shard_cuts(X.indices[X.indptr[:-1]], world)
+    box = [cuts]
+    dist.broadcast_object_list(box, src=0)
+    assert box[0] == cuts  # every rank derives the same partition from the same data
+    first = X.indices[X.indptr[:-1]]
+    for c in cuts[1:-1]:
+        assert first[c] != first[c - 1]  # cut between two first-level columns
+    assert cuts[0] == 0 and cuts[-1] == 5000 and all(b >= a for a, b in zip(cuts, cuts[1:]))
+    assert abs((cuts[rank + 1] - cuts[rank]) - 5000 // world) < 500
+    D.disable()
+    assert not D.active()
+    dist.destroy_process_group()
+    out.put((rank, "ok"))
+
+
+def test_fit_sharding_plan_two_ranks():
+    """MyFM*.fit() under myfm_amd.distributed.enable(): the row partition every rank computes (host logic; the device side
+    of the same path is tests/test_gpu_sharded.py)."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + 17
+    ps = [ctx.Process(target=_cuts_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p_ in ps:
+        p_.start()
+    got = sorted(out.get(timeout=240) for _ in ps)
+    for p_ in ps:
+        p_.join(60)
+    assert got == [(0, "ok"), (1, "ok")]
