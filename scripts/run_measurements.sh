@@ -1,11 +1,15 @@
+# round-2 measurement batch (run on the GPU box through gpurun): bench line, kernel trace, PMC traffic, SQ counters,
+# predictor timing, other workloads. Outputs under gpurun_out/r02_z_*; summaries are copied to profiles/ afterwards.
 set -x
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python bench.py --steps 30 --warmup 5 > gpurun_out/r01_i_bench.json 2> gpurun_out/r01_i_bench.err
+T=${1:-r02_z}
+python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r01_i_trace -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --cpu-iters 0 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r01_i_pmc_fetch -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-iters 0 --no-kernel-timing > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r01_i_pmc_write -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-iters 0 --no-kernel-timing > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${T}_trace -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --cpu-seconds 0 --fit-iters 0 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${T}_pmc_fetch -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --fit-iters 0 --no-kernel-timing > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${T}_pmc_write -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --fit-iters 0 --no-kernel-timing > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
-ls gpurun_out/r01_i_pmc_fetch gpurun_out/r01_i_pmc_write
-du -sh gpurun_out/r01_i_pmc_fetch gpurun_out/r01_i_pmc_write
+python scripts/pmc_to_traffic.py gpurun_out/${T}_pmc_fetch gpurun_out/${T}_pmc_write gpurun_out/${T}_pmc_traffic | head -30
+python scripts/rocpd_summary.py gpurun_out/${T}_trace > gpurun_out/${T}_kernel_stats.txt 2>&1; head -30 gpurun_out/${T}_kernel_stats.txt
+rm -rf gpurun_out/${T}_pmc_fetch gpurun_out/${T}_pmc_write/p_agent_info.csv
+python scripts/bench_predict.py > gpurun_out/${T}_predict.txt 2>&1; tail -5 gpurun_out/${T}_predict.txt
