@@ -663,6 +663,18 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   if (c->sharded_fused) {
     c->ec.alloc((size_t)c->N);
     c->qc.alloc((size_t)c->N);
+    // no first-level column straddles a rank boundary (and none is longer than ... any length is fine): the two-field pass
+    c->mf = plan_supports_mf(c->plan_V) && c->plan_V.n_special == 0 && !std::getenv("MFM_NO_MF") &&
+            !std::getenv("MFM_NO_FUSED_TWO") && !std::getenv("MFM_NO_FUSED_STATS");
+    {  // every rank must take the same path
+      double no = c->mf ? 0.0 : 1.0;
+      DevBuf<double> d;
+      d.upload(&no, 1);
+      c->comm.allreduce(d.p, 1);
+      MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
+      MFM_HIP_CHECK(hipMemcpy(&no, d.p, sizeof(double), hipMemcpyDeviceToHost));
+      c->mf = no == 0.0;
+    }
   }
   if (c->soa) {
     c->ec.alloc((size_t)c->N);
@@ -979,7 +991,12 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       a.r_ell = (int)c->X.ell_width;
       return a;
     };
-    if (c->plan_V.steps.size() > 2) {
+    if (c->mf) {
+      if (c->X.unit)
+        run_sweep_mf<true>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, &c->comm);
+      else
+        run_sweep_mf<false>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, &c->comm);
+    } else if (c->plan_V.steps.size() > 2) {
       if (c->X.unit)
         run_sweep_soa_multi<true>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, &c->comm);
       else

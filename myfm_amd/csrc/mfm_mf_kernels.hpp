@@ -604,6 +604,21 @@ __global__ __launch_bounds__(512) void k_mf_score(MfScoreArgs a) {
   }
 }
 
+// row-sharded mode: the item draw from the all-reduced per-column statistics S (k_tile_sum), identical on every rank
+__global__ void k_mf_draw_S(SweepArgs a, const int32_t *__restrict__ cols, int n_cols, const double2 *__restrict__ S,
+                            const double *__restrict__ theta_next, double2 *__restrict__ dv) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cols) return;
+  const int j = cols[c];
+  const double vn = theta_next ? theta_next[j] : 0.0;
+  const double2 s = S[c];
+  const double old = a.theta[j];
+  const int g = a.group[j];
+  const double fresh = PMainV::draw(s.x, s.y, old, a.alpha, a.lambda[g], a.mu[g], a.z[j]);
+  a.theta[j] = fresh;
+  dv[c] = make_double2(fresh - old, vn);
+}
+
 // before the first pass of a sweep: dv[c] = (0, V[column c, first factor])
 __global__ void k_mf_gather(const double *__restrict__ theta, const int32_t *__restrict__ cols, int n_cols,
                             double2 *__restrict__ dv) {

@@ -1486,7 +1486,9 @@ static inline int mf_rows_per_thread() {
 // residual is read from at the start and written back to at the end. K + 1 passes over the residual for K factors.
 template <bool UNIT, class ArgsOf>
 static void run_sweep_mf(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf args, int f_begin, int f_end, LongScratch &ls,
-                         const SweepClasses &kc) {
+                         const SweepClasses &kc, const Comm *comm = nullptr) {
+  // comm != null: row-sharded, every first-level column complete on one rank (shards cut between two of them): the user
+  // level runs locally inside the tiles, per factor ONE all-reduce carries the item level's statistics (2 n_cols doubles)
   const ParLevel &L = plan.steps.back().par;
   const int swz = xcd_swizzle_enabled();
   const int KR = mf_rows_per_thread();
@@ -1531,7 +1533,7 @@ static void run_sweep_mf(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf
   // MFM_MF_STREAM_SLOTS=1: slots in stream order (whole-line stores) + a transpose-reduce before the draw. Measured at
   // config 3: the pass 116 -> 100 us, but the 4.6 M random 16-byte reads of the transpose cost 59 us (the column-major
   // scatter costs ~28 us on the store side): random 16-byte accesses run at ~80 G/s chip-wide either way. Default off.
-  const bool stream_slots = std::getenv("MFM_MF_STREAM_SLOTS") != nullptr;
+  const bool stream_slots = std::getenv("MFM_MF_STREAM_SLOTS") != nullptr && !(comm && comm->active());
   m.slot_pos = stream_slots ? nullptr : L.slot_pos.p;
   m.slots = L.slots.p;
   m.solo_col = plan.n_long_cols ? plan.solo_col.p : nullptr;
@@ -1587,7 +1589,12 @@ static void run_sweep_mf(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf
     if (more) an = args(f + 1);
     {
       TimedLaunch t(tm, s, kc.scat, (stream_slots ? 20.0 : 16.0) * L.n_runs + 56.0 * L.n_cols);
-      if (stream_slots) {
+      if (comm && comm->active()) {
+        hipLaunchKernelGGL(k_tile_sum, dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, L.n_cols, L.slot_ptr.p, L.slots.p, ls.S_col.p);
+        comm->allreduce(ls.S_col.p, 2 * (int64_t)L.n_cols);
+        hipLaunchKernelGGL(k_mf_draw_S, dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a, L.scols.p, L.n_cols, ls.S_col.p,
+                           more ? an.theta : (const double *)nullptr, ls.dv_col.p);
+      } else if (stream_slots) {
         hipLaunchKernelGGL(k_mf_gather_reduce, dim3((L.n_runs + WG - 1) / WG), dim3(WG), 0, s, L.g_inv.p, L.n_runs, L.g_wbase.p,
                            L.slots.p, L.g_part.p);
         hipLaunchKernelGGL(k_mf_draw, dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.g_ptr.p, L.g_part.p,

@@ -330,3 +330,57 @@ def test_empty_shard_does_not_hang_or_corrupt(oracle, monkeypatch):
         np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(ge, t.e(n)[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize("world,values", [(2, False), (3, True)])
+def test_sharded_two_field_pass(oracle, world, values, monkeypatch):
+    """shards cut BETWEEN users (myfm_amd.distributed.shard_cuts: what fit() and bench.py do): no first-level column
+    straddles a rank, the q-cache-free two-field pass runs on every rank with one all-reduce of the item statistics per
+    factor; one user is longer than a tile (solo tiles + finish pass)"""
+    from myfm_amd import _capi, _myfm
+    from myfm_amd.distributed import shard_cuts
+
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    n = 90001
+    X, y, shapes = ds.onehot_mf(n, 80, 70, seed=9, sort_by_user=True)
+    if values:
+        X = X.copy()
+        X.data = np.where(np.arange(X.nnz) % 3 == 0, 0.5, 1.5)
+    gi = ds.group_index_from_shapes(shapes)
+    K = 3
+    cuts = shard_cuts(X.indices[X.indptr[:-1]], world)
+    ls = Lockstep(world)
+    levels = _capi.column_levels(X)[0]
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            lo, hi = cuts[rank], cuts[rank + 1]
+            s = _myfm.GibbsSession(K, 0.1, X[lo:hi], [], y[lo:hi], 42, _config(gi), allreduce=ls.callback(rank), n_total_rows=n,
+                                   row_offset=lo, main_levels=levels, shard_rank=rank, shard_world=world)
+            flags = s.plan_flags()
+            for it in range(3):
+                s.step()
+            out[rank] = (s.fm.w0, np.asarray(s.fm.w), np.asarray(s.fm.V), s.residual(), lo, flags)
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            ls.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=300)
+    assert not errs, errs
+    t = oracle.OracleTrainer(X, y, rank=K, group_index=gi)
+    for it in range(3):
+        t.step()
+    w0, w, V = t.fm()
+    e = t.e(n)
+    for rank in range(world):
+        gw0, gw, gV, ge, lo, flags = out[rank]
+        assert flags & 64 and flags & 128, flags  # sharded fused path + two-field pass
+        assert abs(gw0 - w0) < 1e-7
+        np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(ge, e[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
