@@ -4,6 +4,7 @@
 // level schedule), launches the kernels of mfm_kernels.hpp / mfm_block_kernels.hpp on one HIP
 // stream and exposes them as the entry points the pybind11 host layer (csrc/_myfm.cpp) binds.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <memory>
@@ -519,10 +520,21 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   if (c->N >= (int64_t)2147483647) throw Error(MFM_ERR_INVALID, "N must be < 2^31 per GPU");
   c->K = rank;
   c->KS = (rank + 1) & ~1;
+  const bool tlog = std::getenv("MFM_SETUP_TIMING") != nullptr;
+  auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_prev = tnow();
+  auto lap = [&](const char *what) {
+    if (!tlog) return;
+    const double t = tnow();
+    std::fprintf(stderr, "[mfm_finalize] %-28s %7.3f s\n", what, t - t_prev);
+    t_prev = t;
+  };
   // main table
   {
     HostCsr Xt = transpose_host(c->hX);
+    lap("transpose (host)");
     c->X.upload(c->hX, &Xt);
+    lap("upload CSR + CSC");
     c->plan_V.sharded = c->plan_W.sharded = c->comm.active();
     c->plan_V.given_levels = c->plan_W.given_levels = c->hlevels;
     // scattered levels: LDS row tiles of 2^tile_bits {e, q} records (64 KiB by default: two workgroups per CU)
@@ -578,6 +590,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     }
     c->plan_V.group_of = &c->hgroup;
     c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_v, true, c->X.unit);
+    lap("plan_V");
     if (try_fused) {
       // every rank must take the same path: agree
       double bad = plan_supports_sharded_fused(c->plan_V) ? 0.0 : 1.0;
@@ -604,6 +617,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
       }
     }
     c->plan_W.build(Xt, PMainW::R_W16, PMainW::R_WG, coop_capacity<PMainW>(), true, c->X.unit);
+    lap("plan_W");
     c->ls.reserve_cols(std::max(c->plan_V.max_cols_scat, c->plan_W.max_cols_scat));
     if (c->comm.active()) {
       c->ls.reserve_cols(c->D0);
@@ -684,6 +698,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
             !std::getenv("MFM_NO_FUSED_STATS");
   }
   MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
+  lap("blocks, state, scratch");
   // host copies are no longer needed
   c->hX = HostCsr();
   c->hy.clear();
