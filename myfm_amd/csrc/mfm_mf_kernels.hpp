@@ -337,7 +337,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
     } else if (a.dbg & 32) {  // the same stores, tile-major (contiguous per tile) instead of column-major
       if (flags[k] & 2u) a.slots[rb[k] + __popcll(__ballot(flags[k] & 1u) & ((2ull << lane) - 1ull)) - 1] = make_double2(s1, s2);
     } else if (flags[k] & 2u) {
-      a.slots[pos[k]] = make_double2(s1, s2);
+      // (dbg 256: timing experiment -- all slot stores folded into a 4 MiB window, i.e. cache-resident targets)
+      a.slots[(a.dbg & 256) ? (pos[k] & 0x3ffff) : pos[k]] = make_double2(s1, s2);
     }
   }
 }
@@ -521,9 +522,25 @@ struct MfScoreArgs {
   int K, KS;
   const double *y;  // may be null
   double2 *eq;
+  int ucache;  // > 0: the Vt rows of the tile's first-level columns (at most this many) are staged in LDS
+  int dbg;     // timing experiments (wrong results): 1 no item-row gather, 2 no user-row gather, 4 no final store
 };
 
-template <int GS, bool UNIT>
+// sum over the GS lanes of a lane group (GS a power of two <= 64, groups aligned to GS), valid in the group's LAST lane:
+// DPP row shifts (and row broadcasts above 16 lanes) in the VALU -- __shfl_xor would be ds_bpermute traffic on the LDS
+// crossbar, 2 GS-step instructions per double and entry, which was this kernel's bottleneck
+template <int GS>
+__device__ __forceinline__ double group_sum_last(double v) {
+  if (GS >= 2) v += dpp_f64<0x111, 0xf>(v);   // row_shr:1
+  if (GS >= 4) v += dpp_f64<0x112, 0xf>(v);   // row_shr:2
+  if (GS >= 8) v += dpp_f64<0x114, 0xf>(v);   // row_shr:4
+  if (GS >= 16) v += dpp_f64<0x118, 0xf>(v);  // row_shr:8
+  if (GS >= 32) v += dpp_f64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  if (GS >= 64) v += dpp_f64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+template <int GS, int SPL, bool UNIT>
 __global__ __launch_bounds__(512) void k_mf_score(MfScoreArgs a) {
   extern __shared__ double2 mf_lds[];
   const int R = 1 << a.tile_bits;
@@ -539,65 +556,119 @@ __global__ __launch_bounds__(512) void k_mf_score(MfScoreArgs a) {
   const int c0 = a.ucol_ptr[b], nu = a.ucol_ptr[b + 1] - c0;
   const int cbase = a.chunk_ptr[b];
   const uint32_t rmask = (uint32_t)R - 1u;
-  for (int uu = tid; uu < nu; uu += nt) {
-    const int4 d = a.udesc[c0 + uu];
-    if (d.y > 0) {
-      ucol[uu] = d.x;
-      if (!UNIT) uvb[uu] = (long long)a.colptr[d.x] - d.z;
-    }
+  const int ucap = mf_user_cap(a.tile_bits);
+  for (int uu = tid; uu < min(nu, ucap); uu += nt) {  // (columns with rows come first and number <= ucap; the never-occurring
+    const int4 d = a.udesc[c0 + uu];                  //  ones behind them get a valid feature too: nobody reads their row)
+    ucol[uu] = d.x;
+    if (!UNIT) uvb[uu] = (long long)a.colptr[d.x] - d.z;
   }
   __syncthreads();
+  // The tile's few first-level columns are needed by every entry: their Vt rows go to LDS once (the stream of item rows
+  // would keep evicting them from the 32 KiB L1, and every miss is another 256-byte L2 read)
+  double2 *uV = (double2 *)(uvb + mf_user_cap(a.tile_bits));  // [ucache][KS / 2]
+  const int KP = a.KS >> 1;
+  const bool cached = a.ucache > 0;
+  if (cached) {
+    const int nrows = solo_j >= 0 ? 1 : min(nu, a.ucache);
+    for (int i = tid; i < nrows * KP; i += nt) {
+      const int ul = i / KP, pr = i - ul * KP;
+      const int j = solo_j >= 0 ? solo_j : ucol[ul];  // (columns with rows come first: ul < number of them <= ucache)
+      uV[i] = ((const double2 *)(a.Vt + (int64_t)j * a.KS))[pr];
+    }
+    __syncthreads();
+  }
   const int64_t p0 = (int64_t)a.tile_ptr[b] * WAVE, p1 = (int64_t)a.tile_ptr[b + 1] * WAVE;
-  const bool own = 2 * lig < a.K;  // (the pad column of an odd K is zero in Vt)
-  constexpr int RU = 4;
-  for (int64_t pb = p0 + grp; pb < p1; pb += (int64_t)ngrp * RU) {
-    uint32_t u[RU];
-    int ju[RU], ji[RU];
-    double xa[RU], xb[RU];
+  // lane `lig` of an entry's GS lanes owns the factor pairs lig + s GS, s < SPL (pairs beyond KS / 2 do not exist; the pad
+  // column of an odd K is zero in Vt). Few lanes per entry: the per-entry index work is not replicated 16 times.
+  constexpr int RU = SPL >= 4 ? 2 : 4;
+  // Software pipeline over the group's entries: while the Vt rows of batch i are gathered and reduced, the entries of
+  // batch i + 1 and their features / chunk descriptors (two dependent round trips) are already in flight.
+  uint32_t u[RU], un[RU];
+  int ju[RU], ji[RU], jun[RU], jin[RU], lu[RU], lun[RU];
+  double xa[RU], xb[RU], xan[RU], xbn[RU];
+  auto load_entries = [&](int64_t pb, uint32_t (&uu)[RU], double (&xxb)[RU]) {
 #pragma unroll
     for (int q = 0; q < RU; q++) {
       const int64_t p = pb + (int64_t)q * ngrp;
-      u[q] = p < p1 ? __builtin_nontemporal_load(&a.tent[p]) : TILE_PAD;  // (streams: keep the L2 for the Vt rows)
-      xb[q] = !UNIT && p < p1 ? __builtin_nontemporal_load(&a.tval[p]) : 1.0;
+      uu[q] = p < p1 ? __builtin_nontemporal_load(&a.tent[p]) : TILE_PAD;  // (streams: keep the L2 for the Vt rows)
+      xxb[q] = !UNIT && p < p1 ? __builtin_nontemporal_load(&a.tval[p]) : 1.0;
     }
+  };
+  auto resolve = [&](const uint32_t (&uu)[RU], int (&jju)[RU], int (&jji)[RU], double (&xxa)[RU], int (&uul)[RU]) {
 #pragma unroll
     for (int q = 0; q < RU; q++) {
-      ju[q] = 0;
-      ji[q] = 0;
-      xa[q] = 1.0;
-      if (u[q] == TILE_PAD) continue;
-      const int r = (int)(u[q] & rmask);
-      ji[q] = a.scols[u[q] >> a.tile_bits];
+      jju[q] = 0;
+      jji[q] = 0;
+      uul[q] = 0;
+      xxa[q] = 1.0;
+      if (uu[q] == TILE_PAD) continue;
+      const int r = (int)(uu[q] & rmask);
+      jji[q] = a.scols[uu[q] >> a.tile_bits];
       if (solo_j >= 0) {
-        ju[q] = solo_j;
-        if (!UNIT) xa[q] = a.cval[a.colptr[solo_j] + (row0 - a.col_row0[solo_j]) + r];
+        jju[q] = solo_j;
+        if (!UNIT) xxa[q] = a.cval[a.colptr[solo_j] + (row0 - a.col_row0[solo_j]) + r];
       } else {
         const MfChunk C = a.chunk[cbase + (r >> 6)];
         const int ul = C.ubase + __popcll(C.heads & ((2ull << (r & 63)) - 2ull));
-        ju[q] = ucol[ul];
-        if (!UNIT) xa[q] = a.cval[uvb[ul] + r];
+        uul[q] = ul;
+        jju[q] = ucol[ul];
+        if (!UNIT) xxa[q] = a.cval[uvb[ul] + r];
       }
     }
+  };
+  const int64_t stride = (int64_t)ngrp * RU;
+  int64_t pb = p0 + grp;
+  load_entries(pb, u, xb);
+  resolve(u, ju, ji, xa, lu);
+  load_entries(pb + stride, un, xbn);
+  for (; pb < p1; pb += stride) {
+    double2 vi[RU][SPL];
     double dot[RU];
 #pragma unroll
     for (int q = 0; q < RU; q++) {
-      dot[q] = 0.0;
-      if (u[q] != TILE_PAD && own) {
-        const double2 vu = ((const double2 *)(a.Vt + (int64_t)ju[q] * a.KS))[lig];
-        const double2 vi = ((const double2 *)(a.Vt + (int64_t)ji[q] * a.KS))[lig];
-        dot[q] = vu.x * vi.x + vu.y * vi.y;
+#pragma unroll
+      for (int sp = 0; sp < SPL; sp++) {
+        vi[q][sp] = make_double2(0.0, 0.0);
+        if (u[q] != TILE_PAD && lig + sp * GS < KP && !(a.dbg & 1))
+          vi[q][sp] = ((const double2 *)(a.Vt + (int64_t)ji[q] * a.KS))[lig + sp * GS];
       }
     }
 #pragma unroll
     for (int q = 0; q < RU; q++) {
-      double part = dot[q];
+      dot[q] = 0.0;
 #pragma unroll
-      for (int m = GS / 2; m >= 1; m >>= 1) part += __shfl_xor(part, m, WAVE);
-      if (lig == 0 && u[q] != TILE_PAD)
+      for (int sp = 0; sp < SPL; sp++) {
+        if (u[q] != TILE_PAD && lig + sp * GS < KP && !(a.dbg & 2)) {
+          const double2 vu = cached ? uV[lu[q] * KP + lig + sp * GS] : ((const double2 *)(a.Vt + (int64_t)ju[q] * a.KS))[lig + sp * GS];
+          dot[q] += vu.x * vi[q][sp].x + vu.y * vi[q][sp].y;
+        }
+      }
+    }
+    // next batch: features / descriptors of the entries loaded one iteration ago, entries of the batch after it
+    resolve(un, jun, jin, xan, lun);
+    uint32_t u2[RU];
+    double xb2[RU];
+    load_entries(pb + 2 * stride, u2, xb2);
+#pragma unroll
+    for (int q = 0; q < RU; q++) {
+      const double part = group_sum_last<GS>(dot[q]);
+      if (lig == GS - 1 && u[q] != TILE_PAD)
         sc[u[q] & rmask] = a.w0 + (xa[q] * a.w[ju[q]] + xb[q] * a.w[ji[q]]) + (xa[q] * xb[q]) * part;
+    }
+#pragma unroll
+    for (int q = 0; q < RU; q++) {
+      u[q] = un[q];
+      lu[q] = lun[q];
+      ju[q] = jun[q];
+      ji[q] = jin[q];
+      xa[q] = xan[q];
+      xb[q] = xbn[q];
+      un[q] = u2[q];
+      xbn[q] = xb2[q];
     }
   }
   __syncthreads();
+  if (a.dbg & 4) return;
   for (int i = tid; i < nr; i += nt) {
     const double yv = a.y ? __builtin_nontemporal_load(&a.y[row0 + i]) : 0.0;
     a.eq[row0 + i].x = sc[i] - yv;

@@ -206,6 +206,7 @@ struct StepPlan {
   DevBuf<int32_t> mf_chunk_ptr;
   DevBuf<int2> mf_upart;
   bool mf_ready = false;
+  int mf_max_users = 0;  // most first-level columns with rows in one tile
 
   // a level is "tiny" when running it as its own launches cannot fill the device anyway
   static bool tiny(size_t n_cols, int64_t nnz) { return n_cols <= 8 && nnz <= 16384; }
@@ -619,6 +620,12 @@ struct StepPlan {
           const int seg = __builtin_popcountll(C[ca].heads & ((2ull << (lr0 & 63)) - 2ull));
           upart[k] = make_int2(C[ca].pbase + seg, cb - ca + 1);
         }
+      }
+      mf_max_users = 0;
+      for (size_t b = 0; b < nt_; b++) {
+        int cnt = 0;
+        for (int32_t k = fptr[b]; k < fptr[b + 1]; k++) cnt += desc[k].y > 0;
+        mf_max_users = std::max(mf_max_users, cnt);
       }
       mf_chunk.upload(chunks.data(), chunks.size());
       mf_chunk_ptr.upload(cptr);
@@ -1640,29 +1647,46 @@ static bool launch_mf_score(hipStream_t s, const StepPlan &plan, const SweepArgs
   m.KS = KS;
   m.y = y;
   m.eq = eq;
-  const size_t lds = ((size_t)8 << L.tile_bits) + (size_t)mf_user_cap(L.tile_bits) * 12 + 16;
-  const int gs = KS / 2;
+  m.dbg = std::getenv("MFM_SCORE_DBG") ? std::atoi(std::getenv("MFM_SCORE_DBG")) : 0;
+  size_t lds = ((size_t)8 << L.tile_bits) + (size_t)mf_user_cap(L.tile_bits) * 12 + 16;
+  {
+    // stage the tile's first-level Vt rows in LDS when they fit next to the score array (three workgroups per CU)
+    const size_t rows = (size_t)std::max(plan.mf_max_users, 1);
+    const size_t need = rows * (size_t)KS * 8;
+    const size_t cap = std::getenv("MFM_SCORE_UCACHE_KB") ? (size_t)std::atoi(std::getenv("MFM_SCORE_UCACHE_KB")) * 1024 : 52 * 1024;
+    if (std::getenv("MFM_SETUP_TIMING")) std::fprintf(stderr, "[k_mf_score] max users per tile %d, LDS %zu + %zu\n", plan.mf_max_users, lds, need);
+    if (lds + need <= cap && !std::getenv("MFM_NO_SCORE_UCACHE")) {
+      m.ucache = (int)rows;
+      lds += need;
+    }
+  }
+  const int kp = KS / 2;  // factor pairs
   const int nt = 512;
-#define MFM_MFS(G)                                                                                                        \
+#define MFM_MFS(G, S)                                                                                                     \
   do {                                                                                                                    \
     static bool raised = false;                                                                                           \
     if (!raised) {                                                                                                        \
-      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_score<G, UNIT>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_score<G, S, UNIT>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                         (int)CHAIN_LDS_MAX));                                                             \
       raised = true;                                                                                                      \
     }                                                                                                                     \
-    hipLaunchKernelGGL((k_mf_score<G, UNIT>), dim3(L.n_tiles), dim3(nt), lds, s, m);                                        \
+    hipLaunchKernelGGL((k_mf_score<G, S, UNIT>), dim3(L.n_tiles), dim3(nt), lds, s, m);                                     \
   } while (0)
-  if (gs <= 4)
-    MFM_MFS(4);
-  else if (gs <= 8)
-    MFM_MFS(8);
-  else if (gs <= 16)
-    MFM_MFS(16);
-  else if (gs <= 32)
-    MFM_MFS(32);
+  // lanes per entry x pairs per lane >= kp
+  if (kp <= 1)
+    MFM_MFS(1, 1);
+  else if (kp <= 2)
+    MFM_MFS(2, 1);
+  else if (kp <= 4)
+    MFM_MFS(2, 2);
+  else if (kp <= 8)
+    MFM_MFS(4, 2);
+  else if (kp <= 16)
+    MFM_MFS(4, 4);
+  else if (kp <= 32)
+    MFM_MFS(8, 4);
   else
-    MFM_MFS(64);
+    MFM_MFS(16, 4);
 #undef MFM_MFS
   MFM_HIP_CHECK(hipGetLastError());
   return true;
