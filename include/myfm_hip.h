@@ -242,6 +242,7 @@ int mfm_store_create(int device, int64_t D, int32_t rank, mfm_store **out);
 void mfm_store_destroy(mfm_store *st);
 const char *mfm_store_last_error(const mfm_store *st);
 int32_t mfm_store_size(const mfm_store *st);
+int mfm_store_reserve(mfm_store *st, int32_t n_samples); /* allocate room for n_samples ahead of the loop (optional) */
 int mfm_store_push_ctx(mfm_store *st, mfm_ctx *ctx);
 int mfm_store_push_host(mfm_store *st, double w0, const double *w, const double *V);
 int mfm_store_get(mfm_store *st, int32_t idx, double *w0, double *w, double *V);

@@ -30,7 +30,7 @@ SYMBOLS = [
     "mfm_rng_get_z", "mfm_design_score_ctx", "mfm_design_n_rows", "mfm_set_allreduce", "mfm_set_row_offset", "mfm_set_main_levels",
     "mfm_test_erfcx", "mfm_test_truncated_normal", "mfm_get_device", "mfm_set_shard", "mfm_comm_unique_id", "mfm_comm_init",
     "mfm_comm_stats", "mfm_store_create", "mfm_store_destroy", "mfm_store_last_error", "mfm_store_size", "mfm_store_push_ctx",
-    "mfm_store_push_host", "mfm_store_get", "mfm_design_predict_store",
+    "mfm_store_push_host", "mfm_store_get", "mfm_design_predict_store", "mfm_store_reserve",
 ]
 
 _lib = None
@@ -126,6 +126,7 @@ def lib():
     L.mfm_store_last_error.restype = C.c_char_p
     L.mfm_store_last_error.argtypes = [vp]
     L.mfm_store_size.argtypes = [vp]
+    L.mfm_store_reserve.argtypes = [vp, i32]
     L.mfm_store_push_ctx.argtypes = [vp, vp]
     L.mfm_store_push_host.argtypes = [vp, dbl, P, P]
     L.mfm_store_get.argtypes = [vp, i32, C.POINTER(dbl), P, P]

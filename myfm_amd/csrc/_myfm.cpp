@@ -1108,7 +1108,10 @@ struct FMTrainer {
     // MYFM_AMD_HOST_SAMPLES=1 or a store that does not fit: plain host copies as before
     std::shared_ptr<DeviceStore> store;
     if (cfg.n_kept_samples > 0 && !std::getenv("MYFM_AMD_HOST_SAMPLES") && !comm_active())
+    {
       store = std::make_shared<DeviceStore>((int64_t)dim_all, fm.n_factors);
+      if (mfm_store_reserve(store->st, cfg.n_kept_samples) != MFM_OK) store.reset();  // (does not fit: host copies)
+    }
     for (int it = 0; it < cfg.n_iter; it++) {
       update_all(fm, hyper);
       fm.stale = true;  // w / V live on the device until somebody reads them

@@ -67,6 +67,7 @@ struct mfm_store {
   std::string err;
   std::vector<double> w0;
   std::vector<std::unique_ptr<DevBuf<double>>> wv;  // per sample: w[D] then V[K][D] (factor-major, the ctx layout)
+  std::vector<std::unique_ptr<DevBuf<double>>> spare;  // buffers allocated ahead (mfm_store_reserve): no hipMalloc in the loop
   void use_device() { MFM_HIP_CHECK(hipSetDevice(device)); }
 };
 
@@ -97,10 +98,26 @@ const char *mfm_store_last_error(const mfm_store *st) { return st ? st->err.c_st
 int32_t mfm_store_size(const mfm_store *st) { return (int32_t)st->wv.size(); }
 
 static DevBuf<double> *store_new_sample(mfm_store *st) {
-  std::unique_ptr<DevBuf<double>> b(new DevBuf<double>());
-  b->alloc((size_t)std::max<int64_t>(st->D * (st->K + 1), 1));
+  std::unique_ptr<DevBuf<double>> b;
+  if (!st->spare.empty()) {
+    b = std::move(st->spare.back());
+    st->spare.pop_back();
+  } else {
+    b.reset(new DevBuf<double>());
+    b->alloc((size_t)std::max<int64_t>(st->D * (st->K + 1), 1));
+  }
   st->wv.push_back(std::move(b));
   return st->wv.back().get();
+}
+
+int mfm_store_reserve(mfm_store *st, int32_t n_samples) {
+  MFM_TRY(st)
+  while ((int)(st->wv.size() + st->spare.size()) < n_samples) {
+    std::unique_ptr<DevBuf<double>> b(new DevBuf<double>());
+    b->alloc((size_t)std::max<int64_t>(st->D * (st->K + 1), 1));
+    st->spare.push_back(std::move(b));
+  }
+  MFM_CATCH(st)
 }
 
 int mfm_store_push_ctx(mfm_store *st, mfm_ctx *ctx) {
