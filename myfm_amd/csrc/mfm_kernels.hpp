@@ -2012,6 +2012,184 @@ __global__ __launch_bounds__(CHAINB_NT) void k_chain_batched(SweepArgs a, const 
   }
 }
 
+// ---- the same batches, cold parts on the WHOLE GPU ------------------------------------------------------------------
+// When a batch's cold entries number in the tens of thousands (relation blocks with 10^5..10^6 rows: config 5) one
+// workgroup streaming them through a single CU is the bottleneck (~25 GB/s). Phases A and C touch every row at most once
+// per batch, so they run as grid launches; only the walk over the hot rows (B) stays on one workgroup:
+//   k_cb_stats  (grid)  per-column partial statistics of the cold entries, one partial row per workgroup
+//   k_cb_hot    (1 WG)  partials summed in workgroup order, hot rows in LDS, the columns in order: draw, (old, new) out
+//   k_cb_apply  (grid)  cold entries updated with their column's (old, new)
+template <class P>
+__global__ __launch_bounds__(CHAINB_NT) void k_cb_stats(SweepArgs a, ChainBatch B, const int32_t *__restrict__ cols,
+                                                        const int32_t *__restrict__ cold_ptr, const int32_t *__restrict__ cold_row,
+                                                        const int32_t *__restrict__ cold_lcol, const double *__restrict__ cold_x,
+                                                        double2 *__restrict__ part_g /* [gridDim.x][CHAINB_MAXCOLS] */) {
+  constexpr int NT = CHAINB_NT, NW = NT / WAVE, MC = CHAINB_MAXCOLS, U = 4;
+  __shared__ double c_old[MC];
+  __shared__ double2 part[MC * NW];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid < B.ncols) c_old[tid] = a.theta[cols[B.col0 + tid]];
+  for (int i = tid; i < MC * NW; i += NT) part[i] = make_double2(0.0, 0.0);
+  __syncthreads();
+  const int cb = cold_ptr[B.col0], ce = cold_ptr[B.col0 + B.ncols];
+  for (int base = cb + ((int)blockIdx.x * NW + wv) * WAVE * U; base < ce; base += (int)gridDim.x * NW * WAVE * U) {
+    int lc[U], row[U];
+    double xv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int p = base + u * WAVE + lane;
+      lc[u] = -1 - lane;
+      row[u] = -1;
+      xv[u] = 0.0;
+      if (p < ce) {
+        lc[u] = cold_lcol[p];
+        row[u] = cold_row[p];
+        xv[u] = cold_x[p];
+      }
+    }
+    typename P::St st[U];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (row[u] >= 0) st[u] = P::load(a, row[u]);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (base + u * WAVE >= ce) break;  // wave-uniform
+      double s1 = 0.0, s2 = 0.0;
+      if (row[u] >= 0) P::stats(xv[u], st[u], c_old[lc[u]], s1, s2);
+      const int lp = dpp_i32<0x138, 0xf>(lc[u], 0), ln = dpp_i32<0x130, 0xf>(lc[u], 0);
+      const bool head = lane == 0 || lp != lc[u], tail = lane == 63 || ln != lc[u];
+      int f = head ? 1 : 0;
+      wave_segscan2(s1, s2, f);
+      if (row[u] >= 0 && tail) {  // one lane per column of this tile; a wave adds its tiles in program order
+        double2 &q = part[lc[u] * NW + wv];
+        q.x += s1;
+        q.y += s2;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < MC) {
+    double S1 = 0.0, S2 = 0.0;
+    if (tid < B.ncols)
+      for (int w = 0; w < NW; w++) {  // wave order: deterministic
+        S1 += part[tid * NW + w].x;
+        S2 += part[tid * NW + w].y;
+      }
+    part_g[(size_t)blockIdx.x * MC + tid] = make_double2(S1, S2);
+  }
+}
+
+template <class P>
+__global__ __launch_bounds__(CHAINB_NT) void k_cb_hot(SweepArgs a, ChainBatch B, const int32_t *__restrict__ cols,
+                                                      const int32_t *__restrict__ hot_ptr, const int32_t *__restrict__ hot_slot,
+                                                      const double *__restrict__ hot_x, const int32_t *__restrict__ hot_rows,
+                                                      int max_hot, int max_hot_ent, const double2 *__restrict__ part_g, int n_part,
+                                                      double2 *__restrict__ oldnew_g /* [CHAINB_MAXCOLS] */) {
+  extern __shared__ double2 lds_hot[];
+  constexpr int NT = CHAINB_NT, MC = CHAINB_MAXCOLS;
+  constexpr int rec2_g = P::REC_DOUBLES / 2;
+  constexpr int rec2_l = P::REC_DOUBLES > 2 ? rec2_g + 1 : rec2_g;
+  double *c_old = (double *)(lds_hot + (size_t)max_hot * rec2_l);
+  double *c_z = c_old + MC, *c_lam = c_z + MC, *c_mu = c_lam + MC, *c_new = c_mu + MC;
+  double2 *csum = (double2 *)(c_new + MC);    // [MC]
+  double *h_x = (double *)(csum + MC);        // [max_hot_ent]
+  int *h_slot = (int *)(h_x + max_hot_ent);
+  int *h_ptr = h_slot + max_hot_ent;          // [MC + 1]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  SweepArgs al = a;
+  al.state = lds_hot;
+  al.rec2 = rec2_l;
+  const int rec2_global = P::REC_DOUBLES > 2 ? a.rec2 : 1;
+  for (int i = tid; i < B.n_hot * rec2_g; i += NT) {
+    const int slot = i / rec2_g, w = i - slot * rec2_g;
+    lds_hot[(size_t)slot * rec2_l + w] = ((const double2 *)a.state)[(int64_t)hot_rows[B.hot_row0 + slot] * rec2_global + w];
+  }
+  const int hb0 = hot_ptr[B.col0], hb1 = hot_ptr[B.col0 + B.ncols];
+  for (int i = tid; i < hb1 - hb0; i += NT) {
+    h_x[i] = hot_x[hb0 + i];
+    h_slot[i] = hot_slot[hb0 + i];
+  }
+  if (tid <= B.ncols) h_ptr[tid] = hot_ptr[B.col0 + tid] - hb0;
+  if (tid < B.ncols) {
+    const int j = cols[B.col0 + tid];
+    c_old[tid] = a.theta[j];
+    c_z[tid] = a.z[j];
+    const int g = a.group[j];
+    c_lam[tid] = a.lambda[g];
+    c_mu[tid] = a.mu[g];
+    double S1 = 0.0, S2 = 0.0;
+    for (int w = 0; w < n_part; w++) {  // workgroup order: deterministic
+      const double2 q = part_g[(size_t)w * MC + tid];
+      S1 += q.x;
+      S2 += q.y;
+    }
+    csum[tid] = make_double2(S1, S2);
+  }
+  __syncthreads();
+  if (wv == 0) {
+    for (int c = 0; c < B.ncols; c++) {
+      const double S1 = csum[c].x, S2 = csum[c].y;
+      const double old = c_old[c];
+      const int hb = h_ptr[c], he = h_ptr[c + 1];
+      double h1 = 0.0, h2 = 0.0;
+      for (int h = hb + lane; h < he; h += WAVE) P::stats(h_x[h], P::load(al, h_slot[h]), old, h1, h2);
+      h1 = wave_allreduce_sum(h1);
+      h2 = wave_allreduce_sum(h2);
+      const double fresh = P::draw(S1 + h1, S2 + h2, old, a.alpha, c_lam[c], c_mu[c], c_z[c]);
+      for (int h = hb + lane; h < he; h += WAVE) {
+        const int slot = h_slot[h];
+        P::apply(al, slot, h_x[h], P::load(al, slot), old, fresh);
+      }
+      if (lane == 0) c_new[c] = fresh;
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < B.n_hot * rec2_g; i += NT) {
+    const int slot = i / rec2_g, w = i - slot * rec2_g;
+    ((double2 *)a.state)[(int64_t)hot_rows[B.hot_row0 + slot] * rec2_global + w] = lds_hot[(size_t)slot * rec2_l + w];
+  }
+  if (tid < B.ncols) {
+    a.theta[cols[B.col0 + tid]] = c_new[tid];
+    oldnew_g[tid] = make_double2(c_old[tid], c_new[tid]);
+  }
+}
+
+template <class P>
+__global__ __launch_bounds__(CHAINB_NT) void k_cb_apply(SweepArgs a, ChainBatch B, const int32_t *__restrict__ cold_ptr,
+                                                        const int32_t *__restrict__ cold_row, const int32_t *__restrict__ cold_lcol,
+                                                        const double *__restrict__ cold_x, const double2 *__restrict__ oldnew_g) {
+  constexpr int NT = CHAINB_NT, MC = CHAINB_MAXCOLS, U = 4;
+  __shared__ double2 on[MC];
+  const int tid = threadIdx.x;
+  if (tid < B.ncols) on[tid] = oldnew_g[tid];
+  __syncthreads();
+  const int cb = cold_ptr[B.col0], ce = cold_ptr[B.col0 + B.ncols];
+  for (int base = cb + (int)blockIdx.x * NT * U + tid; base < ce; base += (int)gridDim.x * NT * U) {
+    int lc[U], row[U];
+    double xv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int p = base + u * NT;
+      row[u] = -1;
+      lc[u] = 0;
+      xv[u] = 0.0;
+      if (p < ce) {
+        lc[u] = cold_lcol[p];
+        row[u] = cold_row[p];
+        xv[u] = cold_x[p];
+      }
+    }
+    typename P::St st[U];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (row[u] >= 0) st[u] = P::load(a, row[u]);
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (row[u] >= 0) P::apply(a, row[u], xv[u], st[u], on[lc[u]].x, on[lc[u]].y);
+  }
+}
+
 // ---- q-cache build: q = X v_f (+ block contributions)  (FMTrainer.hpp:320-340), CSR SpMV --------
 constexpr int MAX_BLOCKS = 16;
 struct BlockGatherArgs {

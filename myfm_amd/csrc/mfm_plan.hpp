@@ -85,6 +85,9 @@ struct ChainRun {
   bool batched = false;
   int n_batches = 0, max_hot = 0, max_hot_ent = 0;
   DevBuf<ChainBatch> batches;
+  std::vector<ChainBatch> h_batches;   // host copies: the grid form (k_cb_*) launches batch by batch
+  std::vector<int32_t> h_cold_cnt;     // cold entries per batch
+  int64_t n_cold = 0;
   DevBuf<int32_t> cold_ptr, cold_row, cold_lcol, hot_ptr, hot_slot, hot_rows;
   DevBuf<double> cold_x, hot_x;
 
@@ -158,6 +161,10 @@ struct ChainRun {
       c = e;
     }
     n_batches = (int)bt.size();
+    h_batches = bt;
+    h_cold_cnt.clear();
+    for (const ChainBatch &B : bt) h_cold_cnt.push_back(cptr[B.col0 + B.ncols] - cptr[B.col0]);
+    n_cold = (int64_t)crow.size();
     batches.upload(bt.data(), bt.size());
     cold_ptr.upload(cptr);
     cold_row.upload(crow);
@@ -824,6 +831,7 @@ struct LongScratch {
   DevBuf<double2> S_compact;   // sharded fused path: statistics of the special first-level columns
   DevBuf<double> told_col;     // multi-level fused flow: current coefficient per column of the level whose statistics are taken
   std::vector<DevBuf<double>> vnext_lvl;  // ... and per tile level: next factor's coefficient per column (MULTIQ)
+  DevBuf<double2> cb_part, cb_oldnew;  // grid-batched chains: per-workgroup column partials, (old, new) per column of a batch
   DevBuf<double2> dv_col;      // two-field pass: (delta of this factor, coefficient of the next) per second-level column
   void reserve_cols(int64_t n_cols) {
     if ((size_t)n_cols > oldnew_col.n) {
@@ -933,7 +941,31 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
         if (!raised) {
           MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_batched<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)CHAIN_LDS_MAX));
+          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_cb_hot<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)CHAIN_LDS_MAX));
           raised = true;
+        }
+        // batches with many cold entries: cold statistics / updates as grid launches (one CU cannot stream them)
+        const int64_t grid_min = std::getenv("MFM_CHAIN_GRID_MIN") ? std::atoll(std::getenv("MFM_CHAIN_GRID_MIN")) : 4096;
+        if (C.n_batches > 0 && C.n_cold / C.n_batches >= grid_min && !std::getenv("MFM_NO_CHAIN_GRID")) {
+          constexpr int GMAX = 64;  // workgroups of a cold launch
+          if (ls.cb_part.n < (size_t)GMAX * CHAINB_MAXCOLS) ls.cb_part.alloc((size_t)GMAX * CHAINB_MAXCOLS);
+          if (ls.cb_oldnew.n < (size_t)CHAINB_MAXCOLS) ls.cb_oldnew.alloc((size_t)CHAINB_MAXCOLS);
+          const size_t lds_h = (size_t)std::max(C.max_hot, 1) * rec2_l * sizeof(double2) + 5 * CHAINB_MAXCOLS * sizeof(double) +
+                               (size_t)CHAINB_MAXCOLS * sizeof(double2) + (size_t)mhe * 12 + (CHAINB_MAXCOLS + 2) * sizeof(int);
+          for (int bi = 0; bi < C.n_batches; bi++) {
+            const ChainBatch &B = C.h_batches[bi];
+            const int ncold = C.h_cold_cnt[bi];
+            const int g = std::max(1, std::min(GMAX, (ncold + CHAINB_NT * 4 - 1) / (CHAINB_NT * 4)));
+            hipLaunchKernelGGL((k_cb_stats<P>), dim3(g), dim3(CHAINB_NT), 0, s, a, B, C.cols.p, C.cold_ptr.p, C.cold_row.p,
+                               C.cold_lcol.p, C.cold_x.p, ls.cb_part.p);
+            hipLaunchKernelGGL((k_cb_hot<P>), dim3(1), dim3(CHAINB_NT), lds_h, s, a, B, C.cols.p, C.hot_ptr.p, C.hot_slot.p,
+                               C.hot_x.p, C.hot_rows.p, std::max(C.max_hot, 1), mhe, ls.cb_part.p, g, ls.cb_oldnew.p);
+            if (ncold)
+              hipLaunchKernelGGL((k_cb_apply<P>), dim3(g), dim3(CHAINB_NT), 0, s, a, B, C.cold_ptr.p, C.cold_row.p,
+                                 C.cold_lcol.p, C.cold_x.p, ls.cb_oldnew.p);
+          }
+          continue;
         }
         hipLaunchKernelGGL((k_chain_batched<P>), dim3(1), dim3(CHAINB_NT), lds_b, s, a, C.batches.p, C.n_batches, C.cols.p,
                            C.cold_ptr.p, C.cold_row.p, C.cold_lcol.p, C.cold_x.p, C.hot_ptr.p, C.hot_slot.p, C.hot_x.p,

@@ -332,12 +332,18 @@ def test_blocks_match_oracle_and_flat(oracle, capi, design):
     np.testing.assert_allclose(cb.get_e(), tb.e(main.shape[0]), rtol=1e-7, atol=1e-7)
 
 
+@pytest.mark.parametrize("grid", [False, True])
 @pytest.mark.parametrize("design", ["onehot", "multihot", "dense_main"])
-def test_conflict_batched_chain(oracle, capi, monkeypatch, design):
+def test_conflict_batched_chain(oracle, capi, monkeypatch, design, grid):
     # chains over state too large for LDS run conflict-batched (k_chain_batched: cold entries in parallel, hot rows
     # staged in LDS and walked in order); forced here on small designs: relation-block sweeps (64-byte records, w and
-    # V) and a main table with dense columns (16-byte records)
+    # V) and a main table with dense columns (16-byte records). grid: the cold parts as grid launches (k_cb_*), the form
+    # big relation blocks take
     monkeypatch.setenv("MFM_CHAIN_FORCE_BATCHED", "1")
+    if grid:
+        monkeypatch.setenv("MFM_CHAIN_GRID_MIN", "0")
+    else:
+        monkeypatch.setenv("MFM_NO_CHAIN_GRID", "1")
     if design == "dense_main":
         X, y = ds.middle_data()
         gi, blocks, rank, kw = np.zeros(X.shape[1], dtype=np.int32), (), 3, {}
