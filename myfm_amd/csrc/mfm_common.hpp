@@ -29,10 +29,11 @@ template <class T>
 struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
+  bool owned = true;  // false: a view of another DevBuf's memory (borrow), never freed here
   DevBuf() {}
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) {
+  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), owned(o.owned) {
     o.p = nullptr;
     o.n = 0;
   }
@@ -41,6 +42,7 @@ struct DevBuf {
       release();
       p = o.p;
       n = o.n;
+      owned = o.owned;
       o.p = nullptr;
       o.n = 0;
     }
@@ -48,9 +50,17 @@ struct DevBuf {
   }
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    owned = true;
+  }
+  // non-owning view of `o` (which must outlive this)
+  void borrow(const DevBuf &o) {
+    release();
+    p = o.p;
+    n = o.n;
+    owned = false;
   }
   void alloc(size_t count) {
     release();

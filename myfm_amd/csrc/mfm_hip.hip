@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "mfm_common.hpp"
 #include "mfm_kernels.hpp"
 #include "mfm_plan.hpp"
@@ -176,6 +178,84 @@ struct mfm_ctx {
 // launch helpers
 // =============================================================================================
 namespace mfm {
+
+// ---- X_t = X.transpose() (BaseFMTrainer.hpp:61) on the device: a stable radix sort of the stored entries by column.
+// Entry order inside a column = ascending entry index = ascending row, exactly the host transpose. The planner (host)
+// receives the result by one bulk copy instead of building it with a 20-million-element scatter.
+__global__ void k_iota_u32(uint32_t *__restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (uint32_t)i;
+}
+__global__ void k_csc_fill(const uint32_t *__restrict__ perm, const int32_t *__restrict__ rowptr, const double *__restrict__ rval,
+                           int64_t nnz, int64_t n_rows, int ell, int32_t *__restrict__ rowidx, double *__restrict__ cval) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nnz) return;
+  const uint32_t p = perm[q];
+  int64_t row;
+  if (ell > 0) {
+    row = p / (uint32_t)ell;
+  } else {  // last row whose first entry is <= p
+    int64_t lo = 0, hi = n_rows;
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((uint32_t)rowptr[mid] <= p) lo = mid; else hi = mid;
+    }
+    row = lo;
+  }
+  rowidx[q] = (int32_t)row;
+  cval[q] = rval[p];
+}
+__global__ void k_colptr(const int32_t *__restrict__ keys_sorted, int64_t nnz, int64_t D, int64_t *__restrict__ colptr) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > D) return;
+  int64_t lo = 0, hi = nnz;  // first position with key >= j
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys_sorted[mid] < (int32_t)j) lo = mid + 1; else hi = mid;
+  }
+  colptr[j] = lo;
+}
+
+// fills X.colptr / rowidx / cval on the device from X's CSR and returns the host copy the planner reads
+static HostCsr transpose_device(DevSparse &X, hipStream_t s) {
+  HostCsr T;
+  T.rows = X.cols;
+  T.cols = X.rows;
+  const int64_t nnz = X.nnz, D = X.cols;
+  X.colptr.alloc((size_t)D + 1);
+  X.rowidx.alloc((size_t)std::max<int64_t>(nnz, 1));
+  X.cval.alloc((size_t)std::max<int64_t>(nnz, 1));
+  T.ptr.assign((size_t)D + 1, 0);
+  T.idx.resize((size_t)nnz);
+  T.val.resize((size_t)nnz);
+  if (nnz == 0) {
+    MFM_HIP_CHECK(hipMemsetAsync(X.colptr.p, 0, ((size_t)D + 1) * sizeof(int64_t), s));
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    return T;
+  }
+  DevBuf<int32_t> keys_out;
+  DevBuf<uint32_t> iota, perm;
+  keys_out.alloc((size_t)nnz);
+  iota.alloc((size_t)nnz);
+  perm.alloc((size_t)nnz);
+  hipLaunchKernelGGL(k_iota_u32, dim3(cdiv(nnz, 256)), dim3(256), 0, s, iota.p, nnz);
+  int end_bit = 1;
+  while (((int64_t)1 << end_bit) < std::max<int64_t>(D, 2)) end_bit++;
+  size_t tmp_bytes = 0;
+  MFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, X.colidx.p, keys_out.p, iota.p, perm.p, (int)nnz, 0, end_bit, s));
+  DevBuf<char> tmp;
+  tmp.alloc(tmp_bytes);
+  MFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, X.colidx.p, keys_out.p, iota.p, perm.p, (int)nnz, 0, end_bit, s));
+  hipLaunchKernelGGL(k_csc_fill, dim3(cdiv(nnz, 256)), dim3(256), 0, s, perm.p, X.rowptr.p, X.rval.p, nnz, X.rows,
+                     (int)(X.ell_width > 0 ? X.ell_width : 0), X.rowidx.p, X.cval.p);
+  hipLaunchKernelGGL(k_colptr, dim3(cdiv(D + 1, 256)), dim3(256), 0, s, keys_out.p, nnz, D, X.colptr.p);
+  MFM_HIP_CHECK(hipGetLastError());
+  MFM_HIP_CHECK(hipMemcpyAsync(T.ptr.data(), X.colptr.p, ((size_t)D + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipMemcpyAsync(T.idx.data(), X.rowidx.p, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipMemcpyAsync(T.val.data(), X.cval.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipStreamSynchronize(s));
+  return T;
+}
 
 static void fill_gather_args(std::vector<std::unique_ptr<DevBlock>> &blocks, BlockGatherArgs &g) {
   std::memset(&g, 0, sizeof(g));
@@ -520,6 +600,14 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   if (c->N >= (int64_t)2147483647) throw Error(MFM_ERR_INVALID, "N must be < 2^31 per GPU");
   c->K = rank;
   c->KS = (rank + 1) & ~1;
+  // the parallel generator's jump polynomials (mfm_rng_set_program needs them right after this call): start computing
+  // them now on a helper thread, sized for one iteration's draws of this problem (an upper estimate of the workgroups)
+  if (!std::getenv("MFM_RNG_SERIAL")) {
+    const double normals = (double)c->D * (c->K + 1) + 4.0 * c->G * (c->K + 1) + 16;
+    const double need = normals * (16.0 / 3.14159265358979) * 1.02 + 6.0 * 2.4 * std::sqrt(normals + 1.0) + 4096.0 * (2 + 2.0 * c->G * (c->K + 1)) + 2e6;
+    const int64_t blocks = (int64_t)(need / MT_N) + 2;
+    if (blocks > MT_PAR_BLOCKS) mtjump::JumpCache::inst().prefetch(MT_PAR_BLOCKS, (int)((blocks + MT_PAR_BLOCKS - 1) / MT_PAR_BLOCKS) + 1);
+  }
   const bool tlog = std::getenv("MFM_SETUP_TIMING") != nullptr;
   auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_prev = tnow();
@@ -531,10 +619,18 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   };
   // main table
   {
-    HostCsr Xt = transpose_host(c->hX);
-    lap("transpose (host)");
-    c->X.upload(c->hX, &Xt);
-    lap("upload CSR + CSC");
+    HostCsr Xt;
+    if (std::getenv("MFM_HOST_TRANSPOSE")) {
+      Xt = transpose_host(c->hX);
+      lap("transpose (host)");
+      c->X.upload(c->hX, &Xt);
+      lap("upload CSR + CSC");
+    } else {
+      c->X.upload(c->hX, nullptr);
+      lap("upload CSR");
+      Xt = transpose_device(c->X, c->stream);
+      lap("transpose (device) + copy back");
+    }
     c->plan_V.sharded = c->plan_W.sharded = c->comm.active();
     c->plan_V.given_levels = c->plan_W.given_levels = c->hlevels;
     // scattered levels: LDS row tiles of 2^tile_bits {e, q} records (64 KiB by default: two workgroups per CU)
@@ -616,7 +712,8 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
         c->sync_mask.upload(mask);
       }
     }
-    c->plan_W.build(Xt, PMainW::R_W16, PMainW::R_WG, coop_capacity<PMainW>(), true, c->X.unit);
+    c->plan_W.build(Xt, PMainW::R_W16, PMainW::R_WG, coop_capacity<PMainW>(), true, c->X.unit,
+                    std::getenv("MFM_NO_PLAN_TWIN") ? nullptr : &c->plan_V);
     lap("plan_W");
     c->ls.reserve_cols(std::max(c->plan_V.max_cols_scat, c->plan_W.max_cols_scat));
     if (c->comm.active()) {
@@ -1183,7 +1280,7 @@ int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops) {
     if (blocks > MT_PAR_BLOCKS && !std::getenv("MFM_RNG_SERIAL")) {
       const int wgs = (int)((blocks + MT_PAR_BLOCKS - 1) / MT_PAR_BLOCKS);
       std::vector<uint32_t> tab;
-      if (mtjump::build_jump_table(MT_PAR_BLOCKS, wgs - 1, tab)) {
+      if (mtjump::JumpCache::inst().get(MT_PAR_BLOCKS, wgs - 1, tab)) {
         r.jump.upload(tab);
         r.state_next.alloc(1);
         r.par_wgs = wgs;

@@ -13,6 +13,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <future>
+#include <mutex>
 #include <vector>
 
 namespace mfm {
@@ -166,6 +168,53 @@ static inline bool build_jump_table(int blocks_per_wg, int n_entries, std::vecto
   }
   return true;
 }
+
+// Process-wide cache: the table for n entries is a prefix of the table for more (entry p depends on p only), and building
+// it costs ~0.3 s of host time (Berlekamp-Massey + n polynomial products). prefetch() starts the computation on a helper
+// thread (mfm_finalize calls it as soon as the problem size is known); get() waits for it / extends it.
+struct JumpCache {
+  std::mutex mu;
+  int blocks = 0, n = -1;
+  std::vector<uint32_t> tab;
+  std::future<void> pending;
+  static JumpCache &inst() {
+    static JumpCache c;
+    return c;
+  }
+  void compute(int blocks_per_wg, int n_entries) {
+    std::vector<uint32_t> t;
+    const bool ok = build_jump_table(blocks_per_wg, n_entries, t);
+    std::lock_guard<std::mutex> g(mu);
+    if (ok && (blocks != blocks_per_wg || n_entries > n)) {
+      blocks = blocks_per_wg;
+      n = n_entries;
+      tab.swap(t);
+    }
+  }
+  void prefetch(int blocks_per_wg, int n_entries) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (blocks == blocks_per_wg && n >= n_entries) return;
+    }
+    if (pending.valid()) pending.wait();
+    pending = std::async(std::launch::async, [this, blocks_per_wg, n_entries]() { compute(blocks_per_wg, n_entries); });
+  }
+  bool get(int blocks_per_wg, int n_entries, std::vector<uint32_t> &out) {
+    if (pending.valid()) pending.wait();
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (blocks == blocks_per_wg && n >= n_entries) {
+        out.assign(tab.begin(), tab.begin() + (size_t)(n_entries + 1) * JUMP_WORDS32);
+        return true;
+      }
+    }
+    compute(blocks_per_wg, n_entries);
+    std::lock_guard<std::mutex> g(mu);
+    if (blocks != blocks_per_wg || n < n_entries) return false;
+    out.assign(tab.begin(), tab.begin() + (size_t)(n_entries + 1) * JUMP_WORDS32);
+    return true;
+  }
+};
 
 }  // namespace mtjump
 }  // namespace mfm

@@ -73,6 +73,31 @@ struct ParLevel {
   bool first_and_once = false;    // ... and it is the first step of the plan: the level can rebuild q itself
   bool contig = false;            // every column of the level covers a contiguous row range (StepPlan::col_row0)
   int64_t nnz_total() const { return nnz_light + nnz_heavy + nnz_long + nnz_huge; }
+  // The row-tile form of the SAME level of the same matrix built by another plan (the w and V sweeps of a table walk
+  // identical tiles): views of its arrays instead of a second build. The sweeps never overlap, so `slots` is shared too.
+  void borrow_tiled(const ParLevel &o) {
+    scattered = o.scattered;
+    tiled = o.tiled;
+    tile_bits = o.tile_bits;
+    n_tiles = o.n_tiles;
+    n_ent = o.n_ent;
+    n_cols = o.n_cols;
+    n_runs = o.n_runs;
+    covers_rows_once = o.covers_rows_once;
+    tent.borrow(o.tent);
+    ent_val.borrow(o.ent_val);
+    tile_ptr.borrow(o.tile_ptr);
+    tile_row0.borrow(o.tile_row0);
+    run_base.borrow(o.run_base);
+    scols.borrow(o.scols);
+    slot_ptr.borrow(o.slot_ptr);
+    slot_pos.borrow(o.slot_pos);
+    slots.borrow(o.slots);
+    g_inv.borrow(o.g_inv);
+    g_wbase.borrow(o.g_wbase);
+    g_ptr.borrow(o.g_ptr);
+    g_part.borrow(o.g_part);
+  }
 };
 
 struct ChainRun {
@@ -197,6 +222,7 @@ struct StepPlan {
   // inside one tile; longer columns get tiles of their own): lets the apply pass of the last level run the
   // first level of the NEXT factor on the tile while it is in LDS (k_tile_apply_next).
   std::vector<int32_t> h_tile_start;
+  std::vector<int32_t> h_level;  // level of every column (kept for a twin plan)
   DevBuf<int32_t> fuse_cols, fuse_col_ptr;  // first-level columns inside each tile, in row order
   DevBuf<int4> fuse_desc;                   // per entry of fuse_cols: {column, length, first row - tile start, group}
   const std::vector<int32_t> *group_of = nullptr;  // (set by the owner before build: group index per column)
@@ -399,7 +425,7 @@ struct StepPlan {
     }
     L.slots.alloc((size_t)std::max<size_t>(run_col.size(), 1));
     MFM_HIP_CHECK(hipMemset(L.slots.p, 0, std::max<size_t>(run_col.size(), 1) * sizeof(double2)));
-    {
+    if (std::getenv("MFM_MF_STREAM_SLOTS")) {  // (transpose-reduce tables of the stream-ordered slot experiment)
       const size_t ns = sidx.size(), nwv = (ns + WAVE - 1) / WAVE;
       std::vector<uint32_t> inv(ns);
       std::vector<int32_t> wbase(nwv + 1, 0), gptr(cols.size() + 1, 0);
@@ -694,7 +720,10 @@ struct StepPlan {
     }
   }
 
-  void build(const HostCsr &csc, int r_w16, int r_wg, int coop_max, bool allow_scatter = false, bool unit = false) {
+  void build(const HostCsr &csc, int r_w16, int r_wg, int coop_max, bool allow_scatter = false, bool unit = false,
+             const StepPlan *twin = nullptr) {
+    // twin: a plan already built for the SAME matrix with the same settings (the other sweep of the table): its level
+    // assignment and its row-tile levels are reused
     const int coop_local = coop_max;  // (sharded_tiles: locally complete long columns still run co-resident)
     if (sharded) coop_max = 0;
     n_state_rows = csc.cols;
@@ -713,9 +742,13 @@ struct StepPlan {
       level = given_levels;
       n_levels = 0;
       for (auto l : level) n_levels = std::max(n_levels, l + 1);
+    } else if (twin && !twin->h_level.empty() && (int64_t)twin->h_level.size() == csc.rows) {
+      level = twin->h_level;
+      n_levels = twin->n_levels;
     } else {
       n_levels = column_levels(csc, level);
     }
+    h_level = level;
     std::vector<std::vector<int32_t>> by_level((size_t)n_levels);
     for (int64_t j = 0; j < csc.rows; j++) by_level[level[j]].push_back((int32_t)j);
     steps.clear();
@@ -758,6 +791,18 @@ struct StepPlan {
       L.n_all = (int)by_level[l].size();
       L.jmin = *std::min_element(by_level[l].begin(), by_level[l].end());
       L.jmax = *std::max_element(by_level[l].begin(), by_level[l].end());
+      {
+        // the twin built this level on row tiles with the same boundaries: borrow it
+        const size_t si = steps.size() - 1;
+        const ParLevel *tw = twin && si < twin->steps.size() && !twin->steps[si].is_chain ? &twin->steps[si].par : nullptr;
+        if (allow_scatter && tw && tw->tiled && tw->tile_bits == tile_bits && tw->n_cols == (int)by_level[l].size() &&
+            tw->n_ent == lnnz && twin->aligned_tiles == aligned_tiles && twin->h_tile_start == h_tile_start && !sharded) {
+          L.borrow_tiled(*tw);
+          launches += 3;
+          max_cols_scat = std::max<int64_t>(max_cols_scat, csc.rows);
+          continue;
+        }
+      }
       if (allow_scatter && build_scattered(csc, by_level[l], lnnz, unit, L, (sharded && !sharded_tiles) ? 0 : tile_bits,
                                            aligned_tiles ? &h_tile_start : nullptr)) {
         launches += 3;
