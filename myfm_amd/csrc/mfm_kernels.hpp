@@ -89,6 +89,23 @@ __device__ __forceinline__ double wave_allreduce_sum(double v) {
   v += dpp_f64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
   return readlane_f64(v, 63);
 }
+// Sums of (a, b) over the 64 lanes at once: v_permlane32_swap folds the two halves of the wavefront so that lanes 0-31
+// carry a and lanes 32-63 carry b, then ONE 32-lane DPP reduction serves both (24 instructions instead of 76 for two
+// wave_allreduce_sum; fixed order, deterministic). Used where the reduction is on a sequential critical path.
+__device__ __forceinline__ void wave_allreduce_sum2(double &a, double &b) {
+  typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+  const u2_t lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const u2_t hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  // lanes < 32: a[l] + a[l + 32]; lanes >= 32: b[l - 32] + b[l]
+  double v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  v += dpp_f64<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_f64<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_f64<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_f64<0x118, 0xf>(v);  // row_shr:8
+  v += dpp_f64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3: lane 31 holds sum(a), lane 63 sum(b)
+  a = readlane_f64(v, 31);
+  b = readlane_f64(v, 63);
+}
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_i32(int v, int fill) {
@@ -142,8 +159,7 @@ __device__ __forceinline__ void wave_segscan2(double &s1, double &s2, int &f) {
 // all threads of the workgroup obtain the same totals; fixed summation tree (deterministic).
 template <int NW>
 __device__ __forceinline__ void wg_allreduce2(double &a, double &b, double *lds /* [2 * NW] */) {
-  a = wave_allreduce_sum(a);
-  b = wave_allreduce_sum(b);
+  wave_allreduce_sum2(a, b);
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) {
     lds[wid * 2] = a;
@@ -163,6 +179,26 @@ __device__ __forceinline__ void wg_allreduce2(double &a, double &b, double *lds 
 // sample_normal (FMTrainer.hpp:122-125) with the N(0,1) variate supplied
 __device__ __forceinline__ double sample_normal_z(double quad, double first, double z) {
   return (first / quad) + z / sqrt(quad);
+}
+// The same draw for the single-wavefront chains, where every instruction of the draw is on the sequential critical path
+// (the IEEE division + square root + division above are ~60 dependent instructions, and a dependent fp64 instruction of
+// a lone wavefront costs ~12 cycles -- scripts/ubench/issue_rate.hip): r = quad^(-1/2) by v_rsq_f64 and two coupled
+// Newton steps (g -> sqrt(quad), h -> r / 2; quadratic convergence from ~2^-26), then first * r^2 + z * r. Differs from the divisions above by a few ulp. quad = lambda +
+// alpha * S2 is a positive normal number.
+__device__ __forceinline__ double sample_normal_z_fast(double quad, double first, double z) {
+  const double r0 = __builtin_amdgcn_rsq(quad);
+  const double f4 = 4.0 * first, z2 = z + z;  // (off the dependent chain of the square root)
+  double g = quad * r0, h = 0.5 * r0;
+  double e = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, e, g);
+  h = __builtin_fma(h, e, h);
+  e = __builtin_fma(-h, g, 0.5);
+  h = __builtin_fma(h, e, h);  // h = r / 2 to rounding level: two coupled steps square the 2^-26 error of v_rsq_f64 twice
+  return __builtin_fma(f4, h, z2) * h;  // first r^2 + z r
+}
+template <bool FAST>
+__device__ __forceinline__ double sample_normal_zt(double quad, double first, double z) {
+  return FAST ? sample_normal_z_fast(quad, first, z) : sample_normal_z(quad, first, z);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -184,6 +220,7 @@ struct PMainV {
     S2 += h * h;
     S1 += (-s.x) * h;
   }
+  template <bool FAST = false>
   static __device__ __forceinline__ double draw(double S1, double S2, double old, double alpha, double lam, double mu,
                                                 double z) {
     double lin = S1 + S2 * old;  // :358
@@ -191,7 +228,7 @@ struct PMainV {
     lin = lin * alpha;           // :361
     sq += lam;                   // :363
     lin += lam * mu;             // :364-365
-    return sample_normal_z(sq, lin, z);
+    return sample_normal_zt<FAST>(sq, lin, z);
   }
   static __device__ __forceinline__ St updated(double x, St s, double old, double fresh) {
     const double delta = fresh - old;
@@ -343,11 +380,12 @@ struct PMainW {
     S2 += x * x;                    // :246
     S1 += x * et;                   // :248
   }
+  template <bool FAST = false>
   static __device__ __forceinline__ double draw(double S1, double S2, double old, double alpha, double lam, double mu,
                                                 double z) {
     const double sq = lam + alpha * S2;
     const double lin = -alpha * S1 + lam * mu;
-    return sample_normal_z(sq, lin, z);
+    return sample_normal_zt<FAST>(sq, lin, z);
   }
   static __device__ __forceinline__ St updated(double x, St e, double old, double fresh) {
     e -= x * old;
@@ -392,9 +430,10 @@ struct PBlockV {
     S2 += h_squared;                                                          // :438
     S1 += (-s.ee.x * h_B - s.ee.y) * x;                                       // :439-441
   }
+  template <bool FAST = false>
   static __device__ __forceinline__ double draw(double S1, double S2, double old, double alpha, double lam, double mu,
                                                 double z) {
-    return PMainV::draw(S1, S2, old, alpha, lam, mu, z);  // :443-450
+    return PMainV::draw<FAST>(S1, S2, old, alpha, lam, mu, z);  // :443-450
   }
   static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St s, double old, double fresh) {
     const double delta = fresh - old;
@@ -428,17 +467,62 @@ struct PBlockW {
     S2 += (x * x) * s.card;  // :285-287
     S1 += x * s.e;           // :288-289
   }
+  template <bool FAST = false>
   static __device__ __forceinline__ double draw(double S1, double S2, double old, double alpha, double lam, double mu,
                                                 double z) {
     double lin = -S1;
     lin += S2 * old;                 // :291
     const double sq = lam + alpha * S2;  // :293
     lin = alpha * lin + lam * mu;    // :294
-    return sample_normal_z(sq, lin, z);
+    return sample_normal_zt<FAST>(sq, lin, z);
   }
   static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, St s, double old, double fresh) {
     s.e += (x * s.card) * (fresh - old);  // :298-301
     ((double *)a.state)[(int64_t)row * (2 * a.rec2) + 4] = s.e;
+  }
+};
+
+// Statistics / update of one entry inside a SEQUENTIAL chain (k_chain_lds, the hot walkers of the conflict-batched
+// chains): the same formulas with explicit fused multiply-adds -- every instruction of a lone wavefront's column step is
+// paid in full, and fusing roughly halves the count. (The level kernels keep the unfused forms of the policies: they are
+// bandwidth-bound, and theirs is the arithmetic the CPU oracle is compiled to, -ffp-contract=off.)
+template <class P>
+struct ChainOps {
+  static __device__ __forceinline__ void stats(double x, const typename P::St &s, double old, double &S1, double &S2) {
+    P::stats(x, s, old, S1, S2);
+  }
+  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, typename P::St s, double old, double fresh) {
+    P::apply(a, row, x, s, old, fresh);
+  }
+};
+template <>
+struct ChainOps<PBlockV> {
+  static __device__ __forceinline__ void stats(double x, const BlockRec &s, double old, double &S1, double &S2) {
+    const double h_B = __builtin_fma(-x, old, s.qq.x);
+    const double t = __builtin_fma(h_B * s.kk.x, h_B, __builtin_fma(s.cc.x + s.cc.x, h_B, s.cc.y));
+    S2 = __builtin_fma(x * x, t, S2);
+    S1 = __builtin_fma(__builtin_fma(-s.ee.x, h_B, -s.ee.y), x, S1);
+  }
+  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, BlockRec s, double old, double fresh) {
+    const double delta = fresh - old, dx = delta * x;
+    const double h_B = __builtin_fma(-x, old, s.qq.x);
+    s.qq.x = __builtin_fma(delta, x, s.qq.x);
+    s.qq.y = __builtin_fma(delta * (fresh + old), x * x, s.qq.y);
+    s.ee.x = __builtin_fma(dx, __builtin_fma(h_B, s.kk.x, s.cc.x), s.ee.x);
+    s.ee.y = __builtin_fma(dx, __builtin_fma(h_B, s.cc.x, s.cc.y), s.ee.y);
+    d2_t *r = (d2_t *)a.state + (int64_t)row * a.rec2;
+    r[0] = s.qq;
+    r[2] = s.ee;
+  }
+};
+template <>
+struct ChainOps<PBlockW> {
+  static __device__ __forceinline__ void stats(double x, const PBlockW::St &s, double old, double &S1, double &S2) {
+    S2 = __builtin_fma(x * x, s.card, S2);
+    S1 = __builtin_fma(x, s.e, S1);
+  }
+  static __device__ __forceinline__ void apply(const SweepArgs &a, int row, double x, PBlockW::St s, double old, double fresh) {
+    ((double *)a.state)[(int64_t)row * (2 * a.rec2) + 4] = __builtin_fma(x * s.card, fresh - old, s.e);
   }
 };
 
@@ -1690,7 +1774,7 @@ __global__ __launch_bounds__(CHAIN_WG) void k_chain(SweepArgs a, const ChainDesc
       P::stats(x, s, old, S1, S2);
     }
     wg_allreduce2<NT / WAVE>(S1, S2, lds);
-    const double fresh = P::draw(S1, S2, old, a.alpha, lam, mu, zc);
+    const double fresh = P::template draw<true>(S1, S2, old, a.alpha, lam, mu, zc);
 #pragma unroll
     for (int r = 0; r < R; r++)
       if (cidx[r] >= 0) P::apply(a, cidx[r], cval[r], st[r], old, fresh);
@@ -1724,35 +1808,55 @@ __global__ __launch_bounds__(WAVE) void k_chain_lds(SweepArgs a, const ChainDesc
   const int l16 = w16 > 1 ? w16 + 1 : w16;      // ... in LDS: 64-byte records are padded to 80 bytes (bank spread)
   const int64_t n16 = n_rows * w16;
   double2 *gst = (double2 *)a.state;
-  for (int64_t i = lane; i < n16; i += WAVE) lst[(i / w16) * l16 + (i % w16)] = gst[i];
+  // staging: eight independent 16-byte loads in flight per lane (a plain copy loop of one wavefront pays a memory round
+  // trip per KB: ~100 us for the 105 KB of an ML-100k-sized block, a tenth of the launch)
+  for (int64_t i0 = lane; i0 < n16; i0 += 8 * WAVE) {
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (i0 + u * WAVE < n16) v[u] = gst[i0 + u * WAVE];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int64_t i = i0 + u * WAVE;
+      if (i < n16) lst[(i / w16) * l16 + (i % w16)] = v[u];
+    }
+  }
   SweepArgs al = a;
   al.state = lst;
   al.rec2 = l16;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-  // per-lane (lane < CB) column scalars and per-column entry registers: cur = batch being processed,
-  // nxt = batch in flight, dsc = descriptors two batches ahead
-  ChainDesc dsc = {0, 0, 0};
-  int32_t c_col = 0, n_col = 0, c_len = 0, n_len = 0;
+  // per-lane (lane < CB) column scalars and per-column entry registers: cur = batch being processed, nxt = batch in
+  // flight. No load inside the loop waits on another load of the same step (the wavefront issues in order: a dependent
+  // pair would stall the chain for a memory round trip per batch): descriptors are fetched three batches ahead (dA), the
+  // group index of a column two batches ahead (gB, from the descriptors dB that have landed), and a batch's coefficients,
+  // variates, hyper-parameters and entries one batch ahead. The drawn coefficients are collected per lane and stored by
+  // ONE instruction after the next batch's registers have been taken over (vmcnt counts stores as well: a store issued
+  // just before that hand-over would make it wait for the store's acknowledgement).
+  ChainDesc dA = {0, 0, 0}, dB = {0, 0, 0};
+  int gB = 0;
+  int32_t c_col = 0, n_col = 0, c_len = 0, n_len = 0, p_col = -1;
   int64_t c_begin = 0, n_begin = 0;
-  double c_old = 0, n_old = 0, c_z = 0, n_z = 0, c_lam = 0, n_lam = 0, c_mu = 0, n_mu = 0;
+  double c_old = 0, n_old = 0, c_z = 0, n_z = 0, c_lam = 0, n_lam = 0, c_mu = 0, n_mu = 0, c_new = 0, p_new = 0;
   // two entries per lane and column are staged ahead (columns of up to 128 entries never touch global memory inside
   // the chain: a load there costs the chain a full memory round trip per column)
   int32_t cidx[CB], nidx[CB], cidx2[CB], nidx2[CB];
   double cval[CB], nval[CB], cval2[CB], nval2[CB];
   auto load_desc = [&](int base) {
-    dsc.len = 0;
-    if (lane < CB && base + lane < n_cols) dsc = desc[base + lane];
+    ChainDesc d = {0, 0, 0};
+    if (lane < CB && base + lane < n_cols) d = desc[base + lane];
+    return d;
   };
-  auto load_batch = [&]() {  // from dsc into nxt
+  auto load_group = [&](const ChainDesc &d, int base) { return (lane < CB && base + lane < n_cols) ? a.group[d.col] : 0; };
+  auto load_batch = [&](const ChainDesc &dsc, int g) {  // into nxt
     n_col = dsc.col;
     n_len = dsc.len;
     n_begin = dsc.begin;
-    int g = 0;
-    if (lane < CB && n_len >= 0 && n_col >= 0) {
+    if (lane < CB) {
       n_old = a.theta[n_col];
       n_z = a.z[n_col];
-      g = a.group[n_col];
+      n_lam = a.lambda[g];
+      n_mu = a.mu[g];
     }
 #pragma unroll
     for (int k = 0; k < CB; k++) {
@@ -1771,14 +1875,13 @@ __global__ __launch_bounds__(WAVE) void k_chain_lds(SweepArgs a, const ChainDesc
         nval2[k] = a.val[b + lane + WAVE];
       }
     }
-    if (lane < CB) {
-      n_lam = a.lambda[g];
-      n_mu = a.mu[g];
-    }
   };
-  load_desc(0);
-  load_batch();
-  load_desc(CB);
+  dB = load_desc(0);
+  gB = load_group(dB, 0);
+  load_batch(dB, gB);
+  dB = load_desc(CB);
+  gB = load_group(dB, CB);
+  dA = load_desc(2 * CB);
   for (int base = 0; base < n_cols; base += CB) {
     // rotate: nxt -> cur, start the loads of the following batch
     c_col = n_col;
@@ -1795,49 +1898,61 @@ __global__ __launch_bounds__(WAVE) void k_chain_lds(SweepArgs a, const ChainDesc
       cidx2[k] = nidx2[k];
       cval2[k] = nval2[k];
     }
+    if (lane < CB && p_col >= 0) a.theta[p_col] = p_new;  // the batch before this one
     if (base + CB < n_cols) {
-      load_batch();
-      load_desc(base + 2 * CB);
+      load_batch(dB, gB);
+      dB = dA;
+      gB = load_group(dB, base + 2 * CB);
+      dA = load_desc(base + 3 * CB);
     }
 #pragma unroll
     for (int k = 0; k < CB; k++) {
       if (base + k < n_cols) {
-        const int cj = __builtin_amdgcn_readlane(c_col, k);
         const int clen = __builtin_amdgcn_readlane(c_len, k);
         const int64_t cbegin = readlane_i64(c_begin, k);
         const double old = readlane_f64(c_old, k);
         double S1 = 0.0, S2 = 0.0;
         typename P::St st0, st1;
-        if (lane < clen) {
-          st0 = P::load(al, cidx[k]);
-          P::stats(cval[k], st0, old, S1, S2);
-        }
-        if (lane + WAVE < clen) {
-          st1 = P::load(al, cidx2[k]);
-          P::stats(cval2[k], st1, old, S1, S2);
+        // lanes past the column's end read row 0 with x = 0 (a zero contribution) instead of branching on the execution
+        // mask: both halves' loads are issued back to back and their statistics interleave
+        const int r0 = max(cidx[k], 0), r1 = max(cidx2[k], 0);
+        const bool two = clen > WAVE;  // (wave-uniform)
+        st0 = P::load(al, r0);
+        if (two) {
+          double T1 = 0.0, T2 = 0.0;
+          st1 = P::load(al, r1);
+          ChainOps<P>::stats(cval[k], st0, old, S1, S2);
+          ChainOps<P>::stats(cval2[k], st1, old, T1, T2);
+          S1 += T1;
+          S2 += T2;
+        } else {
+          ChainOps<P>::stats(cval[k], st0, old, S1, S2);
         }
         for (int p = lane + 2 * WAVE; p < clen; p += WAVE) {
           const int32_t row = a.rowidx[cbegin + p];
           const double x = a.val[cbegin + p];
           const typename P::St st = P::load(al, row);
-          P::stats(x, st, old, S1, S2);
+          ChainOps<P>::stats(x, st, old, S1, S2);
         }
-        S1 = wave_allreduce_sum(S1);
-        S2 = wave_allreduce_sum(S2);
-        const double fresh = P::draw(S1, S2, old, a.alpha, readlane_f64(c_lam, k), readlane_f64(c_mu, k), readlane_f64(c_z, k));
-        if (lane < clen) P::apply(al, cidx[k], cval[k], st0, old, fresh);
-        if (lane + WAVE < clen) P::apply(al, cidx2[k], cval2[k], st1, old, fresh);
+        wave_allreduce_sum2(S1, S2);
+        const double fresh =
+            P::template draw<true>(S1, S2, old, a.alpha, readlane_f64(c_lam, k), readlane_f64(c_mu, k), readlane_f64(c_z, k));
+        if (lane < clen) ChainOps<P>::apply(al, r0, cval[k], st0, old, fresh);
+        if (two && lane + WAVE < clen) ChainOps<P>::apply(al, r1, cval2[k], st1, old, fresh);
         for (int p = lane + 2 * WAVE; p < clen; p += WAVE) {
           const int32_t row = a.rowidx[cbegin + p];
           const double x = a.val[cbegin + p];
           const typename P::St st = P::load(al, row);
-          P::apply(al, row, x, st, old, fresh);
+          ChainOps<P>::apply(al, row, x, st, old, fresh);
         }
-        if (lane == 0) a.theta[cj] = fresh;
+        if (lane == k) c_new = fresh;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     }
+    p_col = base + lane < n_cols ? c_col : -1;
+    p_new = c_new;
   }
+  if (lane < CB && p_col >= 0) a.theta[p_col] = p_new;
   for (int64_t i = lane; i < n16; i += WAVE) gst[i] = lst[(i / w16) * l16 + (i % w16)];
 }
 
@@ -1966,13 +2081,12 @@ __global__ __launch_bounds__(CHAINB_NT) void k_chain_batched(SweepArgs a, const 
         const double old = c_old[c];
         const int hb = h_ptr[c], he = h_ptr[c + 1];
         double h1 = 0.0, h2 = 0.0;
-        for (int h = hb + lane; h < he; h += WAVE) P::stats(h_x[h], P::load(al, h_slot[h]), old, h1, h2);
-        h1 = wave_allreduce_sum(h1);
-        h2 = wave_allreduce_sum(h2);
-        const double fresh = P::draw(S1 + h1, S2 + h2, old, a.alpha, c_lam[c], c_mu[c], c_z[c]);
+        for (int h = hb + lane; h < he; h += WAVE) ChainOps<P>::stats(h_x[h], P::load(al, h_slot[h]), old, h1, h2);
+        wave_allreduce_sum2(h1, h2);
+        const double fresh = P::template draw<true>(S1 + h1, S2 + h2, old, a.alpha, c_lam[c], c_mu[c], c_z[c]);
         for (int h = hb + lane; h < he; h += WAVE) {
           const int slot = h_slot[h];
-          P::apply(al, slot, h_x[h], P::load(al, slot), old, fresh);
+          ChainOps<P>::apply(al, slot, h_x[h], P::load(al, slot), old, fresh);
         }
         if (lane == 0) c_new[c] = fresh;
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this column's LDS updates before the next column's loads
@@ -2132,13 +2246,12 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_hot(SweepArgs a, ChainBatch B,
       const double old = c_old[c];
       const int hb = h_ptr[c], he = h_ptr[c + 1];
       double h1 = 0.0, h2 = 0.0;
-      for (int h = hb + lane; h < he; h += WAVE) P::stats(h_x[h], P::load(al, h_slot[h]), old, h1, h2);
-      h1 = wave_allreduce_sum(h1);
-      h2 = wave_allreduce_sum(h2);
-      const double fresh = P::draw(S1 + h1, S2 + h2, old, a.alpha, c_lam[c], c_mu[c], c_z[c]);
+      for (int h = hb + lane; h < he; h += WAVE) ChainOps<P>::stats(h_x[h], P::load(al, h_slot[h]), old, h1, h2);
+      wave_allreduce_sum2(h1, h2);
+      const double fresh = P::template draw<true>(S1 + h1, S2 + h2, old, a.alpha, c_lam[c], c_mu[c], c_z[c]);
       for (int h = hb + lane; h < he; h += WAVE) {
         const int slot = h_slot[h];
-        P::apply(al, slot, h_x[h], P::load(al, slot), old, fresh);
+        ChainOps<P>::apply(al, slot, h_x[h], P::load(al, slot), old, fresh);
       }
       if (lane == 0) c_new[c] = fresh;
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: scripts/sweep_env.sh "VAR1=a VAR2=b" "VAR1=c" ...   -- one short bench.py run per environment, one summary line each
 for envs in "$@"; do
-  out=$(env $envs python bench.py --steps 20 --warmup 3 --cpu-iters 0 2>/dev/null | tail -1)
+  out=$(env $envs python bench.py ${BENCH_ARGS:---steps 20 --warmup 3} --cpu-iters 0 --fit-iters 0 2>/dev/null | tail -1)
   python - "$envs" "$out" <<'PY'
 import json, sys
 try:
