@@ -159,6 +159,105 @@ __global__ void k_unsync_long_fin(const int32_t *__restrict__ lrows, const int32
   unsync_store<IS_W>(rec, lrows[l], s);
 }
 
+// ---- statistics + un-sync, STREAMING over the training rows (few block rows, each with very many training rows) --------
+// The inverse-map kernels above gather eq[t] for the rows of one block row: when a block has ~10^3 rows and the table
+// 5 * 10^7, those lists stride through the whole table (a 16-byte access per DRAM page: ~1 TB/s). Here the rows are
+// read and written in order (36 B / row, coalesced) and the four sums per block row live in an LDS table of the
+// workgroup, B x 32 bytes. Fixed order of every floating-point sum (deterministic, like the rest of the sampler):
+//   * a workgroup owns a contiguous range of rows and walks it in steps of UNSYNC_R rows per thread;
+//   * after a step's loads and updates the wavefronts add their contributions to the table ONE WAVEFRONT AT A TIME
+//     (barriers in between), each with ds_add_f64 in program order (lanes of one instruction that hit the same block
+//     row are serialised by the LDS unit in lane order);
+//   * the workgroups' tables go to partial[workgroup][B][4] and k_unsync_stream_fin adds them in workgroup order.
+// The LDS adds are ~1 row per clock and CU: a fifth of the kernel's memory time.
+constexpr int UNSYNC_R = 4;          // rows per thread and step
+constexpr int UNSYNC_STREAM_WGS = 1024;
+constexpr int64_t UNSYNC_STREAM_MAX_B = 4096;  // 128 KiB table
+
+template <bool IS_W>
+__global__ __launch_bounds__(WG) void k_unsync_stream(const int32_t *__restrict__ map, double2 *__restrict__ eq,
+                                                      const double *__restrict__ rec, int64_t N, int B, int64_t rows_per_wg,
+                                                      double *__restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NS = IS_W ? 1 : 4;
+  double *tab = (double *)smem;  // [B][NS]
+  for (int i = threadIdx.x; i < B * NS; i += WG) tab[i] = 0.0;
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = min(N, r0 + rows_per_wg);
+  const int wv = threadIdx.x >> 6;
+  for (int64_t base = r0; base < r1; base += (int64_t)WG * UNSYNC_R) {
+    int key[UNSYNC_R];
+    double s[UNSYNC_R][NS];
+    double2 v[UNSYNC_R];
+#pragma unroll
+    for (int u = 0; u < UNSYNC_R; u++) {
+      const int64_t t = base + (int64_t)u * WG + threadIdx.x;
+      key[u] = -1;
+      if (t < r1) {
+        key[u] = map[t];
+        v[u] = eq[t];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNSYNC_R; u++) {
+      const int64_t t = base + (int64_t)u * WG + threadIdx.x;
+      if (key[u] >= 0) {
+        const double2 qq = ((const double2 *)rec)[(int64_t)key[u] * 4];
+        if (IS_W) {
+          s[u][0] = v[u].x;   // FMTrainer.hpp:271
+          v[u].x -= qq.x;     // :272-273
+          eq[t].x = v[u].x;
+        } else {
+          const double temp = v[u].y - qq.x;  // :402
+          s[u][0] = temp;                     // :403
+          s[u][1] = temp * temp;              // :404
+          s[u][2] = v[u].x;                   // :405
+          s[u][3] = v[u].x * temp;            // :406
+          v[u].y = temp;                      // :408
+          v[u].x -= (v[u].y * qq.x + 0.5 * qq.x * qq.x - 0.5 * qq.y);  // :412-415
+          eq[t] = v[u];
+        }
+      }
+    }
+    for (int w = 0; w < WG / WAVE; w++) {
+      if (wv == w) {
+#pragma unroll
+        for (int u = 0; u < UNSYNC_R; u++)
+          if (key[u] >= 0) {
+#pragma unroll
+            for (int k = 0; k < NS; k++)
+              __hip_atomic_fetch_add(&tab[key[u] * NS + k], s[u][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+      }
+      __syncthreads();
+    }
+  }
+  double *o = partial + (int64_t)blockIdx.x * B * NS;
+  for (int i = threadIdx.x; i < B * NS; i += WG) o[i] = tab[i];
+}
+// 32 outputs x 8 slices of the workgroup tables per 256 threads: slice sl adds tables sl, sl + 8, ... in order, the eight
+// slice sums are then added in slice order (fixed association)
+template <bool IS_W>
+__global__ __launch_bounds__(256) void k_unsync_stream_fin(const double *__restrict__ partial, int n_wg, int B,
+                                                           double *__restrict__ rec) {
+  constexpr int NS = IS_W ? 1 : 4;
+  __shared__ double part[8][32];
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + o;  // (block row, statistic)
+  double acc = 0.0;
+  if (i < B * NS)
+    for (int g = sl; g < n_wg; g += 8) acc += partial[(int64_t)g * B * NS + i];
+  part[sl][o] = acc;
+  __syncthreads();
+  if (sl == 0 && i < B * NS) {
+    double t = part[0][o];
+#pragma unroll
+    for (int k = 1; k < 8; k++) t += part[k][o];
+    const int row = i / NS, k = i - row * NS;
+    rec[(int64_t)row * BLOCK_REC + (IS_W ? 4 : 2 + k)] = t;
+  }
+}
+
 // re-sync, streaming over training rows: FMTrainer.hpp:473-480 (V) / :306-311 (w)
 template <bool IS_W>
 __global__ __launch_bounds__(WG) void k_resync(const int32_t *__restrict__ map, const double *__restrict__ rec,
@@ -253,6 +352,11 @@ struct DevBlock {
   DevBuf<InvChunk> inv_chunks;
   DevBuf<double> inv_partial;
   DevBuf<double> comm_buf;  // [B][4] packed statistics for the all-reduce (sharded mode)
+  // streaming statistics pass (k_unsync_stream): few block rows with very many training rows each
+  bool stream_unsync = false;
+  int stream_wgs = 0;
+  int64_t stream_rows_per_wg = 0;
+  DevBuf<double> stream_partial;  // [stream_wgs][B][4]
   int n_inv_wave = 0, n_inv_wg = 0, n_inv_long = 0, n_inv_chunks = 0;
 
   void build(const HostCsr &hX, const std::vector<int64_t> &hmap, int64_t N, int KS, hipStream_t s) {
@@ -313,6 +417,22 @@ struct DevBlock {
     bl.alloc_zero((size_t)B, s);
     bs.alloc_zero((size_t)B, s);
     comm_buf.alloc((size_t)std::max<int64_t>(B, 1) * 4);
+    // rows of a block row far apart in the table (lists longer than a workgroup handles at once) and a table that fits
+    // in LDS: stream. (A map that is sorted -- the block follows the table's row order -- has contiguous lists; those
+    // stay with the inverse-map kernels, which then stream as well.)
+    bool sorted = true;
+    for (int64_t t = 1; t < N && sorted; t++) sorted = hmap[t] >= hmap[t - 1];
+    stream_unsync = !sorted && B >= 1 && B <= UNSYNC_STREAM_MAX_B && N >= 64 * B && N >= ((int64_t)1 << 20) &&
+                    !std::getenv("MFM_NO_UNSYNC_STREAM");  // (short tables: too few workgroups to stream with)
+    if (const char *e = std::getenv("MFM_UNSYNC_STREAM_FORCE")) stream_unsync = std::atoi(e) != 0 && B >= 1 && B <= UNSYNC_STREAM_MAX_B;
+    if (stream_unsync) {
+      const int64_t step = (int64_t)WG * UNSYNC_R;
+      const int64_t steps = (N + step - 1) / step;
+      stream_wgs = (int)std::min<int64_t>(UNSYNC_STREAM_WGS, std::max<int64_t>(steps, 1));
+      stream_rows_per_wg = ((steps + stream_wgs - 1) / stream_wgs) * step;
+      stream_wgs = (int)((N + stream_rows_per_wg - 1) / stream_rows_per_wg);
+      stream_partial.alloc((size_t)std::max(stream_wgs, 1) * (size_t)B * 4);
+    }
   }
   // sum record words [first, first + n) of every block row over the ranks
   void allreduce_fields(hipStream_t s, const Comm &comm, int first, int n) {
@@ -347,6 +467,24 @@ static void block_rowcache(hipStream_t s, Timing &tm, DevBlock &B, const double 
 template <bool IS_W>
 static void block_unsync(hipStream_t s, Timing &tm, DevBlock &B, int64_t N, double2 *eq) {
   TimedLaunch t(tm, s, KC_BLOCK_UNSYNC, (IS_W ? 4.0 + 8.0 + 8.0 : 4.0 + 16.0 + 16.0) * N + 32.0 * B.B);
+  if (B.stream_unsync && N > 0) {
+    constexpr int NS = IS_W ? 1 : 4;
+    const size_t lds = (size_t)B.B * NS * sizeof(double);
+    static bool raised = false;
+    if (!raised) {
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_unsync_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(UNSYNC_STREAM_MAX_B * 4 * sizeof(double))));
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_unsync_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(UNSYNC_STREAM_MAX_B * sizeof(double))));
+      raised = true;
+    }
+    hipLaunchKernelGGL((k_unsync_stream<IS_W>), dim3(B.stream_wgs), dim3(WG), lds, s, B.map.p, eq, B.rec.p, N, (int)B.B,
+                       B.stream_rows_per_wg, B.stream_partial.p);
+    hipLaunchKernelGGL((k_unsync_stream_fin<IS_W>), dim3(cdiv_i(B.B * NS, 32)), dim3(256), 0, s, B.stream_partial.p,
+                       B.stream_wgs, (int)B.B, B.rec.p);
+    MFM_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (B.n_inv_wave)
     hipLaunchKernelGGL((k_unsync_wave<IS_W>), dim3(cdiv_i(B.n_inv_wave, WG / WAVE)), dim3(WG), 0, s, B.inv_ptr.p,
                        B.inv_rows.p, B.inv_wave.p, B.n_inv_wave, eq, B.rec.p);

@@ -770,7 +770,7 @@ struct StepPlan {
       }
       // state too large for the LDS chain of any policy: also keep the conflict-batched form
       if ((csc.cols > 1900 || std::getenv("MFM_CHAIN_FORCE_BATCHED")) && run.size() >= 2 && !std::getenv("MFM_NO_CHAIN_BATCHED"))
-        s.chain.build_batched(csc, run, 1200);
+        s.chain.build_batched(csc, run, std::getenv("MFM_CHAIN_HOT_CAP") ? std::max(64, std::atoi(std::getenv("MFM_CHAIN_HOT_CAP"))) : 1200);
       launches += 1;
       run.clear();
       run_nnz = 0;

@@ -303,9 +303,14 @@ def _timing_classes(c, drv):
     return names
 
 
+@pytest.mark.parametrize("stream", [False, True])
 @pytest.mark.parametrize("design", ["onehot", "multihot"])
-def test_blocks_match_oracle_and_flat(oracle, capi, design):
+def test_blocks_match_oracle_and_flat(oracle, capi, monkeypatch, design, stream):
     # tests/regression/test_block.py:80-149 on the device path + against the oracle
+    # stream: the statistics / un-sync pass (FMTrainer.hpp:268-275, :401-417) streaming over the training rows with the
+    # sums in an LDS table (k_unsync_stream, the form of blocks with few rows under a long table), else by block row
+    # through the inverse map
+    monkeypatch.setenv("MFM_UNSYNC_STREAM_FORCE", "1" if stream else "0")
     if design == "onehot":
         main, X_flat, blocks, y, shapes = ds.block_design()
         rank = 2
@@ -316,6 +321,7 @@ def test_blocks_match_oracle_and_flat(oracle, capi, design):
     kw = dict(fit_w0=False)
     tb, cb, _ = _pair(oracle, capi, main, y, gi, rank, blocks, **kw)
     tf, cf, _ = _pair(oracle, capi, X_flat, y, gi, rank, (), **kw)
+    tb0 = tb.clone()
     db = CapiGibbs(cb, tb.clone(), main.shape[0], gi, fit_w0=False)
     df = CapiGibbs(cf, tf.clone(), main.shape[0], gi, fit_w0=False)
     for it in range(6):
@@ -330,6 +336,12 @@ def test_blocks_match_oracle_and_flat(oracle, capi, design):
         np.testing.assert_allclose(gV, fV, rtol=1e-7, atol=1e-8)  # blocked == flat on the device
         np.testing.assert_allclose(gw, fw, rtol=1e-7, atol=1e-8)
     np.testing.assert_allclose(cb.get_e(), tb.e(main.shape[0]), rtol=1e-7, atol=1e-7)
+    if stream:  # the LDS sums are taken in a fixed order: a second chain from the same state is bit-identical
+        _, c2, _ = _pair(oracle, capi, main, y, gi, rank, blocks, **kw)
+        d2 = CapiGibbs(c2, tb0.clone(), main.shape[0], gi, fit_w0=False)
+        for it in range(6):
+            d2.step()
+        assert np.array_equal(c2.get_state()[2], cb.get_state()[2]) and np.array_equal(c2.get_e(), cb.get_e())
 
 
 @pytest.mark.parametrize("grid", [False, True])
