@@ -1974,6 +1974,52 @@ struct ChainBatch {
 constexpr int CHAINB_NT = 512;
 constexpr int CHAINB_MAXCOLS = 64;
 
+// One column of a hot walk (k_chain_batched phase B, k_cb_hot), by ONE wavefront over records staged in LDS: statistics of
+// the column's hot entries [hb, he), draw, update. Up to 4 x 64 entries are handled in a single round -- their slots and
+// records are loaded back to back (one LDS round trip instead of one per 64 entries), the four partial statistics
+// interleave, and the records stay in registers for the update. Lanes past the end read slot 0 with x = 0.
+template <class P>
+__device__ __forceinline__ double hot_column(const SweepArgs &a, const SweepArgs &al, const double *h_x, const int *h_slot, int hb,
+                                             int he, int lane, double S1c, double S2c, double old, double lam, double mu, double z) {
+  constexpr int U = 4;
+  if (he - hb <= U * WAVE) {
+    int sl[U];
+    double hx[U], t1[U], t2[U];
+    typename P::St st[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int h = hb + u * WAVE + lane;
+      const bool ok = h < he;
+      sl[u] = ok ? h_slot[h] : 0;
+      hx[u] = ok ? h_x[h] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) st[u] = P::load(al, sl[u]);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      t1[u] = 0.0;
+      t2[u] = 0.0;
+      ChainOps<P>::stats(hx[u], st[u], old, t1[u], t2[u]);
+    }
+    double h1 = (t1[0] + t1[1]) + (t1[2] + t1[3]), h2 = (t2[0] + t2[1]) + (t2[2] + t2[3]);
+    wave_allreduce_sum2(h1, h2);
+    const double fresh = P::template draw<true>(S1c + h1, S2c + h2, old, a.alpha, lam, mu, z);
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (hb + u * WAVE + lane < he) ChainOps<P>::apply(al, sl[u], hx[u], st[u], old, fresh);
+    return fresh;
+  }
+  double h1 = 0.0, h2 = 0.0;
+  for (int h = hb + lane; h < he; h += WAVE) ChainOps<P>::stats(h_x[h], P::load(al, h_slot[h]), old, h1, h2);
+  wave_allreduce_sum2(h1, h2);
+  const double fresh = P::template draw<true>(S1c + h1, S2c + h2, old, a.alpha, lam, mu, z);
+  for (int h = hb + lane; h < he; h += WAVE) {
+    const int slot = h_slot[h];
+    ChainOps<P>::apply(al, slot, h_x[h], P::load(al, slot), old, fresh);
+  }
+  return fresh;
+}
+
 template <class P>
 __global__ __launch_bounds__(CHAINB_NT) void k_chain_batched(SweepArgs a, const ChainBatch *__restrict__ batches, int n_batches,
                                                              const int32_t *__restrict__ cols,
@@ -2080,14 +2126,7 @@ __global__ __launch_bounds__(CHAINB_NT) void k_chain_batched(SweepArgs a, const 
         const double S1 = part[c * NW].x, S2 = part[c * NW].y;
         const double old = c_old[c];
         const int hb = h_ptr[c], he = h_ptr[c + 1];
-        double h1 = 0.0, h2 = 0.0;
-        for (int h = hb + lane; h < he; h += WAVE) ChainOps<P>::stats(h_x[h], P::load(al, h_slot[h]), old, h1, h2);
-        wave_allreduce_sum2(h1, h2);
-        const double fresh = P::template draw<true>(S1 + h1, S2 + h2, old, a.alpha, c_lam[c], c_mu[c], c_z[c]);
-        for (int h = hb + lane; h < he; h += WAVE) {
-          const int slot = h_slot[h];
-          ChainOps<P>::apply(al, slot, h_x[h], P::load(al, slot), old, fresh);
-        }
+        const double fresh = hot_column<P>(a, al, h_x, h_slot, hb, he, lane, S1, S2, old, c_lam[c], c_mu[c], c_z[c]);
         if (lane == 0) c_new[c] = fresh;
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this column's LDS updates before the next column's loads
       }
@@ -2245,14 +2284,7 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_hot(SweepArgs a, ChainBatch B,
       const double S1 = csum[c].x, S2 = csum[c].y;
       const double old = c_old[c];
       const int hb = h_ptr[c], he = h_ptr[c + 1];
-      double h1 = 0.0, h2 = 0.0;
-      for (int h = hb + lane; h < he; h += WAVE) ChainOps<P>::stats(h_x[h], P::load(al, h_slot[h]), old, h1, h2);
-      wave_allreduce_sum2(h1, h2);
-      const double fresh = P::template draw<true>(S1 + h1, S2 + h2, old, a.alpha, c_lam[c], c_mu[c], c_z[c]);
-      for (int h = hb + lane; h < he; h += WAVE) {
-        const int slot = h_slot[h];
-        ChainOps<P>::apply(al, slot, h_x[h], P::load(al, slot), old, fresh);
-      }
+      const double fresh = hot_column<P>(a, al, h_x, h_slot, hb, he, lane, S1, S2, old, c_lam[c], c_mu[c], c_z[c]);
       if (lane == 0) c_new[c] = fresh;
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     }
