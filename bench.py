@@ -167,12 +167,30 @@ def main():
         cuts = mdist.shard_cuts(X.indices[X.indptr[:-1]], world)
         lo, hi = cuts[rank], cuts[rank + 1]
         rels = [_myfm.RelationBlock(np.asarray(m, dtype=np.int64)[lo:hi], B) for m, B in blocks]
-        cid = mdist.native_comm_id()
-        sess = _myfm.GibbsSession(K, 0.1, X[lo:hi], rels, y[lo:hi], 42, make_config(_myfm, gi, a.steps + a.warmup + 8, 0, W["task"], hi - lo),
-                                  n_total_rows=N, row_offset=lo, main_levels=levels, comm_id=cid, shard_rank=rank, shard_world=world)
-        parallelism = ("one chain over the same %d rows, sharded over %d GPUs at user boundaries (%d rows on rank 0); RCCL all-reduce "
-                       "called by libmyfm_hip.so on its stream: per factor the item level's statistics, per sweep one model "
-                       "synchronisation" % (N, world, hi - lo))
+        cfg = make_config(_myfm, gi, a.steps + a.warmup + 8, 0, W["task"], hi - lo)
+        sess, err = None, ""
+        if not os.environ.get("MYFM_BENCH_TORCH_ALLREDUCE"):
+            try:
+                cid = mdist.native_comm_id()
+                sess = _myfm.GibbsSession(K, 0.1, X[lo:hi], rels, y[lo:hi], 42, cfg, n_total_rows=N, row_offset=lo, main_levels=levels,
+                                          comm_id=cid, shard_rank=rank, shard_world=world)
+            except Exception as ex:  # noqa: BLE001 -- reported below; every rank must take the same branch
+                err = "%s: %s" % (type(ex).__name__, ex)
+        ok = torch.tensor([1 if sess is not None else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        how = "RCCL all-reduce called by libmyfm_hip.so on its stream"
+        if int(ok.item()) == 0:
+            # the library could not open its own communicator on some rank: the same all-reduces through torch.distributed
+            # (the same librccl, called back from the library on a torch stream)
+            print("bench.py rank %d: native RCCL communicator unavailable (%s); using the torch.distributed callback" % (rank, err),
+                  file=sys.stderr)
+            sess = None
+            ar = mdist.TorchAllReduce()
+            sess = _myfm.GibbsSession(K, 0.1, X[lo:hi], rels, y[lo:hi], 42, cfg, allreduce=ar, n_total_rows=N, row_offset=lo,
+                                      stream=ar.stream_ptr, main_levels=levels, shard_rank=rank, shard_world=world)
+            how = "all-reduce through torch.distributed (RCCL) called back from libmyfm_hip.so on a shared stream"
+        parallelism = ("one chain over the same %d rows, sharded over %d GPUs at user boundaries (%d rows on rank 0); %s: per factor "
+                       "the item level's statistics, per sweep one model synchronisation" % (N, world, hi - lo, how))
     t_setup = time.time() - t0
 
     def sync():
