@@ -129,8 +129,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the sampler has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    os.environ["MYFM_AMD_DEVICE"] = str(local_rank)  # one process per GPU
+    # MYFM_BENCH_BACKEND=gloo MYFM_BENCH_DEVICE=0: several ranks on ONE GPU (the multi-process flow on a 1-GPU box: RCCL
+    # refuses two ranks on a device, so the all-reduces then go through torch.distributed / gloo from the library's callback)
+    backend = os.environ.get("MYFM_BENCH_BACKEND", "nccl")
+    dev = int(os.environ.get("MYFM_BENCH_DEVICE", local_rank))
+    if backend != "nccl":
+        os.environ["MYFM_BENCH_TORCH_ALLREDUCE"] = "1"
+    torch.cuda.set_device(dev)
+    os.environ["MYFM_AMD_DEVICE"] = str(dev)  # one process per GPU
     dist = None
     force_sharded = bool(os.environ.get("MYFM_BENCH_FORCE_SHARDED"))  # exercise the N > 1 code path at world = 1
     if world > 1 or force_sharded:
@@ -138,7 +144,10 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from myfm_amd import _capi, _myfm
     from tests import datasets as ds
@@ -188,7 +197,7 @@ def main():
             ar = mdist.TorchAllReduce()
             sess = _myfm.GibbsSession(K, 0.1, X[lo:hi], rels, y[lo:hi], 42, cfg, allreduce=ar, n_total_rows=N, row_offset=lo,
                                       stream=ar.stream_ptr, main_levels=levels, shard_rank=rank, shard_world=world)
-            how = "all-reduce through torch.distributed (RCCL) called back from libmyfm_hip.so on a shared stream"
+            how = "all-reduce through torch.distributed (%s) called back from libmyfm_hip.so on a shared stream" % backend
         parallelism = ("one chain over the same %d rows, sharded over %d GPUs at user boundaries (%d rows on rank 0); %s: per factor "
                        "the item level's statistics, per sweep one model synchronisation" % (N, world, hi - lo, how))
     t_setup = time.time() - t0

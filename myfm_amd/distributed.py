@@ -71,20 +71,23 @@ class TorchAllReduce:
 
 
 # ---- native provider: the library calls RCCL itself (mfm_comm_init) -------------------------------------------------
-_STATE = {"on": False, "group": None}
+_STATE = {"on": False, "group": None, "native": True}
 
 
-def enable(group=None, set_device=True):
+def enable(group=None, set_device=True, native=True):
     """Make `MyFM*.fit()` row-sharded over the ranks of `group` (default: the world group of an initialised
     torch.distributed): every rank calls fit() with the SAME full data, trains on its contiguous slice of the rows on its
-    own GPU (LOCAL_RANK) with the all-reduces issued by libmyfm_hip.so through RCCL, and ends with the same samples."""
+    own GPU (LOCAL_RANK) with the all-reduces issued by libmyfm_hip.so through RCCL, and ends with the same samples.
+
+    native=False: the library calls back into `torch.distributed.all_reduce` of `group` instead of opening its own RCCL
+    communicator (any backend -- e.g. gloo with several ranks on one GPU, which RCCL refuses)."""
     import os
 
     import torch.distributed as dist
 
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised (init_process_group first)")
-    _STATE.update(on=True, group=group)
+    _STATE.update(on=True, group=group, native=bool(native))
     if set_device and "MYFM_AMD_DEVICE" not in os.environ:
         os.environ["MYFM_AMD_DEVICE"] = os.environ.get("LOCAL_RANK", "0")
 
@@ -99,6 +102,14 @@ def active():
     import torch.distributed as dist
 
     return dist.is_initialized() and dist.get_world_size(_STATE["group"]) > 1
+
+
+def comm_kwargs():
+    """Keyword arguments of `_myfm.create_train_fm_sharded` that select the all-reduce provider."""
+    if _STATE["native"]:
+        return dict(comm_id=native_comm_id(_STATE["group"]))
+    ar = TorchAllReduce(group=_STATE["group"])
+    return dict(allreduce=ar, stream=ar.stream_ptr)
 
 
 def rank_world():

@@ -238,7 +238,7 @@ class MyFMGibbsBase:
                 y_l = np.ascontiguousarray(np.asarray(y, dtype=REAL)[lo:hi])
                 self.predictor_, self.history_ = _myfm.create_train_fm_sharded(
                     self.rank, self.init_stdev, X[lo:hi], rel_l, y_l, self.random_seed, config, wrapped, rank, world, n, lo,
-                    np.ascontiguousarray(levels, dtype=np.int32), comm_id=_dist.native_comm_id(_dist._STATE["group"]))
+                    np.ascontiguousarray(levels, dtype=np.int32), **_dist.comm_kwargs())
             else:
                 self.predictor_, self.history_ = _myfm.create_train_fm(
                     self.rank, self.init_stdev, X, list(X_rel), np.ascontiguousarray(y, dtype=REAL), self.random_seed, config,

@@ -15,14 +15,23 @@ def main():
     import torch.distributed as dist
 
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    # MP_FIT_ONE_GPU=1: every rank on device 0, process group over gloo, the library's all-reduces through the
+    # torch.distributed callback (RCCL refuses two ranks on one device): the multi-PROCESS flow on a 1-GPU box
+    one_gpu = bool(os.environ.get("MP_FIT_ONE_GPU"))
+    if one_gpu:
+        local = 0
+        os.environ["MYFM_AMD_DEVICE"] = "0"
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if one_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     import myfm_amd
     from myfm_amd import distributed as D
     from oracle import oracle as O
     from tests import datasets as ds
 
-    D.enable()
+    D.enable(native=not one_gpu)
     X, y, shapes = ds.onehot_mf(40000, 300, 80, seed=5)
     gi = ds.group_index_from_shapes(shapes)
     fm = myfm_amd.MyFMRegressor(6).fit(X, y, group_shapes=shapes, n_iter=6, n_kept_samples=6)

@@ -288,6 +288,22 @@ def test_multi_gpu_sharded_fit():
     assert r.returncode == 0 and "mp_fit_worker ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+def test_two_processes_one_gpu_sharded_fit():
+    # the multi-PROCESS flow of the row-sharded fit() on a 1-GPU box: two ranks under torch.distributed.run, both on
+    # device 0, process group over gloo, the library's all-reduces through the torch.distributed callback; each rank
+    # reproduces the oracle's unsharded chain and the replicas agree bit for bit
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(root, "tests", "mp_fit_worker.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MP_FIT_ONE_GPU="1")
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "mp_fit_worker ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_empty_shard_does_not_hang_or_corrupt(oracle, monkeypatch):
     # a rank without rows must take part in every collective of mfm_finalize and of the sweeps, and the owner of
     # the replicated columns is rank 0 of the communicator, not "the rank whose first row is global row 0"
