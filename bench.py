@@ -97,7 +97,8 @@ def cpu_baseline(W, gi, min_seconds, max_iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=0, help="timed iterations (0: enough for >= 10 s of GPU work at config 3, so that "
+                    "a 5-second utilisation sampler sees the timed region; 100 for the other configs)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="config 5: fraction of the full N = 50 M shape")
@@ -112,6 +113,8 @@ def main():
     a = ap.parse_args()
     if a.cpu_iters == 0:
         a.cpu_seconds = 0.0
+    if a.steps <= 0:
+        a.steps = 2000 if a.config == 3 else (100 if a.config != 5 else 10)
 
     # stdout carries exactly ONE line (the JSON): whatever native libraries print there (RCCL's version banner is flushed
     # at exit) goes to stderr instead
