@@ -1,3 +1,4 @@
+#include <cstdio>
 // _myfm.cpp -- the drop-in boundary: a pybind11 module with the names and signatures of the
 // reference's `myfm._myfm` (cpp_source/declare_module.hpp:67-404, stubs src/myfm/_myfm.pyi), whose
 // trainer drives the MI355X device path through the C ABI of include/myfm_hip.h.
@@ -15,6 +16,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdint>
 #include <cstdlib>
 #include <functional>
@@ -763,6 +765,20 @@ struct OprobitSampler {
 };
 
 // ---- GibbsFMTrainer (BaseFMTrainer.hpp + FMTrainer.hpp) on the device path ---------------------------
+// MFM_SETUP_TIMING=1: wall time of the host-side setup stages (stderr)
+struct SetupLap {
+  const char *who;
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  explicit SetupLap(const char *w) : who(w), on(std::getenv("MFM_SETUP_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void operator()(const char *what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[%s] %-44s %.3f s\n", who, what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+
 struct FMTrainer {
   mfm_ctx *ctx = nullptr;
   int64_t N = 0, D0 = 0;
@@ -1096,11 +1112,15 @@ struct FMTrainer {
   std::pair<Predictor, LearningHistory> learn_with_callback(
       FM &fm, Hyper &hyper, const std::function<bool(int, FM *, Hyper *, LearningHistory *)> &cb) {
     std::pair<Predictor, LearningHistory> result{Predictor((size_t)fm.n_factors, dim_all, cfg.task_type), LearningHistory()};
+    SetupLap lap("learn_with_callback");
     build_device(fm.n_factors);
+    lap("build_device (set_main, blocks, finalize)");
     upload(fm);
     initialize_hyper(hyper);
     initialize_e(fm);
+    lap("state upload + initialize_e");
     start_device_rng(fm.n_factors);
+    lap("device RNG hand-over");
     fm.fetch = [this](FM &f) { this->download(f); };
     fm.live_ctx = ctx;
     result.first.samples.reserve((size_t)cfg.n_kept_samples);
@@ -1160,8 +1180,11 @@ std::pair<Predictor, LearningHistory> create_train_fm(size_t n_factor, Real init
                                                       const py::object &relations, const py::object &y, int random_seed,
                                                       FMLearningConfig &config,
                                                       std::function<bool(int, FM *, Hyper *, LearningHistory *)> cb) {
+  SetupLap lap("create_train_fm");
   FMTrainer fm_trainer(X, relations, y, random_seed, config);
+  lap("trainer (copy of X, relations, y)");
   auto fm = fm_trainer.create_FM((int)n_factor, init_std);
+  lap("initialize_weight");
   auto hyper_param = fm_trainer.create_Hyper((size_t)fm.n_factors);
   return fm_trainer.learn_with_callback(fm, hyper_param, cb);
 }

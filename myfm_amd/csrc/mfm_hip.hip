@@ -685,6 +685,11 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
       c->plan_V.special = std::move(special);
     }
     c->plan_V.group_of = &c->hgroup;
+    // the row-tile layouts of scattered levels are packed on the device from the device-resident CSC
+    static thread_local DevCscView dev_view;
+    dev_view = DevCscView{c->X.colptr.p, c->X.rowidx.p, c->X.cval.p, c->stream};
+    c->plan_V.dev_csc = c->X.colptr.p ? &dev_view : nullptr;
+    c->plan_W.dev_csc = c->plan_V.dev_csc;
     c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_v, true, c->X.unit);
     lap("plan_V");
     if (try_fused) {
@@ -701,6 +706,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
         c->plan_V.given_levels = c->hlevels;
         c->plan_V.tile_bits = tile_bits;
         c->plan_V.group_of = &c->hgroup;
+        c->plan_V.dev_csc = c->plan_W.dev_csc;
         c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_v, true, c->X.unit);
       } else {
         c->sharded_fused = true;

@@ -15,9 +15,13 @@
 #pragma once
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <string>
+#include <type_traits>
 #include <vector>
 
 #include <dlfcn.h>
+#include <hipcub/hipcub.hpp>
 
 #include "mfm_common.hpp"
 #include "mfm_kernels.hpp"
@@ -209,6 +213,98 @@ struct Step {
   ChainRun chain;
 };
 
+// ---- row-tile layout of a scattered level built ON THE DEVICE --------------------------------------------------
+// The same structure build_tiled() makes on the host (entries of the level sorted by (tile, column, row), padded per tile to
+// whole wavefronts, runs per wave tile, column-major slot positions), from the device-resident CSC: a stable radix sort of
+// (tile << cbits | column) keys over the level's entries in (column, row) order, lower bounds for the tile / column
+// boundaries, an exclusive scan of the runs per wave tile, a second stable sort of the runs by column.
+struct DevCscView {
+  const int64_t *colptr = nullptr;
+  const int32_t *rowidx = nullptr;
+  const double *cval = nullptr;
+  hipStream_t stream = nullptr;
+};
+__device__ __forceinline__ int dp_upper_tile(const int32_t *tstart, int nb, int r) {  // tile b with tstart[b] <= r < tstart[b + 1]
+  int lo = 0, hi = nb;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tstart[mid] <= r) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+// one wavefront per level column: key / payload of its entries at the column's offset in the level's entry list
+__global__ __launch_bounds__(WG) void k_dp_keys(const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
+                                                 const int32_t *__restrict__ cols, const int32_t *__restrict__ lvl_ptr, int n_cols,
+                                                 const int32_t *__restrict__ tstart, int nb, int cbits,
+                                                 uint64_t *__restrict__ key, uint32_t *__restrict__ pos) {
+  const int c = blockIdx.x * (WG / WAVE) + (threadIdx.x >> 6);
+  if (c >= n_cols) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t b = colptr[cols[c]], e = colptr[cols[c] + 1];
+  const int32_t o = lvl_ptr[c];
+  for (int64_t p = b + lane; p < e; p += WAVE) {
+    const int t = dp_upper_tile(tstart, nb, rowidx[p]);
+    key[o + (p - b)] = ((uint64_t)t << cbits) | (uint32_t)c;
+    pos[o + (p - b)] = (uint32_t)p;
+  }
+}
+template <class T>
+__global__ void k_dp_lower_bound(const T *__restrict__ sorted, int64_t n, int shift, int n_q, int32_t *__restrict__ out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;  // first position whose (key >> shift) >= q
+  if (q >= n_q) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)(sorted[mid] >> shift) < (int64_t)q) lo = mid + 1; else hi = mid;
+  }
+  out[q] = (int32_t)lo;
+}
+__global__ void k_dp_fill(const uint64_t *__restrict__ key, const uint32_t *__restrict__ pos, int64_t n, int cbits, int tile_bits,
+                          const int32_t *__restrict__ tile_begin, const int32_t *__restrict__ tptr, const int32_t *__restrict__ tstart,
+                          const int32_t *__restrict__ rowidx, const double *__restrict__ cval, uint32_t *__restrict__ tent,
+                          double *__restrict__ ev) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint64_t k = key[p];
+  const int b = (int)(k >> cbits);
+  const uint32_t c = (uint32_t)(k & (((uint64_t)1 << cbits) - 1));
+  const int64_t q = (int64_t)tptr[b] * WAVE + (p - tile_begin[b]);
+  const uint32_t cp = pos[p];
+  tent[q] = (c << tile_bits) | (uint32_t)(rowidx[cp] - tstart[b]);
+  if (ev) ev[q] = cval[cp];
+}
+// runs of one column inside a wave tile: count (pass 0) / column of every run at run_base[t] + rank (pass 1)
+__global__ __launch_bounds__(WG) void k_dp_runs(const uint32_t *__restrict__ tent, int64_t n_wt, int tile_bits,
+                                                 int32_t *__restrict__ run_cnt, const int32_t *__restrict__ run_base,
+                                                 int32_t *__restrict__ run_col) {
+  const int64_t t = (int64_t)blockIdx.x * (WG / WAVE) + (threadIdx.x >> 6);
+  if (t >= n_wt) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t u = tent[t * WAVE + lane];
+  const uint32_t prev = __shfl_up(u, 1, WAVE);
+  const bool head = u != TILE_PAD && (lane == 0 || (prev >> tile_bits) != (u >> tile_bits));
+  const unsigned long long m = __ballot(head);
+  if (run_col) {
+    if (head) run_col[run_base[t] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)(u >> tile_bits);
+  } else if (lane == 0) {
+    run_cnt[t] = __popcll(m);
+  }
+}
+__global__ void k_dp_iota(uint32_t *__restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (uint32_t)i;
+}
+__global__ void k_dp_invert(const uint32_t *__restrict__ sidx, int64_t n, int32_t *__restrict__ slot_pos) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) slot_pos[sidx[k]] = (int32_t)k;
+}
+__global__ void k_dp_row_once(const uint64_t *__restrict__ key, const uint32_t *__restrict__ pos, int64_t n,
+                              const int32_t *__restrict__ rowidx, int32_t *__restrict__ cnt, int *__restrict__ dup) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  if (atomicAdd(&cnt[rowidx[pos[p]]], 1) != 0) *dup = 1;
+}
+
 constexpr size_t CHAIN_LDS_MAX = 156 * 1024;  // of the CU's 160 KiB
 
 struct StepPlan {
@@ -252,7 +348,7 @@ struct StepPlan {
   // L untouched) when the level is small or its columns are mostly contiguous.
   // tile_bits > 0: row-tile variant (tiles of 2^tile_bits rows staged in LDS, packed + padded entries)
   static bool build_scattered(const HostCsr &csc, const std::vector<int32_t> &cols, int64_t lnnz, bool unit, ParLevel &L,
-                              int tile_bits = 0, const std::vector<int32_t> *bounds = nullptr) {
+                              int tile_bits = 0, const std::vector<int32_t> *bounds = nullptr, const DevCscView *dev = nullptr) {
     int64_t min_nnz = 1 << 16;  // (measured: the tile path and the fusions it enables win from ~10^5 entries per level on)
     if (const char *e = std::getenv("MFM_SCATTER_MIN_NNZ")) min_nnz = std::atoll(e);
     if (lnnz < min_nnz) return false;
@@ -268,7 +364,36 @@ struct StepPlan {
       // packed entry must hold the column's position in the level
       if (2 * lnnz < N || (int64_t)cols.size() >= ((int64_t)1 << (32 - tile_bits)) - 1) tile_bits = 0;
     }
-    if (tile_bits > 0) return build_tiled(csc, cols, lnnz, unit, L, tile_bits, bounds);
+    if (tile_bits > 0) {
+      if (dev && dev->colptr && !std::getenv("MFM_HOST_TILE_PACK") && !std::getenv("MFM_MF_STREAM_SLOTS") &&
+          build_tiled_device(*dev, csc, cols, lnnz, unit, L, tile_bits, bounds)) {
+        if (std::getenv("MFM_PLAN_CHECK")) {  // tests: the device layout must be the host layout, array by array
+          ParLevel H;
+          if (!build_tiled(csc, cols, lnnz, unit, H, tile_bits, bounds)) throw Error(MFM_ERR_RUNTIME, "plan check: host layout failed");
+          auto same = [](const auto &a, const auto &b, size_t n, const char *what) {
+            typedef typename std::remove_pointer<decltype(a.p)>::type T;
+            std::vector<T> x(n), y(n);
+            if (n) {
+              MFM_HIP_CHECK(hipMemcpy(x.data(), a.p, n * sizeof(T), hipMemcpyDeviceToHost));
+              MFM_HIP_CHECK(hipMemcpy(y.data(), b.p, n * sizeof(T), hipMemcpyDeviceToHost));
+            }
+            if (std::memcmp(x.data(), y.data(), n * sizeof(T)) != 0)
+              throw Error(MFM_ERR_RUNTIME, std::string("plan check: device and host tile layouts differ in ") + what);
+          };
+          if (L.n_runs != H.n_runs || L.n_tiles != H.n_tiles || L.n_ent != H.n_ent || L.covers_rows_once != H.covers_rows_once)
+            throw Error(MFM_ERR_RUNTIME, "plan check: device and host tile layouts differ in their sizes");
+          const size_t n_pad = H.tent.n;
+          same(L.tent, H.tent, n_pad, "tent");
+          if (!unit) same(L.ent_val, H.ent_val, n_pad, "ent_val");
+          same(L.tile_ptr, H.tile_ptr, (size_t)H.n_tiles + 1, "tile_ptr");
+          same(L.run_base, H.run_base, H.run_base.n, "run_base");
+          same(L.slot_ptr, H.slot_ptr, cols.size() + 1, "slot_ptr");
+          same(L.slot_pos, H.slot_pos, (size_t)H.n_runs, "slot_pos");
+        }
+        return true;
+      }
+      return build_tiled(csc, cols, lnnz, unit, L, tile_bits, bounds);
+    }
     int64_t RB = SCAT_RB;
     if (const char *e = std::getenv("MFM_SCAT_RB")) RB = std::max<int64_t>(1024, std::atoll(e));
     const int64_t nb = (N + RB - 1) / RB;
@@ -330,6 +455,136 @@ struct StepPlan {
     L.slot_ptr.upload(sptr);
     L.slot_idx.upload(sidx);
     L.slots.alloc((size_t)std::max<size_t>(run_col.size(), 1));
+    return true;
+  }
+
+  const DevCscView *dev_csc = nullptr;  // (set by the owner before build: the table's CSC on the device -> tile packing there)
+
+  static bool build_tiled_device(const DevCscView &dv, const HostCsr &csc, const std::vector<int32_t> &cols, int64_t lnnz,
+                                 bool unit, ParLevel &L, int tile_bits, const std::vector<int32_t> *bounds) {
+    const int64_t N = csc.cols, RB = (int64_t)1 << tile_bits;
+    hipStream_t s = dv.stream;
+    std::vector<int32_t> grid;
+    if (!bounds || bounds->size() < 2) {
+      for (int64_t r = 0; r < N; r += RB) grid.push_back((int32_t)r);
+      grid.push_back((int32_t)N);
+      bounds = &grid;
+    }
+    const std::vector<int32_t> &tstart = *bounds;
+    const int nb = (int)tstart.size() - 1, ncols = (int)cols.size();
+    int cbits = 1, bbits = 1;
+    while (((int64_t)1 << cbits) < ncols) cbits++;
+    while (((int64_t)1 << bbits) < nb) bbits++;
+    if (cbits + bbits > 62 || lnnz >= ((int64_t)1 << 31) || lnnz == 0) return false;
+    std::vector<int32_t> lptr((size_t)ncols + 1, 0);
+    for (int c = 0; c < ncols; c++) lptr[c + 1] = lptr[c] + (int32_t)(csc.ptr[cols[c] + 1] - csc.ptr[cols[c]]);
+    DevBuf<int32_t> d_cols, d_lptr, d_tstart, d_tbegin, d_tptr;
+    d_cols.upload(cols);
+    d_lptr.upload(lptr);
+    d_tstart.upload(tstart);
+    DevBuf<uint64_t> key, key2;
+    DevBuf<uint32_t> pos, pos2;
+    key.alloc((size_t)lnnz);
+    key2.alloc((size_t)lnnz);
+    pos.alloc((size_t)lnnz);
+    pos2.alloc((size_t)lnnz);
+    hipLaunchKernelGGL(k_dp_keys, dim3((ncols + WG / WAVE - 1) / (WG / WAVE)), dim3(WG), 0, s, dv.colptr, dv.rowidx, d_cols.p, d_lptr.p,
+                       ncols, d_tstart.p, nb, cbits, key.p, pos.p);
+    size_t tmp_bytes = 0;
+    MFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key.p, key2.p, pos.p, pos2.p, (int)lnnz, 0, cbits + bbits, s));
+    DevBuf<char> tmp;
+    tmp.alloc(tmp_bytes);
+    MFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, key.p, key2.p, pos.p, pos2.p, (int)lnnz, 0, cbits + bbits, s));
+    // tile boundaries in the sorted order -> padded wave-tile offsets (host: nb + 1 integers)
+    d_tbegin.alloc((size_t)nb + 1);
+    hipLaunchKernelGGL((k_dp_lower_bound<uint64_t>), dim3((nb + 256) / 256), dim3(256), 0, s, key2.p, lnnz, cbits, nb + 1, d_tbegin.p);
+    std::vector<int32_t> tbegin((size_t)nb + 1), tptr((size_t)nb + 1, 0);
+    MFM_HIP_CHECK(hipMemcpyAsync(tbegin.data(), d_tbegin.p, ((size_t)nb + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    for (int b = 0; b < nb; b++) {
+      const int64_t t = (int64_t)tptr[b] + ((int64_t)(tbegin[b + 1] - tbegin[b]) + WAVE - 1) / WAVE;
+      if (t >= (int64_t)1 << 30) return false;
+      tptr[b + 1] = (int32_t)t;
+    }
+    const int64_t n_wt = tptr[nb], n_pad = n_wt * WAVE;
+    d_tptr.upload(tptr);
+    L.tent.alloc((size_t)std::max<int64_t>(n_pad, 1));
+    MFM_HIP_CHECK(hipMemsetAsync(L.tent.p, 0xff, (size_t)n_pad * sizeof(uint32_t), s));
+    if (!unit) {
+      L.ent_val.alloc((size_t)std::max<int64_t>(n_pad, 1));
+      MFM_HIP_CHECK(hipMemsetAsync(L.ent_val.p, 0, (size_t)n_pad * sizeof(double), s));
+    }
+    hipLaunchKernelGGL(k_dp_fill, dim3((unsigned)((lnnz + 255) / 256)), dim3(256), 0, s, key2.p, pos2.p, lnnz, cbits, tile_bits,
+                       d_tbegin.p, d_tptr.p, d_tstart.p, dv.rowidx, unit ? nullptr : dv.cval, L.tent.p, unit ? nullptr : L.ent_val.p);
+    // runs per wave tile -> run_base (exclusive scan), column of every run
+    DevBuf<int32_t> run_cnt;
+    run_cnt.alloc((size_t)n_wt + 1);
+    MFM_HIP_CHECK(hipMemsetAsync(run_cnt.p, 0, ((size_t)n_wt + 1) * sizeof(int32_t), s));
+    const unsigned g_wt = (unsigned)((n_wt + WG / WAVE - 1) / (WG / WAVE));
+    hipLaunchKernelGGL(k_dp_runs, dim3(std::max(g_wt, 1u)), dim3(WG), 0, s, L.tent.p, n_wt, tile_bits, run_cnt.p, nullptr, nullptr);
+    L.run_base.alloc((size_t)n_wt + 1);
+    size_t scan_bytes = 0;
+    MFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, run_cnt.p, L.run_base.p, (int)(n_wt + 1), s));
+    DevBuf<char> tmp2;
+    tmp2.alloc(scan_bytes);
+    MFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp2.p, scan_bytes, run_cnt.p, L.run_base.p, (int)(n_wt + 1), s));
+    int32_t n_runs = 0;
+    MFM_HIP_CHECK(hipMemcpyAsync(&n_runs, L.run_base.p + n_wt, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    DevBuf<int32_t> run_col, run_col2;
+    DevBuf<uint32_t> ridx, sidx;
+    run_col.alloc((size_t)std::max(n_runs, 1));
+    run_col2.alloc((size_t)std::max(n_runs, 1));
+    ridx.alloc((size_t)std::max(n_runs, 1));
+    sidx.alloc((size_t)std::max(n_runs, 1));
+    hipLaunchKernelGGL(k_dp_runs, dim3(std::max(g_wt, 1u)), dim3(WG), 0, s, L.tent.p, n_wt, tile_bits, nullptr, L.run_base.p, run_col.p);
+    // slots in column-major order: the runs sorted by column (stable: stream order inside a column)
+    L.slot_ptr.alloc((size_t)ncols + 1);
+    L.slot_pos.alloc((size_t)std::max(n_runs, 1));
+    if (n_runs > 0) {
+      hipLaunchKernelGGL(k_dp_iota, dim3((unsigned)((n_runs + 255) / 256)), dim3(256), 0, s, ridx.p, (int64_t)n_runs);
+      size_t sb = 0;
+      MFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sb, run_col.p, run_col2.p, ridx.p, sidx.p, n_runs, 0, cbits, s));
+      DevBuf<char> tmp3;
+      tmp3.alloc(sb);
+      MFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp3.p, sb, run_col.p, run_col2.p, ridx.p, sidx.p, n_runs, 0, cbits, s));
+      hipLaunchKernelGGL((k_dp_lower_bound<int32_t>), dim3((ncols + 256) / 256), dim3(256), 0, s, run_col2.p, (int64_t)n_runs, 0, ncols + 1,
+                         L.slot_ptr.p);
+      hipLaunchKernelGGL(k_dp_invert, dim3((unsigned)((n_runs + 255) / 256)), dim3(256), 0, s, sidx.p, (int64_t)n_runs, L.slot_pos.p);
+      MFM_HIP_CHECK(hipStreamSynchronize(s));  // (the sort's temporaries are released on return)
+    } else {
+      MFM_HIP_CHECK(hipMemsetAsync(L.slot_ptr.p, 0, ((size_t)ncols + 1) * sizeof(int32_t), s));
+    }
+    // does the level touch every row exactly once?
+    bool once = lnnz == N;
+    if (once) {
+      DevBuf<int32_t> cnt;
+      DevBuf<int> dup;
+      cnt.alloc((size_t)N);
+      dup.alloc(1);
+      MFM_HIP_CHECK(hipMemsetAsync(cnt.p, 0, (size_t)N * sizeof(int32_t), s));
+      MFM_HIP_CHECK(hipMemsetAsync(dup.p, 0, sizeof(int), s));
+      hipLaunchKernelGGL(k_dp_row_once, dim3((unsigned)((lnnz + 255) / 256)), dim3(256), 0, s, key2.p, pos2.p, lnnz, dv.rowidx, cnt.p, dup.p);
+      int h = 0;
+      MFM_HIP_CHECK(hipMemcpyAsync(&h, dup.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      MFM_HIP_CHECK(hipStreamSynchronize(s));
+      once = h == 0;
+    }
+    MFM_HIP_CHECK(hipGetLastError());
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    L.covers_rows_once = once;
+    L.scattered = true;
+    L.tiled = true;
+    L.tile_bits = tile_bits;
+    L.n_tiles = nb;
+    L.n_ent = lnnz;
+    L.n_cols = ncols;
+    L.n_runs = n_runs;
+    L.tile_ptr.upload(tptr);
+    L.tile_row0.upload(tstart);
+    L.scols.upload(cols);
+    L.slots.alloc((size_t)std::max<size_t>((size_t)n_runs, 1));
+    MFM_HIP_CHECK(hipMemset(L.slots.p, 0, std::max<size_t>((size_t)n_runs, 1) * sizeof(double2)));
     return true;
   }
 
@@ -804,7 +1059,7 @@ struct StepPlan {
         }
       }
       if (allow_scatter && build_scattered(csc, by_level[l], lnnz, unit, L, (sharded && !sharded_tiles) ? 0 : tile_bits,
-                                           aligned_tiles ? &h_tile_start : nullptr)) {
+                                           aligned_tiles ? &h_tile_start : nullptr, dev_csc)) {
         launches += 3;
         max_cols_scat = std::max<int64_t>(max_cols_scat, csc.rows);
         continue;
