@@ -820,9 +820,12 @@ struct FMTrainer {
   // BaseFMTrainer.hpp:58-105
   FMTrainer(const py::object &Xo, const py::object &relso, const py::object &yo, int random_seed, FMLearningConfig config)
       : cfg(std::move(config)), random_seed(random_seed), gen_(random_seed) {
+    SetupLap lap("FMTrainer");
     X_ = csr_from_py(Xo);
+    lap("copy of X");
     rels_ = relations_from_py(relso);
     dim_all = check_row_consistency_return_column(X_, rels_);
+    lap("relations");
     y = np_to_vec(yo);
     N = X_.rows;
     N_total = N;
@@ -852,6 +855,7 @@ struct FMTrainer {
           throw std::invalid_argument(ss.str());
         }
     }
+    lap("y, cutpoint group checks");
     if (cfg.group_index.size() != dim_all) throw std::out_of_range("group_index does not cover all features");  // .at()
     n_in_group.assign(cfg.n_groups, 0);
     for (auto g : cfg.group_index) n_in_group[g] += 1;
@@ -885,12 +889,15 @@ struct FMTrainer {
       ck(ctx, mfm_set_shard(ctx, shard_rank, shard_world));
       ck(ctx, mfm_set_row_offset(ctx, row_offset));
     }
+    SetupLap lap("build_device");
     if (!main_levels.empty()) ck(ctx, mfm_set_main_levels(ctx, main_levels.data(), (int64_t)main_levels.size()));
     ck(ctx, mfm_set_main(ctx, X_.rows, X_.cols, X_.indptr.data(), X_.indices.data(), X_.data.data(), y.data()));
+    lap("mfm_set_main");
     for (auto &r : rels_) {
       auto m = r->map64();
       ck(ctx, mfm_add_block(ctx, r->X.rows, r->X.cols, r->X.indptr.data(), r->X.indices.data(), r->X.data.data(), m.data()));
     }
+    lap("mfm_add_block (all)");
     vector<int32_t> gi(cfg.group_index.begin(), cfg.group_index.end());
     ck(ctx, mfm_set_groups(ctx, gi.data(), (int64_t)gi.size(), (int32_t)cfg.n_groups));
     ck(ctx, mfm_finalize(ctx, rank));
@@ -1358,7 +1365,35 @@ PYBIND11_MODULE(_myfm, m) {
       .def("set_group_index", &ConfigBuilder::set_group_index)
       .def("set_identical_groups", &ConfigBuilder::set_identical_groups)
       .def("set_cutpoint_scale", &ConfigBuilder::set_cutpoint_scale)
-      .def("set_cutpoint_groups", &ConfigBuilder::set_cutpoint_groups)
+      .def("set_cutpoint_groups",
+           // [(n_class, row indices)]: the reference's list-of-lists (declare_module.hpp:139-156), and numpy index arrays
+           // without a per-element Python conversion (5e7 rows at config 5)
+           [](ConfigBuilder &b, const py::object &groups) -> ConfigBuilder & {
+             CutpointGroupType g;
+             for (auto item : groups) {
+               py::sequence t = py::reinterpret_borrow<py::sequence>(item);
+               if (py::len(t) != 2) throw std::invalid_argument("cutpoint group: (n_class, row indices) expected");
+               const size_t n_class = t[0].cast<size_t>();
+               py::object rows = t[1];
+               vector<size_t> v;
+               if (py::isinstance<py::array>(rows)) {
+                 auto a = py::array_t<int64_t, py::array::c_style | py::array::forcecast>::ensure(rows);
+                 if (!a) throw std::invalid_argument("cutpoint group: integer row indices expected");
+                 v.resize((size_t)a.size());
+                 const int64_t *p = a.data();
+                 for (size_t k = 0; k < v.size(); k++) {
+                   if (p[k] < 0) throw std::invalid_argument("cutpoint group: negative row index");
+                   v[k] = (size_t)p[k];
+                 }
+               } else {
+                 v = rows.cast<vector<size_t>>();
+               }
+               g.emplace_back(n_class, std::move(v));
+             }
+             b.cutpoint_groups = std::move(g);
+             return b;
+           },
+           py::return_value_policy::reference_internal)
       .def("build", &ConfigBuilder::build);
 
   py::class_<FM>(m, "FM")

@@ -367,6 +367,15 @@ struct DevBlock {
     X.upload(hX, &Xt);
     plan_V.build(Xt, PBlockV::R_W16, PBlockV::R_WG, coop_capacity<PBlockV>());
     plan_W.build(Xt, PBlockW::R_W16, PBlockW::R_WG, coop_capacity<PBlockW>());
+    // rows of a block row far apart in the table (lists longer than a workgroup handles at once) and a table that fits
+    // in LDS: the statistics pass streams the training rows (k_unsync_stream) and needs no inverse map. (A map that is
+    // sorted -- the block follows the table's row order -- has contiguous lists; those stay with the inverse-map kernels,
+    // which then stream as well.)
+    bool sorted = true;
+    for (int64_t t = 1; t < N && sorted; t++) sorted = hmap[t] >= hmap[t - 1];
+    stream_unsync = !sorted && B >= 1 && B <= UNSYNC_STREAM_MAX_B && N >= 64 * B && N >= ((int64_t)1 << 20) &&
+                    !std::getenv("MFM_NO_UNSYNC_STREAM");  // (short tables: too few workgroups to stream with)
+    if (const char *e = std::getenv("MFM_UNSYNC_STREAM_FORCE")) stream_unsync = std::atoi(e) != 0 && B >= 1 && B <= UNSYNC_STREAM_MAX_B;
     std::vector<int32_t> m32((size_t)N);
     std::vector<int64_t> iptr((size_t)B + 1, 0);
     for (int64_t t = 0; t < N; t++) {
@@ -378,14 +387,15 @@ struct DevBlock {
       hrec[(size_t)i * BLOCK_REC + 6] = (double)iptr[i + 1];  // cardinality, definitions.hpp:65-68
       iptr[i + 1] += iptr[i];
     }
-    std::vector<int32_t> irows((size_t)N);
-    {
+    std::vector<int32_t> irows;
+    if (!stream_unsync) {
+      irows.resize((size_t)N);
       std::vector<int64_t> cur(iptr.begin(), iptr.end() - 1);
       for (int64_t t = 0; t < N; t++) irows[cur[hmap[t]]++] = (int32_t)t;
     }
     std::vector<int32_t> bw, bg, bl_, cptr;
     std::vector<InvChunk> ch;
-    for (int64_t i = 0; i < B; i++) {
+    for (int64_t i = 0; i < B && !stream_unsync; i++) {
       int64_t len = iptr[i + 1] - iptr[i];
       if (len <= INV_WAVE_CAP)
         bw.push_back((int32_t)i);
@@ -417,14 +427,6 @@ struct DevBlock {
     bl.alloc_zero((size_t)B, s);
     bs.alloc_zero((size_t)B, s);
     comm_buf.alloc((size_t)std::max<int64_t>(B, 1) * 4);
-    // rows of a block row far apart in the table (lists longer than a workgroup handles at once) and a table that fits
-    // in LDS: stream. (A map that is sorted -- the block follows the table's row order -- has contiguous lists; those
-    // stay with the inverse-map kernels, which then stream as well.)
-    bool sorted = true;
-    for (int64_t t = 1; t < N && sorted; t++) sorted = hmap[t] >= hmap[t - 1];
-    stream_unsync = !sorted && B >= 1 && B <= UNSYNC_STREAM_MAX_B && N >= 64 * B && N >= ((int64_t)1 << 20) &&
-                    !std::getenv("MFM_NO_UNSYNC_STREAM");  // (short tables: too few workgroups to stream with)
-    if (const char *e = std::getenv("MFM_UNSYNC_STREAM_FORCE")) stream_unsync = std::atoi(e) != 0 && B >= 1 && B <= UNSYNC_STREAM_MAX_B;
     if (stream_unsync) {
       const int64_t step = (int64_t)WG * UNSYNC_R;
       const int64_t steps = (N + step - 1) / step;

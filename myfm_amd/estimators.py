@@ -232,7 +232,7 @@ class MyFMGibbsBase:
                     cuts = [(n * r) // world for r in range(world + 1)]
                 lo, hi = cuts[rank], cuts[rank + 1]
                 if self._task_type == TaskType.ORDERED:  # the cutpoint group lists LOCAL rows
-                    config_builder.set_cutpoint_groups([(int(np.asarray(y).max()) + 1, list(range(hi - lo)))])
+                    config_builder.set_cutpoint_groups([(int(np.asarray(y).max()) + 1, np.arange(hi - lo, dtype=np.int64))])
                     config = config_builder.build()
                 rel_l = [RelationBlock(r.original_to_block_array[lo:hi], r.data) for r in X_rel]
                 y_l = np.ascontiguousarray(np.asarray(y, dtype=REAL)[lo:hi])
@@ -401,7 +401,7 @@ class MyFMOrderedProbit(MyFMGibbsBase):
         builder = ConfigBuilder()
         y = np.asarray(y)
         n_class = int(y.max()) + 1
-        groups = [(n_class, list(range(y.shape[0])))]
+        groups = [(n_class, np.arange(y.shape[0], dtype=np.int64))]
         self.n_cutpoint_groups = len(groups)
         builder.set_cutpoint_groups(groups)
         self._fit(X, y, X_rel=X_rel, X_test=X_test, y_test=y_test, X_rel_test=X_rel_test, n_iter=n_iter,
