@@ -1,3 +1,4 @@
+#include <thread>
 #include <cstdio>
 // _myfm.cpp -- the drop-in boundary: a pybind11 module with the names and signatures of the
 // reference's `myfm._myfm` (cpp_source/declare_module.hpp:67-404, stubs src/myfm/_myfm.pyi), whose
@@ -1556,6 +1557,70 @@ PYBIND11_MODULE(_myfm, m) {
         py::arg("config"), py::arg("callback"), py::arg("shard_rank"), py::arg("shard_world"), py::arg("n_total_rows"),
         py::arg("row_offset"), py::arg("main_levels"), py::arg("comm_id") = py::bytes(""), py::arg("allreduce") = py::none(),
         py::arg("stream") = 0, py::return_value_policy::move);
+  // fit()'s row sort without numpy's argsort + fancy indexing (6 s for 1e7 shuffled rows): a stable counting
+  // sort of the rows by their first stored column, and a threaded gather of the CSR rows in that order
+  m.def("row_order_by_first_column",
+        [](py::array_t<int64_t, py::array::c_style | py::array::forcecast> indptr,
+           py::array_t<int32_t, py::array::c_style | py::array::forcecast> indices, int64_t n_cols) {
+          const int64_t n = (int64_t)indptr.size() - 1;
+          const int64_t *ip = indptr.data();
+          const int32_t *ix = indices.data();
+          py::array_t<int64_t> order((size_t)std::max<int64_t>(n, 0));
+          int64_t *o = order.mutable_data();
+          vector<int64_t> cnt((size_t)n_cols + 1, 0);
+          for (int64_t t = 0; t < n; t++) {
+            if (ip[t + 1] <= ip[t]) throw std::invalid_argument("row_order_by_first_column: a row has no stored entry");
+            const int32_t j = ix[ip[t]];
+            if (j < 0 || j >= n_cols) throw std::invalid_argument("row_order_by_first_column: column index out of range");
+            cnt[(size_t)j + 1]++;
+          }
+          for (int64_t j = 0; j < n_cols; j++) cnt[j + 1] += cnt[j];
+          for (int64_t t = 0; t < n; t++) o[cnt[ix[ip[t]]]++] = t;
+          return order;
+        },
+        py::arg("indptr"), py::arg("indices"), py::arg("n_cols"));
+  m.def("permute_csr_rows",
+        [](py::array_t<int64_t, py::array::c_style | py::array::forcecast> indptr,
+           py::array_t<int32_t, py::array::c_style | py::array::forcecast> indices,
+           py::array_t<double, py::array::c_style | py::array::forcecast> data,
+           py::array_t<int64_t, py::array::c_style | py::array::forcecast> order) {
+          const int64_t n = (int64_t)order.size();
+          const int64_t *ip = indptr.data(), *od = order.data();
+          const int32_t *ix = indices.data();
+          const double *dv = data.data();
+          const int64_t n_src = (int64_t)indptr.size() - 1;
+          py::array_t<int64_t> nptr((size_t)n + 1);
+          int64_t *np_ = nptr.mutable_data();
+          np_[0] = 0;
+          for (int64_t t = 0; t < n; t++) {
+            if (od[t] < 0 || od[t] >= n_src) throw std::invalid_argument("permute_csr_rows: row index out of range");
+            np_[t + 1] = np_[t] + (ip[od[t] + 1] - ip[od[t]]);
+          }
+          py::array_t<int32_t> nidx((size_t)np_[n]);
+          py::array_t<double> nval((size_t)np_[n]);
+          int32_t *ni = nidx.mutable_data();
+          double *nv = nval.mutable_data();
+          const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+          const int64_t chunk = (n + hw - 1) / hw;
+          {
+            py::gil_scoped_release rel;
+            vector<std::thread> th;
+            for (unsigned k = 0; k < hw; k++)
+              th.emplace_back([=]() {
+                const int64_t b = (int64_t)k * chunk, e = std::min<int64_t>(n, b + chunk);
+                for (int64_t t = b; t < e; t++) {
+                  const int64_t s0 = ip[od[t]], len = ip[od[t] + 1] - s0, d0 = np_[t];
+                  for (int64_t q = 0; q < len; q++) {
+                    ni[d0 + q] = ix[s0 + q];
+                    nv[d0 + q] = dv[s0 + q];
+                  }
+                }
+              });
+            for (auto &t : th) t.join();
+          }
+          return py::make_tuple(nptr, nidx, nval);
+        },
+        py::arg("indptr"), py::arg("indices"), py::arg("data"), py::arg("order"));
   m.def("comm_unique_id", []() {
     char id[128];
     if (mfm_comm_unique_id(id) != MFM_OK) throw std::runtime_error(mfm_global_error());

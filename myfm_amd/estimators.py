@@ -201,7 +201,8 @@ class MyFMGibbsBase:
         # arrive in another order are sorted by the first stored column here, together with y and the relation maps.
         perm = _device_row_order(X)
         if perm is not None:
-            X = X[perm]
+            ptr, idx, val = _myfm.permute_csr_rows(X.indptr, X.indices, X.data, perm)
+            X = sps.csr_matrix((val, idx, ptr), shape=X.shape)
             y = np.asarray(y)[perm]
             X_rel = [RelationBlock(r.original_to_block_array[perm], r.data) for r in X_rel]
         config_builder.set_task_type(self._task_type)
@@ -383,7 +384,7 @@ def _device_row_order(X):
     first = X.indices[X.indptr[:-1]]
     if np.all(first[1:] >= first[:-1]):
         return None
-    return np.argsort(first, kind="stable")
+    return _myfm.row_order_by_first_column(X.indptr, X.indices, X.shape[1])  # (stable counting sort)
 
 
 class MyFMOrderedProbit(MyFMGibbsBase):
