@@ -1,21 +1,19 @@
+"""Iteration rate of the three task types at the config-3 shape through the estimators (fit(3 n) - fit(n)) / 2 n."""
 import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-sys.path.insert(0, os.getcwd())
-from myfm_amd import _myfm
 from tests import datasets as ds
-X, y, shapes = ds.movielens_like(10_000_000, 69878, 10677, rank_true=32, seed=1)
-gi = ds.group_index_from_shapes(shapes)
-for task, yy in (("CLASSIFICATION", (y > 3.5).astype(np.float64)), ("ORDERED", np.clip(np.floor(y) - 1, 0, 4))):
-    b = _myfm.ConfigBuilder()
-    b.set_alpha_0(1.0).set_beta_0(1.0).set_gamma_0(1.0).set_mu_0(0.0).set_reg_0(1.0)
-    b.set_group_index([int(g) for g in gi]).set_n_iter(40).set_n_kept_samples(0).set_task_type(getattr(_myfm.TaskType, task))
-    if task == "ORDERED":
-        b.set_cutpoint_groups([(5, list(range(X.shape[0])))])
-    s = _myfm.GibbsSession(32, 0.1, X, [], yy, 42, b.build())
-    for _ in range(3): s.step()
-    s.synchronize(); s.timing_enable(True); s.timing_reset()
-    t0 = time.perf_counter()
-    for _ in range(10): s.step()
-    s.synchronize(); el = time.perf_counter() - t0
-    tm = s.timing()
-    print(task, "%.1f it/s (%.2f ms)" % (10 / el, el / 10 * 1e3), {k: round(v[0] / 10, 3) for k, v in sorted(tm.items(), key=lambda kv: -kv[1][0])[:6]}, flush=True)
+import myfm_amd
+
+X, y, shapes = ds.movielens_like(10_000_000, 69878, 10677)
+yc = (y > 3.5)
+yo = np.clip(np.round(y), 1, 5).astype(np.int64) - 1
+myfm_amd.MyFMRegressor(32).fit(X, y, group_shapes=shapes, n_iter=3, n_kept_samples=1)  # warm-up (module load, jump polynomials)
+for name, est, yy in (("regression", myfm_amd.MyFMRegressor, y), ("classification", myfm_amd.MyFMClassifier, yc),
+                      ("ordered probit", myfm_amd.MyFMOrderedProbit, yo)):
+    ts = []
+    for n in (10, 30):
+        t = time.time()
+        est(32).fit(X, yy, group_shapes=shapes, n_iter=n, n_kept_samples=1)
+        ts.append(time.time() - t)
+    print("%-16s %.1f it/s  (fit(10) %.2f s, fit(30) %.2f s)" % (name, 20 / (ts[1] - ts[0]), ts[0], ts[1]))
