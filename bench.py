@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=-1, help="(compat) 0 disables the CPU baseline")
     ap.add_argument("--fit-iters", type=int, default=30, help="iterations of the MyFM*.fit() leg (0 disables)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--weak-steps", type=int, default=20, help="N > 1: timed iterations of the weak-scaling leg (0 disables)")
     a = ap.parse_args()
     if a.cpu_iters == 0:
         a.cpu_seconds = 0.0
@@ -228,7 +229,10 @@ def main():
             dom_name = max(breakdown.items(), key=lambda kv: kv[1][0])[0]
     for _ in range(a.warmup):
         sess.step()
-    if dom_name:
+    # (several ranks: no events inside the timed region -- the dominant class then contains the collective, and its figures come
+    # from the diagnostic steps above)
+    live_timing = bool(dom_name) and world == 1
+    if live_timing:
         sess.timing_select(dom_name)
         sess.timing_enable(True)
         sess.timing_reset()
@@ -243,8 +247,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    timing = dict(sess.timing()) if dom_name else {}
-    if dom_name:
+    timing = dict(sess.timing()) if live_timing else ({dom_name: breakdown[dom_name]} if dom_name else {})
+    if live_timing:
         sess.timing_enable(False)
         sess.timing_select("")
     calls = (sess.comm_stats()[0] - calls0) if sharded else 0
@@ -260,6 +264,53 @@ def main():
         dist.all_gather(allv, mine)
         for v in allv[1:]:
             assert torch.allclose(v, allv[0], rtol=1e-12, atol=0), ("replicas diverged", [x.tolist() for x in allv])
+
+    plan_flags = int(sess.plan_flags())
+    # Weak-scaling leg (N > 1, config 3): the table grows with the GPUs -- rank r holds ~a.rows rows of ONE user-sorted table of
+    # world * a.rows rows over the same users / items (tests/datasets.py::movielens_like_shard). Reported as an extra field;
+    # `value` stays the strong-scaling rate of config 3 itself.
+    weak = None
+    if sharded and a.config == 3 and a.weak_steps > 0 and not blocks:
+        del sess
+        Xw, yw, shw, lo_w, total_w = ds.movielens_like_shard(a.rows, rank, world, a.users, a.items)
+        levels_w = np.concatenate([np.zeros(a.users, np.int32), np.ones(a.items, np.int32)])
+        gi_w = ds.group_index_from_shapes(shw)
+        cfg_w = make_config(_myfm, gi_w, a.weak_steps + 8, 0, "regression", Xw.shape[0])
+        if os.environ.get("MYFM_BENCH_TORCH_ALLREDUCE") or "torch.distributed" in how:
+            ar_w = mdist.TorchAllReduce()
+            sw = _myfm.GibbsSession(K, 0.1, Xw, [], yw, 42, cfg_w, allreduce=ar_w, n_total_rows=total_w, row_offset=lo_w,
+                                    stream=ar_w.stream_ptr, main_levels=levels_w, shard_rank=rank, shard_world=world)
+        else:
+            sw = _myfm.GibbsSession(K, 0.1, Xw, [], yw, 42, cfg_w, n_total_rows=total_w, row_offset=lo_w, main_levels=levels_w,
+                                    comm_id=mdist.native_comm_id(), shard_rank=rank, shard_world=world)
+        for _ in range(3):
+            sw.step()
+        sw.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.weak_steps):
+            sw.step()
+        sw.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        tw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        tw = float(tw.item())
+        if world > 1:  # the replicated model is identical on every rank here too
+            fw = sw.fm
+            mine = torch.tensor([float(fw.w0), float(sw.hyper.alpha), float(np.abs(np.asarray(fw.V)).sum()), float(np.asarray(fw.w).sum())],
+                                dtype=torch.float64, device="cuda")
+            allv = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allv, mine)
+            for v in allv[1:]:
+                assert torch.allclose(v, allv[0], rtol=1e-12, atol=0), ("weak-scaling replicas diverged", [x.tolist() for x in allv])
+        weak = {"rows_total": int(total_w), "rows_per_gpu": int(a.rows), "steps": a.weak_steps, "it_per_s": round(a.weak_steps / tw, 3),
+                "allreduce_calls_per_step": round(sw.comm_stats()[0] / (a.weak_steps + 3), 1),
+                "ms_per_step": round(tw / a.weak_steps * 1e3, 3), "row_iterations_per_s": round(total_w * a.weak_steps / tw),
+                "note": "ONE chain over a user-sorted table of world x rows_per_gpu rows (same users / items), every rank holds a "
+                        "contiguous range of users; timing as for `value` (barrier + synchronize, max over ranks)"}
+        del sw
 
     if rank != 0:
         if dist is not None:
@@ -312,7 +363,6 @@ def main():
                         "iteration) divided by measured time: 'bytes the fusion avoids', not achieved bandwidth",
             }
 
-    plan_flags = int(sess.plan_flags())
     # ---- the path users call: MyFM*.fit() (create_train_fm: retention of the last n_kept samples + callback per iteration)
     fit = None
     if a.fit_iters > 0 and world == 1 and a.config in (2, 3, 4):
@@ -369,6 +419,8 @@ def main():
     }
     if cpu and cpu.get("value"):
         out["speedup_vs_cpu_baseline"] = round(it_per_s / cpu["value"], 1)
+    if weak:
+        out["weak_scaling"] = weak
     if sharded:
         out["config"]["allreduce_calls_per_step"] = round(calls / a.steps, 1)
         out["config"]["rows_this_rank"] = hi - lo
