@@ -2165,6 +2165,11 @@ __global__ __launch_bounds__(CHAINB_NT) void k_chain_batched(SweepArgs a, const 
   }
 }
 
+__global__ void k_gather_i32(const int32_t *__restrict__ src, const int32_t *__restrict__ idx, int n, int32_t *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = src[idx[i]];
+}
+
 // ---- the same batches, cold parts on the WHOLE GPU ------------------------------------------------------------------
 // When a batch's cold entries number in the tens of thousands (relation blocks with 10^5..10^6 rows: config 5) one
 // workgroup streaming them through a single CU is the bottleneck (~25 GB/s). Phases A and C touch every row at most once
@@ -2176,11 +2181,22 @@ template <class P>
 __global__ __launch_bounds__(CHAINB_NT) void k_cb_stats(SweepArgs a, ChainBatch B, const int32_t *__restrict__ cols,
                                                         const int32_t *__restrict__ cold_ptr, const int32_t *__restrict__ cold_row,
                                                         const int32_t *__restrict__ cold_lcol, const double *__restrict__ cold_x,
-                                                        double2 *__restrict__ part_g /* [gridDim.x][CHAINB_MAXCOLS] */) {
+                                                        double2 *__restrict__ part_g /* [gridDim.x][CHAINB_MAXCOLS] */,
+                                                        const int32_t *__restrict__ hot_rows, double2 *__restrict__ hot_pack) {
   constexpr int NT = CHAINB_NT, NW = NT / WAVE, MC = CHAINB_MAXCOLS, U = 4;
   __shared__ double c_old[MC];
   __shared__ double2 part[MC * NW];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  {
+    // the batch's hot records, gathered by the whole grid into a packed buffer: k_cb_hot then stages them with ONE coalesced
+    // round trip instead of a dependent pair (row list -> records) on a single workgroup
+    constexpr int rec2_g = P::REC_DOUBLES / 2;
+    const int rec2_global = P::REC_DOUBLES > 2 ? a.rec2 : 1;
+    for (int i = (int)blockIdx.x * NT + tid; i < B.n_hot * rec2_g; i += (int)gridDim.x * NT) {
+      const int slot = i / rec2_g, w = i - slot * rec2_g;
+      hot_pack[i] = ((const double2 *)a.state)[(int64_t)hot_rows[B.hot_row0 + slot] * rec2_global + w];
+    }
+  }
   if (tid < B.ncols) c_old[tid] = a.theta[cols[B.col0 + tid]];
   for (int i = tid; i < MC * NW; i += NT) part[i] = make_double2(0.0, 0.0);
   __syncthreads();
@@ -2235,8 +2251,9 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_stats(SweepArgs a, ChainBatch 
 template <class P>
 __global__ __launch_bounds__(CHAINB_NT) void k_cb_hot(SweepArgs a, ChainBatch B, const int32_t *__restrict__ cols,
                                                       const int32_t *__restrict__ hot_ptr, const int32_t *__restrict__ hot_slot,
-                                                      const double *__restrict__ hot_x, const int32_t *__restrict__ hot_rows,
-                                                      int max_hot, int max_hot_ent, const double2 *__restrict__ part_g, int n_part,
+                                                      const double *__restrict__ hot_x, double2 *__restrict__ hot_pack,
+                                                      const int32_t *__restrict__ col_group, int max_hot, int max_hot_ent,
+                                                      const double2 *__restrict__ part_g, int n_part,
                                                       double2 *__restrict__ oldnew_g /* [CHAINB_MAXCOLS] */) {
   extern __shared__ double2 lds_hot[];
   constexpr int NT = CHAINB_NT, MC = CHAINB_MAXCOLS;
@@ -2252,10 +2269,17 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_hot(SweepArgs a, ChainBatch B,
   SweepArgs al = a;
   al.state = lds_hot;
   al.rec2 = rec2_l;
-  const int rec2_global = P::REC_DOUBLES > 2 ? a.rec2 : 1;
+  if (tid < B.ncols) {  // (first: the longest dependent chain of the prologue, column -> coefficient / variate, group -> lambda / mu)
+    const int j = cols[B.col0 + tid];
+    const int g = col_group[B.col0 + tid];
+    c_old[tid] = a.theta[j];
+    c_z[tid] = a.z[j];
+    c_lam[tid] = a.lambda[g];
+    c_mu[tid] = a.mu[g];
+  }
   for (int i = tid; i < B.n_hot * rec2_g; i += NT) {
     const int slot = i / rec2_g, w = i - slot * rec2_g;
-    lds_hot[(size_t)slot * rec2_l + w] = ((const double2 *)a.state)[(int64_t)hot_rows[B.hot_row0 + slot] * rec2_global + w];
+    lds_hot[(size_t)slot * rec2_l + w] = hot_pack[i];  // (packed by k_cb_stats)
   }
   const int hb0 = hot_ptr[B.col0], hb1 = hot_ptr[B.col0 + B.ncols];
   for (int i = tid; i < hb1 - hb0; i += NT) {
@@ -2264,17 +2288,16 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_hot(SweepArgs a, ChainBatch B,
   }
   if (tid <= B.ncols) h_ptr[tid] = hot_ptr[B.col0 + tid] - hb0;
   if (tid < B.ncols) {
-    const int j = cols[B.col0 + tid];
-    c_old[tid] = a.theta[j];
-    c_z[tid] = a.z[j];
-    const int g = a.group[j];
-    c_lam[tid] = a.lambda[g];
-    c_mu[tid] = a.mu[g];
     double S1 = 0.0, S2 = 0.0;
-    for (int w = 0; w < n_part; w++) {  // workgroup order: deterministic
-      const double2 q = part_g[(size_t)w * MC + tid];
-      S1 += q.x;
-      S2 += q.y;
+    for (int w0 = 0; w0 < n_part; w0 += 8) {  // workgroup order: deterministic (eight loads in flight)
+      double2 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) q[u] = w0 + u < n_part ? part_g[(size_t)(w0 + u) * MC + tid] : make_double2(0.0, 0.0);
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        S1 += q[u].x;
+        S2 += q[u].y;
+      }
     }
     csum[tid] = make_double2(S1, S2);
   }
@@ -2292,7 +2315,7 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_hot(SweepArgs a, ChainBatch B,
   __syncthreads();
   for (int i = tid; i < B.n_hot * rec2_g; i += NT) {
     const int slot = i / rec2_g, w = i - slot * rec2_g;
-    ((double2 *)a.state)[(int64_t)hot_rows[B.hot_row0 + slot] * rec2_global + w] = lds_hot[(size_t)slot * rec2_l + w];
+    hot_pack[i] = lds_hot[(size_t)slot * rec2_l + w];  // (k_cb_apply scatters them to their rows)
   }
   if (tid < B.ncols) {
     a.theta[cols[B.col0 + tid]] = c_new[tid];
@@ -2303,10 +2326,19 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_hot(SweepArgs a, ChainBatch B,
 template <class P>
 __global__ __launch_bounds__(CHAINB_NT) void k_cb_apply(SweepArgs a, ChainBatch B, const int32_t *__restrict__ cold_ptr,
                                                         const int32_t *__restrict__ cold_row, const int32_t *__restrict__ cold_lcol,
-                                                        const double *__restrict__ cold_x, const double2 *__restrict__ oldnew_g) {
+                                                        const double *__restrict__ cold_x, const double2 *__restrict__ oldnew_g,
+                                                        const int32_t *__restrict__ hot_rows, const double2 *__restrict__ hot_pack) {
   constexpr int NT = CHAINB_NT, MC = CHAINB_MAXCOLS, U = 4;
   __shared__ double2 on[MC];
   const int tid = threadIdx.x;
+  {
+    constexpr int rec2_g = P::REC_DOUBLES / 2;
+    const int rec2_global = P::REC_DOUBLES > 2 ? a.rec2 : 1;
+    for (int i = (int)blockIdx.x * NT + tid; i < B.n_hot * rec2_g; i += (int)gridDim.x * NT) {
+      const int slot = i / rec2_g, w = i - slot * rec2_g;
+      ((double2 *)a.state)[(int64_t)hot_rows[B.hot_row0 + slot] * rec2_global + w] = hot_pack[i];
+    }
+  }
   if (tid < B.ncols) on[tid] = oldnew_g[tid];
   __syncthreads();
   const int cb = cold_ptr[B.col0], ce = cold_ptr[B.col0 + B.ncols];

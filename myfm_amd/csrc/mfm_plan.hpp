@@ -119,6 +119,8 @@ struct ChainRun {
   int64_t n_cold = 0;
   DevBuf<int32_t> cold_ptr, cold_row, cold_lcol, hot_ptr, hot_slot, hot_rows;
   DevBuf<double> cold_x, hot_x;
+  mutable DevBuf<int32_t> col_group;             // group index of every chain column (filled at the first launch)
+  mutable const int32_t *col_group_of = nullptr;  // ... from this group array
 
   void build_batched(const HostCsr &csc, const std::vector<int32_t> &run, int hot_cap) {
     const int64_t n_rows = csc.cols;
@@ -1132,6 +1134,7 @@ struct LongScratch {
   DevBuf<double> told_col;     // multi-level fused flow: current coefficient per column of the level whose statistics are taken
   std::vector<DevBuf<double>> vnext_lvl;  // ... and per tile level: next factor's coefficient per column (MULTIQ)
   DevBuf<double2> cb_part, cb_oldnew;  // grid-batched chains: per-workgroup column partials, (old, new) per column of a batch
+  DevBuf<double2> cb_hot;              // ... and the batch's hot records, packed (k_cb_stats -> k_cb_hot -> k_cb_apply)
   DevBuf<double2> dv_col;      // two-field pass: (delta of this factor, coefficient of the next) per second-level column
   void reserve_cols(int64_t n_cols) {
     if ((size_t)n_cols > oldnew_col.n) {
@@ -1251,6 +1254,13 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
           constexpr int GMAX = 64;  // workgroups of a cold launch
           if (ls.cb_part.n < (size_t)GMAX * CHAINB_MAXCOLS) ls.cb_part.alloc((size_t)GMAX * CHAINB_MAXCOLS);
           if (ls.cb_oldnew.n < (size_t)CHAINB_MAXCOLS) ls.cb_oldnew.alloc((size_t)CHAINB_MAXCOLS);
+          const size_t hot16 = (size_t)std::max(C.max_hot, 1) * (P::REC_DOUBLES / 2);
+          if (ls.cb_hot.n < hot16) ls.cb_hot.alloc(hot16);
+          if (C.col_group.n < (size_t)C.n_cols || C.col_group_of != a.group) {  // group index per chain column (gathered once)
+            C.col_group.alloc((size_t)std::max(C.n_cols, 1));
+            hipLaunchKernelGGL(k_gather_i32, dim3((C.n_cols + 255) / 256), dim3(256), 0, s, a.group, C.cols.p, C.n_cols, C.col_group.p);
+            C.col_group_of = a.group;
+          }
           const size_t lds_h = (size_t)std::max(C.max_hot, 1) * rec2_l * sizeof(double2) + 5 * CHAINB_MAXCOLS * sizeof(double) +
                                (size_t)CHAINB_MAXCOLS * sizeof(double2) + (size_t)mhe * 12 + (CHAINB_MAXCOLS + 2) * sizeof(int);
           for (int bi = 0; bi < C.n_batches; bi++) {
@@ -1258,12 +1268,12 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
             const int ncold = C.h_cold_cnt[bi];
             const int g = std::max(1, std::min(GMAX, (ncold + CHAINB_NT * 4 - 1) / (CHAINB_NT * 4)));
             hipLaunchKernelGGL((k_cb_stats<P>), dim3(g), dim3(CHAINB_NT), 0, s, a, B, C.cols.p, C.cold_ptr.p, C.cold_row.p,
-                               C.cold_lcol.p, C.cold_x.p, ls.cb_part.p);
+                               C.cold_lcol.p, C.cold_x.p, ls.cb_part.p, C.hot_rows.p, ls.cb_hot.p);
             hipLaunchKernelGGL((k_cb_hot<P>), dim3(1), dim3(CHAINB_NT), lds_h, s, a, B, C.cols.p, C.hot_ptr.p, C.hot_slot.p,
-                               C.hot_x.p, C.hot_rows.p, std::max(C.max_hot, 1), mhe, ls.cb_part.p, g, ls.cb_oldnew.p);
-            if (ncold)
+                               C.hot_x.p, ls.cb_hot.p, C.col_group.p, std::max(C.max_hot, 1), mhe, ls.cb_part.p, g, ls.cb_oldnew.p);
+            if (ncold || B.n_hot)
               hipLaunchKernelGGL((k_cb_apply<P>), dim3(g), dim3(CHAINB_NT), 0, s, a, B, C.cold_ptr.p, C.cold_row.p,
-                                 C.cold_lcol.p, C.cold_x.p, ls.cb_oldnew.p);
+                                 C.cold_lcol.p, C.cold_x.p, ls.cb_oldnew.p, C.hot_rows.p, ls.cb_hot.p);
           }
           continue;
         }
