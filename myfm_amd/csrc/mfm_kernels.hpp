@@ -1970,6 +1970,8 @@ __global__ __launch_bounds__(WAVE) void k_chain_lds(SweepArgs a, const ChainDesc
 struct ChainBatch {
   int32_t col0, ncols;      // columns [col0, col0 + ncols) of the run
   int32_t hot_row0, n_hot;  // hot rows: hot_rows[hot_row0 ..)
+  int32_t cold_b, cold_e;   // cold entries [cold_ptr[col0], cold_ptr[col0 + ncols])  (copies: one dependent load less per launch)
+  int32_t hot_b, hot_e;     // hot entries  [hot_ptr[col0], hot_ptr[col0 + ncols])
 };
 constexpr int CHAINB_NT = 512;
 constexpr int CHAINB_MAXCOLS = 64;
@@ -2200,7 +2202,7 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_stats(SweepArgs a, ChainBatch 
   if (tid < B.ncols) c_old[tid] = a.theta[cols[B.col0 + tid]];
   for (int i = tid; i < MC * NW; i += NT) part[i] = make_double2(0.0, 0.0);
   __syncthreads();
-  const int cb = cold_ptr[B.col0], ce = cold_ptr[B.col0 + B.ncols];
+  const int cb = B.cold_b, ce = B.cold_e;
   for (int base = cb + ((int)blockIdx.x * NW + wv) * WAVE * U; base < ce; base += (int)gridDim.x * NW * WAVE * U) {
     int lc[U], row[U];
     double xv[U];
@@ -2281,7 +2283,7 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_hot(SweepArgs a, ChainBatch B,
     const int slot = i / rec2_g, w = i - slot * rec2_g;
     lds_hot[(size_t)slot * rec2_l + w] = hot_pack[i];  // (packed by k_cb_stats)
   }
-  const int hb0 = hot_ptr[B.col0], hb1 = hot_ptr[B.col0 + B.ncols];
+  const int hb0 = B.hot_b, hb1 = B.hot_e;
   for (int i = tid; i < hb1 - hb0; i += NT) {
     h_x[i] = hot_x[hb0 + i];
     h_slot[i] = hot_slot[hb0 + i];
@@ -2341,7 +2343,7 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_apply(SweepArgs a, ChainBatch 
   }
   if (tid < B.ncols) on[tid] = oldnew_g[tid];
   __syncthreads();
-  const int cb = cold_ptr[B.col0], ce = cold_ptr[B.col0 + B.ncols];
+  const int cb = B.cold_b, ce = B.cold_e;
   for (int base = cb + (int)blockIdx.x * NT * U + tid; base < ce; base += (int)gridDim.x * NT * U) {
     int lc[U], row[U];
     double xv[U];

@@ -182,6 +182,10 @@ struct ChainRun {
         cptr.push_back((int32_t)crow.size());
         hptr.push_back((int32_t)hslot.size());
       }
+      B.cold_e = (int32_t)crow.size();
+      B.hot_e = (int32_t)hslot.size();
+      B.cold_b = cptr[c];
+      B.hot_b = hptr[c];
       for (int32_t r : touched) {
         cnt[r] = 0;
         slot_of[r] = -1;
