@@ -99,10 +99,9 @@ __device__ __forceinline__ void mf_run_structure(const uint32_t (&u)[K], const i
     const bool head = lane == 0 || cp != c;
     const bool tail = lane == 63 || cn != c;
     const unsigned long long hb = __ballot(head);
-    // slot_pos == null: slots in stream ("tile-major") order -- a wave's stores are contiguous, whole lines
     if (valid && tail) {
       const int run = rb[k] + __popcll(hb & ((2ull << lane) - 1ull)) - 1;
-      pos[k] = slot_pos ? slot_pos[run] : run;
+      pos[k] = slot_pos[run];
     }
     flags[k] = (head ? 1u : 0u) | (valid && tail ? 2u : 0u);
   }
@@ -418,30 +417,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4))) vo
     wave_segscan2(s1, s2, f);
     if (flags[k] & 2u) a.slots[pos[k]] = make_double2(s1, s2);
   }
-}
-
-// The statistics slots arrive in stream order (tile after tile, columns ascending inside a tile). Transpose-reduce: lane q
-// takes the q-th slot in COLUMN-major order (inv[q]: its stream index, bit 31 = first slot of a column; a random 16-byte read
-// of a buffer the pass has just written), a wave-level segmented scan sums each column's stretch, one partial per
-// (column, wavefront) goes to gp[] -- whose per-column ranges k_mf_draw then sums exactly like slot ranges.
-__global__ __launch_bounds__(WG) void k_mf_gather_reduce(const uint32_t *__restrict__ inv, int n_slots,
-                                                         const int32_t *__restrict__ wbase, const double2 *__restrict__ slots,
-                                                         double2 *__restrict__ gp) {
-  const int q = blockIdx.x * WG + threadIdx.x, lane = threadIdx.x & 63;
-  const bool valid = q < n_slots;
-  const uint32_t v = valid ? inv[q] : 0x80000000u;
-  int f = (int)(v >> 31) | (lane == 0 ? 1 : 0);
-  const int head = f;
-  double s1 = 0.0, s2 = 0.0;
-  if (valid) {
-    const double2 s = slots[v & 0x7fffffffu];
-    s1 = s.x;
-    s2 = s.y;
-  }
-  const int nh = dpp_i32<0x130, 0xf>(head, 1);  // wave_shl:1 (lane 63 reads the fill: a head follows)
-  const unsigned long long hb = __ballot(head != 0);
-  wave_segscan2(s1, s2, f);
-  if (valid && (lane == 63 || nh)) gp[wbase[q >> 6] + __popcll(hb & ((2ull << lane) - 1ull)) - 1] = make_double2(s1, s2);
 }
 
 // item level: a wavefront per column sums the column's slots (contiguous, fixed order), draws (FMTrainer.hpp:357-369) and

@@ -68,11 +68,6 @@ struct ParLevel {
   DevBuf<uint32_t> tent;      // padded per tile to whole 64-entry wave tiles
   DevBuf<int32_t> tile_ptr;   // [n_tiles + 1], in wave tiles
   DevBuf<int32_t> tile_row0;  // [n_tiles + 1] first row of every tile (fixed 2^tile_bits grid, or StepPlan::h_tile_start)
-  // transpose-reduce of stream-ordered slots (k_mf_gather_reduce): column-major list of stream indices (bit 31: first of
-  // its column), first partial of every wavefront, partial range per column, the partials
-  DevBuf<uint32_t> g_inv;
-  DevBuf<int32_t> g_wbase, g_ptr;
-  DevBuf<double2> g_part;
   bool covers_rows_once = false;  // every row of the table has exactly one entry in this level
   bool first_and_once = false;    // ... and it is the first step of the plan: the level can rebuild q itself
   bool contig = false;            // every column of the level covers a contiguous row range (StepPlan::col_row0)
@@ -97,10 +92,6 @@ struct ParLevel {
     slot_ptr.borrow(o.slot_ptr);
     slot_pos.borrow(o.slot_pos);
     slots.borrow(o.slots);
-    g_inv.borrow(o.g_inv);
-    g_wbase.borrow(o.g_wbase);
-    g_ptr.borrow(o.g_ptr);
-    g_part.borrow(o.g_part);
   }
 };
 
@@ -371,7 +362,7 @@ struct StepPlan {
       if (2 * lnnz < N || (int64_t)cols.size() >= ((int64_t)1 << (32 - tile_bits)) - 1) tile_bits = 0;
     }
     if (tile_bits > 0) {
-      if (dev && dev->colptr && !std::getenv("MFM_HOST_TILE_PACK") && !std::getenv("MFM_MF_STREAM_SLOTS") &&
+      if (dev && dev->colptr && !std::getenv("MFM_HOST_TILE_PACK") &&
           build_tiled_device(*dev, csc, cols, lnnz, unit, L, tile_bits, bounds)) {
         if (std::getenv("MFM_PLAN_CHECK")) {  // tests: the device layout must be the host layout, array by array
           ParLevel H;
@@ -686,30 +677,6 @@ struct StepPlan {
     }
     L.slots.alloc((size_t)std::max<size_t>(run_col.size(), 1));
     MFM_HIP_CHECK(hipMemset(L.slots.p, 0, std::max<size_t>(run_col.size(), 1) * sizeof(double2)));
-    if (std::getenv("MFM_MF_STREAM_SLOTS")) {  // (transpose-reduce tables of the stream-ordered slot experiment)
-      const size_t ns = sidx.size(), nwv = (ns + WAVE - 1) / WAVE;
-      std::vector<uint32_t> inv(ns);
-      std::vector<int32_t> wbase(nwv + 1, 0), gptr(cols.size() + 1, 0);
-      size_t c = 0;
-      int32_t seg = 0;
-      for (size_t q = 0; q < ns; q++) {
-        while (c < cols.size() && (size_t)sptr[c + 1] <= q) c++;  // column of position q
-        const bool first = (size_t)sptr[c] == q;
-        inv[q] = (uint32_t)sidx[q] | (first ? 0x80000000u : 0u);
-        if (q % WAVE == 0) wbase[q / WAVE] = seg;
-        if (first || q % WAVE == 0) seg++;
-        if (first) gptr[c] = seg - 1;
-      }
-      // columns without any slot: empty ranges
-      wbase[nwv] = seg;
-      gptr[cols.size()] = seg;
-      for (size_t k = cols.size(); k-- > 0;)
-        if (sptr[k + 1] == sptr[k]) gptr[k] = gptr[k + 1];
-      L.g_inv.upload(inv);
-      L.g_wbase.upload(wbase);
-      L.g_ptr.upload(gptr);
-      L.g_part.alloc((size_t)std::max<int32_t>(seg, 1));
-    }
     return true;
   }
 
@@ -1883,11 +1850,7 @@ static void run_sweep_mf(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf
   m.cval = a0.val;
   m.col_row0 = plan.col_row0.p;
   m.run_base = L.run_base.p;
-  // MFM_MF_STREAM_SLOTS=1: slots in stream order (whole-line stores) + a transpose-reduce before the draw. Measured at
-  // config 3: the pass 116 -> 100 us, but the 4.6 M random 16-byte reads of the transpose cost 59 us (the column-major
-  // scatter costs ~28 us on the store side): random 16-byte accesses run at ~80 G/s chip-wide either way. Default off.
-  const bool stream_slots = std::getenv("MFM_MF_STREAM_SLOTS") != nullptr && !(comm && comm->active());
-  m.slot_pos = stream_slots ? nullptr : L.slot_pos.p;
+  m.slot_pos = L.slot_pos.p;
   m.slots = L.slots.p;
   m.solo_col = plan.n_long_cols ? plan.solo_col.p : nullptr;
   m.long_partial = plan.long_partial.p;
@@ -1941,16 +1904,11 @@ static void run_sweep_mf(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf
     SweepArgs an;
     if (more) an = args(f + 1);
     {
-      TimedLaunch t(tm, s, kc.scat, (stream_slots ? 20.0 : 16.0) * L.n_runs + 56.0 * L.n_cols);
+      TimedLaunch t(tm, s, kc.scat, 16.0 * L.n_runs + 56.0 * L.n_cols);
       if (comm && comm->active()) {
         hipLaunchKernelGGL(k_tile_sum, dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, L.n_cols, L.slot_ptr.p, L.slots.p, ls.S_col.p);
         comm->allreduce(ls.S_col.p, 2 * (int64_t)L.n_cols);
         hipLaunchKernelGGL(k_mf_draw_S, dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a, L.scols.p, L.n_cols, ls.S_col.p,
-                           more ? an.theta : (const double *)nullptr, ls.dv_col.p);
-      } else if (stream_slots) {
-        hipLaunchKernelGGL(k_mf_gather_reduce, dim3((L.n_runs + WG - 1) / WG), dim3(WG), 0, s, L.g_inv.p, L.n_runs, L.g_wbase.p,
-                           L.slots.p, L.g_part.p);
-        hipLaunchKernelGGL(k_mf_draw, dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.g_ptr.p, L.g_part.p,
                            more ? an.theta : (const double *)nullptr, ls.dv_col.p);
       } else {
         hipLaunchKernelGGL(k_mf_draw, dim3((L.n_cols + 3) / 4), dim3(WG), 0, s, a, L.scols.p, L.n_cols, L.slot_ptr.p, L.slots.p,
