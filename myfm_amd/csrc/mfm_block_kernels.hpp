@@ -174,10 +174,13 @@ constexpr int UNSYNC_R = 4;          // rows per thread and step
 constexpr int UNSYNC_STREAM_WGS = 1024;
 constexpr int64_t UNSYNC_STREAM_MAX_B = 4096;  // 128 KiB table
 
-template <bool IS_W>
+// PRE: the re-sync of the PREVIOUS block (FMTrainer.hpp:473-480, its map / records) is applied to the row first -- that
+// block's own streaming re-sync pass (a read + write of eq) is then not launched
+template <bool IS_W, bool PRE = false>
 __global__ __launch_bounds__(WG) void k_unsync_stream(const int32_t *__restrict__ map, double2 *__restrict__ eq,
                                                       const double *__restrict__ rec, int64_t N, int B, int64_t rows_per_wg,
-                                                      double *__restrict__ partial) {
+                                                      double *__restrict__ partial, const int32_t *__restrict__ map_prev = nullptr,
+                                                      const double *__restrict__ rec_prev = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NS = IS_W ? 1 : 4;
   double *tab = (double *)smem;  // [B][NS]
@@ -186,17 +189,28 @@ __global__ __launch_bounds__(WG) void k_unsync_stream(const int32_t *__restrict_
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = min(N, r0 + rows_per_wg);
   const int wv = threadIdx.x >> 6;
   for (int64_t base = r0; base < r1; base += (int64_t)WG * UNSYNC_R) {
-    int key[UNSYNC_R];
+    int key[UNSYNC_R], kprev[UNSYNC_R];
     double s[UNSYNC_R][NS];
     double2 v[UNSYNC_R];
 #pragma unroll
     for (int u = 0; u < UNSYNC_R; u++) {
       const int64_t t = base + (int64_t)u * WG + threadIdx.x;
       key[u] = -1;
+      kprev[u] = 0;
       if (t < r1) {
         key[u] = map[t];
+        if (PRE) kprev[u] = map_prev[t];
         v[u] = eq[t];
       }
+    }
+    if (PRE) {
+#pragma unroll
+      for (int u = 0; u < UNSYNC_R; u++)
+        if (key[u] >= 0) {
+          const double2 qp = ((const double2 *)rec_prev)[(int64_t)kprev[u] * 4];
+          v[u].x += (v[u].y * qp.x + 0.5 * qp.x * qp.x - 0.5 * qp.y);  // :476-478 of the previous block
+          v[u].y += qp.x;                                             // :479
+        }
     }
 #pragma unroll
     for (int u = 0; u < UNSYNC_R; u++) {
@@ -467,8 +481,8 @@ static void block_rowcache(hipStream_t s, Timing &tm, DevBlock &B, const double 
 }
 
 template <bool IS_W>
-static void block_unsync(hipStream_t s, Timing &tm, DevBlock &B, int64_t N, double2 *eq) {
-  TimedLaunch t(tm, s, KC_BLOCK_UNSYNC, (IS_W ? 4.0 + 8.0 + 8.0 : 4.0 + 16.0 + 16.0) * N + 32.0 * B.B);
+static void block_unsync(hipStream_t s, Timing &tm, DevBlock &B, int64_t N, double2 *eq, DevBlock *pending_resync = nullptr) {
+  TimedLaunch t(tm, s, KC_BLOCK_UNSYNC, (IS_W ? 4.0 + 8.0 + 8.0 : 4.0 + 16.0 + 16.0) * N + 32.0 * B.B + (pending_resync ? 4.0 * N : 0.0));
   if (B.stream_unsync && N > 0) {
     constexpr int NS = IS_W ? 1 : 4;
     const size_t lds = (size_t)B.B * NS * sizeof(double);
@@ -480,8 +494,19 @@ static void block_unsync(hipStream_t s, Timing &tm, DevBlock &B, int64_t N, doub
                                          (int)(UNSYNC_STREAM_MAX_B * sizeof(double))));
       raised = true;
     }
-    hipLaunchKernelGGL((k_unsync_stream<IS_W>), dim3(B.stream_wgs), dim3(WG), lds, s, B.map.p, eq, B.rec.p, N, (int)B.B,
-                       B.stream_rows_per_wg, B.stream_partial.p);
+    if (pending_resync && !IS_W) {
+      static bool raised2 = false;
+      if (!raised2) {
+        MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_unsync_stream<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(UNSYNC_STREAM_MAX_B * 4 * sizeof(double))));
+        raised2 = true;
+      }
+      hipLaunchKernelGGL((k_unsync_stream<false, true>), dim3(B.stream_wgs), dim3(WG), lds, s, B.map.p, eq, B.rec.p, N, (int)B.B,
+                         B.stream_rows_per_wg, B.stream_partial.p, pending_resync->map.p, pending_resync->rec.p);
+    } else {
+      hipLaunchKernelGGL((k_unsync_stream<IS_W>), dim3(B.stream_wgs), dim3(WG), lds, s, B.map.p, eq, B.rec.p, N, (int)B.B,
+                         B.stream_rows_per_wg, B.stream_partial.p, nullptr, nullptr);
+    }
     hipLaunchKernelGGL((k_unsync_stream_fin<IS_W>), dim3(cdiv_i(B.B * NS, 32)), dim3(256), 0, s, B.stream_partial.p,
                        B.stream_wgs, (int)B.B, B.rec.p);
     MFM_HIP_CHECK(hipGetLastError());
@@ -543,16 +568,22 @@ static void block_sweep_w(hipStream_t s, Timing &tm, LongScratch &ls, DevBlock &
 
 // FMTrainer.hpp:378-482 for one block and one factor (q_B / q_S were filled by block_rowcache before
 // the q-cache build, :331-333 / :388-393: V_B does not change in between)
+// pending: a block whose re-sync is still owed (it was deferred so that THIS block's streaming statistics pass applies it on
+// the fly); defer_resync: leave this block's own re-sync to the next block's statistics pass
 static void block_sweep_V(hipStream_t s, Timing &tm, LongScratch &ls, DevBlock &B, int64_t N, double2 *eq, double *Vf,
                           const double *zf, const int32_t *group, const double *lamf, const double *muf, double alpha,
-                          const Comm &comm) {
-  block_unsync<false>(s, tm, B, N, eq);  // :401-417
+                          const Comm &comm, DevBlock *pending = nullptr, bool defer_resync = false) {
+  if (pending && !(B.stream_unsync && N > 0)) {  // (cannot be absorbed: apply it now)
+    block_resync<false>(s, tm, *pending, N, eq);
+    pending = nullptr;
+  }
+  block_unsync<false>(s, tm, B, N, eq, pending);  // :401-417
   B.allreduce_fields(s, comm, 2, 4);     // sharded rows: c, c_S, e, e_q are sums over all ranks' rows
   SweepArgs a = block_args(B, Vf, zf, group, lamf, muf, alpha);
   const SweepClasses kc{KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP,
                         KC_BLOCK_SWEEP, KC_BLOCK_SWEEP};
   run_plan<PBlockV>(s, tm, B.plan_V, a, ls, kc, false);  // :419-470
-  block_resync<false>(s, tm, B, N, eq);  // :473-480
+  if (!defer_resync) block_resync<false>(s, tm, B, N, eq);  // :473-480
 }
 
 template <int GS, int SPL>

@@ -1188,8 +1188,15 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       run_plan_sharded<PMainV>(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit, c->comm);
     else
       run_plan<PMainV>(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit, first_q);  // :343-376
-    for (auto &B : c->blocks)
-      block_sweep_V(s, c->timing, c->ls, *B, c->N, c->eq.p, Vf, zf, c->group.p, lamf, muf, alpha, c->comm);  // :378-482
+    // a block whose successor streams its statistics pass leaves its re-sync to that pass (one read + write of eq less)
+    static const bool fuse_resync = !std::getenv("MFM_NO_RESYNC_FUSE");
+    DevBlock *pending = nullptr;
+    for (size_t bi = 0; bi < c->blocks.size(); bi++) {
+      DevBlock &B = *c->blocks[bi];
+      const bool defer = fuse_resync && bi + 1 < c->blocks.size() && c->blocks[bi + 1]->stream_unsync && c->N > 0;
+      block_sweep_V(s, c->timing, c->ls, B, c->N, c->eq.p, Vf, zf, c->group.p, lamf, muf, alpha, c->comm, pending, defer);  // :378-482
+      pending = defer ? &B : nullptr;
+    }
   }
   MFM_CATCH(ctx)
 }
