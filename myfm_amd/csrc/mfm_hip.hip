@@ -634,7 +634,9 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     c->plan_V.sharded = c->plan_W.sharded = c->comm.active();
     c->plan_V.given_levels = c->plan_W.given_levels = c->hlevels;
     // scattered levels: LDS row tiles of 2^tile_bits {e, q} records (64 KiB by default: two workgroups per CU)
-    int tile_bits = 12;
+    // (short tables: 1024-row tiles -- a 4096-row tile leaves most of the 256 CUs without a workgroup and the pass is bound by
+    // the life time of one workgroup: ML-100k shape 3270 -> 4040 it/s)
+    int tile_bits = (c->N < ((int64_t)1 << 20) && !c->comm.active()) ? 10 : 12;
     if (const char *e = std::getenv("MFM_TILE_BITS")) tile_bits = std::atoi(e);
     if (tile_bits < 9 || tile_bits > 13) tile_bits = 0;  // 0: L2-window path (k_scat_*)
     c->plan_V.tile_bits = c->plan_W.tile_bits = tile_bits;

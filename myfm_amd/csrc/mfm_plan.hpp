@@ -1797,9 +1797,10 @@ static inline bool plan_supports_mf(const StepPlan &plan) {
   return first.first_and_once && last.covers_rows_once && last.tile_bits >= 9 && last.tile_bits <= 13;
 }
 
-static inline int mf_rows_per_thread() {
+static inline int mf_rows_per_thread(int64_t n_rows) {
   const char *e = std::getenv("MFM_MF_K");  // (read per sweep: the tests switch it inside one process)
-  return e && std::atoi(e) == 4 ? 4 : 8;
+  if (e) return std::atoi(e) == 4 ? 4 : 8;
+  return n_rows < ((int64_t)1 << 20) ? 4 : 8;  // short tables: more, shorter-lived threads per tile
 }
 
 // Latent sweep of factors [f_begin, f_end): args(f).state = e[N] (split array), .aos = the interleaved {e, q} array the
@@ -1811,7 +1812,7 @@ static void run_sweep_mf(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf
   // level runs locally inside the tiles, per factor ONE all-reduce carries the item level's statistics (2 n_cols doubles)
   const ParLevel &L = plan.steps.back().par;
   const int swz = xcd_swizzle_enabled();
-  const int KR = mf_rows_per_thread();
+  const int KR = mf_rows_per_thread(plan.n_state_rows);
   const int nt = (1 << L.tile_bits) / KR;
   const size_t lds = mf_lds_bytes(L.tile_bits, UNIT);
   {
