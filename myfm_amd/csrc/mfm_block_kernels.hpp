@@ -78,6 +78,23 @@ __device__ __forceinline__ void unsync_entry(double2 *__restrict__ eq, int32_t t
   }
 }
 
+// The same sums taken AFTER the row was un-synced by a streaming pass (k_unsync_update): the stored q is temp, and the
+// residual before the un-sync is e + (temp q_B + q_B^2 / 2 - q_S / 2) (:412-415 undone). Read-only.
+template <bool IS_W>
+__device__ __forceinline__ void unsync_entry_post(const double2 *__restrict__ eq, int32_t t, double qB, double qS, double *s) {
+  const double2 v = eq[t];
+  if (IS_W) {
+    s[0] += v.x + qB;
+  } else {
+    const double temp = v.y;
+    const double e_pre = v.x + (temp * qB + 0.5 * qB * qB - 0.5 * qS);
+    s[0] += temp;
+    s[1] += temp * temp;
+    s[2] += e_pre;
+    s[3] += e_pre * temp;
+  }
+}
+
 template <bool IS_W>
 __device__ __forceinline__ void unsync_store(double *__restrict__ rec, int64_t i, const double *s) {
   double2 *r = (double2 *)rec + i * 4;
@@ -89,7 +106,7 @@ __device__ __forceinline__ void unsync_store(double *__restrict__ rec, int64_t i
   }
 }
 
-template <bool IS_W>
+template <bool IS_W, bool POST = false>
 __global__ __launch_bounds__(WG) void k_unsync_wave(const int64_t *__restrict__ inv_ptr,
                                                     const int32_t *__restrict__ inv_rows,
                                                     const int32_t *__restrict__ brow, int n, double2 *__restrict__ eq,
@@ -101,13 +118,15 @@ __global__ __launch_bounds__(WG) void k_unsync_wave(const int64_t *__restrict__ 
   const double2 qq = ((const double2 *)rec)[i * 4];
   const int64_t b = inv_ptr[i], e = inv_ptr[i + 1];
   double s[4] = {0, 0, 0, 0};
-  for (int64_t p = b + lane; p < e; p += WAVE) unsync_entry<IS_W>(eq, inv_rows[p], qq.x, qq.y, s);
+  for (int64_t p = b + lane; p < e; p += WAVE) {
+    if (POST) unsync_entry_post<IS_W>(eq, inv_rows[p], qq.x, qq.y, s); else unsync_entry<IS_W>(eq, inv_rows[p], qq.x, qq.y, s);
+  }
 #pragma unroll
   for (int k = 0; k < (IS_W ? 1 : 4); k++) s[k] = wave_allreduce_sum(s[k]);
   if (lane == 0) unsync_store<IS_W>(rec, i, s);
 }
 
-template <bool IS_W>
+template <bool IS_W, bool POST = false>
 __global__ __launch_bounds__(WG) void k_unsync_wg(const int64_t *__restrict__ inv_ptr,
                                                   const int32_t *__restrict__ inv_rows,
                                                   const int32_t *__restrict__ brow, double2 *__restrict__ eq,
@@ -117,7 +136,9 @@ __global__ __launch_bounds__(WG) void k_unsync_wg(const int64_t *__restrict__ in
   const double2 qq = ((const double2 *)rec)[i * 4];
   const int64_t b = inv_ptr[i], e = inv_ptr[i + 1];
   double s[4] = {0, 0, 0, 0};
-  for (int64_t p = b + threadIdx.x; p < e; p += WG) unsync_entry<IS_W>(eq, inv_rows[p], qq.x, qq.y, s);
+  for (int64_t p = b + threadIdx.x; p < e; p += WG) {
+    if (POST) unsync_entry_post<IS_W>(eq, inv_rows[p], qq.x, qq.y, s); else unsync_entry<IS_W>(eq, inv_rows[p], qq.x, qq.y, s);
+  }
   wg_allreduce2<WG / WAVE>(s[0], s[1], lds);
   if (!IS_W) wg_allreduce2<WG / WAVE>(s[2], s[3], lds);
   if (threadIdx.x == 0) unsync_store<IS_W>(rec, i, s);
@@ -129,7 +150,7 @@ struct InvChunk {
   int32_t brow;
 };
 // long block rows: every chunk un-syncs its rows and leaves partial sums; k_unsync_long_fin adds them
-template <bool IS_W>
+template <bool IS_W, bool POST = false>
 __global__ __launch_bounds__(WG) void k_unsync_long(const InvChunk *__restrict__ chunks,
                                                     const int32_t *__restrict__ inv_rows, double2 *__restrict__ eq,
                                                     const double *__restrict__ rec, double *__restrict__ partial) {
@@ -137,7 +158,9 @@ __global__ __launch_bounds__(WG) void k_unsync_long(const InvChunk *__restrict__
   const InvChunk c = chunks[blockIdx.x];
   const double2 qq = ((const double2 *)rec)[(int64_t)c.brow * 4];
   double s[4] = {0, 0, 0, 0};
-  for (int p = threadIdx.x; p < c.len; p += WG) unsync_entry<IS_W>(eq, inv_rows[c.begin + p], qq.x, qq.y, s);
+  for (int p = threadIdx.x; p < c.len; p += WG) {
+    if (POST) unsync_entry_post<IS_W>(eq, inv_rows[c.begin + p], qq.x, qq.y, s); else unsync_entry<IS_W>(eq, inv_rows[c.begin + p], qq.x, qq.y, s);
+  }
   wg_allreduce2<WG / WAVE>(s[0], s[1], lds);
   if (!IS_W) wg_allreduce2<WG / WAVE>(s[2], s[3], lds);
   if (threadIdx.x == 0) {
@@ -157,6 +180,34 @@ __global__ void k_unsync_long_fin(const int32_t *__restrict__ lrows, const int32
   for (int c = chunk_ptr[l]; c < chunk_ptr[l + 1]; c++)
     for (int k = 0; k < 4; k++) s[k] += partial[(int64_t)c * 4 + k];
   unsync_store<IS_W>(rec, lrows[l], s);
+}
+
+// un-sync of every training row, streaming (no statistics): (PRE: first the re-sync the previous block owes, as in
+// k_unsync_stream). The statistics follow read-only through the inverse map (POST forms of the kernels above): a block row's
+// scattered training rows are then read, not read-modified-written -- half the random traffic -- and the previous block's
+// re-sync pass disappears.
+template <bool IS_W, bool PRE>
+__global__ __launch_bounds__(WG) void k_unsync_update(const int32_t *__restrict__ map, double2 *__restrict__ eq,
+                                                      const double *__restrict__ rec, int64_t N, const int32_t *__restrict__ map_prev,
+                                                      const double *__restrict__ rec_prev) {
+  const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x;
+  if (t >= N) return;
+  double2 v = eq[t];
+  const double2 qq = ((const double2 *)rec)[(int64_t)map[t] * 4];
+  if (PRE) {
+    const double2 qp = ((const double2 *)rec_prev)[(int64_t)map_prev[t] * 4];
+    v.x += (v.y * qp.x + 0.5 * qp.x * qp.x - 0.5 * qp.y);
+    v.y += qp.x;
+  }
+  if (IS_W) {
+    v.x -= qq.x;
+    eq[t].x = v.x;
+  } else {
+    const double temp = v.y - qq.x;
+    v.y = temp;
+    v.x -= (v.y * qq.x + 0.5 * qq.x * qq.x - 0.5 * qq.y);
+    eq[t] = v;
+  }
 }
 
 // ---- statistics + un-sync, STREAMING over the training rows (few block rows, each with very many training rows) --------
@@ -368,6 +419,7 @@ struct DevBlock {
   DevBuf<double> comm_buf;  // [B][4] packed statistics for the all-reduce (sharded mode)
   // streaming statistics pass (k_unsync_stream): few block rows with very many training rows each
   bool stream_unsync = false;
+  bool split_unsync = false;  // streaming un-sync (k_unsync_update) + read-only statistics through the inverse map
   int stream_wgs = 0;
   int64_t stream_rows_per_wg = 0;
   DevBuf<double> stream_partial;  // [stream_wgs][B][4]
@@ -390,6 +442,9 @@ struct DevBlock {
     stream_unsync = !sorted && B >= 1 && B <= UNSYNC_STREAM_MAX_B && N >= 64 * B && N >= ((int64_t)1 << 20) &&
                     !std::getenv("MFM_NO_UNSYNC_STREAM");  // (short tables: too few workgroups to stream with)
     if (const char *e = std::getenv("MFM_UNSYNC_STREAM_FORCE")) stream_unsync = std::atoi(e) != 0 && B >= 1 && B <= UNSYNC_STREAM_MAX_B;
+    // too many block rows for the LDS table, lists scattered over a long table: split form
+    split_unsync = !sorted && !stream_unsync && N >= ((int64_t)1 << 20) && !std::getenv("MFM_NO_UNSYNC_SPLIT");
+    if (const char *e = std::getenv("MFM_UNSYNC_SPLIT_FORCE")) split_unsync = std::atoi(e) != 0 && !stream_unsync;
     std::vector<int32_t> m32((size_t)N);
     std::vector<int64_t> iptr((size_t)B + 1, 0);
     for (int64_t t = 0; t < N; t++) {
@@ -512,6 +567,27 @@ static void block_unsync(hipStream_t s, Timing &tm, DevBlock &B, int64_t N, doub
     MFM_HIP_CHECK(hipGetLastError());
     return;
   }
+  if (B.split_unsync && N > 0) {
+    if (pending_resync && !IS_W)
+      hipLaunchKernelGGL((k_unsync_update<false, true>), dim3(cdiv_i(N, WG)), dim3(WG), 0, s, B.map.p, eq, B.rec.p, N,
+                         pending_resync->map.p, pending_resync->rec.p);
+    else
+      hipLaunchKernelGGL((k_unsync_update<IS_W, false>), dim3(cdiv_i(N, WG)), dim3(WG), 0, s, B.map.p, eq, B.rec.p, N, nullptr, nullptr);
+    if (B.n_inv_wave)
+      hipLaunchKernelGGL((k_unsync_wave<IS_W, true>), dim3(cdiv_i(B.n_inv_wave, WG / WAVE)), dim3(WG), 0, s, B.inv_ptr.p,
+                         B.inv_rows.p, B.inv_wave.p, B.n_inv_wave, eq, B.rec.p);
+    if (B.n_inv_wg)
+      hipLaunchKernelGGL((k_unsync_wg<IS_W, true>), dim3(B.n_inv_wg), dim3(WG), 0, s, B.inv_ptr.p, B.inv_rows.p, B.inv_wg.p, eq,
+                         B.rec.p);
+    if (B.n_inv_long) {
+      hipLaunchKernelGGL((k_unsync_long<IS_W, true>), dim3(B.n_inv_chunks), dim3(WG), 0, s, B.inv_chunks.p, B.inv_rows.p, eq,
+                         B.rec.p, B.inv_partial.p);
+      hipLaunchKernelGGL((k_unsync_long_fin<IS_W>), dim3(cdiv_i(B.n_inv_long, 64)), dim3(64), 0, s, B.inv_long.p,
+                         B.inv_long_chunk_ptr.p, B.n_inv_long, B.inv_partial.p, B.rec.p);
+    }
+    MFM_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (B.n_inv_wave)
     hipLaunchKernelGGL((k_unsync_wave<IS_W>), dim3(cdiv_i(B.n_inv_wave, WG / WAVE)), dim3(WG), 0, s, B.inv_ptr.p,
                        B.inv_rows.p, B.inv_wave.p, B.n_inv_wave, eq, B.rec.p);
@@ -573,7 +649,7 @@ static void block_sweep_w(hipStream_t s, Timing &tm, LongScratch &ls, DevBlock &
 static void block_sweep_V(hipStream_t s, Timing &tm, LongScratch &ls, DevBlock &B, int64_t N, double2 *eq, double *Vf,
                           const double *zf, const int32_t *group, const double *lamf, const double *muf, double alpha,
                           const Comm &comm, DevBlock *pending = nullptr, bool defer_resync = false) {
-  if (pending && !(B.stream_unsync && N > 0)) {  // (cannot be absorbed: apply it now)
+  if (pending && !((B.stream_unsync || B.split_unsync) && N > 0)) {  // (cannot be absorbed: apply it now)
     block_resync<false>(s, tm, *pending, N, eq);
     pending = nullptr;
   }

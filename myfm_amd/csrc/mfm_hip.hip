@@ -1195,7 +1195,8 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     DevBlock *pending = nullptr;
     for (size_t bi = 0; bi < c->blocks.size(); bi++) {
       DevBlock &B = *c->blocks[bi];
-      const bool defer = fuse_resync && bi + 1 < c->blocks.size() && c->blocks[bi + 1]->stream_unsync && c->N > 0;
+      const bool defer = fuse_resync && bi + 1 < c->blocks.size() && c->N > 0 &&
+                         (c->blocks[bi + 1]->stream_unsync || c->blocks[bi + 1]->split_unsync);
       block_sweep_V(s, c->timing, c->ls, B, c->N, c->eq.p, Vf, zf, c->group.p, lamf, muf, alpha, c->comm, pending, defer);  // :378-482
       pending = defer ? &B : nullptr;
     }

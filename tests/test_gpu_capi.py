@@ -303,14 +303,17 @@ def _timing_classes(c, drv):
     return names
 
 
-@pytest.mark.parametrize("stream", [False, True])
+@pytest.mark.parametrize("stream", [False, True, "split"])
 @pytest.mark.parametrize("design", ["onehot", "multihot"])
 def test_blocks_match_oracle_and_flat(oracle, capi, monkeypatch, design, stream):
     # tests/regression/test_block.py:80-149 on the device path + against the oracle
     # stream: the statistics / un-sync pass (FMTrainer.hpp:268-275, :401-417) streaming over the training rows with the
     # sums in an LDS table (k_unsync_stream, the form of blocks with few rows under a long table), else by block row
     # through the inverse map
-    monkeypatch.setenv("MFM_UNSYNC_STREAM_FORCE", "1" if stream else "0")
+    # "split": streaming un-sync of the rows (which also applies the previous block's re-sync) + read-only statistics through
+    # the inverse map, the form of blocks with too many rows for the LDS table
+    monkeypatch.setenv("MFM_UNSYNC_STREAM_FORCE", "1" if stream is True else "0")
+    monkeypatch.setenv("MFM_UNSYNC_SPLIT_FORCE", "1" if stream == "split" else "0")
     if design == "onehot":
         main, X_flat, blocks, y, shapes = ds.block_design()
         rank = 2
