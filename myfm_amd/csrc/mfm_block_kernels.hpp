@@ -323,6 +323,11 @@ __global__ __launch_bounds__(256) void k_unsync_stream_fin(const double *__restr
   }
 }
 
+__global__ void k_save_q(const double *__restrict__ rec, int64_t B, double2 *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) out[i] = ((const double2 *)rec)[i * 4];  // (q_B, q_S)
+}
+
 // re-sync, streaming over training rows: FMTrainer.hpp:473-480 (V) / :306-311 (w)
 template <bool IS_W>
 __global__ __launch_bounds__(WG) void k_resync(const int32_t *__restrict__ map, const double *__restrict__ rec,
@@ -417,6 +422,7 @@ struct DevBlock {
   DevBuf<InvChunk> inv_chunks;
   DevBuf<double> inv_partial;
   DevBuf<double> comm_buf;  // [B][4] packed statistics for the all-reduce (sharded mode)
+  DevBuf<double2> q_saved;  // (q_B, q_S) of the previous factor while its re-sync is folded into the next q-cache build
   // streaming statistics pass (k_unsync_stream): few block rows with very many training rows each
   bool stream_unsync = false;
   bool split_unsync = false;  // streaming un-sync (k_unsync_update) + read-only statistics through the inverse map

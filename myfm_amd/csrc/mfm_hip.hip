@@ -267,18 +267,21 @@ static void fill_gather_args(std::vector<std::unique_ptr<DevBlock>> &blocks, Blo
 }
 
 // q = X v_f + sum_b q_B[map_b]   (FMTrainer.hpp:320-340); the blocks' q_B must be in rec already
-static void launch_qbuild(mfm_ctx *c, const double *vf) {
+static bool qbuild_by_rows(const mfm_ctx *c) { return c->X.avg_row_nnz <= 16.0; }
+// pending: a block whose re-sync of the previous factor is applied by this pass (q_saved holds its old (q_B, q_S))
+static void launch_qbuild(mfm_ctx *c, const double *vf, DevBlock *pending = nullptr) {
   if (c->N == 0) return;
   hipStream_t s = c->stream;
   BlockGatherArgs g;
   fill_gather_args(c->blocks, g);
   TimedLaunch t(c->timing, s, KC_QBUILD, 12.0 * c->X.nnz + 8.0 * c->N + 8.0 * c->D0 + 12.0 * c->N * g.n_blocks);
-  if (c->X.avg_row_nnz <= 16.0) {
+  if (qbuild_by_rows(c)) {
     const bool ell = c->X.ell_width >= 0;
     dim3 grid(cdiv(c->N, WG)), block(WG);
 #define MFM_QB(U, E) \
   hipLaunchKernelGGL((k_qbuild_rows<U, E>), grid, block, 0, s, c->X.rowptr.p, c->X.colidx.p, c->X.rval.p, vf, c->eq.p, c->N, \
-                     (int)c->X.ell_width, g)
+                     (int)c->X.ell_width, g, pending ? pending->map.p : (const int32_t *)nullptr,                          \
+                     pending ? pending->q_saved.p : (const double2 *)nullptr)
     if (c->X.unit) {
       if (ell) MFM_QB(true, true); else MFM_QB(true, false);
     } else {
@@ -1170,13 +1173,19 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     MFM_HIP_CHECK(hipGetLastError());
     return MFM_OK;
   }
+  DevBlock *carry = nullptr;  // last block of the previous factor, re-sync still owed
   for (int f = f_begin; f < f_end; f++) {
     double *Vf = c->V.p + (size_t)f * c->D;
     const double *zf = zbase + (size_t)(f - f_begin) * c->D;
     const double *lamf = c->lam.p + (size_t)f * c->G;
     const double *muf = c->mu.p + (size_t)f * c->G;
+    if (carry) {  // the last block of the previous factor owes its re-sync: keep its (q_B, q_S) for the q-cache build below
+      if (carry->q_saved.n < (size_t)carry->B) carry->q_saved.alloc((size_t)carry->B);
+      hipLaunchKernelGGL(k_save_q, dim3(cdiv(carry->B, 256)), dim3(256), 0, s, carry->rec.p, carry->B, carry->q_saved.p);
+    }
     for (auto &B : c->blocks) block_rowcache(s, c->timing, *B, Vf + B->col_off, true);  // :331-333, :388-393
-    if (!first_q) launch_qbuild(c, Vf);                                                 // :320, :334-337
+    if (!first_q) launch_qbuild(c, Vf, carry);                                          // :320, :334-337
+    carry = nullptr;
     SweepArgs a = main_args(c, Vf, zf, lamf, muf, alpha);
     if (first_q) {
       a.r_rowptr = c->X.rowptr.p;
@@ -1195,11 +1204,15 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     DevBlock *pending = nullptr;
     for (size_t bi = 0; bi < c->blocks.size(); bi++) {
       DevBlock &B = *c->blocks[bi];
-      const bool defer = fuse_resync && bi + 1 < c->blocks.size() && c->N > 0 &&
-                         (c->blocks[bi + 1]->stream_unsync || c->blocks[bi + 1]->split_unsync);
+      const bool last = bi + 1 == c->blocks.size();
+      // ... and the last block leaves it to the next factor's q-cache build (thread-per-row form)
+      const bool defer = fuse_resync && c->N > 0 &&
+                         (last ? (f + 1 < f_end && !first_q && qbuild_by_rows(c))
+                               : (c->blocks[bi + 1]->stream_unsync || c->blocks[bi + 1]->split_unsync));
       block_sweep_V(s, c->timing, c->ls, B, c->N, c->eq.p, Vf, zf, c->group.p, lamf, muf, alpha, c->comm, pending, defer);  // :378-482
       pending = defer ? &B : nullptr;
     }
+    carry = pending;
   }
   MFM_CATCH(ctx)
 }

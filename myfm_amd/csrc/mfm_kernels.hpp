@@ -2384,7 +2384,9 @@ template <bool UNIT, bool ELL>
 __global__ __launch_bounds__(WG) void k_qbuild_rows(const int32_t *__restrict__ rowptr,
                                                     const int32_t *__restrict__ colidx,
                                                     const double *__restrict__ val, const double *__restrict__ vf,
-                                                    double2 *__restrict__ eq, int64_t N, int ell, BlockGatherArgs blk) {
+                                                    double2 *__restrict__ eq, int64_t N, int ell, BlockGatherArgs blk,
+                                                    const int32_t *__restrict__ map_prev = nullptr,
+                                                    const double2 *__restrict__ q_prev = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * WG + threadIdx.x;
   if (i >= N) return;
   int64_t b, e;
@@ -2398,7 +2400,17 @@ __global__ __launch_bounds__(WG) void k_qbuild_rows(const int32_t *__restrict__ 
   double s = 0.0;
   for (int64_t p = b; p < e; p++) s += (UNIT ? 1.0 : val[p]) * vf[colidx[p]];
   for (int bi = 0; bi < blk.n_blocks; bi++) s += blk.rec[bi][(int64_t)blk.map[bi][i] * BLOCK_REC];  // :335-337
-  eq[i].y = s;
+  if (map_prev) {
+    // the re-sync the last block of the PREVIOUS factor still owes (FMTrainer.hpp:473-480; its (q_B, q_S) of that factor were
+    // saved before the row caches were rebuilt): the residual term uses the old q, which this pass then overwrites
+    double2 v = eq[i];
+    const double2 qp = q_prev[map_prev[i]];
+    v.x += (v.y * qp.x + 0.5 * qp.x * qp.x - 0.5 * qp.y);
+    v.y = s;
+    eq[i] = v;
+  } else {
+    eq[i].y = s;
+  }
 }
 // wavefront per row: long rows (dense main tables)
 __global__ __launch_bounds__(WG) void k_qbuild_wave(const int32_t *__restrict__ rowptr,
