@@ -90,8 +90,13 @@ class Lockstep:
         return cb
 
 
-@pytest.mark.parametrize("name", ["onehot_plus_dense", "relation_blocks"])
-def test_two_shards_lockstep(oracle, name):
+@pytest.mark.parametrize("name,unsync", [("onehot_plus_dense", "inverse"), ("relation_blocks", "inverse"),
+                                         ("relation_blocks", "stream"), ("relation_blocks", "split")])
+def test_two_shards_lockstep(oracle, monkeypatch, name, unsync):
+    # unsync: form of the relation blocks' statistics / un-sync pass on every shard (inverse map | streaming with the sums in
+    # LDS | streaming un-sync + read-only statistics); the latter two also fold each block's re-sync into the next pass
+    monkeypatch.setenv("MFM_UNSYNC_STREAM_FORCE", "1" if unsync == "stream" else "0")
+    monkeypatch.setenv("MFM_UNSYNC_SPLIT_FORCE", "1" if unsync == "split" else "0")
     import myfm_amd
     from myfm_amd import _myfm
     from myfm_amd.distributed import shard_rows
