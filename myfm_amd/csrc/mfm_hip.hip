@@ -693,6 +693,11 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     // the row-tile layouts of scattered levels are packed on the device from the device-resident CSC
     static thread_local DevCscView dev_view;
     dev_view = DevCscView{c->X.colptr.p, c->X.rowidx.p, c->X.cval.p, c->stream};
+    dev_view.rowptr = c->X.rowptr.p;
+    dev_view.colidx = c->X.colidx.p;
+    dev_view.n_rows = c->N;
+    dev_view.n_cols = c->D0;
+    dev_view.ell = (int)c->X.ell_width;
     c->plan_V.dev_csc = c->X.colptr.p ? &dev_view : nullptr;
     c->plan_W.dev_csc = c->plan_V.dev_csc;
     c->plan_V.build(Xt, PMainV::R_W16, PMainV::R_WG, coop_v, true, c->X.unit);

@@ -220,7 +220,62 @@ struct DevCscView {
   const int32_t *rowidx = nullptr;
   const double *cval = nullptr;
   hipStream_t stream = nullptr;
+  // the same table by rows (level schedule on the device)
+  const int32_t *rowptr = nullptr;
+  const int32_t *colidx = nullptr;
+  int64_t n_rows = 0, n_cols = 0;
+  int ell = -1;  // >= 0: every row has exactly this many entries (rowptr not read)
 };
+// Level schedule (level(j) = 1 + max level of earlier columns sharing a row with j) as the least fixed point of
+// level[c_k] >= level[c_{k-1}] + 1 over consecutive stored columns of every row: row-parallel relaxation passes with atomicMax
+// until nothing changes -- as many passes as there are levels, so this is for the shallow schedules of one-hot designs (deep
+// ones, e.g. multi-hot relation blocks, are scheduled on the host). flags[0]: something changed; flags[1]: a row's column
+// indices are not ascending (host schedule instead).
+__global__ void k_dp_level_relax(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int64_t N, int ell,
+                                 int32_t *__restrict__ level, int *__restrict__ flags) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  const int64_t b = ell >= 0 ? t * ell : rowptr[t], e = ell >= 0 ? b + ell : rowptr[t + 1];
+  int prev_c = -1, prev_l = 0;
+  for (int64_t p = b; p < e; p++) {
+    const int c = colidx[p];
+    if (c < prev_c) flags[1] = 1;
+    if (c == prev_c) continue;
+    int l = level[c];
+    if (prev_c >= 0 && l < prev_l + 1) {
+      l = prev_l + 1;
+      atomicMax(&level[c], l);
+      flags[0] = 1;
+    }
+    prev_c = c;
+    prev_l = l;
+  }
+}
+static inline bool column_levels_device(const DevCscView &dv, std::vector<int32_t> &level, int32_t &n_levels) {
+  if (!dv.colidx || dv.n_cols <= 0 || dv.n_rows <= 0 || (dv.ell < 0 && !dv.rowptr)) return false;
+  DevBuf<int32_t> lv;
+  DevBuf<int> fl;
+  lv.alloc((size_t)dv.n_cols);
+  fl.alloc(2);
+  MFM_HIP_CHECK(hipMemsetAsync(lv.p, 0, (size_t)dv.n_cols * sizeof(int32_t), dv.stream));
+  bool done = false;
+  for (int pass = 0; pass < 16 && !done; pass++) {
+    MFM_HIP_CHECK(hipMemsetAsync(fl.p, 0, 2 * sizeof(int), dv.stream));
+    hipLaunchKernelGGL(k_dp_level_relax, dim3((unsigned)((dv.n_rows + 255) / 256)), dim3(256), 0, dv.stream, dv.rowptr, dv.colidx,
+                       dv.n_rows, dv.ell, lv.p, fl.p);
+    int h[2] = {0, 0};
+    MFM_HIP_CHECK(hipMemcpyAsync(h, fl.p, 2 * sizeof(int), hipMemcpyDeviceToHost, dv.stream));
+    MFM_HIP_CHECK(hipStreamSynchronize(dv.stream));
+    if (h[1]) return false;
+    done = h[0] == 0;
+  }
+  if (!done) return false;
+  level.resize((size_t)dv.n_cols);
+  MFM_HIP_CHECK(hipMemcpy(level.data(), lv.p, (size_t)dv.n_cols * sizeof(int32_t), hipMemcpyDeviceToHost));
+  n_levels = 0;
+  for (int32_t l : level) n_levels = std::max(n_levels, l + 1);
+  return true;
+}
 __device__ __forceinline__ int dp_upper_tile(const int32_t *tstart, int nb, int r) {  // tile b with tstart[b] <= r < tstart[b + 1]
   int lo = 0, hi = nb;
   while (hi - lo > 1) {
@@ -973,6 +1028,12 @@ struct StepPlan {
     } else if (twin && !twin->h_level.empty() && (int64_t)twin->h_level.size() == csc.rows) {
       level = twin->h_level;
       n_levels = twin->n_levels;
+    } else if (dev_csc && !std::getenv("MFM_HOST_LEVELS") && column_levels_device(*dev_csc, level, n_levels)) {
+      if (std::getenv("MFM_PLAN_CHECK")) {  // tests: the device schedule must be the host schedule
+        std::vector<int32_t> hl;
+        const int32_t hn = column_levels(csc, hl);
+        if (hn != n_levels || hl != level) throw Error(MFM_ERR_RUNTIME, "plan check: device and host level schedules differ");
+      }
     } else {
       n_levels = column_levels(csc, level);
     }
