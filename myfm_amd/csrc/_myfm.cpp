@@ -58,6 +58,36 @@ struct Csr {
   int64_t nnz() const { return (int64_t)indices.size(); }
 };
 
+// The training table as the caller's own arrays (kept alive, converted only when dtype / layout require it): the trainer hands
+// the pointers straight to mfm_set_main, which makes the library's one host copy -- no second copy of 3e8 bytes at config 3.
+struct CsrView {
+  int64_t rows = 0, cols = 0;
+  py::array_t<int64_t, py::array::c_style | py::array::forcecast> indptr;
+  py::array_t<int32_t, py::array::c_style | py::array::forcecast> indices;
+  py::array_t<double, py::array::c_style | py::array::forcecast> data;
+  void release() {
+    indptr = py::array_t<int64_t, py::array::c_style | py::array::forcecast>();
+    indices = py::array_t<int32_t, py::array::c_style | py::array::forcecast>();
+    data = py::array_t<double, py::array::c_style | py::array::forcecast>();
+  }
+};
+CsrView csr_view_from_py(const py::handle &obj) {
+  py::object sparse = py::module_::import("scipy.sparse");
+  py::object m = py::reinterpret_borrow<py::object>(obj);
+  if (!py::isinstance(m, sparse.attr("csr_matrix"))) m = sparse.attr("csr_matrix")(m);
+  py::tuple shape = m.attr("shape");
+  CsrView X;
+  X.rows = shape[0].cast<int64_t>();
+  X.cols = shape[1].cast<int64_t>();
+  X.indptr = py::array_t<int64_t, py::array::c_style | py::array::forcecast>::ensure(m.attr("indptr"));
+  X.indices = py::array_t<int32_t, py::array::c_style | py::array::forcecast>::ensure(m.attr("indices"));
+  X.data = py::array_t<double, py::array::c_style | py::array::forcecast>::ensure(m.attr("data"));
+  if (!X.indptr || !X.indices || !X.data) throw std::invalid_argument("could not convert the sparse matrix to CSR arrays");
+  if ((int64_t)X.indptr.size() != X.rows + 1 || X.indices.size() != X.data.size())
+    throw std::invalid_argument("inconsistent CSR arrays");
+  return X;
+}
+
 Csr csr_from_py(const py::handle &obj) {
   py::object sparse = py::module_::import("scipy.sparse");
   py::object m = py::reinterpret_borrow<py::object>(obj);
@@ -201,7 +231,8 @@ Relations relations_from_py(const py::handle &h) {
 }
 
 // util.hpp:147-165
-size_t check_row_consistency_return_column(const Csr &X, const Relations &relations) {
+template <class M>
+size_t check_row_consistency_return_column(const M &X, const Relations &relations) {
   size_t row = (size_t)X.rows, col = (size_t)X.cols;
   int i = 0;
   for (const auto &rel : relations) {
@@ -822,8 +853,8 @@ struct FMTrainer {
   FMTrainer(const py::object &Xo, const py::object &relso, const py::object &yo, int random_seed, FMLearningConfig config)
       : cfg(std::move(config)), random_seed(random_seed), gen_(random_seed) {
     SetupLap lap("FMTrainer");
-    X_ = csr_from_py(Xo);
-    lap("copy of X");
+    X_ = csr_view_from_py(Xo);
+    lap("view of X");
     rels_ = relations_from_py(relso);
     dim_all = check_row_consistency_return_column(X_, rels_);
     lap("relations");
@@ -893,6 +924,7 @@ struct FMTrainer {
     SetupLap lap("build_device");
     if (!main_levels.empty()) ck(ctx, mfm_set_main_levels(ctx, main_levels.data(), (int64_t)main_levels.size()));
     ck(ctx, mfm_set_main(ctx, X_.rows, X_.cols, X_.indptr.data(), X_.indices.data(), X_.data.data(), y.data()));
+    X_.release();  // (the library holds its own copy now)
     lap("mfm_set_main");
     for (auto &r : rels_) {
       auto m = r->map64();
@@ -902,7 +934,6 @@ struct FMTrainer {
     vector<int32_t> gi(cfg.group_index.begin(), cfg.group_index.end());
     ck(ctx, mfm_set_groups(ctx, gi.data(), (int64_t)gi.size(), (int32_t)cfg.n_groups));
     ck(ctx, mfm_finalize(ctx, rank));
-    X_ = Csr();  // the design now lives on the device
   }
   void upload(const FM &fm) { ck(ctx, mfm_set_state(ctx, fm.w0, fm.w.data(), fm.V.data())); }
   void download(FM &fm) {
@@ -1179,7 +1210,7 @@ struct FMTrainer {
   }
 
  private:
-  Csr X_;
+  CsrView X_;
   Relations rels_;
 };
 
