@@ -220,7 +220,12 @@ struct RelationBlock {
     for (auto c : original_to_block)
       if (c >= block_size) throw std::runtime_error("index mapping points to non-existing row.");
   }
-  vector<int64_t> map64() const { return vector<int64_t>(original_to_block.begin(), original_to_block.end()); }
+  // the map as int64 for the C ABI: size_t and int64_t have the same width and the entries are validated < block_size
+  // (definitions.hpp:39-41), so the array is handed over in place (5e7 entries per block at config 5)
+  const int64_t *map64() const {
+    static_assert(sizeof(size_t) == sizeof(int64_t), "original_to_block is reinterpreted as int64");
+    return reinterpret_cast<const int64_t *>(original_to_block.data());
+  }
 };
 typedef vector<std::shared_ptr<RelationBlock>> Relations;
 
@@ -262,9 +267,8 @@ struct DeviceDesign {
     int code = mfm_design_create(device, X.rows, X.cols, X.indptr.data(), X.indices.data(), X.data.data(), &d);
     if (code != MFM_OK) throw_code(code, mfm_global_error());
     for (auto &r : rels) {
-      auto m = r->map64();
       code = mfm_design_add_block(d, r->X.rows, r->X.cols, r->X.indptr.data(), r->X.indices.data(), r->X.data.data(),
-                                  m.data());
+                                  r->map64());
       if (code != MFM_OK) {
         std::string msg = mfm_design_last_error(d);
         mfm_design_destroy(d);
@@ -927,8 +931,7 @@ struct FMTrainer {
     X_.release();  // (the library holds its own copy now)
     lap("mfm_set_main");
     for (auto &r : rels_) {
-      auto m = r->map64();
-      ck(ctx, mfm_add_block(ctx, r->X.rows, r->X.cols, r->X.indptr.data(), r->X.indices.data(), r->X.data.data(), m.data()));
+      ck(ctx, mfm_add_block(ctx, r->X.rows, r->X.cols, r->X.indptr.data(), r->X.indices.data(), r->X.data.data(), r->map64()));
     }
     lap("mfm_add_block (all)");
     vector<int32_t> gi(cfg.group_index.begin(), cfg.group_index.end());
