@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--rank", type=int, default=0, help="0: the config's own rank")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="CPU-oracle time budget (0 disables)")
     ap.add_argument("--cpu-iters", type=int, default=-1, help="(compat) 0 disables the CPU baseline")
-    ap.add_argument("--fit-iters", type=int, default=30, help="iterations of the MyFM*.fit() leg (0 disables)")
+    ap.add_argument("--fit-iters", type=int, default=100, help="iterations of the MyFM*.fit() leg (0 disables)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--weak-steps", type=int, default=20, help="N > 1: timed iterations of the weak-scaling leg (0 disables)")
     a = ap.parse_args()
