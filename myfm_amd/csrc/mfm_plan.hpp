@@ -1624,6 +1624,11 @@ static inline bool plan_supports_fused_multi(const StepPlan &plan) {
   return true;
 }
 
+struct Comm;
+template <class PS, class PA, bool UNIT>
+static void run_level_sharded(hipStream_t s, Timing &tm, const ParLevel &L, const SweepArgs &a, LongScratch &ls,
+                              const SweepClasses &kc, const Comm &comm, const int32_t *ccols, int n_c);
+
 template <bool UNIT, class ArgsOf>
 static void run_sweep_soa_multi(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf args, int f_begin, int f_end,
                                 LongScratch &ls, const SweepClasses &kc, const Comm *comm = nullptr) {
