@@ -29,7 +29,7 @@ __global__ __launch_bounds__(WG) void k_block_rowcache(const int32_t *__restrict
                                                        const int32_t *__restrict__ colidx,
                                                        const double *__restrict__ val,
                                                        const double *__restrict__ theta, double *__restrict__ rec,
-                                                       int64_t B) {
+                                                       int64_t B, double *__restrict__ qc = nullptr) {
   int64_t i;
   int lane = 0;
   if (WAVE_PER_ROW) {
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(WG) void k_block_rowcache(const int32_t *__restrict
   r[0] = make_double2(q, qs);
   r[1] = make_double2(0.0, 0.0);
   r[2] = make_double2(0.0, 0.0);
+  if (qc) qc[i] = q;  // compact copy for the q-cache build's gather (8-byte stride: a 500 000-row block is 4 MB, not 32)
 }
 
 // per-entry body of the statistics + un-sync pass for training row t mapped to a block row whose
@@ -422,6 +423,7 @@ struct DevBlock {
   DevBuf<InvChunk> inv_chunks;
   DevBuf<double> inv_partial;
   DevBuf<double> comm_buf;  // [B][4] packed statistics for the all-reduce (sharded mode)
+  DevBuf<double> qc;        // q_B alone, compact (filled by k_block_rowcache)
   DevBuf<double2> q_saved;  // (q_B, q_S) of the previous factor while its re-sync is folded into the next q-cache build
   // streaming statistics pass (k_unsync_stream): few block rows with very many training rows each
   bool stream_unsync = false;
@@ -502,6 +504,7 @@ struct DevBlock {
     bl.alloc_zero((size_t)B, s);
     bs.alloc_zero((size_t)B, s);
     comm_buf.alloc((size_t)std::max<int64_t>(B, 1) * 4);
+    if (!std::getenv("MFM_NO_COMPACT_QB")) qc.alloc_zero((size_t)std::max<int64_t>(B, 1), s);
     if (stream_unsync) {
       const int64_t step = (int64_t)WG * UNSYNC_R;
       const int64_t steps = (N + step - 1) / step;
@@ -531,7 +534,7 @@ static void block_rowcache(hipStream_t s, Timing &tm, DevBlock &B, const double 
   const bool wave = B.X.avg_row_nnz > 16.0;
   dim3 grid(wave ? cdiv_i(B.B, WG / WAVE) : cdiv_i(B.B, WG)), block(WG);
 #define MFM_RC(QS, WV) \
-  hipLaunchKernelGGL((k_block_rowcache<QS, WV>), grid, block, 0, s, B.X.rowptr.p, B.X.colidx.p, B.X.rval.p, theta, B.rec.p, B.B)
+  hipLaunchKernelGGL((k_block_rowcache<QS, WV>), grid, block, 0, s, B.X.rowptr.p, B.X.colidx.p, B.X.rval.p, theta, B.rec.p, B.B, B.qc.p)
   if (with_qs) {
     if (wave) MFM_RC(true, true); else MFM_RC(true, false);
   } else {

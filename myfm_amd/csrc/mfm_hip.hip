@@ -262,7 +262,8 @@ static void fill_gather_args(std::vector<std::unique_ptr<DevBlock>> &blocks, Blo
   g.n_blocks = (int)blocks.size();
   for (size_t b = 0; b < blocks.size(); b++) {
     g.map[b] = blocks[b]->map.p;
-    g.rec[b] = blocks[b]->rec.p;
+    g.rec[b] = blocks[b]->qc.p ? blocks[b]->qc.p : blocks[b]->rec.p;
+    g.stride[b] = blocks[b]->qc.p ? 1 : BLOCK_REC;
   }
 }
 

@@ -2375,6 +2375,7 @@ struct BlockGatherArgs {
   int n_blocks;
   const int32_t *map[MAX_BLOCKS];
   const double *rec[MAX_BLOCKS];
+  int stride[MAX_BLOCKS];  // doubles between two block rows' q_B in rec[b]: BLOCK_REC (the 64-byte records) or 1 (a compact copy)
 };
 
 // thread per row: the right shape for one-hot / few-nnz rows (coalesced over consecutive rows).
@@ -2399,7 +2400,7 @@ __global__ __launch_bounds__(WG) void k_qbuild_rows(const int32_t *__restrict__ 
   }
   double s = 0.0;
   for (int64_t p = b; p < e; p++) s += (UNIT ? 1.0 : val[p]) * vf[colidx[p]];
-  for (int bi = 0; bi < blk.n_blocks; bi++) s += blk.rec[bi][(int64_t)blk.map[bi][i] * BLOCK_REC];  // :335-337
+  for (int bi = 0; bi < blk.n_blocks; bi++) s += blk.rec[bi][(int64_t)blk.map[bi][i] * blk.stride[bi]];  // :335-337
   if (map_prev) {
     // the re-sync the last block of the PREVIOUS factor still owes (FMTrainer.hpp:473-480; its (q_B, q_S) of that factor were
     // saved before the row caches were rebuilt): the residual term uses the old q, which this pass then overwrites
@@ -2425,7 +2426,7 @@ __global__ __launch_bounds__(WG) void k_qbuild_wave(const int32_t *__restrict__ 
   for (int32_t p = b + lane; p < e; p += WAVE) s += val[p] * vf[colidx[p]];
   s = wave_allreduce_sum(s);
   if (lane == 0) {
-    for (int bi = 0; bi < blk.n_blocks; bi++) s += blk.rec[bi][(int64_t)blk.map[bi][i] * BLOCK_REC];
+    for (int bi = 0; bi < blk.n_blocks; bi++) s += blk.rec[bi][(int64_t)blk.map[bi][i] * blk.stride[bi]];
     eq[i].y = s;
   }
 }
