@@ -195,3 +195,47 @@ def test_mt19937_jump_ahead_polynomials():
 
     assert _myfm.mt_jump_selftest(64, 3, 12345) == 0
     assert _myfm.mt_jump_selftest(512, 2, 7) == 0
+
+
+def test_native_row_sort_helpers(built):
+    # fit()'s row preparation (estimators._device_row_order): stable counting sort by the first stored column and the
+    # threaded CSR row gather must agree with numpy's stable argsort / scipy's fancy indexing, for int32 and int64 index
+    # arrays, ragged rows and explicit values
+    from myfm_amd import _myfm
+
+    rng = np.random.default_rng(3)
+    n, d = 5000, 37
+    lens = rng.integers(1, 5, size=n)
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(d, size=k, replace=False)) for k in lens]).astype(np.int32)
+    data = rng.normal(size=indices.size)
+    X = sps.csr_matrix((data, indices, indptr), shape=(n, d))
+    first = X.indices[X.indptr[:-1]]
+    for ptr_t in (np.int32, np.int64):
+        order = _myfm.row_order_by_first_column(X.indptr.astype(ptr_t), X.indices, d)
+        assert order.dtype == np.int64 and np.array_equal(order, np.argsort(first, kind="stable"))
+        ptr, idx, val = _myfm.permute_csr_rows(X.indptr.astype(ptr_t), X.indices, X.data, order)
+        Y = sps.csr_matrix((val, idx, ptr), shape=X.shape)
+        Z = X[order]
+        assert np.array_equal(Y.indptr, Z.indptr) and np.array_equal(Y.indices, Z.indices) and np.array_equal(Y.data, Z.data)
+    with pytest.raises(ValueError, match="no stored entry"):
+        _myfm.row_order_by_first_column(np.array([0, 1, 1]), np.array([0], dtype=np.int32), 3)
+    with pytest.raises(ValueError, match="out of range"):
+        _myfm.permute_csr_rows(X.indptr, X.indices, X.data, np.array([n], dtype=np.int64))
+    from myfm_amd.estimators import _device_row_order
+
+    assert _device_row_order(X[np.argsort(first, kind="stable")]) is None  # already sorted: nothing to do
+    assert np.array_equal(_device_row_order(X), np.argsort(first, kind="stable"))
+
+
+def test_cutpoint_groups_accept_index_arrays(built):
+    # set_cutpoint_groups takes the reference's list-of-lists (declare_module.hpp:139-156) and numpy index arrays
+    from myfm_amd import _myfm
+
+    b = _myfm.ConfigBuilder().set_identical_groups(2).set_n_iter(3).set_n_kept_samples(1).set_task_type(_myfm.TaskType.ORDERED)
+    assert isinstance(b.set_cutpoint_groups([(3, [0, 1, 2]), (4, [3, 4])]).build(), _myfm.FMLearningConfig)
+    assert isinstance(b.set_cutpoint_groups([(3, np.arange(3)), (4, np.array([3, 4], dtype=np.int32))]).build(), _myfm.FMLearningConfig)
+    with pytest.raises(ValueError, match="negative row index"):
+        b.set_cutpoint_groups([(3, np.array([0, -1]))])
+    with pytest.raises(ValueError, match="expected"):
+        b.set_cutpoint_groups([(3,)])
