@@ -2369,6 +2369,137 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_apply(SweepArgs a, ChainBatch 
   }
 }
 
+// ---- cold update of batch b and cold statistics of batch b + 1 in ONE launch ----------------------------------------------
+// Both touch block-row records only, so the rows are split into CB_BUCKETS contiguous ranges and workgroup w owns range w in
+// both halves (the batches' cold entries and hot rows are bucketed by row range on the host): the statistics of batch b + 1
+// depend on the update of batch b only through rows of the same range, i.e. through this workgroup -- a workgroup barrier
+// replaces the kernel boundary (two launches per batch instead of three). Bp.ncols == 0: nothing to update (first batch);
+// Bn.ncols == 0: no statistics to take (after the last batch).
+constexpr int CB_BUCKETS = 16;
+template <class P>
+__global__ __launch_bounds__(CHAINB_NT) void k_cb_step(SweepArgs a, ChainBatch Bp, int ip, ChainBatch Bn, int in_, const int32_t *__restrict__ cols,
+                                                       const int32_t *__restrict__ bk_ptr, const int32_t *__restrict__ bk_row,
+                                                       const int32_t *__restrict__ bk_lcol, const double *__restrict__ bk_x,
+                                                       const int32_t *__restrict__ hbk_ptr, const int32_t *__restrict__ hot_rows,
+                                                       const double2 *__restrict__ oldnew_g, double2 *__restrict__ part_g,
+                                                       const double2 *__restrict__ hot_pack_p, double2 *__restrict__ hot_pack_n) {
+  constexpr int NT = CHAINB_NT, NW = NT / WAVE, MC = CHAINB_MAXCOLS, U = 4, NB = CB_BUCKETS;
+  constexpr int rec2_g = P::REC_DOUBLES / 2;
+  __shared__ double2 on[MC];
+  __shared__ double c_old[MC];
+  __shared__ double2 part[MC * NW];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, w = blockIdx.x;
+  const int rec2_global = P::REC_DOUBLES > 2 ? a.rec2 : 1;
+  if (tid < Bp.ncols) on[tid] = oldnew_g[tid];
+  if (tid < Bn.ncols) c_old[tid] = a.theta[cols[Bn.col0 + tid]];
+  for (int i = tid; i < MC * NW; i += NT) part[i] = make_double2(0.0, 0.0);
+  // the first round of the statistics half's entries is requested now: it does not depend on the update half, and after the
+  // barrier only the record gather is left of that half's dependent loads
+  const int cbn = Bn.ncols > 0 ? bk_ptr[in_ * (NB + 1) + w] : 0, cen = Bn.ncols > 0 ? bk_ptr[in_ * (NB + 1) + w + 1] : 0;
+  int lc0[U], row0[U];
+  double xv0[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int p = cbn + wv * WAVE * U + u * WAVE + lane;
+    lc0[u] = -1 - lane;
+    row0[u] = -1;
+    xv0[u] = 0.0;
+    if (p < cen) {
+      lc0[u] = bk_lcol[p];
+      row0[u] = bk_row[p];
+      xv0[u] = bk_x[p];
+    }
+  }
+  __syncthreads();
+  if (Bp.ncols > 0) {
+    const int hb = hbk_ptr[ip * (NB + 1) + w], he = hbk_ptr[ip * (NB + 1) + w + 1];
+    for (int i = hb * rec2_g + tid; i < he * rec2_g; i += NT) {
+      const int slot = i / rec2_g, q = i - slot * rec2_g;
+      ((double2 *)a.state)[(int64_t)hot_rows[Bp.hot_row0 + slot] * rec2_global + q] = hot_pack_p[i];
+    }
+    const int cb = bk_ptr[ip * (NB + 1) + w], ce = bk_ptr[ip * (NB + 1) + w + 1];
+    for (int base = cb + tid; base < ce; base += NT * U) {
+      int lc[U], row[U];
+      double xv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int p = base + u * NT;
+        row[u] = -1;
+        lc[u] = 0;
+        xv[u] = 0.0;
+        if (p < ce) {
+          lc[u] = bk_lcol[p];
+          row[u] = bk_row[p];
+          xv[u] = bk_x[p];
+        }
+      }
+      typename P::St st[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (row[u] >= 0) st[u] = P::load(a, row[u]);
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (row[u] >= 0) P::apply(a, row[u], xv[u], st[u], on[lc[u]].x, on[lc[u]].y);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();  // this range's records are up to date for everything below (the only reader of them is this workgroup)
+  if (Bn.ncols > 0) {
+    const int hb = hbk_ptr[in_ * (NB + 1) + w], he = hbk_ptr[in_ * (NB + 1) + w + 1];
+    for (int i = hb * rec2_g + tid; i < he * rec2_g; i += NT) {
+      const int slot = i / rec2_g, q = i - slot * rec2_g;
+      hot_pack_n[i] = ((const double2 *)a.state)[(int64_t)hot_rows[Bn.hot_row0 + slot] * rec2_global + q];
+    }
+    const int cb = cbn, ce = cen;
+    for (int base = cb + wv * WAVE * U; base < ce; base += NW * WAVE * U) {
+      int lc[U], row[U];
+      double xv[U];
+      const bool first = base == cb + wv * WAVE * U;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int p = base + u * WAVE + lane;
+        lc[u] = first ? lc0[u] : -1 - lane;
+        row[u] = first ? row0[u] : -1;
+        xv[u] = first ? xv0[u] : 0.0;
+        if (!first && p < ce) {
+          lc[u] = bk_lcol[p];
+          row[u] = bk_row[p];
+          xv[u] = bk_x[p];
+        }
+      }
+      typename P::St st[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (row[u] >= 0) st[u] = P::load(a, row[u]);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (base + u * WAVE >= ce) break;  // wave-uniform
+        double s1 = 0.0, s2 = 0.0;
+        if (row[u] >= 0) P::stats(xv[u], st[u], c_old[lc[u]], s1, s2);
+        const int lp = dpp_i32<0x138, 0xf>(lc[u], 0), ln = dpp_i32<0x130, 0xf>(lc[u], 0);
+        const bool head = lane == 0 || lp != lc[u], tail = lane == 63 || ln != lc[u];
+        int f = head ? 1 : 0;
+        wave_segscan2(s1, s2, f);
+        if (row[u] >= 0 && tail) {  // one lane per column of this tile; a wave adds its tiles in program order
+          double2 &q = part[lc[u] * NW + wv];
+          q.x += s1;
+          q.y += s2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < MC) {
+      double S1 = 0.0, S2 = 0.0;
+      if (tid < Bn.ncols)
+        for (int k = 0; k < NW; k++) {  // wave order: deterministic
+          S1 += part[tid * NW + k].x;
+          S2 += part[tid * NW + k].y;
+        }
+      part_g[(size_t)w * MC + tid] = make_double2(S1, S2);
+    }
+  }
+}
+
 // ---- q-cache build: q = X v_f (+ block contributions)  (FMTrainer.hpp:320-340), CSR SpMV --------
 constexpr int MAX_BLOCKS = 16;
 struct BlockGatherArgs {

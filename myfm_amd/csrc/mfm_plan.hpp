@@ -110,6 +110,10 @@ struct ChainRun {
   int64_t n_cold = 0;
   DevBuf<int32_t> cold_ptr, cold_row, cold_lcol, hot_ptr, hot_slot, hot_rows;
   DevBuf<double> cold_x, hot_x;
+  // row-bucketed copies for k_cb_step: per batch the cold entries ordered by (row range, column) and the hot slots' row ranges
+  bool bucketed = false;
+  DevBuf<int32_t> bk_ptr, bk_row, bk_lcol, hbk_ptr;
+  DevBuf<double> bk_x;
   mutable DevBuf<int32_t> col_group;             // group index of every chain column (filled at the first launch)
   mutable const int32_t *col_group_of = nullptr;  // ... from this group array
 
@@ -146,14 +150,14 @@ struct ChainRun {
       B.ncols = (int32_t)(e - c);
       B.hot_row0 = (int32_t)hrows.size();
       int ns = 0;
-      for (size_t k = c; k < e; k++) {  // hot slots in order of first appearance
-        const int32_t j = run[k];
-        for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) {
-          const int32_t r = csc.idx[p];
-          if (cnt[r] > 1 && slot_of[r] < 0) {
-            slot_of[r] = ns++;
-            hrows.push_back(r);
-          }
+      {  // hot slots in ascending row order (k_cb_step splits them by row range)
+        std::vector<int32_t> hr;
+        for (int32_t r : touched)
+          if (cnt[r] > 1) hr.push_back(r);
+        std::sort(hr.begin(), hr.end());
+        for (int32_t r : hr) {
+          slot_of[r] = ns++;
+          hrows.push_back(r);
         }
       }
       B.n_hot = ns;
@@ -201,6 +205,43 @@ struct ChainRun {
     hot_x.upload(hx);
     hot_rows.upload(hrows);
     batched = true;
+    // the grid form (k_cb_*) also gets the row-bucketed copies
+    const int64_t grid_min = std::getenv("MFM_CHAIN_GRID_MIN") ? std::atoll(std::getenv("MFM_CHAIN_GRID_MIN")) : 4096;
+    if (n_batches > 0 && n_cold / n_batches >= grid_min && !std::getenv("MFM_NO_CHAIN_GRID") && !std::getenv("MFM_NO_CB_MERGE")) {
+      constexpr int NB = CB_BUCKETS;
+      auto bucket = [&](int32_t r) { return (int)(((int64_t)r * NB) / std::max<int64_t>(n_rows, 1)); };
+      std::vector<int32_t> bptr((size_t)n_batches * (NB + 1), 0), hbptr((size_t)n_batches * (NB + 1), 0);
+      std::vector<int32_t> brow(crow.size()), blcol(crow.size());
+      std::vector<double> bx(crow.size());
+      for (int b = 0; b < n_batches; b++) {
+        const ChainBatch &B = bt[b];
+        const int cb = B.cold_b, ce = B.cold_e;
+        int cntb[NB + 1] = {0};
+        for (int p = cb; p < ce; p++) cntb[bucket(crow[p]) + 1]++;
+        int32_t *bp = bptr.data() + (size_t)b * (NB + 1);
+        bp[0] = cb;
+        for (int k = 0; k < NB; k++) bp[k + 1] = bp[k] + cntb[k + 1];
+        int cur[NB];
+        for (int k = 0; k < NB; k++) cur[k] = bp[k];
+        for (int p = cb; p < ce; p++) {  // (entries arrive ordered by column: stable => (range, column) order)
+          const int q = cur[bucket(crow[p])]++;
+          brow[q] = crow[p];
+          blcol[q] = clcol[p];
+          bx[q] = cx[p];
+        }
+        int32_t *hp = hbptr.data() + (size_t)b * (NB + 1);
+        int hc[NB + 1] = {0};
+        for (int k = 0; k < B.n_hot; k++) hc[bucket(hrows[B.hot_row0 + k]) + 1]++;
+        hp[0] = 0;
+        for (int k = 0; k < NB; k++) hp[k + 1] = hp[k] + hc[k + 1];  // (slots are in ascending row order)
+      }
+      bk_ptr.upload(bptr);
+      hbk_ptr.upload(hbptr);
+      bk_row.upload(brow);
+      bk_lcol.upload(blcol);
+      bk_x.upload(bx);
+      bucketed = true;
+    }
   }
 };
 
@@ -1166,7 +1207,8 @@ struct LongScratch {
   DevBuf<double> told_col;     // multi-level fused flow: current coefficient per column of the level whose statistics are taken
   std::vector<DevBuf<double>> vnext_lvl;  // ... and per tile level: next factor's coefficient per column (MULTIQ)
   DevBuf<double2> cb_part, cb_oldnew;  // grid-batched chains: per-workgroup column partials, (old, new) per column of a batch
-  DevBuf<double2> cb_hot;              // ... and the batch's hot records, packed (k_cb_stats -> k_cb_hot -> k_cb_apply)
+  DevBuf<double2> cb_hot, cb_hot2;     // ... and the batch's hot records, packed (k_cb_stats -> k_cb_hot -> k_cb_apply; two: k_cb_step
+                                       //     reads the previous batch's while it packs the next one's)
   DevBuf<double2> dv_col;      // two-field pass: (delta of this factor, coefficient of the next) per second-level column
   void reserve_cols(int64_t n_cols) {
     if ((size_t)n_cols > oldnew_col.n) {
@@ -1295,6 +1337,25 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
           }
           const size_t lds_h = (size_t)std::max(C.max_hot, 1) * rec2_l * sizeof(double2) + 5 * CHAINB_MAXCOLS * sizeof(double) +
                                (size_t)CHAINB_MAXCOLS * sizeof(double2) + (size_t)mhe * 12 + (CHAINB_MAXCOLS + 2) * sizeof(int);
+          if (C.bucketed) {
+            // two launches per batch: k_cb_step = cold update of the batch before + cold statistics of this one, by row range
+            if (ls.cb_hot2.n < hot16) ls.cb_hot2.alloc(hot16);
+            if (ls.cb_part.n < (size_t)CB_BUCKETS * CHAINB_MAXCOLS) ls.cb_part.alloc((size_t)CB_BUCKETS * CHAINB_MAXCOLS);
+            const ChainBatch none{0, 0, 0, 0, 0, 0, 0, 0};
+            double2 *pack[2] = {ls.cb_hot.p, ls.cb_hot2.p};
+            for (int bi = 0; bi <= C.n_batches; bi++) {
+              const ChainBatch &Bp = bi > 0 ? C.h_batches[bi - 1] : none;
+              const ChainBatch &Bn = bi < C.n_batches ? C.h_batches[bi] : none;
+              hipLaunchKernelGGL((k_cb_step<P>), dim3(CB_BUCKETS), dim3(CHAINB_NT), 0, s, a, Bp, bi - 1, Bn, bi, C.cols.p, C.bk_ptr.p,
+                                 C.bk_row.p, C.bk_lcol.p, C.bk_x.p, C.hbk_ptr.p, C.hot_rows.p, ls.cb_oldnew.p, ls.cb_part.p,
+                                 pack[(bi + 1) & 1], pack[bi & 1]);
+              if (bi < C.n_batches)
+                hipLaunchKernelGGL((k_cb_hot<P>), dim3(1), dim3(CHAINB_NT), lds_h, s, a, Bn, C.cols.p, C.hot_ptr.p, C.hot_slot.p,
+                                   C.hot_x.p, pack[bi & 1], C.col_group.p, std::max(C.max_hot, 1), mhe, ls.cb_part.p, CB_BUCKETS,
+                                   ls.cb_oldnew.p);
+            }
+            continue;
+          }
           for (int bi = 0; bi < C.n_batches; bi++) {
             const ChainBatch &B = C.h_batches[bi];
             const int ncold = C.h_cold_cnt[bi];
