@@ -2256,7 +2256,8 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_hot(SweepArgs a, ChainBatch B,
                                                       const double *__restrict__ hot_x, double2 *__restrict__ hot_pack,
                                                       const int32_t *__restrict__ col_group, int max_hot, int max_hot_ent,
                                                       const double2 *__restrict__ part_g, int n_part,
-                                                      double2 *__restrict__ oldnew_g /* [CHAINB_MAXCOLS] */) {
+                                                      double2 *__restrict__ oldnew_g /* [CHAINB_MAXCOLS] */,
+                                                      const double *__restrict__ colpack = nullptr) {
   extern __shared__ double2 lds_hot[];
   constexpr int NT = CHAINB_NT, MC = CHAINB_MAXCOLS;
   constexpr int rec2_g = P::REC_DOUBLES / 2;
@@ -2272,12 +2273,19 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_hot(SweepArgs a, ChainBatch B,
   al.state = lds_hot;
   al.rec2 = rec2_l;
   if (tid < B.ncols) {  // (first: the longest dependent chain of the prologue, column -> coefficient / variate, group -> lambda / mu)
-    const int j = cols[B.col0 + tid];
-    const int g = col_group[B.col0 + tid];
-    c_old[tid] = a.theta[j];
-    c_z[tid] = a.z[j];
-    c_lam[tid] = a.lambda[g];
-    c_mu[tid] = a.mu[g];
+    if (colpack) {      //  ... or one load each when k_cb_step packed them)
+      c_old[tid] = colpack[tid];
+      c_z[tid] = colpack[MC + tid];
+      c_lam[tid] = colpack[2 * MC + tid];
+      c_mu[tid] = colpack[3 * MC + tid];
+    } else {
+      const int j = cols[B.col0 + tid];
+      const int g = col_group[B.col0 + tid];
+      c_old[tid] = a.theta[j];
+      c_z[tid] = a.z[j];
+      c_lam[tid] = a.lambda[g];
+      c_mu[tid] = a.mu[g];
+    }
   }
   for (int i = tid; i < B.n_hot * rec2_g; i += NT) {
     const int slot = i / rec2_g, w = i - slot * rec2_g;
@@ -2382,7 +2390,8 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_step(SweepArgs a, ChainBatch B
                                                        const int32_t *__restrict__ bk_lcol, const double *__restrict__ bk_x,
                                                        const int32_t *__restrict__ hbk_ptr, const int32_t *__restrict__ hot_rows,
                                                        const double2 *__restrict__ oldnew_g, double2 *__restrict__ part_g,
-                                                       const double2 *__restrict__ hot_pack_p, double2 *__restrict__ hot_pack_n) {
+                                                       const double2 *__restrict__ hot_pack_p, double2 *__restrict__ hot_pack_n,
+                                                       const int32_t *__restrict__ col_group, double *__restrict__ colpack) {
   constexpr int NT = CHAINB_NT, NW = NT / WAVE, MC = CHAINB_MAXCOLS, U = 4, NB = CB_BUCKETS;
   constexpr int rec2_g = P::REC_DOUBLES / 2;
   __shared__ double2 on[MC];
@@ -2391,7 +2400,18 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_step(SweepArgs a, ChainBatch B
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, w = blockIdx.x;
   const int rec2_global = P::REC_DOUBLES > 2 ? a.rec2 : 1;
   if (tid < Bp.ncols) on[tid] = oldnew_g[tid];
-  if (tid < Bn.ncols) c_old[tid] = a.theta[cols[Bn.col0 + tid]];
+  if (tid < Bn.ncols) {
+    const int j = cols[Bn.col0 + tid];
+    const double th = a.theta[j];
+    c_old[tid] = th;
+    if (w == 0) {  // the hot walk's per-column scalars, packed: k_cb_hot reads them with one round trip
+      const int g = col_group[Bn.col0 + tid];
+      colpack[tid] = th;
+      colpack[MC + tid] = a.z[j];
+      colpack[2 * MC + tid] = a.lambda[g];
+      colpack[3 * MC + tid] = a.mu[g];
+    }
+  }
   for (int i = tid; i < MC * NW; i += NT) part[i] = make_double2(0.0, 0.0);
   // the first round of the statistics half's entries is requested now: it does not depend on the update half, and after the
   // barrier only the record gather is left of that half's dependent loads

@@ -1207,6 +1207,7 @@ struct LongScratch {
   DevBuf<double> told_col;     // multi-level fused flow: current coefficient per column of the level whose statistics are taken
   std::vector<DevBuf<double>> vnext_lvl;  // ... and per tile level: next factor's coefficient per column (MULTIQ)
   DevBuf<double2> cb_part, cb_oldnew;  // grid-batched chains: per-workgroup column partials, (old, new) per column of a batch
+  DevBuf<double> cb_colpack;           // ... the batch's per-column scalars (old coefficient, variate, lambda, mu), packed
   DevBuf<double2> cb_hot, cb_hot2;     // ... and the batch's hot records, packed (k_cb_stats -> k_cb_hot -> k_cb_apply; two: k_cb_step
                                        //     reads the previous batch's while it packs the next one's)
   DevBuf<double2> dv_col;      // two-field pass: (delta of this factor, coefficient of the next) per second-level column
@@ -1340,6 +1341,7 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
           if (C.bucketed) {
             // two launches per batch: k_cb_step = cold update of the batch before + cold statistics of this one, by row range
             if (ls.cb_hot2.n < hot16) ls.cb_hot2.alloc(hot16);
+            if (ls.cb_colpack.n < (size_t)4 * CHAINB_MAXCOLS) ls.cb_colpack.alloc((size_t)4 * CHAINB_MAXCOLS);
             if (ls.cb_part.n < (size_t)CB_BUCKETS * CHAINB_MAXCOLS) ls.cb_part.alloc((size_t)CB_BUCKETS * CHAINB_MAXCOLS);
             const ChainBatch none{0, 0, 0, 0, 0, 0, 0, 0};
             double2 *pack[2] = {ls.cb_hot.p, ls.cb_hot2.p};
@@ -1348,11 +1350,11 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
               const ChainBatch &Bn = bi < C.n_batches ? C.h_batches[bi] : none;
               hipLaunchKernelGGL((k_cb_step<P>), dim3(CB_BUCKETS), dim3(CHAINB_NT), 0, s, a, Bp, bi - 1, Bn, bi, C.cols.p, C.bk_ptr.p,
                                  C.bk_row.p, C.bk_lcol.p, C.bk_x.p, C.hbk_ptr.p, C.hot_rows.p, ls.cb_oldnew.p, ls.cb_part.p,
-                                 pack[(bi + 1) & 1], pack[bi & 1]);
+                                 pack[(bi + 1) & 1], pack[bi & 1], C.col_group.p, ls.cb_colpack.p);
               if (bi < C.n_batches)
                 hipLaunchKernelGGL((k_cb_hot<P>), dim3(1), dim3(CHAINB_NT), lds_h, s, a, Bn, C.cols.p, C.hot_ptr.p, C.hot_slot.p,
                                    C.hot_x.p, pack[bi & 1], C.col_group.p, std::max(C.max_hot, 1), mhe, ls.cb_part.p, CB_BUCKETS,
-                                   ls.cb_oldnew.p);
+                                   ls.cb_oldnew.p, ls.cb_colpack.p);
             }
             continue;
           }
