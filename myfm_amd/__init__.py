@@ -10,7 +10,8 @@ import os as _os
 _here = _os.path.dirname(_os.path.abspath(__file__))
 if not any(f.startswith("_myfm.") and f.endswith(".so") for f in _os.listdir(_here)):
     raise ImportError(
-        "myfm_amd._myfm is not built. Run `python -m myfm_amd._build` (needs hipcc for gfx950 and g++). "
+        "myfm_amd._myfm is not built. Run `python myfm_amd/_build.py` or `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(needs hipcc for gfx950 and g++). "
         "The package has no pure-Python / CPU fallback."
     )
 
