@@ -13,6 +13,12 @@ def pytest_configure(config):
     # every row-tile layout the planner packs on the device is also packed on the host and compared array by array
     # (mfm_plan.hpp build_scattered): a mismatch fails mfm_finalize of the test that built it
     os.environ.setdefault("MFM_PLAN_CHECK", "1")
+    # a fresh checkout has no built extension yet (the .so files are git-ignored): build in-tree once
+    pkg = os.path.join(ROOT, "myfm_amd")
+    if not any(f.startswith("_myfm.") and f.endswith(".so") for f in os.listdir(pkg)):
+        import __graft_entry__ as g
+
+        g.build()
 
 
 @pytest.fixture(scope="session")
