@@ -153,6 +153,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if not any(f.startswith("_myfm.") and f.endswith(".so") for f in os.listdir(os.path.join(ROOT, "myfm_amd"))):
+        import __graft_entry__ as _g  # (a tree without the built extension: build it in place, hipcc cross-compiles)
+
+        _g.build()
     from myfm_amd import _capi, _myfm
     from tests import datasets as ds
 
