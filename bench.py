@@ -5,7 +5,9 @@ Default workload = BASELINE configs[2]: MovieLens-10M-shaped synthetic CSR (N = 
 features, nnz = 20 M), MyFMRegressor rank 32, fp64, the full update_all per step (BaseFMTrainer.hpp:135-152).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 without a launcher: bench.py starts its own N ranks -- python -m torch.distributed.run --nnodes=1
+     --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ... -- and passes rank 0's line through;
+     under a launcher (WORLD_SIZE set) it is one of the ranks.)
 
 N > 1: ONE chain over the SAME table, rows sharded over the N GPUs at user boundaries, the all-reduces issued by
 libmyfm_hip.so through RCCL (strong scaling: `value` = iterations/s of that chain).
@@ -94,6 +96,57 @@ def cpu_baseline(W, gi, min_seconds, max_iters):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: run the N ranks under torch.distributed.run (one process per GPU,
+    rendezvous on 127.0.0.1) and pass rank 0's single JSON line through. Returns the exit code."""
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL across processes needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith('{"metric"')]
+    for l in r.stdout.decode(errors="replace").splitlines():
+        if not l.startswith('{"metric"') and l.strip():
+            print(l, file=sys.stderr)
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return r.returncode if (r.returncode != 0 or lines) else 1
+
+
+def other_configs(budget_s):
+    """BASELINE's other workloads through the same code path, each as `bench.py --config C` in a subprocess (a fresh context,
+    bounded samples): iterations/s on the GPU next to the pinned CPU oracle. Reported inside the default line."""
+    out = {}
+    runs = [("configs[1]", ["--config", "2", "--steps", "300", "--warmup", "20", "--cpu-seconds", "3"]),
+            ("configs[3]", ["--config", "4", "--steps", "40", "--warmup", "5", "--cpu-seconds", "3"]),
+            ("configs[4] at scale 0.1", ["--config", "5", "--scale", "0.1", "--steps", "6", "--warmup", "2", "--cpu-seconds", "1"])]
+    t_all = time.time()
+    for name, args in runs:
+        if time.time() - t_all > budget_s:
+            out[name] = {"skipped": "time budget"}
+            continue
+        t0 = time.time()
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--fit-iters", "0", "--no-other-configs",
+                            "--no-kernel-timing"] + args, capture_output=True, text=True, cwd=ROOT)
+        line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+        if r.returncode != 0 or not line:
+            out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+            continue
+        d = json.loads(line[-1])
+        cpu = d.get("cpu_baseline") or {}
+        out[name] = {"workload": d["config"]["workload"], "it_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                     "cpu_it_per_s": cpu.get("value"), "cpu_iterations": cpu.get("iterations"), "cpu_pinned": cpu.get("pinned_to_one_core"),
+                     "setup_s": d["config"]["setup_s"], "wall_s": round(time.time() - t0, 1)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,7 +164,10 @@ def main():
     ap.add_argument("--fit-iters", type=int, default=100, help="iterations of the MyFM*.fit() leg (0 disables)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--weak-steps", type=int, default=20, help="N > 1: timed iterations of the weak-scaling leg (0 disables)")
+    ap.add_argument("--no-other-configs", action="store_true", help="default run (config 3, 1 GPU): skip the other_configs legs")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus))
     if a.cpu_iters == 0:
         a.cpu_seconds = 0.0
     if a.steps <= 0:
@@ -270,6 +326,7 @@ def main():
             assert torch.allclose(v, allv[0], rtol=1e-12, atol=0), ("replicas diverged", [x.tolist() for x in allv])
 
     plan_flags = int(sess.plan_flags())
+    rccl_ranks, rccl_path = sess.comm_info() if sharded else (0, "")
     # Weak-scaling leg (N > 1, config 3): the table grows with the GPUs -- rank r holds ~a.rows rows of ONE user-sorted table of
     # world * a.rows rows over the same users / items (tests/datasets.py::movielens_like_shard). Reported as an extra field;
     # `value` stays the strong-scaling rate of config 3 itself.
@@ -342,7 +399,7 @@ def main():
         roofline = {
             "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_source": src,
+            "traffic": traffic, "traffic_source": src, "traffic_measured": False,
             "traffic_gbs": round(traffic / (us * 1e-6) / 1e9, 1) if traffic else None,
             "traffic_over_algorithmic": round(traffic / (alg_bytes / launches), 3) if traffic else None,
             "avg_launch_us": round(us, 2), "launches": int(launches), "alg_bytes_per_launch": round(alg_bytes / launches),
@@ -425,9 +482,16 @@ def main():
         out["speedup_vs_cpu_baseline"] = round(it_per_s / cpu["value"], 1)
     if weak:
         out["weak_scaling"] = weak
+    if a.config == 3 and world == 1 and not a.no_other_configs and not force_sharded:
+        out["other_configs"] = other_configs(budget_s=75.0)
     if sharded:
         out["config"]["allreduce_calls_per_step"] = round(calls / a.steps, 1)
         out["config"]["rows_this_rank"] = hi - lo
+        # evidence that the collective spans the ranks: ncclCommCount of the communicator libmyfm_hip.so opened itself, and the
+        # librccl it bound (0 / "": the torch.distributed callback carried the all-reduces instead, see `parallelism`)
+        out["config"]["rccl_ranks"] = int(rccl_ranks)
+        out["config"]["rccl_path"] = rccl_path
+        out["config"]["torch_world_size"] = world
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()

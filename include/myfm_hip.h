@@ -71,8 +71,10 @@ int mfm_synchronize(mfm_ctx *ctx);
  * of every sweep (2 |level| doubles), once per (block, factor) for the block statistics, and for
  * sum e / sum e^2 and the ordered-probit likelihood terms. Must be called before mfm_finalize.        */
 int mfm_set_allreduce(mfm_ctx *ctx, int (*fn)(void *user, void *dev_buf, int64_t count), void *user);
-/* ... with the callback provider: this rank's index and the number of ranks (rank 0 contributes the replicated columns
- * to the model synchronisation; default rank 0 of 1).                                                                */
+/* ... with the callback provider: this rank's index and the number of ranks. REQUIRED together with mfm_set_allreduce
+ * (mfm_comm_init implies it): rank 0 alone contributes the replicated columns to the model synchronisation after a
+ * sharded latent sweep. A caller that never says (the older sequence mfm_set_allreduce + mfm_set_row_offset) is taken
+ * to be the root exactly when its shard starts at global row 0.                                                       */
 int mfm_set_shard(mfm_ctx *ctx, int32_t rank, int32_t world);
 /* Native provider: RCCL called from this library on the ctx stream (ncclAllReduce, fp64 sum, in place) -- no callback,
  * no interpreter in the loop. One rank obtains the 128-byte id (ncclGetUniqueId) and hands it to the others by any
@@ -82,6 +84,10 @@ int mfm_comm_unique_id(void *out128);
 int mfm_comm_init(mfm_ctx *ctx, const void *id128, int32_t rank, int32_t world);
 /* collectives issued so far and doubles they carried (either provider) */
 int mfm_comm_stats(const mfm_ctx *ctx, int64_t *calls, int64_t *doubles);
+/* native provider: the communicator's own rank count (ncclCommCount) and the path of the librccl.so that was bound
+ * (resolution order: one already mapped into the process, the directory of the HIP runtime in use, the loader's search
+ * path, /opt/rocm/lib). n_ranks = 0 and an empty path when the ctx has no native communicator.                         */
+int mfm_comm_info(const mfm_ctx *ctx, int32_t *n_ranks, char *path, int64_t path_cap);
 /* The level schedule of the main table's columns (mfm_host_column_levels of the GLOBAL design): in the
  * row-sharded mode it must be identical on every rank (a conflict may exist only in another rank's
  * rows), so the caller computes it before sharding. Checked against the local rows at mfm_finalize.

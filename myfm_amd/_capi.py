@@ -29,7 +29,7 @@ SYMBOLS = [
     "mfm_host_column_levels", "mfm_rng_seed_mt19937", "mfm_rng_set_program", "mfm_rng_prefetch", "mfm_rng_acquire",
     "mfm_rng_get_z", "mfm_design_score_ctx", "mfm_design_n_rows", "mfm_set_allreduce", "mfm_set_row_offset", "mfm_set_main_levels",
     "mfm_test_erfcx", "mfm_test_truncated_normal", "mfm_get_device", "mfm_set_shard", "mfm_comm_unique_id", "mfm_comm_init",
-    "mfm_comm_stats", "mfm_store_create", "mfm_store_destroy", "mfm_store_last_error", "mfm_store_size", "mfm_store_push_ctx",
+    "mfm_comm_stats", "mfm_comm_info", "mfm_store_create", "mfm_store_destroy", "mfm_store_last_error", "mfm_store_size", "mfm_store_push_ctx",
     "mfm_store_push_host", "mfm_store_get", "mfm_design_predict_store", "mfm_store_reserve",
 ]
 
@@ -120,6 +120,7 @@ def lib():
     L.mfm_comm_unique_id.argtypes = [P]
     L.mfm_comm_init.argtypes = [vp, P, i32, i32]
     L.mfm_comm_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.mfm_comm_info.argtypes = [vp, C.POINTER(i32), C.c_char_p, i64]
     L.mfm_store_create.argtypes = [C.c_int, i64, i32, C.POINTER(vp)]
     L.mfm_store_destroy.argtypes = [vp]
     L.mfm_store_destroy.restype = None

@@ -1573,6 +1573,14 @@ PYBIND11_MODULE(_myfm, m) {
              mfm_comm_stats(s.trainer->ctx, &c, &d);
              return py::make_tuple(c, d);
            })
+      .def("comm_info",
+           [](GibbsSession &s) {
+             int32_t n = 0;
+             char path[512];
+             if (mfm_comm_info(s.trainer->ctx, &n, path, sizeof(path)) != MFM_OK) throw std::runtime_error(mfm_global_error());
+             return py::make_tuple((int)n, std::string(path));
+           },
+           "(ranks of the library's own RCCL communicator (ncclCommCount), path of the librccl.so it bound); (0, '') without one")
       .def("step", &GibbsSession::step)
       .def("synchronize", &GibbsSession::synchronize)
       .def("residual", &GibbsSession::residual)

@@ -550,20 +550,20 @@ static void block_unsync(hipStream_t s, Timing &tm, DevBlock &B, int64_t N, doub
   if (B.stream_unsync && N > 0) {
     constexpr int NS = IS_W ? 1 : 4;
     const size_t lds = (size_t)B.B * NS * sizeof(double);
-    static bool raised = false;
-    if (!raised) {
+    static DeviceOnce raised;
+    if (raised.need()) {
       MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_unsync_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(UNSYNC_STREAM_MAX_B * 4 * sizeof(double))));
       MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_unsync_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(UNSYNC_STREAM_MAX_B * sizeof(double))));
-      raised = true;
+      raised.mark();
     }
     if (pending_resync && !IS_W) {
-      static bool raised2 = false;
-      if (!raised2) {
+      static DeviceOnce raised2;
+      if (raised2.need()) {
         MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_unsync_stream<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(UNSYNC_STREAM_MAX_B * 4 * sizeof(double))));
-        raised2 = true;
+        raised2.mark();
       }
       hipLaunchKernelGGL((k_unsync_stream<false, true>), dim3(B.stream_wgs), dim3(WG), lds, s, B.map.p, eq, B.rec.p, N, (int)B.B,
                          B.stream_rows_per_wg, B.stream_partial.p, pending_resync->map.p, pending_resync->rec.p);

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -16,6 +17,26 @@ namespace mfm {
 struct Error : std::runtime_error {
   int code;
   Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+// "done once" per DEVICE: kernel function attributes (hipFuncAttributeMaxDynamicSharedMemorySize) belong to the device
+// that was current when they were set; a process that opens contexts on several GPUs must raise them on each. Racing
+// threads may both find need() true: setting an attribute twice is harmless.
+struct DeviceOnce {
+  std::atomic<unsigned long long> done[4] = {};
+  static int current() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d & 255;
+  }
+  bool need() const {
+    const int d = current();
+    return !(done[d >> 6].load(std::memory_order_acquire) & (1ull << (d & 63)));
+  }
+  void mark() {
+    const int d = current();
+    done[d >> 6].fetch_or(1ull << (d & 63), std::memory_order_release);
+  }
 };
 
 #define MFM_HIP_CHECK(expr)                                                                                   \

@@ -513,6 +513,7 @@ int mfm_comm_init(mfm_ctx *ctx, const void *id128, int32_t rank, int32_t world) 
   ctx->comm.stream = ctx->stream;
   ctx->comm.rank = rank;
   ctx->comm.world = world;
+  ctx->comm.shard_set = true;
   MFM_CATCH(ctx)
 }
 
@@ -521,7 +522,29 @@ int mfm_set_shard(mfm_ctx *ctx, int32_t rank, int32_t world) {
   if (world < 1 || rank < 0 || rank >= world) throw Error(MFM_ERR_INVALID, "bad rank / world size");
   ctx->comm.rank = rank;
   ctx->comm.world = world;
+  ctx->comm.shard_set = true;
   MFM_CATCH(ctx)
+}
+
+int mfm_comm_info(const mfm_ctx *ctx, int32_t *n_ranks, char *path, int64_t path_cap) {
+  // evidence for a scaling run: the communicator's own rank count (ncclCommCount) and the librccl that carries it
+  if (n_ranks) *n_ranks = 0;
+  if (path && path_cap > 0) path[0] = 0;
+  if (!ctx || !ctx->comm.nccl) return MFM_OK;
+  try {
+    Rccl &r = Rccl::get();
+    int n = 0;
+    if (r.CommCount) r.check(r.CommCount(ctx->comm.nccl, &n), "ncclCommCount");
+    if (n_ranks) *n_ranks = n;
+    if (path && path_cap > 0) {
+      std::strncpy(path, r.path.c_str(), (size_t)path_cap - 1);
+      path[path_cap - 1] = 0;
+    }
+    return MFM_OK;
+  } catch (const std::exception &ex) {
+    g_global_error = ex.what();
+    return MFM_ERR_RUNTIME;
+  }
 }
 
 int mfm_comm_stats(const mfm_ctx *ctx, int64_t *calls, int64_t *doubles) {
@@ -692,8 +715,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     }
     c->plan_V.group_of = &c->hgroup;
     // the row-tile layouts of scattered levels are packed on the device from the device-resident CSC
-    static thread_local DevCscView dev_view;
-    dev_view = DevCscView{c->X.colptr.p, c->X.rowidx.p, c->X.cval.p, c->stream};
+    DevCscView dev_view = DevCscView{c->X.colptr.p, c->X.rowidx.p, c->X.cval.p, c->stream};
     dev_view.rowptr = c->X.rowptr.p;
     dev_view.colidx = c->X.colidx.p;
     dev_view.n_rows = c->N;
@@ -723,7 +745,10 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
         c->sharded_fused = true;
         // model synchronisation after the sweep: a non-special first-level column is contributed by the rank
         // that holds its rows, every other column (identical on all ranks) by rank 0 of the communicator
-        std::vector<double> mask((size_t)c->D, c->comm.rank == 0 ? 1.0 : 0.0);
+        // (a caller of the older sequence mfm_set_allreduce + mfm_set_row_offset never said which rank it is: the shard
+        // that starts at global row 0 is the root then)
+        const bool root = c->comm.shard_set ? c->comm.rank == 0 : c->row_offset == 0;
+        std::vector<double> mask((size_t)c->D, root ? 1.0 : 0.0);
         for (int64_t j = 0; j < c->D0; j++)
           if (c->hlevels[j] == 0 && c->plan_V.special[j] == 0) mask[j] = col_cnt[j] > 0 ? 1.0 : 0.0;
         c->sync_mask.upload(mask);
@@ -732,6 +757,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     c->plan_W.build(Xt, PMainW::R_W16, PMainW::R_WG, coop_capacity<PMainW>(), true, c->X.unit,
                     std::getenv("MFM_NO_PLAN_TWIN") ? nullptr : &c->plan_V);
     lap("plan_W");
+    c->plan_V.dev_csc = c->plan_W.dev_csc = nullptr;  // (the view lives on this frame: build() is its only reader)
     c->ls.reserve_cols(std::max(c->plan_V.max_cols_scat, c->plan_W.max_cols_scat));
     if (c->comm.active()) {
       c->ls.reserve_cols(c->D0);

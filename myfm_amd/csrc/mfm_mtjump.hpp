@@ -173,7 +173,7 @@ static inline bool build_jump_table(int blocks_per_wg, int n_entries, std::vecto
 // it costs ~0.3 s of host time (Berlekamp-Massey + n polynomial products). prefetch() starts the computation on a helper
 // thread (mfm_finalize calls it as soon as the problem size is known); get() waits for it / extends it.
 struct JumpCache {
-  std::mutex mu;
+  std::mutex mu, pmu;  // mu: the table; pmu: the `pending` future
   int blocks = 0, n = -1;
   std::vector<uint32_t> tab;
   std::future<void> pending;
@@ -196,11 +196,28 @@ struct JumpCache {
       std::lock_guard<std::mutex> g(mu);
       if (blocks == blocks_per_wg && n >= n_entries) return;
     }
-    if (pending.valid()) pending.wait();
-    pending = std::async(std::launch::async, [this, blocks_per_wg, n_entries]() { compute(blocks_per_wg, n_entries); });
+    // `pending` is only touched under pmu (two contexts finalizing at once, or a prefetch racing get()); the wait itself
+    // runs on a moved-out future, outside the lock
+    std::unique_lock<std::mutex> pl(pmu);
+    if (pending.valid()) {
+      std::future<void> prev = std::move(pending);
+      pl.unlock();
+      prev.wait();
+      pl.lock();
+    }
+    if (!pending.valid())
+      pending = std::async(std::launch::async, [this, blocks_per_wg, n_entries]() { compute(blocks_per_wg, n_entries); });
+  }
+  void wait_pending() {
+    std::future<void> prev;
+    {
+      std::lock_guard<std::mutex> pl(pmu);
+      if (pending.valid()) prev = std::move(pending);
+    }
+    if (prev.valid()) prev.wait();
   }
   bool get(int blocks_per_wg, int n_entries, std::vector<uint32_t> &out) {
-    if (pending.valid()) pending.wait();
+    wait_pending();
     {
       std::lock_guard<std::mutex> g(mu);
       if (blocks == blocks_per_wg && n >= n_entries) {

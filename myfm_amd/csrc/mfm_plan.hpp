@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -1315,13 +1316,13 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
         const size_t lds_b = (size_t)std::max(C.max_hot, 1) * rec2_l * sizeof(double2) + 5 * CHAINB_MAXCOLS * sizeof(double) +
                              (size_t)CHAINB_MAXCOLS * (CHAINB_NT / WAVE) * sizeof(double2) + (size_t)mhe * 12 +
                              (CHAINB_MAXCOLS + 2) * sizeof(int);
-        static bool raised = false;
-        if (!raised) {
+        static DeviceOnce raised;
+        if (raised.need()) {
           MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_chain_batched<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)CHAIN_LDS_MAX));
           MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_cb_hot<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)CHAIN_LDS_MAX));
-          raised = true;
+          raised.mark();
         }
         // batches with many cold entries: cold statistics / updates as grid launches (one CU cannot stream them)
         const int64_t grid_min = std::getenv("MFM_CHAIN_GRID_MIN") ? std::atoll(std::getenv("MFM_CHAIN_GRID_MIN")) : 4096;
@@ -1388,13 +1389,13 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
         const size_t lds = sizeof(double2) << L.tile_bits;
         const int nt = tile_threads(L.tile_bits);
         if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit: opt in once per kernel
-          static bool raised = false;
-          if (!raised) {
+          static DeviceOnce raised;
+          if (raised.need()) {
             MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_stats<P, UNIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)CHAIN_LDS_MAX));
             MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply<P, UNIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)CHAIN_LDS_MAX));
-            raised = true;
+            raised.mark();
           }
         }
         hipLaunchKernelGGL(k_tile_old, dim3((L.n_cols + 255) / 256), dim3(256), 0, s, a.theta, L.scols.p, L.n_cols,
@@ -1466,26 +1467,54 @@ typedef int (*mfm_allreduce_fn)(void *user, void *dev_buf, int64_t count);
 // bound at run time (dlopen) so that single-GPU use does not depend on it.
 struct Rccl {
   void *lib = nullptr;
+  std::string path;  // where the bound librccl lives (dladdr of ncclAllReduce)
   int (*GetUniqueId)(void *) = nullptr;
   int (*CommInitRank)(void **, int, mfm_nccl_id, int) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
   int (*CommDestroy)(void *) = nullptr;
+  int (*CommCount)(void *, int *) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  // Resolution order: (1) a librccl the process has already mapped (a torch process: torch/lib/librccl.so -- two RCCL copies
+  // in one process would each open their own xGMI rings), (2) the directory the HIP runtime in use was loaded from (a wheel
+  // that bundles libamdhip64 bundles its RCCL next to it), (3) the dynamic loader's search path, (4) /opt/rocm/lib.
+  static void *open_any() {
+    static const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : names)
+      if (void *h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD)) return h;
+    Dl_info di;
+    if (dladdr((const void *)&hipGetDeviceCount, &di) && di.dli_fname) {
+      std::string dir(di.dli_fname);
+      const size_t slash = dir.rfind('/');
+      if (slash != std::string::npos) {
+        dir.resize(slash + 1);
+        for (const char *n : names)
+          if (void *h = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_GLOBAL)) return h;
+      }
+    }
+    for (const char *n : names)
+      if (void *h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) return h;
+    for (const char *n : {"/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
+      if (void *h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) return h;
+    return nullptr;
+  }
   static Rccl &get() {
     static Rccl r;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     if (!r.lib) {
-      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (r.lib) break;
-      }
-      if (!r.lib) throw Error(MFM_ERR_RUNTIME, std::string("cannot load librccl.so: ") + dlerror());
-      r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
-      r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
-      r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
-      r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
-      r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+      void *h = open_any();
+      if (!h) throw Error(MFM_ERR_RUNTIME, std::string("cannot load librccl.so: ") + dlerror());
+      r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+      r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+      r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+      r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+      r.CommCount = (decltype(r.CommCount))dlsym(h, "ncclCommCount");
+      r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
       if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy)
         throw Error(MFM_ERR_RUNTIME, "librccl.so lacks the expected entry points");
+      Dl_info di;
+      if (dladdr((const void *)r.AllReduce, &di) && di.dli_fname) r.path = di.dli_fname;
+      r.lib = h;
     }
     return r;
   }
@@ -1501,6 +1530,7 @@ struct Comm {
   void *nccl = nullptr;        // ncclComm_t (mfm_comm_init)
   hipStream_t stream = nullptr;  // the ctx stream the native collective is enqueued on
   int rank = 0, world = 1;
+  bool shard_set = false;  // mfm_set_shard / mfm_comm_init told us this rank's place (else: rank 0 <=> row offset 0)
   mutable int64_t calls = 0, doubles = 0;
   bool active() const { return fn != nullptr || nccl != nullptr; }
   void allreduce(void *buf, int64_t count) const {
@@ -1653,12 +1683,12 @@ static void launch_tile_head(hipStream_t s, const ParLevel &L, const SweepArgs &
 // the fused pass keeps 256 bytes of reduction scratch behind its tile: above the default dynamic-LDS limit
 template <bool UNIT>
 static void raise_fused_lds_limit() {
-  static bool raised = false;
-  if (raised) return;
+  static DeviceOnce raised;
+  if (!raised.need()) return;
   const int lim = (int)CHAIN_LDS_MAX;
   MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply_next<UNIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
   MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply_next<UNIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-  raised = true;
+  raised.mark();
 }
 
 // fused flow, first-level columns longer than a tile: k_tile_apply_next left their tiles' partial statistics
@@ -1701,11 +1731,11 @@ static void run_sweep_soa_multi(hipStream_t s, Timing &tm, const StepPlan &plan,
   const int swz = xcd_swizzle_enabled();
   raise_fused_lds_limit<UNIT>();
   {
-    static bool raised = false;
-    if (!raised) {
+    static DeviceOnce raised;
+    if (raised.need()) {
       MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply_next<UNIT, false, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_MAX));
-      raised = true;
+      raised.mark();
     }
   }
   const int nl = (int)plan.steps.size();
@@ -1719,11 +1749,11 @@ static void run_sweep_soa_multi(hipStream_t s, Timing &tm, const StepPlan &plan,
   for (int l = 1; l < nl; l++)
     if (ls.vnext_lvl[l].n < (size_t)plan.steps[l].par.n_cols) ls.vnext_lvl[l].alloc((size_t)plan.steps[l].par.n_cols);
   {
-    static bool raised2 = false;
-    if (!raised2) {
+    static DeviceOnce raised2;
+    if (raised2.need()) {
       MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply_next<UNIT, false, true, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_MAX));
-      raised2 = true;
+      raised2.mark();
     }
   }
   auto draw = [&](int l, const SweepArgs &a, const double *theta_next) {
@@ -1834,8 +1864,8 @@ static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsO
   // two-level plan: the fused pass also produces the next factor's last-level statistics
   const int fuse_stats = fuse && plan.steps.size() == 2 && !std::getenv("MFM_NO_FUSED_STATS") ? 1 : 0;
   {
-    static bool raised = false;  // tiles beyond the default dynamic-LDS limit: opt in once
-    if (!raised && plan.tile_bits > 12) {
+    static DeviceOnce raised;  // tiles beyond the default dynamic-LDS limit: opt in once
+    if (raised.need() && plan.tile_bits > 12) {
       const int lim = (int)CHAIN_LDS_MAX;
       MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_stats<PMainV, UNIT, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -1843,7 +1873,7 @@ static void run_sweep_soa(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsO
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lim));
       MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_tile_apply<PMainV, UNIT, true, false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-      raised = true;
+      raised.mark();
     }
   }
   for (int f = f_begin; f < f_end; f++) {
@@ -1945,14 +1975,14 @@ static void run_sweep_mf(hipStream_t s, Timing &tm, const StepPlan &plan, ArgsOf
   const int nt = (1 << L.tile_bits) / KR;
   const size_t lds = mf_lds_bytes(L.tile_bits, UNIT);
   {
-    static bool raised = false;
-    if (!raised) {
+    static DeviceOnce raised;
+    if (raised.need()) {
       const int lim = (int)CHAIN_LDS_MAX;
       MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_pass<UNIT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
       MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_pass<UNIT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
       MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_long_finish<UNIT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
       MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_long_finish<UNIT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-      raised = true;
+      raised.mark();
     }
   }
   if (ls.dv_col.n < (size_t)L.n_cols) ls.dv_col.alloc((size_t)std::max(L.n_cols, 1));
@@ -2098,11 +2128,11 @@ static bool launch_mf_score(hipStream_t s, const StepPlan &plan, const SweepArgs
   const int nt = 512;
 #define MFM_MFS(G, S)                                                                                                     \
   do {                                                                                                                    \
-    static bool raised = false;                                                                                           \
-    if (!raised) {                                                                                                        \
+    static DeviceOnce raised;                                                                                           \
+    if (raised.need()) {                                                                                                        \
       MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_score<G, S, UNIT>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                         (int)CHAIN_LDS_MAX));                                                             \
-      raised = true;                                                                                                      \
+      raised.mark();                                                                                                      \
     }                                                                                                                     \
     hipLaunchKernelGGL((k_mf_score<G, S, UNIT>), dim3(L.n_tiles), dim3(nt), lds, s, m);                                     \
   } while (0)

@@ -362,10 +362,10 @@ int mfm_oprobit_eval(mfm_ctx *ctx, int32_t group, const double *gamma, double *l
   const int nt = C <= 5 ? 256 : (C <= 10 ? 128 : 64);
   const size_t lds = (size_t)C * OPROBIT_SLOTS * nt * sizeof(double);
   {
-    static bool raised = false;
-    if (!raised && lds > 64 * 1024) {
+    static DeviceOnce raised;
+    if (raised.need() && lds > 64 * 1024) {
       MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_oprobit_eval, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-      raised = true;
+      raised.mark();
     }
   }
   const int nb = (int)std::min<int64_t>(OPROBIT_BLOCKS, std::max<int64_t>(1, cdiv(g.n_rows, nt)));

@@ -49,12 +49,19 @@ class _DevView:
 class TorchAllReduce:
     """all-reduce callback for `_myfm.GibbsSession(allreduce=...)` / `mfm_set_allreduce`."""
 
-    def __init__(self, group=None, stream=None):
+    def __init__(self, group=None, stream=None, device=None):
+        import os
+
         import torch
         import torch.distributed as dist
 
         self.torch, self.dist, self.group = torch, dist, group
-        self.stream = stream if stream is not None else torch.cuda.Stream()
+        # the stream and the tensor views must live on the device of the library's context (MYFM_AMD_DEVICE, else torch's
+        # current device) -- not on whatever device torch happens to have current in this process
+        if device is None:
+            device = int(os.environ["MYFM_AMD_DEVICE"]) if "MYFM_AMD_DEVICE" in os.environ else torch.cuda.current_device()
+        self.device = int(device)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
         self.calls = 0
         self.doubles = 0
 
@@ -63,9 +70,10 @@ class TorchAllReduce:
         return self.stream.cuda_stream
 
     def __call__(self, ptr, count):
-        t = self.torch.as_tensor(_DevView(ptr, count), device="cuda")
-        with self.torch.cuda.stream(self.stream):
-            self.dist.all_reduce(t, group=self.group)
+        with self.torch.cuda.device(self.device):
+            t = self.torch.as_tensor(_DevView(ptr, count), device=self.torch.device("cuda", self.device))
+            with self.torch.cuda.stream(self.stream):
+                self.dist.all_reduce(t, group=self.group)
         self.calls += 1
         self.doubles += int(count)
 

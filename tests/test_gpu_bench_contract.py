@@ -10,8 +10,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, capture_output=True, text=True, timeout=900)
+def _run(*args, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines  # native libraries' banners must not reach stdout
@@ -19,7 +20,7 @@ def _run(*args):
 
 
 def test_bench_line_small_config3():
-    d = _run("--rows", "300000", "--steps", "4", "--warmup", "2", "--cpu-seconds", "2", "--fit-iters", "3")
+    d = _run("--rows", "300000", "--steps", "4", "--warmup", "2", "--cpu-seconds", "2", "--fit-iters", "3", "--no-other-configs")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -40,3 +41,25 @@ def test_bench_line_small_config3():
 def test_bench_line_relation_blocks():
     d = _run("--config", "4", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--fit-iters", "0")
     assert d["config"]["relation_blocks"] and d["value"] > 0 and d["cpu_baseline"] is None
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE (the driver's scaling command): bench.py spawns the two
+    ranks itself and prints rank 0's single line. On a 1-GPU box both ranks share device 0 and the library's all-reduces go
+    through torch.distributed / gloo (RCCL refuses two ranks on one device)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MYFM_BENCH_BACKEND="gloo", MYFM_BENCH_DEVICE="0")
+    d = _run("--gpus", "2", "--rows", "300000", "--steps", "3", "--warmup", "1", "--weak-steps", "2", env=env)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "strong"
+    c = d["config"]
+    assert c["torch_world_size"] == 2 and c["allreduce_calls_per_step"] > 0 and c["rows_this_rank"] < c["rows"]
+    assert c["rccl_ranks"] == 0 and c["rccl_path"] == ""  # (gloo carried the collectives here; on N GPUs: rccl_ranks == N)
+    assert d["weak_scaling"]["it_per_s"] > 0
+
+
+def test_bench_sharded_world1_reports_the_rccl_communicator():
+    """world = 1 through the library's own RCCL communicator: the line proves which librccl carried the all-reduces."""
+    env = dict(os.environ, MYFM_BENCH_FORCE_SHARDED="1")
+    d = _run("--rows", "300000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--fit-iters", "0", "--weak-steps", "0", env=env)
+    c = d["config"]
+    assert c["rccl_ranks"] == 1 and "librccl" in c["rccl_path"], c
