@@ -14,7 +14,7 @@ EXT_SUFFIX = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
 PYMOD = os.path.join(HERE, "_myfm" + EXT_SUFFIX)
 
 HIP_SOURCES = ["mfm_hip.hip"]
-HIP_HEADERS = ["mfm_common.hpp", "mfm_kernels.hpp", "mfm_mf_kernels.hpp", "mfm_plan.hpp", "mfm_block_kernels.hpp", "mfm_tasks.hpp",
+HIP_HEADERS = ["mfm_common.hpp", "mfm_kernels.hpp", "mfm_mf_kernels.hpp", "mfm_res.hpp", "mfm_plan.hpp", "mfm_block_kernels.hpp", "mfm_tasks.hpp",
                "mfm_predict.hpp", "mfm_rng.hpp", "mfm_mtjump.hpp"]
 
 

@@ -169,6 +169,7 @@ enum KernelClass {
   KC_OPROBIT_EVAL,     // cutpoint likelihood / gradient / Hessian          OProbitSampler.hpp:389-413
   KC_PREDICT,          // Predictor::predict*                               predictor.hpp:35-147
   KC_SWEEP_V_FUSED,    // latent sweep: last level's apply pass + next factor's first level on the LDS tile
+  KC_SWEEP_V_RESIDENT, // latent sweep of a two-field table, all factors in one persistent launch (mfm_res.hpp)
   KC_N
 };
 
@@ -179,7 +180,7 @@ static const char *const kKernelClassNames[KC_N] = {
     "update_e_score",     "build_vt",
     "reduce_e",           "shift_e",           "group_stats",        "block_rowcache",     "block_unsync",
     "block_resync",       "block_sweep",       "tn_sample",          "oprobit_eval",       "predict",
-    "sweep_V_fused_next"};
+    "sweep_V_fused_next", "sweep_V_resident"};
 
 struct Timing {
   bool on = false;

@@ -78,6 +78,7 @@ struct mfm_ctx {
   DevBuf<double> ec, qc;        // split e / q arrays of the latent sweep (soa), compact residual (qfree)
   bool qfree = false, soa = false, fuse_next = false;
   bool mf = false;              // two-field pass (run_sweep_mf): no q-cache in HBM during update_V
+  ResPlan res;                  // ... as one persistent launch with the residual resident on chip (mfm_res.hpp)
   bool sharded_fused = false;   // row-sharded + fused tile path (run_sweep_soa_sharded)
   int q_stale_factor = -1;      // >= 0: the stored q column is stale, mfm_get_q rebuilds it for this factor first
   DevBuf<double> sync_mask;     // [D] 1: this rank contributes the column to the model synchronisation
@@ -645,8 +646,9 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     t_prev = t;
   };
   // main table
+  HostCsr Xt_keep;  // (X_t outlives the planner's scope: the resident layout is built from it once the path is known)
   {
-    HostCsr Xt;
+    HostCsr &Xt = Xt_keep;
     if (std::getenv("MFM_HOST_TRANSPOSE")) {
       Xt = transpose_host(c->hX);
       lap("transpose (host)");
@@ -837,6 +839,18 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     c->mf = c->fuse_next && plan_supports_mf(c->plan_V) && !std::getenv("MFM_NO_MF") && !std::getenv("MFM_NO_FUSED_TWO") &&
             !std::getenv("MFM_NO_FUSED_STATS");
   }
+  // two-field unit-valued table on one GPU: the whole update_V as one persistent launch, residual resident on chip
+  if (c->soa && c->mf && c->X.unit && !c->comm.active() && !std::getenv("MFM_NO_RESIDENT")) {
+    int n_cu = 0;
+    MFM_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
+    if (const char *e = std::getenv("MFM_RES_CUS")) n_cu = std::max(1, std::min(n_cu, std::atoi(e)));
+    c->res.build(Xt_keep, c->plan_V.h_level, &c->hgroup, n_cu);
+    if (tlog) std::fprintf(stderr, "[mfm_finalize] resident plan: %s (G=%d RV=%d RL=%d umax=%d runs=%lld lds=%zu)\n",
+                           c->res.ready ? "ready" : c->res.why.c_str(), c->res.G, c->res.RV, c->res.RL, c->res.umax,
+                           (long long)c->res.n_runs, c->res.lds_bytes);
+    lap("resident plan");
+  }
+  Xt_keep = HostCsr();
   MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
   lap("blocks, state, scratch");
   // host copies are no longer needed
@@ -862,7 +876,8 @@ int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launche
 
 int mfm_plan_flags(const mfm_ctx *ctx) {
   return (ctx->qfree ? 1 : 0) | (ctx->X.unit ? 2 : 0) | (ctx->X.ell_width >= 0 ? 4 : 0) | (ctx->comm.active() ? 8 : 0) |
-         (ctx->soa ? 16 : 0) | (ctx->fuse_next ? 32 : 0) | (ctx->sharded_fused ? 64 : 0) | (ctx->mf ? 128 : 0);
+         (ctx->soa ? 16 : 0) | (ctx->fuse_next ? 32 : 0) | (ctx->sharded_fused ? 64 : 0) | (ctx->mf ? 128 : 0) |
+         (ctx->res.ready ? 256 : 0);
 }
 
 // ---- state ------------------------------------------------------------------------------------
@@ -954,7 +969,7 @@ int mfm_reduce_e(mfm_ctx *ctx, double *sum_e, double *sum_e2) {
   MFM_HIP_CHECK(hipMemcpyAsync(h + 1, ctx->ls.error.p, sizeof(int), hipMemcpyDeviceToHost, s));
   MFM_HIP_CHECK(hipStreamSynchronize(s));
   if (*(const int *)(h + 1) != 0)
-    throw Error(MFM_ERR_RUNTIME, "long-column sweep: co-resident chunks timed out waiting for each other");
+    throw Error(MFM_ERR_RUNTIME, "co-resident workgroups timed out waiting for each other (long-column sweep / resident latent sweep)");
   *sum_e = h[0].x;
   *sum_e2 = h[0].y;
   MFM_CATCH(ctx)
@@ -1044,7 +1059,7 @@ int mfm_hyper_stats(mfm_ctx *ctx, int32_t need_e, const double *mu_w, const doub
   MFM_HIP_CHECK(hipMemcpyAsync(h + n_out, c->ls.error.p, sizeof(int), hipMemcpyDeviceToHost, s));
   MFM_HIP_CHECK(hipStreamSynchronize(s));
   if (*(const int *)(h + n_out) != 0)
-    throw Error(MFM_ERR_RUNTIME, "long-column sweep: co-resident chunks timed out waiting for each other");
+    throw Error(MFM_ERR_RUNTIME, "co-resident workgroups timed out waiting for each other (long-column sweep / resident latent sweep)");
   if (need_e) {
     *sum_e = h[0].x;
     *sum_e2 = h[0].y;
@@ -1190,6 +1205,12 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       return a;
     };
     const bool fuse = c->fuse_next;
+    if (c->res.ready) {
+      run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq.p, c->V.p, c->D, f_begin, f_end, zbase, c->lam.p, c->mu.p,
+                         c->group.p, c->G, alpha, c->ls.error.p);
+      c->q_stale_factor = f_end - 1;
+      return MFM_OK;
+    }
     if (c->mf) {
       if (c->X.unit)
         run_sweep_mf<true>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv);

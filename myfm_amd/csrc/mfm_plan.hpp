@@ -27,6 +27,7 @@
 #include "mfm_common.hpp"
 #include "mfm_kernels.hpp"
 #include "mfm_mf_kernels.hpp"
+#include "mfm_res.hpp"
 
 struct mfm_nccl_id {
   char internal[128];  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES)

@@ -239,6 +239,84 @@ def test_split_layout_latent_sweep(oracle, capi, monkeypatch, n_fields, fused):
         np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-7, atol=1e-7)
 
 
+@pytest.mark.parametrize("cus", [None, 12, 4, 1])
+def test_resident_latent_sweep(oracle, capi, monkeypatch, cus):
+    # update_V of a two-field one-hot table as ONE persistent launch (mfm_res.hpp): a workgroup per CU keeps the residual of
+    # its users' rows in registers / LDS for all factors, item statistics leave the CU once per (workgroup, item), grid
+    # barriers around the item draw. cus = CUs the planner may use: all (8 slots per thread, ~37 workgroups), 12 (32 slots per
+    # thread), 4 (64 register + 16 LDS slots per thread), 1 (a single workgroup: no second arrival at the barriers).
+    # Against the oracle draw for draw; a second context reproduces the chain bit for bit.
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    if cus:
+        monkeypatch.setenv("MFM_RES_CUS", str(cus))
+    n = 150001 if cus != 1 else 30011
+    X, y, shapes = ds.onehot_mf(n, 200 if cus != 1 else 90, 120, seed=21, sort_by_user=True)
+    gi = ds.group_index_from_shapes(shapes)
+    chains = []
+    for rep in range(2):
+        t, c, _ = _pair(oracle, capi, X, y, gi, 3)
+        assert c.plan_flags()["resident"] and c.plan_flags()["mf"]
+        drv = CapiGibbs(c, t.clone(), n, gi)
+        for it in range(3):
+            t.step()
+            drv.step()
+            np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-7, atol=1e-8, err_msg="iteration %d" % it)
+        np.testing.assert_allclose(c.get_q(), t.q(n), rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(c.get_state()[1], t.fm()[1], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-7, atol=1e-7)
+        chains.append((c.get_state()[2].copy(), c.get_e().copy()))
+        assert "sweep_V_resident" in _timing_classes(c, drv)
+    assert np.array_equal(chains[0][0], chains[1][0]) and np.array_equal(chains[0][1], chains[1][1])
+    # the per-factor passes (MFM_NO_RESIDENT) walk the same chain
+    monkeypatch.setenv("MFM_NO_RESIDENT", "1")
+    t, c, _ = _pair(oracle, capi, X, y, gi, 3)
+    assert not c.plan_flags()["resident"] and c.plan_flags()["mf"]
+    drv = CapiGibbs(c, t.clone(), n, gi)
+    for it in range(3):
+        drv.step()
+    np.testing.assert_allclose(c.get_state()[2], chains[0][0], rtol=1e-9, atol=1e-10)
+
+
+def test_resident_factor_subranges_and_empty_columns(oracle, capi, monkeypatch):
+    # mfm_sweep_V over [0, 2), [2, 3), [3, 5) through the resident launch, on a table with features that never occur in either
+    # field (drawn from the prior by the workgroup / item slice they are dealt to)
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    n, K = 60001, 5
+    X, y, shapes = ds.onehot_mf(n, 300, 90, seed=31, sort_by_user=True)
+    import scipy.sparse as sps
+
+    C = X.tocoo()
+    keep_u = np.setdiff1d(np.arange(300), [0, 17, 299])  # users / items without rows
+    keep_i = np.setdiff1d(np.arange(90), [3, 89])
+    u = X.indices[0::2]
+    i = X.indices[1::2] - 300
+    u2 = keep_u[u % len(keep_u)]
+    order = np.argsort(u2, kind="stable")
+    u2, i2 = u2[order], keep_i[i[order] % len(keep_i)]
+    ind = np.empty(2 * n, dtype=np.int32)
+    ind[0::2] = u2
+    ind[1::2] = 300 + i2
+    X = sps.csr_matrix((np.ones(2 * n), ind, np.arange(0, 2 * n + 1, 2)), shape=(n, 390))
+    y = y[order]
+    gi = ds.group_index_from_shapes(shapes)
+    t, c, _ = _pair(oracle, capi, X, y, gi, K)
+    assert c.plan_flags()["resident"]
+    G, D = t.G, t.D
+    rng = np.random.default_rng(8)
+    lam = rng.uniform(0.5, 2.0, size=(G, K))
+    mu = rng.normal(size=(G, K)) * 0.1
+    h = t.hyper()
+    t.set_hyper(0.9, h["mu_w"], h["lambda_w"], mu, lam)
+    for f0, f1 in ((0, 2), (2, 3), (3, 5)):
+        z = t.clone().rng_sample_normals(D * (f1 - f0)).reshape(f1 - f0, D)
+        for f in range(f0, f1):
+            t.update_V_factor(f)
+        c.sweep_V(f0, f1, 0.9, lam, mu, z)
+        np.testing.assert_allclose(c.get_state()[2][:, f0:f1], t.fm()[2][:, f0:f1], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(c.get_q(), t.q(n), rtol=1e-8, atol=1e-9)
+
+
 @pytest.mark.parametrize("n_fields", [2, 3])
 def test_split_layout_factor_subranges(oracle, capi, monkeypatch, n_fields):
     # mfm_sweep_V over [0, 2), [2, 3), [3, 5): every call starts with an unfused first level, ends with an unfused
