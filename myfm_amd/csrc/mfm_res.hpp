@@ -24,6 +24,13 @@
 //   sweep B (apply the user update, item statistics) -> barrier -> item draw (each workgroup a slice of the items, wave per
 //   item over its contiguous partials) -> barrier.
 #pragma once
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mfm_common.hpp"
 #include "mfm_mf_kernels.hpp"
 
 namespace mfm {
@@ -33,13 +40,14 @@ struct ResArgs {
   const int32_t *perm;       // [G][R][NT] row of the slot, -1: pad
   const uint32_t *meta;      // [G][R][NT] item | user << item_bits; pads: (pad item = n_items, pad user = umax - 1)
   const int32_t *first_run;  // [G][NT]   run containing the thread's first slot
-  const int32_t *run_slot;   // [runs]    (workgroup, item) run -> position of its partial (item-major)
   const int32_t *wg_user_ptr;  // [G + 1]
   const int2 *user_desc;     // {feature, group}
   const int32_t *wg_item_ptr;  // [G + 1] items (positions in the level) drawn by the workgroup
-  const int32_t *slot_ptr;   // [items + 1]
+  const int32_t *ent_ptr;    // [G + 1] the workgroup's slice of `entries`, in entries (a multiple of 64)
+  const int2 *entries;       // item-major: {run whose partial belongs to the item, row of the item draw's LDS table}
+  const int2 *item_rid;      // per item: {first row of that table, number of rows}
   const int32_t *scols;      // item -> feature
-  double *partials;          // [runs][2]
+  double *partials;          // [runs + 1][2], workgroup-major: a thread's runs are consecutive; the last stays (0, 0)
   double *dv;                // [items][2]  (delta of this factor, coefficient of the next)
   double *V;                 // factor-major [K][D]
   int64_t D;
@@ -50,10 +58,14 @@ struct ResArgs {
   int n_groups;
   double alpha;
   int item_bits, umax;       // umax: LDS stride of the per-wave user arrays (>= users of any workgroup)
+  int rid_max;               // rows of the item draw's LDS table
   unsigned long long *bar;   // monotone arrival counter
   unsigned long long bar_base;  // its value before this launch
   int n_wg;
   int *error;                // set on a spin timeout
+  int dbg;                   // timing experiments only (MFM_RES_DBG; results are wrong when set): 1 no LDS atomics, 2 no partial
+                             // stores, 4 no grid barriers, 8 no dv gathers, 16 no per-slot word loads, 32 no item draw, 64 no sweep A,
+                             // 128 no sweep B
 };
 
 __device__ __forceinline__ void res_store2(double *p, double a, double b) {
@@ -66,7 +78,11 @@ __device__ __forceinline__ void res_store2(double *p, double a, double b) {
 __device__ __forceinline__ void res_grid_barrier(const ResArgs &a, unsigned long long k, int tid, bool &dead) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0 && !dead) {
+  if (tid == 0 && !dead && !(a.dbg & 4)) {
+    // (the partials are plain 16-byte stores -- a thread's runs are adjacent, whole lines form in L2 --: one agent-scope
+    //  release writes them back; the asm wait restates the wait the compiler may drop, Guideline 16 pitfall 12)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(a.bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long target = a.bar_base + k * (unsigned long long)a.n_wg;
     unsigned spins = 0;
@@ -113,7 +129,8 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   double *acc2 = acc1 + NW * U;           // [NW][U]  sum of h^2
   d2_t *utab = (d2_t *)(acc2 + NW * U);   // [U] {new coefficient, new - old}
   d2_t *wcarry = utab + U;                // [NW]
-  int *wflag = (int *)(wcarry + NW);      // [NW]
+  d2_t *cpart = wcarry + NW;              // [rid_max] item draw: sums per (64-entry chunk, item)
+  int *wflag = (int *)(cpart + a.rid_max);  // [NW]
   const uint32_t imask = (1u << a.item_bits) - 1u;
   const int ib = a.item_bits;
   // (uniform bases + the thread index: the R loads of a sweep share one 32-bit lane offset instead of R 64-bit addresses)
@@ -181,10 +198,10 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
         const int t = res_fence_lane(tid);
         const uint32_t *mp = meta_g + rb * NT;
 #pragma unroll
-        for (int k = 0; k < B; k++) m[k] = mp[k * NT + t];
+        for (int k = 0; k < B; k++) m[k] = (a.dbg & 16) ? (uint32_t)(t & 63) : mp[k * NT + t];
         d2_t dd[B];
 #pragma unroll
-        for (int k = 0; k < B; k++) dd[k] = dv2[m[k] & imask];
+        for (int k = 0; k < B; k++) dd[k] = (a.dbg & 8) ? d2_t{1e-3, 1e-3} : dv2[m[k] & imask];
         double up[B];
 #pragma unroll
         for (int k = 0; k < B; k++) up[k] = utab[m[k] >> ib][0];
@@ -194,27 +211,30 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
           const double er = ev[k] + up[k] * dd[k][0];
           ev[k] = er;
           const double c = dd[k][1];
+          if (a.dbg & 1) continue;
           __hip_atomic_fetch_add(&acc1[wv * U + uid], (-er) * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           __hip_atomic_fetch_add(&acc2[wv * U + uid], c * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       };
+      if (!(a.dbg & 64)) {
 #pragma unroll
-      for (int rb = 0; rb < RV; rb += B) {
-        double ev[B];
+        for (int rb = 0; rb < RV; rb += B) {
+          double ev[B];
 #pragma unroll
-        for (int k = 0; k < B; k++) ev[k] = e[rb + k];
-        batch(rb, ev);
+          for (int k = 0; k < B; k++) ev[k] = e[rb + k];
+          batch(rb, ev);
 #pragma unroll
-        for (int k = 0; k < B; k++) e[rb + k] = ev[k];
-      }
+          for (int k = 0; k < B; k++) e[rb + k] = ev[k];
+        }
 #pragma unroll 1
-      for (int rb = RV; rb < R; rb += B) {
-        double ev[B];
+        for (int rb = RV; rb < R; rb += B) {
+          double ev[B];
 #pragma unroll
-        for (int k = 0; k < B; k++) ev[k] = elds[(rb - RV + k) * NT + tid];
-        batch(rb, ev);
+          for (int k = 0; k < B; k++) ev[k] = elds[(rb - RV + k) * NT + tid];
+          batch(rb, ev);
 #pragma unroll
-        for (int k = 0; k < B; k++) elds[(rb - RV + k) * NT + tid] = ev[k];
+          for (int k = 0; k < B; k++) elds[(rb - RV + k) * NT + tid] = ev[k];
+        }
       }
     }
     __syncthreads();
@@ -239,16 +259,17 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       bool have_head = false;
       double f1 = 0.0, f2 = 0.0, s1 = 0.0, s2 = 0.0;
       int next_run = head0 ? run0 : run0 + 1;  // the next run to OPEN
-      int cur_pos = 0;
+      int cur_run = 0;
+      d2_t *part2 = (d2_t *)a.partials;
       auto batch = [&](int rb, double (&ev)[B]) {
         uint32_t m[B];
         const int t = res_fence_lane(tid);
         const uint32_t *mp = meta_g + rb * NT;
 #pragma unroll
-        for (int k = 0; k < B; k++) m[k] = mp[k * NT + t];
+        for (int k = 0; k < B; k++) m[k] = (a.dbg & 16) ? (uint32_t)(t & 63) : mp[k * NT + t];
         double cc[B];
 #pragma unroll
-        for (int k = 0; k < B; k++) cc[k] = a.dv[2 * (int64_t)(m[k] & imask) + 1];
+        for (int k = 0; k < B; k++) cc[k] = (a.dbg & 8) ? 1e-3 : a.dv[2 * (int64_t)(m[k] & imask) + 1];
         d2_t ut[B];
 #pragma unroll
         for (int k = 0; k < B; k++) ut[k] = utab[m[k] >> ib];
@@ -258,9 +279,8 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
           const bool head = key != kp;
           kp = key;
           if (head) {
-            if (have_head) res_store2(a.partials + 2 * (int64_t)cur_pos, s1, s2);  // a run that began and ended in this thread
-            cur_pos = a.run_slot[next_run];
-            next_run++;
+            if (have_head && !(a.dbg & 2)) part2[cur_run] = d2_t{s1, s2};  // a run that began and ended in this thread
+            cur_run = next_run++;
           }
           f1 = head && !have_head ? s1 : f1;
           f2 = head && !have_head ? s2 : f2;
@@ -271,23 +291,25 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
           s2 = (head ? 0.0 : s2) + ut[k][0] * ut[k][0];
         }
       };
+      if (!(a.dbg & 128)) {
 #pragma unroll
-      for (int rb = 0; rb < RV; rb += B) {
-        double ev[B];
+        for (int rb = 0; rb < RV; rb += B) {
+          double ev[B];
 #pragma unroll
-        for (int k = 0; k < B; k++) ev[k] = e[rb + k];
-        batch(rb, ev);
+          for (int k = 0; k < B; k++) ev[k] = e[rb + k];
+          batch(rb, ev);
 #pragma unroll
-        for (int k = 0; k < B; k++) e[rb + k] = ev[k];
-      }
+          for (int k = 0; k < B; k++) e[rb + k] = ev[k];
+        }
 #pragma unroll 1
-      for (int rb = RV; rb < R; rb += B) {
-        double ev[B];
+        for (int rb = RV; rb < R; rb += B) {
+          double ev[B];
 #pragma unroll
-        for (int k = 0; k < B; k++) ev[k] = elds[(rb - RV + k) * NT + tid];
-        batch(rb, ev);
+          for (int k = 0; k < B; k++) ev[k] = elds[(rb - RV + k) * NT + tid];
+          batch(rb, ev);
 #pragma unroll
-        for (int k = 0; k < B; k++) elds[(rb - RV + k) * NT + tid] = ev[k];
+          for (int k = 0; k < B; k++) elds[(rb - RV + k) * NT + tid] = ev[k];
+        }
       }
       // stitch the runs that cross thread boundaries: a thread with a head restarts the running sum with its open tail,
       // a thread without one passes its whole sum on
@@ -321,32 +343,55 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
         }
         // the run that ends at this thread's first head: run0 when the first slot is not a head, else the one before
         const int closing = head0 ? run0 - 1 : run0;
-        res_store2(a.partials + 2 * (int64_t)a.run_slot[closing], x1 + f1, x2 + f2);
+        part2[closing] = d2_t{x1 + f1, x2 + f2};
       }
     }
     res_grid_barrier(a, ++nbar, tid, dead);
-    // ---- item draw (:357-369): a wave per item over its contiguous partials
-    {
+    // ---- item draw (:357-369). The workgroup's items own a contiguous, item-major slice of `entries`; a wave takes 64-entry
+    //      chunks of it (the partials are gathered, 4 chunks in flight), a DPP segmented scan sums each chunk's stretch of
+    //      one item, the stretch's last lane leaves the sum in the LDS table at a precomputed row; then a thread per item adds
+    //      the item's rows in order (fixed association) and draws -- every item of the slice in parallel.
+    if (!(a.dbg & 32)) {
+      constexpr int CH = 4;
+      const int c0 = a.ent_ptr[g] >> 6, c1 = a.ent_ptr[g + 1] >> 6;
+      const d2_t *part2 = (const d2_t *)a.partials;
+      for (int cb = c0 + wv * CH; cb < c1; cb += NW * CH) {
+        int2 en[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) en[k] = cb + k < c1 ? a.entries[(int64_t)(cb + k) * WAVE + lane] : make_int2(0, -1 - lane);
+        d2_t sv[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) sv[k] = cb + k < c1 ? part2[en[k].x] : d2_t{0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          if (cb + k >= c1) break;  // wave-uniform
+          const int rid = en[k].y;
+          const int rp = dpp_i32<0x138, 0xf>(rid, 0), rn = dpp_i32<0x130, 0xf>(rid, 0);  // wave_shr:1 / wave_shl:1
+          int hd = (lane == 0 || rp != rid) ? 1 : 0;
+          const bool tail = lane == 63 || rn != rid;
+          double s1 = sv[k][0], s2 = sv[k][1];
+          wave_segscan2(s1, s2, hd);
+          if (tail) cpart[rid] = d2_t{s1, s2};
+        }
+      }
+      lds_barrier();
       const int i0 = a.wg_item_ptr[g], i1 = a.wg_item_ptr[g + 1];
       const bool more = f + 1 < a.f_end;
-      for (int i = i0 + wv; i < i1; i += NW) {
-        const int p0 = a.slot_ptr[i], p1 = a.slot_ptr[i + 1];
+      for (int i = i0 + tid; i < i1; i += NT) {
+        const int2 rr = a.item_rid[i];
+        const int j = a.scols[i];
+        const int gj = a.group[j];
+        const double old = Vf[j], zj = zf[j], vn = more ? a.V[(int64_t)(f + 1) * a.D + j] : 0.0;
+        const double lj = a.lam[(int64_t)f * a.n_groups + gj], mj = a.mu[(int64_t)f * a.n_groups + gj];
         double S1 = 0.0, S2 = 0.0;
-        for (int p = p0 + lane; p < p1; p += WAVE) {
-          const d2_t s = ((const d2_t *)a.partials)[p];
-          S1 += s[0];
-          S2 += s[1];
+        for (int r = rr.x; r < rr.x + rr.y; r++) {
+          const d2_t cp = cpart[r];
+          S1 += cp[0];
+          S2 += cp[1];
         }
-        wave_allreduce_sum2(S1, S2);
-        if (lane == 0) {
-          const int j = a.scols[i];
-          const int gj = a.group[j];
-          const double old = Vf[j];
-          const double fresh = PMainV::draw(S1, S2, old, a.alpha, a.lam[(int64_t)f * a.n_groups + gj],
-                                            a.mu[(int64_t)f * a.n_groups + gj], zf[j]);
-          Vf[j] = fresh;
-          res_store2(a.dv + 2 * (int64_t)i, fresh - old, more ? a.V[(int64_t)(f + 1) * a.D + j] : 0.0);
-        }
+        const double fresh = PMainV::draw(S1, S2, old, a.alpha, lj, mj, zj);
+        Vf[j] = fresh;
+        res_store2(a.dv + 2 * (int64_t)i, fresh - old, vn);
       }
     }
     res_grid_barrier(a, ++nbar, tid, dead);
@@ -404,7 +449,9 @@ struct ResPlan {
   int G = 0, NT = 512, RV = 0, RL = 0, umax = 0, item_bits = 0, n_items = 0;
   int64_t n_rows = 0, n_runs = 0;  // (workgroup, item) pairs
   size_t lds_bytes = 0;
-  DevBuf<int32_t> perm, first_run, run_slot, wg_user_ptr, wg_item_ptr, slot_ptr, scols;
+  DevBuf<int32_t> perm, first_run, wg_user_ptr, wg_item_ptr, ent_ptr, scols;
+  DevBuf<int2> entries, item_rid;
+  int rid_max = 0;
   DevBuf<uint32_t> meta;
   DevBuf<int2> user_desc;
   DevBuf<double> partials, dv;
@@ -525,8 +572,6 @@ struct ResPlan {
     umax = maxu + 1;
     item_bits = bits_for((int64_t)n_items + 1);
     if (item_bits + bits_for(umax) > 32) return fail("item and user indices do not fit one word");
-    lds_bytes = (size_t)RL * NT * 8 + (size_t)2 * (NT / WAVE) * umax * 8 + (size_t)umax * 16 + (size_t)(NT / WAVE) * 16 + (NT / WAVE) * 4 + 64;
-    if (lds_bytes > 160 * 1024 - 512) return fail("LDS");
     // slots: per workgroup the rows in (item, row) order
     const uint32_t pad_word = (uint32_t)n_items | ((uint32_t)(umax - 1) << item_bits);
     std::vector<uint32_t> h_meta((size_t)G * cap_slots, pad_word);
@@ -538,7 +583,7 @@ struct ResPlan {
       for (int64_t r = ustart[u]; r < ustart[u + 1]; r++) uord_of_row[r] = (int32_t)u;
     std::vector<int64_t> fill((size_t)G, 0);
     std::vector<int32_t> last_item((size_t)G, -1), nruns((size_t)G, 0);
-    std::vector<std::vector<int32_t>> run_pos((size_t)G);  // per workgroup: partial position of each run
+    std::vector<int32_t> pair_g, pair_local;  // the (workgroup, item) runs in item-major order
     std::vector<int32_t> h_slot_ptr((size_t)n_items + 1, 0);
     int64_t counter = 0;
     for (int c = 0; c < n_items; c++) {
@@ -550,7 +595,9 @@ struct ResPlan {
         const int64_t sidx = fill[g]++;
         if (last_item[g] != c) {
           last_item[g] = c;
-          run_pos[g].push_back((int32_t)counter++);
+          pair_g.push_back(g);
+          pair_local.push_back(nruns[g]);
+          counter++;
           nruns[g]++;
         }
         const int t = (int)(sidx / R), r = (int)(sidx % R);
@@ -563,13 +610,11 @@ struct ResPlan {
     h_slot_ptr[n_items] = (int32_t)counter;
     n_runs = counter;
     if (counter >= ((int64_t)1 << 31) - 2) return fail("too many runs");
-    // run tables: global run index = run_base[g] + local; every workgroup ends with its pad run (-> the dummy partial)
+    // runs, workgroup-major: global run index = run_base[g] + local; every workgroup ends with its pad run (never stored)
     std::vector<int32_t> run_base((size_t)G + 1, 0);
     for (int g = 0; g < G; g++) run_base[g + 1] = run_base[g] + nruns[g] + 1;
-    std::vector<int32_t> h_run_slot((size_t)run_base[G]);
+    const int32_t zero_run = run_base[G];  // a partial that stays (0, 0): what the padding entries of the item draw gather
     for (int g = 0; g < G; g++) {
-      std::copy(run_pos[g].begin(), run_pos[g].end(), h_run_slot.begin() + run_base[g]);
-      h_run_slot[(size_t)run_base[g] + nruns[g]] = (int32_t)counter;  // dummy
       // threads whose first slot is a pad: the pad run
       for (int t = 0; t < NT; t++) {
         const int64_t s0 = (int64_t)t * R;
@@ -597,16 +642,49 @@ struct ResPlan {
       for (; g <= G; g++) h_iptr[g] = n_items;
       h_iptr[G] = n_items;
     }
+    // item draw tables: per workgroup the item-major entries of its items, padded to whole 64-entry chunks; the (chunk, item)
+    // stretches of a slice are numbered chunk + item (both only grow along the slice: distinct stretches, distinct rows)
+    std::vector<int2> h_entries, h_item_rid((size_t)n_items, make_int2(0, 0));
+    std::vector<int32_t> h_eptr((size_t)G + 1, 0);
+    rid_max = 1;
+    for (int g = 0; g < G; g++) {
+      const size_t e_begin = h_entries.size();
+      int last_rid = 0;
+      for (int c = h_iptr[g]; c < h_iptr[g + 1]; c++) {
+        const int li = c - h_iptr[g];
+        int first = -1, last = -1;
+        for (int32_t q = h_slot_ptr[c]; q < h_slot_ptr[c + 1]; q++) {
+          const int k = (int)(h_entries.size() - e_begin);
+          const int rid = (k >> 6) + li;
+          if (first < 0) first = rid;
+          last = rid;
+          h_entries.push_back(make_int2(run_base[pair_g[q]] + pair_local[q], rid));
+        }
+        if (first >= 0) {
+          h_item_rid[c] = make_int2(first, last - first + 1);
+          last_rid = last;
+        }
+      }
+      while ((h_entries.size() - e_begin) % WAVE) h_entries.push_back(make_int2(zero_run, last_rid));
+      h_eptr[g + 1] = (int32_t)h_entries.size();
+      rid_max = std::max(rid_max, last_rid + 1);
+    }
+    if (h_entries.size() >= ((size_t)1 << 31)) return fail("too many entries");
+    lds_bytes = (size_t)RL * NT * 8 + (size_t)2 * (NT / WAVE) * umax * 8 + (size_t)umax * 16 + (size_t)(NT / WAVE) * 16 + (size_t)rid_max * 16 +
+                (NT / WAVE) * 4 + 64;
+    if (lds_bytes > 160 * 1024 - 512) return fail("LDS");
     meta.upload(h_meta);
     perm.upload(h_perm);
     first_run.upload(h_first);
-    run_slot.upload(h_run_slot);
     wg_user_ptr.upload(h_uptr);
     user_desc.upload(h_udesc.data(), h_udesc.size());
     wg_item_ptr.upload(h_iptr);
-    slot_ptr.upload(h_slot_ptr);
+    ent_ptr.upload(h_eptr);
+    entries.upload(h_entries.data(), h_entries.size());
+    item_rid.upload(h_item_rid.data(), h_item_rid.size());
     scols.upload(items);
-    partials.alloc((size_t)2 * (counter + 1));
+    partials.alloc((size_t)2 * ((size_t)zero_run + 1));
+    MFM_HIP_CHECK(hipMemset(partials.p, 0, (size_t)16 * ((size_t)zero_run + 1)));
     dv.alloc((size_t)2 * (n_items + 1));
     bar.alloc(1);
     MFM_HIP_CHECK(hipMemset(bar.p, 0, sizeof(unsigned long long)));
@@ -632,11 +710,13 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   a.perm = rp.perm.p;
   a.meta = rp.meta.p;
   a.first_run = rp.first_run.p;
-  a.run_slot = rp.run_slot.p;
   a.wg_user_ptr = rp.wg_user_ptr.p;
   a.user_desc = rp.user_desc.p;
   a.wg_item_ptr = rp.wg_item_ptr.p;
-  a.slot_ptr = rp.slot_ptr.p;
+  a.ent_ptr = rp.ent_ptr.p;
+  a.entries = rp.entries.p;
+  a.item_rid = rp.item_rid.p;
+  a.rid_max = rp.rid_max;
   a.scols = rp.scols.p;
   a.partials = rp.partials.p;
   a.dv = rp.dv.p;
@@ -656,6 +736,7 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   a.bar_base = rp.bar_count;
   a.n_wg = rp.G;
   a.error = error;
+  a.dbg = std::getenv("MFM_RES_DBG") ? std::atoi(std::getenv("MFM_RES_DBG")) : 0;
   rp.bar_count += 2ull * (unsigned long long)(f_end - f_begin) * (unsigned long long)rp.G;
   const int K = f_end - f_begin;
   // algorithmic bytes of the launch: e read + written once, the per-slot words twice per factor (+ once at either end),
