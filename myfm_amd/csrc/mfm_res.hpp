@@ -38,7 +38,9 @@ namespace mfm {
 struct ResArgs {
   double2 *eq;               // residual: read at [row].x at the start, written back at the end
   const int32_t *perm;       // [G][R][NT] row of the slot, -1: pad
-  const uint32_t *meta;      // [G][R][NT] item | user << item_bits; pads: (pad item = n_items, pad user = umax - 1)
+  const uint32_t *uidw;      // [G][R / 2][NT] the slots' users (index within the workgroup), 16 bits each; pads: umax - 1
+  const uint32_t *headw;     // [G][R / 16][NT] bit r % 16: slot r starts a new item run (slot 0 of thread 0 always)
+  const int32_t *run_item;   // [runs + 1] item of every (workgroup, item) run; pad runs: the pad item n_items
   const int32_t *first_run;  // [G][NT]   run containing the thread's first slot
   const int32_t *wg_user_ptr;  // [G + 1]
   const int2 *user_desc;     // {feature, group}
@@ -63,9 +65,9 @@ struct ResArgs {
   unsigned long long bar_base;  // its value before this launch
   int n_wg;
   int *error;                // set on a spin timeout
-  int dbg;                   // timing experiments only (MFM_RES_DBG; results are wrong when set): 1 no LDS atomics, 2 no partial
-                             // stores, 4 no grid barriers, 8 no dv gathers, 16 no per-slot word loads, 32 no item draw, 64 no sweep A,
-                             // 128 no sweep B
+  int dbg;                   // timing experiments only (MFM_RES_DBG; results are wrong when set): 4 no grid barriers, 32 no item
+                             // draw, 64 no sweep A, 128 no sweep B (whole phases only: a switch inside a sweep's batches breaks
+                             // them into basic blocks and serialises their loads)
 };
 
 __device__ __forceinline__ void res_store2(double *p, double a, double b) {
@@ -108,19 +110,24 @@ __device__ __forceinline__ int res_fence_lane(int t) {
   asm volatile("" : "+v"(t)::"memory");
   return t;
 }
-template <class T>
-__device__ __forceinline__ const T *res_fence_ptr(const T *p) {
-  asm volatile("" : "+s"(p)::"memory");
-  return p;
-}
+typedef double res_d16_t __attribute__((ext_vector_type(16)));
+typedef unsigned res_u8_t __attribute__((ext_vector_type(8)));
 
-// NT threads, RV slots per thread in registers + RL slots per thread in LDS ([RL][NT] doubles: lane-consecutive, conflict-free).
-template <int NT, int RV, int RL>
+// NT threads; a thread's slots come in groups of 16: NGV groups live in registers (one 16-double vector each), NGL groups in
+// LDS ([16 NGL][NT] doubles: lane-consecutive, conflict-free). Everything static about a group stays in registers for the whole
+// launch: 16 head bits (a new item run starts at the slot) and the slots' users, 16 bits each (8 words). The sweeps are REAL
+// loops over batches of 4 slots -- the loop counter is wave-uniform, so the batch's residuals and words are picked out of the
+// register vectors with s_set_gpr_idx (no scratch, no waterfall) -- and only the group loop is unrolled. (A fully unrolled
+// sweep leaves the compiler free to hoist the loads of all 20 batches -- every address is a function of static registers --
+// and it then spills the residual; pinning each batch behind the previous one with empty asm statements was tried and lost.)
+// The item of a run comes from run_item[run] (4 bytes per (workgroup, item) run, walked sequentially by every thread: cache
+// resident); the head bits give the run index of every slot without a memory access, so the run_item loads of batch b + 1 are
+// in flight while batch b computes and the only dependent global access of a batch is its dv gather.
+template <int NT, int NGV, int NGL>
 __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) char res_smem[];
-  constexpr int NW = NT / WAVE, R = RV + RL;
-  constexpr int B = 4;  // slots per batch of loads
-  static_assert(RV % B == 0 && RL % B == 0, "slot counts must be multiples of the load batch");
+  constexpr int NW = NT / WAVE, NG = NGV + NGL, R = 16 * NG, RL = 16 * NGL;
+  constexpr int B = 4;  // slots per batch
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int U = a.umax;
@@ -131,10 +138,6 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   d2_t *wcarry = utab + U;                // [NW]
   d2_t *cpart = wcarry + NW;              // [rid_max] item draw: sums per (64-entry chunk, item)
   int *wflag = (int *)(cpart + a.rid_max);  // [NW]
-  const uint32_t imask = (1u << a.item_bits) - 1u;
-  const int ib = a.item_bits;
-  // (uniform bases + the thread index: the R loads of a sweep share one 32-bit lane offset instead of R 64-bit addresses)
-  const uint32_t *meta_g = a.meta + (int64_t)g * R * NT;
   const int32_t *perm_g = a.perm + (int64_t)g * R * NT;
   const d2_t *dv2 = (const d2_t *)a.dv;
   const int u0 = a.wg_user_ptr[g], nu = a.wg_user_ptr[g + 1] - u0;
@@ -144,36 +147,38 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   for (int i = tid; i < 2 * NW * U; i += NT) acc1[i] = 0.0;
   for (int i = tid; i < U; i += NT) utab[i] = d2_t{0.0, 0.0};
 
-  // Pad slots carry a word of their own -- (pad item, pad user): an item whose dv entry stays (0, 0) and a user slot nobody
-  // draws -- so that every slot runs the same straight-line code: a pad's statistics add 0 whatever its residual holds.
-  double e[RV > 0 ? RV : 1];
-  auto load_e = [&](int rb, double (&ev)[B]) {
-    int row[B];
-    const int t = res_fence_lane(tid);
-    const int32_t *pp = perm_g + rb * NT;
+  // static per-thread words
+  res_u8_t uwv[NG];
+  unsigned hbv[NG];
 #pragma unroll
-    for (int k = 0; k < B; k++) row[k] = pp[k * NT + t];
+  for (int j = 0; j < NG; j++) {
 #pragma unroll
-    for (int k = 0; k < B; k++) ev[k] = a.eq[row[k] < 0 ? 0 : row[k]].x;
-  };
-#pragma unroll
-  for (int rb = 0; rb < RV; rb += B) {
-    double ev[B];
-    load_e(rb, ev);
-#pragma unroll
-    for (int k = 0; k < B; k++) e[rb + k] = ev[k];
+    for (int w = 0; w < 8; w++) uwv[j][w] = a.uidw[((int64_t)g * (8 * NG) + 8 * j + w) * NT + tid];
+    hbv[j] = a.headw[((int64_t)g * NG + j) * NT + tid];
   }
+  const int run0 = a.first_run[g * NT + tid];  // the run containing this thread's first slot
+  const bool head0 = (hbv[0] & 1u) != 0u;
+
+  // Pad slots carry (pad item, pad user): an item whose dv entry stays (0, 0) and a user slot nobody draws, so that every slot
+  // runs the same straight-line code: a pad's statistics add 0 whatever its residual holds.
+  res_d16_t ev[NGV > 0 ? NGV : 1];
+#pragma unroll
+  for (int j = 0; j < NG; j++) {
 #pragma unroll 1
-  for (int rb = RV; rb < R; rb += B) {
-    double ev[B];
-    load_e(rb, ev);
+    for (int bb = 0; bb < 4; bb++) {
+      int row[B];
 #pragma unroll
-    for (int k = 0; k < B; k++) elds[(rb - RV + k) * NT + tid] = ev[k];
+      for (int k = 0; k < B; k++) row[k] = perm_g[(16 * j + 4 * bb + k) * NT + tid];
+#pragma unroll
+      for (int k = 0; k < B; k++) {
+        const double x = a.eq[row[k] < 0 ? 0 : row[k]].x;
+        if (j < NGV)
+          ev[j < NGV ? j : 0][4 * bb + k] = x;
+        else
+          elds[(16 * (j - NGV) + 4 * bb + k) * NT + tid] = x;
+      }
+    }
   }
-  // item of the slot before this thread's first one (thread 0: a key no slot has) and the run containing the first slot
-  const uint32_t key_prev0 = tid > 0 ? (meta_g[(R - 1) * NT + tid - 1] & imask) : 0xfffffffeu;
-  const int run0 = a.first_run[g * NT + tid];
-  const bool head0 = (meta_g[tid] & imask) != key_prev0;
   __syncthreads();
 
   for (int f = a.f_begin; f < a.f_end; f++) {
@@ -192,48 +197,55 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
     }
     // ---- sweep A: the item update of the previous factor (:371-375; dv.x = 0 before the first), the user level's
     //      statistics (:351-356)
-    {
-      auto batch = [&](int rb, double (&ev)[B]) {
-        uint32_t m[B];
-        const int t = res_fence_lane(tid);
-        const uint32_t *mp = meta_g + rb * NT;
-#pragma unroll
-        for (int k = 0; k < B; k++) m[k] = (a.dbg & 16) ? (uint32_t)(t & 63) : mp[k * NT + t];
-        d2_t dd[B];
-#pragma unroll
-        for (int k = 0; k < B; k++) dd[k] = (a.dbg & 8) ? d2_t{1e-3, 1e-3} : dv2[m[k] & imask];
-        double up[B];
-#pragma unroll
-        for (int k = 0; k < B; k++) up[k] = utab[m[k] >> ib][0];
+    if (!(a.dbg & 64)) {
+      // run indices of the first batch (slot 0 belongs to run0 whether or not it is a head) and their items
+      int itn[B];
+      int run_last = run0;
+      {
+        const unsigned h4 = hbv[0] & 15u;
 #pragma unroll
         for (int k = 0; k < B; k++) {
-          const int uid = (int)(m[k] >> ib);
-          const double er = ev[k] + up[k] * dd[k][0];
-          ev[k] = er;
-          const double c = dd[k][1];
-          if (a.dbg & 1) continue;
-          __hip_atomic_fetch_add(&acc1[wv * U + uid], (-er) * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(&acc2[wv * U + uid], c * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (k > 0) run_last += (int)((h4 >> k) & 1u);
+          itn[k] = a.run_item[run_last];
         }
-      };
-      if (!(a.dbg & 64)) {
+      }
 #pragma unroll
-        for (int rb = 0; rb < RV; rb += B) {
-          double ev[B];
-#pragma unroll
-          for (int k = 0; k < B; k++) ev[k] = e[rb + k];
-          batch(rb, ev);
-#pragma unroll
-          for (int k = 0; k < B; k++) e[rb + k] = ev[k];
-        }
+      for (int j = 0; j < NG; j++) {
 #pragma unroll 1
-        for (int rb = RV; rb < R; rb += B) {
-          double ev[B];
+        for (int bb = 0; bb < 4; bb++) {
+          int it[B];
 #pragma unroll
-          for (int k = 0; k < B; k++) ev[k] = elds[(rb - RV + k) * NT + tid];
-          batch(rb, ev);
+          for (int k = 0; k < B; k++) it[k] = itn[k];
+          {  // the next batch's items: in flight while this batch computes (past the last batch: the same runs again)
+            const unsigned hn = bb < 3 ? (hbv[j] >> (4 * (bb + 1))) & 15u : (j + 1 < NG ? hbv[j + 1 < NG ? j + 1 : j] & 15u : 0u);
 #pragma unroll
-          for (int k = 0; k < B; k++) elds[(rb - RV + k) * NT + tid] = ev[k];
+            for (int k = 0; k < B; k++) {
+              run_last += (int)((hn >> k) & 1u);
+              itn[k] = a.run_item[run_last];
+            }
+          }
+          d2_t dd[B];
+#pragma unroll
+          for (int k = 0; k < B; k++) dd[k] = dv2[it[k]];
+          const unsigned w0 = uwv[j][2 * bb], w1 = uwv[j][2 * bb + 1];
+          const int uid[B] = {(int)(w0 & 0xffffu), (int)(w0 >> 16), (int)(w1 & 0xffffu), (int)(w1 >> 16)};
+          double up[B], ex[B];
+#pragma unroll
+          for (int k = 0; k < B; k++) {
+            up[k] = utab[uid[k]][0];
+            ex[k] = j < NGV ? ev[j < NGV ? j : 0][4 * bb + k] : elds[(16 * (j - NGV) + 4 * bb + k) * NT + tid];
+          }
+#pragma unroll
+          for (int k = 0; k < B; k++) {
+            const double er = ex[k] + up[k] * dd[k][0];
+            if (j < NGV)
+              ev[j < NGV ? j : 0][4 * bb + k] = er;
+            else
+              elds[(16 * (j - NGV) + 4 * bb + k) * NT + tid] = er;
+            const double c = dd[k][1];
+            __hip_atomic_fetch_add(&acc1[wv * U + uid[k]], (-er) * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&acc2[wv * U + uid[k]], c * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
       }
     }
@@ -255,60 +267,70 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
     __syncthreads();
     // ---- sweep B: the user update (:371-375), the item level's statistics run by run
     {
-      uint32_t kp = key_prev0;
       bool have_head = false;
       double f1 = 0.0, f2 = 0.0, s1 = 0.0, s2 = 0.0;
-      int next_run = head0 ? run0 : run0 + 1;  // the next run to OPEN
-      int cur_run = 0;
       d2_t *part2 = (d2_t *)a.partials;
-      auto batch = [&](int rb, double (&ev)[B]) {
-        uint32_t m[B];
-        const int t = res_fence_lane(tid);
-        const uint32_t *mp = meta_g + rb * NT;
-#pragma unroll
-        for (int k = 0; k < B; k++) m[k] = (a.dbg & 16) ? (uint32_t)(t & 63) : mp[k * NT + t];
-        double cc[B];
-#pragma unroll
-        for (int k = 0; k < B; k++) cc[k] = (a.dbg & 8) ? 1e-3 : a.dv[2 * (int64_t)(m[k] & imask) + 1];
-        d2_t ut[B];
-#pragma unroll
-        for (int k = 0; k < B; k++) ut[k] = utab[m[k] >> ib];
-#pragma unroll
-        for (int k = 0; k < B; k++) {
-          const uint32_t key = m[k] & imask;
-          const bool head = key != kp;
-          kp = key;
-          if (head) {
-            if (have_head && !(a.dbg & 2)) part2[cur_run] = d2_t{s1, s2};  // a run that began and ended in this thread
-            cur_run = next_run++;
-          }
-          f1 = head && !have_head ? s1 : f1;
-          f2 = head && !have_head ? s2 : f2;
-          have_head = have_head || head;
-          const double er = ev[k] + cc[k] * ut[k][1];
-          ev[k] = er;
-          s1 = (head ? 0.0 : s1) + (-er) * ut[k][0];
-          s2 = (head ? 0.0 : s2) + ut[k][0] * ut[k][0];
-        }
-      };
       if (!(a.dbg & 128)) {
+        int itn[B], rkn[B];
+        int run_last = run0;
+        {
+          const unsigned h4 = hbv[0] & 15u;
 #pragma unroll
-        for (int rb = 0; rb < RV; rb += B) {
-          double ev[B];
-#pragma unroll
-          for (int k = 0; k < B; k++) ev[k] = e[rb + k];
-          batch(rb, ev);
-#pragma unroll
-          for (int k = 0; k < B; k++) e[rb + k] = ev[k];
+          for (int k = 0; k < B; k++) {
+            if (k > 0) run_last += (int)((h4 >> k) & 1u);
+            rkn[k] = run_last;
+            itn[k] = a.run_item[run_last];
+          }
         }
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
 #pragma unroll 1
-        for (int rb = RV; rb < R; rb += B) {
-          double ev[B];
+          for (int bb = 0; bb < 4; bb++) {
+            int it[B], rk[B];
 #pragma unroll
-          for (int k = 0; k < B; k++) ev[k] = elds[(rb - RV + k) * NT + tid];
-          batch(rb, ev);
+            for (int k = 0; k < B; k++) {
+              it[k] = itn[k];
+              rk[k] = rkn[k];
+            }
+            const unsigned h4 = (hbv[j] >> (4 * bb)) & 15u;
+            {
+              const unsigned hn = bb < 3 ? (hbv[j] >> (4 * (bb + 1))) & 15u : (j + 1 < NG ? hbv[j + 1 < NG ? j + 1 : j] & 15u : 0u);
 #pragma unroll
-          for (int k = 0; k < B; k++) elds[(rb - RV + k) * NT + tid] = ev[k];
+              for (int k = 0; k < B; k++) {
+                run_last += (int)((hn >> k) & 1u);
+                rkn[k] = run_last;
+                itn[k] = a.run_item[run_last];
+              }
+            }
+            double cc[B];
+#pragma unroll
+            for (int k = 0; k < B; k++) cc[k] = a.dv[2 * (int64_t)it[k] + 1];
+            const unsigned w0 = uwv[j][2 * bb], w1 = uwv[j][2 * bb + 1];
+            const int uid[B] = {(int)(w0 & 0xffffu), (int)(w0 >> 16), (int)(w1 & 0xffffu), (int)(w1 >> 16)};
+            d2_t ut[B];
+            double ex[B];
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+              ut[k] = utab[uid[k]];
+              ex[k] = j < NGV ? ev[j < NGV ? j : 0][4 * bb + k] : elds[(16 * (j - NGV) + 4 * bb + k) * NT + tid];
+            }
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+              const bool head = ((h4 >> k) & 1u) != 0u;
+              // a run that began and ended in this thread: the slot before this head closed run rk[k] - 1
+              if (head && have_head) part2[rk[k] - 1] = d2_t{s1, s2};
+              f1 = head && !have_head ? s1 : f1;
+              f2 = head && !have_head ? s2 : f2;
+              have_head = have_head || head;
+              const double er = ex[k] + cc[k] * ut[k][1];
+              if (j < NGV)
+                ev[j < NGV ? j : 0][4 * bb + k] = er;
+              else
+                elds[(16 * (j - NGV) + 4 * bb + k) * NT + tid] = er;
+              s1 = (head ? 0.0 : s1) + (-er) * ut[k][0];
+              s2 = (head ? 0.0 : s2) + ut[k][0] * ut[k][0];
+            }
+          }
         }
       }
       // stitch the runs that cross thread boundaries: a thread with a head restarts the running sum with its open tail,
@@ -397,39 +419,32 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
     res_grid_barrier(a, ++nbar, tid, dead);
   }
   // the last factor's item update, then the residual goes back
-  auto store_e = [&](int rb, const double (&ev)[B]) {
-    uint32_t m[B];
-    int row[B];
-    const int t = res_fence_lane(tid);
-    const uint32_t *mp = meta_g + rb * NT;
-    const int32_t *pp = perm_g + rb * NT;
+  {
+    int run_last = run0;
 #pragma unroll
-    for (int k = 0; k < B; k++) {
-      m[k] = mp[k * NT + t];
-      row[k] = pp[k * NT + t];
-    }
-#pragma unroll
-    for (int k = 0; k < B; k++) {
-      const double dl = a.dv[2 * (int64_t)(m[k] & imask)];
-      if (row[k] >= 0) a.eq[row[k]].x = ev[k] + utab[m[k] >> ib][0] * dl;
-    }
-  };
-#pragma unroll
-  for (int rb = 0; rb < RV; rb += B) {
-    double ev[B];
-#pragma unroll
-    for (int k = 0; k < B; k++) ev[k] = e[rb + k];
-    store_e(rb, ev);
-  }
+    for (int j = 0; j < NG; j++) {
 #pragma unroll 1
-  for (int rb = RV; rb < R; rb += B) {
-    double ev[B];
+      for (int bb = 0; bb < 4; bb++) {
+        const unsigned h4 = (hbv[j] >> (4 * bb)) & 15u;
+        int row[B], it[B];
 #pragma unroll
-    for (int k = 0; k < B; k++) ev[k] = elds[(rb - RV + k) * NT + tid];
-    store_e(rb, ev);
+        for (int k = 0; k < B; k++) {
+          if (16 * j + 4 * bb + k > 0) run_last += (int)((h4 >> k) & 1u);
+          it[k] = a.run_item[run_last];
+          row[k] = perm_g[(16 * j + 4 * bb + k) * NT + tid];
+        }
+        const unsigned w0 = uwv[j][2 * bb], w1 = uwv[j][2 * bb + 1];
+        const int uid[B] = {(int)(w0 & 0xffffu), (int)(w0 >> 16), (int)(w1 & 0xffffu), (int)(w1 >> 16)};
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+          const double dl = a.dv[2 * (int64_t)it[k]];
+          const double ex = j < NGV ? ev[j < NGV ? j : 0][4 * bb + k] : elds[(16 * (j - NGV) + 4 * bb + k) * NT + tid];
+          if (row[k] >= 0) a.eq[row[k]].x = ex + utab[uid[k]][0] * dl;
+        }
+      }
+    }
   }
 }
-
 
 // ---- host side: the resident layout of a two-field table and the launch ---------------------------------------------
 __global__ void k_res_init_dv(const double *__restrict__ theta, const int32_t *__restrict__ scols, int n_items,
@@ -452,7 +467,8 @@ struct ResPlan {
   DevBuf<int32_t> perm, first_run, wg_user_ptr, wg_item_ptr, ent_ptr, scols;
   DevBuf<int2> entries, item_rid;
   int rid_max = 0;
-  DevBuf<uint32_t> meta;
+  DevBuf<uint32_t> uidw, headw;
+  DevBuf<int32_t> run_item;
   DevBuf<int2> user_desc;
   DevBuf<double> partials, dv;
   DevBuf<unsigned long long> bar;
@@ -469,7 +485,7 @@ struct ResPlan {
     int rv, rl;
   };
   static const Variant *variants(int &n) {
-    static const Variant v[] = {{8, 0}, {32, 0}, {64, 16}};
+    static const Variant v[] = {{16, 0}, {32, 0}, {64, 16}};
     n = 3;
     return v;
   }
@@ -571,11 +587,12 @@ struct ResPlan {
     if (maxu > NT) return fail("more first-level columns in a workgroup than threads");
     umax = maxu + 1;
     item_bits = bits_for((int64_t)n_items + 1);
-    if (item_bits + bits_for(umax) > 32) return fail("item and user indices do not fit one word");
     // slots: per workgroup the rows in (item, row) order
-    const uint32_t pad_word = (uint32_t)n_items | ((uint32_t)(umax - 1) << item_bits);
-    std::vector<uint32_t> h_meta((size_t)G * cap_slots, pad_word);
+    const int UW = R / 2, HW = R / 16;  // users 16 bits each, head bits 16 per word (one word per group of 16 slots)
+    std::vector<uint32_t> h_uidw((size_t)G * UW * NT, (uint32_t)(umax - 1) * 0x10001u);  // every slot starts as a pad
+    std::vector<uint32_t> h_headw((size_t)G * HW * NT, 0);
     std::vector<int32_t> h_perm((size_t)G * cap_slots, -1), h_first((size_t)G * NT, 0);
+    std::vector<std::vector<int32_t>> wg_run_item((size_t)G);
     std::vector<int32_t> uord_of_row((size_t)N), wg_of_user(users.size());
     for (int g = 0; g < G; g++)
       for (int64_t u = ucut[g]; u < ucut[g + 1]; u++) wg_of_user[u] = g;
@@ -597,13 +614,17 @@ struct ResPlan {
           last_item[g] = c;
           pair_g.push_back(g);
           pair_local.push_back(nruns[g]);
+          wg_run_item[g].push_back(c);
           counter++;
           nruns[g]++;
+          const int th = (int)(sidx / R), rh = (int)(sidx % R);
+          h_headw[((size_t)g * HW + rh / 16) * NT + th] |= 1u << (rh % 16);
         }
         const int t = (int)(sidx / R), r = (int)(sidx % R);
-        const size_t at = (size_t)g * cap_slots + (size_t)r * NT + t;
-        h_meta[at] = (uint32_t)c | ((uint32_t)(uo - (int32_t)ucut[g]) << item_bits);
-        h_perm[at] = row;
+        h_perm[(size_t)g * cap_slots + (size_t)r * NT + t] = row;
+        uint32_t &uw = h_uidw[((size_t)g * UW + r / 2) * NT + t];
+        const int sh = 16 * (r % 2);
+        uw = (uw & ~(0xffffu << sh)) | ((uint32_t)(uo - (int32_t)ucut[g]) << sh);
         if (r == 0) h_first[(size_t)g * NT + t] = nruns[g] - 1;
       }
     }
@@ -614,7 +635,15 @@ struct ResPlan {
     std::vector<int32_t> run_base((size_t)G + 1, 0);
     for (int g = 0; g < G; g++) run_base[g + 1] = run_base[g] + nruns[g] + 1;
     const int32_t zero_run = run_base[G];  // a partial that stays (0, 0): what the padding entries of the item draw gather
+    std::vector<int32_t> h_run_item((size_t)zero_run + 1, n_items);
     for (int g = 0; g < G; g++) {
+      std::copy(wg_run_item[g].begin(), wg_run_item[g].end(), h_run_item.begin() + run_base[g]);
+      // the first pad slot opens the pad run (item n_items); thread 0's first slot is a head whatever it holds
+      if (fill[g] < cap_slots) {
+        const int th = (int)(fill[g] / R), rh = (int)(fill[g] % R);
+        h_headw[((size_t)g * HW + rh / 16) * NT + th] |= 1u << (rh % 16);
+      }
+      h_headw[((size_t)g * HW) * NT] |= 1u;
       // threads whose first slot is a pad: the pad run
       for (int t = 0; t < NT; t++) {
         const int64_t s0 = (int64_t)t * R;
@@ -673,7 +702,9 @@ struct ResPlan {
     lds_bytes = (size_t)RL * NT * 8 + (size_t)2 * (NT / WAVE) * umax * 8 + (size_t)umax * 16 + (size_t)(NT / WAVE) * 16 + (size_t)rid_max * 16 +
                 (NT / WAVE) * 4 + 64;
     if (lds_bytes > 160 * 1024 - 512) return fail("LDS");
-    meta.upload(h_meta);
+    uidw.upload(h_uidw);
+    headw.upload(h_headw);
+    run_item.upload(h_run_item);
     perm.upload(h_perm);
     first_run.upload(h_first);
     wg_user_ptr.upload(h_uptr);
@@ -708,7 +739,9 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   std::memset(&a, 0, sizeof(a));
   a.eq = eq;
   a.perm = rp.perm.p;
-  a.meta = rp.meta.p;
+  a.uidw = rp.uidw.p;
+  a.headw = rp.headw.p;
+  a.run_item = rp.run_item.p;
   a.first_run = rp.first_run.p;
   a.wg_user_ptr = rp.wg_user_ptr.p;
   a.user_desc = rp.user_desc.p;
@@ -749,14 +782,14 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   do {                                                                                                                        \
     static DeviceOnce raised;                                                                                                 \
     if (raised.need()) {                                                                                                      \
-      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_resident<512, RV_, RL_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                        160 * 1024));                                                                         \
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_resident<512, RV_ / 16, RL_ / 16>,                                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                             \
       raised.mark();                                                                                                          \
     }                                                                                                                         \
-    hipLaunchKernelGGL((k_mf_resident<512, RV_, RL_>), dim3(rp.G), dim3(512), rp.lds_bytes, s, a);                              \
+    hipLaunchKernelGGL((k_mf_resident<512, RV_ / 16, RL_ / 16>), dim3(rp.G), dim3(512), rp.lds_bytes, s, a);                    \
   } while (0)
-  if (rp.RV == 8 && rp.RL == 0)
-    MFM_RES_LAUNCH(8, 0);
+  if (rp.RV == 16 && rp.RL == 0)
+    MFM_RES_LAUNCH(16, 0);
   else if (rp.RV == 32 && rp.RL == 0)
     MFM_RES_LAUNCH(32, 0);
   else if (rp.RV == 64 && rp.RL == 16)
