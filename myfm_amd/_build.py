@@ -36,7 +36,8 @@ def build_hip(force=False, verbose=False):
     if not (force or _newer(HIP_LIB, deps)):
         return HIP_LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-I" + INCLUDE, "-I" + CSRC] + [os.path.join(CSRC, f) for f in HIP_SOURCES] + ["-o", HIP_LIB]
+           "-I" + INCLUDE, "-I" + CSRC] + os.environ.get("MYFM_AMD_HIPCC_FLAGS", "").split() + \
+          [os.path.join(CSRC, f) for f in HIP_SOURCES] + ["-o", HIP_LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -38,19 +38,23 @@ namespace mfm {
 struct ResArgs {
   double2 *eq;               // residual: read at [row].x at the start, written back at the end
   const int32_t *perm;       // [G][R][NT] row of the slot, -1: pad
-  const uint32_t *uidw;      // [G][R / 2][NT] the slots' users (index within the workgroup), 16 bits each; pads: umax - 1
+  const uint32_t *uidw;      // [G][5 R / 16][NT] the slots' users (index within the workgroup), 10 bits each: per group of
+                             // 16 slots 4 words (3 users + 2 bits of the 4th of a batch) + 1 word (its other 8 bits);
+                             // pads: umax - 1
   const uint32_t *headw;     // [G][R / 16][NT] bit r % 16: slot r starts a new item run (slot 0 of thread 0 always)
   const int32_t *run_item;   // [runs + 1] item of every (workgroup, item) run; pad runs: the pad item n_items
   const int32_t *first_run;  // [G][NT]   run containing the thread's first slot
+  const int32_t *wg_run_ptr; // [G + 1] first run of the workgroup
+  const int32_t *wg_nruns;   // [G] its runs; run wg_run_ptr[g] + wg_nruns[g] is its pad run (never gathered)
   const int32_t *wg_user_ptr;  // [G + 1]
   const int2 *user_desc;     // {feature, group}
-  const int32_t *wg_item_ptr;  // [G + 1] items (positions in the level) drawn by the workgroup
+  const int32_t *wg_item_ptr;  // [G + 1] items (positions in the level) drawn by the workgroup: at most umax - 1
   const int32_t *ent_ptr;    // [G + 1] the workgroup's slice of `entries`, in entries (a multiple of 64)
-  const int2 *entries;       // item-major: {run whose partial belongs to the item, row of the item draw's LDS table}
-  const int2 *item_rid;      // per item: {first row of that table, number of rows}
+  const int2 *entries;       // per slice, source-workgroup-major: {run whose partial belongs to the item, item - first item
+                             // of the slice}; pads: {the zero run, 0}
   const int32_t *scols;      // item -> feature
   double *partials;          // [runs + 1][2], workgroup-major: a thread's runs are consecutive; the last stays (0, 0)
-  double *dv;                // [items][2]  (delta of this factor, coefficient of the next)
+  double *dv;                // [items + 1][2]  (delta of this factor, coefficient of the next); the pad item stays (0, 0)
   double *V;                 // factor-major [K][D]
   int64_t D;
   int f_begin, f_end;
@@ -59,15 +63,14 @@ struct ResArgs {
   const int32_t *group;      // per feature
   int n_groups;
   double alpha;
-  int item_bits, umax;       // umax: LDS stride of the per-wave user arrays (>= users of any workgroup)
-  int rid_max;               // rows of the item draw's LDS table
-  unsigned long long *bar;   // monotone arrival counter
-  unsigned long long bar_base;  // its value before this launch
+  int n_items, umax;         // umax: LDS stride of the per-wave accumulator arrays (> users of any workgroup, > items of any slice)
+  unsigned long long *bar;   // barrier state (RES_BAR_*), zeroed before the launch
   int n_wg;
   int *error;                // set on a spin timeout
+  unsigned long long *prof;  // MFM_RES_PROF: [G][factors][8] s_memrealtime stamps of thread 0 (100 MHz), else null
+  int rot;                   // workgroup g runs as block (g - rot) mod G (MFM_RES_ROT: placement experiments)
   int dbg;                   // timing experiments only (MFM_RES_DBG; results are wrong when set): 4 no grid barriers, 32 no item
-                             // draw, 64 no sweep A, 128 no sweep B (whole phases only: a switch inside a sweep's batches breaks
-                             // them into basic blocks and serialises their loads)
+                             // draw, 64 no sweep A, 128 no sweep B, 4096 no partial stores inside sweep B
 };
 
 __device__ __forceinline__ void res_store2(double *p, double a, double b) {
@@ -75,89 +78,150 @@ __device__ __forceinline__ void res_store2(double *p, double a, double b) {
   __hip_atomic_store(p + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Grid barrier #k of the launch (k counted from 1): every workgroup arrives once; payloads were stored write-through and are
-// drained by every wave before the arrival; one acquire per workgroup afterwards, then plain loads.
-__device__ __forceinline__ void res_grid_barrier(const ResArgs &a, unsigned long long k, int tid, bool &dead) {
+// Grid barrier, hierarchical by XCD (MI355X_MICROARCH.md "barrier-xcd"). The workgroups of one XCD share its L2: each of
+// them drains its own stores into that L2 and arrives at the XCD's counter; only the LAST arriver of the XCD runs the
+// agent-scope release (buffer_wbl2: the whole L2's dirty lines -- 128 KB of partials per workgroup) and then meets the other
+// XCDs' leaders at the top counter; it releases its XCD through a generation word. (With a release per workgroup every
+// early arriver started a write-back of the L2 the late ones were still storing into: the slowest workgroups of sweep B ran
+// 20 us longer than the rest.) Every workgroup acquires afterwards. State: 128-byte spaced words, zeroed before each launch.
+// The XCD a workgroup runs on is read from the hardware (HW_REG_XCC_ID), the workgroups per XCD are counted at the start of
+// the launch: nothing depends on how the dispatcher places blocks.
+enum { RES_BAR_START = 0, RES_BAR_TOP = 16, RES_BAR_XCNT = 32, RES_BAR_GEN = 160, RES_BAR_CENSUS = 288, RES_BAR_WORDS = 416 };
+struct ResBar {
+  int xcc;                     // this workgroup's XCD
+  unsigned long long n_x, nx;  // workgroups on it, XCDs in use
+};
+
+__device__ __forceinline__ bool res_spin(const ResArgs &a, const unsigned long long *w, unsigned long long target, bool &dead) {
+  unsigned spins = 0;
+  while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 1023u) == 0u) {
+      if (spins > (1u << 22) || __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(a.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead = true;  // (every later barrier of this workgroup falls through: the launch ends, the host reports)
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
+// start of the launch (thread 0 only): census of the workgroups per XCD, one flat barrier
+__device__ __forceinline__ void res_bar_init(const ResArgs &a, ResBar &rb, bool &dead) {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+  rb.xcc = (int)(x & 7u);
+  __hip_atomic_fetch_add(a.bar + RES_BAR_CENSUS + 16 * rb.xcc, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_fetch_add(a.bar + RES_BAR_START, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  rb.n_x = 1;
+  rb.nx = 1;
+  if (a.dbg & 4) return;
+  if (!res_spin(a, a.bar + RES_BAR_START, (unsigned long long)a.n_wg, dead)) return;
+  rb.nx = 0;
+  for (int i = 0; i < 8; i++) {
+    const unsigned long long c = __hip_atomic_load(a.bar + RES_BAR_CENSUS + 16 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rb.nx += c > 0 ? 1 : 0;
+    if (i == rb.xcc) rb.n_x = c;
+  }
+}
+
+// barrier #k of the launch (k counted from 1)
+__device__ __forceinline__ void res_grid_barrier(const ResArgs &a, const ResBar &rb, unsigned long long k, int tid, bool &dead) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have reached the XCD's L2
   __syncthreads();
   if (tid == 0 && !dead && !(a.dbg & 4)) {
-    // (the partials are plain 16-byte stores -- a thread's runs are adjacent, whole lines form in L2 --: one agent-scope
-    //  release writes them back; the asm wait restates the wait the compiler may drop, Guideline 16 pitfall 12)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(a.bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long target = a.bar_base + k * (unsigned long long)a.n_wg;
-    unsigned spins = 0;
-    while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 1023u) == 0u) {
-        if (spins > (1u << 22) || __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          __hip_atomic_store(a.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          dead = true;  // (every later barrier of this workgroup falls through: the launch ends, the host reports)
-          break;
-        }
-      }
+    const unsigned long long old =
+        __hip_atomic_fetch_add(a.bar + RES_BAR_XCNT + 16 * rb.xcc, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == k * rb.n_x) {
+      // (the asm wait restates the wait the compiler may drop after the fence, Guideline 16 pitfall 12)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(a.bar + RES_BAR_TOP, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (res_spin(a, a.bar + RES_BAR_TOP, k * rb.nx, dead))
+        __hip_atomic_store(a.bar + RES_BAR_GEN + 16 * rb.xcc, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      res_spin(a, a.bar + RES_BAR_GEN + 16 * rb.xcc, k, dead);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
 }
 
-// Optimisation fence of the unrolled sweeps: the lane offset and the base pointers of the next batch of loads pass through an
-// empty volatile asm, so that the compiler can neither precompute the addresses of all R / B batches (80 SGPR pairs + the
-// VGPRs of every hoisted load: the residual spilled) nor move a batch's loads above the previous batch.
-__device__ __forceinline__ int res_fence_lane(int t) {
-  asm volatile("" : "+v"(t)::"memory");
-  return t;
-}
 typedef double res_d16_t __attribute__((ext_vector_type(16)));
-typedef unsigned res_u8_t __attribute__((ext_vector_type(8)));
+typedef unsigned res_u4_t __attribute__((ext_vector_type(4)));
 
 // NT threads; a thread's slots come in groups of 16: NGV groups live in registers (one 16-double vector each), NGL groups in
 // LDS ([16 NGL][NT] doubles: lane-consecutive, conflict-free). Everything static about a group stays in registers for the whole
-// launch: 16 head bits (a new item run starts at the slot) and the slots' users, 16 bits each (8 words). The sweeps are REAL
-// loops over batches of 4 slots -- the loop counter is wave-uniform, so the batch's residuals and words are picked out of the
-// register vectors with s_set_gpr_idx (no scratch, no waterfall) -- and only the group loop is unrolled. (A fully unrolled
-// sweep leaves the compiler free to hoist the loads of all 20 batches -- every address is a function of static registers --
-// and it then spills the residual; pinning each batch behind the previous one with empty asm statements was tried and lost.)
-// The item of a run comes from run_item[run] (4 bytes per (workgroup, item) run, walked sequentially by every thread: cache
-// resident); the head bits give the run index of every slot without a memory access, so the run_item loads of batch b + 1 are
-// in flight while batch b computes and the only dependent global access of a batch is its dv gather.
+// launch: 16 head bits (a new item run starts at the slot) and the slots' users, 10 bits each (5 words). The sweeps are REAL
+// loops over batches of 4 slots -- the loop counter is wave-uniform, so the batch's residuals are picked out of the register
+// vectors with s_set_gpr_idx (no scratch, no waterfall) -- and only the group loop is unrolled.
+//
+// What a slot needs from outside the CU is its item's pair dv[item]; the item changes only where a run starts (every 4.9th
+// slot at config 3). A 64-lane gather costs the CU's address path one cycle per distinct line, so the sweeps gather ONLY at
+// run starts: every other lane of the instruction reads one wave-uniform dummy element (no branch, no execution mask) and
+// carries the previous slot's value. The item of a run comes from run_item[run] -- the head bits give the run index of
+// every slot without a memory access -- gathered the same way. Both chains are software-pipelined by hand: while batch b
+// computes, the dv gathers of batch b + 1 and the run_item gathers of batch b + 2 are in flight.
 template <int NT, int NGV, int NGL>
 __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) char res_smem[];
   constexpr int NW = NT / WAVE, NG = NGV + NGL, R = 16 * NG, RL = 16 * NGL;
   constexpr int B = 4;  // slots per batch
-  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int g = (int)((blockIdx.x + (unsigned)a.rot) % gridDim.x), tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int U = a.umax;
   double *elds = (double *)res_smem;      // [RL][NT] residual of the LDS-resident slots
-  double *acc1 = elds + (size_t)RL * NT;  // [NW][U]  sum of -e h per (wave, user)
+  double *acc1 = elds + (size_t)RL * NT;  // [NW][U]  sum of -e h per (wave, user) / (wave, item of the slice)
   double *acc2 = acc1 + NW * U;           // [NW][U]  sum of h^2
   d2_t *utab = (d2_t *)(acc2 + NW * U);   // [U] {new coefficient, new - old}
   d2_t *wcarry = utab + U;                // [NW]
-  d2_t *cpart = wcarry + NW;              // [rid_max] item draw: sums per (64-entry chunk, item)
-  int *wflag = (int *)(cpart + a.rid_max);  // [NW]
+  int *wflag = (int *)(wcarry + NW);      // [NW]
   const int32_t *perm_g = a.perm + (int64_t)g * R * NT;
   const d2_t *dv2 = (const d2_t *)a.dv;
   const int u0 = a.wg_user_ptr[g], nu = a.wg_user_ptr[g + 1] - u0;
+  const int rb0 = a.wg_run_ptr[g];
+  const int pad_item = a.n_items;
   bool dead = false;
   unsigned long long nbar = 0;
+  ResBar rbar;
+  rbar.xcc = 0;
+  rbar.n_x = rbar.nx = 1;
+  if (tid == 0) res_bar_init(a, rbar, dead);
+  const bool nost = (a.dbg & 4096) != 0;  // (4096: no partial stores inside sweep B)
+  const int trash_run = a.wg_run_ptr[g] + a.wg_nruns[g];
+#define RES_STAMP(k)                                                                                      \
+  if (a.prof && tid == 0) a.prof[((int64_t)g * (a.f_end - a.f_begin) + (f - a.f_begin)) * 64 + (k)] = __builtin_amdgcn_s_memrealtime()
 
   for (int i = tid; i < 2 * NW * U; i += NT) acc1[i] = 0.0;
   for (int i = tid; i < U; i += NT) utab[i] = d2_t{0.0, 0.0};
 
   // static per-thread words
-  res_u8_t uwv[NG];
-  unsigned hbv[NG];
+  res_u4_t uw[NG];            // word bb of a group: users 0..2 of batch bb and the low 2 bits of user 3
+  unsigned ux[NG];            // byte bb: the high 8 bits of user 3 of batch bb
+  unsigned hbv[NG], nbv[NG];  // head bits; "gather here" bits = the head bits + the thread's first slot
 #pragma unroll
   for (int j = 0; j < NG; j++) {
 #pragma unroll
-    for (int w = 0; w < 8; w++) uwv[j][w] = a.uidw[((int64_t)g * (8 * NG) + 8 * j + w) * NT + tid];
+    for (int w = 0; w < 4; w++) uw[j][w] = a.uidw[((int64_t)g * (5 * NG) + 5 * j + w) * NT + tid];
+    ux[j] = a.uidw[((int64_t)g * (5 * NG) + 5 * j + 4) * NT + tid];
     hbv[j] = a.headw[((int64_t)g * NG + j) * NT + tid];
+    nbv[j] = hbv[j] | (j == 0 ? 1u : 0u);
   }
   const int run0 = a.first_run[g * NT + tid];  // the run containing this thread's first slot
   const bool head0 = (hbv[0] & 1u) != 0u;
+  // gather bits of batch q of group j; q may run past the group (0 .. 5)
+#define RES_NIB(j, q) ((((nbv[j]) | ((j) + 1 < NG ? nbv[(j) + 1 < NG ? (j) + 1 : (j)] << 16 : 0u)) >> (4 * (q))) & 15u)
+  // the four users of batch bb of group j
+#define RES_UIDS(j, bb, uid)                                                     \
+  {                                                                              \
+    const unsigned lo_ = uw[j][bb];                                              \
+    uid[0] = (int)(lo_ & 0x3ffu);                                                \
+    uid[1] = (int)((lo_ >> 10) & 0x3ffu);                                        \
+    uid[2] = (int)((lo_ >> 20) & 0x3ffu);                                        \
+    uid[3] = (int)((lo_ >> 30) | (((ux[j] >> (8 * (bb))) & 0xffu) << 2));        \
+  }
 
   // Pad slots carry (pad item, pad user): an item whose dv entry stays (0, 0) and a user slot nobody draws, so that every slot
   // runs the same straight-line code: a pad's statistics add 0 whatever its residual holds.
@@ -195,61 +259,76 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       ulam = a.lam[(int64_t)f * a.n_groups + d.y];
       umu = a.mu[(int64_t)f * a.n_groups + d.y];
     }
+    RES_STAMP(0);
     // ---- sweep A: the item update of the previous factor (:371-375; dv.x = 0 before the first), the user level's
     //      statistics (:351-356)
     if (!(a.dbg & 64)) {
-      // run indices of the first batch (slot 0 belongs to run0 whether or not it is a head) and their items
-      int itn[B];
-      int run_last = run0;
+      int rc = run0 - 1;  // run counter of the run_item stage
+      int itA[B];         // items of the next batch (in flight)
+      d2_t ddA[B];        // dv pairs of this batch (in flight)
       {
-        const unsigned h4 = hbv[0] & 15u;
+        int it0[B];
+        const unsigned n0 = RES_NIB(0, 0), n1 = RES_NIB(0, 1);
 #pragma unroll
         for (int k = 0; k < B; k++) {
-          if (k > 0) run_last += (int)((h4 >> k) & 1u);
-          itn[k] = a.run_item[run_last];
+          rc += (int)((n0 >> k) & 1u);
+          it0[k] = a.run_item[(n0 >> k) & 1u ? rc : rb0];
         }
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+          rc += (int)((n1 >> k) & 1u);
+          itA[k] = a.run_item[(n1 >> k) & 1u ? rc : rb0];
+        }
+#pragma unroll
+        for (int k = 0; k < B; k++) ddA[k] = dv2[(n0 >> k) & 1u ? it0[k] : pad_item];
       }
+      d2_t ddc = d2_t{0.0, 0.0};
+      int itB[B];
+      d2_t ddB[B];
+      // one batch: the run_item gathers of batch b + 2 (-> ito), the dv gathers of batch b + 1 (items iti -> ddo), then batch
+      // b from ddi. Two steps with the buffers swapped make one iteration of the rolled loop: no register is copied while
+      // its load is in flight.
+#define RES_STEP_A(j, bb, iti, ito, ddi, ddo)                                                                              \
+  {                                                                                                                        \
+    const unsigned n4 = RES_NIB(j, bb), n4a = RES_NIB(j, (bb) + 1), n4b = RES_NIB(j, (bb) + 2);                            \
+    _Pragma("unroll") for (int k = 0; k < B; k++) {                                                                        \
+      rc += (int)((n4b >> k) & 1u);                                                                                        \
+      ito[k] = a.run_item[(n4b >> k) & 1u ? rc : rb0];                                                                     \
+    }                                                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < B; k++) ddo[k] = dv2[(n4a >> k) & 1u ? iti[k] : pad_item];                       \
+    int uid[B];                                                                                                            \
+    RES_UIDS(j, bb, uid);                                                                                                  \
+    double up[B], ex[B];                                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < B; k++) {                                                                        \
+      up[k] = utab[uid[k]][0];                                                                                             \
+      ex[k] = j < NGV ? ev[j < NGV ? j : 0][4 * (bb) + k] : elds[(16 * (j - NGV) + 4 * (bb) + k) * NT + tid];              \
+    }                                                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < B; k++) {                                                                        \
+      const bool need = ((n4 >> k) & 1u) != 0u;                                                                            \
+      ddc[0] = need ? ddi[k][0] : ddc[0];                                                                                  \
+      ddc[1] = need ? ddi[k][1] : ddc[1];                                                                                  \
+      const double er = ex[k] + up[k] * ddc[0];                                                                            \
+      if (j < NGV)                                                                                                         \
+        ev[j < NGV ? j : 0][4 * (bb) + k] = er;                                                                            \
+      else                                                                                                                 \
+        elds[(16 * (j - NGV) + 4 * (bb) + k) * NT + tid] = er;                                                             \
+      const double c = ddc[1];                                                                                             \
+      __hip_atomic_fetch_add(&acc1[wv * U + uid[k]], (-er) * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);           \
+      __hip_atomic_fetch_add(&acc2[wv * U + uid[k]], c * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);               \
+    }                                                                                                                      \
+  }
 #pragma unroll
       for (int j = 0; j < NG; j++) {
 #pragma unroll 1
-        for (int bb = 0; bb < 4; bb++) {
-          int it[B];
-#pragma unroll
-          for (int k = 0; k < B; k++) it[k] = itn[k];
-          {  // the next batch's items: in flight while this batch computes (past the last batch: the same runs again)
-            const unsigned hn = bb < 3 ? (hbv[j] >> (4 * (bb + 1))) & 15u : (j + 1 < NG ? hbv[j + 1 < NG ? j + 1 : j] & 15u : 0u);
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-              run_last += (int)((hn >> k) & 1u);
-              itn[k] = a.run_item[run_last];
-            }
-          }
-          d2_t dd[B];
-#pragma unroll
-          for (int k = 0; k < B; k++) dd[k] = dv2[it[k]];
-          const unsigned w0 = uwv[j][2 * bb], w1 = uwv[j][2 * bb + 1];
-          const int uid[B] = {(int)(w0 & 0xffffu), (int)(w0 >> 16), (int)(w1 & 0xffffu), (int)(w1 >> 16)};
-          double up[B], ex[B];
-#pragma unroll
-          for (int k = 0; k < B; k++) {
-            up[k] = utab[uid[k]][0];
-            ex[k] = j < NGV ? ev[j < NGV ? j : 0][4 * bb + k] : elds[(16 * (j - NGV) + 4 * bb + k) * NT + tid];
-          }
-#pragma unroll
-          for (int k = 0; k < B; k++) {
-            const double er = ex[k] + up[k] * dd[k][0];
-            if (j < NGV)
-              ev[j < NGV ? j : 0][4 * bb + k] = er;
-            else
-              elds[(16 * (j - NGV) + 4 * bb + k) * NT + tid] = er;
-            const double c = dd[k][1];
-            __hip_atomic_fetch_add(&acc1[wv * U + uid[k]], (-er) * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&acc2[wv * U + uid[k]], c * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
+        for (int bp = 0; bp < 2; bp++) {
+          RES_STEP_A(j, 2 * bp, itA, itB, ddA, ddB);
+          RES_STEP_A(j, 2 * bp + 1, itB, itA, ddB, ddA);
         }
       }
+#undef RES_STEP_A
     }
     __syncthreads();
+    RES_STAMP(1);
     // ---- user draw (:357-369): thread u sums user u's wave accumulators in wave order
     if (tid < nu) {
       double S1 = 0.0, S2 = 0.0;
@@ -265,74 +344,96 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       utab[tid] = d2_t{fresh, fresh - uold};
     }
     __syncthreads();
+    RES_STAMP(2);
     // ---- sweep B: the user update (:371-375), the item level's statistics run by run
     {
       bool have_head = false;
       double f1 = 0.0, f2 = 0.0, s1 = 0.0, s2 = 0.0;
       d2_t *part2 = (d2_t *)a.partials;
       if (!(a.dbg & 128)) {
-        int itn[B], rkn[B];
-        int run_last = run0;
+        int rc = run0 - 1, rcC = run0 - 1;  // run counters of the run_item stage and of the compute stage
+        int itA[B];
+        double ccA[B];
         {
-          const unsigned h4 = hbv[0] & 15u;
+          int it0[B];
+          const unsigned n0 = RES_NIB(0, 0), n1 = RES_NIB(0, 1);
 #pragma unroll
           for (int k = 0; k < B; k++) {
-            if (k > 0) run_last += (int)((h4 >> k) & 1u);
-            rkn[k] = run_last;
-            itn[k] = a.run_item[run_last];
+            rc += (int)((n0 >> k) & 1u);
+            it0[k] = a.run_item[(n0 >> k) & 1u ? rc : rb0];
           }
+#pragma unroll
+          for (int k = 0; k < B; k++) {
+            rc += (int)((n1 >> k) & 1u);
+            itA[k] = a.run_item[(n1 >> k) & 1u ? rc : rb0];
+          }
+#pragma unroll
+          for (int k = 0; k < B; k++) ccA[k] = a.dv[2 * (int64_t)((n0 >> k) & 1u ? it0[k] : pad_item) + 1];
         }
+        double ccc = 0.0;
+        int itB[B];
+        double ccB[B];
+#ifdef MFM_RES_UCST  // (experiment: a fixed number of stores per batch, the slots that close nothing store to the pad run)
+#define RES_PARTIAL_STORE() part2[head && have_head ? rcC - 1 : trash_run] = d2_t{s1, s2}
+#else
+#define RES_PARTIAL_STORE() \
+  if (head && have_head && !nost) part2[rcC - 1] = d2_t{s1, s2}
+#endif
+#define RES_STEP_B(j, bb, iti, ito, cci, cco)                                                                              \
+  {                                                                                                                        \
+    const unsigned n4 = RES_NIB(j, bb), n4a = RES_NIB(j, (bb) + 1), n4b = RES_NIB(j, (bb) + 2);                            \
+    const unsigned h4 = (hbv[j] >> (4 * (bb))) & 15u;                                                                      \
+    _Pragma("unroll") for (int k = 0; k < B; k++) {                                                                        \
+      rc += (int)((n4b >> k) & 1u);                                                                                        \
+      ito[k] = a.run_item[(n4b >> k) & 1u ? rc : rb0];                                                                     \
+    }                                                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < B; k++) cco[k] = a.dv[2 * (int64_t)((n4a >> k) & 1u ? iti[k] : pad_item) + 1];   \
+    int uid[B];                                                                                                            \
+    RES_UIDS(j, bb, uid);                                                                                                  \
+    d2_t ut[B];                                                                                                            \
+    double ex[B];                                                                                                          \
+    _Pragma("unroll") for (int k = 0; k < B; k++) {                                                                        \
+      ut[k] = utab[uid[k]];                                                                                                \
+      ex[k] = j < NGV ? ev[j < NGV ? j : 0][4 * (bb) + k] : elds[(16 * (j - NGV) + 4 * (bb) + k) * NT + tid];              \
+    }                                                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < B; k++) {                                                                        \
+      const bool need = ((n4 >> k) & 1u) != 0u;                                                                            \
+      const bool head = ((h4 >> k) & 1u) != 0u;                                                                            \
+      ccc = need ? cci[k] : ccc;                                                                                           \
+      rcC += need ? 1 : 0; /* the run of this slot */                                                                      \
+      /* a run that began and ended in this thread: the slot before this head closed run rcC - 1 */                        \
+      RES_PARTIAL_STORE();                                                                                                 \
+      f1 = head && !have_head ? s1 : f1;                                                                                   \
+      f2 = head && !have_head ? s2 : f2;                                                                                   \
+      have_head = have_head || head;                                                                                       \
+      const double er = ex[k] + ccc * ut[k][1];                                                                            \
+      if (j < NGV)                                                                                                         \
+        ev[j < NGV ? j : 0][4 * (bb) + k] = er;                                                                            \
+      else                                                                                                                 \
+        elds[(16 * (j - NGV) + 4 * (bb) + k) * NT + tid] = er;                                                             \
+      s1 = (head ? 0.0 : s1) + (-er) * ut[k][0];                                                                           \
+      s2 = (head ? 0.0 : s2) + ut[k][0] * ut[k][0];                                                                        \
+    }                                                                                                                      \
+  }
 #pragma unroll
         for (int j = 0; j < NG; j++) {
 #pragma unroll 1
-          for (int bb = 0; bb < 4; bb++) {
-            int it[B], rk[B];
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-              it[k] = itn[k];
-              rk[k] = rkn[k];
-            }
-            const unsigned h4 = (hbv[j] >> (4 * bb)) & 15u;
-            {
-              const unsigned hn = bb < 3 ? (hbv[j] >> (4 * (bb + 1))) & 15u : (j + 1 < NG ? hbv[j + 1 < NG ? j + 1 : j] & 15u : 0u);
-#pragma unroll
-              for (int k = 0; k < B; k++) {
-                run_last += (int)((hn >> k) & 1u);
-                rkn[k] = run_last;
-                itn[k] = a.run_item[run_last];
-              }
-            }
-            double cc[B];
-#pragma unroll
-            for (int k = 0; k < B; k++) cc[k] = a.dv[2 * (int64_t)it[k] + 1];
-            const unsigned w0 = uwv[j][2 * bb], w1 = uwv[j][2 * bb + 1];
-            const int uid[B] = {(int)(w0 & 0xffffu), (int)(w0 >> 16), (int)(w1 & 0xffffu), (int)(w1 >> 16)};
-            d2_t ut[B];
-            double ex[B];
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-              ut[k] = utab[uid[k]];
-              ex[k] = j < NGV ? ev[j < NGV ? j : 0][4 * bb + k] : elds[(16 * (j - NGV) + 4 * bb + k) * NT + tid];
-            }
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-              const bool head = ((h4 >> k) & 1u) != 0u;
-              // a run that began and ended in this thread: the slot before this head closed run rk[k] - 1
-              if (head && have_head) part2[rk[k] - 1] = d2_t{s1, s2};
-              f1 = head && !have_head ? s1 : f1;
-              f2 = head && !have_head ? s2 : f2;
-              have_head = have_head || head;
-              const double er = ex[k] + cc[k] * ut[k][1];
-              if (j < NGV)
-                ev[j < NGV ? j : 0][4 * bb + k] = er;
-              else
-                elds[(16 * (j - NGV) + 4 * bb + k) * NT + tid] = er;
-              s1 = (head ? 0.0 : s1) + (-er) * ut[k][0];
-              s2 = (head ? 0.0 : s2) + ut[k][0] * ut[k][0];
-            }
+          for (int bp = 0; bp < 2; bp++) {
+            RES_STEP_B(j, 2 * bp, itA, itB, ccA, ccB);
+            if (a.prof && lane == 0 && (wv == 4 || wv == 7))  // (waves 4 and 7: every batch)
+              a.prof[((int64_t)g * (a.f_end - a.f_begin) + (f - a.f_begin)) * 64 + 16 + (wv == 4 ? 0 : 20) + 4 * j + 2 * bp] =
+                  __builtin_amdgcn_s_memrealtime();
+            RES_STEP_B(j, 2 * bp + 1, itB, itA, ccB, ccA);
+            if (a.prof && lane == 0 && (wv == 4 || wv == 7))
+              a.prof[((int64_t)g * (a.f_end - a.f_begin) + (f - a.f_begin)) * 64 + 16 + (wv == 4 ? 0 : 20) + 4 * j + 2 * bp + 1] =
+                  __builtin_amdgcn_s_memrealtime();
           }
         }
+#undef RES_STEP_B
+#undef RES_PARTIAL_STORE
       }
+      if (a.prof && lane == 0)  // (per wave: the end of its own sweep B)
+        a.prof[((int64_t)g * (a.f_end - a.f_begin) + (f - a.f_begin)) * 64 + 8 + wv] = __builtin_amdgcn_s_memrealtime();
       // stitch the runs that cross thread boundaries: a thread with a head restarts the running sum with its open tail,
       // a thread without one passes its whole sum on
       double v1 = s1, v2 = s2;
@@ -368,56 +469,61 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
         part2[closing] = d2_t{x1 + f1, x2 + f2};
       }
     }
-    res_grid_barrier(a, ++nbar, tid, dead);
-    // ---- item draw (:357-369). The workgroup's items own a contiguous, item-major slice of `entries`; a wave takes 64-entry
-    //      chunks of it (the partials are gathered, 4 chunks in flight), a DPP segmented scan sums each chunk's stretch of
-    //      one item, the stretch's last lane leaves the sum in the LDS table at a precomputed row; then a thread per item adds
-    //      the item's rows in order (fixed association) and draws -- every item of the slice in parallel.
+    RES_STAMP(3);
+    res_grid_barrier(a, rbar, ++nbar, tid, dead);
+    RES_STAMP(4);
+    // ---- item draw (:357-369). The workgroup draws a contiguous slice of the items. The slice's partials are listed source
+    //      workgroup by source workgroup (a source's runs of consecutive items are adjacent in `partials`: the gathers read
+    //      whole lines); a wave takes a contiguous stretch of the list and adds into its own accumulator array (ds_add_f64:
+    //      the lanes of one instruction that hit the same item are serialised in lane order, a wave's instructions run in
+    //      program order); then a thread per item adds the wave arrays in wave order (fixed association) and draws.
     if (!(a.dbg & 32)) {
       constexpr int CH = 4;
       const int c0 = a.ent_ptr[g] >> 6, c1 = a.ent_ptr[g + 1] >> 6;
+      const int per = (c1 - c0 + NW - 1) / NW;
+      const int wb = c0 + wv * per, we = wb + per < c1 ? wb + per : c1;
       const d2_t *part2 = (const d2_t *)a.partials;
-      for (int cb = c0 + wv * CH; cb < c1; cb += NW * CH) {
+      for (int cb = wb; cb < we; cb += CH) {
         int2 en[CH];
 #pragma unroll
-        for (int k = 0; k < CH; k++) en[k] = cb + k < c1 ? a.entries[(int64_t)(cb + k) * WAVE + lane] : make_int2(0, -1 - lane);
+        for (int k = 0; k < CH; k++) en[k] = a.entries[(int64_t)(cb + k < we ? cb + k : cb) * WAVE + lane];
         d2_t sv[CH];
 #pragma unroll
-        for (int k = 0; k < CH; k++) sv[k] = cb + k < c1 ? part2[en[k].x] : d2_t{0.0, 0.0};
+        for (int k = 0; k < CH; k++) sv[k] = part2[en[k].x];
 #pragma unroll
         for (int k = 0; k < CH; k++) {
-          if (cb + k >= c1) break;  // wave-uniform
-          const int rid = en[k].y;
-          const int rp = dpp_i32<0x138, 0xf>(rid, 0), rn = dpp_i32<0x130, 0xf>(rid, 0);  // wave_shr:1 / wave_shl:1
-          int hd = (lane == 0 || rp != rid) ? 1 : 0;
-          const bool tail = lane == 63 || rn != rid;
-          double s1 = sv[k][0], s2 = sv[k][1];
-          wave_segscan2(s1, s2, hd);
-          if (tail) cpart[rid] = d2_t{s1, s2};
+          if (cb + k >= we) break;  // wave-uniform
+          __hip_atomic_fetch_add(&acc1[wv * U + en[k].y], sv[k][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&acc2[wv * U + en[k].y], sv[k][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
-      lds_barrier();
-      const int i0 = a.wg_item_ptr[g], i1 = a.wg_item_ptr[g + 1];
+      __syncthreads();
+      const int i0 = a.wg_item_ptr[g], ni = a.wg_item_ptr[g + 1] - i0;
       const bool more = f + 1 < a.f_end;
-      for (int i = i0 + tid; i < i1; i += NT) {
-        const int2 rr = a.item_rid[i];
+      if (tid < ni) {
+        const int i = i0 + tid;
         const int j = a.scols[i];
         const int gj = a.group[j];
         const double old = Vf[j], zj = zf[j], vn = more ? a.V[(int64_t)(f + 1) * a.D + j] : 0.0;
         const double lj = a.lam[(int64_t)f * a.n_groups + gj], mj = a.mu[(int64_t)f * a.n_groups + gj];
         double S1 = 0.0, S2 = 0.0;
-        for (int r = rr.x; r < rr.x + rr.y; r++) {
-          const d2_t cp = cpart[r];
-          S1 += cp[0];
-          S2 += cp[1];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          S1 += acc1[w * U + tid];
+          S2 += acc2[w * U + tid];
+          acc1[w * U + tid] = 0.0;
+          acc2[w * U + tid] = 0.0;
         }
         const double fresh = PMainV::draw(S1, S2, old, a.alpha, lj, mj, zj);
         Vf[j] = fresh;
         res_store2(a.dv + 2 * (int64_t)i, fresh - old, vn);
       }
     }
-    res_grid_barrier(a, ++nbar, tid, dead);
+    RES_STAMP(5);
+    res_grid_barrier(a, rbar, ++nbar, tid, dead);
+    RES_STAMP(6);
   }
+#undef RES_STAMP
   // the last factor's item update, then the residual goes back
   {
     int run_last = run0;
@@ -433,8 +539,8 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
           it[k] = a.run_item[run_last];
           row[k] = perm_g[(16 * j + 4 * bb + k) * NT + tid];
         }
-        const unsigned w0 = uwv[j][2 * bb], w1 = uwv[j][2 * bb + 1];
-        const int uid[B] = {(int)(w0 & 0xffffu), (int)(w0 >> 16), (int)(w1 & 0xffffu), (int)(w1 >> 16)};
+        int uid[B];
+        RES_UIDS(j, bb, uid);
 #pragma unroll
         for (int k = 0; k < B; k++) {
           const double dl = a.dv[2 * (int64_t)it[k]];
@@ -444,6 +550,8 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       }
     }
   }
+#undef RES_NIB
+#undef RES_UIDS
 }
 
 // ---- host side: the resident layout of a two-field table and the launch ---------------------------------------------
@@ -464,16 +572,16 @@ struct ResPlan {
   int G = 0, NT = 512, RV = 0, RL = 0, umax = 0, item_bits = 0, n_items = 0;
   int64_t n_rows = 0, n_runs = 0;  // (workgroup, item) pairs
   size_t lds_bytes = 0;
-  DevBuf<int32_t> perm, first_run, wg_user_ptr, wg_item_ptr, ent_ptr, scols;
-  DevBuf<int2> entries, item_rid;
-  int rid_max = 0;
+  DevBuf<int32_t> perm, first_run, wg_run_ptr, wg_nruns, wg_user_ptr, wg_item_ptr, ent_ptr, scols;
+  DevBuf<int2> entries;
   DevBuf<uint32_t> uidw, headw;
   DevBuf<int32_t> run_item;
   DevBuf<int2> user_desc;
   DevBuf<double> partials, dv;
   DevBuf<unsigned long long> bar;
-  unsigned long long bar_count = 0;
   std::string why;  // why the layout was not built (diagnostics)
+  std::vector<int32_t> h_nruns;  // runs per workgroup (diagnostics)
+  std::vector<std::string> h_diag;  // per workgroup (MFM_RES_PROF only)
 
   static int bits_for(int64_t n) {  // bits that hold the values 0 .. n - 1
     int b = 1;
@@ -585,11 +693,12 @@ struct ResPlan {
     int maxu = 0;
     for (int g = 0; g < G; g++) maxu = std::max(maxu, (int)wg_users[g].size());
     if (maxu > NT) return fail("more first-level columns in a workgroup than threads");
-    umax = maxu + 1;
     item_bits = bits_for((int64_t)n_items + 1);
     // slots: per workgroup the rows in (item, row) order
-    const int UW = R / 2, HW = R / 16;  // users 16 bits each, head bits 16 per word (one word per group of 16 slots)
-    std::vector<uint32_t> h_uidw((size_t)G * UW * NT, (uint32_t)(umax - 1) * 0x10001u);  // every slot starts as a pad
+    // users 10 bits each (16 slots in 5 words), head bits 16 per word (one word per group of 16 slots); every slot starts
+    // as a pad (user field 0: rewritten below once umax is known)
+    const int UW = 5 * (R / 16), HW = R / 16;
+    std::vector<uint16_t> h_uid((size_t)G * cap_slots, 0xffffu);  // [g][slot]: user within the workgroup, 0xffff: pad
     std::vector<uint32_t> h_headw((size_t)G * HW * NT, 0);
     std::vector<int32_t> h_perm((size_t)G * cap_slots, -1), h_first((size_t)G * NT, 0);
     std::vector<std::vector<int32_t>> wg_run_item((size_t)G);
@@ -600,7 +709,6 @@ struct ResPlan {
       for (int64_t r = ustart[u]; r < ustart[u + 1]; r++) uord_of_row[r] = (int32_t)u;
     std::vector<int64_t> fill((size_t)G, 0);
     std::vector<int32_t> last_item((size_t)G, -1), nruns((size_t)G, 0);
-    std::vector<int32_t> pair_g, pair_local;  // the (workgroup, item) runs in item-major order
     std::vector<int32_t> h_slot_ptr((size_t)n_items + 1, 0);
     int64_t counter = 0;
     for (int c = 0; c < n_items; c++) {
@@ -612,8 +720,6 @@ struct ResPlan {
         const int64_t sidx = fill[g]++;
         if (last_item[g] != c) {
           last_item[g] = c;
-          pair_g.push_back(g);
-          pair_local.push_back(nruns[g]);
           wg_run_item[g].push_back(c);
           counter++;
           nruns[g]++;
@@ -622,9 +728,7 @@ struct ResPlan {
         }
         const int t = (int)(sidx / R), r = (int)(sidx % R);
         h_perm[(size_t)g * cap_slots + (size_t)r * NT + t] = row;
-        uint32_t &uw = h_uidw[((size_t)g * UW + r / 2) * NT + t];
-        const int sh = 16 * (r % 2);
-        uw = (uw & ~(0xffffu << sh)) | ((uint32_t)(uo - (int32_t)ucut[g]) << sh);
+        h_uid[(size_t)g * cap_slots + (size_t)sidx] = (uint16_t)(uo - (int32_t)ucut[g]);
         if (r == 0) h_first[(size_t)g * NT + t] = nruns[g] - 1;
       }
     }
@@ -633,7 +737,13 @@ struct ResPlan {
     if (counter >= ((int64_t)1 << 31) - 2) return fail("too many runs");
     // runs, workgroup-major: global run index = run_base[g] + local; every workgroup ends with its pad run (never stored)
     std::vector<int32_t> run_base((size_t)G + 1, 0);
-    for (int g = 0; g < G; g++) run_base[g + 1] = run_base[g] + nruns[g] + 1;
+    const int run_align = std::getenv("MFM_RES_RUN_ALIGN") ? std::max(1, std::atoi(std::getenv("MFM_RES_RUN_ALIGN"))) : 1;
+    const int run_skew = std::getenv("MFM_RES_RUN_SKEW") ? std::atoi(std::getenv("MFM_RES_RUN_SKEW")) : 0;
+    for (int g = 0; g < G; g++) {
+      int64_t nb = run_base[g] + nruns[g] + 1;
+      nb = (nb + run_align - 1) / run_align * run_align + (run_align > 1 ? (int64_t)run_skew * ((g + 1) % 8) : 0);
+      run_base[g + 1] = (int32_t)nb;
+    }
     const int32_t zero_run = run_base[G];  // a partial that stays (0, 0): what the padding entries of the item draw gather
     std::vector<int32_t> h_run_item((size_t)zero_run + 1, n_items);
     for (int g = 0; g < G; g++) {
@@ -658,49 +768,78 @@ struct ResPlan {
       for (int32_t j : wg_users[g]) h_udesc.push_back(make_int2(j, group_of && (size_t)j < group_of->size() ? (*group_of)[j] : 0));
       h_uptr[g + 1] = (int32_t)h_udesc.size();
     }
-    // item draw: contiguous item ranges of about equal cost (partials + a constant per item)
+    // item draw: contiguous item ranges of about equal cost (partials + a constant per item), at most NT items each (a thread
+    // per item)
     std::vector<int32_t> h_iptr((size_t)G + 1, 0);
     {
-      const double total = (double)counter + 16.0 * n_items;
-      double acc = 0.0;
-      int g = 1;
-      for (int c = 0; c < n_items && g < G; c++) {
-        acc += (double)(h_slot_ptr[c + 1] - h_slot_ptr[c]) + 16.0;
-        while (g < G && acc >= total * g / G) h_iptr[g++] = c + 1;
+      bool ok = false;
+      for (double scale = 1.0; scale < 3.0 && !ok; scale *= 1.1) {
+        const double target = scale * ((double)counter + 16.0 * n_items) / G;
+        double acc = 0.0;
+        int gq = 0, cnt = 0;
+        for (int c = 0; c < n_items; c++) {
+          acc += (double)(h_slot_ptr[c + 1] - h_slot_ptr[c]) + 16.0;
+          cnt++;
+          if ((acc >= target || cnt == NT) && gq + 1 < G) {
+            h_iptr[++gq] = c + 1;
+            acc = 0.0;
+            cnt = 0;
+          }
+        }
+        ok = cnt <= NT;
+        for (gq++; gq <= G; gq++) h_iptr[gq] = n_items;
       }
-      for (; g <= G; g++) h_iptr[g] = n_items;
-      h_iptr[G] = n_items;
+      if (!ok) return fail("more second-level columns than the workgroups can draw");
     }
-    // item draw tables: per workgroup the item-major entries of its items, padded to whole 64-entry chunks; the (chunk, item)
-    // stretches of a slice are numbered chunk + item (both only grow along the slice: distinct stretches, distinct rows)
-    std::vector<int2> h_entries, h_item_rid((size_t)n_items, make_int2(0, 0));
-    std::vector<int32_t> h_eptr((size_t)G + 1, 0);
-    rid_max = 1;
-    for (int g = 0; g < G; g++) {
-      const size_t e_begin = h_entries.size();
-      int last_rid = 0;
-      for (int c = h_iptr[g]; c < h_iptr[g + 1]; c++) {
-        const int li = c - h_iptr[g];
-        int first = -1, last = -1;
-        for (int32_t q = h_slot_ptr[c]; q < h_slot_ptr[c + 1]; q++) {
-          const int k = (int)(h_entries.size() - e_begin);
-          const int rid = (k >> 6) + li;
-          if (first < 0) first = rid;
-          last = rid;
-          h_entries.push_back(make_int2(run_base[pair_g[q]] + pair_local[q], rid));
-        }
-        if (first >= 0) {
-          h_item_rid[c] = make_int2(first, last - first + 1);
-          last_rid = last;
+    int imax = 0;
+    for (int g = 0; g < G; g++) imax = std::max(imax, h_iptr[g + 1] - h_iptr[g]);
+    umax = std::max(maxu, imax) + 1;  // stride of the per-wave accumulator arrays; the pad user is umax - 1
+    if (umax > 1024) return fail("internal: user field");
+    std::vector<uint32_t> h_uidw((size_t)G * UW * NT, 0);
+    for (int g = 0; g < G; g++)
+      for (int64_t sl = 0; sl < cap_slots; sl++) {
+        const uint16_t u16 = h_uid[(size_t)g * cap_slots + (size_t)sl];
+        const uint32_t u = u16 == 0xffffu ? (uint32_t)(umax - 1) : u16;
+        const int t = (int)(sl / R), r = (int)(sl % R);
+        // word bb of a group: users 0 .. 2 of batch bb and the low 2 bits of user 3; word 4: byte bb = its high 8 bits
+        const int w0 = 5 * (r / 16), bb = (r % 16) / 4, k = r % 4;
+        if (k < 3) {
+          h_uidw[((size_t)g * UW + w0 + bb) * NT + t] |= u << (10 * k);
+        } else {
+          h_uidw[((size_t)g * UW + w0 + bb) * NT + t] |= (u & 3u) << 30;
+          h_uidw[((size_t)g * UW + w0 + 4) * NT + t] |= (u >> 2) << (8 * bb);
         }
       }
-      while ((h_entries.size() - e_begin) % WAVE) h_entries.push_back(make_int2(zero_run, last_rid));
-      h_eptr[g + 1] = (int32_t)h_entries.size();
-      rid_max = std::max(rid_max, last_rid + 1);
+    h_uid = std::vector<uint16_t>();
+    // item draw tables: per slice its (run, item) pairs source workgroup by source workgroup (a source's runs are in item
+    // order: the slice's share of them is a contiguous stretch of its partials), padded to whole 64-entry chunks
+    std::vector<int32_t> slice_of((size_t)n_items);
+    for (int g = 0; g < G; g++)
+      for (int c = h_iptr[g]; c < h_iptr[g + 1]; c++) slice_of[c] = g;
+    std::vector<int32_t> h_eptr((size_t)G + 1, 0);
+    {
+      std::vector<int64_t> cnt((size_t)G, 0);
+      for (int g = 0; g < G; g++)
+        for (int32_t c : wg_run_item[g]) cnt[slice_of[c]]++;
+      for (int g = 0; g < G; g++) {
+        const int64_t e = h_eptr[g] + ((cnt[g] + WAVE - 1) / WAVE) * WAVE;
+        if (e >= ((int64_t)1 << 31)) return fail("too many entries");
+        h_eptr[g + 1] = (int32_t)e;
+      }
+    }
+    std::vector<int2> h_entries((size_t)h_eptr[G], make_int2(zero_run, 0));
+    {
+      std::vector<int64_t> pos((size_t)G);
+      for (int g = 0; g < G; g++) pos[g] = h_eptr[g];
+      for (int g = 0; g < G; g++)
+        for (size_t l = 0; l < wg_run_item[g].size(); l++) {
+          const int32_t c = wg_run_item[g][l];
+          const int sgl = slice_of[c];
+          h_entries[(size_t)pos[sgl]++] = make_int2(run_base[g] + (int32_t)l, c - h_iptr[sgl]);
+        }
     }
     if (h_entries.size() >= ((size_t)1 << 31)) return fail("too many entries");
-    lds_bytes = (size_t)RL * NT * 8 + (size_t)2 * (NT / WAVE) * umax * 8 + (size_t)umax * 16 + (size_t)(NT / WAVE) * 16 + (size_t)rid_max * 16 +
-                (NT / WAVE) * 4 + 64;
+    lds_bytes = (size_t)RL * NT * 8 + (size_t)2 * (NT / WAVE) * umax * 8 + (size_t)umax * 16 + (size_t)(NT / WAVE) * 16 + (NT / WAVE) * 4 + 64;
     if (lds_bytes > 160 * 1024 - 512) return fail("LDS");
     uidw.upload(h_uidw);
     headw.upload(h_headw);
@@ -712,14 +851,49 @@ struct ResPlan {
     wg_item_ptr.upload(h_iptr);
     ent_ptr.upload(h_eptr);
     entries.upload(h_entries.data(), h_entries.size());
-    item_rid.upload(h_item_rid.data(), h_item_rid.size());
+    wg_run_ptr.upload(run_base);
+    wg_nruns.upload(nruns);
+    h_nruns = nruns;
+    if (std::getenv("MFM_RES_PROF")) {
+      h_diag.assign((size_t)G, "");
+      for (int g = 0; g < G; g++) {
+        int64_t maxlen = 0;
+        for (int64_t u = ucut[g]; u < ucut[g + 1]; u++) maxlen = std::max(maxlen, ustart[u + 1] - ustart[u]);
+        // store instructions of sweep B: (wave, slot) pairs in which some lane closes a run; lanes that store per thread
+        int64_t sinstr = 0, maxst = 0, nthr_head = 0;
+        for (int w = 0; w < NT / WAVE; w++) {
+          std::vector<char> hh(WAVE, 0);
+          std::vector<int> st(WAVE, 0);
+          for (int r = 0; r < R; r++) {
+            bool any = false;
+            for (int l = 0; l < WAVE; l++) {
+              const int t = w * WAVE + l;
+              const bool head = (h_headw[((size_t)g * HW + r / 16) * NT + t] >> (r % 16)) & 1u;
+              if (head && hh[l]) {
+                any = true;
+                st[l]++;
+              }
+              hh[l] = hh[l] || head;
+            }
+            sinstr += any;
+          }
+          for (int l = 0; l < WAVE; l++) {
+            maxst = std::max<int64_t>(maxst, st[l]);
+            nthr_head += hh[l];
+          }
+        }
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "users %d maxlen %lld rows %lld store-instr %lld max-stores/thread %lld threads-with-head %lld",
+                      (int)(ucut[g + 1] - ucut[g]), (long long)maxlen, (long long)fill[g], (long long)sinstr, (long long)maxst,
+                      (long long)nthr_head);
+        h_diag[g] = buf;
+      }
+    }
     scols.upload(items);
     partials.alloc((size_t)2 * ((size_t)zero_run + 1));
     MFM_HIP_CHECK(hipMemset(partials.p, 0, (size_t)16 * ((size_t)zero_run + 1)));
     dv.alloc((size_t)2 * (n_items + 1));
-    bar.alloc(1);
-    MFM_HIP_CHECK(hipMemset(bar.p, 0, sizeof(unsigned long long)));
-    bar_count = 0;
+    bar.alloc(RES_BAR_WORDS);
     ready = true;
     why.clear();
     return true;
@@ -748,8 +922,8 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   a.wg_item_ptr = rp.wg_item_ptr.p;
   a.ent_ptr = rp.ent_ptr.p;
   a.entries = rp.entries.p;
-  a.item_rid = rp.item_rid.p;
-  a.rid_max = rp.rid_max;
+  a.wg_run_ptr = rp.wg_run_ptr.p;
+  a.wg_nruns = rp.wg_nruns.p;
   a.scols = rp.scols.p;
   a.partials = rp.partials.p;
   a.dv = rp.dv.p;
@@ -763,14 +937,23 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   a.group = group;
   a.n_groups = n_groups;
   a.alpha = alpha;
-  a.item_bits = rp.item_bits;
+  a.n_items = rp.n_items;
   a.umax = rp.umax;
   a.bar = rp.bar.p;
-  a.bar_base = rp.bar_count;
+  MFM_HIP_CHECK(hipMemsetAsync(rp.bar.p, 0, RES_BAR_WORDS * sizeof(unsigned long long), s));
   a.n_wg = rp.G;
   a.error = error;
   a.dbg = std::getenv("MFM_RES_DBG") ? std::atoi(std::getenv("MFM_RES_DBG")) : 0;
-  rp.bar_count += 2ull * (unsigned long long)(f_end - f_begin) * (unsigned long long)rp.G;
+  a.rot = std::getenv("MFM_RES_ROT") ? std::atoi(std::getenv("MFM_RES_ROT")) : 0;
+  // MFM_RES_PROF=n: the n-th launch of the process records the phase stamps of every workgroup and prints a summary
+  static int prof_launch = 0;
+  const bool prof = std::getenv("MFM_RES_PROF") && ++prof_launch == std::atoi(std::getenv("MFM_RES_PROF"));
+  DevBuf<unsigned long long> prof_buf;
+  if (prof) {
+    prof_buf.alloc((size_t)rp.G * (f_end - f_begin) * 64);
+    MFM_HIP_CHECK(hipMemsetAsync(prof_buf.p, 0, (size_t)rp.G * (f_end - f_begin) * 512, s));
+    a.prof = prof_buf.p;
+  }
   const int K = f_end - f_begin;
   // algorithmic bytes of the launch: e read + written once, the per-slot words twice per factor (+ once at either end),
   // one 16-byte partial per (workgroup, item) written and read per factor
@@ -798,6 +981,80 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
     throw Error(MFM_ERR_RUNTIME, "internal: no resident kernel variant for this plan");
 #undef MFM_RES_LAUNCH
   MFM_HIP_CHECK(hipGetLastError());
+  if (prof) {
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    const int K2 = f_end - f_begin;
+    std::vector<unsigned long long> h((size_t)rp.G * K2 * 64);
+    MFM_HIP_CHECK(hipMemcpy(h.data(), prof_buf.p, h.size() * 8, hipMemcpyDeviceToHost));
+    // per phase: mean over (workgroup, factor) and mean over factors of the slowest / fastest workgroup, in us
+    const char *names[6] = {"sweep A", "user draw", "sweep B", "barrier 1 (wait)", "item draw", "barrier 2 (wait)"};
+    std::fprintf(stderr, "[resident profile] G=%d factors=%d; us per factor: mean | mean of max over workgroups | mean of min\n", rp.G, K2);
+    for (int ph = 0; ph < 6; ph++) {
+      double sm = 0, smax = 0, smin = 0;
+      for (int f = 0; f < K2; f++) {
+        double mx = 0, mn = 1e30;
+        for (int g = 0; g < rp.G; g++) {
+          const unsigned long long *t = &h[((size_t)g * K2 + f) * 64];
+          const double d = (double)(t[ph + 1] - t[ph]) * 0.01;
+          sm += d;
+          mx = std::max(mx, d);
+          mn = std::min(mn, d);
+        }
+        smax += mx;
+        smin += mn;
+      }
+      std::fprintf(stderr, "  %-18s %8.2f | %8.2f | %8.2f\n", names[ph], sm / ((double)rp.G * K2), smax / K2, smin / K2);
+    }
+    {  // the workgroups that are slowest in sweep B
+      std::vector<std::pair<double, int>> tb;
+      for (int g = 0; g < rp.G; g++) {
+        double d = 0;
+        for (int f = 0; f < K2; f++) d += (double)(h[((size_t)g * K2 + f) * 64 + 3] - h[((size_t)g * K2 + f) * 64 + 2]) * 0.01;
+        tb.push_back({d / K2, g});
+      }
+      std::sort(tb.begin(), tb.end());
+      std::fprintf(stderr, "  sweep B by workgroup: fastest");
+      for (int k = 0; k < 4; k++) std::fprintf(stderr, " wg %d %.1f (%d runs)", tb[k].second, tb[k].first, rp.h_nruns[tb[k].second]);
+      std::fprintf(stderr, "; median wg %d %.1f (%d runs); slowest", tb[rp.G / 2].second, tb[rp.G / 2].first, rp.h_nruns[tb[rp.G / 2].second]);
+      for (int k = rp.G - 4; k < rp.G; k++) std::fprintf(stderr, " wg %d %.1f (%d runs)", tb[k].second, tb[k].first, rp.h_nruns[tb[k].second]);
+      std::fprintf(stderr, "\n");
+      if (!rp.h_diag.empty())
+        for (int k : {0, 1, rp.G / 2, rp.G - 3, rp.G - 2, rp.G - 1})
+        {
+          const int g = tb[k].second;
+          std::fprintf(stderr, "    wg %d %.1f us: %s; waves:", g, tb[k].first, rp.h_diag[g].c_str());
+          for (int w = 0; w < 8; w++) {
+            double d = 0;
+            for (int f = 0; f < K2; f++) d += (double)(h[((size_t)g * K2 + f) * 64 + 8 + w] - h[((size_t)g * K2 + f) * 64 + 2]) * 0.01;
+            std::fprintf(stderr, " %.1f", d / K2);
+          }
+          std::fprintf(stderr, "\n      batches of waves 4 and 7 (factor 3 alone):");
+          for (int w : {0, 20}) {
+            std::fprintf(stderr, " |");
+            for (int b = 0; b < (rp.RV + rp.RL) / 4; b++)
+              std::fprintf(stderr, " %.1f", (double)(h[((size_t)g * K2 + 3) * 64 + 16 + w + b] - h[((size_t)g * K2 + 3) * 64 + 2]) * 0.01);
+          }
+          std::fprintf(stderr, "\n");
+        }
+    }
+    if (const char *dump = std::getenv("MFM_RES_PROF_DUMP")) {  // one line per workgroup: phase means, then the diagnostics
+      if (FILE *fp = std::fopen(dump, "w")) {
+        for (int g = 0; g < rp.G; g++) {
+          std::fprintf(fp, "%d", g);
+          for (int ph = 0; ph < 6; ph++) {
+            double d = 0;
+            for (int f = 0; f < K2; f++) d += (double)(h[((size_t)g * K2 + f) * 64 + ph + 1] - h[((size_t)g * K2 + f) * 64 + ph]) * 0.01;
+            std::fprintf(fp, " %.2f", d / K2);
+          }
+          std::fprintf(fp, " | %s\n", rp.h_diag.empty() ? "" : rp.h_diag[g].c_str());
+        }
+        std::fclose(fp);
+      }
+    }
+    double tot = 0;
+    for (int g = 0; g < rp.G; g++) tot += (double)(h[((size_t)g * K2 + K2 - 1) * 64 + 6] - h[(size_t)g * K2 * 64]) * 0.01;
+    std::fprintf(stderr, "  factors, start to end: %.1f us (%.2f per factor)\n", tot / rp.G, tot / rp.G / K2);
+  }
 }
 
 }  // namespace mfm
