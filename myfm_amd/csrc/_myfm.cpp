@@ -996,6 +996,7 @@ struct FMTrainer {
     }
     ck(ctx, mfm_rng_set_program(ctx, ops.data(), (int32_t)ops.size()));
     hv.assign((size_t)n, 0);
+    ck(ctx, mfm_rng_prefetch(ctx));  // the first iteration's set and the second's (update_all keeps two ahead)
     ck(ctx, mfm_rng_prefetch(ctx));
     device_rng = true;
   }
@@ -1057,7 +1058,6 @@ struct FMTrainer {
     if (device_rng) {
       ck(ctx, mfm_rng_acquire(ctx, hv.data(), (int64_t)hv.size()));  // this iteration's variates
       hv_pos = 0;
-      ck(ctx, mfm_rng_prefetch(ctx));  // the next iteration's are produced while this one runs
     }
     // every reduction the hyper-parameter updates need, one host synchronisation: sum e / sum e^2 (update_alpha,
     // FMTrainer.hpp:127-145, update_w0 :218-229) and the group sums of w and V (:150-216) -- the latter are taken
@@ -1133,6 +1133,9 @@ struct FMTrainer {
         ck(ctx, mfm_sweep_V(ctx, 0, Kf, hyper.alpha, hyper.lambda_V.data(), hyper.mu_V.data(), zbuf.data()));
       }
     }
+    // the variates of the iteration after the next: generated on the side stream from the end of this iteration's latent
+    // sweep on (the persistent sweep leaves no CU to anything else), next to update_e and the start of the next iteration
+    if (device_rng) ck(ctx, mfm_rng_prefetch(ctx));
     // update_e (:493-522)
     if (cfg.task_type == TaskType::REGRESSION) {
       ck(ctx, mfm_update_e_regression(ctx));

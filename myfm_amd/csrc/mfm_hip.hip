@@ -81,6 +81,8 @@ struct mfm_ctx {
   ResPlan res;                  // ... as one persistent launch with the residual resident on chip (mfm_res.hpp)
   bool sharded_fused = false;   // row-sharded + fused tile path (run_sweep_soa_sharded)
   int q_stale_factor = -1;      // >= 0: the stored q column is stale, mfm_get_q rebuilds it for this factor first
+  bool e_in_slots = false;      // the residual after the resident latent sweep lives in res.e_slots (slot order): every
+                                // reader of eq calls materialize_e first; update_e overwrites it and just drops the flag
   DevBuf<double> sync_mask;     // [D] 1: this rank contributes the column to the model synchronisation
   PinnedRing ring;
   double2 *h_red = nullptr;  // pinned readback
@@ -95,6 +97,7 @@ struct mfm_ctx {
     DevBuf<uint32_t> raw;
     DevBuf<uint32_t> jump;  // jump-ahead polynomials of the parallel generator (mfm_mtjump.hpp)
     int par_wgs = 1;        // workgroups of k_mt_generate_par (1: the serial generator)
+    int par_blocks = 0;     // ... and the blocks each of them generates (chosen at mfm_finalize from the problem size)
     uint64_t mask = 0, need = 0;
     DevBuf<RngOp> ops;
     int n_ops = 0;
@@ -104,7 +107,9 @@ struct mfm_ctx {
       double *h_hv = nullptr;  // pinned: [n_hv] variates + RngState header (3 x 8 bytes)
       hipEvent_t ready = nullptr, free_ev = nullptr;
       bool free_valid = false;
-    } slot[2];
+    } slot[3];
+    static constexpr int N_SLOTS = 3;
+    hipEvent_t gate = nullptr;  // recorded on the main stream at every prefetch: the side stream starts behind it
     int64_t produced = 0, acquired = 0;
     int current = -1;
     // big NORMALS ops run as eval / scan / scatter over the whole GPU
@@ -124,6 +129,7 @@ struct mfm_ctx {
         if (sl.ready) (void)hipEventDestroy(sl.ready);
         if (sl.free_ev) (void)hipEventDestroy(sl.free_ev);
       }
+      if (gate) (void)hipEventDestroy(gate);
       if (stream) (void)hipStreamDestroy(stream);
     }
   } rng;
@@ -394,7 +400,18 @@ static SweepArgs main_args(mfm_ctx *c, double *theta, const double *z, const dou
   return a;
 }
 
+// the residual the resident latent sweep left in slot order -> eq (only when somebody reads it: in the Gibbs loop update_e
+// follows and recomputes it)
+static void materialize_e(mfm_ctx *c) {
+  if (!c->e_in_slots) return;
+  const int64_t n_slots = (int64_t)c->res.G * c->res.NT * (c->res.RV + c->res.RL);
+  hipLaunchKernelGGL(k_res_unpermute, dim3((unsigned)cdiv(n_slots, 256)), dim3(256), 0, c->stream, c->res.e_slots.p, c->res.perm.p,
+                     n_slots, c->eq.p);
+  c->e_in_slots = false;
+}
+
 static void score_train(mfm_ctx *c, bool subtract_y) {
+  c->e_in_slots = false;  // (every residual is overwritten)
   if (c->mf && !std::getenv("MFM_NO_MF_SCORE")) {
     // two-field table: scorer on the row tiles of the latent sweep (item rows gathered once per run, not once per row)
     hipStream_t s = c->stream;
@@ -634,7 +651,10 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     const double normals = (double)c->D * (c->K + 1) + 4.0 * c->G * (c->K + 1) + 16;
     const double need = normals * (16.0 / 3.14159265358979) * 1.02 + 6.0 * 2.4 * std::sqrt(normals + 1.0) + 4096.0 * (2 + 2.0 * c->G * (c->K + 1)) + 2e6;
     const int64_t blocks = (int64_t)(need / MT_N) + 2;
-    if (blocks > MT_PAR_BLOCKS) mtjump::JumpCache::inst().prefetch(MT_PAR_BLOCKS, (int)((blocks + MT_PAR_BLOCKS - 1) / MT_PAR_BLOCKS) + 1);
+    if (blocks > MT_PAR_BLOCKS) {
+      c->rng.par_blocks = mt_par_blocks_for(blocks);
+      mtjump::JumpCache::inst().prefetch(c->rng.par_blocks, (int)((blocks + c->rng.par_blocks - 1) / c->rng.par_blocks) + 1);
+    }
   }
   const bool tlog = std::getenv("MFM_SETUP_TIMING") != nullptr;
   auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -918,6 +938,7 @@ int mfm_zero_w(mfm_ctx *ctx) {
 static int get_eq(mfm_ctx *ctx, double *dst, int which) {
   MFM_TRY(ctx)
   ctx->need_final();
+  materialize_e(ctx);
   if (ctx->N) {
     hipLaunchKernelGGL(k_get_eq, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq.p, ctx->scratch_n.p, ctx->N,
                        which);
@@ -944,6 +965,7 @@ int mfm_get_q(mfm_ctx *ctx, double *q) {
 int mfm_set_e(mfm_ctx *ctx, const double *e) {
   MFM_TRY(ctx)
   ctx->need_final();
+  materialize_e(ctx);
   if (ctx->N) {
     MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     MFM_HIP_CHECK(hipMemcpy(ctx->scratch_n.p, e, (size_t)ctx->N * sizeof(double), hipMemcpyHostToDevice));
@@ -957,6 +979,7 @@ int mfm_set_e(mfm_ctx *ctx, const double *e) {
 int mfm_reduce_e(mfm_ctx *ctx, double *sum_e, double *sum_e2) {
   MFM_TRY(ctx)
   ctx->need_final();
+  materialize_e(ctx);
   hipStream_t s = ctx->stream;
   {
     TimedLaunch t(ctx->timing, s, KC_REDUCE_E, 8.0 * ctx->N);
@@ -978,6 +1001,7 @@ int mfm_reduce_e(mfm_ctx *ctx, double *sum_e, double *sum_e2) {
 int mfm_shift_e(mfm_ctx *ctx, double delta) {
   MFM_TRY(ctx)
   ctx->need_final();
+  materialize_e(ctx);
   if (ctx->N) {
     TimedLaunch t(ctx->timing, ctx->stream, KC_SHIFT_E, 16.0 * ctx->N);
     hipLaunchKernelGGL(k_shift_e, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq.p, ctx->N, delta);
@@ -1028,6 +1052,7 @@ int mfm_hyper_stats(mfm_ctx *ctx, int32_t need_e, const double *mu_w, const doub
                     double *sum_w, double *ssd_w, double *sum_V, double *ssd_V) {
   MFM_TRY(ctx)
   ctx->need_final();
+  materialize_e(ctx);
   mfm_ctx *c = ctx;
   hipStream_t s = c->stream;
   const int G = c->G, K = c->K, n_ch = std::max(1, c->gs_chunks);
@@ -1079,6 +1104,7 @@ int mfm_hyper_stats(mfm_ctx *ctx, int32_t need_e, const double *mu_w, const doub
 int mfm_sweep_w(mfm_ctx *ctx, double alpha, const double *lambda_w, const double *mu_w, const double *z) {
   MFM_TRY(ctx)
   ctx->need_final();
+  materialize_e(ctx);
   mfm_ctx *c = ctx;
   hipStream_t s = c->stream;
   c->ring.upload(c->lam.p, lambda_w, (size_t)c->G * sizeof(double), s);
@@ -1107,6 +1133,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
                 const double *z) {
   MFM_TRY(ctx)
   ctx->need_final();
+  materialize_e(ctx);
   mfm_ctx *c = ctx;
   if (f_begin < 0 || f_end > c->K || f_begin > f_end) throw Error(MFM_ERR_INVALID, "factor range out of bounds");
   if (f_begin == f_end) return MFM_OK;
@@ -1206,8 +1233,10 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     };
     const bool fuse = c->fuse_next;
     if (c->res.ready) {
+      const bool lazy_store = !std::getenv("MFM_RES_EAGER_STORE");
       run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq.p, c->V.p, c->D, f_begin, f_end, zbase, c->lam.p, c->mu.p,
-                         c->group.p, c->G, alpha, c->ls.error.p);
+                         c->group.p, c->G, alpha, c->ls.error.p, lazy_store);
+      c->e_in_slots = lazy_store;
       c->q_stale_factor = f_end - 1;
       return MFM_OK;
     }
@@ -1289,7 +1318,14 @@ int mfm_rng_seed_mt19937(mfm_ctx *ctx, const uint32_t *state624, int32_t positio
   MFM_TRY(ctx)
   auto &r = ctx->rng;
   if (position < 0 || position > MT_N) throw Error(MFM_ERR_INVALID, "mt19937 position out of range");
-  if (!r.stream) MFM_HIP_CHECK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+  if (!r.stream) {
+    // the generator runs one iteration ahead next to the sweeps; at the highest priority its workgroups take the CUs the
+    // short kernels at the start of an iteration free, so that it is done before the persistent latent sweep (which needs
+    // every CU at once: a generator workgroup still running then delays all of its workgroups) is launched
+    int lo = 0, hi = 0;
+    MFM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    MFM_HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, std::getenv("MFM_RNG_NO_PRIORITY") ? lo : hi));
+  }
   MFM_HIP_CHECK(hipStreamSynchronize(r.stream));
   RngState h;
   std::memset(&h, 0, sizeof(h));
@@ -1360,9 +1396,10 @@ int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops) {
   {
     const int64_t blocks = (int64_t)(r.need / MT_N) + 2;
     if (blocks > MT_PAR_BLOCKS && !std::getenv("MFM_RNG_SERIAL")) {
-      const int wgs = (int)((blocks + MT_PAR_BLOCKS - 1) / MT_PAR_BLOCKS);
+      if (r.par_blocks <= 0) r.par_blocks = mt_par_blocks_for(blocks);
+      const int wgs = (int)((blocks + r.par_blocks - 1) / r.par_blocks);
       std::vector<uint32_t> tab;
-      if (mtjump::JumpCache::inst().get(MT_PAR_BLOCKS, wgs - 1, tab)) {
+      if (mtjump::JumpCache::inst().get(r.par_blocks, wgs - 1, tab)) {
         r.jump.upload(tab);
         r.state_next.alloc(1);
         r.par_wgs = wgs;
@@ -1394,17 +1431,24 @@ int mfm_rng_prefetch(mfm_ctx *ctx) {
   MFM_TRY(ctx)
   auto &r = ctx->rng;
   if (!r.programmed) throw Error(MFM_ERR_RUNTIME, "mfm_rng_set_program has not been called");
-  // two slots: the acquired set stays valid until the next acquire, so at most one further set may be in flight (two
-  // before the first acquire)
-  if (r.produced - r.acquired >= (r.current >= 0 ? 1 : 2))
-    throw Error(MFM_ERR_RUNTIME, "both random sets are in use (one acquired / in flight): acquire the next one first");
-  auto &sl = r.slot[r.produced % 2];
+  // three slots: the acquired set stays valid until the next acquire, so at most two further sets may be in flight (three
+  // before the first acquire). The trainer keeps two ahead: the set of iteration t + 2 is requested right after the latent
+  // sweep of iteration t is enqueued and starts when that sweep ends (the gate below) -- the persistent sweep occupies every
+  // CU, nothing of the side stream can run beside it, and a generator workgroup still running when it is launched delays
+  // all of its workgroups; the generator has the rest of iteration t and the start of iteration t + 1, and the set
+  // iteration t + 1 needs at its very start was finished one iteration earlier.
+  if (r.produced - r.acquired >= (r.current >= 0 ? mfm_ctx::RngEngine::N_SLOTS - 1 : mfm_ctx::RngEngine::N_SLOTS))
+    throw Error(MFM_ERR_RUNTIME, "every random set is in use (one acquired, the others in flight): acquire the next one first");
+  auto &sl = r.slot[r.produced % mfm_ctx::RngEngine::N_SLOTS];
   hipStream_t s = r.stream;
+  if (!r.gate) MFM_HIP_CHECK(hipEventCreateWithFlags(&r.gate, hipEventDisableTiming));
+  MFM_HIP_CHECK(hipEventRecord(r.gate, ctx->stream));
+  MFM_HIP_CHECK(hipStreamWaitEvent(s, r.gate, 0));
   if (sl.free_valid) MFM_HIP_CHECK(hipStreamWaitEvent(s, sl.free_ev, 0));
   if (r.par_wgs > 1) {
     hipLaunchKernelGGL(k_mt_generate_par, dim3(r.par_wgs), dim3(MT_GEN_THREADS),
                        (MT_JUMP_SPAN * MT_N + 2 * (MT_N + 1)) * sizeof(uint32_t), s, r.state.p, r.state_next.p, r.raw.p, r.mask,
-                       r.need, r.jump.p);
+                       r.need, r.jump.p, r.par_blocks);
     hipLaunchKernelGGL(k_mt_commit, dim3(1), dim3(MT_GEN_THREADS), 0, s, r.state.p, r.state_next.p);
   } else {
     hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(MT_GEN_THREADS), 0, s, r.state.p, r.raw.p, r.mask, r.need);
@@ -1451,13 +1495,13 @@ int mfm_rng_acquire(mfm_ctx *ctx, double *hyper_variates, int64_t n_hyper_variat
     MFM_HIP_CHECK(hipEventRecord(prev.free_ev, ctx->stream));
     prev.free_valid = true;
   }
-  auto &sl = r.slot[r.acquired % 2];
+  auto &sl = r.slot[r.acquired % mfm_ctx::RngEngine::N_SLOTS];
   MFM_HIP_CHECK(hipEventSynchronize(sl.ready));
   RngState hdr;
   std::memcpy(&hdr, sl.h_hv + r.n_hv, 3 * sizeof(double));
   if (hdr.error) throw Error(MFM_ERR_RUNTIME, "device random stream underflow (generated range exhausted)");
   if (r.n_hv) std::memcpy(hyper_variates, sl.h_hv, (size_t)r.n_hv * sizeof(double));
-  r.current = (int)(r.acquired % 2);
+  r.current = (int)(r.acquired % mfm_ctx::RngEngine::N_SLOTS);
   r.acquired++;
   MFM_CATCH(ctx)
 }

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstring>
 #include <future>
+#include <thread>
 #include <mutex>
 #include <vector>
 
@@ -155,17 +156,42 @@ static inline bool build_jump_table(int blocks_per_wg, int n_entries, std::vecto
   if (!F.ok()) return false;
   out.assign((size_t)(n_entries + 1) * JUMP_WORDS32, 0u);
   if (n_entries < 1) return true;
-  const Poly h = F.xpow((uint64_t)blocks_per_wg * 624u);
-  Poly g = F.xpow((uint64_t)(blocks_per_wg - 1) * 624u);
-  for (int p = 1; p <= n_entries; p++) {
+  // g_(p+1) = g_p h with h = x^(blocks_per_wg * 624): T independent chains g_(p+T) = g_p h^T, one per thread (a product of
+  // two 19937-bit polynomials mod phi costs ~3 ms)
+  Poly h, g1;
+  {
+    std::thread th([&]() { h = F.xpow((uint64_t)blocks_per_wg * 624u); });
+    g1 = F.xpow((uint64_t)(blocks_per_wg - 1) * 624u);
+    th.join();
+  }
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int T = std::max(1, std::min({n_entries, 8, hw > 0 ? hw : 1}));
+  std::vector<Poly> seed((size_t)T);
+  seed[0] = g1;
+  Poly hT = h;
+  for (int i = 1; i < T; i++) {
+    seed[i] = F.mulmod(seed[i - 1], h);
+    hT = F.mulmod(hT, h);
+  }
+  auto emit = [&](int p, const Poly &g) {
     uint32_t *dst = out.data() + (size_t)p * JUMP_WORDS32;
     for (int w = 0; w < JUMP_WORDS32 / 2; w++) {
       const uint64_t v = w < (int)g.size() ? g[w] : 0;
       dst[2 * w] = (uint32_t)v;
       dst[2 * w + 1] = (uint32_t)(v >> 32);
     }
-    if (p < n_entries) g = F.mulmod(g, h);
-  }
+  };
+  auto chain = [&](int i) {
+    Poly g = seed[i];
+    for (int p = 1 + i; p <= n_entries; p += T) {
+      emit(p, g);
+      if (p + T <= n_entries) g = F.mulmod(g, hT);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int i = 1; i < T; i++) pool.emplace_back(chain, i);
+  chain(0);
+  for (auto &t : pool) t.join();
   return true;
 }
 

@@ -36,7 +36,10 @@
 namespace mfm {
 
 struct ResArgs {
-  double2 *eq;               // residual: read at [row].x at the start, written back at the end
+  double2 *eq;               // residual: read at [row].x at the start, written back at the end ...
+  double *e_slots;           // ... unless this is set: [G][R][NT], the residual in slot order (coalesced; k_res_unpermute
+                             // moves it to eq when somebody needs it there -- update_e, which follows in the Gibbs loop,
+                             // recomputes the residual and does not)
   const int32_t *perm;       // [G][R][NT] row of the slot, -1: pad
   const uint32_t *uidw;      // [G][5 R / 16][NT] the slots' users (index within the workgroup), 10 bits each: per group of
                              // 16 slots 4 words (3 users + 2 bits of the 4th of a batch) + 1 word (its other 8 bits);
@@ -188,7 +191,11 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   ResBar rbar;
   rbar.xcc = 0;
   rbar.n_x = rbar.nx = 1;
+#define RES_STAMP0(k) \
+  if (a.prof && tid == 0) a.prof[(int64_t)g * (a.f_end - a.f_begin) * 64 + 56 + (k)] = __builtin_amdgcn_s_memrealtime()
+  RES_STAMP0(0);
   if (tid == 0) res_bar_init(a, rbar, dead);
+  RES_STAMP0(1);
   const bool nost = (a.dbg & 4096) != 0;  // (4096: no partial stores inside sweep B)
   const int trash_run = a.wg_run_ptr[g] + a.wg_nruns[g];
 #define RES_STAMP(k)                                                                                      \
@@ -245,6 +252,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   }
   __syncthreads();
 
+  RES_STAMP0(2);
   for (int f = a.f_begin; f < a.f_end; f++) {
     double *Vf = a.V + (int64_t)f * a.D;
     const double *zf = a.z + (int64_t)(f - a.f_begin) * a.D;
@@ -524,6 +532,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
     RES_STAMP(6);
   }
 #undef RES_STAMP
+  RES_STAMP0(3);
   // the last factor's item update, then the residual goes back
   {
     int run_last = run0;
@@ -545,13 +554,20 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
         for (int k = 0; k < B; k++) {
           const double dl = a.dv[2 * (int64_t)it[k]];
           const double ex = j < NGV ? ev[j < NGV ? j : 0][4 * bb + k] : elds[(16 * (j - NGV) + 4 * bb + k) * NT + tid];
-          if (row[k] >= 0) a.eq[row[k]].x = ex + utab[uid[k]][0] * dl;
+          const double ef = ex + utab[uid[k]][0] * dl;
+          if (a.e_slots)
+            a.e_slots[((int64_t)g * R + 16 * j + 4 * bb + k) * NT + tid] = ef;
+          else if (row[k] >= 0)
+            a.eq[row[k]].x = ef;
         }
       }
     }
   }
 #undef RES_NIB
 #undef RES_UIDS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RES_STAMP0(4);
+#undef RES_STAMP0
 }
 
 // ---- host side: the resident layout of a two-field table and the launch ---------------------------------------------
@@ -567,6 +583,15 @@ __global__ void k_res_init_dv(const double *__restrict__ theta, const int32_t *_
   }
 }
 
+// eq[row].x of every slot's row from the slot-ordered copy the resident sweep left
+__global__ void k_res_unpermute(const double *__restrict__ e_slots, const int32_t *__restrict__ perm, int64_t n_slots,
+                                double2 *__restrict__ eq) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots) return;
+  const int32_t row = perm[i];
+  if (row >= 0) eq[row].x = e_slots[i];
+}
+
 struct ResPlan {
   bool ready = false;
   int G = 0, NT = 512, RV = 0, RL = 0, umax = 0, item_bits = 0, n_items = 0;
@@ -577,7 +602,7 @@ struct ResPlan {
   DevBuf<uint32_t> uidw, headw;
   DevBuf<int32_t> run_item;
   DevBuf<int2> user_desc;
-  DevBuf<double> partials, dv;
+  DevBuf<double> partials, dv, e_slots;
   DevBuf<unsigned long long> bar;
   std::string why;  // why the layout was not built (diagnostics)
   std::vector<int32_t> h_nruns;  // runs per workgroup (diagnostics)
@@ -853,6 +878,7 @@ struct ResPlan {
     entries.upload(h_entries.data(), h_entries.size());
     wg_run_ptr.upload(run_base);
     wg_nruns.upload(nruns);
+    e_slots.alloc((size_t)G * cap_slots);
     h_nruns = nruns;
     if (std::getenv("MFM_RES_PROF")) {
       h_diag.assign((size_t)G, "");
@@ -908,10 +934,11 @@ struct ResPlan {
 // update_V of factors [f_begin, f_end) in one launch. zbase: variates of factor f_begin (factor f at + (f - f_begin) D).
 static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, int kernel_class, double2 *eq, double *V, int64_t D,
                                       int f_begin, int f_end, const double *zbase, const double *lam, const double *mu,
-                                      const int32_t *group, int n_groups, double alpha, int *error) {
+                                      const int32_t *group, int n_groups, double alpha, int *error, bool lazy_store) {
   ResArgs a;
   std::memset(&a, 0, sizeof(a));
   a.eq = eq;
+  a.e_slots = lazy_store ? rp.e_slots.p : nullptr;
   a.perm = rp.perm.p;
   a.uidw = rp.uidw.p;
   a.headw = rp.headw.p;
@@ -958,6 +985,7 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   // algorithmic bytes of the launch: e read + written once, the per-slot words twice per factor (+ once at either end),
   // one 16-byte partial per (workgroup, item) written and read per factor
   const double bytes = 16.0 * rp.n_rows + 8.0 * rp.n_rows + K * (8.0 * rp.n_rows + 32.0 * rp.n_runs);
+  (void)lazy_store;
   hipLaunchKernelGGL(k_res_init_dv, dim3((rp.n_items + 256) / 256), dim3(256), 0, s, V + (int64_t)f_begin * D, rp.scols.p, rp.n_items,
                      rp.dv.p);
   TimedLaunch t(tm, s, kernel_class, bytes);
@@ -1050,6 +1078,24 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
         }
         std::fclose(fp);
       }
+    }
+    {
+      const char *nm[4] = {"census barrier", "residual load", "factor loop", "residual store"};
+      for (int ph = 0; ph < 4; ph++) {
+        double sm = 0, mx = 0;
+        for (int g = 0; g < rp.G; g++) {
+          const double d = (double)(h[(size_t)g * K2 * 64 + 56 + ph + 1] - h[(size_t)g * K2 * 64 + 56 + ph]) * 0.01;
+          sm += d;
+          mx = std::max(mx, d);
+        }
+        std::fprintf(stderr, "  %-18s %8.2f mean | %8.2f max (us, whole launch)\n", nm[ph], sm / rp.G, mx);
+      }
+      unsigned long long t0 = ~0ull, t1 = 0;
+      for (int g = 0; g < rp.G; g++) {
+        t0 = std::min(t0, h[(size_t)g * K2 * 64 + 56]);
+        t1 = std::max(t1, h[(size_t)g * K2 * 64 + 60]);
+      }
+      std::fprintf(stderr, "  first workgroup in to last workgroup out: %.1f us\n", (double)(t1 - t0) * 0.01);
     }
     double tot = 0;
     for (int g = 0; g < rp.G; g++) tot += (double)(h[((size_t)g * K2 + K2 - 1) * 64 + 6] - h[(size_t)g * K2 * 64]) * 0.01;

@@ -23,6 +23,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace mfm {
 
 constexpr int MT_N = 624, MT_M = 397;
@@ -130,17 +133,26 @@ __global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate(RngState *__rest
 // ---- parallel generation with jump-ahead ----------------------------------------------------------------
 // One workgroup is a serial chain (~0.33 us per 624-word block: 7.4 ms for the 13.5 M words of an iteration at
 // the ML-10M shape -- the wall once the sweeps dropped below that). Here workgroup p produces blocks
-// [p * MT_PAR_BLOCKS, (p + 1) * MT_PAR_BLOCKS) of the request. To start there it needs the block before its
+// [p * par_blocks, (p + 1) * par_blocks) of the request. To start there it needs the block before its
 // first one: it walks 33 blocks from the stored state (20 592 words, in LDS) and applies the jump polynomial
-// g_p = x^((p * MT_PAR_BLOCKS - 1) * 624) mod phi (mfm_mtjump.hpp): word l of the target block is the XOR of
+// g_p = x^((p * par_blocks - 1) * 624) mod phi (mfm_mtjump.hpp): word l of the target block is the XOR of
 // x[l + i] over the set bits i of g_p -- ~10 k conflict-free LDS reads per lane, no barriers. The new state is
 // written to a staging copy (late workgroups must still see the old one) and committed by k_mt_commit.
-constexpr int MT_PAR_BLOCKS = 512;
+constexpr int MT_PAR_BLOCKS = 512;  // blocks per workgroup at most (and the request size from which the generator is parallel)
+// blocks per workgroup for a request of `blocks`. A workgroup pays ~100 us for its jump and ~1 us per block, so fewer,
+// longer workgroups cost the kernels running beside the generator less CU time in total; its latency matters little (the
+// trainer requests a set a whole iteration before it is needed; measured: 128 / 256 / 512 blocks give the same iteration
+// rate): 512 blocks -- 43 workgroups, ~0.6 ms at the ML-10M shape.
+static inline int mt_par_blocks_for(int64_t blocks) {
+  (void)blocks;
+  if (const char *e = std::getenv("MFM_RNG_PAR_BLOCKS")) return std::max(32, std::min(MT_PAR_BLOCKS, std::atoi(e)));
+  return MT_PAR_BLOCKS;
+}
 constexpr int MT_JUMP_SPAN = 33;  // blocks covering 19937 + 624 words
 
 __global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate_par(const RngState *__restrict__ st, RngState *__restrict__ st_next,
                                                                     uint32_t *__restrict__ raw, uint64_t mask, uint64_t need,
-                                                                    const uint32_t *__restrict__ jump_tab) {
+                                                                    const uint32_t *__restrict__ jump_tab, int par_blocks) {
   extern __shared__ uint32_t lds_seq[];  // [MT_JUMP_SPAN * 624] sequence, then 2 x 625 generation buffers
   uint32_t *seq = lds_seq;
   uint32_t(*buf)[MT_N + 1] = (uint32_t(*)[MT_N + 1])(lds_seq + MT_JUMP_SPAN * MT_N);
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate_par(const RngSta
     pos = MT_N;
   }
   const int64_t nblk = p_gen < target ? (int64_t)((target - p_gen + MT_N - 1) / MT_N) : 0;
-  const int64_t b0 = (int64_t)p * MT_PAR_BLOCKS, b1 = min(nblk, b0 + MT_PAR_BLOCKS);
+  const int64_t b0 = (int64_t)p * par_blocks, b1 = min(nblk, b0 + par_blocks);
   if (nblk == 0) {  // nothing to generate: only the position may have moved
     if (p == 0) {
       if (t < MT_N) st_next->mt[t] = buf[0][t];
@@ -197,17 +209,27 @@ __global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate_par(const RngSta
       step(seq + (r - 1) * MT_N, seq + r * MT_N);
       __syncthreads();
     }
-    // block b0 - 1 = block 0 advanced by (p * MT_PAR_BLOCKS - 1) blocks
+    // block b0 - 1 = block 0 advanced by (p * par_blocks - 1) blocks
+    // (the polynomial's 624 words are staged in LDS by one coalesced load -- buf[1] is free until the generation loop --:
+    //  a global load per word inside the loop below cost ~350 us per workgroup, twice the generation of its blocks)
+    if (t < MT_N) buf[1][t] = jump_tab[(size_t)p * MT_N + t];
+    __syncthreads();
     if (t < MT_N) {
-      const uint32_t *g = jump_tab + (size_t)p * MT_N;
+      const uint32_t *g = buf[1];
       uint32_t y = 0;
-      for (int w = 0; w < MT_N; w++) {
-        uint32_t gw = g[w];  // wave-uniform
-        const uint32_t *xs = seq + t + 32 * w;
-        while (gw) {
-          const int b = __builtin_ctz(gw);
-          y ^= xs[b];
-          gw &= gw - 1;
+      for (int w0 = 0; w0 < MT_N; w0 += 8) {
+        uint32_t gq[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) gq[i] = g[w0 + i];  // wave-uniform LDS reads (broadcast), 8 in flight
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          uint32_t gw = __builtin_amdgcn_readfirstlane(gq[i]);
+          const uint32_t *xs = seq + t + 32 * (w0 + i);
+          while (gw) {
+            const int b = __builtin_ctz(gw);
+            y ^= xs[b];
+            gw &= gw - 1;
+          }
         }
       }
       buf[0][t] = y;

@@ -353,6 +353,7 @@ int mfm_oprobit_add_group(mfm_ctx *ctx, int32_t n_class, const int64_t *rows, in
 int mfm_oprobit_eval(mfm_ctx *ctx, int32_t group, const double *gamma, double *ll, double *dgamma, double *H) {
   MFM_TRY(ctx)
   ctx->need_final();
+  materialize_e(ctx);
   if (group < 0 || group >= (int)ctx->ogroups.size()) throw Error(MFM_ERR_INVALID, "bad cutpoint group");
   mfm_ctx::OGroup &g = *ctx->ogroups[group];
   hipStream_t s = ctx->stream;
@@ -413,6 +414,7 @@ int mfm_oprobit_eval(mfm_ctx *ctx, int32_t group, const double *gamma, double *l
 int mfm_oprobit_sample_z(mfm_ctx *ctx, int32_t group, const double *gamma, uint64_t seed, uint64_t draw_index) {
   MFM_TRY(ctx)
   ctx->need_final();
+  materialize_e(ctx);
   if (group < 0 || group >= (int)ctx->ogroups.size()) throw Error(MFM_ERR_INVALID, "bad cutpoint group");
   mfm_ctx::OGroup &g = *ctx->ogroups[group];
   hipStream_t s = ctx->stream;

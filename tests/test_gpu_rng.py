@@ -55,13 +55,14 @@ def test_device_stream_matches_libstdcxx(oracle, seed, n_users, K):
     ]
     c.rng_set_program(ops)
     c.rng_prefetch()
-    c.rng_prefetch()  # two sets in flight before the first acquire
+    c.rng_prefetch()
+    c.rng_prefetch()  # three sets in flight before the first acquire
     with pytest.raises(RuntimeError):
         c.rng_prefetch()
     for it in range(3):
         hv = c.rng_acquire()
         if it == 0:
-            with pytest.raises(RuntimeError):  # the acquired set and the one in flight occupy both slots
+            with pytest.raises(RuntimeError):  # the acquired set and the two in flight occupy the three slots
                 c.rng_prefetch()
         else:
             c.rng_prefetch()  # the Gibbs loop's pattern: acquire, then produce the next set while this one is used
