@@ -158,6 +158,12 @@ int mfm_sweep_w(mfm_ctx *ctx, double alpha, const double *lambda_w, const double
  * lambda_V / mu_V: full (G, K) column-major; z: (f_end - f_begin) * D variates, factor-major. */
 int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, const double *lambda_V,
                 const double *mu_V, const double *z);
+/* update_w0's residual shift (FMTrainer.hpp:226: e += e_shift), update_w (:231-314) and update_V (:316-486) of factors
+ * [f_begin, f_end) as ONE call: BaseFMTrainer.hpp:143-148 draws lambda_V / mu_V between the two sweeps, but those draws read
+ * neither w nor e, so the caller can make them first. Same results as mfm_shift_e + mfm_sweep_w + mfm_sweep_V; on a
+ * two-field one-hot table it is one persistent launch. zw / zv: both NULL (the acquired device random set) or both given. */
+int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambda_w, const double *mu_w, const double *zw,
+                 int32_t f_begin, int32_t f_end, const double *lambda_V, const double *mu_V, const double *zv);
 /* update_e (FMTrainer.hpp:493-522), regression: e = predict_score(X_train) - y.             */
 int mfm_update_e_regression(mfm_ctx *ctx);
 /* update_e, probit classification (:498-512): e_t = score_t - z_t, z_t ~ TN(score_t, 1) on

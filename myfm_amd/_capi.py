@@ -22,7 +22,7 @@ SYMBOLS = [
     "mfm_set_stream", "mfm_synchronize", "mfm_set_main", "mfm_add_block", "mfm_set_groups", "mfm_finalize",
     "mfm_dim_all", "mfm_plan_info", "mfm_plan_flags", "mfm_set_state", "mfm_get_state", "mfm_set_w0", "mfm_zero_w", "mfm_get_e",
     "mfm_get_q", "mfm_set_e", "mfm_reduce_e", "mfm_shift_e", "mfm_group_stats_w", "mfm_group_stats_V",
-    "mfm_sweep_w", "mfm_sweep_V", "mfm_update_e_regression", "mfm_update_e_classification", "mfm_score_train",
+    "mfm_sweep_w", "mfm_sweep_V", "mfm_sweep_wV", "mfm_update_e_regression", "mfm_update_e_classification", "mfm_score_train",
     "mfm_oprobit_add_group", "mfm_oprobit_eval", "mfm_oprobit_sample_z", "mfm_hyper_stats", "mfm_timing_enable", "mfm_timing_select", "mfm_timing_reset",
     "mfm_timing_n_classes", "mfm_timing_class_name", "mfm_timing_get", "mfm_design_create", "mfm_design_add_block",
     "mfm_design_destroy", "mfm_design_last_error", "mfm_design_dim_all", "mfm_design_predict",
@@ -82,6 +82,7 @@ def lib():
     L.mfm_hyper_stats.argtypes = [vp, C.c_int32, P, P, P, P, P, P, P, P]
     L.mfm_sweep_w.argtypes = [vp, dbl, P, P, P]
     L.mfm_sweep_V.argtypes = [vp, i32, i32, dbl, P, P, P]
+    L.mfm_sweep_wV.argtypes = [vp, dbl, dbl, P, P, P, i32, i32, P, P, P]
     L.mfm_update_e_regression.argtypes = [vp]
     L.mfm_update_e_classification.argtypes = [vp, u64, u64]
     L.mfm_score_train.argtypes = [vp]
@@ -306,6 +307,16 @@ class Context:
             z = _f64(z)
             assert z.size == (f_end - f_begin) * self.D
         self._ck(lib().mfm_sweep_V(self.h, f_begin, f_end, float(alpha), _p(lam), _p(mu), _p(z)))
+
+    def sweep_wV(self, alpha, e_shift, lambda_w, mu_w, zw, f_begin, f_end, lambda_V, mu_V, zv):
+        """update_w0's residual shift, update_w and update_V of factors [f_begin, f_end) as one call"""
+        lambda_w, mu_w = _f64(lambda_w), _f64(mu_w)
+        lam, mu = _f64(np.asarray(lambda_V).T), _f64(np.asarray(mu_V).T)
+        if zw is not None:
+            zw, zv = _f64(zw), _f64(zv)
+            assert zw.shape[0] == self.D and zv.size == (f_end - f_begin) * self.D
+        self._ck(lib().mfm_sweep_wV(self.h, float(alpha), float(e_shift), _p(lambda_w), _p(mu_w), _p(zw), f_begin, f_end,
+                                    _p(lam), _p(mu), _p(zv)))
 
     def update_e_regression(self):
         self._ck(lib().mfm_update_e_regression(self.h))

@@ -1062,7 +1062,7 @@ struct FMTrainer {
     // every reduction the hyper-parameter updates need, one host synchronisation: sum e / sum e^2 (update_alpha,
     // FMTrainer.hpp:127-145, update_w0 :218-229) and the group sums of w and V (:150-216) -- the latter are taken
     // before update_w / update_V touch w / V, which is where the reference takes them too
-    Real sum_e = 0, sum_e2 = 0;
+    Real sum_e = 0, sum_e2 = 0, e_shift = 0;
     const bool need_alpha = cfg.task_type == TaskType::REGRESSION;
     vector<Real> sum(G), ssd(G), sumV(G * std::max(Kf, 1)), ssdV(G * std::max(Kf, 1));
     ck(ctx, mfm_hyper_stats(ctx, (need_alpha || cfg.fit_w0) ? 1 : 0, hyper.mu_w.data(), hyper.mu_V.data(), &sum_e, &sum_e2,
@@ -1080,8 +1080,15 @@ struct FMTrainer {
       Real w0_lin_term = hyper.alpha * (N_total * fm.w0 - sum_e);  // sum(w0 - e) over all (ranks') rows
       Real w0_quad_term = hyper.alpha * N_total + cfg.reg_0;
       Real w0_new = sample_normal(w0_quad_term, w0_lin_term);
-      ck(ctx, mfm_shift_e(ctx, w0_new - fm.w0));
+      e_shift = w0_new - fm.w0;  // e += w0' - w0 (:226): applied by the sweep that follows (or right below)
       fm.w0 = w0_new;
+    }
+    // update_w and update_V as one device call when both run on the device stream: the draws of lambda_V / mu_V that the
+    // reference makes between them (BaseFMTrainer.hpp:143-148) read neither w nor e
+    const bool fuse_wV = device_rng && cfg.fit_linear && dim_all && Kf > 0;
+    if (e_shift != 0 && !fuse_wV) {
+      ck(ctx, mfm_shift_e(ctx, e_shift));
+      e_shift = 0;
     }
     ck(ctx, mfm_set_w0(ctx, fm.w0));
     // update_lambda_w / update_mu_w (:150-200)
@@ -1100,7 +1107,9 @@ struct FMTrainer {
     if (!cfg.fit_linear) {
       ck(ctx, mfm_zero_w(ctx));
     } else {
-      if (device_rng && dim_all) {
+      if (fuse_wV) {
+        // (below, with update_V)
+      } else if (device_rng && dim_all) {
         ck(ctx, mfm_sweep_w(ctx, hyper.alpha, hyper.lambda_w.data(), hyper.mu_w.data(), nullptr));
       } else {
         zbuf.resize(std::max<size_t>(dim_all, 1));
@@ -1125,7 +1134,10 @@ struct FMTrainer {
           hyper.mu_V[(size_t)f * G + g] = sample_normal(square, linear);
         }
       // update_V (:316-486)
-      if (device_rng && dim_all) {
+      if (fuse_wV) {
+        ck(ctx, mfm_sweep_wV(ctx, hyper.alpha, e_shift, hyper.lambda_w.data(), hyper.mu_w.data(), nullptr, 0, Kf,
+                             hyper.lambda_V.data(), hyper.mu_V.data(), nullptr));
+      } else if (device_rng && dim_all) {
         ck(ctx, mfm_sweep_V(ctx, 0, Kf, hyper.alpha, hyper.lambda_V.data(), hyper.mu_V.data(), nullptr));
       } else {
         zbuf.resize(dim_all * (size_t)Kf);

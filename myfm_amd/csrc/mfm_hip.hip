@@ -81,6 +81,7 @@ struct mfm_ctx {
   ResPlan res;                  // ... as one persistent launch with the residual resident on chip (mfm_res.hpp)
   bool sharded_fused = false;   // row-sharded + fused tile path (run_sweep_soa_sharded)
   int q_stale_factor = -1;      // >= 0: the stored q column is stale, mfm_get_q rebuilds it for this factor first
+  DevBuf<double> lam_w, mu_w, zw_host;  // mfm_sweep_wV: the linear sweep's hyper-parameters / host-given variates
   bool e_in_slots = false;      // the residual after the resident latent sweep lives in res.e_slots (slot order): every
                                 // reader of eq calls materialize_e first; update_e overwrites it and just drops the flag
   DevBuf<double> sync_mask;     // [D] 1: this rank contributes the column to the model synchronisation
@@ -1126,6 +1127,57 @@ int mfm_sweep_w(mfm_ctx *ctx, double alpha, const double *lambda_w, const double
     run_plan<PMainW>(s, c->timing, c->plan_W, a, c->ls, kcw, c->X.unit);
   for (auto &B : c->blocks)
     block_sweep_w(s, c->timing, c->ls, *B, c->N, c->eq.p, c->w.p, zdev, c->group.p, c->lam.p, c->mu.p, alpha, c->comm);
+  MFM_CATCH(ctx)
+}
+
+// update_w followed by update_V (BaseFMTrainer.hpp:143-148: the hyper-parameter draws between them read neither w nor e), with
+// update_w0's residual shift (:226) in front. On a two-field one-hot table all of it is ONE persistent launch (mfm_res.hpp:
+// the linear sweep is the latent sweep with h = 1); everywhere else the three calls in sequence.
+int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambda_w, const double *mu_w, const double *zw,
+                 int32_t f_begin, int32_t f_end, const double *lambda_V, const double *mu_V, const double *zv) {
+  {
+    mfm_ctx *c = ctx;
+    const bool fused = c && c->finalized && c->res.ready && f_begin < f_end && !std::getenv("MFM_RES_NO_LINEAR");
+    if (!fused) {
+      int rc = e_shift != 0.0 ? mfm_shift_e(ctx, e_shift) : MFM_OK;
+      if (rc == MFM_OK) rc = mfm_sweep_w(ctx, alpha, lambda_w, mu_w, zw);
+      if (rc == MFM_OK) rc = mfm_sweep_V(ctx, f_begin, f_end, alpha, lambda_V, mu_V, zv);
+      return rc;
+    }
+  }
+  MFM_TRY(ctx)
+  ctx->need_final();
+  materialize_e(ctx);
+  mfm_ctx *c = ctx;
+  if (f_begin < 0 || f_end > c->K) throw Error(MFM_ERR_INVALID, "factor range out of bounds");
+  hipStream_t s = c->stream;
+  if (!c->lam_w.p) {
+    c->lam_w.alloc((size_t)c->G);
+    c->mu_w.alloc((size_t)c->G);
+  }
+  c->ring.upload(c->lam_w.p, lambda_w, (size_t)c->G * sizeof(double), s);
+  c->ring.upload(c->mu_w.p, mu_w, (size_t)c->G * sizeof(double), s);
+  c->ring.upload(c->lam.p, lambda_V, (size_t)c->G * c->K * sizeof(double), s);
+  c->ring.upload(c->mu.p, mu_V, (size_t)c->G * c->K * sizeof(double), s);
+  if ((zw == nullptr) != (zv == nullptr)) throw Error(MFM_ERR_INVALID, "mfm_sweep_wV: give both variate arrays or none");
+  const double *zwdev, *zbase;
+  if (zw) {
+    if (!c->zw_host.p) c->zw_host.alloc((size_t)c->D);
+    c->ring.upload(c->zw_host.p, zw, (size_t)c->D * sizeof(double), s);
+    c->ring.upload(c->z.p, zv, (size_t)c->D * (f_end - f_begin) * sizeof(double), s);
+    zwdev = c->zw_host.p;
+    zbase = c->z.p;
+  } else {
+    if (c->rng.current < 0 || c->rng.n_zw != c->D || c->rng.n_zv != c->D * (int64_t)c->K)
+      throw Error(MFM_ERR_RUNTIME, "mfm_sweep_wV(z = NULL) needs an acquired device random set with D + K*D variates");
+    zwdev = c->rng.slot[c->rng.current].zw.p;
+    zbase = c->rng.slot[c->rng.current].zv.p + (size_t)f_begin * c->D;
+  }
+  const bool lazy_store = !std::getenv("MFM_RES_EAGER_STORE");
+  run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq.p, c->V.p, c->D, f_begin, f_end, zbase, c->lam.p, c->mu.p,
+                     c->group.p, c->G, alpha, c->ls.error.p, lazy_store, c->w.p, zwdev, c->lam_w.p, c->mu_w.p, e_shift);
+  c->e_in_slots = lazy_store;
+  c->q_stale_factor = f_end - 1;
   MFM_CATCH(ctx)
 }
 

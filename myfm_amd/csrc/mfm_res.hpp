@@ -61,6 +61,15 @@ struct ResArgs {
   double *V;                 // factor-major [K][D]
   int64_t D;
   int f_begin, f_end;
+  // update_w (FMTrainer.hpp:231-254) as one more sweep in front of the factors: for a one-hot table it IS the latent sweep
+  // with h = 1 for both levels (the other field's "coefficient" is 1: S2 = the column's entry count, S1 = -sum e, and
+  // lin = alpha (S1 + S2 w_old) + lambda mu is :241-249's -alpha sum(e - w_old) + lambda mu)
+  int linear;                // 1: sweep w first
+  int n_sw;                  // sweeps of the launch: f_end - f_begin + linear
+  double *w;                 // [D]
+  const double *zw;          // [D] variates of the linear sweep
+  const double *lam_w, *mu_w;  // [n_groups]
+  double e_shift;            // added to every residual as it is loaded (update_w0's e += w0' - w0, :226)
   const double *z;           // variates of factor f at z + (f - f_begin) D
   const double *lam, *mu;    // [K][n_groups]
   const int32_t *group;      // per feature
@@ -192,14 +201,14 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   rbar.xcc = 0;
   rbar.n_x = rbar.nx = 1;
 #define RES_STAMP0(k) \
-  if (a.prof && tid == 0) a.prof[(int64_t)g * (a.f_end - a.f_begin) * 64 + 56 + (k)] = __builtin_amdgcn_s_memrealtime()
+  if (a.prof && tid == 0) a.prof[(int64_t)g * a.n_sw * 64 + 56 + (k)] = __builtin_amdgcn_s_memrealtime()
   RES_STAMP0(0);
   if (tid == 0) res_bar_init(a, rbar, dead);
   RES_STAMP0(1);
   const bool nost = (a.dbg & 4096) != 0;  // (4096: no partial stores inside sweep B)
   const int trash_run = a.wg_run_ptr[g] + a.wg_nruns[g];
 #define RES_STAMP(k)                                                                                      \
-  if (a.prof && tid == 0) a.prof[((int64_t)g * (a.f_end - a.f_begin) + (f - a.f_begin)) * 64 + (k)] = __builtin_amdgcn_s_memrealtime()
+  if (a.prof && tid == 0) a.prof[((int64_t)g * a.n_sw + (f - f_first)) * 64 + (k)] = __builtin_amdgcn_s_memrealtime()
 
   for (int i = tid; i < 2 * NW * U; i += NT) acc1[i] = 0.0;
   for (int i = tid; i < U; i += NT) utab[i] = d2_t{0.0, 0.0};
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       for (int k = 0; k < B; k++) row[k] = perm_g[(16 * j + 4 * bb + k) * NT + tid];
 #pragma unroll
       for (int k = 0; k < B; k++) {
-        const double x = a.eq[row[k] < 0 ? 0 : row[k]].x;
+        const double x = a.eq[row[k] < 0 ? 0 : row[k]].x + a.e_shift;
         if (j < NGV)
           ev[j < NGV ? j : 0][4 * bb + k] = x;
         else
@@ -253,9 +262,13 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   __syncthreads();
 
   RES_STAMP0(2);
-  for (int f = a.f_begin; f < a.f_end; f++) {
-    double *Vf = a.V + (int64_t)f * a.D;
-    const double *zf = a.z + (int64_t)(f - a.f_begin) * a.D;
+  const int f_first = a.f_begin - a.linear;
+  for (int f = f_first; f < a.f_end; f++) {
+    const bool lin = f < a.f_begin;  // the linear sweep
+    double *Vf = lin ? a.w : a.V + (int64_t)f * a.D;
+    const double *zf = lin ? a.zw : a.z + (int64_t)(f - a.f_begin) * a.D;
+    const double *lamf = lin ? a.lam_w : a.lam + (int64_t)f * a.n_groups;
+    const double *muf = lin ? a.mu_w : a.mu + (int64_t)f * a.n_groups;
     // this thread's user: everything its draw needs is requested now
     int uj = 0;
     double uold = 0.0, uz = 0.0, ulam = 0.0, umu = 0.0;
@@ -264,8 +277,8 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       uj = d.x;
       uold = Vf[uj];
       uz = zf[uj];
-      ulam = a.lam[(int64_t)f * a.n_groups + d.y];
-      umu = a.mu[(int64_t)f * a.n_groups + d.y];
+      ulam = lamf[d.y];
+      umu = muf[d.y];
     }
     RES_STAMP(0);
     // ---- sweep A: the item update of the previous factor (:371-375; dv.x = 0 before the first), the user level's
@@ -349,7 +362,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       }
       const double fresh = PMainV::draw(S1, S2, uold, a.alpha, ulam, umu, uz);
       Vf[uj] = fresh;
-      utab[tid] = d2_t{fresh, fresh - uold};
+      utab[tid] = d2_t{lin ? 1.0 : fresh, fresh - uold};  // {h of the item level, delta}
     }
     __syncthreads();
     RES_STAMP(2);
@@ -429,11 +442,11 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
           for (int bp = 0; bp < 2; bp++) {
             RES_STEP_B(j, 2 * bp, itA, itB, ccA, ccB);
             if (a.prof && lane == 0 && (wv == 4 || wv == 7))  // (waves 4 and 7: every batch)
-              a.prof[((int64_t)g * (a.f_end - a.f_begin) + (f - a.f_begin)) * 64 + 16 + (wv == 4 ? 0 : 20) + 4 * j + 2 * bp] =
+              a.prof[((int64_t)g * a.n_sw + (f - f_first)) * 64 + 16 + (wv == 4 ? 0 : 20) + 4 * j + 2 * bp] =
                   __builtin_amdgcn_s_memrealtime();
             RES_STEP_B(j, 2 * bp + 1, itB, itA, ccB, ccA);
             if (a.prof && lane == 0 && (wv == 4 || wv == 7))
-              a.prof[((int64_t)g * (a.f_end - a.f_begin) + (f - a.f_begin)) * 64 + 16 + (wv == 4 ? 0 : 20) + 4 * j + 2 * bp + 1] =
+              a.prof[((int64_t)g * a.n_sw + (f - f_first)) * 64 + 16 + (wv == 4 ? 0 : 20) + 4 * j + 2 * bp + 1] =
                   __builtin_amdgcn_s_memrealtime();
           }
         }
@@ -441,7 +454,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
 #undef RES_PARTIAL_STORE
       }
       if (a.prof && lane == 0)  // (per wave: the end of its own sweep B)
-        a.prof[((int64_t)g * (a.f_end - a.f_begin) + (f - a.f_begin)) * 64 + 8 + wv] = __builtin_amdgcn_s_memrealtime();
+        a.prof[((int64_t)g * a.n_sw + (f - f_first)) * 64 + 8 + wv] = __builtin_amdgcn_s_memrealtime();
       // stitch the runs that cross thread boundaries: a thread with a head restarts the running sum with its open tail,
       // a thread without one passes its whole sum on
       double v1 = s1, v2 = s2;
@@ -513,7 +526,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
         const int j = a.scols[i];
         const int gj = a.group[j];
         const double old = Vf[j], zj = zf[j], vn = more ? a.V[(int64_t)(f + 1) * a.D + j] : 0.0;
-        const double lj = a.lam[(int64_t)f * a.n_groups + gj], mj = a.mu[(int64_t)f * a.n_groups + gj];
+        const double lj = lamf[gj], mj = muf[gj];
         double S1 = 0.0, S2 = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; w++) {
@@ -576,7 +589,7 @@ __global__ void k_res_init_dv(const double *__restrict__ theta, const int32_t *_
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_items) {
     dv[2 * i] = 0.0;
-    dv[2 * i + 1] = theta[scols[i]];
+    dv[2 * i + 1] = theta ? theta[scols[i]] : 1.0;  // (theta == null: the linear sweep, h = 1)
   } else if (i == n_items) {  // the pad item: (0, 0) for ever
     dv[2 * i] = 0.0;
     dv[2 * i + 1] = 0.0;
@@ -934,11 +947,20 @@ struct ResPlan {
 // update_V of factors [f_begin, f_end) in one launch. zbase: variates of factor f_begin (factor f at + (f - f_begin) D).
 static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, int kernel_class, double2 *eq, double *V, int64_t D,
                                       int f_begin, int f_end, const double *zbase, const double *lam, const double *mu,
-                                      const int32_t *group, int n_groups, double alpha, int *error, bool lazy_store) {
+                                      const int32_t *group, int n_groups, double alpha, int *error, bool lazy_store,
+                                      double *w = nullptr, const double *zw = nullptr, const double *lam_w = nullptr,
+                                      const double *mu_w = nullptr, double e_shift = 0.0) {
   ResArgs a;
   std::memset(&a, 0, sizeof(a));
   a.eq = eq;
   a.e_slots = lazy_store ? rp.e_slots.p : nullptr;
+  a.linear = w ? 1 : 0;
+  a.n_sw = f_end - f_begin + a.linear;
+  a.w = w;
+  a.zw = zw;
+  a.lam_w = lam_w;
+  a.mu_w = mu_w;
+  a.e_shift = e_shift;
   a.perm = rp.perm.p;
   a.uidw = rp.uidw.p;
   a.headw = rp.headw.p;
@@ -977,16 +999,17 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   const bool prof = std::getenv("MFM_RES_PROF") && ++prof_launch == std::atoi(std::getenv("MFM_RES_PROF"));
   DevBuf<unsigned long long> prof_buf;
   if (prof) {
-    prof_buf.alloc((size_t)rp.G * (f_end - f_begin) * 64);
-    MFM_HIP_CHECK(hipMemsetAsync(prof_buf.p, 0, (size_t)rp.G * (f_end - f_begin) * 512, s));
+    prof_buf.alloc((size_t)rp.G * a.n_sw * 64);
+    MFM_HIP_CHECK(hipMemsetAsync(prof_buf.p, 0, (size_t)rp.G * a.n_sw * 512, s));
     a.prof = prof_buf.p;
   }
-  const int K = f_end - f_begin;
+  const int K = a.n_sw;
   // algorithmic bytes of the launch: e read + written once, the per-slot words twice per factor (+ once at either end),
   // one 16-byte partial per (workgroup, item) written and read per factor
   const double bytes = 16.0 * rp.n_rows + 8.0 * rp.n_rows + K * (8.0 * rp.n_rows + 32.0 * rp.n_runs);
   (void)lazy_store;
-  hipLaunchKernelGGL(k_res_init_dv, dim3((rp.n_items + 256) / 256), dim3(256), 0, s, V + (int64_t)f_begin * D, rp.scols.p, rp.n_items,
+  hipLaunchKernelGGL(k_res_init_dv, dim3((rp.n_items + 256) / 256), dim3(256), 0, s,
+                     w ? (const double *)nullptr : V + (int64_t)f_begin * D, rp.scols.p, rp.n_items,
                      rp.dv.p);
   TimedLaunch t(tm, s, kernel_class, bytes);
 #define MFM_RES_LAUNCH(RV_, RL_)                                                                                              \
@@ -1011,7 +1034,7 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   MFM_HIP_CHECK(hipGetLastError());
   if (prof) {
     MFM_HIP_CHECK(hipStreamSynchronize(s));
-    const int K2 = f_end - f_begin;
+    const int K2 = a.n_sw;
     std::vector<unsigned long long> h((size_t)rp.G * K2 * 64);
     MFM_HIP_CHECK(hipMemcpy(h.data(), prof_buf.p, h.size() * 8, hipMemcpyDeviceToHost));
     // per phase: mean over (workgroup, factor) and mean over factors of the slowest / fastest workgroup, in us

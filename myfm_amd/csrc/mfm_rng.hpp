@@ -31,6 +31,9 @@ namespace mfm {
 constexpr int MT_N = 624, MT_M = 397;
 constexpr int RNG_CONSUME_THREADS = 1024;
 constexpr int RNG_ATT = 4;  // attempts per thread per batch
+#ifndef MFM_RNG_SPEC
+#define MFM_RNG_SPEC 16  // gamma draws evaluated speculatively at once (k_rng_consume), at most the number of waves
+#endif
 
 struct RngOp {
   int32_t kind;   // 0 = NORMALS, 1 = GAMMA
@@ -139,14 +142,14 @@ __global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate(RngState *__rest
 // x[l + i] over the set bits i of g_p -- ~10 k conflict-free LDS reads per lane, no barriers. The new state is
 // written to a staging copy (late workgroups must still see the old one) and committed by k_mt_commit.
 constexpr int MT_PAR_BLOCKS = 512;  // blocks per workgroup at most (and the request size from which the generator is parallel)
-// blocks per workgroup for a request of `blocks`. A workgroup pays ~100 us for its jump and ~1 us per block, so fewer,
-// longer workgroups cost the kernels running beside the generator less CU time in total; its latency matters little (the
-// trainer requests a set a whole iteration before it is needed; measured: 128 / 256 / 512 blocks give the same iteration
-// rate): 512 blocks -- 43 workgroups, ~0.6 ms at the ML-10M shape.
+// blocks per workgroup for a request of `blocks`. A workgroup pays ~100 us for its jump and ~1 us per block. The
+// generator can only run in the part of an iteration that is not the persistent latent sweep (update_e, the reductions, the
+// host's draws: ~0.6 ms at the ML-10M shape) and the draw program behind it is a serial chain, so its latency counts:
+// 128 blocks -- 169 workgroups, ~0.25 ms there (measured: 512 / 256 / 128 / 96 blocks -> 255 / 260 / 263 / 260 it/s).
 static inline int mt_par_blocks_for(int64_t blocks) {
   (void)blocks;
   if (const char *e = std::getenv("MFM_RNG_PAR_BLOCKS")) return std::max(32, std::min(MT_PAR_BLOCKS, std::atoi(e)));
-  return MT_PAR_BLOCKS;
+  return 128;
 }
 constexpr int MT_JUMP_SPAN = 33;  // blocks covering 19937 + 624 words
 
@@ -276,7 +279,17 @@ __device__ __forceinline__ double canonical(uint32_t lo, uint32_t hi) {
 struct RawReader {
   const uint32_t *raw;
   uint64_t mask, p;
-  __device__ __forceinline__ uint32_t next() { return mt_temper(raw[(p++) & mask]); }
+  // optional window of tempered words in LDS: outputs [wbase, wbase + wlen) (a lone thread walking the ring in HBM pays a
+  // dependent global round trip per word: ~4 us per gamma draw)
+  const uint32_t *win = nullptr;
+  uint64_t wbase = 0;
+  uint32_t wlen = 0;
+  __device__ __forceinline__ uint32_t next() {
+    const uint64_t i = p++;
+    const uint64_t o = i - wbase;
+    if (o < (uint64_t)wlen) return win[o];
+    return mt_temper(raw[i & mask]);
+  }
   __device__ __forceinline__ double uniform() {
     const uint32_t lo = next();
     const uint32_t hi = next();
@@ -288,7 +301,7 @@ struct RawReader {
 struct NormalDist {
   bool saved_available = false;
   double saved = 0.0;
-  __device__ double operator()(RawReader &g) {
+  __device__ __forceinline__ double operator()(RawReader &g) {
     double ret;
     if (saved_available) {
       saved_available = false;
@@ -309,21 +322,46 @@ struct NormalDist {
   }
 };
 
-// unit-scale gamma_distribution<double>(alpha, .)(gen): the caller multiplies by beta
-__device__ double gamma_unit(RawReader &g, double alpha) {
+// unit-scale gamma_distribution<double>(alpha, .)(gen): the caller multiplies by beta. The distribution's own
+// normal_distribution member keeps the second value of a polar pair for its next call (random.tcc:2337-2392, :1802-1835).
+__device__ __forceinline__ double gamma_unit(RawReader &g, double alpha) {
   const double malpha = alpha < 1.0 ? alpha + 1.0 : alpha;
   const double a1 = malpha - 1.0 / 3.0;
   const double a2 = 1.0 / sqrt(9.0 * a1);
-  NormalDist nd;
+  // (the "second value is available" flag lives in a vector register, pinned by the empty asm: kept as a lane mask across
+  //  the divergent loops, the compiler lost it -- a rejected lane drew a new pair instead of taking the saved value, seen
+  //  as soon as more than one lane of a wave evaluated draws)
+  int have_saved = 0;
+  double saved = 0.0;
   double u, v, n;
-  do {
-    do {
-      n = nd(g);
+  for (;;) {
+    for (;;) {
+      asm volatile("" : "+v"(have_saved));
+      if (have_saved != 0) {
+        have_saved = 0;
+        n = saved;
+      } else {
+        double x, y, r2;
+        do {
+          x = 2.0 * g.uniform() - 1.0;
+          y = 2.0 * g.uniform() - 1.0;
+          r2 = x * x + y * y;
+        } while (r2 > 1.0 || r2 == 0.0);
+        const double mult = sqrt(-2 * log(r2) / r2);
+        saved = x * mult;
+        have_saved = 1;
+        n = y * mult;
+      }
+      asm volatile("" : "+v"(have_saved));
+      n = n * 1.0 + 0.0;
       v = 1.0 + a2 * n;
-    } while (v <= 0.0);
+      if (v > 0.0) break;
+    }
     v = v * v * v;
     u = g.uniform();
-  } while (u > 1.0 - 0.0331 * n * n * n * n && (log(u) > (0.5 * n * n + a1 * (1.0 - v + log(v)))));
+    const bool again = u > 1.0 - 0.0331 * n * n * n * n && (log(u) > (0.5 * n * n + a1 * (1.0 - v + log(v))));
+    if (!again) break;
+  }
   if (alpha == malpha) return a1 * v;
   do u = g.uniform();
   while (u == 0.0);
@@ -336,23 +374,65 @@ __global__ __launch_bounds__(RNG_CONSUME_THREADS) void k_rng_consume(RngState *_
                                                                      int op_end, double *__restrict__ hv,
                                                                      double *__restrict__ zw, double *__restrict__ zv) {
   constexpr int NW = RNG_CONSUME_THREADS / 64;
+  constexpr int WIN = 8192;  // words of the gamma draws' look-ahead window (a draw takes ~10, rarely more than 100)
   __shared__ int s_tot[RNG_ATT][NW];
   __shared__ unsigned long long s_p;
   __shared__ int s_kstar;
+  __shared__ uint32_t s_win[WIN];
+  __shared__ double s_gval[NW][64];  // speculative gamma draws: value / outputs consumed up to the end, per (op, start)
+  __shared__ int s_gend[NW][64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   uint64_t p = st->p_cons;
+  uint64_t wbase = 0;
+  uint32_t wlen = 0;
   for (int oi = op_begin; oi < op_end; oi++) {
     const RngOp op = ops[oi];
     double *dst = (op.dest == 0 ? hv : (op.dest == 1 ? zw : zv)) + op.offset;
     if (op.kind == 1) {
-      if (tid == 0) {
-        RawReader g{raw, mask, p};
-        dst[0] = gamma_unit(g, op.shape);
-        s_p = g.p;
+      // A run of consecutive GAMMA ops. Each draw starts where the one before ended -- a data-dependent number of outputs
+      // later -- and a lone lane takes ~4 us per draw (dependent fp64 log / sqrt chains). So up to 16 draws are evaluated
+      // at once, SPECULATIVELY: wave j evaluates op j of the run at 64 candidate start positions (a draw consumes an
+      // even number of outputs, at least 6), then thread 0 walks the chain start -> end -> next start through the table;
+      // where a start falls outside the candidates the walk stops and the next round begins there. Same variates, same
+      // consumption as the sequential evaluation.
+      int n_run = 1;
+      while (oi + n_run < op_end && ops[oi + n_run].kind == 1) n_run++;
+      int done_ops = 0;
+      while (done_ops < n_run) {  // (every quantity here is workgroup-uniform)
+        if (p < wbase || p + 2048 > wbase + wlen) {  // refill: the window starts at the next output
+          __syncthreads();
+          for (int i = tid; i < WIN; i += RNG_CONSUME_THREADS) s_win[i] = mt_temper(raw[(p + (uint64_t)i) & mask]);
+          wbase = p;
+          wlen = WIN;
+          __syncthreads();
+        }
+        const int batch = min(MFM_RNG_SPEC, n_run - done_ops);
+        if (wid < batch && (MFM_RNG_SPEC > 1 || lane == 0)) {
+          const RngOp oj = ops[oi + done_ops + wid];
+          RawReader g{raw, mask, p + (uint64_t)(6 * wid + 2 * lane), s_win, wbase, wlen};
+          s_gval[wid][lane] = gamma_unit(g, oj.shape);
+          s_gend[wid][lane] = (int)(g.p - p);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int pos = 0, j = 0;
+          for (; j < batch; j++) {
+            const int l2 = pos - 6 * j;
+            if (l2 < 0 || l2 >= 128) break;  // (l2 is even: every draw consumes an even number of outputs)
+            const RngOp oj = ops[oi + done_ops + j];
+            double *dj = (oj.dest == 0 ? hv : (oj.dest == 1 ? zw : zv)) + oj.offset;
+            dj[0] = s_gval[j][l2 >> 1];
+            pos = s_gend[j][l2 >> 1];
+          }
+          s_p = p + (uint64_t)pos;
+          s_kstar = j;  // draws resolved (>= 1: the first one's start is candidate 0)
+        }
+        __syncthreads();
+        p = s_p;
+        done_ops += s_kstar;
+        __syncthreads();
       }
-      __syncthreads();
-      p = s_p;
-      __syncthreads();
+      oi += n_run - 1;
       continue;
     }
     int64_t done = 0;

@@ -11,7 +11,7 @@ import numpy as np
 
 class CapiGibbs:
     def __init__(self, ctx, rng_trainer, n_rows, group_index, alpha_0=1.0, beta_0=1.0, gamma_0=1.0, mu_0=0.0, reg_0=1.0,
-                 fit_w0=True, fit_linear=True):
+                 fit_w0=True, fit_linear=True, fused=False):
         self.c = ctx
         self.rng = rng_trainer  # oracle trainer used ONLY as the mt19937 source
         self.N = n_rows
@@ -20,6 +20,7 @@ class CapiGibbs:
         self.n_g = np.bincount(self.gi, minlength=self.G).astype(np.float64)
         self.a0, self.b0, self.g0, self.m0, self.r0 = alpha_0, beta_0, gamma_0, mu_0, reg_0
         self.fit_w0, self.fit_linear = fit_w0, fit_linear
+        self.fused = fused  # update_w0's shift + update_w + update_V through mfm_sweep_wV (one call)
         K, G = ctx.K, self.G
         self.alpha = 1.0
         self.mu_w, self.lam_w = np.zeros(G), np.full(G, 1e-5)
@@ -75,6 +76,8 @@ class CapiGibbs:
 
     def step(self, before_update_e=None):
         c, K, G, D = self.c, self.c.K, self.G, self.c.D
+        fuse = self.fused and self.fit_linear and K > 0
+        e_shift = 0.0
         self._begin()
         # update_alpha, FMTrainer.hpp:127-145
         se, se2 = c.reduce_e()
@@ -84,10 +87,12 @@ class CapiGibbs:
             lin = self.alpha * (self.N * self.w0 - se)
             quad = self.alpha * self.N + self.r0
             w0_new = self._normal(quad, lin)
-            c.shift_e(w0_new - self.w0)
+            e_shift = w0_new - self.w0
             self.w0 = w0_new
         else:
             self.w0 = 0.0
+        if e_shift != 0.0 and not fuse:
+            c.shift_e(e_shift)
         c.set_w0(self.w0)
         # update_lambda_w / update_mu_w, :150-200
         s, ssd = c.group_stats_w(self.mu_w)
@@ -98,7 +103,10 @@ class CapiGibbs:
             lin = (self.g0 * self.m0 + s[g]) * self.lam_w[g]
             self.mu_w[g] = self._normal(sq, lin)
         # update_w, :231-314
-        if self.fit_linear:
+        zw = None
+        if fuse:
+            zw = self._z(D)  # (drawn here: the reference's stream order)
+        elif self.fit_linear:
             c.sweep_w(self.alpha, self.lam_w, self.mu_w, self._z(D))
         else:
             c.zero_w()
@@ -114,7 +122,10 @@ class CapiGibbs:
                     lin = (self.g0 * self.m0 + s[g, f]) * self.lam_V[g, f]
                     self.mu_V[g, f] = self._normal(sq, lin)
             # update_V, :316-486
-            c.sweep_V(0, K, self.alpha, self.lam_V, self.mu_V, self._z(K * D))
+            if fuse:
+                c.sweep_wV(self.alpha, e_shift, self.lam_w, self.mu_w, zw, 0, K, self.lam_V, self.mu_V, self._z(K * D))
+            else:
+                c.sweep_V(0, K, self.alpha, self.lam_V, self.mu_V, self._z(K * D))
         # update_e, :493-497
         if before_update_e is not None:
             before_update_e()

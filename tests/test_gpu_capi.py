@@ -277,6 +277,38 @@ def test_resident_latent_sweep(oracle, capi, monkeypatch, cus):
     np.testing.assert_allclose(c.get_state()[2], chains[0][0], rtol=1e-9, atol=1e-10)
 
 
+@pytest.mark.parametrize("device_rng", [False, True])
+def test_resident_linear_and_latent_sweeps_in_one_launch(oracle, capi, monkeypatch, device_rng):
+    # mfm_sweep_wV: update_w0's residual shift, update_w and update_V of a two-field one-hot table as ONE persistent launch
+    # (the linear sweep is the latent sweep with h = 1), against the oracle's update_all draw for draw; variates from the
+    # host (the oracle's generator) and from the device stream
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    n = 120001
+    X, y, shapes = ds.onehot_mf(n, 260, 140, seed=5, sort_by_user=True)
+    gi = ds.group_index_from_shapes(shapes)
+    t, c, _ = _pair(oracle, capi, X, y, gi, 4)
+    assert c.plan_flags()["resident"]
+    drv = CapiGibbs(c, t.clone(), n, gi, fused=True)
+    if device_rng:
+        state, pos = t.rng_state()
+        drv.use_device_rng(state, pos)
+    for it in range(4):
+        t.step()
+        drv.step()
+        w0, w, V = t.fm()
+        gw0, gw, gV = c.get_state()
+        assert abs(gw0 - w0) < 1e-9
+        np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-9, err_msg="w, iteration %d" % it)
+        np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-9, err_msg="V, iteration %d" % it)
+    np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-7, atol=1e-7)
+    c.timing_enable(True)
+    c.timing_reset()
+    drv.step()
+    classes = set(c.timing())
+    c.timing_enable(False)
+    assert "sweep_V_resident" in classes and not any(k.startswith("sweep_w") for k in classes), classes
+
+
 def test_resident_factor_subranges_and_empty_columns(oracle, capi, monkeypatch):
     # mfm_sweep_V over [0, 2), [2, 3), [3, 5) through the resident launch, on a table with features that never occur in either
     # field (drawn from the prior by the workgroup / item slice they are dealt to)
