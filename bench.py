@@ -386,11 +386,11 @@ def main():
         name, (ms, launches, alg_bytes) = max(timing.items(), key=lambda kv: kv[1][0])
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         # HBM bytes per launch of that class from the committed PMC passes of THIS round (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE of the same command, corrected as MI355X_MICROARCH.md prescribes; profiles/r02_*_pmc_traffic.*)
+        # WRITE_SIZE of the same command, corrected as MI355X_MICROARCH.md prescribes; profiles/r03_*_pmc_traffic.*)
         traffic, src = None, None
         default_workload = a.config == 3 and (a.rows, a.users, a.items, K) == (10_000_000, 69878, 10677, 32) and world == 1
         pdir = os.path.join(ROOT, "profiles")
-        pmc = sorted(f for f in os.listdir(pdir) if f.startswith("r02") and f.endswith("_pmc_traffic.json")) if os.path.isdir(pdir) else []
+        pmc = sorted(f for f in os.listdir(pdir) if f.startswith("r03") and f.endswith("_pmc_traffic.json")) if os.path.isdir(pdir) else []
         if default_workload and pmc:
             tr = json.load(open(os.path.join(pdir, pmc[-1])))
             if name in tr:
@@ -404,9 +404,13 @@ def main():
             "traffic_over_algorithmic": round(traffic / (alg_bytes / launches), 3) if traffic else None,
             "avg_launch_us": round(us, 2), "launches": int(launches), "alg_bytes_per_launch": round(alg_bytes / launches),
             "note": "achieved = the kernel's OWN algorithmic bytes / HIP-event time of its launches in the timed region. "
-                    "sweep_V_fused_next = one pass of the two-field latent sweep: e read + written once (16 B / row), 4-byte "
-                    "entries, one 16-byte statistics slot per run -- no q-cache in HBM (r01's pass moved 451 MB per factor, "
-                    "this one 274 MB)",
+                    "sweep_V_resident = update_w0's shift + update_w + update_V of a two-field table as ONE persistent launch, "
+                    "the residual on chip for all K + 1 sweeps: e read once (8 B / row + its 4-byte slot map) and left once in "
+                    "slot order (8 B / row), per sweep one 16-byte statistics partial per (workgroup, item) run written + read, "
+                    "its 8-byte list entry and two 4-byte item reads. The launch is bound by instruction issue, LDS atomics "
+                    "and two grid barriers per sweep, not by HBM: its fraction of the HBM roofline is low BECAUSE the bytes are "
+                    "gone (r02's per-factor pass moved 289 MB per factor, this one 98 MB); see DESIGN.md 4.3b. "
+                    "sweep_V_fused_next (other shapes) = one per-factor pass of the two-field latent sweep.",
             "kernel_ms_per_step": round(sum(v[0] for v in breakdown.values()), 3),
             "by_kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
             "by_kernel_note": "per-class times from 3 diagnostic steps with every launch bracketed (outside the timed region)",

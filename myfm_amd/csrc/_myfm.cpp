@@ -595,6 +595,51 @@ Real norm2(const vector<Real> &v) {
 // gradient / Hessian accumulation over the rows (:402-413) and the per-row latent draw (:238-272)
 // run on the device; the (K-1)-dimensional reparametrisation, damped Newton search and the
 // multivariate-t Metropolis step stay here.
+// ---- truncated-normal samplers on the trainer's own std::mt19937 (util.hpp:15-78), for the parity mode
+// MYFM_AMD_HOST_RNG=1 ONLY: there the latent draws of probit classification / ordered probit consume the generator row
+// after row exactly as the reference does (FMTrainer.hpp:498-521, OProbitSampler.hpp:238-272), so that those chains can
+// be compared with the CPU sampler draw for draw. The product path draws them on the device (mfm_tasks.hpp).
+static Real host_tn_left(std::mt19937 &gen, Real mu_minus) {  // util.hpp:15-38
+  if (mu_minus < 0) {
+    std::normal_distribution<Real> dist(0, 1);
+    for (;;) {
+      Real z = dist(gen);
+      if (z > mu_minus) return z;
+    }
+  }
+  Real alpha_star = (mu_minus + std::sqrt(mu_minus * mu_minus + 4)) / 2;
+  std::uniform_real_distribution<Real> dist(0, 1);
+  for (;;) {
+    Real z = -std::log(dist(gen)) / alpha_star + mu_minus;
+    Real rho = std::exp(-(z - alpha_star) * (z - alpha_star) / 2);
+    Real u = dist(gen);
+    if (u < rho) return z;
+  }
+}
+static Real host_tn_twoside(std::mt19937 &gen, Real mu_minus, Real mu_plus) {  // util.hpp:40-62
+  std::uniform_real_distribution<Real> proposal(mu_minus, mu_plus);
+  std::uniform_real_distribution<Real> acceptance(0, 1);
+  for (;;) {
+    Real z = proposal(gen);
+    Real rho;
+    if (mu_minus <= 0 && mu_plus >= 0)
+      rho = std::exp(-z * z / 2);
+    else if (mu_plus < 0)
+      rho = std::exp((mu_plus * mu_plus - z * z) / 2);
+    else
+      rho = std::exp((mu_minus * mu_minus - z * z) / 2);
+    Real u = acceptance(gen);
+    if (u < rho) return z;
+  }
+}
+static Real host_tn_left(std::mt19937 &gen, Real mean, Real sd, Real mu_minus) {  // :63-68
+  return mean + sd * host_tn_left(gen, (mu_minus - mean) / sd);
+}
+static Real host_tn_right(std::mt19937 &gen, Real mu_plus) { return -host_tn_left(gen, -mu_plus); }  // :70-73
+static Real host_tn_right(std::mt19937 &gen, Real mean, Real sd, Real mu_plus) {                      // :75-79
+  return mean + sd * host_tn_right(gen, (mu_plus - mean) / sd);
+}
+
 struct OprobitSampler {
   mfm_ctx *ctx;
   int group;  // device-side cutpoint group
@@ -795,8 +840,31 @@ struct OprobitSampler {
     }
     return false;
   }
-  void sample_z_given_cutpoint(uint64_t seed, uint64_t draw) {  // :238-272 on the device
-    ck(ctx, mfm_oprobit_sample_z(ctx, group, gamma_now.data(), seed, draw));
+  // parity mode (MYFM_AMD_HOST_RNG=1): the group's rows in the reference's order and the targets
+  const vector<size_t> *host_rows = nullptr;
+  const vector<Real> *host_y = nullptr;
+  int64_t host_n = 0;
+  void sample_z_given_cutpoint(uint64_t seed, uint64_t draw) {  // :238-272
+    if (!host_rows) {  // on the device
+      ck(ctx, mfm_oprobit_sample_z(ctx, group, gamma_now.data(), seed, draw));
+      return;
+    }
+    vector<Real> e((size_t)host_n);
+    ck(ctx, mfm_get_e(ctx, e.data()));  // the scores (x_ of the reference)
+    const Real deviation = 1;
+    for (size_t t : *host_rows) {
+      const int c = (int)(*host_y)[t];
+      const Real pred = e[t];
+      Real z_new;
+      if (c == 0)
+        z_new = deviation * host_tn_right(*rng, (gamma_now[c] - pred) / deviation) + pred;
+      else if (c == K - 1)
+        z_new = deviation * host_tn_left(*rng, (gamma_now[K - 2] - pred) / deviation) + pred;
+      else
+        z_new = deviation * host_tn_twoside(*rng, (gamma_now[c - 1] - pred) / deviation, (gamma_now[c] - pred) / deviation) + pred;
+      e[t] -= z_new;
+    }
+    ck(ctx, mfm_set_e(ctx, e.data()));
   }
 };
 
@@ -1041,6 +1109,11 @@ struct FMTrainer {
         ck(ctx, mfm_oprobit_add_group(ctx, (int32_t)c.first, all_rows ? nullptr : rows.data(), (int64_t)rows.size(), &g));
         cutpoint_sampler.emplace_back(ctx, g, (int)c.first, std::getenv("MYFM_AMD_HOST_RNG") ? gen_ : gen_mh_, cfg.reg_0,
                                       cfg.nu_oprobit);
+        if (std::getenv("MYFM_AMD_HOST_RNG")) {  // parity mode: latent draws on the host, in the reference's row order
+          cutpoint_sampler[i].host_rows = &c.second;
+          cutpoint_sampler[i].host_y = &y;
+          cutpoint_sampler[i].host_n = N;
+        }
         cutpoint_sampler[i].start_sample();
         OprobitSampler::alpha_to_gamma(fm.cutpoints[i], cutpoint_sampler[i].alpha_now);
         cutpoint_sampler[i].sample_z_given_cutpoint((uint64_t)random_seed, latent_draws++);
@@ -1152,7 +1225,19 @@ struct FMTrainer {
     if (cfg.task_type == TaskType::REGRESSION) {
       ck(ctx, mfm_update_e_regression(ctx));
     } else if (cfg.task_type == TaskType::CLASSIFICATION) {
-      ck(ctx, mfm_update_e_classification(ctx, (uint64_t)random_seed, latent_draws++));
+      if (std::getenv("MYFM_AMD_HOST_RNG")) {  // parity mode: FMTrainer.hpp:498-512 on the trainer's generator, row by row
+        ck(ctx, mfm_score_train(ctx));
+        vector<Real> e((size_t)N);
+        ck(ctx, mfm_get_e(ctx, e.data()));
+        for (int64_t t = 0; t < N; t++) {
+          const Real pred = e[(size_t)t];
+          const Real n = y[(size_t)t] > 0 ? host_tn_left(gen_, pred, (Real)1, (Real)0) : host_tn_right(gen_, pred, (Real)1, (Real)0);
+          e[(size_t)t] -= n;
+        }
+        ck(ctx, mfm_set_e(ctx, e.data()));
+      } else {
+        ck(ctx, mfm_update_e_classification(ctx, (uint64_t)random_seed, latent_draws++));
+      }
     } else {
       ck(ctx, mfm_score_train(ctx));
       int i = 0;

@@ -1004,9 +1004,10 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
     a.prof = prof_buf.p;
   }
   const int K = a.n_sw;
-  // algorithmic bytes of the launch: e read + written once, the per-slot words twice per factor (+ once at either end),
-  // one 16-byte partial per (workgroup, item) written and read per factor
-  const double bytes = 16.0 * rp.n_rows + 8.0 * rp.n_rows + K * (8.0 * rp.n_rows + 32.0 * rp.n_runs);
+  // algorithmic bytes of the launch: e read once (8 B) with its slot map (4 B) and the static slot words (11 bits), written
+  // once (8 B: slot order, or scattered to eq); per sweep one 16-byte partial per (workgroup, item) run written and read,
+  // its 8-byte list entry, its item read by both sweeps (2 x 4 B)
+  const double bytes = (8.0 + 4.0 + 1.4 + 8.0) * rp.n_rows + K * 48.0 * rp.n_runs;
   (void)lazy_store;
   hipLaunchKernelGGL(k_res_init_dv, dim3((rp.n_items + 256) / 256), dim3(256), 0, s,
                      w ? (const double *)nullptr : V + (int64_t)f_begin * D, rp.scols.p, rp.n_items,

@@ -1,16 +1,16 @@
-# round-2 measurement batch (run on the GPU box through gpurun): bench line, kernel trace, PMC traffic, SQ counters,
+# measurement batch (run on the GPU box through gpurun): bench line, kernel trace, PMC traffic, SQ counters,
 # predictor timing, other workloads. Outputs under gpurun_out/r02_z_*; summaries are copied to profiles/ afterwards.
 set -x
 cd $GRAFT_REPO_ROOT
-T=${1:-r02_z}
+T=${1:-r03_a}
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${T}_trace -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --cpu-seconds 0 --fit-iters 0 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${T}_pmc_fetch -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --fit-iters 0 --no-kernel-timing > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${T}_pmc_write -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --fit-iters 0 --no-kernel-timing > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${T}_trace -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --cpu-seconds 0 --fit-iters 0 --no-other-configs > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${T}_pmc_fetch -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --fit-iters 0 --no-kernel-timing --no-other-configs > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${T}_pmc_write -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --fit-iters 0 --no-kernel-timing --no-other-configs > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 python scripts/pmc_to_traffic.py gpurun_out/${T}_pmc_fetch gpurun_out/${T}_pmc_write gpurun_out/${T}_pmc_traffic | head -30
-python scripts/rocpd_summary.py $(ls gpurun_out/${T}_trace/*/*_results.db | head -1) gpurun_out/${T}_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --cpu-seconds 0 --fit-iters 0" | head -14
+python scripts/rocpd_summary.py $(ls gpurun_out/${T}_trace/*/*_results.db | head -1) gpurun_out/${T}_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --cpu-seconds 0 --fit-iters 0 --no-other-configs" | head -14
 rm -rf gpurun_out/${T}_trace
 rm -rf gpurun_out/${T}_pmc_fetch gpurun_out/${T}_pmc_write/p_agent_info.csv
 python scripts/bench_predict.py > gpurun_out/${T}_predict.txt 2>&1; tail -5 gpurun_out/${T}_predict.txt
