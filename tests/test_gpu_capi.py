@@ -564,6 +564,38 @@ def test_sample_store_predicts_like_host_samples(oracle, capi):
         st.predict(dev, 0, first=3, count=5)
 
 
+@pytest.mark.parametrize("K,unit", [(4, True), (7, False), (20, True), (0, True)])
+def test_store_prediction_in_one_pass_over_the_rows(oracle, capi, monkeypatch, K, unit):
+    # designs without relation blocks: Predictor::predict* over a store scores ALL samples in one pass over the test rows
+    # (k_score_store: samples as the inner loop, sums in registers); bit-identical to the per-sample passes
+    # (MFM_PREDICT_PER_SAMPLE=1) in all three modes, including sample sub-ranges, == the oracle's scorer
+    X, y, shapes = ds.onehot_mf(5003, 120, 60, seed=3)
+    if not unit:
+        X = X.copy()
+        X.data = np.where(np.arange(X.nnz) % 3 == 0, 0.5, 1.5)
+    rng = np.random.default_rng(11)
+    D, S = X.shape[1], 9
+    samples = [(rng.normal(), rng.normal(size=D) * 0.3, rng.normal(size=(D, K)) * 0.3) for _ in range(S)]
+    st = capi.Store(D, K)
+    for smp in samples:
+        st.push(*smp)
+    dev = capi.Design(X, [])
+    cuts = [np.sort(rng.normal(size=3)) for _ in samples]
+    got = {}
+    for mode in (0, 1, 2):
+        got[mode] = st.predict(dev, mode, cuts if mode == 2 else None)
+        got[mode, "sub"] = st.predict(dev, mode, cuts[2:7] if mode == 2 else None, first=2, count=5)
+    monkeypatch.setenv("MFM_PREDICT_PER_SAMPLE", "1")
+    for mode in (0, 1, 2):
+        assert np.array_equal(got[mode], st.predict(dev, mode, cuts if mode == 2 else None))
+        assert np.array_equal(got[mode, "sub"], st.predict(dev, mode, cuts[2:7] if mode == 2 else None, first=2, count=5))
+        assert np.array_equal(got[mode], dev.predict(samples, mode, cuts if mode == 2 else None))
+    od = oracle.OracleDesign(X, [])
+    want = np.mean([od.predict_score(*smp) for smp in samples], axis=0)
+    np.testing.assert_allclose(got[0], want, rtol=1e-11, atol=1e-11)
+    assert got[2].shape == (5003, 4) and np.allclose(got[2].sum(axis=1), 1.0)
+
+
 def test_error_paths(capi):
     X, y = ds.toy()
     with pytest.raises(RuntimeError, match="index mapping points to non-existing row"):
