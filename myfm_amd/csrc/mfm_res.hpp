@@ -27,7 +27,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mfm_common.hpp"
@@ -605,6 +607,29 @@ __global__ void k_res_unpermute(const double *__restrict__ e_slots, const int32_
   if (row >= 0) eq[row].x = e_slots[i];
 }
 
+// host threads for the layout's per-workgroup work
+template <class F>
+static inline void res_parallel_for(int n, F f) {
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int T = std::max(1, std::min({n, 16, hw > 0 ? hw : 1}));
+  if (T == 1) {
+    for (int i = 0; i < n; i++) f(i);
+    return;
+  }
+  std::atomic<int> next(0);
+  auto work = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) return;
+      f(i);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < T; t++) pool.emplace_back(work);
+  work();
+  for (auto &t : pool) t.join();
+}
+
 struct ResPlan {
   bool ready = false;
   int G = 0, NT = 512, RV = 0, RL = 0, umax = 0, item_bits = 0, n_items = 0;
@@ -672,13 +697,20 @@ struct ResPlan {
     std::vector<int32_t> item_of_row((size_t)N, -1);
     {
       int64_t cnt = 0;
-      for (int c = 0; c < n_items; c++)
-        for (int64_t p = csc.ptr[items[c]]; p < csc.ptr[items[c] + 1]; p++) {
-          if (item_of_row[csc.idx[p]] >= 0) return fail("second level touches a row twice");
-          item_of_row[csc.idx[p]] = c;
-          cnt++;
-        }
+      for (int c = 0; c < n_items; c++) cnt += csc.ptr[items[c] + 1] - csc.ptr[items[c]];
       if (cnt != N) return fail("second level does not cover the rows");
+      const int chunks = std::max(1, std::min(n_items, 64));
+      res_parallel_for(chunks, [&](int k) {
+        for (int c = (int)((int64_t)n_items * k / chunks); c < (int)((int64_t)n_items * (k + 1) / chunks); c++)
+          for (int64_t p = csc.ptr[items[c]]; p < csc.ptr[items[c] + 1]; p++) item_of_row[csc.idx[p]] = c;
+      });
+      // (N entries and no row left out: every row exactly once)
+      std::atomic<bool> bad(false);
+      res_parallel_for(chunks, [&](int k) {
+        for (int64_t r = N * k / chunks; r < N * (k + 1) / chunks; r++)
+          if (item_of_row[r] < 0) bad = true;
+      });
+      if (bad) return fail("second level touches a row twice");
     }
     // workgroups: contiguous user ranges of at most cap rows; the smallest variant that fits the device
     int nv = 0;
@@ -740,36 +772,55 @@ struct ResPlan {
     std::vector<uint32_t> h_headw((size_t)G * HW * NT, 0);
     std::vector<int32_t> h_perm((size_t)G * cap_slots, -1), h_first((size_t)G * NT, 0);
     std::vector<std::vector<int32_t>> wg_run_item((size_t)G);
-    std::vector<int32_t> uord_of_row((size_t)N), wg_of_user(users.size());
-    for (int g = 0; g < G; g++)
-      for (int64_t u = ucut[g]; u < ucut[g + 1]; u++) wg_of_user[u] = g;
-    for (size_t u = 0; u < users.size(); u++)
-      for (int64_t r = ustart[u]; r < ustart[u + 1]; r++) uord_of_row[r] = (int32_t)u;
     std::vector<int64_t> fill((size_t)G, 0);
-    std::vector<int32_t> last_item((size_t)G, -1), nruns((size_t)G, 0);
-    std::vector<int32_t> h_slot_ptr((size_t)n_items + 1, 0);
-    int64_t counter = 0;
-    for (int c = 0; c < n_items; c++) {
-      h_slot_ptr[c] = (int32_t)counter;
-      for (int64_t p = csc.ptr[items[c]]; p < csc.ptr[items[c] + 1]; p++) {
-        const int32_t row = csc.idx[p];
-        const int32_t uo = uord_of_row[row];
-        const int g = wg_of_user[uo];
-        const int64_t sidx = fill[g]++;
-        if (last_item[g] != c) {
-          last_item[g] = c;
-          wg_run_item[g].push_back(c);
-          counter++;
-          nruns[g]++;
+    std::vector<int32_t> nruns((size_t)G, 0);
+    // per workgroup (its rows are one contiguous range): the rows in (item, row) order by a counting sort, run starts,
+    // slot -> row, slot -> user, the first run of every thread. Workgroups are independent: host threads.
+    res_parallel_for(G, [&](int g) {
+      const int64_t row0 = ustart[ucut[g]], row1 = ustart[ucut[g + 1]];
+      const int64_t n = row1 - row0;
+      std::vector<int32_t> cnt((size_t)n_items + 1, 0), uloc((size_t)n);
+      for (int64_t u = ucut[g]; u < ucut[g + 1]; u++)
+        for (int64_t r = ustart[u]; r < ustart[u + 1]; r++) uloc[(size_t)(r - row0)] = (int32_t)(u - ucut[g]);
+      for (int64_t r = row0; r < row1; r++) cnt[(size_t)item_of_row[r] + 1]++;
+      std::vector<int32_t> &runs = wg_run_item[g];
+      for (int c = 0; c < n_items; c++) {
+        if (cnt[c + 1]) {  // a run of the workgroup starts at slot cnt[c] (after the prefix sum)
+          const int64_t sidx = cnt[c];
           const int th = (int)(sidx / R), rh = (int)(sidx % R);
           h_headw[((size_t)g * HW + rh / 16) * NT + th] |= 1u << (rh % 16);
+          runs.push_back(c);
         }
-        const int t = (int)(sidx / R), r = (int)(sidx % R);
-        h_perm[(size_t)g * cap_slots + (size_t)r * NT + t] = row;
-        h_uid[(size_t)g * cap_slots + (size_t)sidx] = (uint16_t)(uo - (int32_t)ucut[g]);
-        if (r == 0) h_first[(size_t)g * NT + t] = nruns[g] - 1;
+        cnt[c + 1] += cnt[c];
       }
+      // the run containing every thread's first slot: the last run that starts at or before it
+      {
+        size_t ri = 0;
+        std::vector<int32_t> run_start(runs.size());
+        for (size_t k = 0; k < runs.size(); k++) run_start[k] = cnt[runs[k]];
+        for (int t = 0; t < NT; t++) {
+          const int64_t s0 = (int64_t)t * R;
+          if (s0 >= n) break;
+          while (ri + 1 < runs.size() && run_start[ri + 1] <= s0) ri++;
+          h_first[(size_t)g * NT + t] = (int32_t)ri;
+        }
+      }
+      for (int64_t r = row0; r < row1; r++) {  // rows ascending: within an item the slots keep the row order
+        const int64_t sidx = cnt[(size_t)item_of_row[r]]++;
+        const int t = (int)(sidx / R), rr = (int)(sidx % R);
+        h_perm[(size_t)g * cap_slots + (size_t)rr * NT + t] = (int32_t)r;
+        h_uid[(size_t)g * cap_slots + (size_t)sidx] = (uint16_t)uloc[(size_t)(r - row0)];
+      }
+      fill[g] = n;
+      nruns[g] = (int32_t)runs.size();
+    });
+    std::vector<int32_t> h_slot_ptr((size_t)n_items + 1, 0);  // (workgroup, item) runs per item, as a prefix sum
+    int64_t counter = 0;
+    for (int g = 0; g < G; g++) {
+      counter += nruns[g];
+      for (int32_t c : wg_run_item[g]) h_slot_ptr[(size_t)c + 1]++;
     }
+    for (int c = 0; c < n_items; c++) h_slot_ptr[(size_t)c + 1] += h_slot_ptr[c];
     h_slot_ptr[n_items] = (int32_t)counter;
     n_runs = counter;
     if (counter >= ((int64_t)1 << 31) - 2) return fail("too many runs");
@@ -834,7 +885,7 @@ struct ResPlan {
     umax = std::max(maxu, imax) + 1;  // stride of the per-wave accumulator arrays; the pad user is umax - 1
     if (umax > 1024) return fail("internal: user field");
     std::vector<uint32_t> h_uidw((size_t)G * UW * NT, 0);
-    for (int g = 0; g < G; g++)
+    res_parallel_for(G, [&](int g) {
       for (int64_t sl = 0; sl < cap_slots; sl++) {
         const uint16_t u16 = h_uid[(size_t)g * cap_slots + (size_t)sl];
         const uint32_t u = u16 == 0xffffu ? (uint32_t)(umax - 1) : u16;
@@ -848,6 +899,7 @@ struct ResPlan {
           h_uidw[((size_t)g * UW + w0 + 4) * NT + t] |= (u >> 2) << (8 * bb);
         }
       }
+    });
     h_uid = std::vector<uint16_t>();
     // item draw tables: per slice its (run, item) pairs source workgroup by source workgroup (a source's runs are in item
     // order: the slice's share of them is a contiguous stretch of its partials), padded to whole 64-entry chunks
