@@ -415,6 +415,7 @@ struct DevBlock {
   DevBuf<int32_t> map;  // original_to_block (B < 2^31)
   DevBuf<double> rec;   // [B][8]
   DevBuf<double> bq, bl, bs;
+  BlockOverflow ov;     // (block MAX_BLOCKS keeps the scorer's pointer arrays of the blocks from there on)
   StepPlan plan_V, plan_W;
   // inverse map + bins of block rows by cardinality
   DevBuf<int64_t> inv_ptr;

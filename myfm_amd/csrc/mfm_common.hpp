@@ -321,6 +321,26 @@ inline int32_t column_levels(const HostCsr &csc, std::vector<int32_t> &level) {
   return n_levels;
 }
 
+// the pointers of the blocks beyond MAX_BLOCKS: device arrays, rebuilt (stream-ordered staging copy) whenever they are needed
+struct BlockOverflow {
+  DevBuf<const int32_t *> map;
+  DevBuf<const double *> p0, p1, p2;
+  DevBuf<int> stride;
+  template <class T>
+  static void put(DevBuf<T> &buf, const std::vector<T> &h, PinnedRing &ring, hipStream_t s) {
+    if (h.empty()) return;
+    if (buf.n < h.size()) buf.alloc(h.size());
+    ring.upload(buf.p, h.data(), h.size() * sizeof(T), s);
+  }
+  template <class T>
+  static void put_sync(DevBuf<T> &buf, const std::vector<T> &h) {
+    if (h.empty()) return;
+    if (buf.n < h.size()) buf.alloc(h.size());
+    MFM_HIP_CHECK(hipMemcpy(buf.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+};
+
+
 // Device-resident sparse matrix: CSR (row passes: q-build, re-score) and CSC (column sweeps).
 struct DevSparse {
   int64_t rows = 0, cols = 0, nnz = 0;

@@ -81,6 +81,7 @@ struct mfm_ctx {
   ResPlan res;                  // ... as one persistent launch with the residual resident on chip (mfm_res.hpp)
   bool sharded_fused = false;   // row-sharded + fused tile path (run_sweep_soa_sharded)
   int q_stale_factor = -1;      // >= 0: the stored q column is stale, mfm_get_q rebuilds it for this factor first
+  BlockOverflow gather_overflow;       // q-cache build: pointers of the relation blocks beyond MAX_BLOCKS
   DevBuf<double> lam_w, mu_w, zw_host;  // mfm_sweep_wV: the linear sweep's hyper-parameters / host-given variates
   bool e_in_slots = false;      // the residual after the resident latent sweep lives in res.e_slots (slot order): every
                                 // reader of eq calls materialize_e first; update_e overwrites it and just drops the flag
@@ -265,14 +266,33 @@ static HostCsr transpose_device(DevSparse &X, hipStream_t s) {
   return T;
 }
 
-static void fill_gather_args(std::vector<std::unique_ptr<DevBlock>> &blocks, BlockGatherArgs &g) {
+static void fill_gather_args(std::vector<std::unique_ptr<DevBlock>> &blocks, BlockGatherArgs &g, BlockOverflow &ov, PinnedRing &ring,
+                             hipStream_t s) {
   std::memset(&g, 0, sizeof(g));
   g.n_blocks = (int)blocks.size();
+  std::vector<const int32_t *> xm;
+  std::vector<const double *> xr;
+  std::vector<int> xs;
   for (size_t b = 0; b < blocks.size(); b++) {
-    g.map[b] = blocks[b]->map.p;
-    g.rec[b] = blocks[b]->qc.p ? blocks[b]->qc.p : blocks[b]->rec.p;
-    g.stride[b] = blocks[b]->qc.p ? 1 : BLOCK_REC;
+    const int32_t *m = blocks[b]->map.p;
+    const double *r = blocks[b]->qc.p ? blocks[b]->qc.p : blocks[b]->rec.p;
+    const int st = blocks[b]->qc.p ? 1 : BLOCK_REC;
+    if (b < (size_t)MAX_BLOCKS) {
+      g.map[b] = m;
+      g.rec[b] = r;
+      g.stride[b] = st;
+    } else {
+      xm.push_back(m);
+      xr.push_back(r);
+      xs.push_back(st);
+    }
   }
+  BlockOverflow::put(ov.map, xm, ring, s);
+  BlockOverflow::put(ov.p0, xr, ring, s);
+  BlockOverflow::put(ov.stride, xs, ring, s);
+  g.xmap = ov.map.p;
+  g.xrec = ov.p0.p;
+  g.xstride = ov.stride.p;
 }
 
 // q = X v_f + sum_b q_B[map_b]   (FMTrainer.hpp:320-340); the blocks' q_B must be in rec already
@@ -282,7 +302,7 @@ static void launch_qbuild(mfm_ctx *c, const double *vf, DevBlock *pending = null
   if (c->N == 0) return;
   hipStream_t s = c->stream;
   BlockGatherArgs g;
-  fill_gather_args(c->blocks, g);
+  fill_gather_args(c->blocks, g, const_cast<mfm_ctx *>(c)->gather_overflow, const_cast<mfm_ctx *>(c)->ring, s);
   TimedLaunch t(c->timing, s, KC_QBUILD, 12.0 * c->X.nnz + 8.0 * c->N + 8.0 * c->D0 + 12.0 * c->N * g.n_blocks);
   if (qbuild_by_rows(c)) {
     const bool ell = c->X.ell_width >= 0;
@@ -372,14 +392,35 @@ static void score_design(hipStream_t s, Timing &tm, int mode, const DevSparse &X
   BlockScoreArgs blk;
   std::memset(&blk, 0, sizeof(blk));
   blk.n_blocks = (int)blocks.size();
+  std::vector<const int32_t *> xm;
+  std::vector<const double *> xq, xl, xs;
   for (size_t b = 0; b < blocks.size(); b++) {
     DevBlock &B = *blocks[b];
     TimedLaunch t(tm, s, KC_BLOCK_ROWCACHE, 12.0 * B.nnz + 8.0 * B.B * (K + 2));
     launch_block_score_cache(s, B, Vt, w, K, KS);
-    blk.map[b] = B.map.p;
-    blk.bq[b] = B.bq.p;
-    blk.bl[b] = B.bl.p;
-    blk.bs[b] = B.bs.p;
+    if (b < (size_t)MAX_BLOCKS) {
+      blk.map[b] = B.map.p;
+      blk.bq[b] = B.bq.p;
+      blk.bl[b] = B.bl.p;
+      blk.bs[b] = B.bs.p;
+    } else {
+      xm.push_back(B.map.p);
+      xq.push_back(B.bq.p);
+      xl.push_back(B.bl.p);
+      xs.push_back(B.bs.p);
+    }
+  }
+  if (!xm.empty()) {  // (more than MAX_BLOCKS blocks: their pointers through device arrays kept by the first of them)
+    BlockOverflow &ov = blocks[MAX_BLOCKS]->ov;
+    MFM_HIP_CHECK(hipStreamSynchronize(s));  // (a pass that reads the arrays may be in flight)
+    BlockOverflow::put_sync(ov.map, xm);
+    BlockOverflow::put_sync(ov.p0, xq);
+    BlockOverflow::put_sync(ov.p1, xl);
+    BlockOverflow::put_sync(ov.p2, xs);
+    blk.xmap = ov.map.p;
+    blk.xbq = ov.p0.p;
+    blk.xbl = ov.p1.p;
+    blk.xbs = ov.p2.p;
   }
   TimedLaunch t(tm, s, KC_UPDATE_E,
                 12.0 * X.nnz + 16.0 * X.rows + 8.0 * D * (K + 1) + (4.0 + 8.0 * (K + 2)) * X.rows * blk.n_blocks);
@@ -603,7 +644,6 @@ int mfm_add_block(mfm_ctx *ctx, int64_t B, int64_t Db, const int64_t *indptr, co
                   const int64_t *original_to_block) {
   MFM_TRY(ctx)
   if (ctx->finalized) throw Error(MFM_ERR_RUNTIME, "design already finalized");
-  if ((int)ctx->hblocks.size() >= MAX_BLOCKS) throw Error(MFM_ERR_INVALID, "too many relation blocks (max 16)");
   mfm_ctx::HostBlock hb;
   hb.X = make_host_csr(B, Db, indptr, indices, data);
   int64_t N = ctx->hX.rows;

@@ -2521,12 +2521,22 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_step(SweepArgs a, ChainBatch B
 }
 
 // ---- q-cache build: q = X v_f (+ block contributions)  (FMTrainer.hpp:320-340), CSR SpMV --------
+// The first MAX_BLOCKS relation blocks travel in the kernel arguments; a design with more (BaseFMTrainer.hpp:58-68 takes any
+// vector of blocks) passes the rest through device arrays (x*: index b - MAX_BLOCKS).
 constexpr int MAX_BLOCKS = 16;
 struct BlockGatherArgs {
   int n_blocks;
   const int32_t *map[MAX_BLOCKS];
   const double *rec[MAX_BLOCKS];
   int stride[MAX_BLOCKS];  // doubles between two block rows' q_B in rec[b]: BLOCK_REC (the 64-byte records) or 1 (a compact copy)
+  const int32_t *const *xmap;
+  const double *const *xrec;
+  const int *xstride;
+  __device__ __forceinline__ double gather(int bi, int64_t i) const {
+    if (bi < MAX_BLOCKS) return rec[bi][(int64_t)map[bi][i] * stride[bi]];
+    const int x = bi - MAX_BLOCKS;
+    return xrec[x][(int64_t)xmap[x][i] * xstride[x]];
+  }
 };
 
 // thread per row: the right shape for one-hot / few-nnz rows (coalesced over consecutive rows).
@@ -2551,7 +2561,7 @@ __global__ __launch_bounds__(WG) void k_qbuild_rows(const int32_t *__restrict__ 
   }
   double s = 0.0;
   for (int64_t p = b; p < e; p++) s += (UNIT ? 1.0 : val[p]) * vf[colidx[p]];
-  for (int bi = 0; bi < blk.n_blocks; bi++) s += blk.rec[bi][(int64_t)blk.map[bi][i] * blk.stride[bi]];  // :335-337
+  for (int bi = 0; bi < blk.n_blocks; bi++) s += blk.gather(bi, i);  // :335-337
   if (map_prev) {
     // the re-sync the last block of the PREVIOUS factor still owes (FMTrainer.hpp:473-480; its (q_B, q_S) of that factor were
     // saved before the row caches were rebuilt): the residual term uses the old q, which this pass then overwrites
@@ -2577,7 +2587,7 @@ __global__ __launch_bounds__(WG) void k_qbuild_wave(const int32_t *__restrict__ 
   for (int32_t p = b + lane; p < e; p += WAVE) s += val[p] * vf[colidx[p]];
   s = wave_allreduce_sum(s);
   if (lane == 0) {
-    for (int bi = 0; bi < blk.n_blocks; bi++) s += blk.rec[bi][(int64_t)blk.map[bi][i] * blk.stride[bi]];
+    for (int bi = 0; bi < blk.n_blocks; bi++) s += blk.gather(bi, i);
     eq[i].y = s;
   }
 }
@@ -2594,6 +2604,9 @@ struct BlockScoreArgs {
   const double *bq[MAX_BLOCKS];  // [B][KS]
   const double *bl[MAX_BLOCKS];  // [B]
   const double *bs[MAX_BLOCKS];  // [B]
+  // blocks MAX_BLOCKS ..: device arrays, index b - MAX_BLOCKS
+  const int32_t *const *xmap;
+  const double *const *xbq, *const *xbl, *const *xbs;
 };
 
 // OUT_MODE 0: eq[t].x = score - y[t] (y may be null => score)   1: out[t] = score
@@ -2665,9 +2678,12 @@ __global__ __launch_bounds__(WG) void k_score(const int32_t *__restrict__ rowptr
     const int64_t t = t0 + u;
     if (t < N) {
       for (int bi = 0; bi < blk.n_blocks; bi++) {
-        const int64_t i = blk.map[bi][t];
-        if (lig == 0) lin[u] += blk.bl[bi][i];
-        const double2 *row = (const double2 *)(blk.bq[bi] + i * KS);
+        const bool in_args = bi < MAX_BLOCKS;
+        const int bx = in_args ? 0 : bi - MAX_BLOCKS;
+        const int64_t i = in_args ? blk.map[bi][t] : blk.xmap[bx][t];
+        const double *bqp = in_args ? blk.bq[bi] : blk.xbq[bx];
+        if (lig == 0) lin[u] += in_args ? blk.bl[bi][i] : blk.xbl[bx][i];
+        const double2 *row = (const double2 *)(bqp + i * KS);
 #pragma unroll
         for (int s = 0; s < SPL; s++) {
           const int pr = lig + s * GS;
@@ -2677,7 +2693,7 @@ __global__ __launch_bounds__(WG) void k_score(const int32_t *__restrict__ rowptr
             a[u][s].y += v.y;
           }
         }
-        if (lig == 0) b[u] += blk.bs[bi][i];
+        if (lig == 0) b[u] += in_args ? blk.bs[bi][i] : blk.xbs[bx][i];
       }
     }
   }

@@ -426,7 +426,6 @@ int mfm_design_create(int device, int64_t N, int64_t D0, const int64_t *indptr, 
 int mfm_design_add_block(mfm_design *d, int64_t B, int64_t Db, const int64_t *indptr, const int32_t *indices,
                          const double *data, const int64_t *original_to_block) {
   MFM_TRY(d)
-  if ((int)d->blocks.size() >= MAX_BLOCKS) throw Error(MFM_ERR_INVALID, "too many relation blocks (max 16)");
   HostCsr X = make_host_csr(B, Db, indptr, indices, data);
   std::vector<int32_t> m32((size_t)d->N);
   for (int64_t t = 0; t < d->N; t++) {

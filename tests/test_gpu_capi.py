@@ -596,6 +596,36 @@ def test_store_prediction_in_one_pass_over_the_rows(oracle, capi, monkeypatch, K
     assert got[2].shape == (5003, 4) and np.allclose(got[2].sum(axis=1), 1.0)
 
 
+def test_more_than_sixteen_relation_blocks(oracle, capi):
+    # BaseFMTrainer.hpp:58-68 takes any vector of relation blocks; the first 16 travel in the kernel arguments of the q-cache
+    # build and of the scorer, the rest through device arrays: 19 small blocks against the oracle (two full iterations) and
+    # against the oracle's scorer through a prediction design
+    rng = np.random.default_rng(12)
+    n, n_blocks, K = 2500, 19, 3
+    main = sps.csr_matrix(rng.normal(size=(n, 2)))
+    blocks, shapes = [], [2]
+    for b in range(n_blocks):
+        rows_b = 15 + b
+        B = sps.hstack([sps.identity(rows_b), sps.csr_matrix(rng.normal(size=(rows_b, 1)))]).tocsr()
+        blocks.append((rng.integers(0, rows_b, size=n), B))
+        shapes.append(B.shape[1])
+    y = rng.normal(size=n)
+    gi = ds.group_index_from_shapes(shapes)
+    t, c, _ = _pair(oracle, capi, main, y, gi, K, blocks=blocks)
+    drv = CapiGibbs(c, t.clone(), n, gi)
+    for it in range(2):
+        t.step()
+        drv.step()
+    w0, w, V = t.fm()
+    gw0, gw, gV = c.get_state()
+    np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-7, atol=1e-8)
+    dev = capi.Design(main, blocks)
+    got = dev.predict([(w0, w, V)], 0, None)
+    np.testing.assert_allclose(got, oracle.OracleDesign(main, blocks).predict_score(w0, w, V), rtol=1e-10, atol=1e-10)
+
+
 def test_error_paths(capi):
     X, y = ds.toy()
     with pytest.raises(RuntimeError, match="index mapping points to non-existing row"):

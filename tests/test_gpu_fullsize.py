@@ -71,3 +71,61 @@ def test_full_size_invariants(capi, oracle, design):
     for it in range(2):
         drv2.step()
     assert np.array_equal(c2.get_state()[2], v_first)
+
+
+def test_config5_full_size_n50m_rank64(capi, oracle):
+    """BASELINE configs[4] at its OWN size: N = 50 M rows (nnz = 100 M), two one-hot fields + 4 relation blocks, rank 64.
+    The CPU oracle needs ~2 minutes per iteration there, so the size-independent properties are checked:
+    * regression twin (the same design, the targets taken as real numbers): after one full update_all the incrementally
+      maintained residual == the residual recomputed from scratch (every update of every row by the (2 + 4 blocks) x 65
+      sweeps is accounted for), == the closed-form FM score minus y on 50 000 sampled rows;
+    * the ordered-probit task itself (5 classes, MyFMOrderedProbit's trainer): two runs of two iterations agree bit for
+      bit, the cutpoints are ordered and finite, the Metropolis step ran."""
+    import scipy.sparse as sps
+
+    from myfm_amd import _myfm
+
+    K = 64
+    main, blocks, y, shapes = ds.config5_like(1.0, ordered=True)
+    N = main.shape[0]
+    assert N == 50_000_000 and main.nnz == 100_000_000 and len(blocks) == 4
+    gi = ds.group_index_from_shapes(shapes)
+    # ---- regression twin
+    c = capi.Context(main, y, blocks, rank=K, group_index=gi)
+    rng = np.random.default_rng(0)
+    D = c.D
+    c.set_state(0.1, rng.normal(size=D) * 0.1, rng.normal(size=(D, K)) * 0.1)
+    c.update_e_regression()
+    drv = CapiGibbs(c, None, N, gi)
+    t = oracle.OracleTrainer(*ds.toy(), rank=2, seed=7)  # only a seeded mt19937 state to hand to the device
+    drv.use_device_rng(*t.rng_state())
+    seen = {}
+    drv.step(before_update_e=lambda: seen.update(e=c.get_e()))
+    e_new = c.get_e()
+    assert np.abs(seen["e"] - e_new).max() < 1e-8 * max(1.0, np.abs(e_new).max())
+    w0, w, V = c.get_state()
+    assert np.isfinite(V).all()
+    rows = np.sort(np.random.default_rng(1).choice(N, size=50_000, replace=False))
+    X_rows = sps.hstack([main[rows]] + [B[m[rows]] for m, B in blocks]).tocsr()
+    np.testing.assert_allclose(e_new[rows], ds.fm_score(X_rows, w0, w, V) - y[rows], rtol=1e-9, atol=1e-9)
+    del c, drv, seen, e_new
+    # ---- the ordered-probit task, twice
+    rels = [_myfm.RelationBlock(np.asarray(m, dtype=np.int64), B) for m, B in blocks]
+    b = _myfm.ConfigBuilder()
+    b.set_alpha_0(1.0).set_beta_0(1.0).set_gamma_0(1.0).set_mu_0(0.0).set_reg_0(1.0)
+    b.set_group_index([int(g) for g in gi]).set_n_iter(2).set_n_kept_samples(1)
+    b.set_task_type(_myfm.TaskType.ORDERED)
+    b.set_cutpoint_groups([(5, np.arange(N))])
+    cfg = b.build()
+    runs = []
+    for rep in range(2):
+        predictor, history = _myfm.create_train_fm(K, 0.1, main, rels, y, 42, cfg, lambda *a: False)
+        fm = predictor.samples[-1]
+        runs.append((np.array(fm.V), np.array(fm.w), fm.w0, np.array(fm.cutpoints[0])))
+        assert len(history.hypers) == 2
+        del predictor
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2]
+    assert np.array_equal(runs[0][3], runs[1][3])
+    cp = runs[0][3]
+    assert cp.shape == (4,) and np.isfinite(cp).all() and np.all(np.diff(cp) > 0)
+    assert np.isfinite(runs[0][0]).all()
