@@ -143,6 +143,9 @@ struct mfm_ctx {
     DevBuf<int32_t> rows;  // empty => all rows
   };
   std::vector<std::unique_ptr<OGroup>> ogroups;
+  int opartial_cmax = 0;  // classes the partial-sum buffer is laid out for
+  DevBuf<double> oacc;    // per-thread accumulators of k_oprobit_eval beyond OPROBIT_LDS_CLASS classes
+
   DevBuf<double> opartial;
 
   ~mfm_ctx() {

@@ -119,7 +119,7 @@ __device__ __forceinline__ double d_erfcx(double x) {
   return 2 * exp(x * x) - d_erfcx_pos(-x);
 }
 
-constexpr int OPROBIT_MAX_CLASS = 32;
+constexpr int OPROBIT_LDS_CLASS = 32;  // up to here the per-thread accumulators live in LDS; beyond, in global memory
 constexpr int OPROBIT_SLOTS = 6;  // ll, d_hi, d_lo, h_hi, h_lo, h_off per label
 constexpr int OPROBIT_BLOCKS = 512;
 
@@ -131,13 +131,16 @@ constexpr int OPROBIT_BLOCKS = 512;
 // over the threads in thread order by thread i. blockDim.x = 256 / 128 / 64 for n_class <= 5 / 10 / 32 (dynamic
 // LDS n_class * 6 * blockDim.x doubles). The kernel is bound by the fp64 erf / erfcx / exp / log chains (~550
 // instructions per row), not by the accumulation (a wave-level reduction per label measured 2x slower).
+// More than OPROBIT_LDS_CLASS classes (OProbitSampler.hpp:36-46 has no bound): the same private accumulators, in global
+// memory (gacc: [blocks][n_class * 6][blockDim.x], zeroed by the kernel itself).
 __global__ __launch_bounds__(WG) void k_oprobit_eval(const double2 *__restrict__ eq, const double *__restrict__ y,
                                                      const int32_t *__restrict__ rows, int64_t n_rows, int n_class,
                                                      const double *__restrict__ gamma, int want_h,
-                                                     double *__restrict__ partial) {
-  extern __shared__ double acc[];  // [n_class * OPROBIT_SLOTS][blockDim.x]
-  __shared__ double gam[OPROBIT_MAX_CLASS];
+                                                     double *__restrict__ partial, double *__restrict__ gacc) {
+  extern __shared__ double oprobit_lds[];  // gam[n_class rounded up to even], then [n_class * OPROBIT_SLOTS][blockDim.x]
+  double *gam = oprobit_lds;
   const int NT = blockDim.x, tid = threadIdx.x;
+  double *acc = gacc ? gacc + (size_t)blockIdx.x * n_class * OPROBIT_SLOTS * NT : oprobit_lds + ((n_class + 1) & ~1);
   for (int i = 0; i < n_class * OPROBIT_SLOTS; i++) acc[i * NT + tid] = 0.0;
   for (int i = tid; i < n_class - 1; i += NT) gam[i] = gamma[i];
   __syncthreads();
@@ -329,8 +332,7 @@ int mfm_update_e_classification(mfm_ctx *ctx, uint64_t seed, uint64_t draw_index
 int mfm_oprobit_add_group(mfm_ctx *ctx, int32_t n_class, const int64_t *rows, int64_t n_rows, int32_t *group) {
   MFM_TRY(ctx)
   ctx->need_final();
-  if (n_class < 2 || n_class > OPROBIT_MAX_CLASS)
-    throw Error(MFM_ERR_INVALID, "ordered probit supports 2.." + std::to_string(OPROBIT_MAX_CLASS) + " classes");
+  if (n_class < 2) throw Error(MFM_ERR_INVALID, "ordered probit needs at least 2 classes");
   std::unique_ptr<mfm_ctx::OGroup> g(new mfm_ctx::OGroup());
   g->n_class = n_class;
   if (rows) {
@@ -346,7 +348,16 @@ int mfm_oprobit_add_group(mfm_ctx *ctx, int32_t n_class, const int64_t *rows, in
   }
   *group = (int32_t)ctx->ogroups.size();
   ctx->ogroups.push_back(std::move(g));
-  if (ctx->opartial.n == 0) ctx->opartial.alloc((size_t)OPROBIT_BLOCKS * OPROBIT_MAX_CLASS * OPROBIT_SLOTS + OPROBIT_MAX_CLASS);
+  {  // partial sums per block + the staging copy of the cutpoints, sized for the largest group
+    int cmax = 0;
+    for (auto &og : ctx->ogroups) cmax = std::max(cmax, og->n_class);
+    const size_t need = (size_t)OPROBIT_BLOCKS * cmax * OPROBIT_SLOTS + cmax;
+    if (ctx->opartial.n < need) {
+      MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      ctx->opartial.alloc(need);
+    }
+    ctx->opartial_cmax = cmax;
+  }
   MFM_CATCH(ctx)
 }
 
@@ -358,22 +369,28 @@ int mfm_oprobit_eval(mfm_ctx *ctx, int32_t group, const double *gamma, double *l
   mfm_ctx::OGroup &g = *ctx->ogroups[group];
   hipStream_t s = ctx->stream;
   const int C = g.n_class, m = C - 1;
-  double *dgam = ctx->opartial.p + (size_t)OPROBIT_BLOCKS * OPROBIT_MAX_CLASS * OPROBIT_SLOTS;
+  double *dgam = ctx->opartial.p + (size_t)OPROBIT_BLOCKS * ctx->opartial_cmax * OPROBIT_SLOTS;
   ctx->ring.upload(dgam, gamma, (size_t)m * sizeof(double), s);
   const int nt = C <= 5 ? 256 : (C <= 10 ? 128 : 64);
-  const size_t lds = (size_t)C * OPROBIT_SLOTS * nt * sizeof(double);
+  const bool in_lds = C <= OPROBIT_LDS_CLASS;
+  const size_t lds = ((size_t)((C + 1) & ~1) + (in_lds ? (size_t)C * OPROBIT_SLOTS * nt : 0)) * sizeof(double);
+  const int nb_cap = in_lds ? OPROBIT_BLOCKS : 128;  // (global accumulators: 3 KB per class and block)
+  if (!in_lds) {
+    const size_t need = (size_t)nb_cap * C * OPROBIT_SLOTS * nt;
+    if (ctx->oacc.n < need) ctx->oacc.alloc(need);
+  }
   {
     static DeviceOnce raised;
     if (raised.need() && lds > 64 * 1024) {
-      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_oprobit_eval, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_oprobit_eval, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
       raised.mark();
     }
   }
-  const int nb = (int)std::min<int64_t>(OPROBIT_BLOCKS, std::max<int64_t>(1, cdiv(g.n_rows, nt)));
+  const int nb = (int)std::min<int64_t>(nb_cap, std::max<int64_t>(1, cdiv(g.n_rows, nt)));
   {
     TimedLaunch t(ctx->timing, s, KC_OPROBIT_EVAL, 16.0 * g.n_rows);
     hipLaunchKernelGGL(k_oprobit_eval, dim3(nb), dim3(nt), lds, s, ctx->eq.p, ctx->y.p, g.rows.p, g.n_rows, C, dgam,
-                       H ? 1 : 0, ctx->opartial.p);
+                       H ? 1 : 0, ctx->opartial.p, in_lds ? (double *)nullptr : ctx->oacc.p);
     MFM_HIP_CHECK(hipGetLastError());
   }
   const size_t cnt = (size_t)nb * C * OPROBIT_SLOTS;
@@ -418,7 +435,7 @@ int mfm_oprobit_sample_z(mfm_ctx *ctx, int32_t group, const double *gamma, uint6
   if (group < 0 || group >= (int)ctx->ogroups.size()) throw Error(MFM_ERR_INVALID, "bad cutpoint group");
   mfm_ctx::OGroup &g = *ctx->ogroups[group];
   hipStream_t s = ctx->stream;
-  double *dgam = ctx->opartial.p + (size_t)OPROBIT_BLOCKS * OPROBIT_MAX_CLASS * OPROBIT_SLOTS;
+  double *dgam = ctx->opartial.p + (size_t)OPROBIT_BLOCKS * ctx->opartial_cmax * OPROBIT_SLOTS;
   ctx->ring.upload(dgam, gamma, (size_t)(g.n_class - 1) * sizeof(double), s);
   if (g.n_rows) {
     TimedLaunch t(ctx->timing, s, KC_TN_SAMPLE, 24.0 * g.n_rows);

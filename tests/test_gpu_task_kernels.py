@@ -54,7 +54,8 @@ def _ordered_problem(n, n_class, seed):
     return X, y, scores
 
 
-@pytest.mark.parametrize("n_class", [2, 3, 5, 9, 17])
+# (32 classes: the last count with the accumulators in LDS; 33 and 70: in global memory -- OProbitSampler.hpp:36-46 has no bound)
+@pytest.mark.parametrize("n_class", [2, 3, 5, 9, 17, 32, 33, 70])
 def test_oprobit_eval_matches_oracle(capi, oracle, n_class):
     n = 20000
     X, y, scores = _ordered_problem(n, n_class, seed=n_class)
