@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <hipcub/hipcub.hpp>
@@ -851,15 +852,46 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   int64_t off = c->D0;
   int max_chunks = std::max(c->plan_V.max_hchunks, c->plan_W.max_hchunks);
   int max_long = std::max(c->plan_V.max_huge, c->plan_W.max_huge);
-  for (auto &hb : c->hblocks) {
-    std::unique_ptr<DevBlock> B(new DevBlock());
-    B->col_off = off;
-    B->build(hb.X, hb.map, c->N, c->KS, c->stream);
-    off += B->Db;
-    max_chunks = std::max({max_chunks, B->plan_V.max_hchunks, B->plan_W.max_hchunks});
-    max_long = std::max({max_long, B->plan_V.max_huge, B->plan_W.max_huge});
-    B->allreduce_fields(c->stream, c->comm, 6, 1);  // cardinality counts the rows of ALL ranks (definitions.hpp:65-68)
-    c->blocks.push_back(std::move(B));
+  {
+    // the blocks' device structures (transpose, plans, inverse maps: O(N) host passes each) are independent: host threads
+    std::vector<std::unique_ptr<DevBlock>> built(c->hblocks.size());
+    std::vector<std::exception_ptr> errs(c->hblocks.size());
+    std::vector<int64_t> offs(c->hblocks.size());
+    for (size_t b = 0; b < c->hblocks.size(); b++) {
+      offs[b] = off;
+      off += c->hblocks[b].X.cols;
+    }
+    auto build_one = [&](size_t b) {
+      try {
+        MFM_HIP_CHECK(hipSetDevice(c->device));
+        built[b].reset(new DevBlock());
+        built[b]->col_off = offs[b];
+        built[b]->build(c->hblocks[b].X, c->hblocks[b].map, c->N, c->KS, c->stream);
+      } catch (...) {
+        errs[b] = std::current_exception();
+      }
+    };
+    {
+      (void)coop_capacity<PBlockV>();  // (function-local caches: filled before the threads start)
+      (void)coop_capacity<PBlockW>();
+      std::vector<std::thread> pool;
+      const bool par = c->hblocks.size() > 1 && !std::getenv("MFM_SERIAL_BLOCK_BUILD");
+      for (size_t b = 0; b < c->hblocks.size(); b++) {
+        if (par && b + 1 < c->hblocks.size())
+          pool.emplace_back(build_one, b);
+        else
+          build_one(b);
+      }
+      for (auto &t : pool) t.join();
+    }
+    for (size_t b = 0; b < built.size(); b++) {
+      if (errs[b]) std::rethrow_exception(errs[b]);
+      std::unique_ptr<DevBlock> &B = built[b];
+      max_chunks = std::max({max_chunks, B->plan_V.max_hchunks, B->plan_W.max_hchunks});
+      max_long = std::max({max_long, B->plan_V.max_huge, B->plan_W.max_huge});
+      B->allreduce_fields(c->stream, c->comm, 6, 1);  // cardinality counts the rows of ALL ranks (definitions.hpp:65-68)
+      c->blocks.push_back(std::move(B));
+    }
   }
   c->ls.reserve(std::max(max_chunks, 1), std::max(max_long, 1));
   // state + scratch
