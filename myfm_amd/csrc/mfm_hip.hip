@@ -101,6 +101,7 @@ struct mfm_ctx {
     DevBuf<uint32_t> jump;  // jump-ahead polynomials of the parallel generator (mfm_mtjump.hpp)
     int par_wgs = 1;        // workgroups of k_mt_generate_par (1: the serial generator)
     int par_blocks = 0;     // ... and the blocks each of them generates (chosen at mfm_finalize from the problem size)
+    DevBuf<uint32_t> starts;  // [par_wgs][624] the block before each workgroup's first one (jump launch -> generation launch)
     uint64_t mask = 0, need = 0;
     DevBuf<RngOp> ops;
     int n_ops = 0;
@@ -1530,7 +1531,10 @@ int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops) {
         r.jump.upload(tab);
         r.state_next.alloc(1);
         r.par_wgs = wgs;
-        MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mt_generate_par, hipFuncAttributeMaxDynamicSharedMemorySize,
+        r.starts.alloc((size_t)wgs * MT_N);
+        MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mt_generate_par<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)((MT_JUMP_SPAN * MT_N + 2 * (MT_N + 1)) * sizeof(uint32_t))));
+        MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mt_generate_par<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)((MT_JUMP_SPAN * MT_N + 2 * (MT_N + 1)) * sizeof(uint32_t))));
       }
     }
@@ -1573,9 +1577,17 @@ int mfm_rng_prefetch(mfm_ctx *ctx) {
   MFM_HIP_CHECK(hipStreamWaitEvent(s, r.gate, 0));
   if (sl.free_valid) MFM_HIP_CHECK(hipStreamWaitEvent(s, sl.free_ev, 0));
   if (r.par_wgs > 1) {
-    hipLaunchKernelGGL(k_mt_generate_par, dim3(r.par_wgs), dim3(MT_GEN_THREADS),
-                       (MT_JUMP_SPAN * MT_N + 2 * (MT_N + 1)) * sizeof(uint32_t), s, r.state.p, r.state_next.p, r.raw.p, r.mask,
-                       r.need, r.jump.p, r.par_blocks);
+    if (std::getenv("MFM_RNG_FUSED_JUMP")) {
+      hipLaunchKernelGGL(k_mt_generate_par<0>, dim3(r.par_wgs), dim3(MT_GEN_THREADS),
+                         (MT_JUMP_SPAN * MT_N + 2 * (MT_N + 1)) * sizeof(uint32_t), s, r.state.p, r.state_next.p, r.raw.p, r.mask,
+                         r.need, r.jump.p, r.par_blocks, (uint32_t *)nullptr);
+    } else {
+      hipLaunchKernelGGL(k_mt_generate_par<1>, dim3(r.par_wgs), dim3(MT_GEN_THREADS),
+                         (MT_JUMP_SPAN * MT_N + 2 * (MT_N + 1)) * sizeof(uint32_t), s, r.state.p, r.state_next.p, r.raw.p, r.mask,
+                         r.need, r.jump.p, r.par_blocks, r.starts.p);
+      hipLaunchKernelGGL(k_mt_generate_par<2>, dim3(r.par_wgs), dim3(MT_GEN_THREADS), 2 * (MT_N + 1) * sizeof(uint32_t), s,
+                         r.state.p, r.state_next.p, r.raw.p, r.mask, r.need, r.jump.p, r.par_blocks, r.starts.p);
+    }
     hipLaunchKernelGGL(k_mt_commit, dim3(1), dim3(MT_GEN_THREADS), 0, s, r.state.p, r.state_next.p);
   } else {
     hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(MT_GEN_THREADS), 0, s, r.state.p, r.raw.p, r.mask, r.need);

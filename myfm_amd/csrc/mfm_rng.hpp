@@ -153,12 +153,18 @@ static inline int mt_par_blocks_for(int64_t blocks) {
 }
 constexpr int MT_JUMP_SPAN = 33;  // blocks covering 19937 + 624 words
 
+// PHASE 0: jump + generation in one launch. PHASE 1: the jump only -- workgroup p leaves the block before its first one in
+// starts[p] -- and PHASE 2: the generation from those blocks. The jump needs 87 KB of LDS, the generation 5 KB: as two
+// launches the ~0.15 ms of generation do not take the LDS of 169 CUs away from the scorer running beside them (update_e
+// ran 0.5 instead of 0.3 ms next to the fused launch).
+template <int PHASE>
 __global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate_par(const RngState *__restrict__ st, RngState *__restrict__ st_next,
                                                                     uint32_t *__restrict__ raw, uint64_t mask, uint64_t need,
-                                                                    const uint32_t *__restrict__ jump_tab, int par_blocks) {
-  extern __shared__ uint32_t lds_seq[];  // [MT_JUMP_SPAN * 624] sequence, then 2 x 625 generation buffers
+                                                                    const uint32_t *__restrict__ jump_tab, int par_blocks,
+                                                                    uint32_t *__restrict__ starts) {
+  extern __shared__ uint32_t lds_seq[];  // [MT_JUMP_SPAN * 624] sequence (PHASE 0, 1), then 2 x 625 generation buffers
   uint32_t *seq = lds_seq;
-  uint32_t(*buf)[MT_N + 1] = (uint32_t(*)[MT_N + 1])(lds_seq + MT_JUMP_SPAN * MT_N);
+  uint32_t(*buf)[MT_N + 1] = (uint32_t(*)[MT_N + 1])(lds_seq + (PHASE == 2 ? 0 : MT_JUMP_SPAN * MT_N));
   const int t = threadIdx.x, p = blockIdx.x;
   __builtin_amdgcn_s_setprio(3);
   int pos = st->mt_pos;
@@ -167,14 +173,14 @@ __global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate_par(const RngSta
   if (t < MT_N) buf[0][t] = st->mt[t];
   __syncthreads();
   if (pos < MT_N && p_gen < target) {  // the not yet emitted tail of the current block
-    if (p == 0 && t >= pos && t < MT_N) raw[(p_gen + (uint64_t)(t - pos)) & mask] = buf[0][t];
+    if (PHASE != 1 && p == 0 && t >= pos && t < MT_N) raw[(p_gen + (uint64_t)(t - pos)) & mask] = buf[0][t];
     p_gen += (uint64_t)(MT_N - pos);
     pos = MT_N;
   }
   const int64_t nblk = p_gen < target ? (int64_t)((target - p_gen + MT_N - 1) / MT_N) : 0;
   const int64_t b0 = (int64_t)p * par_blocks, b1 = min(nblk, b0 + par_blocks);
   if (nblk == 0) {  // nothing to generate: only the position may have moved
-    if (p == 0) {
+    if (PHASE != 1 && p == 0) {
       if (t < MT_N) st_next->mt[t] = buf[0][t];
       if (t == 0) {
         st_next->mt_pos = pos;
@@ -204,7 +210,13 @@ __global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate_par(const RngSta
     return v;
   };
   int cur = 0;
-  if (p > 0) {
+  if (PHASE == 2) {
+    if (p > 0) {
+      __syncthreads();
+      if (t < MT_N) buf[0][t] = starts[(size_t)p * MT_N + t];
+      __syncthreads();
+    }
+  } else if (p > 0) {
     // blocks r = 0 .. 32 after the stored state (all of them generated words: the relation holds for every bit)
     step(buf[0], seq);
     __syncthreads();
@@ -236,9 +248,11 @@ __global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate_par(const RngSta
         }
       }
       buf[0][t] = y;
+      if (PHASE == 1) starts[(size_t)p * MT_N + t] = y;
     }
     __syncthreads();
   }
+  if (PHASE == 1) return;
   const uint32_t m32 = (uint32_t)mask;
   uint32_t off = (uint32_t)((p_gen + (uint64_t)b0 * MT_N) & mask);
   for (int64_t b = b0; b < b1; b++) {
