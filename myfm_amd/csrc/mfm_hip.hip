@@ -99,6 +99,7 @@ struct mfm_ctx {
     DevBuf<RngState> state, state_next;
     DevBuf<uint32_t> raw;
     DevBuf<uint32_t> jump;  // jump-ahead polynomials of the parallel generator (mfm_mtjump.hpp)
+    uint64_t need_gen = 0;  // outputs the parallel generator keeps ahead of the consumer (several iterations of `need`)
     int par_wgs = 1;        // workgroups of k_mt_generate_par (1: the serial generator)
     int par_blocks = 0;     // ... and the blocks each of them generates (chosen at mfm_finalize from the problem size)
     DevBuf<uint32_t> starts;  // [par_wgs][624] the block before each workgroup's first one (jump launch -> generation launch)
@@ -698,8 +699,9 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     const double need = normals * (16.0 / 3.14159265358979) * 1.02 + 6.0 * 2.4 * std::sqrt(normals + 1.0) + 4096.0 * (2 + 2.0 * c->G * (c->K + 1)) + 2e6;
     const int64_t blocks = (int64_t)(need / MT_N) + 2;
     if (blocks > MT_PAR_BLOCKS) {
-      c->rng.par_blocks = mt_par_blocks_for(blocks);
-      mtjump::JumpCache::inst().prefetch(c->rng.par_blocks, (int)((blocks + c->rng.par_blocks - 1) / c->rng.par_blocks) + 1);
+      const int64_t gblocks = blocks * mt_gen_batch();  // (the generator is asked for several iterations at a time)
+      c->rng.par_blocks = mt_par_blocks_for(gblocks);
+      mtjump::JumpCache::inst().prefetch(c->rng.par_blocks, (int)((gblocks + c->rng.par_blocks - 1) / c->rng.par_blocks) + 1);
     }
   }
   const bool tlog = std::getenv("MFM_SETUP_TIMING") != nullptr;
@@ -1521,9 +1523,12 @@ int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops) {
       r.need += (uint64_t)(4 * (mfm_ctx::RngEngine::attempts_for(o.count) - (int64_t)((double)o.count * 1.2732)));
   // more than one workgroup's worth of blocks per iteration: generate in parallel with jump-ahead
   r.par_wgs = 1;
+  r.need_gen = r.need;
   {
-    const int64_t blocks = (int64_t)(r.need / MT_N) + 2;
-    if (blocks > MT_PAR_BLOCKS && !std::getenv("MFM_RNG_SERIAL")) {
+    const int64_t blocks1 = (int64_t)(r.need / MT_N) + 2;
+    if (blocks1 > MT_PAR_BLOCKS && !std::getenv("MFM_RNG_SERIAL")) {
+      r.need_gen = r.need * (uint64_t)mt_gen_batch();
+      const int64_t blocks = (int64_t)(r.need_gen / MT_N) + 2;
       if (r.par_blocks <= 0) r.par_blocks = mt_par_blocks_for(blocks);
       const int wgs = (int)((blocks + r.par_blocks - 1) / r.par_blocks);
       std::vector<uint32_t> tab;
@@ -1540,7 +1545,7 @@ int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops) {
     }
   }
   uint64_t cap = 1;
-  while (cap < r.need + 2 * MT_N) cap <<= 1;
+  while (cap < r.need_gen + r.need + 2 * MT_N) cap <<= 1;
   r.raw.alloc((size_t)cap);
   r.mask = cap - 1;
   for (auto &sl : r.slot) {
@@ -1580,13 +1585,13 @@ int mfm_rng_prefetch(mfm_ctx *ctx) {
     if (std::getenv("MFM_RNG_FUSED_JUMP")) {
       hipLaunchKernelGGL(k_mt_generate_par<0>, dim3(r.par_wgs), dim3(MT_GEN_THREADS),
                          (MT_JUMP_SPAN * MT_N + 2 * (MT_N + 1)) * sizeof(uint32_t), s, r.state.p, r.state_next.p, r.raw.p, r.mask,
-                         r.need, r.jump.p, r.par_blocks, (uint32_t *)nullptr);
+                         r.need_gen, r.jump.p, r.par_blocks, (uint32_t *)nullptr, r.need);
     } else {
       hipLaunchKernelGGL(k_mt_generate_par<1>, dim3(r.par_wgs), dim3(MT_GEN_THREADS),
                          (MT_JUMP_SPAN * MT_N + 2 * (MT_N + 1)) * sizeof(uint32_t), s, r.state.p, r.state_next.p, r.raw.p, r.mask,
-                         r.need, r.jump.p, r.par_blocks, r.starts.p);
+                         r.need_gen, r.jump.p, r.par_blocks, r.starts.p, r.need);
       hipLaunchKernelGGL(k_mt_generate_par<2>, dim3(r.par_wgs), dim3(MT_GEN_THREADS), 2 * (MT_N + 1) * sizeof(uint32_t), s,
-                         r.state.p, r.state_next.p, r.raw.p, r.mask, r.need, r.jump.p, r.par_blocks, r.starts.p);
+                         r.state.p, r.state_next.p, r.raw.p, r.mask, r.need_gen, r.jump.p, r.par_blocks, r.starts.p, r.need);
     }
     hipLaunchKernelGGL(k_mt_commit, dim3(1), dim3(MT_GEN_THREADS), 0, s, r.state.p, r.state_next.p);
   } else {

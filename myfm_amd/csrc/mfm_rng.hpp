@@ -142,14 +142,18 @@ __global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate(RngState *__rest
 // x[l + i] over the set bits i of g_p -- ~10 k conflict-free LDS reads per lane, no barriers. The new state is
 // written to a staging copy (late workgroups must still see the old one) and committed by k_mt_commit.
 constexpr int MT_PAR_BLOCKS = 512;  // blocks per workgroup at most (and the request size from which the generator is parallel)
-// blocks per workgroup for a request of `blocks`. A workgroup pays ~100 us for its jump and ~1 us per block. The
-// generator can only run in the part of an iteration that is not the persistent latent sweep (update_e, the reductions, the
-// host's draws: ~0.6 ms at the ML-10M shape) and the draw program behind it is a serial chain, so its latency counts:
-// 128 blocks -- 169 workgroups, ~0.25 ms there (measured: 512 / 256 / 128 / 96 blocks -> 255 / 260 / 263 / 260 it/s).
+// blocks per workgroup for a request of `blocks`: about 170 workgroups (each takes a CU: 87 KB of LDS for its jump), between
+// 64 and 512 blocks, multiples of 16. A workgroup's jump costs ~0.45 ms whatever it generates afterwards (0.4 us per
+// block), so the generator is asked for several iterations' worth at a time (MT_GEN_BATCH): one jump per four iterations.
+constexpr int MT_GEN_BATCH = 4;
+static inline int mt_gen_batch() {
+  if (const char *e = std::getenv("MFM_RNG_GEN_BATCH")) return std::max(1, std::min(16, std::atoi(e)));
+  return MT_GEN_BATCH;
+}
 static inline int mt_par_blocks_for(int64_t blocks) {
-  (void)blocks;
   if (const char *e = std::getenv("MFM_RNG_PAR_BLOCKS")) return std::max(32, std::min(MT_PAR_BLOCKS, std::atoi(e)));
-  return 128;
+  const int64_t b = ((blocks + 169) / 170 + 15) / 16 * 16;
+  return (int)std::max<int64_t>(64, std::min<int64_t>(MT_PAR_BLOCKS, b));
 }
 constexpr int MT_JUMP_SPAN = 33;  // blocks covering 19937 + 624 words
 
@@ -161,7 +165,7 @@ template <int PHASE>
 __global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate_par(const RngState *__restrict__ st, RngState *__restrict__ st_next,
                                                                     uint32_t *__restrict__ raw, uint64_t mask, uint64_t need,
                                                                     const uint32_t *__restrict__ jump_tab, int par_blocks,
-                                                                    uint32_t *__restrict__ starts) {
+                                                                    uint32_t *__restrict__ starts, uint64_t need_min) {
   extern __shared__ uint32_t lds_seq[];  // [MT_JUMP_SPAN * 624] sequence (PHASE 0, 1), then 2 x 625 generation buffers
   uint32_t *seq = lds_seq;
   uint32_t(*buf)[MT_N + 1] = (uint32_t(*)[MT_N + 1])(lds_seq + (PHASE == 2 ? 0 : MT_JUMP_SPAN * MT_N));
@@ -169,7 +173,9 @@ __global__ __launch_bounds__(MT_GEN_THREADS) void k_mt_generate_par(const RngSta
   __builtin_amdgcn_s_setprio(3);
   int pos = st->mt_pos;
   uint64_t p_gen = st->p_gen;
-  const uint64_t target = st->p_cons + need;
+  // `need` outputs ahead of the consumer (several iterations' worth) -- unless the next iteration's `need_min` are there
+  // already: then nothing at all (the launch costs a few microseconds; every workgroup takes the same decision)
+  const uint64_t target = p_gen >= st->p_cons + need_min ? 0 : st->p_cons + need;
   if (t < MT_N) buf[0][t] = st->mt[t];
   __syncthreads();
   if (pos < MT_N && p_gen < target) {  // the not yet emitted tail of the current block
