@@ -233,13 +233,52 @@ struct Timing {
   }
 };
 
+// debugging aid (MFM_DEBUG_POISON_LDS=1): before every bracketed launch fill the whole LDS of every CU with signalling NaN
+// patterns, so that a kernel reading LDS it has not written shows up deterministically instead of only when another
+// stream's workgroup happened to leave bits there
+__global__ __launch_bounds__(1024) void k_poison_lds(uint32_t word) {
+  extern __shared__ uint32_t poison_words[];
+  for (int i = threadIdx.x; i < 160 * 256; i += 1024) poison_words[i] = word;
+  __syncthreads();
+  if (poison_words[(threadIdx.x * 37) % (160 * 256)] == 1u) __builtin_trap();  // (keeps the stores)
+}
+inline bool poison_lds(hipStream_t s, int cls, int line, bool clean = false) {  // MFM_DEBUG_POISON_LDS = a kernel class, or -1 for all;
+  static const bool on = std::getenv("MFM_DEBUG_POISON_LDS") != nullptr;  // MFM_DEBUG_POISON_LINE = one launch site
+  if (!on) return false;
+  static const int only = std::atoi(std::getenv("MFM_DEBUG_POISON_LDS"));
+  static const int only_line = std::getenv("MFM_DEBUG_POISON_LINE") ? std::atoi(std::getenv("MFM_DEBUG_POISON_LINE")) : -1;
+  if (std::getenv("MFM_DEBUG_POISON_LIST")) {
+    static std::vector<int> seen;
+    if (std::find(seen.begin(), seen.end(), cls * 100000 + line) == seen.end()) {
+      seen.push_back(cls * 100000 + line);
+      std::fprintf(stderr, "[launch site] class %d line %d\n", cls, line);
+    }
+  }
+  if (only >= 0 && only != cls) return false;
+  if (only_line >= 0 && only_line != line) return false;
+  static bool raised = false;
+  if (!raised) {
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_poison_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    raised = true;
+  }
+  static const uint32_t word =
+      std::getenv("MFM_DEBUG_POISON_WORD") ? (uint32_t)std::strtoul(std::getenv("MFM_DEBUG_POISON_WORD"), nullptr, 16) : 0x7ff4deadu;
+  hipLaunchKernelGGL(k_poison_lds, dim3(1024), dim3(1024), 160 * 1024, s, clean ? 0u : word);  // (clean: after the scope)
+  return true;
+}
+
 // RAII scope: brackets one kernel launch with events when timing is on.
 struct TimedLaunch {
   Timing &t;
   hipStream_t s;
   int cls;
   hipEvent_t a;
-  TimedLaunch(Timing &t_, hipStream_t s_, int cls_, double alg_bytes) : t(t_), s(s_), cls(cls_), a(nullptr) {
+  bool poisoned = false;
+  int site = 0;
+  TimedLaunch(Timing &t_, hipStream_t s_, int cls_, double alg_bytes, int line = __builtin_LINE())
+      : t(t_), s(s_), cls(cls_), a(nullptr) {
+    poisoned = poison_lds(s, cls_, line);
+    site = line;
     if (t.on && (t.only < 0 || t.only == cls)) {
       t.launches[cls]++;
       t.bytes[cls] += alg_bytes;
@@ -248,6 +287,7 @@ struct TimedLaunch {
     }
   }
   ~TimedLaunch() {
+    if (poisoned) poison_lds(s, cls, site, true);
     if (t.on && a) {
       hipEvent_t b = t.get_event();
       (void)hipEventRecord(b, s);

@@ -1979,7 +1979,7 @@ constexpr int CHAINB_MAXCOLS = 64;
 // One column of a hot walk (k_chain_batched phase B, k_cb_hot), by ONE wavefront over records staged in LDS: statistics of
 // the column's hot entries [hb, he), draw, update. Up to 4 x 64 entries are handled in a single round -- their slots and
 // records are loaded back to back (one LDS round trip instead of one per 64 entries), the four partial statistics
-// interleave, and the records stay in registers for the update. Lanes past the end read slot 0 with x = 0.
+// interleave, and the records stay in registers for the update. Lanes past the end read slot 0 and contribute nothing.
 template <class P>
 __device__ __forceinline__ double hot_column(const SweepArgs &a, const SweepArgs &al, const double *h_x, const int *h_slot, int hb,
                                              int he, int lane, double S1c, double S2c, double old, double lam, double mu, double z) {
@@ -2002,6 +2002,8 @@ __device__ __forceinline__ double hot_column(const SweepArgs &a, const SweepArgs
       t1[u] = 0.0;
       t2[u] = 0.0;
       ChainOps<P>::stats(hx[u], st[u], old, t1[u], t2[u]);
+      // (a batch without hot rows has staged no record at all: slot 0 is then whatever the LDS held, and 0 * NaN is NaN)
+      if (!(hb + u * WAVE + lane < he)) t1[u] = t2[u] = 0.0;
     }
     double h1 = (t1[0] + t1[1]) + (t1[2] + t1[3]), h2 = (t2[0] + t2[1]) + (t2[2] + t2[3]);
     wave_allreduce_sum2(h1, h2);
