@@ -84,6 +84,7 @@ struct mfm_ctx {
   int q_stale_factor = -1;      // >= 0: the stored q column is stale, mfm_get_q rebuilds it for this factor first
   BlockOverflow gather_overflow;       // q-cache build: pointers of the relation blocks beyond MAX_BLOCKS
   DevBuf<double> lam_w, mu_w, zw_host;  // mfm_sweep_wV: the linear sweep's hyper-parameters / host-given variates
+  bool res_fills_device = false;  // the persistent sweep takes (nearly) every CU: nothing runs beside it
   bool e_in_slots = false;      // the residual after the resident latent sweep lives in res.e_slots (slot order): every
                                 // reader of eq calls materialize_e first; update_e overwrites it and just drops the flag
   DevBuf<double> sync_mask;     // [D] 1: this rank contributes the column to the model synchronisation
@@ -939,11 +940,15 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
             !std::getenv("MFM_NO_FUSED_STATS");
   }
   // two-field unit-valued table on one GPU: the whole update_V as one persistent launch, residual resident on chip
-  if (c->soa && c->mf && c->X.unit && !c->comm.active() && !std::getenv("MFM_NO_RESIDENT")) {
+  // (small tables stay with the per-factor passes: the launch's fixed costs -- two grid barriers per sweep, census, slot-ordered
+  //  residual -- outweigh the bytes it saves; ML-100k shape: fit() 3060 it/s resident, 3950 per-factor. MFM_RES_MIN_ROWS)
+  const int64_t res_min_rows = std::getenv("MFM_RES_MIN_ROWS") ? std::atoll(std::getenv("MFM_RES_MIN_ROWS")) : ((int64_t)1 << 20);
+  if (c->soa && c->mf && c->X.unit && !c->comm.active() && c->N >= res_min_rows && !std::getenv("MFM_NO_RESIDENT")) {
     int n_cu = 0;
     MFM_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
     if (const char *e = std::getenv("MFM_RES_CUS")) n_cu = std::max(1, std::min(n_cu, std::atoi(e)));
     c->res.build(Xt_keep, c->plan_V.h_level, &c->hgroup, n_cu);
+    c->res_fills_device = c->res.ready && c->res.G > n_cu - n_cu / 4;
     if (tlog) std::fprintf(stderr, "[mfm_finalize] resident plan: %s (G=%d RV=%d RL=%d umax=%d runs=%lld lds=%zu)\n",
                            c->res.ready ? "ready" : c->res.why.c_str(), c->res.G, c->res.RV, c->res.RL, c->res.umax,
                            (long long)c->res.n_runs, c->res.lds_bytes);
@@ -1577,9 +1582,13 @@ int mfm_rng_prefetch(mfm_ctx *ctx) {
     throw Error(MFM_ERR_RUNTIME, "every random set is in use (one acquired, the others in flight): acquire the next one first");
   auto &sl = r.slot[r.produced % mfm_ctx::RngEngine::N_SLOTS];
   hipStream_t s = r.stream;
-  if (!r.gate) MFM_HIP_CHECK(hipEventCreateWithFlags(&r.gate, hipEventDisableTiming));
-  MFM_HIP_CHECK(hipEventRecord(r.gate, ctx->stream));
-  MFM_HIP_CHECK(hipStreamWaitEvent(s, r.gate, 0));
+  // (the gate only where the persistent sweep fills the device: a small table's launch leaves most CUs free, and there the
+  //  generator should run beside it -- ML-100k shape: 2700 it/s gated, 3000 not)
+  if (ctx->res.ready && ctx->res_fills_device) {
+    if (!r.gate) MFM_HIP_CHECK(hipEventCreateWithFlags(&r.gate, hipEventDisableTiming));
+    MFM_HIP_CHECK(hipEventRecord(r.gate, ctx->stream));
+    MFM_HIP_CHECK(hipStreamWaitEvent(s, r.gate, 0));
+  }
   if (sl.free_valid) MFM_HIP_CHECK(hipStreamWaitEvent(s, sl.free_ev, 0));
   if (r.par_wgs > 1) {
     if (std::getenv("MFM_RNG_FUSED_JUMP")) {

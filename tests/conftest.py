@@ -13,6 +13,9 @@ def pytest_configure(config):
     # every row-tile layout the planner packs on the device is also packed on the host and compared array by array
     # (mfm_plan.hpp build_scattered): a mismatch fails mfm_finalize of the test that built it
     os.environ.setdefault("MFM_PLAN_CHECK", "1")
+    # the persistent latent sweep (mfm_res.hpp) is the default only from 2^20 rows on; the tests' small two-field tables take it
+    # too, so that every chain test of such a table also covers it (tests that want the per-factor passes set MFM_NO_RESIDENT)
+    os.environ.setdefault("MFM_RES_MIN_ROWS", "0")
     # a fresh checkout has no built extension yet (the .so files are git-ignored): build in-tree once
     pkg = os.path.join(ROOT, "myfm_amd")
     if not any(f.startswith("_myfm.") and f.endswith(".so") for f in os.listdir(pkg)):
