@@ -230,7 +230,13 @@ def main():
     parallelism = "1 GPU"
     if not sharded:
         rels = [_myfm.RelationBlock(np.asarray(m, dtype=np.int64), B) for m, B in blocks]
-        sess = _myfm.GibbsSession(K, 0.1, X, rels, y, 42, make_config(_myfm, gi, a.steps + a.warmup + 8, 0, W["task"], N))
+        t1 = time.time()
+        cfg1 = make_config(_myfm, gi, a.steps + a.warmup + 8, 0, W["task"], N)
+        t2 = time.time()
+        sess = _myfm.GibbsSession(K, 0.1, X, rels, y, 42, cfg1)
+        if os.environ.get("MFM_SETUP_TIMING"):
+            print("[bench] RelationBlock %.3f s, config %.3f s, GibbsSession %.3f s" % (t1 - t0, t2 - t1, time.time() - t2),
+                  file=sys.stderr)
     else:
         from myfm_amd import distributed as mdist
 

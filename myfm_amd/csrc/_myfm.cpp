@@ -1380,13 +1380,18 @@ struct GibbsSession {
     if (n_total_rows > 0) trainer->N_total = n_total_rows;
     trainer->row_offset = row_offset;
     trainer->stream_ptr = stream;
+    SetupLap lap("GibbsSession");
     fm = trainer->create_FM((int)n_factor, init_std);
     hyper = trainer->create_Hyper((size_t)fm.n_factors);
+    lap("create_FM / create_Hyper");
     trainer->build_device(fm.n_factors);
+    lap("build_device (set_main, blocks, finalize)");
     trainer->upload(fm);
     trainer->initialize_hyper(hyper);
     trainer->initialize_e(fm);
+    lap("state upload + initialize_e");
     trainer->start_device_rng(fm.n_factors);
+    lap("device RNG hand-over");
     fm.fetch = [this](FM &f) { this->trainer->download(f); };
     fm.live_ctx = trainer->ctx;
   }
