@@ -58,6 +58,7 @@ struct ResArgs {
   const int2 *entries;       // per slice, source-workgroup-major: {run whose partial belongs to the item, item - first item
                              // of the slice}; pads: {the zero run, 0}
   const int32_t *scols;      // item -> feature
+  const int2 *item_desc;     // item -> {feature, group}
   double *partials;          // [runs + 1][2], workgroup-major: a thread's runs are consecutive; the last stays (0, 0)
   double *dv;                // [items + 1][2]  (delta of this factor, coefficient of the next); the pad item stays (0, 0)
   double *V;                 // factor-major [K][D]
@@ -493,6 +494,32 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       }
     }
     RES_STAMP(3);
+    // everything of the item draw that does not depend on the partials is requested before the barrier: this thread's item
+    // (coefficient, variate, hyper-parameters, the next factor's coefficient) and the wave's first list entries
+    constexpr int CH = 4;
+    const int c0 = a.ent_ptr[g] >> 6, c1 = a.ent_ptr[g + 1] >> 6;
+    const int per = (c1 - c0 + NW - 1) / NW;
+    const int wb = c0 + wv * per, we = wb + per < c1 ? wb + per : c1;
+    const int i0 = a.wg_item_ptr[g], ni = a.wg_item_ptr[g + 1] - i0;
+    const bool more = f + 1 < a.f_end;
+    int ij = 0;
+    double iold = 0.0, iz = 0.0, ivn = 0.0, ilam = 0.0, imu = 0.0;
+    if (tid < ni) {
+      const int2 d = a.item_desc[i0 + tid];
+      ij = d.x;
+      iold = Vf[ij];
+      iz = zf[ij];
+      ivn = more ? a.V[(int64_t)(f + 1) * a.D + ij] : 0.0;
+      ilam = lamf[d.y];
+      imu = muf[d.y];
+    }
+    int2 en[CH];
+#pragma unroll
+    for (int k = 0; k < CH; k++) en[k] = make_int2(0, 0);
+    if (wb < we) {  // (wave-uniform)
+#pragma unroll
+      for (int k = 0; k < CH; k++) en[k] = a.entries[(int64_t)(wb + k < we ? wb + k : wb) * WAVE + lane];
+    }
     res_grid_barrier(a, rbar, ++nbar, tid, dead);
     RES_STAMP(4);
     // ---- item draw (:357-369). The workgroup draws a contiguous slice of the items. The slice's partials are listed source
@@ -501,34 +528,27 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
     //      the lanes of one instruction that hit the same item are serialised in lane order, a wave's instructions run in
     //      program order); then a thread per item adds the wave arrays in wave order (fixed association) and draws.
     if (!(a.dbg & 32)) {
-      constexpr int CH = 4;
-      const int c0 = a.ent_ptr[g] >> 6, c1 = a.ent_ptr[g + 1] >> 6;
-      const int per = (c1 - c0 + NW - 1) / NW;
-      const int wb = c0 + wv * per, we = wb + per < c1 ? wb + per : c1;
       const d2_t *part2 = (const d2_t *)a.partials;
       for (int cb = wb; cb < we; cb += CH) {
-        int2 en[CH];
-#pragma unroll
-        for (int k = 0; k < CH; k++) en[k] = a.entries[(int64_t)(cb + k < we ? cb + k : cb) * WAVE + lane];
         d2_t sv[CH];
 #pragma unroll
         for (int k = 0; k < CH; k++) sv[k] = part2[en[k].x];
+        int il[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) il[k] = en[k].y;
+        if (cb + CH < we) {  // the next entries while the partials are in flight (wave-uniform)
+#pragma unroll
+          for (int k = 0; k < CH; k++) en[k] = a.entries[(int64_t)(cb + CH + k < we ? cb + CH + k : cb + CH) * WAVE + lane];
+        }
 #pragma unroll
         for (int k = 0; k < CH; k++) {
           if (cb + k >= we) break;  // wave-uniform
-          __hip_atomic_fetch_add(&acc1[wv * U + en[k].y], sv[k][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(&acc2[wv * U + en[k].y], sv[k][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&acc1[wv * U + il[k]], sv[k][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&acc2[wv * U + il[k]], sv[k][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
       __syncthreads();
-      const int i0 = a.wg_item_ptr[g], ni = a.wg_item_ptr[g + 1] - i0;
-      const bool more = f + 1 < a.f_end;
       if (tid < ni) {
-        const int i = i0 + tid;
-        const int j = a.scols[i];
-        const int gj = a.group[j];
-        const double old = Vf[j], zj = zf[j], vn = more ? a.V[(int64_t)(f + 1) * a.D + j] : 0.0;
-        const double lj = lamf[gj], mj = muf[gj];
         double S1 = 0.0, S2 = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; w++) {
@@ -537,9 +557,9 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
           acc1[w * U + tid] = 0.0;
           acc2[w * U + tid] = 0.0;
         }
-        const double fresh = PMainV::draw(S1, S2, old, a.alpha, lj, mj, zj);
-        Vf[j] = fresh;
-        res_store2(a.dv + 2 * (int64_t)i, fresh - old, vn);
+        const double fresh = PMainV::draw(S1, S2, iold, a.alpha, ilam, imu, iz);
+        Vf[ij] = fresh;
+        res_store2(a.dv + 2 * (int64_t)(i0 + tid), fresh - iold, ivn);
       }
     }
     RES_STAMP(5);
@@ -639,7 +659,7 @@ struct ResPlan {
   DevBuf<int2> entries;
   DevBuf<uint32_t> uidw, headw;
   DevBuf<int32_t> run_item;
-  DevBuf<int2> user_desc;
+  DevBuf<int2> user_desc, item_desc;
   DevBuf<double> partials, dv, e_slots;
   DevBuf<unsigned long long> bar;
   std::string why;  // why the layout was not built (diagnostics)
@@ -981,6 +1001,14 @@ struct ResPlan {
       }
     }
     scols.upload(items);
+    {
+      std::vector<int2> h_idesc(items.size());
+      for (size_t i = 0; i < items.size(); i++) {
+        const int32_t j = items[i];
+        h_idesc[i] = make_int2(j, group_of && (size_t)j < group_of->size() ? (*group_of)[j] : 0);
+      }
+      item_desc.upload(h_idesc.data(), h_idesc.size());
+    }
     partials.alloc((size_t)2 * ((size_t)zero_run + 1));
     MFM_HIP_CHECK(hipMemset(partials.p, 0, (size_t)16 * ((size_t)zero_run + 1)));
     dv.alloc((size_t)2 * (n_items + 1));
@@ -1026,6 +1054,7 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   a.wg_run_ptr = rp.wg_run_ptr.p;
   a.wg_nruns = rp.wg_nruns.p;
   a.scols = rp.scols.p;
+  a.item_desc = rp.item_desc.p;
   a.partials = rp.partials.p;
   a.dv = rp.dv.p;
   a.V = V;
