@@ -30,6 +30,7 @@
 #include <string>
 #include <vector>
 
+#include "mfm_hostnormals.hpp"
 #include "mfm_mtjump.hpp"
 #include "myfm_hip.h"
 
@@ -375,12 +376,22 @@ struct FM {
   // FM.hpp:34-45: one persistent normal_distribution; Eigen fills the col-major V in storage order.
   void initialize_weight(int64_t n_features, Real init_std, std::mt19937 &gen) {
     initialized = false;
-    std::normal_distribution<Real> nd;
-    V.resize((size_t)n_features * n_factors);
-    for (auto &v : V) v = nd(gen) * init_std;
-    w.resize((size_t)n_features);
-    for (auto &v : w) v = nd(gen) * init_std;
-    w0 = nd(gen) * init_std;
+    const size_t nV = (size_t)n_features * n_factors, nw = (size_t)n_features;
+    if (std::getenv("MYFM_AMD_STD_INIT")) {  // the plain loop (tests hold the bulk filler against it)
+      std::normal_distribution<Real> nd;
+      V.resize(nV);
+      for (auto &v : V) v = nd(gen) * init_std;
+      w.resize(nw);
+      for (auto &v : w) v = nd(gen) * init_std;
+      w0 = nd(gen) * init_std;
+    } else {
+      // V, w, w0 are consecutive outputs of one distribution object: drawn as one sequence, then split
+      V.resize(nV + nw + 1);
+      mfm_hostnormals::fill_normals(gen, V.data(), nV + nw + 1, init_std);
+      w.assign(V.begin() + (std::ptrdiff_t)nV, V.begin() + (std::ptrdiff_t)(nV + nw));
+      w0 = V[nV + nw];
+      V.resize(nV);
+    }
     initialized = true;
   }
 
@@ -981,6 +992,7 @@ struct FMTrainer {
   void build_device(int rank) {
     if (ctx) return;
     K = rank;
+    SetupLap lap("build_device");
     int code = mfm_create(selected_device(), &ctx);
     if (code != MFM_OK) throw_code(code, mfm_global_error());
     if (stream_ptr) ck(ctx, mfm_set_stream(ctx, (void *)stream_ptr));
@@ -993,7 +1005,7 @@ struct FMTrainer {
       ck(ctx, mfm_set_shard(ctx, shard_rank, shard_world));
       ck(ctx, mfm_set_row_offset(ctx, row_offset));
     }
-    SetupLap lap("build_device");
+    lap("mfm_create (HIP runtime, stream, communicator)");
     if (!main_levels.empty()) ck(ctx, mfm_set_main_levels(ctx, main_levels.data(), (int64_t)main_levels.size()));
     ck(ctx, mfm_set_main(ctx, X_.rows, X_.cols, X_.indptr.data(), X_.indices.data(), X_.data.data(), y.data()));
     X_.release();  // (the library holds its own copy now)
@@ -1105,8 +1117,9 @@ struct FMTrainer {
               all_rows = false;
               break;
             }
-        vector<int64_t> rows(c.second.begin(), c.second.end());
-        ck(ctx, mfm_oprobit_add_group(ctx, (int32_t)c.first, all_rows ? nullptr : rows.data(), (int64_t)rows.size(), &g));
+        vector<int64_t> rows;
+        if (!all_rows) rows.assign(c.second.begin(), c.second.end());
+        ck(ctx, mfm_oprobit_add_group(ctx, (int32_t)c.first, all_rows ? nullptr : rows.data(), (int64_t)c.second.size(), &g));
         cutpoint_sampler.emplace_back(ctx, g, (int)c.first, std::getenv("MYFM_AMD_HOST_RNG") ? gen_ : gen_mh_, cfg.reg_0,
                                       cfg.nu_oprobit);
         if (std::getenv("MYFM_AMD_HOST_RNG")) {  // parity mode: latent draws on the host, in the reference's row order
@@ -1795,5 +1808,19 @@ PYBIND11_MODULE(_myfm, m) {
       bad += yv != x[m0 + l + J];
     }
     return bad;
+  });
+  // host-only self-test of the bulk normal filler (csrc/mfm_hostnormals.hpp) against one persistent
+  // std::normal_distribution<double> on the same std::mt19937: (values, values of the plain loop, the next raw output of
+  // either engine afterwards). `discard` outputs are taken first so that the sequence starts inside a state block.
+  m.def("host_normals_selftest", [](unsigned seed, int64_t discard, int64_t count, double scale, int threads) {
+    std::mt19937 g1(seed), g2(seed);
+    g1.discard((unsigned long long)discard);
+    g2.discard((unsigned long long)discard);
+    py::array_t<double> fast((py::ssize_t)count), plain((py::ssize_t)count);
+    mfm_hostnormals::fill_normals(g1, fast.mutable_data(), (size_t)count, scale, threads);
+    std::normal_distribution<double> nd;
+    double *pp = plain.mutable_data();
+    for (int64_t i = 0; i < count; i++) pp[i] = nd(g2) * scale;
+    return py::make_tuple(fast, plain, (uint32_t)g1(), (uint32_t)g2());
   });
 }

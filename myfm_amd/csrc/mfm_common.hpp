@@ -3,11 +3,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "myfm_hip.h"
@@ -305,22 +307,54 @@ struct HostCsr {
   int64_t nnz() const { return (int64_t)idx.size(); }
 };
 
+// [0, n) in contiguous ranges on host threads (the copies of a 10^8-entry design are bound by first-touch page faults of one
+// thread otherwise); f(lo, hi) must not throw. Small n: the calling thread alone.
+template <class F>
+inline void parallel_ranges(int64_t n, F f) {
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>({n >> 20, 16, hw > 0 ? hw : 1}));
+  if (T <= 1) {
+    f((int64_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int t = 1; t < T; t++) pool.emplace_back(f, n * t / T, n * (t + 1) / T);
+  f((int64_t)0, n / T);
+  for (auto &t : pool) t.join();
+}
+
 inline HostCsr make_host_csr(int64_t rows, int64_t cols, const int64_t *indptr, const int32_t *indices,
                              const double *data) {
   if (rows < 0 || cols < 0) throw Error(MFM_ERR_INVALID, "negative matrix shape");
   HostCsr X;
   X.rows = rows;
   X.cols = cols;
-  X.ptr.assign(indptr, indptr + rows + 1);
-  if (X.ptr[0] != 0) throw Error(MFM_ERR_INVALID, "indptr[0] must be 0");
-  for (int64_t i = 0; i < rows; i++)
-    if (X.ptr[i + 1] < X.ptr[i]) throw Error(MFM_ERR_INVALID, "indptr must be non-decreasing");
-  int64_t nnz = X.ptr[rows];
+  if (indptr[0] != 0) throw Error(MFM_ERR_INVALID, "indptr[0] must be 0");
+  std::atomic<int> bad(0);
+  parallel_ranges(rows, [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; i++)
+      if (indptr[i + 1] < indptr[i]) bad = 1;
+  });
+  if (bad) throw Error(MFM_ERR_INVALID, "indptr must be non-decreasing");
+  const int64_t nnz = indptr[rows];
   if (nnz >= (int64_t)2147483647) throw Error(MFM_ERR_INVALID, "nnz must be < 2^31 per matrix");
-  X.idx.assign(indices, indices + nnz);
-  X.val.assign(data, data + nnz);
-  for (int64_t p = 0; p < nnz; p++)
-    if (X.idx[p] < 0 || X.idx[p] >= cols) throw Error(MFM_ERR_INVALID, "column index out of range");
+  parallel_ranges(nnz, [&](int64_t lo, int64_t hi) {
+    for (int64_t p = lo; p < hi; p++)
+      if (indices[p] < 0 || indices[p] >= cols) bad = 1;
+  });
+  if (bad) throw Error(MFM_ERR_INVALID, "column index out of range");
+  // the three copies side by side (each is bound by the first-touch page faults of its thread)
+  if (nnz >= ((int64_t)1 << 22)) {
+    std::thread t1([&]() { X.ptr.assign(indptr, indptr + rows + 1); });
+    std::thread t2([&]() { X.idx.assign(indices, indices + nnz); });
+    X.val.assign(data, data + nnz);
+    t1.join();
+    t2.join();
+  } else {
+    X.ptr.assign(indptr, indptr + rows + 1);
+    X.idx.assign(indices, indices + nnz);
+    X.val.assign(data, data + nnz);
+  }
   return X;
 }
 

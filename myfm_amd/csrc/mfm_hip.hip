@@ -654,9 +654,13 @@ int mfm_add_block(mfm_ctx *ctx, int64_t B, int64_t Db, const int64_t *indptr, co
   mfm_ctx::HostBlock hb;
   hb.X = make_host_csr(B, Db, indptr, indices, data);
   int64_t N = ctx->hX.rows;
+  std::atomic<int> bad(0);
+  parallel_ranges(N, [&](int64_t lo, int64_t hi) {  // definitions.hpp:38-41
+    for (int64_t t = lo; t < hi; t++)
+      if (original_to_block[t] < 0 || original_to_block[t] >= B) bad = 1;
+  });
+  if (bad) throw Error(MFM_ERR_RUNTIME, "index mapping points to non-existing row.");
   hb.map.assign(original_to_block, original_to_block + N);
-  for (int64_t t = 0; t < N; t++)  // definitions.hpp:38-41
-    if (hb.map[t] < 0 || hb.map[t] >= B) throw Error(MFM_ERR_RUNTIME, "index mapping points to non-existing row.");
   ctx->hblocks.push_back(std::move(hb));
   MFM_CATCH(ctx)
 }
