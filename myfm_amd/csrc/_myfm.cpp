@@ -1138,13 +1138,40 @@ struct FMTrainer {
   }
 
   // ---- one Gibbs iteration, BaseFMTrainer.hpp:135-152 ----
+  // MYFM_AMD_HOST_TIMELINE=1: where the host thread spends an iteration (mean microseconds per stage, every 100 iterations)
+  struct HostTimeline {
+    bool on = std::getenv("MYFM_AMD_HOST_TIMELINE") != nullptr;
+    std::chrono::steady_clock::time_point t;
+    double acc[8] = {0};
+    int n = 0;
+    void start() {
+      if (on) t = std::chrono::steady_clock::now();
+    }
+    void mark(int k) {
+      if (!on) return;
+      const auto now = std::chrono::steady_clock::now();
+      acc[k] += std::chrono::duration<double, std::micro>(now - t).count();
+      t = now;
+    }
+    void end() {
+      if (!on || ++n % 100) return;
+      static const char *names[8] = {"rng acquire", "hyper_stats (sync)", "host draws", "sweep launch", "rng prefetch", "update_e", "", ""};
+      std::fprintf(stderr, "[host timeline]");
+      for (int k = 0; k < 6; k++) std::fprintf(stderr, " %s %.1f us |", names[k], acc[k] / 100.0);
+      std::fprintf(stderr, "\n");
+      for (auto &a : acc) a = 0;
+    }
+  } htl;
+
   void update_all(FM &fm, Hyper &hyper) {
     const size_t G = cfg.n_groups;
     const int Kf = fm.n_factors;
+    htl.start();
     if (device_rng) {
       ck(ctx, mfm_rng_acquire(ctx, hv.data(), (int64_t)hv.size()));  // this iteration's variates
       hv_pos = 0;
     }
+    htl.mark(0);
     // every reduction the hyper-parameter updates need, one host synchronisation: sum e / sum e^2 (update_alpha,
     // FMTrainer.hpp:127-145, update_w0 :218-229) and the group sums of w and V (:150-216) -- the latter are taken
     // before update_w / update_V touch w / V, which is where the reference takes them too
@@ -1153,6 +1180,7 @@ struct FMTrainer {
     vector<Real> sum(G), ssd(G), sumV(G * std::max(Kf, 1)), ssdV(G * std::max(Kf, 1));
     ck(ctx, mfm_hyper_stats(ctx, (need_alpha || cfg.fit_w0) ? 1 : 0, hyper.mu_w.data(), hyper.mu_V.data(), &sum_e, &sum_e2,
                             sum.data(), ssd.data(), sumV.data(), ssdV.data()));
+    htl.mark(1);
     if (need_alpha) {
       Real exponent = (cfg.alpha_0 + N_total) / 2;
       Real variance = (cfg.beta_0 + sum_e2) / 2;
@@ -1220,6 +1248,7 @@ struct FMTrainer {
           hyper.mu_V[(size_t)f * G + g] = sample_normal(square, linear);
         }
       // update_V (:316-486)
+      htl.mark(2);
       if (fuse_wV) {
         ck(ctx, mfm_sweep_wV(ctx, hyper.alpha, e_shift, hyper.lambda_w.data(), hyper.mu_w.data(), nullptr, 0, Kf,
                              hyper.lambda_V.data(), hyper.mu_V.data(), nullptr));
@@ -1233,7 +1262,9 @@ struct FMTrainer {
     }
     // the variates of the iteration after the next: generated on the side stream from the end of this iteration's latent
     // sweep on (the persistent sweep leaves no CU to anything else), next to update_e and the start of the next iteration
+    htl.mark(3);
     if (device_rng) ck(ctx, mfm_rng_prefetch(ctx));
+    htl.mark(4);
     // update_e (:493-522)
     if (cfg.task_type == TaskType::REGRESSION) {
       ck(ctx, mfm_update_e_regression(ctx));
@@ -1261,6 +1292,8 @@ struct FMTrainer {
         i++;
       }
     }
+    htl.mark(5);
+    htl.end();
   }
 
   // FMTrainer.hpp:56-87

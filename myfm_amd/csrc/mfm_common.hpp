@@ -258,10 +258,10 @@ inline bool poison_lds(hipStream_t s, int cls, int line, bool clean = false) {  
   }
   if (only >= 0 && only != cls) return false;
   if (only_line >= 0 && only_line != line) return false;
-  static bool raised = false;
-  if (!raised) {
+  static DeviceOnce raised;
+  if (raised.need()) {
     MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_poison_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    raised = true;
+    raised.mark();
   }
   static const uint32_t word =
       std::getenv("MFM_DEBUG_POISON_WORD") ? (uint32_t)std::strtoul(std::getenv("MFM_DEBUG_POISON_WORD"), nullptr, 16) : 0x7ff4deadu;

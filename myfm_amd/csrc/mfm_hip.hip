@@ -83,7 +83,9 @@ struct mfm_ctx {
   bool sharded_fused = false;   // row-sharded + fused tile path (run_sweep_soa_sharded)
   int q_stale_factor = -1;      // >= 0: the stored q column is stale, mfm_get_q rebuilds it for this factor first
   BlockOverflow gather_overflow;       // q-cache build: pointers of the relation blocks beyond MAX_BLOCKS
-  DevBuf<double> lam_w, mu_w, zw_host;  // mfm_sweep_wV: the linear sweep's hyper-parameters / host-given variates
+  DevBuf<double> wv_pack, zw_host;  // mfm_sweep_wV: [lambda_w | mu_w | lambda_V | mu_V] of the launch / host-given variates
+  std::vector<double> hs_stage;     // host staging of the packed hyper-parameter copies
+  bool slot_sums_valid = false;     // res.sums holds sum e / sum e^2 of the residual that is in slot order right now
   bool res_fills_device = false;  // the persistent sweep takes (nearly) every CU: nothing runs beside it
   bool e_in_slots = false;      // the residual after the resident latent sweep lives in res.e_slots (slot order): every
                                 // reader of eq calls materialize_e first; update_e overwrites it and just drops the flag
@@ -452,6 +454,7 @@ static SweepArgs main_args(mfm_ctx *c, double *theta, const double *z, const dou
 // the residual the resident latent sweep left in slot order -> eq (only when somebody reads it: in the Gibbs loop update_e
 // follows and recomputes it)
 static void materialize_e(mfm_ctx *c) {
+  c->slot_sums_valid = false;  // (whoever asks for the residual in row order may change it)
   if (!c->e_in_slots) return;
   const int64_t n_slots = (int64_t)c->res.G * c->res.NT * (c->res.RV + c->res.RL);
   hipLaunchKernelGGL(k_res_unpermute, dim3((unsigned)cdiv(n_slots, 256)), dim3(256), 0, c->stream, c->res.e_slots.p, c->res.perm.p,
@@ -461,12 +464,21 @@ static void materialize_e(mfm_ctx *c) {
 
 static void score_train(mfm_ctx *c, bool subtract_y) {
   c->e_in_slots = false;  // (every residual is overwritten)
+  c->slot_sums_valid = false;
   if (c->mf && !std::getenv("MFM_NO_MF_SCORE")) {
     // two-field table: scorer on the row tiles of the latent sweep (item rows gathered once per run, not once per row)
     hipStream_t s = c->stream;
     {
       TimedLaunch t(c->timing, s, KC_BUILD_VT, 16.0 * c->D * c->K);
       build_vt(s, c->V.p, c->Vt.p, c->D, c->K, c->KS);
+    }
+    // regression on a table that takes the persistent sweep: e = score - y straight in the sweep's slot order, with its sums
+    static const bool no_res_score = std::getenv("MFM_NO_RES_SCORE") != nullptr;
+    if (subtract_y && c->res.ready && !no_res_score && res_score_supported(c->res, c->K)) {
+      run_res_score(s, c->timing, c->res, KC_UPDATE_E, c->Vt.p, c->w.p, c->w0, c->K, c->y.p, c->X.nnz);
+      c->e_in_slots = true;
+      c->slot_sums_valid = true;
+      return;
     }
     TimedLaunch t(c->timing, s, KC_UPDATE_E, 12.0 * c->X.nnz + 16.0 * c->X.rows + 8.0 * c->D * (c->K + 1));
     SweepArgs a = main_args(c, c->w.p, nullptr, nullptr, nullptr, 0.0);
@@ -1140,22 +1152,32 @@ int mfm_hyper_stats(mfm_ctx *ctx, int32_t need_e, const double *mu_w, const doub
                     double *sum_w, double *ssd_w, double *sum_V, double *ssd_V) {
   MFM_TRY(ctx)
   ctx->need_final();
-  materialize_e(ctx);
   mfm_ctx *c = ctx;
+  // the slot-order scorer has left sum e / sum e^2 as one partial per workgroup: no pass over the residual, which stays in
+  // slot order for the next persistent launch
+  const bool slot_sums = need_e && c->e_in_slots && c->slot_sums_valid && !c->comm.active();
+  if (need_e && !slot_sums) materialize_e(ctx);
   hipStream_t s = c->stream;
   const int G = c->G, K = c->K, n_ch = std::max(1, c->gs_chunks);
   const size_t n_out = 1 + (size_t)G * (K + 1);
   if (c->hs_out.n < n_out) c->hs_out.alloc(n_out);
   if (c->hs_mu.n < (size_t)G * (K + 1)) c->hs_mu.alloc((size_t)G * (K + 1));
   if (c->gs_partial.n < (size_t)G * (K + 1) * n_ch) c->gs_partial.alloc((size_t)G * (K + 1) * n_ch);
-  if (need_e) {
+  {  // (one copy for both mean vectors, ahead of the reduction it does not depend on: every async call costs the host ~10 us)
+    c->hs_stage.resize((size_t)G * (K + 1));
+    std::memcpy(c->hs_stage.data(), mu_w, (size_t)G * sizeof(double));
+    if (K) std::memcpy(c->hs_stage.data() + G, mu_V, (size_t)G * K * sizeof(double));
+    c->ring.upload(c->hs_mu.p, c->hs_stage.data(), c->hs_stage.size() * sizeof(double), s);
+  }
+  if (slot_sums) {
+    TimedLaunch t(c->timing, s, KC_REDUCE_E, 16.0 * c->res.G);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, s, c->res.sums.p, c->res.G, c->hs_out.p);
+  } else if (need_e) {
     TimedLaunch t(c->timing, s, KC_REDUCE_E, 8.0 * c->N);
     hipLaunchKernelGGL(k_reduce_e_partial, dim3(REDUCE_BLOCKS), dim3(WG), 0, s, c->eq.p, c->N, c->red_partial.p);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, s, c->red_partial.p, REDUCE_BLOCKS, c->hs_out.p);
     c->comm.allreduce(c->hs_out.p, 2);
   }
-  c->ring.upload(c->hs_mu.p, mu_w, (size_t)G * sizeof(double), s);
-  if (K) c->ring.upload(c->hs_mu.p + G, mu_V, (size_t)G * K * sizeof(double), s);
   {
     TimedLaunch t(c->timing, s, KC_GROUP_STATS, 12.0 * c->D * (K + 1));
     hipLaunchKernelGGL(k_group_stats, dim3(G, 1, n_ch), dim3(WG), 0, s, c->w.p, c->D, c->feat_sorted.p, c->group_ptr.p,
@@ -1234,18 +1256,22 @@ int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambd
   }
   MFM_TRY(ctx)
   ctx->need_final();
-  materialize_e(ctx);
   mfm_ctx *c = ctx;
+  const bool load_slots = c->e_in_slots;  // the residual is already in the launch's slot order: read it there
+  c->slot_sums_valid = false;
   if (f_begin < 0 || f_end > c->K) throw Error(MFM_ERR_INVALID, "factor range out of bounds");
   hipStream_t s = c->stream;
-  if (!c->lam_w.p) {
-    c->lam_w.alloc((size_t)c->G);
-    c->mu_w.alloc((size_t)c->G);
-  }
-  c->ring.upload(c->lam_w.p, lambda_w, (size_t)c->G * sizeof(double), s);
-  c->ring.upload(c->mu_w.p, mu_w, (size_t)c->G * sizeof(double), s);
-  c->ring.upload(c->lam.p, lambda_V, (size_t)c->G * c->K * sizeof(double), s);
-  c->ring.upload(c->mu.p, mu_V, (size_t)c->G * c->K * sizeof(double), s);
+  // the four hyper-parameter vectors in ONE copy: [lambda_w | mu_w | lambda_V | mu_V]
+  const size_t nG = (size_t)c->G, nGK = (size_t)c->G * c->K;
+  if (c->wv_pack.n < 2 * nG + 2 * nGK) c->wv_pack.alloc(2 * nG + 2 * nGK);
+  c->hs_stage.resize(2 * nG + 2 * nGK);
+  std::memcpy(c->hs_stage.data(), lambda_w, nG * sizeof(double));
+  std::memcpy(c->hs_stage.data() + nG, mu_w, nG * sizeof(double));
+  std::memcpy(c->hs_stage.data() + 2 * nG, lambda_V, nGK * sizeof(double));
+  std::memcpy(c->hs_stage.data() + 2 * nG + nGK, mu_V, nGK * sizeof(double));
+  c->ring.upload(c->wv_pack.p, c->hs_stage.data(), c->hs_stage.size() * sizeof(double), s);
+  const double *d_lam_w = c->wv_pack.p, *d_mu_w = c->wv_pack.p + nG, *d_lam = c->wv_pack.p + 2 * nG,
+               *d_mu = c->wv_pack.p + 2 * nG + nGK;
   if ((zw == nullptr) != (zv == nullptr)) throw Error(MFM_ERR_INVALID, "mfm_sweep_wV: give both variate arrays or none");
   const double *zwdev, *zbase;
   if (zw) {
@@ -1261,8 +1287,8 @@ int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambd
     zbase = c->rng.slot[c->rng.current].zv.p + (size_t)f_begin * c->D;
   }
   const bool lazy_store = !std::getenv("MFM_RES_EAGER_STORE");
-  run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq.p, c->V.p, c->D, f_begin, f_end, zbase, c->lam.p, c->mu.p,
-                     c->group.p, c->G, alpha, c->ls.error.p, lazy_store, c->w.p, zwdev, c->lam_w.p, c->mu_w.p, e_shift);
+  run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq.p, c->V.p, c->D, f_begin, f_end, zbase, d_lam, d_mu,
+                     c->group.p, c->G, alpha, c->ls.error.p, lazy_store, c->w.p, zwdev, d_lam_w, d_mu_w, e_shift, load_slots);
   c->e_in_slots = lazy_store;
   c->q_stale_factor = f_end - 1;
   MFM_CATCH(ctx)

@@ -39,6 +39,8 @@ namespace mfm {
 
 struct ResArgs {
   double2 *eq;               // residual: read at [row].x at the start, written back at the end ...
+  const double *e_in;        // set: the residual is read from this slot-ordered copy (what the previous launch or the slot-order
+                             // scorer k_res_score left) instead of eq
   double *e_slots;           // ... unless this is set: [G][R][NT], the residual in slot order (coalesced; k_res_unpermute
                              // moves it to eq when somebody needs it there -- update_e, which follows in the Gibbs loop,
                              // recomputes the residual and does not)
@@ -251,10 +253,10 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
     for (int bb = 0; bb < 4; bb++) {
       int row[B];
 #pragma unroll
-      for (int k = 0; k < B; k++) row[k] = perm_g[(16 * j + 4 * bb + k) * NT + tid];
+      for (int k = 0; k < B; k++) row[k] = a.e_in ? 0 : perm_g[(16 * j + 4 * bb + k) * NT + tid];
 #pragma unroll
       for (int k = 0; k < B; k++) {
-        const double x = a.eq[row[k] < 0 ? 0 : row[k]].x + a.e_shift;
+        const double x = (a.e_in ? a.e_in[((int64_t)g * R + 16 * j + 4 * bb + k) * NT + tid] : a.eq[row[k] < 0 ? 0 : row[k]].x) + a.e_shift;
         if (j < NGV)
           ev[j < NGV ? j : 0][4 * bb + k] = x;
         else
@@ -607,8 +609,10 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
 
 // ---- host side: the resident layout of a two-field table and the launch ---------------------------------------------
 __global__ void k_res_init_dv(const double *__restrict__ theta, const int32_t *__restrict__ scols, int n_items,
-                              double *__restrict__ dv) {
+                              double *__restrict__ dv, unsigned long long *__restrict__ bar) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0)  // the launch's barrier words start from zero (one dispatch less than a memset of their own)
+    for (int k = threadIdx.x; k < RES_BAR_WORDS; k += blockDim.x) bar[k] = 0ull;
   if (i < n_items) {
     dv[2 * i] = 0.0;
     dv[2 * i + 1] = theta ? theta[scols[i]] : 1.0;  // (theta == null: the linear sweep, h = 1)
@@ -625,6 +629,174 @@ __global__ void k_res_unpermute(const double *__restrict__ e_slots, const int32_
   if (i >= n_slots) return;
   const int32_t row = perm[i];
   if (row >= 0) eq[row].x = e_slots[i];
+}
+
+// ---- update_e (FMTrainer.hpp:493-497 -> FM.hpp:54-136) in the resident layout ----------------------------------------------
+// e = w0 + w_u + w_i + <V_u, V_i> - y for every slot, written in slot order: the next persistent launch reads it back coalesced
+// (no slot -> row gather), nothing touches eq inside the Gibbs loop (materialize_e moves it there when somebody asks). A
+// workgroup's users' rows of Vt sit in LDS for the launch; the slots are in item order, so a thread walks its R slots with the
+// current item's row in registers and fetches a new one at every run head (the run's feature comes from run_feat, one round
+// trip). sum e and sum e^2 (update_alpha, update_w0: FMTrainer.hpp:127-145, 218-229) are taken on the way: one partial per
+// workgroup, thread order inside the waves and wave order inside the workgroup fixed.
+struct ResScoreArgs {
+  const uint32_t *uidw, *headw;
+  const int32_t *first_run, *run_feat, *wg_user_ptr, *wg_fill;
+  const int2 *user_desc;
+  int umax, KS;
+  const double *Vt, *w;
+  double w0;
+  const double *y_slots;
+  double *e_slots;
+  double2 *sums;  // [G] {sum e, sum e^2}
+  int dbg;        // timing experiments (wrong results): 1 no item-row fetch, 2 no user-row reads, 4 one user row for all
+};
+
+template <int NT, int NG, int KPT>
+__global__ __launch_bounds__(NT) void k_res_score(ResScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char res_smem[];
+  constexpr int R = 16 * NG, NW = NT / WAVE;
+  constexpr int US = 2 * KPT + 2;  // doubles per user row in LDS (16-byte aligned, rows shifted by 4 banks)
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int KP = a.KS >> 1;
+  double *uV = (double *)res_smem;         // [umax][US]
+  double *uW = uV + (size_t)a.umax * US;   // [umax]
+  double2 *wsum = (double2 *)(uW + ((a.umax + 1) & ~1));  // [NW]
+  int *ucol = (int *)(wsum + NW);  // [umax] feature of the workgroup's u-th user
+  const int u0 = a.wg_user_ptr[g], nu = a.wg_user_ptr[g + 1] - u0;
+  for (int ul = tid; ul < a.umax; ul += NT) {  // (first the features: the row copy below then depends on LDS only)
+    const int ju = ul < nu ? a.user_desc[u0 + ul].x : -1;
+    ucol[ul] = ju;
+    uW[ul] = ju >= 0 ? a.w[ju] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = tid; i < a.umax * KPT; i += NT) {
+    const int ul = i / KPT, pr = i - ul * KPT;
+    const int ju = ucol[ul];
+    double2 v = make_double2(0.0, 0.0);
+    if (ju >= 0 && pr < KP) v = ((const double2 *)(a.Vt + (int64_t)ju * a.KS))[pr];
+    ((double2 *)(uV + (size_t)ul * US))[pr] = v;
+  }
+  // static per-thread words (as in k_mf_resident)
+  res_u4_t uw[NG];
+  unsigned ux[NG], hbv[NG];
+#pragma unroll
+  for (int j = 0; j < NG; j++) {
+#pragma unroll
+    for (int w = 0; w < 4; w++) uw[j][w] = a.uidw[((int64_t)g * (5 * NG) + 5 * j + w) * NT + tid];
+    ux[j] = a.uidw[((int64_t)g * (5 * NG) + 5 * j + 4) * NT + tid];
+    hbv[j] = a.headw[((int64_t)g * NG + j) * NT + tid];
+  }
+  int run = a.first_run[g * NT + tid];
+  const int64_t fill = a.wg_fill[g];
+  __syncthreads();
+  // (measured: reading the item's row again for every slot by straight-line code, two slots in flight, is twice as slow as
+  //  this divergent fetch at the run heads -- the texture path pays per cache line touched, and 64 lanes on 64 different
+  //  rows touch 64 lines per instruction)
+  double2 vi[KPT];
+  double wi = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int p = 0; p < KPT; p++) vi[p] = make_double2(0.0, 0.0);
+  // the features of a batch's runs are requested one batch ahead by straight-line code (the run of every slot follows from
+  // the head bits alone): the divergent fetch at a run head is then ONE round trip (the row), not two
+  int jc[4], jn[4];
+  {
+    const unsigned h0 = hbv[0] & 15u;
+    int r = run;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (k > 0) r += (int)((h0 >> k) & 1u);
+      jc[k] = a.run_feat[r];
+    }
+    run = r;  // (the run of the last slot whose feature has been requested)
+  }
+#pragma unroll
+  for (int j = 0; j < NG; j++) {
+    const unsigned hb2 = hbv[j] | (j + 1 < NG ? hbv[j + 1 < NG ? j + 1 : j] << 16 : 0u);
+#pragma unroll 1
+    for (int bb = 0; bb < 4; bb++) {
+      {
+        const unsigned hn = (hb2 >> (4 * (bb + 1))) & 15u;
+        int r = run;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          r += (int)((hn >> k) & 1u);
+          jn[k] = a.run_feat[r];
+        }
+        run = r;
+      }
+      const unsigned lo_ = uw[j][bb];
+      int uid[4];
+      uid[0] = (int)(lo_ & 0x3ffu);
+      uid[1] = (int)((lo_ >> 10) & 0x3ffu);
+      uid[2] = (int)((lo_ >> 20) & 0x3ffu);
+      uid[3] = (int)((lo_ >> 30) | (((ux[j] >> (8 * bb)) & 0xffu) << 2));
+      const unsigned h4 = (hbv[j] >> (4 * bb)) & 15u;
+      // the residual's other operand is requested first: it does not depend on anything computed here
+      double yv[4], eb[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) yv[k] = a.y_slots[((int64_t)g * R + 16 * j + 4 * bb + k) * NT + tid];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int slot = 16 * j + 4 * bb + k;
+        const bool head = slot == 0 || ((h4 >> k) & 1u);
+        if (head) {
+          const int ji = jc[k];  // (-1: the pad run)
+          wi = 0.0;
+          if (ji >= 0 && !(a.dbg & 1)) {
+            const double2 *src = (const double2 *)(a.Vt + (int64_t)ji * a.KS);
+#pragma unroll
+            for (int p = 0; p < KPT; p++) vi[p] = p < KP ? src[p] : make_double2(0.0, 0.0);
+            wi = a.w[ji];
+          } else {
+#pragma unroll
+            for (int p = 0; p < KPT; p++) vi[p] = make_double2(0.0, 0.0);
+          }
+        }
+        const double2 *vu = (const double2 *)(uV + (size_t)((a.dbg & 4) ? 0 : uid[k]) * US);
+        double d0 = 0.0, d1 = 0.0;  // two chains: even / odd pairs
+#pragma unroll
+        for (int p = 0; p < KPT; p += 2) {
+          if (a.dbg & 2) break;
+          const double2 x0 = vu[p], x1 = vu[p + 1];
+          d0 += x0.x * vi[p].x + x0.y * vi[p].y;
+          d1 += x1.x * vi[p + 1].x + x1.y * vi[p + 1].y;
+        }
+        const double pred = a.w0 + (uW[uid[k]] + wi) + (d0 + d1);
+        const bool real = (int64_t)tid * R + slot < fill;
+        const double e = real ? pred - yv[k] : 0.0;  // (pads stay finite: 0 * NaN would poison the sweeps' statistics)
+        eb[k] = e;
+        s1 += e;
+        s2 += e * e;
+      }
+      // (the batch's stores together, behind its last fetch: the wave has ONE memory counter, and a wait for a row that was
+      //  requested after a store also waits for that store's acknowledgement)
+#pragma unroll
+      for (int k = 0; k < 4; k++) a.e_slots[((int64_t)g * R + 16 * j + 4 * bb + k) * NT + tid] = eb[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) jc[k] = jn[k];
+    }
+  }
+  wave_allreduce_sum2(s1, s2);
+  if (lane == 0) wsum[wv] = make_double2(s1, s2);
+  __syncthreads();
+  if (tid == 0) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int w = 0; w < NW; w++) {
+      t1 += wsum[w].x;
+      t2 += wsum[w].y;
+    }
+    a.sums[g] = make_double2(t1, t2);
+  }
+}
+
+// y in slot order (pads: 0), once per plan
+__global__ void k_res_permute_y(const double *__restrict__ y, const int32_t *__restrict__ perm, int64_t n_slots,
+                                double *__restrict__ y_slots) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots) return;
+  const int32_t row = perm[i];
+  y_slots[i] = row >= 0 ? y[row] : 0.0;
 }
 
 // host threads for the layout's per-workgroup work
@@ -662,6 +834,11 @@ struct ResPlan {
   DevBuf<int2> user_desc, item_desc;
   DevBuf<double> partials, dv, e_slots;
   DevBuf<unsigned long long> bar;
+  // the slot-order scorer (k_res_score)
+  DevBuf<int32_t> run_feat, wg_fill;  // feature of every run (-1: pad run); rows of every workgroup
+  DevBuf<double> y_slots;             // y in slot order, built at the first scoring
+  DevBuf<double2> sums;               // [G] {sum e, sum e^2} of the last scoring
+  int maxu_rows = 0;                  // users of the largest workgroup (+ the pad user)
   std::string why;  // why the layout was not built (diagnostics)
   std::vector<int32_t> h_nruns;  // runs per workgroup (diagnostics)
   std::vector<std::string> h_diag;  // per workgroup (MFM_RES_PROF only)
@@ -964,6 +1141,16 @@ struct ResPlan {
     wg_run_ptr.upload(run_base);
     wg_nruns.upload(nruns);
     e_slots.alloc((size_t)G * cap_slots);
+    {
+      std::vector<int32_t> h_run_feat(h_run_item.size() + 8, -1);  // (the scorer's look-ahead reads a few runs past the last)
+      for (size_t r = 0; r < h_run_item.size(); r++) h_run_feat[r] = h_run_item[r] < n_items ? items[(size_t)h_run_item[r]] : -1;
+      run_feat.upload(h_run_feat);
+      std::vector<int32_t> h_fill((size_t)G);
+      for (int g = 0; g < G; g++) h_fill[g] = (int32_t)fill[g];
+      wg_fill.upload(h_fill);
+      sums.alloc((size_t)G);
+      y_slots = DevBuf<double>();
+    }
     h_nruns = nruns;
     if (std::getenv("MFM_RES_PROF")) {
       h_diag.assign((size_t)G, "");
@@ -1029,11 +1216,12 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
                                       int f_begin, int f_end, const double *zbase, const double *lam, const double *mu,
                                       const int32_t *group, int n_groups, double alpha, int *error, bool lazy_store,
                                       double *w = nullptr, const double *zw = nullptr, const double *lam_w = nullptr,
-                                      const double *mu_w = nullptr, double e_shift = 0.0) {
+                                      const double *mu_w = nullptr, double e_shift = 0.0, bool load_slots = false) {
   ResArgs a;
   std::memset(&a, 0, sizeof(a));
   a.eq = eq;
   a.e_slots = lazy_store ? rp.e_slots.p : nullptr;
+  a.e_in = load_slots ? rp.e_slots.p : nullptr;
   a.linear = w ? 1 : 0;
   a.n_sw = f_end - f_begin + a.linear;
   a.w = w;
@@ -1070,7 +1258,6 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   a.n_items = rp.n_items;
   a.umax = rp.umax;
   a.bar = rp.bar.p;
-  MFM_HIP_CHECK(hipMemsetAsync(rp.bar.p, 0, RES_BAR_WORDS * sizeof(unsigned long long), s));
   a.n_wg = rp.G;
   a.error = error;
   a.dbg = std::getenv("MFM_RES_DBG") ? std::atoi(std::getenv("MFM_RES_DBG")) : 0;
@@ -1092,7 +1279,7 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   (void)lazy_store;
   hipLaunchKernelGGL(k_res_init_dv, dim3((rp.n_items + 256) / 256), dim3(256), 0, s,
                      w ? (const double *)nullptr : V + (int64_t)f_begin * D, rp.scols.p, rp.n_items,
-                     rp.dv.p);
+                     rp.dv.p, rp.bar.p);
   TimedLaunch t(tm, s, kernel_class, bytes);
 #define MFM_RES_LAUNCH(RV_, RL_)                                                                                              \
   do {                                                                                                                        \
@@ -1206,6 +1393,67 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
     for (int g = 0; g < rp.G; g++) tot += (double)(h[((size_t)g * K2 + K2 - 1) * 64 + 6] - h[(size_t)g * K2 * 64]) * 0.01;
     std::fprintf(stderr, "  factors, start to end: %.1f us (%.2f per factor)\n", tot / rp.G, tot / rp.G / K2);
   }
+}
+
+// update_e in slot order (k_res_score). false: this plan / rank is not covered (the caller scores in row order).
+static inline bool res_score_supported(const ResPlan &rp, int K) {
+  const int KS = (K + 1) & ~1;
+  if (!rp.ready || K < 1 || KS > 32) return false;
+  const size_t lds = ((size_t)rp.umax * (2 * 16 + 2) + ((rp.umax + 1) & ~1)) * 8 + 8 * 16 + (size_t)rp.umax * 4 + 64;
+  return lds <= 160 * 1024 - 512;
+}
+
+static inline void run_res_score(hipStream_t s, Timing &tm, ResPlan &rp, int kernel_class, const double *Vt, const double *w,
+                                 double w0, int K, const double *y, int64_t nnz) {
+  const int KS = (K + 1) & ~1;
+  const int64_t n_slots = (int64_t)rp.G * (rp.RV + rp.RL) * 512;
+  if (!rp.y_slots.p) {
+    rp.y_slots.alloc((size_t)n_slots);
+    hipLaunchKernelGGL(k_res_permute_y, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, y, rp.perm.p, n_slots,
+                       rp.y_slots.p);
+  }
+  ResScoreArgs a;
+  a.uidw = rp.uidw.p;
+  a.headw = rp.headw.p;
+  a.first_run = rp.first_run.p;
+  a.run_feat = rp.run_feat.p;
+  a.wg_user_ptr = rp.wg_user_ptr.p;
+  a.wg_fill = rp.wg_fill.p;
+  a.user_desc = rp.user_desc.p;
+  a.umax = rp.umax;
+  a.KS = KS;
+  a.Vt = Vt;
+  a.w = w;
+  a.w0 = w0;
+  a.y_slots = rp.y_slots.p;
+  a.e_slots = rp.e_slots.p;
+  a.sums = rp.sums.p;
+  a.dbg = std::getenv("MFM_RES_SCORE_DBG") ? std::atoi(std::getenv("MFM_RES_SCORE_DBG")) : 0;
+  const size_t lds = ((size_t)rp.umax * (2 * 16 + 2) + ((rp.umax + 1) & ~1)) * 8 + 8 * 16 + (size_t)rp.umax * 4 + 64;
+  // algorithmic bytes: y and e in slot order (8 + 8 B / row), the static slot words (1.4 B), one Vt row per run and per user
+  TimedLaunch t(tm, s, kernel_class, 17.4 * rp.n_rows + 8.0 * KS * (double)rp.n_runs);
+  (void)nnz;
+#define MFM_RES_SCORE(NG_)                                                                                              \
+  do {                                                                                                                  \
+    static DeviceOnce raised;                                                                                           \
+    if (raised.need()) {                                                                                                \
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_res_score<512, NG_, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        160 * 1024));                                                                   \
+      raised.mark();                                                                                                    \
+    }                                                                                                                   \
+    hipLaunchKernelGGL((k_res_score<512, NG_, 16>), dim3(rp.G), dim3(512), lds, s, a);                                   \
+  } while (0)
+  const int NG = (rp.RV + rp.RL) / 16;
+  if (NG == 1)
+    MFM_RES_SCORE(1);
+  else if (NG == 2)
+    MFM_RES_SCORE(2);
+  else if (NG == 5)
+    MFM_RES_SCORE(5);
+  else
+    throw Error(MFM_ERR_RUNTIME, "internal: no slot-order scorer for this plan");
+#undef MFM_RES_SCORE
+  MFM_HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace mfm

@@ -28,3 +28,7 @@ cb = d.get("cpu_baseline") or {}
 print("%-48s value %9.3f  ms/step %9.3f  cpu %s  fit %s  setup_s %s" % (sys.argv[1], d["value"], d["ms_per_step"], cb.get("value"), (d.get("fit") or {}).get("fit_it_per_s"), d["config"].get("setup_s")))
 PY
 done
+# the bench line once more, now that this batch's own PMC summary is in profiles/ form (roofline.traffic is read from it)
+cp gpurun_out/${T}_pmc_traffic.json gpurun_out/${T}_pmc_traffic.txt profiles/ 2>/dev/null
+python bench.py > gpurun_out/${T}_bench_config3.json 2> /dev/null
+MFM_RES_PROF=5 python bench.py --steps 10 --warmup 3 --no-other-configs --cpu-seconds 0 --fit-iters 0 2>&1 | grep -A30 "resident profile" | cut -c1-330 > gpurun_out/${T}_res_phases.txt

@@ -634,3 +634,46 @@ def test_error_paths(capi):
         capi.Context(X, y, rank=2, group_index=np.array([0, 0, 0, 2, 2, 2, 2, 2, 2], np.int32))
     with pytest.raises(ValueError):
         capi.Context(X, y, rank=2, group_index=np.zeros(5, np.int32))
+
+
+def test_slot_order_scorer_residual_and_sums(capi, monkeypatch):
+    # update_e of a regression on a table that takes the persistent sweep: the residual is scored straight in the sweep's slot
+    # order (k_res_score) with sum e / sum e^2 as by-products, and moved to row order only on request. Held against numpy on
+    # the state the context reports, before and after a further fused sweep reads it back in slot order.
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    n, K = 90001, 6
+    X, y, shapes = ds.onehot_mf(n, 230, 170, seed=12, sort_by_user=True)
+    gi = ds.group_index_from_shapes(shapes)
+    c = capi.Context(X, y, rank=K, group_index=gi)
+    assert c.plan_flags()["resident"]
+    D, G = X.shape[1], int(max(gi)) + 1
+    rng = np.random.default_rng(3)
+    c.set_state(0.3, rng.normal(size=D) * 0.1, rng.normal(size=(D, K)) * 0.1)
+    u, i = X.indices[0::2], X.indices[1::2]
+
+    def numpy_residual():
+        w0, w, V = c.get_state()
+        return w0 + w[u] + w[i] + np.einsum("nf,nf->n", V[u], V[i]) - y
+
+    c.update_e_regression()
+    s, s2 = c.reduce_e()  # (materialises the row order)
+    want = numpy_residual()
+    np.testing.assert_allclose(c.get_e(), want, rtol=1e-12, atol=1e-12)
+    assert abs(s - want.sum()) < 1e-8 * n and abs(s2 - (want ** 2).sum()) < 1e-8 * n
+    # a fused sweep that starts from the slot-ordered residual, against the same sweep started from the row-ordered one
+    lam_w, mu_w = np.full(G, 1.5), np.zeros(G)
+    lam_V, mu_V = np.full((G, K), 2.0), np.zeros((G, K))
+    zw, zv = rng.normal(size=D), rng.normal(size=(K, D))
+    state = c.get_state()
+    c.update_e_regression()  # residual in slot order now
+    c.sweep_wV(1.1, 0.05, lam_w, mu_w, zw, 0, K, lam_V, mu_V, zv)
+    a_state, a_e = c.get_state(), c.get_e()
+    c.set_state(*state)
+    c.update_e_regression()
+    c.get_e()  # row order
+    c.sweep_wV(1.1, 0.05, lam_w, mu_w, zw, 0, K, lam_V, mu_V, zv)
+    b_state, b_e = c.get_state(), c.get_e()
+    assert a_state[0] == b_state[0]
+    np.testing.assert_array_equal(a_state[1], b_state[1])
+    np.testing.assert_array_equal(a_state[2], b_state[2])
+    np.testing.assert_array_equal(a_e, b_e)
