@@ -649,6 +649,7 @@ struct ResScoreArgs {
   double *e_slots;
   double2 *sums;  // [G] {sum e, sum e^2}
   int dbg;        // timing experiments (wrong results): 1 no item-row fetch, 2 no user-row reads, 4 one user row for all
+  unsigned long long *prof;  // (MFM_RES_SCORE_PROF) [G][4] s_memrealtime at start / users staged / slots done / end
 };
 
 template <int NT, int NG, int KPT>
@@ -661,6 +662,7 @@ __global__ __launch_bounds__(NT) void k_res_score(ResScoreArgs a) {
   double *uV = (double *)res_smem;         // [umax][US]
   double *uW = uV + (size_t)a.umax * US;   // [umax]
   double2 *wsum = (double2 *)(uW + ((a.umax + 1) & ~1));  // [NW]
+  if (a.prof && tid == 0) a.prof[4 * g] = __builtin_amdgcn_s_memrealtime();
   int *ucol = (int *)(wsum + NW);  // [umax] feature of the workgroup's u-th user
   const int u0 = a.wg_user_ptr[g], nu = a.wg_user_ptr[g + 1] - u0;
   for (int ul = tid; ul < a.umax; ul += NT) {  // (first the features: the row copy below then depends on LDS only)
@@ -690,6 +692,7 @@ __global__ __launch_bounds__(NT) void k_res_score(ResScoreArgs a) {
   int run = a.first_run[g * NT + tid];
   const int64_t fill = a.wg_fill[g];
   __syncthreads();
+  if (a.prof && tid == 0) a.prof[4 * g + 1] = __builtin_amdgcn_s_memrealtime();
   // (measured: reading the item's row again for every slot by straight-line code, two slots in flight, is twice as slow as
   //  this divergent fetch at the run heads -- the texture path pays per cache line touched, and 64 lanes on 64 different
   //  rows touch 64 lines per instruction)
@@ -700,6 +703,9 @@ __global__ __launch_bounds__(NT) void k_res_score(ResScoreArgs a) {
   // the features of a batch's runs are requested one batch ahead by straight-line code (the run of every slot follows from
   // the head bits alone): the divergent fetch at a run head is then ONE round trip (the row), not two
   int jc[4], jn[4];
+  double yn[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) yn[k] = a.y_slots[((int64_t)g * R + k) * NT + tid];
   {
     const unsigned h0 = hbv[0] & 15u;
     int r = run;
@@ -735,7 +741,12 @@ __global__ __launch_bounds__(NT) void k_res_score(ResScoreArgs a) {
       // the residual's other operand is requested first: it does not depend on anything computed here
       double yv[4], eb[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) yv[k] = a.y_slots[((int64_t)g * R + 16 * j + 4 * bb + k) * NT + tid];
+      for (int k = 0; k < 4; k++) yv[k] = yn[k];
+      {  // (the next batch's targets, one batch ahead like its features; past the last slot: the first ones again)
+        const int nb = 16 * j + 4 * bb + 4 < R ? 16 * j + 4 * bb + 4 : 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) yn[k] = a.y_slots[((int64_t)g * R + nb + k) * NT + tid];
+      }
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int slot = 16 * j + 4 * bb + k;
@@ -777,9 +788,11 @@ __global__ __launch_bounds__(NT) void k_res_score(ResScoreArgs a) {
       for (int k = 0; k < 4; k++) jc[k] = jn[k];
     }
   }
+  if (a.prof && lane == 0) a.prof[4 * g + 2] = __builtin_amdgcn_s_memrealtime();  // (the last wave to finish wins)
   wave_allreduce_sum2(s1, s2);
   if (lane == 0) wsum[wv] = make_double2(s1, s2);
   __syncthreads();
+  if (a.prof && tid == 0) a.prof[4 * g + 3] = __builtin_amdgcn_s_memrealtime();
   if (tid == 0) {
     double t1 = 0.0, t2 = 0.0;
     for (int w = 0; w < NW; w++) {
@@ -1429,6 +1442,14 @@ static inline void run_res_score(hipStream_t s, Timing &tm, ResPlan &rp, int ker
   a.e_slots = rp.e_slots.p;
   a.sums = rp.sums.p;
   a.dbg = std::getenv("MFM_RES_SCORE_DBG") ? std::atoi(std::getenv("MFM_RES_SCORE_DBG")) : 0;
+  static int prof_calls = 0;
+  const bool prof = std::getenv("MFM_RES_SCORE_PROF") && ++prof_calls == std::atoi(std::getenv("MFM_RES_SCORE_PROF"));
+  DevBuf<unsigned long long> prof_buf;
+  a.prof = nullptr;
+  if (prof) {
+    prof_buf.alloc((size_t)rp.G * 4);
+    a.prof = prof_buf.p;
+  }
   const size_t lds = ((size_t)rp.umax * (2 * 16 + 2) + ((rp.umax + 1) & ~1)) * 8 + 8 * 16 + (size_t)rp.umax * 4 + 64;
   // algorithmic bytes: y and e in slot order (8 + 8 B / row), the static slot words (1.4 B), one Vt row per run and per user
   TimedLaunch t(tm, s, kernel_class, 17.4 * rp.n_rows + 8.0 * KS * (double)rp.n_runs);
@@ -1454,6 +1475,22 @@ static inline void run_res_score(hipStream_t s, Timing &tm, ResPlan &rp, int ker
     throw Error(MFM_ERR_RUNTIME, "internal: no slot-order scorer for this plan");
 #undef MFM_RES_SCORE
   MFM_HIP_CHECK(hipGetLastError());
+  if (prof) {
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<unsigned long long> h((size_t)rp.G * 4);
+    MFM_HIP_CHECK(hipMemcpy(h.data(), prof_buf.p, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    double st = 0, lp = 0, en = 0;
+    for (int g = 0; g < rp.G; g++) {
+      t0 = std::min(t0, h[4 * g]);
+      t1 = std::max(t1, h[4 * g + 3]);
+      st += (double)(h[4 * g + 1] - h[4 * g]) * 0.01;
+      lp += (double)(h[4 * g + 2] - h[4 * g + 1]) * 0.01;
+      en += (double)(h[4 * g + 3] - h[4 * g + 2]) * 0.01;
+    }
+    std::fprintf(stderr, "[k_res_score] first start to last end %.1f us; per workgroup (mean): users staged %.1f, slots %.1f, reduction %.1f us\n",
+                 (double)(t1 - t0) * 0.01, st / rp.G, lp / rp.G, en / rp.G);
+  }
 }
 
 }  // namespace mfm
