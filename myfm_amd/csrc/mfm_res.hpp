@@ -1288,7 +1288,7 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   // algorithmic bytes of the launch: e read once (8 B) with its slot map (4 B) and the static slot words (11 bits), written
   // once (8 B: slot order, or scattered to eq); per sweep one 16-byte partial per (workgroup, item) run written and read,
   // its 8-byte list entry, its item read by both sweeps (2 x 4 B)
-  const double bytes = (8.0 + 4.0 + 1.4 + 8.0) * rp.n_rows + K * 48.0 * rp.n_runs;
+  const double bytes = (8.0 + (load_slots ? 0.0 : 4.0) + 1.4 + 8.0) * rp.n_rows + K * 48.0 * rp.n_runs;  // (slot order: no map)
   (void)lazy_store;
   hipLaunchKernelGGL(k_res_init_dv, dim3((rp.n_items + 256) / 256), dim3(256), 0, s,
                      w ? (const double *)nullptr : V + (int64_t)f_begin * D, rp.scols.p, rp.n_items,

@@ -29,7 +29,10 @@
 namespace mfm {
 
 constexpr int MT_N = 624, MT_M = 397;
-constexpr int RNG_CONSUME_THREADS = 1024;
+#ifndef MFM_RNG_CONSUME_THREADS
+#define MFM_RNG_CONSUME_THREADS 1024
+#endif
+constexpr int RNG_CONSUME_THREADS = MFM_RNG_CONSUME_THREADS;
 constexpr int RNG_ATT = 4;  // attempts per thread per batch
 #ifndef MFM_RNG_SPEC
 #define MFM_RNG_SPEC 16  // gamma draws evaluated speculatively at once (k_rng_consume), at most the number of waves
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(RNG_CONSUME_THREADS) void k_rng_consume(RngState *_
           wlen = WIN;
           __syncthreads();
         }
-        const int batch = min(MFM_RNG_SPEC, n_run - done_ops);
+        const int batch = min(MFM_RNG_SPEC < NW ? MFM_RNG_SPEC : NW, n_run - done_ops);
         if (wid < batch && (MFM_RNG_SPEC > 1 || lane == 0)) {
           const RngOp oj = ops[oi + done_ops + wid];
           RawReader g{raw, mask, p + (uint64_t)(6 * wid + 2 * lane), s_win, wbase, wlen};
