@@ -2522,6 +2522,293 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_step(SweepArgs a, ChainBatch B
   }
 }
 
+// ---- the whole batch sequence of a chain run as ONE launch (k_cb_persist) ------------------------------------------------------
+// k_cb_step and k_cb_hot alternate strictly (step b -> hot b -> step b + 1): 2 launches per batch, and at ~11 columns per batch a
+// kernel's start, its prologue round trips and the boundary's cache write-back / invalidate are most of its 16-20 us. Here
+// workgroup 0 is the hot walker and workgroups 1 .. CB_BUCKETS own the row ranges for the whole run; what used to be a kernel
+// boundary is a counter in device memory. Everything the two sides exchange (the batch's packed hot records, the per-range
+// partial statistics, the packed column scalars, the (old, new) pairs) is written with agent-scope stores and read with
+// agent-scope loads (write-through / L2-bypassing on gfx950: visible across XCDs without a fence), so no L2 is written back
+// or invalidated between batches and a range's block-row records stay in its workgroup's L2. The block-row records themselves
+// are only ever touched by their range's workgroup. Same arithmetic, same summation order as the two-launch form.
+struct CbSync {
+  unsigned long long step_done;  // += 1 per range workgroup and batch step
+  unsigned long long pad0[15];
+  unsigned long long hot_done;  // batches walked
+  unsigned long long pad1[15];
+};
+__device__ __forceinline__ double2 cb_ld2(const double2 *p) {
+  return make_double2(__hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                      __hip_atomic_load(&p->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void cb_st2(double2 *p, double2 v) {
+  __hip_atomic_store(&p->x, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double cb_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cb_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// thread 0 of a workgroup: wait until *w >= target (bounded: a lost partner sets *error and every later wait falls through)
+__device__ __forceinline__ void cb_wait(const unsigned long long *w, unsigned long long target, int *error, bool &dead) {
+  if (dead) return;
+  unsigned spins = 0;
+  while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 1023u) == 0u) {
+      if (spins > (1u << 23) || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead = true;
+        return;
+      }
+    }
+  }
+}
+
+struct CbPersistArgs {
+  const ChainBatch *batches;
+  int n_batches;
+  const int32_t *cols, *col_group;
+  const int32_t *bk_ptr, *bk_row, *bk_lcol, *hbk_ptr, *hot_rows;
+  const double *bk_x;
+  const int32_t *hot_ptr, *hot_slot;
+  const double *hot_x;
+  int max_hot, max_hot_ent;
+  double2 *oldnew_g;  // [MC]
+  double2 *part_g;    // [CB_BUCKETS][MC]
+  double2 *pack[2];   // packed hot records, by batch parity
+  double *colpack;    // [2][4 MC], by batch parity
+  CbSync *sync;       // zeroed before the launch
+  int *error;
+  int dbg;            // timing experiments only (MFM_CB_DBG; results are wrong when set): 1 no hot walk, 2 no hot-record staging,
+                      // 4 no cold statistics, 8 no cold update
+};
+
+template <class P>
+__global__ __launch_bounds__(CHAINB_NT) void k_cb_persist(SweepArgs a, CbPersistArgs g) {
+  extern __shared__ double2 lds_hot[];
+  constexpr int NT = CHAINB_NT, NW = NT / WAVE, MC = CHAINB_MAXCOLS, U = 4, NB = CB_BUCKETS;
+  constexpr int rec2_g = P::REC_DOUBLES / 2;
+  constexpr int rec2_l = P::REC_DOUBLES > 2 ? rec2_g + 1 : rec2_g;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int rec2_global = P::REC_DOUBLES > 2 ? a.rec2 : 1;
+  bool dead = false;
+  const ChainBatch none{0, 0, 0, 0, 0, 0, 0, 0};
+  if (blockIdx.x == 0) {
+    // ---- the hot walker -----------------------------------------------------------------------------------------------
+    double *c_old = (double *)(lds_hot + (size_t)g.max_hot * rec2_l);
+    double *c_z = c_old + MC, *c_lam = c_z + MC, *c_mu = c_lam + MC, *c_new = c_mu + MC;
+    double2 *csum = (double2 *)(c_new + MC);  // [MC]
+    double *h_x = (double *)(csum + MC);      // [max_hot_ent]
+    int *h_slot = (int *)(h_x + g.max_hot_ent);
+    int *h_ptr = h_slot + g.max_hot_ent;  // [MC + 1]
+    SweepArgs al = a;
+    al.state = lds_hot;
+    al.rec2 = rec2_l;
+    for (int bi = 0; bi < g.n_batches; bi++) {
+      const ChainBatch B = g.batches[bi];
+      double2 *hot_pack = g.pack[bi & 1];
+      const double *colpack = g.colpack + (size_t)(bi & 1) * 4 * MC;
+      // static parts of the batch while the range workgroups are still at work
+      const int hb0 = B.hot_b, hb1 = B.hot_e;
+      for (int i = tid; i < hb1 - hb0; i += NT) {
+        h_x[i] = g.hot_x[hb0 + i];
+        h_slot[i] = g.hot_slot[hb0 + i];
+      }
+      if (tid <= B.ncols) h_ptr[tid] = g.hot_ptr[B.col0 + tid] - hb0;
+      if (tid == 0) cb_wait(&g.sync->step_done, (unsigned long long)NB * (bi + 1), g.error, dead);
+      __syncthreads();
+      if (tid < B.ncols) {
+        c_old[tid] = cb_ld(colpack + tid);
+        c_z[tid] = cb_ld(colpack + MC + tid);
+        c_lam[tid] = cb_ld(colpack + 2 * MC + tid);
+        c_mu[tid] = cb_ld(colpack + 3 * MC + tid);
+      }
+      for (int i = tid; i < ((g.dbg & 2) ? 0 : B.n_hot * rec2_g); i += NT) {
+        const int slot = i / rec2_g, w = i - slot * rec2_g;
+        lds_hot[(size_t)slot * rec2_l + w] = cb_ld2(hot_pack + i);
+      }
+      if (tid < B.ncols) {
+        double S1 = 0.0, S2 = 0.0;
+        for (int w0 = 0; w0 < NB; w0 += 8) {  // range order: deterministic (eight loads in flight)
+          double2 q[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) q[u] = cb_ld2(g.part_g + (size_t)(w0 + u) * MC + tid);
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            S1 += q[u].x;
+            S2 += q[u].y;
+          }
+        }
+        csum[tid] = make_double2(S1, S2);
+      }
+      __syncthreads();
+      if (wv == 0 && !(g.dbg & 1)) {
+        for (int c = 0; c < B.ncols; c++) {
+          const double S1 = csum[c].x, S2 = csum[c].y;
+          const double old = c_old[c];
+          const int hb = h_ptr[c], he = h_ptr[c + 1];
+          const double fresh = hot_column<P>(a, al, h_x, h_slot, hb, he, lane, S1, S2, old, c_lam[c], c_mu[c], c_z[c]);
+          if (lane == 0) c_new[c] = fresh;
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        }
+      }
+      if ((g.dbg & 1) && tid < B.ncols) c_new[tid] = c_old[tid];
+      __syncthreads();
+      for (int i = tid; i < ((g.dbg & 2) ? 0 : B.n_hot * rec2_g); i += NT) {
+        const int slot = i / rec2_g, w = i - slot * rec2_g;
+        cb_st2(hot_pack + i, lds_hot[(size_t)slot * rec2_l + w]);
+      }
+      if (tid < B.ncols) {
+        a.theta[g.cols[B.col0 + tid]] = c_new[tid];
+        cb_st2(g.oldnew_g + tid, make_double2(c_old[tid], c_new[tid]));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&g.sync->hot_done, (unsigned long long)(bi + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  // ---- a row range: cold update of batch bi - 1, cold statistics of batch bi ---------------------------------------------
+  const int w = (int)blockIdx.x - 1;
+  double2 *on = lds_hot;                     // [MC]
+  double *c_old = (double *)(on + MC);       // [MC]
+  double2 *part = (double2 *)(c_old + MC);   // [MC * NW]
+  for (int bi = 0; bi <= g.n_batches; bi++) {
+    const int ip = bi - 1, in_ = bi;
+    const ChainBatch Bp = bi > 0 ? g.batches[bi - 1] : none;
+    const ChainBatch Bn = bi < g.n_batches ? g.batches[bi] : none;
+    const double2 *hot_pack_p = g.pack[(bi + 1) & 1];
+    double2 *hot_pack_n = g.pack[bi & 1];
+    if (tid < Bn.ncols) {
+      const int j = g.cols[Bn.col0 + tid];
+      const double th = a.theta[j];
+      c_old[tid] = th;
+      if (w == 0) {  // the hot walk's per-column scalars, packed
+        double *colpack = g.colpack + (size_t)(bi & 1) * 4 * MC;
+        const int gr = g.col_group[Bn.col0 + tid];
+        cb_st(colpack + tid, th);
+        cb_st(colpack + MC + tid, a.z[j]);
+        cb_st(colpack + 2 * MC + tid, a.lambda[gr]);
+        cb_st(colpack + 3 * MC + tid, a.mu[gr]);
+      }
+    }
+    for (int i = tid; i < MC * NW; i += NT) part[i] = make_double2(0.0, 0.0);
+    const int cbn = Bn.ncols > 0 ? g.bk_ptr[in_ * (NB + 1) + w] : 0, cen = Bn.ncols > 0 ? g.bk_ptr[in_ * (NB + 1) + w + 1] : 0;
+    int lc0[U], row0[U];
+    double xv0[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int p = cbn + wv * WAVE * U + u * WAVE + lane;
+      lc0[u] = -1 - lane;
+      row0[u] = -1;
+      xv0[u] = 0.0;
+      if (p < cen) {
+        lc0[u] = g.bk_lcol[p];
+        row0[u] = g.bk_row[p];
+        xv0[u] = g.bk_x[p];
+      }
+    }
+    int hbp = 0, hep = 0, cbp = 0, cep = 0;
+    if (Bp.ncols > 0) {
+      hbp = g.hbk_ptr[ip * (NB + 1) + w];
+      hep = g.hbk_ptr[ip * (NB + 1) + w + 1];
+      cbp = g.bk_ptr[ip * (NB + 1) + w];
+      cep = g.bk_ptr[ip * (NB + 1) + w + 1];
+      if (tid == 0) cb_wait(&g.sync->hot_done, (unsigned long long)bi, g.error, dead);
+    }
+    __syncthreads();
+    if (tid < Bp.ncols) on[tid] = cb_ld2(g.oldnew_g + tid);
+    __syncthreads();
+    if (Bp.ncols > 0) {
+      for (int i = hbp * rec2_g + tid; i < hep * rec2_g; i += NT) {
+        const int slot = i / rec2_g, q = i - slot * rec2_g;
+        ((double2 *)a.state)[(int64_t)g.hot_rows[Bp.hot_row0 + slot] * rec2_global + q] = cb_ld2(hot_pack_p + i);
+      }
+      for (int base = cbp + tid; base < ((g.dbg & 8) ? 0 : cep); base += NT * U) {
+        int lc[U], row[U];
+        double xv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int p = base + u * NT;
+          row[u] = -1;
+          lc[u] = 0;
+          xv[u] = 0.0;
+          if (p < cep) {
+            lc[u] = g.bk_lcol[p];
+            row[u] = g.bk_row[p];
+            xv[u] = g.bk_x[p];
+          }
+        }
+        typename P::St st[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (row[u] >= 0) st[u] = P::load(a, row[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (row[u] >= 0) P::apply(a, row[u], xv[u], st[u], on[lc[u]].x, on[lc[u]].y);
+      }
+    }
+    __threadfence_block();
+    __syncthreads();  // this range's records are up to date for everything below (the only reader of them is this workgroup)
+    if (Bn.ncols > 0) {
+      const int hb = g.hbk_ptr[in_ * (NB + 1) + w], he = g.hbk_ptr[in_ * (NB + 1) + w + 1];
+      for (int i = hb * rec2_g + tid; i < he * rec2_g; i += NT) {
+        const int slot = i / rec2_g, q = i - slot * rec2_g;
+        cb_st2(hot_pack_n + i, ((const double2 *)a.state)[(int64_t)g.hot_rows[Bn.hot_row0 + slot] * rec2_global + q]);
+      }
+      const int cb = cbn, ce = (g.dbg & 4) ? 0 : cen;
+      for (int base = cb + wv * WAVE * U; base < ce; base += NW * WAVE * U) {
+        int lc[U], row[U];
+        double xv[U];
+        const bool first = base == cb + wv * WAVE * U;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int p = base + u * WAVE + lane;
+          lc[u] = first ? lc0[u] : -1 - lane;
+          row[u] = first ? row0[u] : -1;
+          xv[u] = first ? xv0[u] : 0.0;
+          if (!first && p < ce) {
+            lc[u] = g.bk_lcol[p];
+            row[u] = g.bk_row[p];
+            xv[u] = g.bk_x[p];
+          }
+        }
+        typename P::St st[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (row[u] >= 0) st[u] = P::load(a, row[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          if (base + u * WAVE >= ce) break;  // wave-uniform
+          double s1 = 0.0, s2 = 0.0;
+          if (row[u] >= 0) P::stats(xv[u], st[u], c_old[lc[u]], s1, s2);
+          const int lp = dpp_i32<0x138, 0xf>(lc[u], 0), ln = dpp_i32<0x130, 0xf>(lc[u], 0);
+          const bool head = lane == 0 || lp != lc[u], tail = lane == 63 || ln != lc[u];
+          int f = head ? 1 : 0;
+          wave_segscan2(s1, s2, f);
+          if (row[u] >= 0 && tail) {  // one lane per column of this tile; a wave adds its tiles in program order
+            double2 &q = part[lc[u] * NW + wv];
+            q.x += s1;
+            q.y += s2;
+          }
+        }
+      }
+      __syncthreads();
+      if (tid < MC) {
+        double S1 = 0.0, S2 = 0.0;
+        if (tid < Bn.ncols)
+          for (int k = 0; k < NW; k++) {  // wave order: deterministic
+            S1 += part[tid * NW + k].x;
+            S2 += part[tid * NW + k].y;
+          }
+        cb_st2(g.part_g + (size_t)w * MC + tid, make_double2(S1, S2));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(&g.sync->step_done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---- q-cache build: q = X v_f (+ block contributions)  (FMTrainer.hpp:320-340), CSR SpMV --------
 // The first MAX_BLOCKS relation blocks travel in the kernel arguments; a design with more (BaseFMTrainer.hpp:58-68 takes any
 // vector of blocks) passes the rest through device arrays (x*: index b - MAX_BLOCKS).

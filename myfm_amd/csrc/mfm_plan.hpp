@@ -1212,6 +1212,7 @@ struct LongScratch {
   DevBuf<double> cb_colpack;           // ... the batch's per-column scalars (old coefficient, variate, lambda, mu), packed
   DevBuf<double2> cb_hot, cb_hot2;     // ... and the batch's hot records, packed (k_cb_stats -> k_cb_hot -> k_cb_apply; two: k_cb_step
                                        //     reads the previous batch's while it packs the next one's)
+  DevBuf<CbSync> cb_sync;              // ... the counters of the one-launch form (k_cb_persist), zeroed before every launch
   DevBuf<double2> dv_col;      // two-field pass: (delta of this factor, coefficient of the next) per second-level column
   void reserve_cols(int64_t n_cols) {
     if ((size_t)n_cols > oldnew_col.n) {
@@ -1323,6 +1324,8 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
                                             (int)CHAIN_LDS_MAX));
           MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_cb_hot<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)CHAIN_LDS_MAX));
+          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_cb_persist<P>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)CHAIN_LDS_MAX));
           raised.mark();
         }
         // batches with many cold entries: cold statistics / updates as grid launches (one CU cannot stream them)
@@ -1343,8 +1346,44 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
           if (C.bucketed) {
             // two launches per batch: k_cb_step = cold update of the batch before + cold statistics of this one, by row range
             if (ls.cb_hot2.n < hot16) ls.cb_hot2.alloc(hot16);
-            if (ls.cb_colpack.n < (size_t)4 * CHAINB_MAXCOLS) ls.cb_colpack.alloc((size_t)4 * CHAINB_MAXCOLS);
+            if (ls.cb_colpack.n < (size_t)8 * CHAINB_MAXCOLS) ls.cb_colpack.alloc((size_t)8 * CHAINB_MAXCOLS);
             if (ls.cb_part.n < (size_t)CB_BUCKETS * CHAINB_MAXCOLS) ls.cb_part.alloc((size_t)CB_BUCKETS * CHAINB_MAXCOLS);
+            static const bool persist = !std::getenv("MFM_NO_CB_PERSIST");
+            if (persist && ls.error.p) {
+              // the whole batch sequence as one launch: the hot walker + CB_BUCKETS row-range workgroups, counters instead of
+              // kernel boundaries
+              if (!ls.cb_sync.p) ls.cb_sync.alloc(1);
+              MFM_HIP_CHECK(hipMemsetAsync(ls.cb_sync.p, 0, sizeof(CbSync), s));
+              CbPersistArgs g;
+              g.batches = C.batches.p;
+              g.n_batches = C.n_batches;
+              g.cols = C.cols.p;
+              g.col_group = C.col_group.p;
+              g.bk_ptr = C.bk_ptr.p;
+              g.bk_row = C.bk_row.p;
+              g.bk_lcol = C.bk_lcol.p;
+              g.hbk_ptr = C.hbk_ptr.p;
+              g.hot_rows = C.hot_rows.p;
+              g.bk_x = C.bk_x.p;
+              g.hot_ptr = C.hot_ptr.p;
+              g.hot_slot = C.hot_slot.p;
+              g.hot_x = C.hot_x.p;
+              g.max_hot = std::max(C.max_hot, 1);
+              g.max_hot_ent = mhe;
+              g.oldnew_g = ls.cb_oldnew.p;
+              g.part_g = ls.cb_part.p;
+              g.pack[0] = ls.cb_hot.p;
+              g.pack[1] = ls.cb_hot2.p;
+              g.colpack = ls.cb_colpack.p;
+              g.sync = ls.cb_sync.p;
+              g.error = ls.error.p;
+              static const int cb_dbg = std::getenv("MFM_CB_DBG") ? std::atoi(std::getenv("MFM_CB_DBG")) : 0;
+              g.dbg = cb_dbg;
+              const size_t lds_range = (size_t)CHAINB_MAXCOLS * (sizeof(double2) + sizeof(double)) +
+                                       (size_t)CHAINB_MAXCOLS * (CHAINB_NT / WAVE) * sizeof(double2);
+              hipLaunchKernelGGL((k_cb_persist<P>), dim3(CB_BUCKETS + 1), dim3(CHAINB_NT), std::max(lds_h, lds_range), s, a, g);
+              continue;
+            }
             const ChainBatch none{0, 0, 0, 0, 0, 0, 0, 0};
             double2 *pack[2] = {ls.cb_hot.p, ls.cb_hot2.p};
             for (int bi = 0; bi <= C.n_batches; bi++) {
