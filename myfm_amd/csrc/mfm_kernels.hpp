@@ -2568,6 +2568,7 @@ struct CbPersistArgs {
   int n_batches;
   const int32_t *cols, *col_group;
   const int32_t *bk_ptr, *bk_row, *bk_lcol, *hbk_ptr, *hot_rows;
+  const int32_t *bk_cls;  // [n_batches][CB_BUCKETS][3]: class boundaries c1, c2, c3 inside a (batch, range)
   const double *bk_x;
   const int32_t *hot_ptr, *hot_slot;
   const double *hot_x;
@@ -2667,85 +2668,149 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_persist(SweepArgs a, CbPersist
     }
     return;
   }
-  // ---- a row range: cold update of batch bi - 1, cold statistics of batch bi ---------------------------------------------
+  // ---- a row range -----------------------------------------------------------------------------------------------------------
+  // Per batch b the range's cold entries come in four classes (ChainRun::build_batched): the row is / is not touched by batch
+  // b - 1 ("statistics near / far") and is / is not touched by batch b + 1 ("update near / far"), stored in the order
+  // [far,near | near,near | near,far | far,far] (statistics,update), boundaries c1 c2 c3 in bk_cls. Only the near parts sit
+  // between the hot walker's two hand-overs:
+  //   wait hot(b - 1) -> update near(b - 1) + hot records back -> statistics near(b) + hot records out -> signal
+  //   and, while the hot walker is busy with batch b:  update far(b - 1) -> statistics far(b + 1)
+  // (a far row of batch b + 1 is not touched by batch b at all, so its record is final once batch b - 1 is applied).
   const int w = (int)blockIdx.x - 1;
-  double2 *on = lds_hot;                     // [MC]
-  double *c_old = (double *)(on + MC);       // [MC]
-  double2 *part = (double2 *)(c_old + MC);   // [MC * NW]
-  for (int bi = 0; bi <= g.n_batches; bi++) {
-    const int ip = bi - 1, in_ = bi;
-    const ChainBatch Bp = bi > 0 ? g.batches[bi - 1] : none;
-    const ChainBatch Bn = bi < g.n_batches ? g.batches[bi] : none;
-    const double2 *hot_pack_p = g.pack[(bi + 1) & 1];
-    double2 *hot_pack_n = g.pack[bi & 1];
-    if (tid < Bn.ncols) {
-      const int j = g.cols[Bn.col0 + tid];
-      const double th = a.theta[j];
-      c_old[tid] = th;
-      if (w == 0) {  // the hot walk's per-column scalars, packed
-        double *colpack = g.colpack + (size_t)(bi & 1) * 4 * MC;
-        const int gr = g.col_group[Bn.col0 + tid];
-        cb_st(colpack + tid, th);
-        cb_st(colpack + MC + tid, a.z[j]);
-        cb_st(colpack + 2 * MC + tid, a.lambda[gr]);
-        cb_st(colpack + 3 * MC + tid, a.mu[gr]);
+  double2 *on = lds_hot;                         // [MC]
+  double *c_oldb = (double *)(on + MC);          // [2][MC], by batch parity
+  double2 *part = (double2 *)(c_oldb + 2 * MC);  // [MC * NW]
+  for (int i = tid; i < MC * NW; i += NT) part[i] = make_double2(0.0, 0.0);
+  if (g.n_batches > 0) {
+    const ChainBatch B0 = g.batches[0];
+    if (tid < B0.ncols) c_oldb[tid] = a.theta[g.cols[B0.col0 + tid]];
+  }
+  __syncthreads();
+  // statistics of the entries [lo, hi) into part (pre: the first tile of this wave, already in registers)
+  auto stats_range = [&](int lo, int hi, const double *c_old, bool pre, const int *lc0, const int *row0, const double *xv0) {
+    for (int base = lo + wv * WAVE * U; base < hi; base += NW * WAVE * U) {
+      int lc[U], row[U];
+      double xv[U];
+      const bool first = pre && base == lo + wv * WAVE * U;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int p = base + u * WAVE + lane;
+        lc[u] = first ? lc0[u] : -1 - lane;
+        row[u] = first ? row0[u] : -1;
+        xv[u] = first ? xv0[u] : 0.0;
+        if (!first && p < hi) {
+          lc[u] = g.bk_lcol[p];
+          row[u] = g.bk_row[p];
+          xv[u] = g.bk_x[p];
+        }
+      }
+      typename P::St st[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (row[u] >= 0) st[u] = P::load(a, row[u]);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (base + u * WAVE >= hi) break;  // wave-uniform
+        double s1 = 0.0, s2 = 0.0;
+        if (row[u] >= 0) P::stats(xv[u], st[u], c_old[lc[u]], s1, s2);
+        const int lp = dpp_i32<0x138, 0xf>(lc[u], 0), ln = dpp_i32<0x130, 0xf>(lc[u], 0);
+        const bool head = lane == 0 || lp != lc[u], tail = lane == 63 || ln != lc[u];
+        int f = head ? 1 : 0;
+        wave_segscan2(s1, s2, f);
+        if (row[u] >= 0 && tail) {  // one lane per column of this tile; a wave adds its tiles in program order
+          double2 &q = part[lc[u] * NW + wv];
+          q.x += s1;
+          q.y += s2;
+        }
       }
     }
-    for (int i = tid; i < MC * NW; i += NT) part[i] = make_double2(0.0, 0.0);
-    const int cbn = Bn.ncols > 0 ? g.bk_ptr[in_ * (NB + 1) + w] : 0, cen = Bn.ncols > 0 ? g.bk_ptr[in_ * (NB + 1) + w + 1] : 0;
+  };
+  auto update_range = [&](int lo, int hi) {
+    for (int base = lo + tid; base < hi; base += NT * U) {
+      int lc[U], row[U];
+      double xv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int p = base + u * NT;
+        row[u] = -1;
+        lc[u] = 0;
+        xv[u] = 0.0;
+        if (p < hi) {
+          lc[u] = g.bk_lcol[p];
+          row[u] = g.bk_row[p];
+          xv[u] = g.bk_x[p];
+        }
+      }
+      typename P::St st[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (row[u] >= 0) st[u] = P::load(a, row[u]);
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (row[u] >= 0) P::apply(a, row[u], xv[u], st[u], on[lc[u]].x, on[lc[u]].y);
+    }
+  };
+  for (int bi = 0; bi <= g.n_batches; bi++) {
+    const int ip = bi - 1, in_ = bi, iq = bi + 1;
+    const ChainBatch Bp = bi > 0 ? g.batches[bi - 1] : none;
+    const ChainBatch Bn = bi < g.n_batches ? g.batches[bi] : none;
+    const ChainBatch Bq = bi + 1 < g.n_batches ? g.batches[bi + 1] : none;
+    const double2 *hot_pack_p = g.pack[(bi + 1) & 1];
+    double2 *hot_pack_n = g.pack[bi & 1];
+    const double *c_old = c_oldb + (size_t)(bi & 1) * MC;
+    if (w == 0 && tid < Bn.ncols) {  // the hot walk's per-column scalars, packed
+      const int j = g.cols[Bn.col0 + tid];
+      double *colpack = g.colpack + (size_t)(bi & 1) * 4 * MC;
+      const int gr = g.col_group[Bn.col0 + tid];
+      cb_st(colpack + tid, c_old[tid]);
+      cb_st(colpack + MC + tid, a.z[j]);
+      cb_st(colpack + 2 * MC + tid, a.lambda[gr]);
+      cb_st(colpack + 3 * MC + tid, a.mu[gr]);
+    }
+    // batch bi: statistics near = [n1, n2) and [n2, n3); the first tile is requested before the wait
+    // (two calls: each class is ordered by column, and a wave tile must not hold two runs of one column -- its tail lanes
+    // add to the column's LDS partial in one instruction)
+    int n1 = 0, n2 = 0, n3 = 0;
+    if (Bn.ncols > 0) {
+      n1 = g.bk_cls[(in_ * NB + w) * 3 + 0];
+      n2 = g.bk_cls[(in_ * NB + w) * 3 + 1];
+      n3 = g.bk_cls[(in_ * NB + w) * 3 + 2];
+    }
+    if (g.dbg & 4) n2 = n3 = n1;
     int lc0[U], row0[U];
     double xv0[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const int p = cbn + wv * WAVE * U + u * WAVE + lane;
+      const int p = n1 + wv * WAVE * U + u * WAVE + lane;
       lc0[u] = -1 - lane;
       row0[u] = -1;
       xv0[u] = 0.0;
-      if (p < cen) {
+      if (p < n2) {
         lc0[u] = g.bk_lcol[p];
         row0[u] = g.bk_row[p];
         xv0[u] = g.bk_x[p];
       }
     }
-    int hbp = 0, hep = 0, cbp = 0, cep = 0;
+    int hbp = 0, hep = 0, p0 = 0, p2 = 0, p4 = 0;
     if (Bp.ncols > 0) {
       hbp = g.hbk_ptr[ip * (NB + 1) + w];
       hep = g.hbk_ptr[ip * (NB + 1) + w + 1];
-      cbp = g.bk_ptr[ip * (NB + 1) + w];
-      cep = g.bk_ptr[ip * (NB + 1) + w + 1];
+      p0 = g.bk_ptr[ip * (NB + 1) + w];
+      p4 = g.bk_ptr[ip * (NB + 1) + w + 1];
+      p2 = g.bk_cls[(ip * NB + w) * 3 + 1];
+      if (g.dbg & 8) p0 = p2 = p4 = 0;
       if (tid == 0) cb_wait(&g.sync->hot_done, (unsigned long long)bi, g.error, dead);
     }
     __syncthreads();
     if (tid < Bp.ncols) on[tid] = cb_ld2(g.oldnew_g + tid);
     __syncthreads();
-    if (Bp.ncols > 0) {
+    if (Bp.ncols > 0) {  // update near: the hot records back to their rows, the entries whose row batch bi touches
       for (int i = hbp * rec2_g + tid; i < hep * rec2_g; i += NT) {
         const int slot = i / rec2_g, q = i - slot * rec2_g;
         ((double2 *)a.state)[(int64_t)g.hot_rows[Bp.hot_row0 + slot] * rec2_global + q] = cb_ld2(hot_pack_p + i);
       }
-      for (int base = cbp + tid; base < ((g.dbg & 8) ? 0 : cep); base += NT * U) {
-        int lc[U], row[U];
-        double xv[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const int p = base + u * NT;
-          row[u] = -1;
-          lc[u] = 0;
-          xv[u] = 0.0;
-          if (p < cep) {
-            lc[u] = g.bk_lcol[p];
-            row[u] = g.bk_row[p];
-            xv[u] = g.bk_x[p];
-          }
-        }
-        typename P::St st[U];
-#pragma unroll
-        for (int u = 0; u < U; u++)
-          if (row[u] >= 0) st[u] = P::load(a, row[u]);
-#pragma unroll
-        for (int u = 0; u < U; u++)
-          if (row[u] >= 0) P::apply(a, row[u], xv[u], st[u], on[lc[u]].x, on[lc[u]].y);
-      }
+      update_range(p0, p2);
+      if (g.dbg & 16) update_range(p2, p4);
     }
     __threadfence_block();
     __syncthreads();  // this range's records are up to date for everything below (the only reader of them is this workgroup)
@@ -2755,43 +2820,8 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_persist(SweepArgs a, CbPersist
         const int slot = i / rec2_g, q = i - slot * rec2_g;
         cb_st2(hot_pack_n + i, ((const double2 *)a.state)[(int64_t)g.hot_rows[Bn.hot_row0 + slot] * rec2_global + q]);
       }
-      const int cb = cbn, ce = (g.dbg & 4) ? 0 : cen;
-      for (int base = cb + wv * WAVE * U; base < ce; base += NW * WAVE * U) {
-        int lc[U], row[U];
-        double xv[U];
-        const bool first = base == cb + wv * WAVE * U;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          const int p = base + u * WAVE + lane;
-          lc[u] = first ? lc0[u] : -1 - lane;
-          row[u] = first ? row0[u] : -1;
-          xv[u] = first ? xv0[u] : 0.0;
-          if (!first && p < ce) {
-            lc[u] = g.bk_lcol[p];
-            row[u] = g.bk_row[p];
-            xv[u] = g.bk_x[p];
-          }
-        }
-        typename P::St st[U];
-#pragma unroll
-        for (int u = 0; u < U; u++)
-          if (row[u] >= 0) st[u] = P::load(a, row[u]);
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          if (base + u * WAVE >= ce) break;  // wave-uniform
-          double s1 = 0.0, s2 = 0.0;
-          if (row[u] >= 0) P::stats(xv[u], st[u], c_old[lc[u]], s1, s2);
-          const int lp = dpp_i32<0x138, 0xf>(lc[u], 0), ln = dpp_i32<0x130, 0xf>(lc[u], 0);
-          const bool head = lane == 0 || lp != lc[u], tail = lane == 63 || ln != lc[u];
-          int f = head ? 1 : 0;
-          wave_segscan2(s1, s2, f);
-          if (row[u] >= 0 && tail) {  // one lane per column of this tile; a wave adds its tiles in program order
-            double2 &q = part[lc[u] * NW + wv];
-            q.x += s1;
-            q.y += s2;
-          }
-        }
-      }
+      stats_range(n1, n2, c_old, true, lc0, row0, xv0);
+      stats_range(n2, n3, c_old, false, nullptr, nullptr, nullptr);
       __syncthreads();
       if (tid < MC) {
         double S1 = 0.0, S2 = 0.0;
@@ -2799,6 +2829,7 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_persist(SweepArgs a, CbPersist
           for (int k = 0; k < NW; k++) {  // wave order: deterministic
             S1 += part[tid * NW + k].x;
             S2 += part[tid * NW + k].y;
+            part[tid * NW + k] = make_double2(0.0, 0.0);
           }
         cb_st2(g.part_g + (size_t)w * MC + tid, make_double2(S1, S2));
       }
@@ -2806,6 +2837,22 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_persist(SweepArgs a, CbPersist
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(&g.sync->step_done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // ---- while the hot walker is busy with batch bi ----
+    if (Bp.ncols > 0 && !(g.dbg & 16)) update_range(p2, p4);  // update far: rows batch bi does not touch
+    __threadfence_block();
+    __syncthreads();
+    if (Bq.ncols > 0) {  // statistics far of batch bi + 1: rows batch bi does not touch
+      double *c_oldq = c_oldb + (size_t)(iq & 1) * MC;
+      if (tid < Bq.ncols) c_oldq[tid] = a.theta[g.cols[Bq.col0 + tid]];
+      const int q0 = g.bk_ptr[iq * (NB + 1) + w], q4 = g.bk_ptr[iq * (NB + 1) + w + 1];
+      const int q1 = g.bk_cls[(iq * NB + w) * 3 + 0], q3 = g.bk_cls[(iq * NB + w) * 3 + 2];
+      __syncthreads();
+      if (!(g.dbg & 4)) {
+        stats_range(q3, q4, c_oldq, false, nullptr, nullptr, nullptr);
+        stats_range(q0, q1, c_oldq, false, nullptr, nullptr, nullptr);
+      }
+    }
+    __syncthreads();
   }
 }
 

@@ -114,7 +114,7 @@ struct ChainRun {
   DevBuf<double> cold_x, hot_x;
   // row-bucketed copies for k_cb_step: per batch the cold entries ordered by (row range, column) and the hot slots' row ranges
   bool bucketed = false;
-  DevBuf<int32_t> bk_ptr, bk_row, bk_lcol, hbk_ptr;
+  DevBuf<int32_t> bk_ptr, bk_row, bk_lcol, hbk_ptr, bk_cls;
   DevBuf<double> bk_x;
   mutable DevBuf<int32_t> col_group;             // group index of every chain column (filled at the first launch)
   mutable const int32_t *col_group_of = nullptr;  // ... from this group array
@@ -213,30 +213,55 @@ struct ChainRun {
       constexpr int NB = CB_BUCKETS;
       auto bucket = [&](int32_t r) { return (int)(((int64_t)r * NB) / std::max<int64_t>(n_rows, 1)); };
       std::vector<int32_t> bptr((size_t)n_batches * (NB + 1), 0), hbptr((size_t)n_batches * (NB + 1), 0);
+      std::vector<int32_t> bcls((size_t)n_batches * NB * 3, 0);
       std::vector<int32_t> brow(crow.size()), blcol(crow.size());
       std::vector<double> bx(crow.size());
+      // Classes of a cold entry of batch b (k_cb_persist): "statistics near" = its row is touched by batch b - 1 (every entry of
+      // the first batch), "update near" = its row is touched by batch b + 1 (every entry of the last batch). Inside a (batch,
+      // range) the entries are ordered by class -- (far, near), (near, near), (near, far), (far, far) as (statistics, update) --
+      // and by column inside a class, so that "update near", "statistics near" and "update far" are contiguous and "statistics
+      // far" is the two ends.
+      std::vector<int32_t> seen_prev((size_t)n_rows, -1), seen_next((size_t)n_rows, -1);
+      // (the two-launch form, MFM_NO_CB_PERSIST, walks a range as ONE column-ordered run: a single class)
+      const int split = std::getenv("MFM_NO_CB_PERSIST") ? 0 : std::getenv("MFM_CB_SPLIT") ? std::atoi(std::getenv("MFM_CB_SPLIT")) : 3;  // (bit 0: statistics, bit 1: update)
+      auto stamp = [&](std::vector<int32_t> &seen, int b) {
+        const ChainBatch &B = bt[b];
+        for (int p = B.cold_b; p < B.cold_e; p++) seen[crow[p]] = b;
+        for (int k = 0; k < B.n_hot; k++) seen[hrows[B.hot_row0 + k]] = b;
+      };
       for (int b = 0; b < n_batches; b++) {
         const ChainBatch &B = bt[b];
         const int cb = B.cold_b, ce = B.cold_e;
-        int cntb[NB + 1] = {0};
-        for (int p = cb; p < ce; p++) cntb[bucket(crow[p]) + 1]++;
+        if (b + 1 < n_batches) stamp(seen_next, b + 1);
+        auto order_of = [&](int32_t r) {
+          const bool sn = b == 0 || seen_prev[r] == b - 1 || !(split & 1), un = b + 1 == n_batches || seen_next[r] == b + 1 || !(split & 2);
+          return sn ? (un ? 1 : 2) : (un ? 0 : 3);
+        };
+        int cntb[NB * 4 + 1] = {0};
+        for (int p = cb; p < ce; p++) cntb[bucket(crow[p]) * 4 + order_of(crow[p]) + 1]++;
         int32_t *bp = bptr.data() + (size_t)b * (NB + 1);
-        bp[0] = cb;
-        for (int k = 0; k < NB; k++) bp[k + 1] = bp[k] + cntb[k + 1];
-        int cur[NB];
-        for (int k = 0; k < NB; k++) cur[k] = bp[k];
-        for (int p = cb; p < ce; p++) {  // (entries arrive ordered by column: stable => (range, column) order)
-          const int q = cur[bucket(crow[p])]++;
+        int cur[NB * 4];
+        cur[0] = cb;
+        for (int k = 1; k < NB * 4; k++) cur[k] = cur[k - 1] + cntb[k];
+        for (int k = 0; k < NB; k++) {
+          bp[k] = cur[k * 4];
+          for (int q = 0; q < 3; q++) bcls[((size_t)b * NB + k) * 3 + q] = cur[k * 4 + q + 1];
+        }
+        bp[NB] = ce;
+        for (int p = cb; p < ce; p++) {  // (entries arrive ordered by column: stable => (range, class, column) order)
+          const int q = cur[bucket(crow[p]) * 4 + order_of(crow[p])]++;
           brow[q] = crow[p];
           blcol[q] = clcol[p];
           bx[q] = cx[p];
         }
+        stamp(seen_prev, b);
         int32_t *hp = hbptr.data() + (size_t)b * (NB + 1);
         int hc[NB + 1] = {0};
         for (int k = 0; k < B.n_hot; k++) hc[bucket(hrows[B.hot_row0 + k]) + 1]++;
         hp[0] = 0;
         for (int k = 0; k < NB; k++) hp[k + 1] = hp[k] + hc[k + 1];  // (slots are in ascending row order)
       }
+      bk_cls.upload(bcls);
       bk_ptr.upload(bptr);
       hbk_ptr.upload(hbptr);
       bk_row.upload(brow);
@@ -1363,6 +1388,7 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
               g.bk_row = C.bk_row.p;
               g.bk_lcol = C.bk_lcol.p;
               g.hbk_ptr = C.hbk_ptr.p;
+              g.bk_cls = C.bk_cls.p;
               g.hot_rows = C.hot_rows.p;
               g.bk_x = C.bk_x.p;
               g.hot_ptr = C.hot_ptr.p;
@@ -1379,7 +1405,7 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
               g.error = ls.error.p;
               static const int cb_dbg = std::getenv("MFM_CB_DBG") ? std::atoi(std::getenv("MFM_CB_DBG")) : 0;
               g.dbg = cb_dbg;
-              const size_t lds_range = (size_t)CHAINB_MAXCOLS * (sizeof(double2) + sizeof(double)) +
+              const size_t lds_range = (size_t)CHAINB_MAXCOLS * (sizeof(double2) + 2 * sizeof(double)) +
                                        (size_t)CHAINB_MAXCOLS * (CHAINB_NT / WAVE) * sizeof(double2);
               hipLaunchKernelGGL((k_cb_persist<P>), dim3(CB_BUCKETS + 1), dim3(CHAINB_NT), std::max(lds_h, lds_range), s, a, g);
               continue;
