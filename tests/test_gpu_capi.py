@@ -485,6 +485,33 @@ def test_conflict_batched_chain(oracle, capi, monkeypatch, design, grid):
     np.testing.assert_allclose(c.get_e(), t.e(X.shape[0]), rtol=1e-7, atol=1e-7)
 
 
+@pytest.mark.parametrize("per_row", [3, 6])
+def test_conflict_batched_chain_many_batches(oracle, capi, monkeypatch, per_row):
+    # the one-launch form of the grid-batched chains (k_cb_persist) classes a batch's cold entries by whether the batch before /
+    # after touches their row and moves the "far" statistics / updates off the hand-over path; that only shows with three or
+    # more batches. A hot-row cap of 64 cuts this 48-column main table into ~20-40 batches of one to three columns.
+    monkeypatch.setenv("MFM_CHAIN_FORCE_BATCHED", "1")
+    monkeypatch.setenv("MFM_CHAIN_GRID_MIN", "0")
+    monkeypatch.setenv("MFM_CHAIN_HOT_CAP", "64")
+    rng = np.random.default_rng(11 + per_row)
+    n, d, rank = 6000, 48, 3
+    cols = np.stack([rng.choice(d, size=per_row, replace=False) for _ in range(n)])
+    vals = np.round(rng.uniform(-1.5, 1.5, size=(n, per_row)), 2)
+    vals[vals == 0.0] = 0.5
+    X = sps.csr_matrix((vals.ravel(), cols.ravel(), np.arange(0, n * per_row + 1, per_row)), shape=(n, d))
+    X.sort_indices()
+    y = ds.fm_score(X, 0.3, rng.normal(size=d) * 0.3, rng.normal(size=(d, rank)) * 0.3) + rng.normal(size=n) * 0.3
+    gi = np.zeros(d, dtype=np.int32)
+    t, c, _ = _pair(oracle, capi, X, y, gi, rank, ())
+    drv = CapiGibbs(c, t.clone(), n, gi)
+    for it in range(3):
+        t.step()
+        drv.step()
+        np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(c.get_state()[1], t.fm()[1], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-7, atol=1e-7)
+
+
 def test_block_only_design_no_main_columns(oracle, capi):
     # X=None => (N, 0) main table (base.py:230-233)
     main, X_flat, blocks, y, shapes = ds.multihot_block_design()
