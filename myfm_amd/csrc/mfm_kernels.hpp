@@ -2895,14 +2895,44 @@ __global__ __launch_bounds__(WG) void k_qbuild_rows(const int32_t *__restrict__ 
     b = rowptr[i];
     e = rowptr[i + 1];
   }
+  // Every index this row needs is requested first, then every gather, then the sums in the reference's order (main entries,
+  // then the blocks in order: bit-identical to the plain loops). With the loops as written -- dynamic trip counts, pointers
+  // picked out of the kernel arguments per iteration -- a thread had ONE dependent pair (index -> gather) in flight at a time,
+  // six pairs in a row at config 5, and the pass ran at the latency of those round trips (1.43 ms for 2.8 GB at N = 50 M).
+  constexpr int NB4 = 4;
+  const int nb = blk.n_blocks;
+  int mi[NB4];
+#pragma unroll
+  for (int bi = 0; bi < NB4; bi++) mi[bi] = bi < nb ? blk.map[bi][i] : 0;
+  const int mp = map_prev ? map_prev[i] : 0;
+  double2 v = make_double2(0.0, 0.0);
+  if (map_prev) v = eq[i];
   double s = 0.0;
-  for (int64_t p = b; p < e; p++) s += (UNIT ? 1.0 : val[p]) * vf[colidx[p]];
-  for (int bi = 0; bi < blk.n_blocks; bi++) s += blk.gather(bi, i);  // :335-337
+  if (ELL && ell == 2) {
+    const int2 ci = *(const int2 *)(colidx + b);
+    double x0 = 1.0, x1 = 1.0;
+    if (!UNIT) {
+      x0 = val[b];
+      x1 = val[b + 1];
+    }
+    const double v0 = vf[ci.x], v1 = vf[ci.y];
+    s += x0 * v0;
+    s += x1 * v1;
+  } else {
+    for (int64_t p = b; p < e; p++) s += (UNIT ? 1.0 : val[p]) * vf[colidx[p]];
+  }
+  double gq[NB4];
+#pragma unroll
+  for (int bi = 0; bi < NB4; bi++) gq[bi] = bi < nb ? blk.rec[bi][(int64_t)mi[bi] * blk.stride[bi]] : 0.0;
+  double2 qp = make_double2(0.0, 0.0);
+  if (map_prev) qp = q_prev[mp];
+#pragma unroll
+  for (int bi = 0; bi < NB4; bi++)
+    if (bi < nb) s += gq[bi];  // :335-337
+  for (int bi = NB4; bi < nb; bi++) s += blk.gather(bi, i);
   if (map_prev) {
     // the re-sync the last block of the PREVIOUS factor still owes (FMTrainer.hpp:473-480; its (q_B, q_S) of that factor were
     // saved before the row caches were rebuilt): the residual term uses the old q, which this pass then overwrites
-    double2 v = eq[i];
-    const double2 qp = q_prev[map_prev[i]];
     v.x += (v.y * qp.x + 0.5 * qp.x * qp.x - 0.5 * qp.y);
     v.y = s;
     eq[i] = v;
