@@ -337,6 +337,18 @@ static DevBuf<double> *store_new_sample(mfm_store *st) {
 
 int mfm_store_reserve(mfm_store *st, int32_t n_samples) {
   MFM_TRY(st)
+  {
+    // the kept samples live in HBM for the Predictor's lifetime: refuse a reservation that would take more than half of what
+    // is free now (MFM_STORE_MAX_FRACTION), so that a later fit / predict on the same GPU still finds room -- the trainer
+    // then keeps host copies, as it does when an allocation fails
+    const int64_t have = (int64_t)(st->wv.size() + st->spare.size());
+    const double need = (double)std::max<int64_t>(n_samples - have, 0) * (double)std::max<int64_t>(st->D * (st->K + 1), 1) * sizeof(double);
+    size_t free_b = 0, total_b = 0;
+    const char *fe = std::getenv("MFM_STORE_MAX_FRACTION");
+    const double frac = fe ? std::atof(fe) : 0.5;
+    if (need > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > frac * (double)free_b)
+      throw Error(MFM_ERR_RUNTIME, "sample store: the reservation exceeds MFM_STORE_MAX_FRACTION of the free device memory");
+  }
   while ((int)(st->wv.size() + st->spare.size()) < n_samples) {
     std::unique_ptr<DevBuf<double>> b(new DevBuf<double>());
     b->alloc((size_t)std::max<int64_t>(st->D * (st->K + 1), 1));

@@ -93,6 +93,12 @@ def test_kept_samples_stay_on_device_until_asked_for(myfm, oracle, monkeypatch):
     fm_h = myfm.MyFMRegressor(5).fit(X, y, group_shapes=shapes, n_iter=8, n_kept_samples=6)
     assert np.array_equal(fm_h.predict(Xt), p_dev)
     assert np.array_equal(fm_h.V_samples, fm.V_samples)
+    # ... and so does a store whose reservation is refused (more than MFM_STORE_MAX_FRACTION of the free HBM): host copies
+    monkeypatch.delenv("MYFM_AMD_HOST_SAMPLES")
+    monkeypatch.setenv("MFM_STORE_MAX_FRACTION", "1e-12")
+    fm_r = myfm.MyFMRegressor(5).fit(X, y, group_shapes=shapes, n_iter=8, n_kept_samples=6)
+    assert np.array_equal(fm_r.predict(Xt), p_dev)
+    assert np.array_equal(fm_r.V_samples, fm.V_samples)
 
 
 def test_toy_config1(myfm):
