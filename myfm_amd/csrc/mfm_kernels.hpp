@@ -2579,6 +2579,8 @@ struct CbPersistArgs {
   double *colpack;    // [2][4 MC], by batch parity
   CbSync *sync;       // zeroed before the launch
   int *error;
+  unsigned long long *prof;  // MFM_CB_PROF: [16] sums of s_memrealtime ticks (100 MHz) of thread 0 of the hot walker (0..4: wait,
+                             // stage in, walk, stage out, batches) and of range 0 (8..11: wait, near part, far part, batches)
   int dbg;            // timing experiments only (MFM_CB_DBG; results are wrong when set): 1 no hot walk, 2 no hot-record staging,
                       // 4 no cold statistics, 8 no cold update
 };
@@ -2615,7 +2617,11 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_persist(SweepArgs a, CbPersist
         h_slot[i] = g.hot_slot[hb0 + i];
       }
       if (tid <= B.ncols) h_ptr[tid] = g.hot_ptr[B.col0 + tid] - hb0;
+      const bool pf = g.prof && tid == 0;
+      unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+      if (pf) t0 = __builtin_amdgcn_s_memrealtime();
       if (tid == 0) cb_wait(&g.sync->step_done, (unsigned long long)NB * (bi + 1), g.error, dead);
+      if (pf) t1 = __builtin_amdgcn_s_memrealtime();
       __syncthreads();
       if (tid < B.ncols) {
         c_old[tid] = cb_ld(colpack + tid);
@@ -2642,6 +2648,7 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_persist(SweepArgs a, CbPersist
         csum[tid] = make_double2(S1, S2);
       }
       __syncthreads();
+      if (pf) t2 = __builtin_amdgcn_s_memrealtime();
       if (wv == 0 && !(g.dbg & 1)) {
         for (int c = 0; c < B.ncols; c++) {
           const double S1 = csum[c].x, S2 = csum[c].y;
@@ -2654,6 +2661,7 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_persist(SweepArgs a, CbPersist
       }
       if ((g.dbg & 1) && tid < B.ncols) c_new[tid] = c_old[tid];
       __syncthreads();
+      if (pf) t3 = __builtin_amdgcn_s_memrealtime();
       for (int i = tid; i < ((g.dbg & 2) ? 0 : B.n_hot * rec2_g); i += NT) {
         const int slot = i / rec2_g, w = i - slot * rec2_g;
         cb_st2(hot_pack + i, lds_hot[(size_t)slot * rec2_l + w]);
@@ -2665,6 +2673,14 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_persist(SweepArgs a, CbPersist
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(&g.sync->hot_done, (unsigned long long)(bi + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (pf) {
+        t4 = __builtin_amdgcn_s_memrealtime();
+        g.prof[0] += t1 - t0;
+        g.prof[1] += t2 - t1;
+        g.prof[2] += t3 - t2;
+        g.prof[3] += t4 - t3;
+        g.prof[4] += 1;
+      }
     }
     return;
   }
@@ -2792,6 +2808,8 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_persist(SweepArgs a, CbPersist
       }
     }
     int hbp = 0, hep = 0, p0 = 0, p2 = 0, p4 = 0;
+    const bool pfr = g.prof && tid == 0 && w == 0;
+    unsigned long long r0 = 0, r1 = 0, r2 = 0;
     if (Bp.ncols > 0) {
       hbp = g.hbk_ptr[ip * (NB + 1) + w];
       hep = g.hbk_ptr[ip * (NB + 1) + w + 1];
@@ -2799,7 +2817,9 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_persist(SweepArgs a, CbPersist
       p4 = g.bk_ptr[ip * (NB + 1) + w + 1];
       p2 = g.bk_cls[(ip * NB + w) * 3 + 1];
       if (g.dbg & 8) p0 = p2 = p4 = 0;
+      if (pfr) r0 = __builtin_amdgcn_s_memrealtime();
       if (tid == 0) cb_wait(&g.sync->hot_done, (unsigned long long)bi, g.error, dead);
+      if (pfr) r1 = __builtin_amdgcn_s_memrealtime();
     }
     __syncthreads();
     if (tid < Bp.ncols) on[tid] = cb_ld2(g.oldnew_g + tid);
@@ -2837,6 +2857,7 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_persist(SweepArgs a, CbPersist
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(&g.sync->step_done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (pfr) r2 = __builtin_amdgcn_s_memrealtime();
     // ---- while the hot walker is busy with batch bi ----
     if (Bp.ncols > 0 && !(g.dbg & 16)) update_range(p2, p4);  // update far: rows batch bi does not touch
     __threadfence_block();
@@ -2853,6 +2874,12 @@ __global__ __launch_bounds__(CHAINB_NT) void k_cb_persist(SweepArgs a, CbPersist
       }
     }
     __syncthreads();
+    if (pfr && Bp.ncols > 0 && Bn.ncols > 0) {
+      g.prof[8] += r1 - r0;
+      g.prof[9] += r2 - r1;
+      g.prof[10] += __builtin_amdgcn_s_memrealtime() - r2;
+      g.prof[11] += 1;
+    }
   }
 }
 

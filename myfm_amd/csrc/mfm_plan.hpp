@@ -1405,9 +1405,33 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
               g.error = ls.error.p;
               static const int cb_dbg = std::getenv("MFM_CB_DBG") ? std::atoi(std::getenv("MFM_CB_DBG")) : 0;
               g.dbg = cb_dbg;
+              // MFM_CB_PROF=n: phase sums of the hot walker and of range 0 (s_memrealtime, thread 0), printed every n launches
+              static const int cb_prof = std::getenv("MFM_CB_PROF") ? std::atoi(std::getenv("MFM_CB_PROF")) : 0;
+              static DevBuf<unsigned long long> prof_buf;
+              static long prof_launches = 0;
+              g.prof = nullptr;
+              if (cb_prof > 0) {
+                if (!prof_buf.p) {
+                  prof_buf.alloc(16);
+                  MFM_HIP_CHECK(hipMemset(prof_buf.p, 0, 16 * sizeof(unsigned long long)));
+                }
+                g.prof = prof_buf.p;
+              }
               const size_t lds_range = (size_t)CHAINB_MAXCOLS * (sizeof(double2) + 2 * sizeof(double)) +
                                        (size_t)CHAINB_MAXCOLS * (CHAINB_NT / WAVE) * sizeof(double2);
               hipLaunchKernelGGL((k_cb_persist<P>), dim3(CB_BUCKETS + 1), dim3(CHAINB_NT), std::max(lds_h, lds_range), s, a, g);
+              if (cb_prof > 0 && ++prof_launches % cb_prof == 0) {
+                unsigned long long h[16];
+                MFM_HIP_CHECK(hipStreamSynchronize(s));
+                MFM_HIP_CHECK(hipMemcpy(h, prof_buf.p, sizeof(h), hipMemcpyDeviceToHost));
+                MFM_HIP_CHECK(hipMemset(prof_buf.p, 0, sizeof(h)));
+                const double nb = (double)std::max<unsigned long long>(h[4], 1), nr = (double)std::max<unsigned long long>(h[11], 1);
+                std::fprintf(stderr,
+                             "[k_cb_persist] %ld launches, us per batch -- hot walker (%llu batches): wait %.2f, stage in %.2f, walk %.2f, "
+                             "stage out + signal %.2f | range 0 (%llu): wait %.2f, near part %.2f, far part %.2f\n",
+                             prof_launches, h[4], h[0] / nb / 100.0, h[1] / nb / 100.0, h[2] / nb / 100.0, h[3] / nb / 100.0, h[11],
+                             h[8] / nr / 100.0, h[9] / nr / 100.0, h[10] / nr / 100.0);
+              }
               continue;
             }
             const ChainBatch none{0, 0, 0, 0, 0, 0, 0, 0};
