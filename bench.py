@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--fit-iters", type=int, default=100, help="iterations of the MyFM*.fit() leg (0 disables)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--weak-steps", type=int, default=20, help="N > 1: timed iterations of the weak-scaling leg (0 disables)")
+    ap.add_argument("--long-seconds", type=float, default=2.0, help="when the timed region is shorter than 1 s: also time the same loop "
+                    "for about this long and report it as value_long (0 disables)")
     ap.add_argument("--no-other-configs", action="store_true", help="default run (config 3, 1 GPU): skip the other_configs legs")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -318,6 +320,17 @@ def main():
         sess.timing_enable(False)
         sess.timing_select("")
     calls = (sess.comm_stats()[0] - calls0) if sharded else 0
+    # a short timed region (the driver's 20 steps at config 3 are 65 ms) gets an in-line cross-check: the same loop for >= 2 s
+    long_run = None
+    if world == 1 and elapsed < 1.0 and a.long_seconds > 0:
+        n_long = max(a.steps, int(np.ceil(a.long_seconds / max(elapsed / a.steps, 1e-6))))
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n_long):
+            sess.step()
+        sync()
+        t_long_run = time.perf_counter() - t0
+        long_run = (n_long, t_long_run)
 
     # sanity: the chain is alive and, when sharded, the replicated model is identical on every rank
     alpha = sess.hyper.alpha
@@ -493,6 +506,10 @@ def main():
         "cpu_baseline": cpu,
         "fit": fit,
     }
+    if long_run:
+        out["value_long"] = round(long_run[0] / long_run[1], 3)
+        out["value_long_steps"] = long_run[0]
+        out["value_long_seconds"] = round(long_run[1], 3)
     if cpu and cpu.get("value"):
         out["speedup_vs_cpu_baseline"] = round(it_per_s / cpu["value"], 1)
     if weak:
