@@ -13,9 +13,15 @@ HIP_LIB = os.path.join(HERE, "libmyfm_hip.so")
 EXT_SUFFIX = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
 PYMOD = os.path.join(HERE, "_myfm" + EXT_SUFFIX)
 
-HIP_SOURCES = ["mfm_hip.hip"]
-HIP_HEADERS = ["mfm_common.hpp", "mfm_kernels.hpp", "mfm_mf_kernels.hpp", "mfm_res.hpp", "mfm_plan.hpp", "mfm_block_kernels.hpp", "mfm_tasks.hpp",
-               "mfm_predict.hpp", "mfm_rng.hpp", "mfm_mtjump.hpp"]
+# translation units of libmyfm_hip.so and the headers each of them includes (a unit is recompiled when one of them is newer than
+# its object file; the objects live in csrc/_obj/, git-ignored)
+HIP_UNITS = {
+    "mfm_hip.hip": ["mfm_common.hpp", "mfm_wave.hpp", "mfm_kernels.hpp", "mfm_mf_kernels.hpp", "mfm_res.hpp", "mfm_plan.hpp",
+                    "mfm_block_kernels.hpp", "mfm_tasks.hpp", "mfm_predict.hpp", "mfm_rng.hpp", "mfm_mtjump.hpp", "mfm_cell.hpp"],
+    "mfm_cell.hip": ["mfm_common.hpp", "mfm_wave.hpp", "mfm_cell.hpp"],
+}
+OBJ_DIR = os.path.join(CSRC, "_obj")
+PYMOD_HEADERS = ["mfm_hostnormals.hpp", "mfm_mtjump.hpp"]
 
 
 def _newer(target, deps):
@@ -32,15 +38,27 @@ def _hipcc():
 
 
 def build_hip(force=False, verbose=False):
-    deps = [os.path.join(CSRC, f) for f in HIP_SOURCES + HIP_HEADERS] + [os.path.join(INCLUDE, "myfm_hip.h")]
-    if not (force or _newer(HIP_LIB, deps)):
-        return HIP_LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-I" + INCLUDE, "-I" + CSRC] + os.environ.get("MYFM_AMD_HIPCC_FLAGS", "").split() + \
-          [os.path.join(CSRC, f) for f in HIP_SOURCES] + ["-o", HIP_LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + INCLUDE, "-I" + CSRC] + \
+        os.environ.get("MYFM_AMD_HIPCC_FLAGS", "").split()
+    jobs, objs = [], []
+    for src, hdrs in HIP_UNITS.items():
+        obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in hdrs] + [os.path.join(INCLUDE, "myfm_hip.h")]
+        if force or _newer(obj, deps):
+            cmd = [_hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((src, subprocess.Popen(cmd)))
+    for src, pr in jobs:  # (the units compile side by side)
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, "hipcc -c " + src)
+    if jobs or not os.path.exists(HIP_LIB) or _newer(HIP_LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", HIP_LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return HIP_LIB
 
 
@@ -48,7 +66,8 @@ def build_pymod(force=False, verbose=False):
     import pybind11
 
     src = os.path.join(CSRC, "_myfm.cpp")
-    if not (force or _newer(PYMOD, [src, os.path.join(INCLUDE, "myfm_hip.h"), HIP_LIB])):
+    deps = [src, os.path.join(INCLUDE, "myfm_hip.h")] + [os.path.join(CSRC, h) for h in PYMOD_HEADERS]  # (linked dynamically)
+    if not (force or _newer(PYMOD, deps)):
         return PYMOD
     cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-I" + pybind11.get_include(),
            "-I" + sysconfig.get_paths()["include"], "-I" + INCLUDE, src, "-o", PYMOD, "-L" + HERE, "-lmyfm_hip",

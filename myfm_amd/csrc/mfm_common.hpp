@@ -172,6 +172,8 @@ enum KernelClass {
   KC_PREDICT,          // Predictor::predict*                               predictor.hpp:35-147
   KC_SWEEP_V_FUSED,    // latent sweep: last level's apply pass + next factor's first level on the LDS tile
   KC_SWEEP_V_RESIDENT, // latent sweep of a two-field table, all factors in one persistent launch (mfm_res.hpp)
+  KC_CELL_PASS,        // latent sweep, cell path: one streaming pass over the rows (apply the pending field + next field's statistics)
+  KC_CELL_SMALL,       // ... its table / draw / reduce kernels (block-row or column sized)
   KC_N
 };
 
@@ -182,7 +184,7 @@ static const char *const kKernelClassNames[KC_N] = {
     "update_e_score",     "build_vt",
     "reduce_e",           "shift_e",           "group_stats",        "block_rowcache",     "block_unsync",
     "block_resync",       "block_sweep",       "tn_sample",          "oprobit_eval",       "predict",
-    "sweep_V_fused_next", "sweep_V_resident"};
+    "sweep_V_fused_next", "sweep_V_resident", "cell_pass",          "cell_small"};
 
 struct Timing {
   bool on = false;
@@ -238,7 +240,7 @@ struct Timing {
 // debugging aid (MFM_DEBUG_POISON_LDS=1): before every bracketed launch fill the whole LDS of every CU with signalling NaN
 // patterns, so that a kernel reading LDS it has not written shows up deterministically instead of only when another
 // stream's workgroup happened to leave bits there
-__global__ __launch_bounds__(1024) void k_poison_lds(uint32_t word) {
+static __global__ __launch_bounds__(1024) void k_poison_lds(uint32_t word) {
   extern __shared__ uint32_t poison_words[];
   for (int i = threadIdx.x; i < 160 * 256; i += 1024) poison_words[i] = word;
   __syncthreads();

@@ -7,10 +7,16 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 
 #include <hipcub/hipcub.hpp>
 
@@ -18,12 +24,82 @@
 #include "mfm_kernels.hpp"
 #include "mfm_plan.hpp"
 #include "mfm_block_kernels.hpp"
+#include "mfm_cell.hpp"
 #include "mfm_mtjump.hpp"
 #include "mfm_rng.hpp"
 
 namespace mfm {
 static thread_local std::string g_global_error;
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Persistent launches with a hand-written grid barrier (k_mf_resident: one workgroup per CU, up to 160 KB of LDS each) are
+// correct only while ALL their workgroups are resident at once. Nothing in a plain launch guarantees that when somebody else
+// occupies CUs for as long as the launch lasts -- a second persistent sweep (another context, thread or process on the same
+// GPU: joblib cross-validation), or a CU mask under which the device still reports every CU. So a context must CLAIM the CUs of
+// its persistent launch here before it may use it: inside a process the claims on a device add up to at most its CU count,
+// across processes a device's persistent sweeps belong to the one process that holds an exclusive flock on a per-device lock
+// file (released by the kernel when the process ends); a context that gets no claim runs the per-factor passes, which assume
+// nothing about co-residency.
+struct ResidentBudget {
+  std::mutex m;
+  struct Dev {
+    int claimed = 0;
+    int lock_fd = -1;
+  };
+  std::map<std::string, Dev> dev;  // keyed by PCI bus id
+  static ResidentBudget &get() {
+    static ResidentBudget b;
+    return b;
+  }
+  static std::string key_of(int device) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) std::snprintf(bus, sizeof(bus), "dev%d", device);
+    for (char *p = bus; *p; p++)
+      if (*p == ':' || *p == '.' || *p == '/') *p = '_';
+    return bus;
+  }
+  bool acquire(int device, int n_cu_total, int want, std::string &why) {
+    for (const char *v : {"HSA_CU_MASK", "ROC_GLOBAL_CU_MASK", "HSA_CU_MASK_SKIP_INIT"})
+      if (const char *e = std::getenv(v))
+        if (*e) {
+          why = std::string(v) + " is set: the CUs a launch really gets are unknown";
+          return false;
+        }
+    std::lock_guard<std::mutex> g(m);
+    const std::string k = key_of(device);
+    Dev &d = dev[k];
+    if (d.claimed + want > n_cu_total) {
+      why = "another context of this process holds the CUs for its persistent sweep";
+      return false;
+    }
+    if (d.lock_fd < 0 && !std::getenv("MFM_RES_NO_PROCESS_LOCK")) {
+      const char *dir = std::getenv("MFM_LOCK_DIR");
+      const std::string path = std::string(dir && *dir ? dir : "/tmp") + "/myfm_amd_resident_" + k + ".lock";
+      const int fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+      if (fd >= 0) {
+        if (::flock(fd, LOCK_EX | LOCK_NB) != 0) {
+          ::close(fd);
+          why = "another process runs a persistent sweep on this GPU (" + path + ")";
+          return false;
+        }
+        d.lock_fd = fd;
+      }  // (no writable lock directory: in-process accounting only)
+    }
+    d.claimed += want;
+    return true;
+  }
+  void release(int device, int n) {
+    if (n <= 0) return;
+    std::lock_guard<std::mutex> g(m);
+    Dev &d = dev[key_of(device)];
+    d.claimed = std::max(0, d.claimed - n);
+    if (d.claimed == 0 && d.lock_fd >= 0) {
+      ::flock(d.lock_fd, LOCK_UN);
+      ::close(d.lock_fd);
+      d.lock_fd = -1;
+    }
+  }
+};
 }  // namespace mfm
 
 using namespace mfm;
@@ -80,6 +156,7 @@ struct mfm_ctx {
   bool qfree = false, soa = false, fuse_next = false;
   bool mf = false;              // two-field pass (run_sweep_mf): no q-cache in HBM during update_V
   ResPlan res;                  // ... as one persistent launch with the residual resident on chip (mfm_res.hpp)
+  CellPlan cell;                // update_V of a design of index tuples (one-hot fields + relation blocks): no q-cache (mfm_cell.hpp)
   bool sharded_fused = false;   // row-sharded + fused tile path (run_sweep_soa_sharded)
   int q_stale_factor = -1;      // >= 0: the stored q column is stale, mfm_get_q rebuilds it for this factor first
   BlockOverflow gather_overflow;       // q-cache build: pointers of the relation blocks beyond MAX_BLOCKS
@@ -87,6 +164,7 @@ struct mfm_ctx {
   std::vector<double> hs_stage;     // host staging of the packed hyper-parameter copies
   bool slot_sums_valid = false;     // res.sums holds sum e / sum e^2 of the residual that is in slot order right now
   bool res_fills_device = false;  // the persistent sweep takes (nearly) every CU: nothing runs beside it
+  int res_claim = 0;              // CUs this context holds in ResidentBudget for its persistent launch
   bool e_in_slots = false;      // the residual after the resident latent sweep lives in res.e_slots (slot order): every
                                 // reader of eq calls materialize_e first; update_e overwrites it and just drops the flag
   DevBuf<double> sync_mask;     // [D] 1: this rank contributes the column to the model synchronisation
@@ -155,10 +233,43 @@ struct mfm_ctx {
   DevBuf<double> opartial;
 
   ~mfm_ctx() {
+    drop_resident();
     if (h_red) (void)hipHostFree(h_red);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
   void use_device() { MFM_HIP_CHECK(hipSetDevice(device)); }
+  // give the persistent sweep up (claim released): every later sweep runs the per-factor passes
+  void drop_resident() {
+    if (res_claim) ResidentBudget::get().release(device, res_claim);
+    res_claim = 0;
+    res.ready = false;
+    res_fills_device = false;
+  }
+  // Co-resident kernels (k_long_coop, k_cb_persist, k_mf_resident) raise ls.error when a partner did not show up within the spin
+  // bound: whatever they computed is then garbage. Called wherever the host waits for the stream anyway. The flag is cleared and
+  // the persistent sweep given up, so the context stays usable -- but the chain state of THIS fit is invalid, hence the throw.
+  void check_coresident(int flag) {
+    if (flag == 0) return;
+    (void)hipMemsetAsync(ls.error.p, 0, sizeof(int), stream);
+    (void)hipStreamSynchronize(stream);
+    const bool had = res.ready;
+    drop_resident();
+    throw Error(MFM_ERR_RUNTIME,
+                std::string("co-resident workgroups timed out waiting for each other (long-column sweep / conflict-batched chain / "
+                            "resident latent sweep): the state of this fit is invalid") +
+                    (had ? "; the persistent sweep is switched off for this context" : ""));
+  }
+  void sync_and_check() {
+    if (!ls.error.p) {
+      MFM_HIP_CHECK(hipStreamSynchronize(stream));
+      return;
+    }
+    double2 *h = readback(1);
+    *(int *)h = 0;
+    MFM_HIP_CHECK(hipMemcpyAsync(h, ls.error.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    MFM_HIP_CHECK(hipStreamSynchronize(stream));
+    check_coresident(*(const int *)h);
+  }
   void need_final() const {
     if (!finalized) throw Error(MFM_ERR_RUNTIME, "mfm_finalize has not been called");
   }
@@ -492,6 +603,80 @@ static void score_train(mfm_ctx *c, bool subtract_y) {
                subtract_y ? c->y.p : nullptr, c->eq.p, nullptr);
 }
 
+// update_V (FMTrainer.hpp:315-482) of factors [f_begin, f_end) on the cell layout: per factor one streaming pass per field
+// (apply the field before it, statistics of its own), the main fields' draws and the blocks' feature sweeps in between.
+static void run_sweep_cell(mfm_ctx *c, int f_begin, int f_end, const double *zbase, double alpha) {
+  hipStream_t s = c->stream;
+  CellPlan &cp = c->cell;
+  Timing &tm = c->timing;
+  const int m = (int)cp.fields.size();
+  cell_pack_e(s, cp, c->eq.p);
+  std::vector<CellSrc> cur((size_t)m);
+  auto set_cur = [&](int f) {
+    for (int k = 0; k < m; k++) {
+      const CellField &fd = cp.fields[k];
+      if (fd.kind == 0) {
+        cur[k].p = c->V.p + (size_t)f * c->D + fd.base;
+        cur[k].stride = 1;
+      } else {
+        cur[k].p = c->blocks[(size_t)fd.base]->rec.p;  // word 0 of the record: q_B
+        cur[k].stride = BLOCK_REC;
+      }
+    }
+  };
+  auto on_I = [&](int field) { return cp.streams[cp.fields[field].stream].type == CELL_I; };
+  const SweepClasses kc{KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP,
+                        KC_BLOCK_SWEEP, KC_BLOCK_SWEEP};
+  int pending = -1;  // the last field of the factor before: drawn, not yet applied to the rows
+  for (int f = f_begin; f < f_end; f++) {
+    double *Vf = c->V.p + (size_t)f * c->D;
+    const double *zf = zbase + (size_t)(f - f_begin) * c->D;
+    const double *lamf = c->lam.p + (size_t)f * c->G;
+    const double *muf = c->mu.p + (size_t)f * c->G;
+    // the pending field is applied with the tables of ITS factor: take them before the blocks' q_B are rebuilt
+    if (pending >= 0) cell_prep(s, tm, cp, cur, true, pending, false, -1, on_I(pending));
+    set_cur(f);
+    for (auto &B : c->blocks) block_rowcache(s, tm, *B, Vf + B->col_off, true);  // :331-333, :388-393
+    for (int k = 0; k < m; k++) {
+      const int P = k == 0 ? pending : k - 1;
+      const bool sw = k == 0 && pending >= 0;
+      const CellField &fd = cp.fields[k];
+      DevBlock *B = fd.kind == 1 ? c->blocks[(size_t)fd.base].get() : nullptr;
+      double *out_u = B ? B->rec.p + 2 : cp.stat.p;  // a U field's sums: (c, c_S, e, e_q) of the record / (S2, S_eh)
+      const int out_stride = B ? BLOCK_REC : 2;
+      const bool split = P >= 0 && cp.lds_bytes(P, k, sw) > CELL_LDS_BYTES;
+      if (sw)
+        cell_prep(s, tm, cp, cur, false, -1, true, k, false);
+      else
+        cell_prep(s, tm, cp, cur, P >= 0, P, true, k, P >= 0 && on_I(P));
+      if (!split) {
+        cell_pass(s, tm, cp, P, k, sw, out_u, out_stride);
+      } else {  // (both roles do not fit the LDS together)
+        cell_pass(s, tm, cp, P, -1, false, nullptr, 0);
+        cell_pass(s, tm, cp, -1, k, false, out_u, out_stride);
+      }
+      if (!B) {
+        cell_draw_main(s, tm, cp, k, Vf, zf, c->group.p, lamf, muf, alpha);  // :357-369
+      } else {
+        cell_block_stats(s, tm, cp, k, B->rec.p);  // :401-407
+        if (B->q_saved.n < (size_t)B->B) B->q_saved.alloc((size_t)B->B);
+        hipLaunchKernelGGL(k_save_q, dim3(cdiv(std::max<int64_t>(B->B, 1), 256)), dim3(256), 0, s, B->rec.p, B->B, B->q_saved.p);
+        SweepArgs a = block_args(*B, Vf, zf, c->group.p, lamf, muf, alpha);
+        run_plan<PBlockV>(s, tm, B->plan_V, a, c->ls, kc, false);  // :419-470
+        cell_block_delta(s, tm, cp, k, B->rec.p, B->q_saved.p);
+      }
+    }
+    pending = m - 1;
+  }
+  if (pending >= 0) {
+    cell_prep(s, tm, cp, cur, true, pending, false, -1, on_I(pending));
+    cell_pass(s, tm, cp, pending, -1, false, nullptr, 0);
+  }
+  cell_unpack_e(s, cp, c->eq.p);
+  c->q_stale_factor = f_end - 1;  // q_train as the reference leaves it (:373, :479): rebuilt when asked for
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace mfm
 
 // =============================================================================================
@@ -646,7 +831,7 @@ int mfm_set_row_offset(mfm_ctx *ctx, int64_t first_global_row) {
 
 int mfm_synchronize(mfm_ctx *ctx) {
   MFM_TRY(ctx)
-  MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->sync_and_check();
   MFM_CATCH(ctx)
 }
 
@@ -962,8 +1147,21 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   if (c->soa && c->mf && c->X.unit && !c->comm.active() && c->N >= res_min_rows && !std::getenv("MFM_NO_RESIDENT")) {
     int n_cu = 0;
     MFM_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
+    const int n_cu_dev = n_cu;
     if (const char *e = std::getenv("MFM_RES_CUS")) n_cu = std::max(1, std::min(n_cu, std::atoi(e)));
     c->res.build(Xt_keep, c->plan_V.h_level, &c->hgroup, n_cu);
+    if (c->res.ready) {
+      // all G workgroups must be resident at once: one per CU must fit (registers + LDS), and the CUs must be ours
+      int per_cu = 0;
+      const hipError_t oe = res_occupancy(c->res, &per_cu);
+      std::string why;
+      if (oe != hipSuccess || per_cu < 1)
+        c->res.fail("the persistent kernel does not fit a CU (occupancy query)");
+      else if (!ResidentBudget::get().acquire(c->device, n_cu_dev, c->res.G, why))
+        c->res.fail(why.c_str());
+      else
+        c->res_claim = c->res.G;
+    }
     c->res_fills_device = c->res.ready && c->res.G > n_cu - n_cu / 4;
     if (tlog) std::fprintf(stderr, "[mfm_finalize] resident plan: %s (G=%d RV=%d RL=%d umax=%d runs=%lld lds=%zu)\n",
                            c->res.ready ? "ready" : c->res.why.c_str(), c->res.G, c->res.RV, c->res.RL, c->res.umax,
@@ -973,6 +1171,24 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   Xt_keep = HostCsr();
   MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
   lap("blocks, state, scratch");
+  // a row of unit-valued one-hot fields + relation blocks on one GPU: update_V on index tuples, no q-cache (mfm_cell.hpp)
+  {
+    const int64_t cell_min_rows = std::getenv("MFM_CELL_MIN_ROWS") ? std::atoll(std::getenv("MFM_CELL_MIN_ROWS")) : ((int64_t)1 << 20);
+    if (!c->blocks.empty() && !c->comm.active() && c->X.unit && c->X.ell_width >= 1 && c->N >= cell_min_rows && c->K > 0 &&
+        !std::getenv("MFM_NO_CELL")) {
+      int n_cu = 0;
+      MFM_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
+      if (const char *e = std::getenv("MFM_CELL_GROUPS")) n_cu = std::max(1, std::atoi(e));
+      std::vector<CellBlockIn> bin;
+      for (auto &hb : c->hblocks) bin.push_back(CellBlockIn{hb.map.data(), hb.X.rows});
+      cell_plan_build(c->cell, c->hX, bin, n_cu, c->stream);
+      if (tlog)
+        std::fprintf(stderr, "[mfm_finalize] cell plan: %s (G=%d umax=%lld streams=%zu fields=%zu item32=%d)\n",
+                     c->cell.ready ? "ready" : c->cell.why.c_str(), c->cell.G, (long long)c->cell.umax, c->cell.streams.size(),
+                     c->cell.fields.size(), (int)c->cell.item32);
+      lap("cell plan");
+    }
+  }
   // host copies are no longer needed
   c->hX = HostCsr();
   c->hy.clear();
@@ -997,7 +1213,7 @@ int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launche
 int mfm_plan_flags(const mfm_ctx *ctx) {
   return (ctx->qfree ? 1 : 0) | (ctx->X.unit ? 2 : 0) | (ctx->X.ell_width >= 0 ? 4 : 0) | (ctx->comm.active() ? 8 : 0) |
          (ctx->soa ? 16 : 0) | (ctx->fuse_next ? 32 : 0) | (ctx->sharded_fused ? 64 : 0) | (ctx->mf ? 128 : 0) |
-         (ctx->res.ready ? 256 : 0);
+         (ctx->res.ready ? 256 : 0) | (ctx->cell.ready ? 512 : 0);
 }
 
 // ---- state ------------------------------------------------------------------------------------
@@ -1019,7 +1235,7 @@ int mfm_get_state(mfm_ctx *ctx, double *w0, double *w, double *V) {
   if (ctx->K && ctx->D)
     MFM_HIP_CHECK(
         hipMemcpyAsync(V, ctx->V.p, (size_t)ctx->D * ctx->K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->sync_and_check();  // (a timed-out persistent sweep of the LAST iteration is reported here, not returned as a sample)
   MFM_CATCH(ctx)
 }
 
@@ -1053,6 +1269,11 @@ int mfm_get_q(mfm_ctx *ctx, double *q) {
   if (ctx->finalized && ctx->q_stale_factor >= 0) {
     // the split-layout sweeps never store q during update_V; nothing on the device path reads it afterwards
     try {
+      ctx->use_device();
+      // (the blocks' feature sweeps update q_B in their records only: the compact copies the q-cache build gathers from are
+      //  rebuilt from the factor's coefficients first)
+      for (auto &B : ctx->blocks)
+        if (ctx->cell.ready) block_rowcache(ctx->stream, ctx->timing, *B, ctx->V.p + (size_t)ctx->q_stale_factor * ctx->D + B->col_off, true);
       launch_qbuild(ctx, ctx->V.p + (size_t)ctx->q_stale_factor * ctx->D);
       ctx->q_stale_factor = -1;
     } catch (const std::exception &ex) {
@@ -1091,8 +1312,7 @@ int mfm_reduce_e(mfm_ctx *ctx, double *sum_e, double *sum_e2) {
   MFM_HIP_CHECK(hipMemcpyAsync(h, ctx->red_out.p, sizeof(double2), hipMemcpyDeviceToHost, s));
   MFM_HIP_CHECK(hipMemcpyAsync(h + 1, ctx->ls.error.p, sizeof(int), hipMemcpyDeviceToHost, s));
   MFM_HIP_CHECK(hipStreamSynchronize(s));
-  if (*(const int *)(h + 1) != 0)
-    throw Error(MFM_ERR_RUNTIME, "co-resident workgroups timed out waiting for each other (long-column sweep / resident latent sweep)");
+  ctx->check_coresident(*(const int *)(h + 1));
   *sum_e = h[0].x;
   *sum_e2 = h[0].y;
   MFM_CATCH(ctx)
@@ -1193,8 +1413,7 @@ int mfm_hyper_stats(mfm_ctx *ctx, int32_t need_e, const double *mu_w, const doub
   MFM_HIP_CHECK(hipMemcpyAsync(h, c->hs_out.p, n_out * sizeof(double2), hipMemcpyDeviceToHost, s));
   MFM_HIP_CHECK(hipMemcpyAsync(h + n_out, c->ls.error.p, sizeof(int), hipMemcpyDeviceToHost, s));
   MFM_HIP_CHECK(hipStreamSynchronize(s));
-  if (*(const int *)(h + n_out) != 0)
-    throw Error(MFM_ERR_RUNTIME, "co-resident workgroups timed out waiting for each other (long-column sweep / resident latent sweep)");
+  c->check_coresident(*(const int *)(h + n_out));
   if (need_e) {
     *sum_e = h[0].x;
     *sum_e2 = h[0].y;
@@ -1418,6 +1637,10 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
     c->q_stale_factor = f_end - 1;  // q_train as the reference leaves it (FMTrainer.hpp:373): rebuilt when asked for
     MFM_HIP_CHECK(hipGetLastError());
+    return MFM_OK;
+  }
+  if (c->cell.ready) {
+    run_sweep_cell(c, f_begin, f_end, zbase, alpha);
     return MFM_OK;
   }
   DevBlock *carry = nullptr;  // last block of the previous factor, re-sync still owed

@@ -1224,6 +1224,23 @@ struct ResPlan {
   }
 };
 
+// resident workgroups of the plan's kernel variant per CU (0: it does not fit): the grid barrier needs all G at once
+static inline hipError_t res_occupancy(const ResPlan &rp, int *per_cu) {
+  *per_cu = 0;
+  const void *fn = nullptr;
+  if (rp.RV == 16 && rp.RL == 0)
+    fn = (const void *)k_mf_resident<512, 1, 0>;
+  else if (rp.RV == 32 && rp.RL == 0)
+    fn = (const void *)k_mf_resident<512, 2, 0>;
+  else if (rp.RV == 64 && rp.RL == 16)
+    fn = (const void *)k_mf_resident<512, 4, 1>;
+  else
+    return hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, fn, 512, rp.lds_bytes);
+}
+
 // update_V of factors [f_begin, f_end) in one launch. zbase: variates of factor f_begin (factor f at + (f - f_begin) D).
 static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, int kernel_class, double2 *eq, double *V, int64_t D,
                                       int f_begin, int f_end, const double *zbase, const double *lam, const double *mu,

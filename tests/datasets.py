@@ -268,3 +268,46 @@ def config5_like(scale=0.01, seed=2, ordered=True):
         y = score
     shapes = [nu, ni] + [b.shape[1] for _, b in blocks]
     return main, blocks, y, shapes
+
+
+def tuple_design(n_rows=60000, n_users=3000, n_items=5000, ctx=(50, 37), user_cols=40, item_cols=30, seed=4, third_field=0,
+                 with_item_field=True, with_item_block=True, user_block_rows=None, user_max=None):
+    """A design whose rows are index tuples (the shape of BASELINE configs[4], any size): main table = one-hot user field
+    (rows sorted by user) [+ one-hot item field] [+ a small third one-hot field]; relation blocks: user side (mapped by the user
+    column, multi-hot), item side (mapped by the item index), one context block per entry of `ctx` (own random maps).
+    Returns (main csr, blocks [(map, csr)], y, group_shapes)."""
+    rng = np.random.default_rng(seed)
+    u = np.sort(rng.integers(0, user_max or n_users, size=n_rows)).astype(np.int32)
+    it = rng.integers(0, n_items, size=n_rows).astype(np.int32)
+    cols, width, shapes = [u], n_users, [n_users]
+    if with_item_field:
+        cols.append(width + it)
+        width += n_items
+        shapes.append(n_items)
+    if third_field:
+        cols.append(width + rng.integers(0, third_field, size=n_rows).astype(np.int32))
+        width += third_field
+        shapes.append(third_field)
+    W = len(cols)
+    indices = np.empty(W * n_rows, dtype=np.int32)
+    for p, c in enumerate(cols):
+        indices[p::W] = c
+    main = sps.csr_matrix((np.ones(W * n_rows), indices, np.arange(0, W * n_rows + 1, W, dtype=np.int64)), shape=(n_rows, width))
+
+    def block(n, n_cols, per_row):
+        c = rng.integers(0, n_cols, size=(n, per_row))
+        c.sort(axis=1)
+        keep = np.ones_like(c, dtype=bool)
+        keep[:, 1:] = c[:, 1:] != c[:, :-1]
+        rows = np.repeat(np.arange(n), per_row).reshape(n, per_row)
+        vals = rng.uniform(0.3, 1.0, size=keep.sum())
+        return sps.csr_matrix((vals, (rows[keep], c[keep])), shape=(n, n_cols))
+
+    blocks = [(u.astype(np.int64), block(user_block_rows or n_users, user_cols, 3))]
+    if with_item_block:
+        blocks.append((it.astype(np.int64), block(n_items, item_cols, 3)))
+    for n_c in ctx:
+        blocks.append((rng.integers(0, n_c, size=n_rows).astype(np.int64), block(n_c, 8, 2)))
+    y = rng.normal(size=n_rows) + 0.5 * np.sin(u * 0.01) + 0.3 * np.cos(it * 0.1)
+    shapes = shapes + [b.shape[1] for _, b in blocks]
+    return main, blocks, y, shapes

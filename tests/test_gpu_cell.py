@@ -1,0 +1,105 @@
+"""The cell path of update_V (myfm_amd/csrc/mfm_cell.hpp: designs whose rows are index tuples -- one-hot main fields + relation
+blocks; no q-cache in HBM, one streaming pass per field and factor) against the CPU oracle's chain and against the generic
+relation-block path of the same library, through the C ABI.  FMTrainer.hpp:315-482."""
+import numpy as np
+import pytest
+
+from . import datasets as ds
+from .gibbs_driver import CapiGibbs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from myfm_amd import _capi
+
+    if _capi.lib().mfm_device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests need a real MI355X")
+    return _capi
+
+
+SHAPES = {
+    # user + item fields, user / item / two context blocks: streams U, I (16-bit), C, C -- the shape of BASELINE configs[4]
+    "u_i_ctx": dict(n_rows=60000, n_users=3000, n_items=5000, ctx=(50, 37)),
+    # the item index needs 32 bits
+    "items32": dict(n_rows=150000, n_users=2000, n_items=70000, ctx=(50,), item_cols=12),
+    # no large scattered stream at all: user field + user block + context blocks
+    "no_item": dict(n_rows=40000, n_users=2500, n_items=10, ctx=(64, 33), with_item_field=False, with_item_block=False),
+    # three main fields (the third small), item block but no item-side context
+    "three_fields": dict(n_rows=50000, n_users=1500, n_items=4500, ctx=(), third_field=24),
+    # few items: every stream but U is an LDS table; the user block has fewer rows than the user field has columns
+    "small_items": dict(n_rows=30000, n_users=1200, n_items=300, ctx=(40,), user_max=1000, user_block_rows=1000),
+}
+
+
+def _pair(oracle, capi, X, y, gi, rank, blocks):
+    t = oracle.OracleTrainer(X, y, blocks, rank=rank, group_index=gi)
+    c = capi.Context(X, y, blocks, rank=rank, group_index=gi)
+    c.set_state(*t.fm())
+    c.set_e(t.e(X.shape[0]))
+    return t, c
+
+
+@pytest.mark.parametrize("groups", ["5", "23"])
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_cell_chain_matches_oracle_and_generic_path(oracle, capi, monkeypatch, shape, groups):
+    monkeypatch.setenv("MFM_CELL_MIN_ROWS", "0")
+    monkeypatch.setenv("MFM_CELL_GROUPS", groups)
+    main, blocks, y, shapes = ds.tuple_design(**SHAPES[shape])
+    gi = ds.group_index_from_shapes(shapes)
+    rank, n = 3, main.shape[0]
+    t, c = _pair(oracle, capi, main, y, gi, rank, blocks)
+    assert c.plan_flags()["cell"]
+    t0 = t.clone()
+    d = CapiGibbs(c, t.clone(), n, gi)
+    monkeypatch.setenv("MFM_NO_CELL", "1")
+    _, cg = _pair(oracle, capi, main, y, gi, rank, blocks)
+    monkeypatch.delenv("MFM_NO_CELL")
+    assert not cg.plan_flags()["cell"]
+    dg = CapiGibbs(cg, t.clone(), n, gi)
+    for it in range(3):
+        t.step()
+        d.step()
+        dg.step()
+        w0, w, V = t.fm()
+        _, gw, gV = c.get_state()
+        _, hw, hV = cg.get_state()
+        np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(gV, hV, rtol=1e-7, atol=1e-8)  # cell path == generic relation-block path
+        assert abs(d.alpha - t.hyper()["alpha"]) < 1e-7 * d.alpha
+    np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-7, atol=1e-7)
+    # every sum has a fixed order: a second context from the same state is bit-identical
+    _, c2 = _pair(oracle, capi, main, y, gi, rank, blocks)
+    c2.set_state(*t0.fm())
+    c2.set_e(t0.e(n))
+    d2 = CapiGibbs(c2, t0.clone(), n, gi)
+    for it in range(3):
+        d2.step()
+    assert np.array_equal(c2.get_state()[2], c.get_state()[2]) and np.array_equal(c2.get_e(), c.get_e())
+
+
+def test_cell_single_sweep_residual_and_q(oracle, capi, monkeypatch):
+    # one update_V call on the cell path: coefficients, the residual it leaves in row order and the q-cache it owes
+    # (q_train as the reference leaves it, FMTrainer.hpp:373 / :479) against the oracle
+    monkeypatch.setenv("MFM_CELL_MIN_ROWS", "0")
+    monkeypatch.setenv("MFM_CELL_GROUPS", "7")
+    main, blocks, y, shapes = ds.tuple_design(**SHAPES["u_i_ctx"])
+    gi = ds.group_index_from_shapes(shapes)
+    rank, n = 2, main.shape[0]
+    t, c = _pair(oracle, capi, main, y, gi, rank, blocks)
+    assert c.plan_flags()["cell"]
+    G, D = t.G, t.D
+    rng = np.random.default_rng(5)
+    lam = rng.uniform(0.5, 2.0, size=(G, rank))
+    mu = rng.normal(size=(G, rank)) * 0.1
+    h = t.hyper()
+    t.set_hyper(0.7, h["mu_w"], h["lambda_w"], mu, lam)
+    z = t.clone().rng_sample_normals(rank * D)
+    for f in range(rank):
+        t.update_V_factor(f)
+    c.sweep_V(0, rank, 0.7, lam, mu, z)
+    np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(c.get_q(), t.q(n), rtol=1e-8, atol=1e-9)
