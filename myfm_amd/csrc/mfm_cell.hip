@@ -42,6 +42,7 @@ size_t CellPlan::lds_bytes(int P, int F, bool sw, int *off) const {
   }
   if (sF >= 0 && streams[sF].type != CELL_I) {
     const size_t ns = fields[F].kind == 0 ? 2 : 4;
+    o = (o + 1) & ~(size_t)1;  // (16-byte accesses)
     off[9] = (int)o;
     o += ns * (streams[sF].type == CELL_U ? (size_t)umax : (size_t)streams[sF].card);
   }
@@ -224,33 +225,77 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
   const int G = cp.G;
   const int64_t cardI = cp.sI >= 0 ? cp.streams[cp.sI].card : 0;
   if (cardI > 0 && (double)G * (double)cardI * 48.0 > 16e9) return cp.fail("the (group, item) partials would not fit");
-  // rows in cell order: inside a group by the I index (stable), chunks cut between two I values
-  std::vector<int32_t> perm((size_t)N), chunk0((size_t)G * CELL_NW + 1, 0), steps((size_t)G, 0), item;
-  std::vector<uint2> ix((size_t)N);
-  if (cp.item32) item.resize((size_t)N);
-  std::atomic<int> next_g(0);
-  auto work = [&]() {
-    std::vector<int32_t> cnt, key;
-    for (;;) {
-      const int g = next_g.fetch_add(1);
-      if (g >= G) break;
-      const int64_t R0 = grow[g], R1 = grow[g + 1], L = R1 - R0;
-      if (cp.sI >= 0) {
-        const HostStream &hI = hs[cp.sI];
-        key.resize((size_t)L);
-        cnt.assign((size_t)cardI + 1, 0);
-        for (int64_t r = 0; r < L; r++) {
-          key[r] = (int32_t)idx_of(hI, R0 + r);
-          cnt[key[r] + 1]++;
-        }
-        for (int64_t i = 0; i < cardI; i++) cnt[i + 1] += cnt[i];
-        for (int64_t r = 0; r < L; r++) perm[R0 + cnt[key[r]]++] = (int32_t)(R0 + r);
-      } else {
-        for (int64_t r = 0; r < L; r++) perm[R0 + r] = (int32_t)(R0 + r);
+  // rows in cell order: inside a group by the I index (stable), the group cut into CELL_NW wave chunks between two I values.
+  // Physical layout: what a workgroup touches in one step is ONE contiguous block -- position of row r of wave w's chunk =
+  // group base + (r / 256) * 4096 + w * 256 + r % 256 (chunks padded to whole steps; pad rows have perm = -1) -- so that HBM
+  // sees 32-KiB bursts per array and step, not 4096 independent 2-KiB streams.
+  constexpr int64_t WROWS = 64 * CELL_R, SROWS = WROWS * CELL_NW;  // rows of a wave / of the workgroup per step
+  std::vector<int32_t> sorted((size_t)N), chunk0((size_t)G * (CELL_NW + 1), 0), steps((size_t)G, 0);
+  auto run_groups = [&](auto fn) {
+    std::atomic<int> next_g(0);
+    auto work = [&]() {
+      for (;;) {
+        const int g = next_g.fetch_add(1);
+        if (g >= G) break;
+        fn(g);
       }
-      // records
-      for (int64_t p = R0; p < R1; p++) {
-        const int64_t t = perm[p];
+    };
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int T = std::max(1, std::min({hw > 0 ? hw : 1, 16, G}));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+  };
+  run_groups([&](int g) {
+    const int64_t R0 = grow[g], R1 = grow[g + 1], L = R1 - R0;
+    if (cp.sI >= 0) {
+      const HostStream &hI = hs[cp.sI];
+      std::vector<int32_t> key((size_t)L), cnt((size_t)cardI + 1, 0);
+      for (int64_t r = 0; r < L; r++) {
+        key[r] = (int32_t)idx_of(hI, R0 + r);
+        cnt[key[r] + 1]++;
+      }
+      for (int64_t i = 0; i < cardI; i++) cnt[i + 1] += cnt[i];
+      for (int64_t r = 0; r < L; r++) sorted[R0 + cnt[key[r]]++] = (int32_t)(R0 + r);
+    } else {
+      for (int64_t r = 0; r < L; r++) sorted[R0 + r] = (int32_t)(R0 + r);
+    }
+    int64_t longest = 0;
+    int32_t *c0 = &chunk0[(size_t)g * (CELL_NW + 1)];
+    c0[0] = (int32_t)R0;
+    for (int j = 1; j <= CELL_NW; j++) {
+      int64_t r = j == CELL_NW ? R1 : R0 + L * j / CELL_NW;
+      if (cp.sI >= 0 && j < CELL_NW) {
+        const HostStream &hI = hs[cp.sI];
+        while (r < R1 && r > R0 && idx_of(hI, sorted[r]) == idx_of(hI, sorted[r - 1])) r++;
+      }
+      r = std::max<int64_t>(r, c0[j - 1]);
+      c0[j] = (int32_t)r;
+      longest = std::max<int64_t>(longest, r - c0[j - 1]);
+    }
+    steps[g] = (int32_t)((longest + WROWS - 1) / WROWS);
+  });
+  std::vector<int32_t> gbase((size_t)G + 1, 0), clen((size_t)G * CELL_NW, 0);
+  int64_t npad = 0;
+  for (int g = 0; g < G; g++) {
+    gbase[g] = (int32_t)npad;
+    npad += (int64_t)steps[g] * SROWS;
+    if (npad >= (int64_t)2147483647) return cp.fail("padded row count exceeds 2^31");
+  }
+  gbase[G] = (int32_t)npad;
+  cp.Npad = npad;
+  std::vector<int32_t> perm((size_t)npad, -1), item;
+  std::vector<uint2> ix((size_t)npad, make_uint2(0, 0));
+  if (cp.item32) item.assign((size_t)npad, 0);
+  run_groups([&](int g) {
+    const int32_t *c0 = &chunk0[(size_t)g * (CELL_NW + 1)];
+    for (int w = 0; w < CELL_NW; w++) {
+      const int64_t len = c0[w + 1] - c0[w];
+      clen[(size_t)g * CELL_NW + w] = (int32_t)len;
+      for (int64_t r = 0; r < len; r++) {
+        const int64_t t = sorted[c0[w] + r];
+        const int64_t p = (int64_t)gbase[g] + (r / WROWS) * SROWS + (int64_t)w * WROWS + (r % WROWS);
         uint32_t sl[4] = {0, 0, 0, 0};
         for (size_t si = 0; si < cp.streams.size(); si++) {
           const int64_t v = idx_of(hs[si], t);
@@ -263,40 +308,20 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
             item[p] = (int32_t)v;
         }
         ix[p] = make_uint2(sl[0] | (sl[1] << 16), sl[2] | (sl[3] << 16));
+        perm[p] = (int32_t)t;
       }
-      // wave chunks
-      int64_t longest = 0;
-      chunk0[(size_t)g * CELL_NW] = (int32_t)R0;
-      for (int j = 1; j <= CELL_NW; j++) {
-        int64_t r = j == CELL_NW ? R1 : R0 + L * j / CELL_NW;
-        if (cp.sI >= 0 && j < CELL_NW) {
-          const HostStream &hI = hs[cp.sI];
-          while (r < R1 && r > R0 && idx_of(hI, perm[r]) == idx_of(hI, perm[r - 1])) r++;
-        }
-        r = std::max<int64_t>(r, chunk0[(size_t)g * CELL_NW + j - 1]);
-        if (j < CELL_NW) chunk0[(size_t)g * CELL_NW + j] = (int32_t)r;
-        longest = std::max<int64_t>(longest, r - chunk0[(size_t)g * CELL_NW + j - 1]);
-      }
-      steps[g] = (int32_t)((longest + 64 * CELL_R - 1) / (64 * CELL_R));
     }
-  };
-  {
-    const int hw = (int)std::thread::hardware_concurrency();
-    const int T = std::max(1, std::min({hw > 0 ? hw : 1, 16, G}));
-    std::vector<std::thread> pool;
-    for (int t = 1; t < T; t++) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
-  }
-  chunk0[(size_t)G * CELL_NW] = (int32_t)N;
+  });
+  sorted = std::vector<int32_t>();
   // device
   cp.ix.upload(ix);
   cp.item.upload(item);
   cp.perm.upload(perm);
-  cp.chunk0.upload(chunk0);
+  cp.chunk_len.upload(clen);
+  cp.grp_base.upload(gbase);
   cp.grp_u0.upload(gu0);
   cp.grp_steps.upload(steps);
-  cp.e.alloc((size_t)N);
+  cp.e.alloc((size_t)npad);
   int64_t maxcard = 0;
   for (size_t si = 0; si < cp.streams.size(); si++) {
     const size_t n = (size_t)cp.streams[si].card;
@@ -325,18 +350,24 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
 // e between row order (eq[t].x) and cell order
 __global__ void k_cell_pack(const double2 *__restrict__ eq, const int32_t *__restrict__ perm, int64_t N, double *__restrict__ e) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < N) e[p] = eq[perm[p]].x;
+  if (p < N) {
+    const int t = perm[p];
+    e[p] = t >= 0 ? eq[t].x : 0.0;  // (pad rows of the step layout)
+  }
 }
 __global__ void k_cell_unpack(const double *__restrict__ e, const int32_t *__restrict__ perm, int64_t N, double2 *__restrict__ eq) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < N) eq[perm[p]].x = e[p];
+  if (p < N) {
+    const int t = perm[p];
+    if (t >= 0) eq[t].x = e[p];
+  }
 }
 void cell_pack_e(hipStream_t s, CellPlan &cp, const double2 *eq) {
-  hipLaunchKernelGGL(k_cell_pack, dim3(cdiv_c(cp.N, 256)), dim3(256), 0, s, eq, cp.perm.p, cp.N, cp.e.p);
+  hipLaunchKernelGGL(k_cell_pack, dim3(cdiv_c(cp.Npad, 256)), dim3(256), 0, s, eq, cp.perm.p, cp.Npad, cp.e.p);
   MFM_HIP_CHECK(hipGetLastError());
 }
 void cell_unpack_e(hipStream_t s, CellPlan &cp, double2 *eq) {
-  hipLaunchKernelGGL(k_cell_unpack, dim3(cdiv_c(cp.N, 256)), dim3(256), 0, s, cp.e.p, cp.perm.p, cp.N, eq);
+  hipLaunchKernelGGL(k_cell_unpack, dim3(cdiv_c(cp.Npad, 256)), dim3(256), 0, s, cp.e.p, cp.perm.p, cp.Npad, eq);
   MFM_HIP_CHECK(hipGetLastError());
 }
 
@@ -347,6 +378,7 @@ struct CellPrepJob {
   int dst_stride, n, nsrc;
   const double *src[4];
   int sstride[4], sn[4];  // (a field shorter than its stream's table contributes only where it has values)
+  double coef[4];
 };
 constexpr int CELL_PREP_JOBS = 12;
 struct CellPrepArgs {
@@ -359,7 +391,7 @@ __global__ __launch_bounds__(256) void k_cell_prep(CellPrepArgs a) {
   if (i >= j.n) return;
   double v = 0.0;
   for (int k = 0; k < j.nsrc; k++)
-    if (i < j.sn[k]) v += j.src[k][(int64_t)i * j.sstride[k]];
+    if (i < j.sn[k]) v += j.coef[k] * j.src[k][(int64_t)i * j.sstride[k]];
   j.dst[(int64_t)i * j.dst_stride] = v;
 }
 
@@ -382,6 +414,7 @@ void cell_prep(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellSr
         j.src[j.nsrc] = cur[f].p;
         j.sstride[j.nsrc] = cur[f].stride;
         j.sn[j.nsrc] = (int)std::min<int64_t>(cp.fields[f].n, n);
+        j.coef[j.nsrc] = 1.0;
         j.nsrc++;
       }
     maxn = std::max(maxn, (int)n);
@@ -399,6 +432,7 @@ void cell_prep(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellSr
           j.src[0] = (const double *)cp.DP.p + k;
           j.sstride[0] = 2;
           j.sn[0] = (int)st.card;
+          j.coef[0] = 1.0;
         }
       }
     } else {
@@ -418,7 +452,7 @@ struct CellPassArgs {
   const uint2 *ix;
   const int32_t *item;
   double *e;
-  const int32_t *chunk0, *grp_u0, *grp_steps;
+  const int32_t *chunk_len, *grp_base, *grp_u0, *grp_steps;
   const double *QA[CELL_MAX_STREAMS], *QS[CELL_MAX_STREAMS];
   const double *packI;
   const double2 *DP;
@@ -474,7 +508,9 @@ __global__ __launch_bounds__(CELL_NT) void k_cell_pass(CellPassArgs a) {
   }
   __syncthreads();
 
-  const int r0 = a.chunk0[g * CELL_NW + wv], r1 = a.chunk0[g * CELL_NW + wv + 1];
+  // row r of this wave's chunk lives at r0 + (r / 256) * 4096 + r % 256 (one contiguous block per workgroup and step)
+  const int len = a.chunk_len[g * CELL_NW + wv];
+  const int r0 = a.grp_base[g] + wv * (64 * CELL_R);
   const int steps = a.grp_steps[g];
   const int slotF = FT >= 0 ? a.slot[a.sF] : 0;
   const int slotP = HASP ? a.slot[a.sP] : 0;
@@ -486,79 +522,81 @@ __global__ __launch_bounds__(CELL_NT) void k_cell_pass(CellPassArgs a) {
   int carry_it = -1;
   double carry[4] = {0.0, 0.0, 0.0, 0.0};
 
-  // software pipeline: the records and residuals of step st + 1 are requested before step st is worked on
+  // software pipeline: the records and residuals of step st + 1 are requested while step st is worked on -- AFTER the I-table
+  // gathers of step st, so that waiting for those (vmcnt counts in order) does not wait for the prefetch
+  constexpr int WROWS = 64 * CELL_R, SROWS = WROWS * CELL_NW;
+  const bool has_I = a.cardI > 0;
+  int slotI = 0;
+#pragma unroll
+  for (int s = 0; s < CELL_MAX_STREAMS; s++)
+    if (s < a.n_streams && a.type[s] == CELL_I) slotI = a.slot[s];
   uint2 rec_n[CELL_R];
   double e_n[CELL_R];
   int it_n[CELL_R];
 #pragma unroll
   for (int k = 0; k < CELL_R; k++) {
-    const int r = r0 + k * 64 + lane;
+    const int lr = k * 64 + lane, pos = r0 + lr;
     rec_n[k] = make_uint2(0, 0);
     e_n[k] = 0.0;
     it_n[k] = 0;
-    if (r < r1) {
-      rec_n[k] = a.ix[r];
-      e_n[k] = __builtin_nontemporal_load(a.e + r);
-      if (ITEM32) it_n[k] = a.item[r];
+    if (lr < len) {
+      rec_n[k] = a.ix[pos];
+      e_n[k] = __builtin_nontemporal_load(a.e + pos);
+      if (ITEM32) it_n[k] = a.item[pos];
     }
   }
   for (int st = 0; st < steps; st++) {
-    const int base = r0 + st * (64 * CELL_R);
+    const int base = r0 + st * SROWS, lbase = st * WROWS;
     uint2 rec[CELL_R];
     double e[CELL_R];
     int it[CELL_R];
+    bool valid[CELL_R];
+    double4 pk[CELL_R];
 #pragma unroll
     for (int k = 0; k < CELL_R; k++) {
       rec[k] = rec_n[k];
       e[k] = e_n[k];
-      it[k] = it_n[k];
+      valid[k] = lbase + k * 64 + lane < len;
+      it[k] = -2;
+      pk[k] = make_double4(0.0, 0.0, 0.0, 0.0);
+      if (has_I && valid[k]) {
+        it[k] = ITEM32 ? it_n[k] : cell_slot(rec[k], slotI);
+        pk[k] = packI[it[k]];
+      }
     }
     if (st + 1 < steps) {
 #pragma unroll
       for (int k = 0; k < CELL_R; k++) {
-        const int r = base + (64 * CELL_R) + k * 64 + lane;
-        if (r < r1) {
-          rec_n[k] = a.ix[r];
-          e_n[k] = __builtin_nontemporal_load(a.e + r);
-          if (ITEM32) it_n[k] = a.item[r];
+        const int lr = lbase + WROWS + k * 64 + lane, pos = base + SROWS + k * 64 + lane;
+        if (lr < len) {
+          rec_n[k] = a.ix[pos];
+          e_n[k] = __builtin_nontemporal_load(a.e + pos);
+          if (ITEM32) it_n[k] = a.item[pos];
         }
       }
     }
     double v[CELL_R][NS > 0 ? NS : 1];
     int idxF[CELL_R];
-    bool valid[CELL_R];
 #pragma unroll
     for (int k = 0; k < CELL_R; k++) {
-      const int r = base + k * 64 + lane;
-      valid[k] = r < r1;
-      double qa = 0.0, qs = 0.0;
-      double2 dI = make_double2(0.0, 0.0);
-      int itv = -2;
+      const int pos = base + k * 64 + lane;
+      double qa = pk[k].x, qs = pk[k].y;  // (fixed order of the sum: I first, then the LDS streams in stream order)
       if (valid[k]) {
 #pragma unroll
         for (int s = 0; s < CELL_MAX_STREAMS; s++) {
-          if (s < a.n_streams) {
-            if (a.type[s] == CELL_I) {
-              itv = ITEM32 ? it[k] : cell_slot(rec[k], a.slot[s]);
-              const double4 pk = packI[itv];
-              qa += pk.x;
-              qs += pk.y;
-              dI = make_double2(pk.z, pk.w);
-            } else {
-              const int i = cell_slot(rec[k], a.slot[s]);
-              const double x = lds[a.ldsS[s] + i];
-              qs += x;
-              if (HASP) qa += a.pair[s] == 1 ? lds[a.ldsA[s] + i] : x;
-            }
+          if (s < a.n_streams && a.type[s] != CELL_I) {
+            const int i = cell_slot(rec[k], a.slot[s]);
+            const double x = lds[a.ldsS[s] + i];
+            qs += x;
+            if (HASP) qa += a.pair[s] == 1 ? lds[a.ldsA[s] + i] : x;
           }
         }
         if (HASP) {
-          const double2 d = p_on_I ? dI : dpl[cell_slot(rec[k], slotP)];
+          const double2 d = p_on_I ? make_double2(pk[k].z, pk[k].w) : dpl[cell_slot(rec[k], slotP)];
           e[k] += qa * d.x + d.y;
-          __builtin_nontemporal_store(e[k], a.e + r);
+          __builtin_nontemporal_store(e[k], a.e + pos);
         }
       }
-      it[k] = itv;
       if (FT >= 0) {
         const double h = qs;
         if (NS == 2) {
@@ -570,7 +608,7 @@ __global__ __launch_bounds__(CELL_NT) void k_cell_pass(CellPassArgs a) {
           v[k][2] = valid[k] ? e[k] : 0.0;
           v[k][3] = valid[k] ? e[k] * h : 0.0;
         }
-        idxF[k] = (FT == CELL_I) ? itv : cell_slot(rec[k], slotF);
+        idxF[k] = (FT == CELL_I) ? it[k] : cell_slot(rec[k], slotF);
       }
     }
     if (FT == CELL_U || FT == CELL_C) {
@@ -673,7 +711,8 @@ void cell_pass(hipStream_t s, Timing &tm, CellPlan &cp, int P, int F, bool sw, d
   a.ix = cp.ix.p;
   a.item = cp.item.p;
   a.e = cp.e.p;
-  a.chunk0 = cp.chunk0.p;
+  a.chunk_len = cp.chunk_len.p;
+  a.grp_base = cp.grp_base.p;
   a.grp_u0 = cp.grp_u0.p;
   a.grp_steps = cp.grp_steps.p;
   a.packI = cp.packI.p;
@@ -730,26 +769,47 @@ void cell_pass(hipStream_t s, Timing &tm, CellPlan &cp, int P, int F, bool sw, d
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// main field: sums over the groups (group order), the draw of FMTrainer.hpp:357-369 with x = 1: S2 = sum q_other^2,
-// S1 = -sum e q_other
-template <int SRC /* 0: direct [n][2], 1: partials [G][card][2] */>
-__global__ __launch_bounds__(256) void k_cell_draw(const double *__restrict__ src, int G, int64_t card, int n, double *__restrict__ Vf,
-                                                   const double *__restrict__ zf, const int32_t *__restrict__ group,
-                                                   const double *__restrict__ lam, const double *__restrict__ mu, double alpha,
-                                                   int64_t base, double2 *__restrict__ DP) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  double S2 = 0.0, Seh = 0.0;
-  if (SRC == 0) {
-    S2 = src[(int64_t)i * 2];
-    Seh = src[(int64_t)i * 2 + 1];
-  } else {
-    for (int g = 0; g < G; g++) {
-      const double2 p = *(const double2 *)(src + ((int64_t)g * card + i) * 2);
-      S2 += p.x;
-      Seh += p.y;
+// Sums of the (group, index) partials over the groups, fixed association: 256 threads = 32 index values x 8 slices of the
+// group range; a slice adds its groups in group order, the eight slice sums are added in slice order.
+template <int NS>
+__device__ __forceinline__ bool cell_group_sums(const double *__restrict__ src, int G, int64_t card, int n, double (&out)[NS]) {
+  __shared__ double part[8][32][NS];
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + o;
+  const int gs = (G + 7) / 8;
+  double acc[NS];
+#pragma unroll
+  for (int j = 0; j < NS; j++) acc[j] = 0.0;
+  if (i < n) {
+    const int g1 = min(G, (sl + 1) * gs);
+    for (int g = sl * gs; g < g1; g++) {
+      const double2 *p = (const double2 *)(src + ((int64_t)g * card + i) * NS);
+#pragma unroll
+      for (int j = 0; j < NS / 2; j++) {
+        const double2 x = p[j];
+        acc[2 * j] += x.x;
+        acc[2 * j + 1] += x.y;
+      }
     }
   }
+#pragma unroll
+  for (int j = 0; j < NS; j++) part[sl][o][j] = acc[j];
+  __syncthreads();
+  if (sl != 0 || i >= n) return false;
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    double t = part[0][o][j];
+#pragma unroll
+    for (int k = 1; k < 8; k++) t += part[k][o][j];
+    out[j] = t;
+  }
+  return true;
+}
+
+// main field: the draw of FMTrainer.hpp:357-369 with x = 1 (S2 = sum q_other^2, S1 = -sum e q_other), V and (d1, d2) = (v' - v, 0)
+__device__ __forceinline__ void cell_draw_one(int i, double S2, double Seh, double *__restrict__ Vf, const double *__restrict__ zf,
+                                              const int32_t *__restrict__ group, const double *__restrict__ lam,
+                                              const double *__restrict__ mu, double alpha, int64_t base, double2 *__restrict__ DP) {
   const int64_t j = base + i;
   const double old = Vf[j];
   const int gi = group[j];
@@ -763,6 +823,23 @@ __global__ __launch_bounds__(256) void k_cell_draw(const double *__restrict__ sr
   Vf[j] = fresh;
   DP[i] = make_double2(fresh - old, 0.0);
 }
+__global__ __launch_bounds__(256) void k_cell_draw_direct(const double *__restrict__ stat, int n, double *__restrict__ Vf,
+                                                          const double *__restrict__ zf, const int32_t *__restrict__ group,
+                                                          const double *__restrict__ lam, const double *__restrict__ mu, double alpha,
+                                                          int64_t base, double2 *__restrict__ DP) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  cell_draw_one(i, stat[(int64_t)i * 2], stat[(int64_t)i * 2 + 1], Vf, zf, group, lam, mu, alpha, base, DP);
+}
+__global__ __launch_bounds__(256) void k_cell_draw_groups(const double *__restrict__ src, int G, int64_t card, int n,
+                                                          double *__restrict__ Vf, const double *__restrict__ zf,
+                                                          const int32_t *__restrict__ group, const double *__restrict__ lam,
+                                                          const double *__restrict__ mu, double alpha, int64_t base,
+                                                          double2 *__restrict__ DP) {
+  double sum[2];
+  if (!cell_group_sums<2>(src, G, card, n, sum)) return;
+  cell_draw_one(blockIdx.x * 32 + (threadIdx.x & 31), sum[0], sum[1], Vf, zf, group, lam, mu, alpha, base, DP);
+}
 
 void cell_draw_main(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *Vf, const double *zf, const int32_t *group, const double *lam,
                     const double *mu, double alpha) {
@@ -771,37 +848,28 @@ void cell_draw_main(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *Vf, 
   TimedLaunch t(tm, s, KC_CELL_SMALL, 0.0);
   const int n = (int)f.n;
   if (st.type == CELL_U)
-    hipLaunchKernelGGL((k_cell_draw<0>), dim3(cdiv_c(n, 256)), dim3(256), 0, s, cp.stat.p, cp.G, st.card, n, Vf, zf, group, lam, mu, alpha,
-                       f.base, cp.DP.p);
+    hipLaunchKernelGGL(k_cell_draw_direct, dim3(cdiv_c(n, 256)), dim3(256), 0, s, cp.stat.p, n, Vf, zf, group, lam, mu, alpha, f.base,
+                       cp.DP.p);
   else
-    hipLaunchKernelGGL((k_cell_draw<1>), dim3(cdiv_c(n, 256)), dim3(256), 0, s, st.type == CELL_I ? cp.cells2.p : cp.cpart.p, cp.G, st.card,
-                       n, Vf, zf, group, lam, mu, alpha, f.base, cp.DP.p);
+    hipLaunchKernelGGL(k_cell_draw_groups, dim3(cdiv_c(n, 32)), dim3(256), 0, s, st.type == CELL_I ? cp.cells2.p : cp.cpart.p, cp.G,
+                       st.card, n, Vf, zf, group, lam, mu, alpha, f.base, cp.DP.p);
   MFM_HIP_CHECK(hipGetLastError());
 }
 
-// block on I / C: rec[i].{c, c_S, e, e_q} (words 2..5) = sum over the groups, group order (FMTrainer.hpp:401-407)
+// block on I / C: rec[i].{c, c_S, e, e_q} (words 2..5) = sum over the groups (FMTrainer.hpp:401-407)
 __global__ __launch_bounds__(256) void k_cell_block_stats(const double *__restrict__ src, int G, int64_t card, int n, double *__restrict__ rec) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  for (int g = 0; g < G; g++) {
-    const double2 *p = (const double2 *)(src + ((int64_t)g * card + i) * 4);
-    const double2 a = p[0], b = p[1];
-    s0 += a.x;
-    s1 += a.y;
-    s2 += b.x;
-    s3 += b.y;
-  }
-  double2 *r = (double2 *)rec + (int64_t)i * 4;
-  r[1] = make_double2(s0, s1);
-  r[2] = make_double2(s2, s3);
+  double sum[4];
+  if (!cell_group_sums<4>(src, G, card, n, sum)) return;
+  double2 *r = (double2 *)rec + (int64_t)(blockIdx.x * 32 + (threadIdx.x & 31)) * 4;
+  r[1] = make_double2(sum[0], sum[1]);
+  r[2] = make_double2(sum[2], sum[3]);
 }
 void cell_block_stats(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *rec) {
   const CellField &f = cp.fields[F];
   const CellStream &st = cp.streams[f.stream];
   if (st.type == CELL_U) return;
   TimedLaunch t(tm, s, KC_CELL_SMALL, 0.0);
-  hipLaunchKernelGGL(k_cell_block_stats, dim3(cdiv_c(f.n, 256)), dim3(256), 0, s, st.type == CELL_I ? cp.cells4.p : cp.cpart.p, cp.G, st.card,
+  hipLaunchKernelGGL(k_cell_block_stats, dim3(cdiv_c(f.n, 32)), dim3(256), 0, s, st.type == CELL_I ? cp.cells4.p : cp.cpart.p, cp.G, st.card,
                      (int)f.n, rec);
   MFM_HIP_CHECK(hipGetLastError());
 }
@@ -820,6 +888,243 @@ void cell_block_delta(hipStream_t s, Timing &tm, CellPlan &cp, int F, const doub
   const CellField &f = cp.fields[F];
   TimedLaunch t(tm, s, KC_CELL_SMALL, 0.0);
   hipLaunchKernelGGL(k_cell_block_delta, dim3(cdiv_c(f.n, 256)), dim3(256), 0, s, rec, saved, (int)f.n, cp.DP.p);
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// update_e on the cell layout (FMTrainer.hpp:493-497 -> FM.hpp:54-136). With the row a tuple of indices
+//     score_t = w0 + sum_s LS_s[idx_s] + 1/2 sum_f (sum_s Q_s,f[idx_s])^2,
+//     Q_s,f = sum of the stream's fields' factor-f tables (V rows of a main field, X_B V_B rows of a block: FM.hpp:104-106),
+//     LS_s  = sum of their linear terms (w, X_B w_B: :81) - 1/2 sum of their sum_f sum_l x^2 v^2 terms (:121-127),
+// so the scorer is K / FB passes over (accumulator, index record), FB factors per pass with the tables in LDS, instead of one
+// pass that gathers three or four K-vectors per row from L2 / HBM (k_score at N = 50 M, rank 64: 68 GB of traffic, 34 ms).
+struct CellScoreArgs {
+  const uint2 *ix;
+  const int32_t *item;
+  double *acc;
+  const int32_t *chunk_len, *grp_base, *grp_u0, *grp_steps;
+  const double *Q[CELL_MAX_STREAMS];   // [card][KS]
+  const double *LS[CELL_MAX_STREAMS];  // [card]
+  int n_streams, type[CELL_MAX_STREAMS], slot[CELL_MAX_STREAMS], card[CELL_MAX_STREAMS], lds_off[CELL_MAX_STREAMS];
+  int KS, f0, nf;  // factors [f0, f0 + nf) of this pass, nf <= FB (nf = 0: the initial pass, acc = w0 + sum LS)
+  double w0;
+  int cardI;
+};
+
+template <int FB, bool ITEM32>
+__global__ __launch_bounds__(CELL_NT) void k_cell_score(CellScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int g = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int u0 = a.grp_u0[g], nu = a.grp_u0[g + 1] - u0;
+  constexpr int TW = FB > 0 ? FB : 1;  // doubles per table entry in LDS
+  for (int s = 0; s < a.n_streams; s++) {
+    if (a.type[s] == CELL_I) continue;
+    const int n = a.type[s] == CELL_U ? nu : a.card[s];
+    const int o = a.type[s] == CELL_U ? u0 : 0;
+    double *t = lds + a.lds_off[s];
+    if (FB == 0) {
+      for (int i = tid; i < n; i += CELL_NT) t[i] = a.LS[s][o + i];
+    } else {
+      for (int i = tid; i < n * FB; i += CELL_NT) {
+        const int r = i / FB, j = i - r * FB;
+        t[i] = j < a.nf ? a.Q[s][(int64_t)(o + r) * a.KS + a.f0 + j] : 0.0;
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int WROWS = 64 * CELL_R, SROWS = WROWS * CELL_NW;
+  const int len = a.chunk_len[g * CELL_NW + wv];
+  const int r0 = a.grp_base[g] + wv * WROWS;
+  const int steps = a.grp_steps[g];
+  int sI = -1;
+#pragma unroll
+  for (int s = 0; s < CELL_MAX_STREAMS; s++)
+    if (s < a.n_streams && a.type[s] == CELL_I) sI = s;
+  for (int st = 0; st < steps; st++) {
+#pragma unroll
+    for (int k = 0; k < CELL_R; k++) {
+      const int lr = st * WROWS + k * 64 + lane, pos = r0 + st * SROWS + k * 64 + lane;
+      if (lr >= len) continue;
+      const uint2 rec = a.ix[pos];
+      double q[TW];
+#pragma unroll
+      for (int j = 0; j < TW; j++) q[j] = 0.0;
+      if (sI >= 0) {
+        const int it = ITEM32 ? a.item[pos] : cell_slot(rec, a.slot[sI]);
+        if (FB == 0) {
+          q[0] = a.LS[sI][it];
+        } else {
+          const double *src = a.Q[sI] + (int64_t)it * a.KS + a.f0;
+#pragma unroll
+          for (int j = 0; j < TW; j++) q[j] = j < a.nf ? src[j] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < CELL_MAX_STREAMS; s++)
+        if (s < a.n_streams && a.type[s] != CELL_I) {
+          const double *t = lds + a.lds_off[s] + cell_slot(rec, a.slot[s]) * TW;
+#pragma unroll
+          for (int j = 0; j < TW; j++) q[j] += t[j];
+        }
+      if (FB == 0) {
+        a.acc[pos] = a.w0 + q[0];
+      } else {
+        double acc = a.acc[pos];
+#pragma unroll
+        for (int j = 0; j < TW; j++) acc += 0.5 * (q[j] * q[j]);
+        a.acc[pos] = acc;
+      }
+    }
+  }
+}
+
+// per feature: sum_f v_jf^2 from the row-major copy of V
+__global__ __launch_bounds__(256) void k_cell_rowsumsq(const double *__restrict__ Vt, int64_t D, int K, int KS, double *__restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= D) return;
+  const double *r = Vt + j * KS;
+  double s = 0.0;
+  for (int f = 0; f < K; f++) s += r[f] * r[f];
+  out[j] = s;
+}
+__global__ void k_cell_unpack_score(const double *__restrict__ acc, const int32_t *__restrict__ perm, int64_t N,
+                                    const double *__restrict__ y, double2 *__restrict__ eq) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < N) {
+    const int t = perm[p];
+    if (t >= 0) eq[t].x = y ? acc[p] - y[t] : acc[p];
+  }
+}
+
+template <int FB>
+static void launch_score_t(hipStream_t s, int G, size_t lds, const CellScoreArgs &a, bool item32) {
+  static DeviceOnce raised;
+  if (raised.need()) {
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_cell_score<FB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_cell_score<FB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    raised.mark();
+  }
+  if (item32)
+    hipLaunchKernelGGL((k_cell_score<FB, true>), dim3(G), dim3(CELL_NT), lds, s, a);
+  else
+    hipLaunchKernelGGL((k_cell_score<FB, false>), dim3(G), dim3(CELL_NT), lds, s, a);
+}
+
+void cell_score(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellScoreSrc> &src, const double *Vt, int64_t D, int K, int KS,
+                double w0, const double *y, double2 *eq) {
+  // tables: Q_s [card][KS], LS_s [card]
+  if (cp.vss.n < (size_t)D) cp.vss.alloc((size_t)std::max<int64_t>(D, 1));
+  for (size_t si = 0; si < cp.streams.size(); si++) {
+    const size_t need = (size_t)cp.streams[si].card * (size_t)std::max(KS, 1);
+    if (cp.scoreQ[si].n < need) cp.scoreQ[si].alloc(need);
+    if (cp.scoreLS[si].n < (size_t)cp.streams[si].card) cp.scoreLS[si].alloc((size_t)cp.streams[si].card);
+  }
+  {
+    TimedLaunch t(tm, s, KC_CELL_SMALL, 0.0);
+    if (K > 0) hipLaunchKernelGGL(k_cell_rowsumsq, dim3(cdiv_c(D, 256)), dim3(256), 0, s, Vt, D, K, KS, cp.vss.p);
+    CellPrepArgs a;
+    a.n_jobs = 0;
+    int64_t maxn = 0;
+    for (size_t si = 0; si < cp.streams.size(); si++) {
+      const CellStream &st = cp.streams[si];
+      CellPrepJob &jq = a.job[a.n_jobs++];
+      CellPrepJob &jl = a.job[a.n_jobs++];
+      jq.dst = cp.scoreQ[si].p;
+      jq.dst_stride = 1;
+      jq.n = (int)(st.card * KS);
+      jq.nsrc = 0;
+      jl.dst = cp.scoreLS[si].p;
+      jl.dst_stride = 1;
+      jl.n = (int)st.card;
+      jl.nsrc = 0;
+      if (st.card * KS >= (int64_t)2147483647) throw Error(MFM_ERR_RUNTIME, "cell scorer: table too large");
+      if (st.fields.size() > 2) throw Error(MFM_ERR_RUNTIME, "internal: more than two fields on one index stream");
+      for (int f : st.fields) {
+        const CellField &fd = cp.fields[f];
+        const CellScoreSrc &sc = src[f];
+        const double *q = fd.kind == 0 ? Vt + fd.base * KS : sc.q;
+        const double *lin = sc.lin;
+        const double *ss = fd.kind == 0 ? cp.vss.p + fd.base : sc.ss;
+        if (K > 0) {
+          jq.src[jq.nsrc] = q;
+          jq.sstride[jq.nsrc] = 1;
+          jq.sn[jq.nsrc] = (int)(std::min<int64_t>(fd.n, st.card) * KS);
+          jq.coef[jq.nsrc] = 1.0;
+          jq.nsrc++;
+        }
+        jl.src[jl.nsrc] = lin;
+        jl.sstride[jl.nsrc] = 1;
+        jl.sn[jl.nsrc] = (int)std::min<int64_t>(fd.n, st.card);
+        jl.coef[jl.nsrc] = 1.0;
+        jl.nsrc++;
+        if (K > 0) {
+          jl.src[jl.nsrc] = ss;
+          jl.sstride[jl.nsrc] = 1;
+          jl.sn[jl.nsrc] = (int)std::min<int64_t>(fd.n, st.card);
+          jl.coef[jl.nsrc] = -0.5;
+          jl.nsrc++;
+        }
+      }
+      maxn = std::max<int64_t>(maxn, std::max<int64_t>(jq.n, jl.n));
+    }
+    hipLaunchKernelGGL(k_cell_prep, dim3(cdiv_c(maxn, 256), a.n_jobs), dim3(256), 0, s, a);
+  }
+  CellScoreArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.ix = cp.ix.p;
+  a.item = cp.item.p;
+  a.acc = cp.e.p;
+  a.chunk_len = cp.chunk_len.p;
+  a.grp_base = cp.grp_base.p;
+  a.grp_u0 = cp.grp_u0.p;
+  a.grp_steps = cp.grp_steps.p;
+  a.n_streams = (int)cp.streams.size();
+  a.KS = KS;
+  a.w0 = w0;
+  a.cardI = cp.sI >= 0 ? (int)cp.streams[cp.sI].card : 0;
+  size_t per_factor = 0;  // LDS doubles per factor of a pass
+  for (int si = 0; si < a.n_streams; si++) {
+    a.Q[si] = cp.scoreQ[si].p;
+    a.LS[si] = cp.scoreLS[si].p;
+    a.type[si] = cp.streams[si].type;
+    a.slot[si] = cp.streams[si].slot;
+    a.card[si] = (int)cp.streams[si].card;
+    if (a.type[si] != CELL_I) per_factor += a.type[si] == CELL_U ? (size_t)cp.umax : (size_t)cp.streams[si].card;
+  }
+  auto layout = [&](int tw) {
+    size_t o = 0;
+    for (int si = 0; si < a.n_streams; si++) {
+      if (a.type[si] == CELL_I) continue;
+      a.lds_off[si] = (int)o;
+      o += (size_t)tw * (a.type[si] == CELL_U ? (size_t)cp.umax : (size_t)cp.streams[si].card);
+      o = (o + 1) & ~(size_t)1;
+    }
+    return (o + 2) * sizeof(double);
+  };
+  int FB = 8;
+  while (FB > 1 && layout(FB) > CELL_LDS_BYTES) FB /= 2;
+  if (layout(1) > CELL_LDS_BYTES) throw Error(MFM_ERR_RUNTIME, "internal: cell scorer tables do not fit the LDS");
+  const double row_bytes = (double)cp.N * (8.0 + 8.0 + 8.0 + (cp.item32 ? 4.0 : 0.0));
+  {
+    TimedLaunch t(tm, s, KC_UPDATE_E, row_bytes - 8.0 * cp.N);
+    a.f0 = 0;
+    a.nf = 0;
+    launch_score_t<0>(s, cp.G, layout(1), a, cp.item32);
+  }
+  for (int f0 = 0; f0 < K; f0 += FB) {
+    TimedLaunch t(tm, s, KC_UPDATE_E, row_bytes);
+    a.f0 = f0;
+    a.nf = std::min(FB, K - f0);
+    const size_t lds = layout(FB);
+    if (FB == 8) launch_score_t<8>(s, cp.G, lds, a, cp.item32);
+    else if (FB == 4) launch_score_t<4>(s, cp.G, lds, a, cp.item32);
+    else if (FB == 2) launch_score_t<2>(s, cp.G, lds, a, cp.item32);
+    else launch_score_t<1>(s, cp.G, lds, a, cp.item32);
+  }
+  {
+    TimedLaunch t(tm, s, KC_UPDATE_E, 28.0 * cp.N);
+    hipLaunchKernelGGL(k_cell_unpack_score, dim3(cdiv_c(cp.Npad, 256)), dim3(256), 0, s, cp.e.p, cp.perm.p, cp.Npad, y, eq);
+  }
   MFM_HIP_CHECK(hipGetLastError());
 }
 

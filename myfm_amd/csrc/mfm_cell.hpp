@@ -39,7 +39,10 @@ constexpr int CELL_MAX_STREAMS = 4;    // index streams of a row (u16 slots of i
 constexpr int CELL_MAX_FIELDS = 16;
 constexpr int CELL_NT = 1024;          // threads of a pass workgroup
 constexpr int CELL_NW = CELL_NT / 64;  // its waves = row chunks of a group
-constexpr int CELL_R = 4;              // 64-row windows per wave and step
+#ifndef MFM_CELL_R
+#define MFM_CELL_R 6
+#endif
+constexpr int CELL_R = MFM_CELL_R;     // 64-row windows per wave and step (MI355X, config 5: 4 -> 6 takes a pass from 280 to 235 us, 8 spills)
 constexpr int64_t CELL_SMALL_MAX = 4096;          // largest index cardinality kept as a whole LDS table
 constexpr size_t CELL_LDS_BYTES = 156 * 1024;     // LDS a pass workgroup may use
 
@@ -69,10 +72,14 @@ struct CellSrc {  // where a field's current table T_F lives: element i at p[i *
   int stride = 1;
 };
 
+struct CellScoreSrc {  // a field's inputs of the scorer: block: q = X_B V_B [B][KS], lin = X_B w_B, ss = sum_f sum_l x^2 v^2;
+  const double *q = nullptr, *lin = nullptr, *ss = nullptr;  // main field: lin = w + base (q and ss come from Vt)
+};
+
 struct CellPlan {
   bool ready = false;
   std::string why;
-  int64_t N = 0;
+  int64_t N = 0, Npad = 0;  // rows / positions of the padded step layout
   int G = 0;
   int sU = -1, sI = -1;
   bool item32 = false;
@@ -83,7 +90,8 @@ struct CellPlan {
   DevBuf<uint2> ix;        // 4 x u16 per row: the row's index in every LDS stream (U: group-local), and in I when it fits
   DevBuf<int32_t> item;    // I index per row when it needs more than 16 bits
   DevBuf<int32_t> perm;    // cell position -> training row
-  DevBuf<int32_t> chunk0;  // [G * CELL_NW + 1] first row of every wave chunk
+  DevBuf<int32_t> chunk_len;  // [G * CELL_NW] rows of every wave chunk
+  DevBuf<int32_t> grp_base;   // [G + 1] first position of every group in the padded step layout
   DevBuf<int32_t> grp_u0;  // [G + 1] first U value of every group
   DevBuf<int32_t> grp_steps;  // [G] steps of the group's longest chunk
   DevBuf<double> e;        // the residual in cell order (valid inside mfm_sweep_V)
@@ -94,6 +102,8 @@ struct CellPlan {
   DevBuf<double> stat;     // direct statistics of a main field on U [card][2]
   DevBuf<double> cells2, cells4;  // [G][card_I][2 | 4] partials of an I field (never-written cells stay zero)
   DevBuf<double> cpart;    // [G][card_C][4] partial tables of a C field
+  // scorer tables (cell_score)
+  DevBuf<double> scoreQ[CELL_MAX_STREAMS], scoreLS[CELL_MAX_STREAMS], vss;
   bool fail(const char *w) {
     why = w;
     ready = false;
@@ -120,5 +130,9 @@ void cell_draw_main(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *Vf, 
 void cell_block_stats(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *rec);
 // block F after its feature sweep: DP[i] = (q' - q, (q'^2 - q^2)/2 - (q_S' - q_S)/2) from the saved and the new (q, q_S)
 void cell_block_delta(hipStream_t s, Timing &tm, CellPlan &cp, int F, const double *rec, const double2 *saved);
+
+// update_e on the cell layout: eq[t].x = score_t (- y_t when y is given). Vt: row-major copy of V [D][KS]
+void cell_score(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellScoreSrc> &src, const double *Vt, int64_t D, int K, int KS,
+                double w0, const double *y, double2 *eq);
 
 }  // namespace mfm

@@ -599,6 +599,31 @@ static void score_train(mfm_ctx *c, bool subtract_y) {
                                                          subtract_y ? c->y.p : nullptr, c->eq.p);
     if (done) return;
   }
+  static const bool no_cell_score = std::getenv("MFM_NO_CELL_SCORE") != nullptr;
+  if (c->cell.ready && !no_cell_score) {
+    // index-tuple design: K / FB passes over (accumulator, index record) with the factor tables in LDS (mfm_cell.hpp)
+    hipStream_t s = c->stream;
+    {
+      TimedLaunch t(c->timing, s, KC_BUILD_VT, 16.0 * c->D * c->K);
+      build_vt(s, c->V.p, c->Vt.p, c->D, c->K, c->KS);
+    }
+    std::vector<CellScoreSrc> src(c->cell.fields.size());
+    for (size_t k = 0; k < c->cell.fields.size(); k++) {
+      const CellField &fd = c->cell.fields[k];
+      if (fd.kind == 0) {
+        src[k].lin = c->w.p + fd.base;
+      } else {
+        DevBlock &B = *c->blocks[(size_t)fd.base];
+        TimedLaunch t(c->timing, s, KC_BLOCK_ROWCACHE, 12.0 * B.nnz + 8.0 * B.B * (c->K + 2));
+        launch_block_score_cache(s, B, c->Vt.p, c->w.p, c->K, c->KS);
+        src[k].q = B.bq.p;
+        src[k].lin = B.bl.p;
+        src[k].ss = B.bs.p;
+      }
+    }
+    cell_score(s, c->timing, c->cell, src, c->Vt.p, c->D, c->K, c->KS, c->w0, subtract_y ? c->y.p : nullptr, c->eq.p);
+    return;
+  }
   score_design(c->stream, c->timing, 0, c->X, c->blocks, c->D, c->K, c->KS, c->w0, c->w.p, c->V.p, c->Vt.p,
                subtract_y ? c->y.p : nullptr, c->eq.p, nullptr);
 }

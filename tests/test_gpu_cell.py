@@ -103,3 +103,25 @@ def test_cell_single_sweep_residual_and_q(oracle, capi, monkeypatch):
     np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(c.get_q(), t.q(n), rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("shape", ["u_i_ctx", "items32", "no_item", "three_fields"])
+@pytest.mark.parametrize("rank", [3, 10])
+def test_cell_scorer(oracle, capi, monkeypatch, shape, rank):
+    # update_e on the cell layout (K / FB passes with the factor tables in LDS) against the oracle's FM::predict_score
+    # (FM.hpp:54-136) and against the library's generic one-pass scorer
+    monkeypatch.setenv("MFM_CELL_MIN_ROWS", "0")
+    monkeypatch.setenv("MFM_CELL_GROUPS", "6")
+    main, blocks, y, shapes = ds.tuple_design(**SHAPES[shape])
+    gi = ds.group_index_from_shapes(shapes)
+    n = main.shape[0]
+    t, c = _pair(oracle, capi, main, y, gi, rank, blocks)
+    assert c.plan_flags()["cell"]
+    t.substep(8)
+    c.update_e_regression()
+    e = c.get_e()
+    np.testing.assert_allclose(e, t.e(n), rtol=1e-10, atol=1e-10)
+    monkeypatch.setenv("MFM_NO_CELL", "1")
+    _, cg = _pair(oracle, capi, main, y, gi, rank, blocks)
+    cg.update_e_regression()
+    np.testing.assert_allclose(e, cg.get_e(), rtol=1e-11, atol=1e-11)
