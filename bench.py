@@ -126,7 +126,9 @@ def other_configs(budget_s):
     out = {}
     runs = [("configs[1]", ["--config", "2", "--steps", "300", "--warmup", "20", "--cpu-seconds", "3"]),
             ("configs[3]", ["--config", "4", "--steps", "40", "--warmup", "5", "--cpu-seconds", "3"]),
-            ("configs[4] at scale 0.1", ["--config", "5", "--scale", "0.1", "--steps", "6", "--warmup", "2", "--cpu-seconds", "1"])]
+            ("configs[4] at scale 0.1", ["--config", "5", "--scale", "0.1", "--steps", "6", "--warmup", "2", "--cpu-seconds", "1"]),
+            # ... and at its own size, N = 50 M rows (one CPU-oracle iteration there is ~130 s: profiles/r03_e_bench_config5_full_cpu.json)
+            ("configs[4] at full size", ["--config", "5", "--scale", "1.0", "--steps", "5", "--warmup", "2", "--cpu-seconds", "0"])]
     t_all = time.time()
     for name, args in runs:
         if time.time() - t_all > budget_s:
@@ -409,7 +411,8 @@ def main():
         traffic, src = None, None
         default_workload = a.config == 3 and (a.rows, a.users, a.items, K) == (10_000_000, 69878, 10677, 32) and world == 1
         pdir = os.path.join(ROOT, "profiles")
-        pmc = sorted(f for f in os.listdir(pdir) if f.startswith("r03") and f.endswith("_pmc_traffic.json")) if os.path.isdir(pdir) else []
+        import re as _re
+        pmc = sorted(f for f in os.listdir(pdir) if _re.fullmatch(r"r\d\d_[a-z]_pmc_traffic\.json", f)) if os.path.isdir(pdir) else []
         if default_workload and pmc:
             tr = json.load(open(os.path.join(pdir, pmc[-1])))
             if name in tr:
@@ -434,6 +437,24 @@ def main():
             "by_kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
             "by_kernel_note": "per-class times from 3 diagnostic steps with every launch bracketed (outside the timed region)",
         }
+        # second bound of the same kernel: VALU instruction issue. One wave-instruction per CU and clock is the machine's rate
+        # (4 SIMDs x 16 lanes, wave64); the instruction count per launch comes from this round's committed SQ-counter pass of the
+        # same workload (rocprofv3 --pmc SQ_INSTS_VALU ..., profiles/r04_sq_counters_config3.*), the launch time is live
+        sq = sorted(f for f in os.listdir(pdir) if _re.fullmatch(r"r\d\d_sq_counters_config3\.json", f)) if os.path.isdir(pdir) else []
+        if default_workload and sq:
+            cnt = json.load(open(os.path.join(pdir, sq[-1]))).get(name)
+            if cnt:
+                n_cu, clock_hz = 256, 2.4e9
+                insts = cnt["insts_valu"]
+                ach = insts / (us * 1e-6)
+                roofline["second_bound"] = {
+                    "bound": "valu_issue", "achieved": round(ach / 1e9, 1), "peak": round(n_cu * clock_hz / 1e9, 1), "unit": "G wave-instructions/s",
+                    "frac": round(ach / (n_cu * clock_hz), 4), "valu_wave_instructions_per_launch": insts,
+                    "all_wave_instructions_per_launch": insts + cnt["insts_salu"] + cnt["insts_lds"] + cnt["insts_vmem_rd"] + cnt["insts_vmem_wr"],
+                    "wave_cycles_waiting_frac": cnt["wave_wait_any_frac"], "lds_active_frac": cnt["lds_active_frac"],
+                    "lds_bank_conflict_frac_of_active": cnt["lds_bank_conflict_frac_of_active"], "counters_source": sq[-1], "counters_measured_live": False,
+                    "note": "no throughput unit of the launch is near its peak (HBM, VALU issue, LDS each <= 0.3): it is bound by dependent "
+                            "latency inside the sweeps and by its grid barriers (62 % of the wave-cycles wait), DESIGN.md 4.3b"}
         if a.config in (2, 3) and not blocks:
             B_iter = b_iter_bytes(N, nnz, D, K)
             unfused = 56.0 * nnz + 8.0 * N + 8.0 * D
@@ -515,7 +536,7 @@ def main():
     if weak:
         out["weak_scaling"] = weak
     if a.config == 3 and world == 1 and not a.no_other_configs and not force_sharded:
-        out["other_configs"] = other_configs(budget_s=75.0)
+        out["other_configs"] = other_configs(budget_s=100.0)
     if sharded:
         out["config"]["allreduce_calls_per_step"] = round(calls / a.steps, 1)
         out["config"]["rows_this_rank"] = hi - lo

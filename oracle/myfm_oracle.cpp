@@ -1315,6 +1315,14 @@ void orc_rng_state(const orc::Trainer *t, uint32_t *out625) {
   }
 }
 
+// ... and back (tests: a small trainer replays the variate stream a large one is about to consume, without cloning it)
+void orc_rng_set_state(orc::Trainer *t, const uint32_t *in625) {
+  std::ostringstream os;
+  for (int i = 0; i < 625; i++) os << (unsigned long)in625[i] << (i < 624 ? " " : "");
+  std::istringstream is(os.str());
+  is >> t->gen_;
+}
+
 void orc_trace_enable(orc::Trainer *t, int on) {
   t->trace_on = on != 0;
   t->trace.clear();

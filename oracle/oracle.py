@@ -70,6 +70,7 @@ def lib():
         L.orc_rng_raw.restype = C.c_uint32
         L.orc_rng_raw.argtypes = [vp]
         L.orc_rng_state.argtypes = [vp, P]
+        L.orc_rng_set_state.argtypes = [vp, P]
         L.orc_trace_enable.argtypes = [vp, C.c_int]
         L.orc_trace_size.restype = i64
         L.orc_trace_size.argtypes = [vp]
@@ -268,6 +269,12 @@ class OracleTrainer:
         out = np.empty(625, dtype=np.uint32)
         lib().orc_rng_state(self.h, _p(out))
         return out[:624].copy(), int(out[624])
+
+    def set_rng_state(self, state624, position):
+        buf = np.empty(625, dtype=np.uint32)
+        buf[:624] = state624
+        buf[624] = position
+        lib().orc_rng_set_state(self.h, _p(buf))
 
     def trace_enable(self, on=True):
         lib().orc_trace_enable(self.h, int(on))

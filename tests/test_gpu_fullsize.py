@@ -34,21 +34,32 @@ def design():
     return X, y, ds.group_index_from_shapes(shapes)
 
 
-def _start(capi, oracle, X, y, gi):
+def _start(capi, oracle, X, y, gi, fused):
     t = oracle.OracleTrainer(X, y, rank=K, group_index=gi)  # initial weights, residual and generator state only
     c = capi.Context(X, y, rank=K, group_index=gi)
     c.set_state(*t.fm())
     c.set_e(t.e(N))
-    drv = CapiGibbs(c, None, N, gi)
+    drv = CapiGibbs(c, None, N, gi, fused=fused)
     drv.use_device_rng(*t.rng_state())
     return c, drv
 
 
-def test_full_size_invariants(capi, oracle, design):
+@pytest.mark.parametrize("fused", [True, False])
+def test_full_size_invariants(capi, oracle, design, fused):
+    # fused = True is the call bench.py times: update_w0's shift + update_w + update_V as ONE mfm_sweep_wV call with the
+    # device's own variates (the persistent launch of mfm_res.hpp); False drives mfm_sweep_w + mfm_sweep_V separately
+    import gc
+
     X, y, gi = design
-    c, drv = _start(capi, oracle, X, y, gi)
+    c, drv = _start(capi, oracle, X, y, gi, fused)
     flags = c.plan_flags()
-    assert flags["soa"] and flags["fused_next"]  # the path bench.py measures
+    assert flags["soa"] and flags["mf"] and flags["resident"]  # the path bench.py measures (plan_flags 438)
+    # while this context holds the device's CUs for its persistent sweep a second one must not get them (two persistent
+    # launches would starve each other's grid barrier): it falls back to the per-factor passes
+    c_other = capi.Context(X, y, rank=K, group_index=gi)
+    assert not c_other.plan_flags()["resident"] and c_other.plan_flags()["mf"]
+    del c_other
+    gc.collect()
     seen = {}
     for it in range(2):
         drv.step(before_update_e=lambda: seen.update(e=c.get_e(), q=c.get_q()))
@@ -66,8 +77,11 @@ def test_full_size_invariants(capi, oracle, design):
         np.testing.assert_allclose(e_new[rows], want, rtol=1e-10, atol=1e-10)
         assert np.isfinite(V).all() and drv.alpha > 0
     v_first = V
-    # bit-reproducible
-    c2, drv2 = _start(capi, oracle, X, y, gi)
+    # bit-reproducible (the first context gives its CUs back before the second asks for them)
+    del c, drv, seen
+    gc.collect()
+    c2, drv2 = _start(capi, oracle, X, y, gi, fused)
+    assert c2.plan_flags()["resident"]
     for it in range(2):
         drv2.step()
     assert np.array_equal(c2.get_state()[2], v_first)
@@ -76,7 +90,8 @@ def test_full_size_invariants(capi, oracle, design):
 def test_config5_full_size_n50m_rank64(capi, oracle):
     """BASELINE configs[4] at its OWN size: N = 50 M rows (nnz = 100 M), two one-hot fields + 4 relation blocks, rank 64.
     The CPU oracle needs ~2 minutes per iteration there, so the size-independent properties are checked:
-    * regression twin (the same design, the targets taken as real numbers): after one full update_all the incrementally
+    * regression twin (the same design, the targets taken as real numbers): update_w and factor 0 of update_V against the
+      ORACLE at this size (1e-9); after one full update_all the incrementally
       maintained residual == the residual recomputed from scratch (every update of every row by the (2 + 4 blocks) x 65
       sweeps is accounted for), == the closed-form FM score minus y on 50 000 sampled rows;
     * the ordered-probit task itself (5 classes, MyFMOrderedProbit's trainer): two runs of two iterations agree bit for
@@ -108,7 +123,33 @@ def test_config5_full_size_n50m_rank64(capi, oracle):
     rows = np.sort(np.random.default_rng(1).choice(N, size=50_000, replace=False))
     X_rows = sps.hstack([main[rows]] + [B[m[rows]] for m, B in blocks]).tocsr()
     np.testing.assert_allclose(e_new[rows], ds.fm_score(X_rows, w0, w, V) - y[rows], rtol=1e-9, atol=1e-9)
-    del c, drv, seen, e_new
+    assert c.plan_flags()["cell"]  # update_V on index tuples (mfm_cell.hpp)
+    del drv, seen, e_new
+    # ---- the same twin against the ORACLE at this size: a whole oracle iteration is ~2 minutes, but update_w and the first
+    # factor of update_V (FMTrainer.hpp:231-313, :315-482 for f = 0) are seconds after the oracle's ~40 s of setup
+    t = oracle.OracleTrainer(main, y, blocks, rank=K, group_index=gi)
+    w0, w, V = t.fm()
+    c.set_state(w0, w, V)
+    c.set_e(t.e(N))
+    G = t.G
+    hrng = np.random.default_rng(3)
+    lam_w, mu_w = hrng.uniform(0.5, 2.0, size=G), hrng.normal(size=G) * 0.1
+    lam_V, mu_V = hrng.uniform(0.5, 2.0, size=(G, K)), hrng.normal(size=(G, K)) * 0.1
+    t.set_hyper(0.8, mu_w, lam_w, mu_V, lam_V)
+    tz = oracle.OracleTrainer(*ds.toy(), rank=2, seed=1)  # replays the variates the big trainer is about to consume
+    tz.set_rng_state(*t.rng_state())
+    zw = tz.rng_sample_normals(D)
+    zv = tz.rng_sample_normals(D)
+    t.substep(4)           # update_w
+    t.update_V_factor(0)   # update_V, factor 0
+    c.sweep_w(0.8, lam_w, mu_w, zw)
+    c.sweep_V(0, 1, 0.8, lam_V, mu_V, zv)
+    _, tw, tV = t.fm()
+    _, gw, gV = c.get_state()
+    np.testing.assert_allclose(gw, tw, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(gV[:, 0], tV[:, 0], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(c.get_e(), t.e(N), rtol=1e-8, atol=1e-8)
+    del c, t, tz
     # ---- the ordered-probit task, twice
     rels = [_myfm.RelationBlock(np.asarray(m, dtype=np.int64), B) for m, B in blocks]
     b = _myfm.ConfigBuilder()
