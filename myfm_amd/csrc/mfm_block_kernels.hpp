@@ -434,7 +434,8 @@ struct DevBlock {
   DevBuf<double> stream_partial;  // [stream_wgs][B][4]
   int n_inv_wave = 0, n_inv_wg = 0, n_inv_long = 0, n_inv_chunks = 0;
 
-  void build(const HostCsr &hX, const std::vector<int64_t> &hmap, int64_t N, int KS, hipStream_t s) {
+  // lean: the cell path (mfm_cell.hpp) takes every O(N) pass of this design -- no inverse map, no streaming tables
+  void build(const HostCsr &hX, const std::vector<int64_t> &hmap, int64_t N, int KS, hipStream_t s, bool lean = false) {
     B = hX.rows;
     Db = hX.cols;
     nnz = hX.nnz();
@@ -447,13 +448,14 @@ struct DevBlock {
     // sorted -- the block follows the table's row order -- has contiguous lists; those stay with the inverse-map kernels,
     // which then stream as well.)
     bool sorted = true;
-    for (int64_t t = 1; t < N && sorted; t++) sorted = hmap[t] >= hmap[t - 1];
+    for (int64_t t = 1; t < N && sorted && !lean; t++) sorted = hmap[t] >= hmap[t - 1];
     stream_unsync = !sorted && B >= 1 && B <= UNSYNC_STREAM_MAX_B && N >= 64 * B && N >= ((int64_t)1 << 20) &&
                     !std::getenv("MFM_NO_UNSYNC_STREAM");  // (short tables: too few workgroups to stream with)
     if (const char *e = std::getenv("MFM_UNSYNC_STREAM_FORCE")) stream_unsync = std::atoi(e) != 0 && B >= 1 && B <= UNSYNC_STREAM_MAX_B;
     // too many block rows for the LDS table, lists scattered over a long table: split form
     split_unsync = !sorted && !stream_unsync && N >= ((int64_t)1 << 20) && !std::getenv("MFM_NO_UNSYNC_SPLIT");
     if (const char *e = std::getenv("MFM_UNSYNC_SPLIT_FORCE")) split_unsync = std::atoi(e) != 0 && !stream_unsync;
+    if (lean) stream_unsync = split_unsync = false;
     std::vector<int32_t> m32((size_t)N);
     std::vector<int64_t> iptr((size_t)B + 1, 0);
     for (int64_t t = 0; t < N; t++) {
@@ -466,14 +468,14 @@ struct DevBlock {
       iptr[i + 1] += iptr[i];
     }
     std::vector<int32_t> irows;
-    if (!stream_unsync) {
+    if (!stream_unsync && !lean) {
       irows.resize((size_t)N);
       std::vector<int64_t> cur(iptr.begin(), iptr.end() - 1);
       for (int64_t t = 0; t < N; t++) irows[cur[hmap[t]]++] = (int32_t)t;
     }
     std::vector<int32_t> bw, bg, bl_, cptr;
     std::vector<InvChunk> ch;
-    for (int64_t i = 0; i < B && !stream_unsync; i++) {
+    for (int64_t i = 0; i < B && !stream_unsync && !lean; i++) {
       int64_t len = iptr[i + 1] - iptr[i];
       if (len <= INV_WAVE_CAP)
         bw.push_back((int32_t)i);

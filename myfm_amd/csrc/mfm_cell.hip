@@ -15,14 +15,14 @@ static inline int cdiv_c(int64_t a, int64_t b) { return (int)((a + b - 1) / b); 
 // ---------------------------------------------------------------------------------------------------------------------------
 // LDS layout of a pass (offsets in doubles): per LDS stream its value table(s), the pending field's (d1, d2), the accumulators
 // of the statistics field, the turn word.   off[0..3] = A, off[4..7] = S, off[8] = DP, off[9] = accumulators, off[10] = turn
-size_t CellPlan::lds_bytes(int P, int F, bool sw, int *off) const {
+size_t CellPlan::lds_bytes(int P, int F, bool sw, int *off, bool linear) const {
   size_t o = 0;
   int tmp[11];
   if (!off) off = tmp;
   const int sP = P >= 0 ? fields[P].stream : -1, sF = F >= 0 ? fields[F].stream : -1;
   for (int s = 0; s < CELL_MAX_STREAMS; s++) off[s] = off[4 + s] = 0;
   for (size_t s = 0; s < streams.size(); s++) {
-    if (streams[s].type == CELL_I) continue;
+    if (streams[s].type == CELL_I || linear) continue;  // (the linear sweep needs no q tables)
     const size_t n = streams[s].type == CELL_U ? (size_t)umax : (size_t)streams[s].card;
     const bool pair = P >= 0 && F >= 0 && (sw || (int)s == sP || (int)s == sF);
     off[s] = (int)o;
@@ -41,7 +41,7 @@ size_t CellPlan::lds_bytes(int P, int F, bool sw, int *off) const {
     o += 2 * (streams[sP].type == CELL_U ? (size_t)umax : (size_t)streams[sP].card);
   }
   if (sF >= 0 && streams[sF].type != CELL_I) {
-    const size_t ns = fields[F].kind == 0 ? 2 : 4;
+    const size_t ns = linear ? 1 : (fields[F].kind == 0 ? 2 : 4);
     o = (o + 1) & ~(size_t)1;  // (16-byte accesses)
     off[9] = (int)o;
     o += ns * (streams[sF].type == CELL_U ? (size_t)umax : (size_t)streams[sF].card);
@@ -332,6 +332,7 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
   }
   if (cp.sI >= 0) {
     cp.packI.alloc_zero((size_t)cardI * 4, s);
+    cp.cells1.alloc_zero((size_t)G * cardI, s);
     cp.cells2.alloc_zero((size_t)G * cardI * 2, s);
     cp.cells4.alloc_zero((size_t)G * cardI * 4, s);
   }
@@ -341,6 +342,10 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
   cp.cpart.alloc_zero((size_t)std::max<int64_t>(1, (int64_t)G * maxC * 4), s);
   cp.DP.alloc_zero((size_t)std::max<int64_t>(1, maxcard), s);
   cp.stat.alloc_zero((size_t)std::max<int64_t>(1, cardU * 2), s);
+  cp.stat1.alloc_zero((size_t)std::max<int64_t>(1, maxcard), s);
+  cp.cnt_ready = false;
+  for (size_t f = 0; f < cp.fields.size(); f++)
+    if (cp.fields[f].kind == 0) cp.cnt[f].alloc_zero((size_t)std::max<int64_t>(1, cp.fields[f].n), s);
   MFM_HIP_CHECK(hipStreamSynchronize(s));
   cp.ready = true;
   return true;
@@ -464,6 +469,7 @@ struct CellPassArgs {
   int out_stride;
   int n_out;  // U statistics: index values the output has room for (a block may have fewer rows than its stream has values)
   int cardI;
+  int linear;  // update_w: no q tables; statistics = sum e (NS = 1), the update is e += d1
 };
 
 __device__ __forceinline__ int cell_slot(uint2 r, int slot) {
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(CELL_NT) void k_cell_pass(CellPassArgs a) {
   const int g = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int u0 = a.grp_u0[g], nu = a.grp_u0[g + 1] - u0;
   // ---- tables -> LDS
-  for (int s = 0; s < a.n_streams; s++) {
+  for (int s = 0; s < (a.linear ? 0 : a.n_streams); s++) {
     const int ty = a.type[s];
     if (ty == CELL_I) continue;
     const int n = ty == CELL_U ? nu : a.card[s];
@@ -561,7 +567,13 @@ __global__ __launch_bounds__(CELL_NT) void k_cell_pass(CellPassArgs a) {
       pk[k] = make_double4(0.0, 0.0, 0.0, 0.0);
       if (has_I && valid[k]) {
         it[k] = ITEM32 ? it_n[k] : cell_slot(rec[k], slotI);
-        pk[k] = packI[it[k]];
+        if (!a.linear) {
+          pk[k] = packI[it[k]];
+        } else if (p_on_I) {  // (update_w: no packed table is built, the pending field's d1 comes straight from DP)
+          const double2 dd = a.DP[it[k]];
+          pk[k].z = dd.x;
+          pk[k].w = dd.y;
+        }
       }
     }
     if (st + 1 < steps) {
@@ -575,7 +587,7 @@ __global__ __launch_bounds__(CELL_NT) void k_cell_pass(CellPassArgs a) {
         }
       }
     }
-    double v[CELL_R][NS > 0 ? NS : 1];
+    double v[CELL_R][NS > 1 ? NS : 2];
     int idxF[CELL_R];
 #pragma unroll
     for (int k = 0; k < CELL_R; k++) {
@@ -584,7 +596,7 @@ __global__ __launch_bounds__(CELL_NT) void k_cell_pass(CellPassArgs a) {
       if (valid[k]) {
 #pragma unroll
         for (int s = 0; s < CELL_MAX_STREAMS; s++) {
-          if (s < a.n_streams && a.type[s] != CELL_I) {
+          if (s < a.n_streams && a.type[s] != CELL_I && !a.linear) {
             const int i = cell_slot(rec[k], a.slot[s]);
             const double x = lds[a.ldsS[s] + i];
             qs += x;
@@ -593,13 +605,16 @@ __global__ __launch_bounds__(CELL_NT) void k_cell_pass(CellPassArgs a) {
         }
         if (HASP) {
           const double2 d = p_on_I ? make_double2(pk[k].z, pk[k].w) : dpl[cell_slot(rec[k], slotP)];
-          e[k] += qa * d.x + d.y;
+          e[k] += a.linear ? d.x : qa * d.x + d.y;
           __builtin_nontemporal_store(e[k], a.e + pos);
         }
       }
       if (FT >= 0) {
         const double h = qs;
-        if (NS == 2) {
+        if (NS == 1) {
+          v[k][0] = valid[k] ? e[k] : 0.0;
+          v[k][1] = 0.0;
+        } else if (NS == 2) {
           v[k][0] = valid[k] ? h * h : 0.0;
           v[k][1] = valid[k] ? e[k] * h : 0.0;
         } else if (NS == 4) {
@@ -701,12 +716,13 @@ static void launch_pass_f(hipStream_t s, int G, size_t lds, const CellPassArgs &
   }
 }
 
-void cell_pass(hipStream_t s, Timing &tm, CellPlan &cp, int P, int F, bool sw, double *out_u, int out_stride) {
+void cell_pass(hipStream_t s, Timing &tm, CellPlan &cp, int P, int F, bool sw, double *out_u, int out_stride, bool linear) {
   if (P < 0 && F < 0) return;
   CellPassArgs a;
   std::memset(&a, 0, sizeof(a));
   int off[11];
-  const size_t lds = cp.lds_bytes(P, F, sw, off);
+  const size_t lds = cp.lds_bytes(P, F, sw, off, linear);
+  a.linear = linear ? 1 : 0;
   if (lds > CELL_LDS_BYTES) throw Error(MFM_ERR_RUNTIME, "internal: cell pass does not fit the LDS");
   a.ix = cp.ix.p;
   a.item = cp.item.p;
@@ -735,14 +751,14 @@ void cell_pass(hipStream_t s, Timing &tm, CellPlan &cp, int P, int F, bool sw, d
   a.ldsTurn = off[10];
   a.cardI = cp.sI >= 0 ? (int)cp.streams[cp.sI].card : 0;
   const int ft = F >= 0 ? cp.streams[a.sF].type : -1;
-  const int ns = F >= 0 ? (cp.fields[F].kind == 0 ? 2 : 4) : 0;
+  const int ns = F >= 0 ? (linear ? 1 : (cp.fields[F].kind == 0 ? 2 : 4)) : 0;
   a.ns = ns;
   if (ft == CELL_U) {
     a.out = out_u;
     a.out_stride = out_stride;
     a.n_out = (int)cp.fields[F].n;
   } else if (ft == CELL_I) {
-    a.out = ns == 2 ? cp.cells2.p : cp.cells4.p;
+    a.out = ns == 1 ? cp.cells1.p : (ns == 2 ? cp.cells2.p : cp.cells4.p);
   } else if (ft == CELL_C) {
     a.out = cp.cpart.p;
   }
@@ -753,6 +769,12 @@ void cell_pass(hipStream_t s, Timing &tm, CellPlan &cp, int P, int F, bool sw, d
   const bool hasp = P >= 0;
   if (ft < 0)
     launch_pass_f<-1, 0>(s, cp.G, lds, a, hasp, cp.item32);
+  else if (ns == 1 && ft == CELL_U)
+    launch_pass_f<CELL_U, 1>(s, cp.G, lds, a, hasp, cp.item32);
+  else if (ns == 1 && ft == CELL_I)
+    launch_pass_f<CELL_I, 1>(s, cp.G, lds, a, hasp, cp.item32);
+  else if (ns == 1)
+    launch_pass_f<CELL_C, 1>(s, cp.G, lds, a, hasp, cp.item32);
   else if (ft == CELL_U && ns == 2)
     launch_pass_f<CELL_U, 2>(s, cp.G, lds, a, hasp, cp.item32);
   else if (ft == CELL_U)
@@ -888,6 +910,91 @@ void cell_block_delta(hipStream_t s, Timing &tm, CellPlan &cp, int F, const doub
   const CellField &f = cp.fields[F];
   TimedLaunch t(tm, s, KC_CELL_SMALL, 0.0);
   hipLaunchKernelGGL(k_cell_block_delta, dim3(cdiv_c(f.n, 256)), dim3(256), 0, s, rec, saved, (int)f.n, cp.DP.p);
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// update_w on the cell layout (FMTrainer.hpp:231-313). A one-hot main column i with x = 1: S2 = n_i (the rows it occurs in: static),
+// S1 = sum_t (e_t - w_old) = sum e - n_i w_old (:242-248); a block needs e_B = sum e per block row (:271) and changes its rows by
+// q_B' - q_B (:272-273 and :306-311 together). So the linear sweep is the same pass with ONE sum per index value and no q tables.
+__global__ __launch_bounds__(256) void k_cell_sum1(const double *__restrict__ src, int G, int64_t card, int n, double *__restrict__ dst,
+                                                   int dst_stride) {
+  // [G][card] partials -> dst[i * dst_stride], 32 values x 8 slices of the group range, fixed association
+  __shared__ double part[8][32];
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + o;
+  const int gs = (G + 7) / 8;
+  double acc = 0.0;
+  if (i < n)
+    for (int g = sl * gs; g < min(G, (sl + 1) * gs); g++) acc += src[(int64_t)g * card + i];
+  part[sl][o] = acc;
+  __syncthreads();
+  if (sl != 0 || i >= n) return;
+  double t = part[0][o];
+#pragma unroll
+  for (int k = 1; k < 8; k++) t += part[k][o];
+  dst[(int64_t)i * dst_stride] = t;
+}
+void cell_sum1(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *dst, int dst_stride) {
+  const CellField &f = cp.fields[F];
+  const CellStream &st = cp.streams[f.stream];
+  if (st.type == CELL_U) return;  // (the pass wrote the sums itself)
+  TimedLaunch t(tm, s, KC_CELL_SMALL, 0.0);
+  hipLaunchKernelGGL(k_cell_sum1, dim3(cdiv_c(f.n, 32)), dim3(256), 0, s, st.type == CELL_I ? cp.cells1.p : cp.cpart.p, cp.G, st.card,
+                     (int)f.n, dst, dst_stride);
+  MFM_HIP_CHECK(hipGetLastError());
+}
+__global__ void k_cell_fill_ones(const int32_t *__restrict__ perm, int64_t N, double *__restrict__ e) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < N) e[p] = perm[p] >= 0 ? 1.0 : 0.0;
+}
+// n_i of every main column: the statistics pass over a residual of ones (once per plan; cp.e is scratch here)
+void cell_counts(hipStream_t s, Timing &tm, CellPlan &cp) {
+  if (cp.cnt_ready) return;
+  hipLaunchKernelGGL(k_cell_fill_ones, dim3(cdiv_c(cp.Npad, 256)), dim3(256), 0, s, cp.perm.p, cp.Npad, cp.e.p);
+  for (size_t F = 0; F < cp.fields.size(); F++) {
+    if (cp.fields[F].kind != 0) continue;
+    cell_pass(s, tm, cp, -1, (int)F, false, cp.cnt[F].p, 1, true);
+    cell_sum1(s, tm, cp, (int)F, cp.cnt[F].p, 1);
+  }
+  cp.cnt_ready = true;
+  MFM_HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(256) void k_cell_draw_w(const double *__restrict__ se, const double *__restrict__ cnt, int n,
+                                                     double *__restrict__ w, const double *__restrict__ z,
+                                                     const int32_t *__restrict__ group, const double *__restrict__ lam,
+                                                     const double *__restrict__ mu, double alpha, int64_t base, double2 *__restrict__ DP) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t j = base + i;
+  const double old = w[j], S2 = cnt[i];
+  const double S1 = se[i] - S2 * old;  // sum_t x (e_t - x w_old), x = 1   (:242-248)
+  const int gi = group[j];
+  const double l = lam[gi], m = mu[gi];
+  const double sq = l + alpha * S2;        // :250
+  const double lin = -alpha * S1 + l * m;  // :251
+  const double fresh = sample_normal_z(sq, lin, z[j]);
+  w[j] = fresh;
+  DP[i] = make_double2(fresh - old, 0.0);  // e += x (w' - w)   (:252)
+}
+void cell_draw_main_w(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *w, const double *z, const int32_t *group, const double *lam,
+                      const double *mu, double alpha) {
+  const CellField &f = cp.fields[F];
+  TimedLaunch t(tm, s, KC_CELL_SMALL, 0.0);
+  hipLaunchKernelGGL(k_cell_draw_w, dim3(cdiv_c(f.n, 256)), dim3(256), 0, s, cp.stat1.p, cp.cnt[F].p, (int)f.n, w, z, group, lam, mu, alpha,
+                     f.base, cp.DP.p);
+  MFM_HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(256) void k_cell_block_delta_w(const double *__restrict__ rec, const double2 *__restrict__ saved, int n,
+                                                            double2 *__restrict__ DP) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  DP[i] = make_double2(rec[(int64_t)i * 8] - saved[i].x, 0.0);
+}
+void cell_block_delta_w(hipStream_t s, Timing &tm, CellPlan &cp, int F, const double *rec, const double2 *saved) {
+  const CellField &f = cp.fields[F];
+  TimedLaunch t(tm, s, KC_CELL_SMALL, 0.0);
+  hipLaunchKernelGGL(k_cell_block_delta_w, dim3(cdiv_c(f.n, 256)), dim3(256), 0, s, rec, saved, (int)f.n, cp.DP.p);
   MFM_HIP_CHECK(hipGetLastError());
 }
 

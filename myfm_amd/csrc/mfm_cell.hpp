@@ -100,7 +100,10 @@ struct CellPlan {
   DevBuf<double> packI;    // [card_I][4] = (QA, QS, d1, d2) gathered per row
   DevBuf<double2> DP;      // (d1, d2) of the pending field, by index value
   DevBuf<double> stat;     // direct statistics of a main field on U [card][2]
-  DevBuf<double> cells2, cells4;  // [G][card_I][2 | 4] partials of an I field (never-written cells stay zero)
+  DevBuf<double> stat1;    // update_w: sum e per index value of the field whose statistics were taken
+  DevBuf<double> cnt[CELL_MAX_FIELDS];  // update_w: rows per column of every main field (cell_counts)
+  bool cnt_ready = false;
+  DevBuf<double> cells1, cells2, cells4;  // [G][card_I][1 | 2 | 4] partials of an I field (never-written cells stay zero)
   DevBuf<double> cpart;    // [G][card_C][4] partial tables of a C field
   // scorer tables (cell_score)
   DevBuf<double> scoreQ[CELL_MAX_STREAMS], scoreLS[CELL_MAX_STREAMS], vss;
@@ -110,7 +113,7 @@ struct CellPlan {
     return false;
   }
   bool fail(const std::string &w) { return fail(w.c_str()); }
-  size_t lds_bytes(int P, int F, bool sw, int *off = nullptr) const;  // LDS of the pass (P, F: field numbers or -1)
+  size_t lds_bytes(int P, int F, bool sw, int *off = nullptr, bool linear = false) const;  // LDS of the pass (P, F: field numbers or -1)
 };
 
 // planner (host): X = the main table in CSR (rows sorted by the first field), blocks in Gibbs order
@@ -122,7 +125,7 @@ void cell_unpack_e(hipStream_t s, CellPlan &cp, double2 *eq);
 void cell_prep(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellSrc> &cur, bool doA, int exA, bool doS, int exS, bool dp_to_I);
 // one pass over the rows: apply the pending field P (-1: none), statistics of field F (-1: none); sw: QA / QS belong to
 // different factors. out / out_stride / ns_out: where a U field's sums go (index i at out[i * out_stride + 0..ns))
-void cell_pass(hipStream_t s, Timing &tm, CellPlan &cp, int P, int F, bool sw, double *out_u, int out_stride);
+void cell_pass(hipStream_t s, Timing &tm, CellPlan &cp, int P, int F, bool sw, double *out_u, int out_stride, bool linear = false);
 // main field F: draw its columns from the statistics the pass left (FMTrainer.hpp:357-369), write V and DP
 void cell_draw_main(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *Vf, const double *zf, const int32_t *group, const double *lam,
                     const double *mu, double alpha);
@@ -131,6 +134,13 @@ void cell_block_stats(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *re
 // block F after its feature sweep: DP[i] = (q' - q, (q'^2 - q^2)/2 - (q_S' - q_S)/2) from the saved and the new (q, q_S)
 void cell_block_delta(hipStream_t s, Timing &tm, CellPlan &cp, int F, const double *rec, const double2 *saved);
 
+// update_w on the cell layout: rows per main column (once), sums of an I / C field over the groups, the draw of a main field's
+// columns (FMTrainer.hpp:237-254) from (sum e, n), a block's row update q_B' - q_B
+void cell_counts(hipStream_t s, Timing &tm, CellPlan &cp);
+void cell_sum1(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *dst, int dst_stride);
+void cell_draw_main_w(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *w, const double *z, const int32_t *group, const double *lam,
+                      const double *mu, double alpha);
+void cell_block_delta_w(hipStream_t s, Timing &tm, CellPlan &cp, int F, const double *rec, const double2 *saved);
 // update_e on the cell layout: eq[t].x = score_t (- y_t when y is given). Vt: row-major copy of V [D][KS]
 void cell_score(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellScoreSrc> &src, const double *Vt, int64_t D, int K, int KS,
                 double w0, const double *y, double2 *eq);

@@ -156,6 +156,8 @@ struct mfm_ctx {
   bool qfree = false, soa = false, fuse_next = false;
   bool mf = false;              // two-field pass (run_sweep_mf): no q-cache in HBM during update_V
   ResPlan res;                  // ... as one persistent launch with the residual resident on chip (mfm_res.hpp)
+  bool e_in_cell = false;       // the residual lives in cell.e (cell order): every reader of eq calls materialize_e first
+  bool cell_w = false;          // ... and update_w runs on the cell layout too (the generic plans of the main table were not built)
   CellPlan cell;                // update_V of a design of index tuples (one-hot fields + relation blocks): no q-cache (mfm_cell.hpp)
   bool sharded_fused = false;   // row-sharded + fused tile path (run_sweep_soa_sharded)
   int q_stale_factor = -1;      // >= 0: the stored q column is stale, mfm_get_q rebuilds it for this factor first
@@ -566,6 +568,10 @@ static SweepArgs main_args(mfm_ctx *c, double *theta, const double *z, const dou
 // follows and recomputes it)
 static void materialize_e(mfm_ctx *c) {
   c->slot_sums_valid = false;  // (whoever asks for the residual in row order may change it)
+  if (c->e_in_cell) {  // (the cell path's sweeps leave it in cell order; update_e, which follows in the Gibbs loop, just drops it)
+    cell_unpack_e(c->stream, c->cell, c->eq.p);
+    c->e_in_cell = false;
+  }
   if (!c->e_in_slots) return;
   const int64_t n_slots = (int64_t)c->res.G * c->res.NT * (c->res.RV + c->res.RL);
   hipLaunchKernelGGL(k_res_unpermute, dim3((unsigned)cdiv(n_slots, 256)), dim3(256), 0, c->stream, c->res.e_slots.p, c->res.perm.p,
@@ -575,6 +581,7 @@ static void materialize_e(mfm_ctx *c) {
 
 static void score_train(mfm_ctx *c, bool subtract_y) {
   c->e_in_slots = false;  // (every residual is overwritten)
+  c->e_in_cell = false;
   c->slot_sums_valid = false;
   if (c->mf && !std::getenv("MFM_NO_MF_SCORE")) {
     // two-field table: scorer on the row tiles of the latent sweep (item rows gathered once per run, not once per row)
@@ -635,7 +642,8 @@ static void run_sweep_cell(mfm_ctx *c, int f_begin, int f_end, const double *zba
   CellPlan &cp = c->cell;
   Timing &tm = c->timing;
   const int m = (int)cp.fields.size();
-  cell_pack_e(s, cp, c->eq.p);
+  if (!c->e_in_cell) cell_pack_e(s, cp, c->eq.p);
+  c->e_in_cell = true;  // (stays in cell order: materialize_e brings it back when somebody reads eq)
   std::vector<CellSrc> cur((size_t)m);
   auto set_cur = [&](int f) {
     for (int k = 0; k < m; k++) {
@@ -697,8 +705,47 @@ static void run_sweep_cell(mfm_ctx *c, int f_begin, int f_end, const double *zba
     cell_prep(s, tm, cp, cur, true, pending, false, -1, on_I(pending));
     cell_pass(s, tm, cp, pending, -1, false, nullptr, 0);
   }
-  cell_unpack_e(s, cp, c->eq.p);
   c->q_stale_factor = f_end - 1;  // q_train as the reference leaves it (:373, :479): rebuilt when asked for
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
+// update_w (FMTrainer.hpp:231-313) on the cell layout: per field one pass (apply the field before it: e += d1; sum e per index
+// value of its own), the main fields' draws and the blocks' feature sweeps (run_plan<PBlockW> on their records) in between
+static void run_sweep_w_cell(mfm_ctx *c, const double *zdev, double alpha) {
+  hipStream_t s = c->stream;
+  CellPlan &cp = c->cell;
+  Timing &tm = c->timing;
+  const int m = (int)cp.fields.size();
+  if (!cp.cnt_ready) {
+    if (c->e_in_cell) materialize_e(c);  // (cell.e is the scratch of the one-off row count)
+    cell_counts(s, tm, cp);
+  }
+  if (!c->e_in_cell) cell_pack_e(s, cp, c->eq.p);
+  c->e_in_cell = true;
+  const SweepClasses kc{KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP,
+                        KC_BLOCK_SWEEP, KC_BLOCK_SWEEP};
+  for (int k = 0; k < m; k++) {
+    const CellField &fd = cp.fields[k];
+    DevBlock *B = fd.kind == 1 ? c->blocks[(size_t)fd.base].get() : nullptr;
+    if (B) {
+      block_rowcache(s, tm, *B, c->w.p + B->col_off, false);  // q_B = X_B w_B (:265-266); zeroes the record's sums
+      if (B->q_saved.n < (size_t)B->B) B->q_saved.alloc((size_t)B->B);
+      hipLaunchKernelGGL(k_save_q, dim3(cdiv(std::max<int64_t>(B->B, 1), 256)), dim3(256), 0, s, B->rec.p, B->B, B->q_saved.p);
+    }
+    double *sums = B ? B->rec.p + 4 : cp.stat1.p;  // e_B of the record (:271) / the draw's input
+    const int stride = B ? BLOCK_REC : 1;
+    cell_pass(s, tm, cp, k - 1, k, false, sums, stride, true);
+    cell_sum1(s, tm, cp, k, sums, stride);
+    if (!B) {
+      cell_draw_main_w(s, tm, cp, k, c->w.p, zdev, c->group.p, c->lam.p, c->mu.p, alpha);  // :237-254
+    } else {
+      SweepArgs a = block_args(*B, c->w.p, zdev, c->group.p, c->lam.p, c->mu.p, alpha);
+      run_plan<PBlockW>(s, tm, B->plan_W, a, c->ls, kc, false);  // :276-302
+      block_rowcache(s, tm, *B, c->w.p + B->col_off, false);     // :304-305
+      cell_block_delta_w(s, tm, cp, k, B->rec.p, B->q_saved.p);  // the rows change by q_B' - q_B (:272-273, :306-311)
+    }
+  }
+  cell_pass(s, tm, cp, m - 1, -1, false, nullptr, 0, true);
   MFM_HIP_CHECK(hipGetLastError());
 }
 
@@ -952,9 +999,34 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     } else {
       c->X.upload(c->hX, nullptr);
       lap("upload CSR");
+    }
+    // a row of unit-valued one-hot fields + relation blocks on one GPU: update_w / update_V / update_e on index tuples, no
+    // q-cache (mfm_cell.hpp). Decided first: when it takes the design, X_t, the main table's level plans and row tiles and
+    // the blocks' inverse maps are never used and are not built (config 5: 1.3 s of mfm_finalize and 3 GB of HBM).
+    {
+      const int64_t cell_min_rows = std::getenv("MFM_CELL_MIN_ROWS") ? std::atoll(std::getenv("MFM_CELL_MIN_ROWS")) : ((int64_t)1 << 20);
+      if (!c->hblocks.empty() && !c->comm.active() && c->X.unit && c->X.ell_width >= 1 && c->N >= cell_min_rows && c->K > 0 &&
+          !std::getenv("MFM_NO_CELL")) {
+        int n_cu = 0;
+        MFM_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
+        if (const char *e = std::getenv("MFM_CELL_GROUPS")) n_cu = std::max(1, std::atoi(e));
+        std::vector<CellBlockIn> bin;
+        for (auto &hb : c->hblocks) bin.push_back(CellBlockIn{hb.map.data(), hb.X.rows});
+        cell_plan_build(c->cell, c->hX, bin, n_cu, c->stream);
+        c->cell_w = c->cell.ready && !std::getenv("MFM_NO_CELL_W");
+        if (tlog)
+          std::fprintf(stderr, "[mfm_finalize] cell plan: %s (G=%d umax=%lld streams=%zu fields=%zu item32=%d)\n",
+                       c->cell.ready ? "ready" : c->cell.why.c_str(), c->cell.G, (long long)c->cell.umax, c->cell.streams.size(),
+                       c->cell.fields.size(), (int)c->cell.item32);
+        lap("cell plan");
+      }
+    }
+    const bool lean = c->cell_w;
+    if (!lean && !std::getenv("MFM_HOST_TRANSPOSE")) {
       Xt = transpose_device(c->X, c->stream);
       lap("transpose (device) + copy back");
     }
+    if (!lean) {
     c->plan_V.sharded = c->plan_W.sharded = c->comm.active();
     c->plan_V.given_levels = c->plan_W.given_levels = c->hlevels;
     // scattered levels: LDS row tiles of 2^tile_bits {e, q} records (64 KiB by default: two workgroups per CU)
@@ -1060,6 +1132,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
       c->ls.reserve_cols(c->D0);
       c->ls.reserve_stats(c->D0);
     }
+    }  // (!lean)
   }
   c->y.upload(c->hy);
   c->eq.alloc_zero((size_t)c->N, c->stream);
@@ -1096,7 +1169,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
         MFM_HIP_CHECK(hipSetDevice(c->device));
         built[b].reset(new DevBlock());
         built[b]->col_off = offs[b];
-        built[b]->build(c->hblocks[b].X, c->hblocks[b].map, c->N, c->KS, c->stream);
+        built[b]->build(c->hblocks[b].X, c->hblocks[b].map, c->N, c->KS, c->stream, c->cell_w);
       } catch (...) {
         errs[b] = std::current_exception();
       }
@@ -1196,24 +1269,6 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   Xt_keep = HostCsr();
   MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
   lap("blocks, state, scratch");
-  // a row of unit-valued one-hot fields + relation blocks on one GPU: update_V on index tuples, no q-cache (mfm_cell.hpp)
-  {
-    const int64_t cell_min_rows = std::getenv("MFM_CELL_MIN_ROWS") ? std::atoll(std::getenv("MFM_CELL_MIN_ROWS")) : ((int64_t)1 << 20);
-    if (!c->blocks.empty() && !c->comm.active() && c->X.unit && c->X.ell_width >= 1 && c->N >= cell_min_rows && c->K > 0 &&
-        !std::getenv("MFM_NO_CELL")) {
-      int n_cu = 0;
-      MFM_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
-      if (const char *e = std::getenv("MFM_CELL_GROUPS")) n_cu = std::max(1, std::atoi(e));
-      std::vector<CellBlockIn> bin;
-      for (auto &hb : c->hblocks) bin.push_back(CellBlockIn{hb.map.data(), hb.X.rows});
-      cell_plan_build(c->cell, c->hX, bin, n_cu, c->stream);
-      if (tlog)
-        std::fprintf(stderr, "[mfm_finalize] cell plan: %s (G=%d umax=%lld streams=%zu fields=%zu item32=%d)\n",
-                     c->cell.ready ? "ready" : c->cell.why.c_str(), c->cell.G, (long long)c->cell.umax, c->cell.streams.size(),
-                     c->cell.fields.size(), (int)c->cell.item32);
-      lap("cell plan");
-    }
-  }
   // host copies are no longer needed
   c->hX = HostCsr();
   c->hy.clear();
@@ -1458,7 +1513,7 @@ int mfm_hyper_stats(mfm_ctx *ctx, int32_t need_e, const double *mu_w, const doub
 int mfm_sweep_w(mfm_ctx *ctx, double alpha, const double *lambda_w, const double *mu_w, const double *z) {
   MFM_TRY(ctx)
   ctx->need_final();
-  materialize_e(ctx);
+  if (!ctx->cell_w) materialize_e(ctx);
   mfm_ctx *c = ctx;
   hipStream_t s = c->stream;
   c->ring.upload(c->lam.p, lambda_w, (size_t)c->G * sizeof(double), s);
@@ -1470,6 +1525,10 @@ int mfm_sweep_w(mfm_ctx *ctx, double alpha, const double *lambda_w, const double
     if (c->rng.current < 0 || c->rng.n_zw != c->D)
       throw Error(MFM_ERR_RUNTIME, "mfm_sweep_w(z = NULL) needs an acquired device random set with D z_w variates");
     zdev = c->rng.slot[c->rng.current].zw.p;
+  }
+  if (c->cell_w) {
+    run_sweep_w_cell(c, zdev, alpha);
+    return MFM_OK;
   }
   SweepArgs a = main_args(c, c->w.p, zdev, c->lam.p, c->mu.p, alpha);
   const SweepClasses kcw{KC_SWEEP_W_LIGHT, KC_SWEEP_W_HEAVY, KC_SWEEP_W_COOP, KC_SWEEP_W_LSTATS, KC_SWEEP_W_LDRAW,
@@ -1542,7 +1601,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
                 const double *z) {
   MFM_TRY(ctx)
   ctx->need_final();
-  materialize_e(ctx);
+  if (!ctx->cell.ready) materialize_e(ctx);
   mfm_ctx *c = ctx;
   if (f_begin < 0 || f_end > c->K || f_begin > f_end) throw Error(MFM_ERR_INVALID, "factor range out of bounds");
   if (f_begin == f_end) return MFM_OK;

@@ -125,3 +125,30 @@ def test_cell_scorer(oracle, capi, monkeypatch, shape, rank):
     _, cg = _pair(oracle, capi, main, y, gi, rank, blocks)
     cg.update_e_regression()
     np.testing.assert_allclose(e, cg.get_e(), rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_cell_linear_sweep(oracle, capi, monkeypatch, shape):
+    # update_w on the cell layout (one sum per index value, no q tables; FMTrainer.hpp:231-313): coefficients and the residual
+    # after ONE call against the oracle, and the generic sweep (MFM_NO_CELL_W) of the same library
+    monkeypatch.setenv("MFM_CELL_MIN_ROWS", "0")
+    monkeypatch.setenv("MFM_CELL_GROUPS", "9")
+    main, blocks, y, shapes = ds.tuple_design(**SHAPES[shape])
+    gi = ds.group_index_from_shapes(shapes)
+    n = main.shape[0]
+    t, c = _pair(oracle, capi, main, y, gi, 2, blocks)
+    assert c.plan_flags()["cell"]
+    G, D = t.G, t.D
+    rng = np.random.default_rng(6)
+    lam, mu = rng.uniform(0.5, 2.0, size=G), rng.normal(size=G) * 0.1
+    h = t.hyper()
+    t.set_hyper(1.3, mu, lam, h["mu_V"], h["lambda_V"])
+    z = t.clone().rng_sample_normals(D)
+    t.substep(4)
+    c.sweep_w(1.3, lam, mu, z)
+    np.testing.assert_allclose(c.get_state()[1], t.fm()[1], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-9, atol=1e-10)
+    monkeypatch.setenv("MFM_NO_CELL_W", "1")
+    t2, cg = _pair(oracle, capi, main, y, gi, 2, blocks)
+    cg.sweep_w(1.3, lam, mu, z)
+    np.testing.assert_allclose(c.get_state()[1], cg.get_state()[1], rtol=1e-10, atol=1e-12)
