@@ -377,7 +377,21 @@ struct FM {
   void initialize_weight(int64_t n_features, Real init_std, std::mt19937 &gen) {
     initialized = false;
     const size_t nV = (size_t)n_features * n_factors, nw = (size_t)n_features;
-    if (std::getenv("MYFM_AMD_STD_INIT")) {  // the plain loop (tests hold the bulk filler against it)
+    // The bulk filler restates libstdc++ internals (generate_canonical<double, 53>, the polar method's return order): checked
+    // once per process against the plain std::normal_distribution loop it replaces (odd and even counts); a C++ library that
+    // differs makes every fit take the plain loop instead of silently changing the initial weights
+    static const bool filler_ok = []() {
+      for (size_t n : {(size_t)4099, (size_t)1024}) {
+        std::mt19937 g1(20240917u), g2(20240917u);
+        std::vector<double> a(n), b(n);
+        std::normal_distribution<Real> nd;
+        for (auto &v : a) v = nd(g1) * 0.1;
+        mfm_hostnormals::fill_normals(g2, b.data(), n, 0.1);
+        if (std::memcmp(a.data(), b.data(), n * sizeof(double)) != 0) return false;
+      }
+      return true;
+    }();
+    if (std::getenv("MYFM_AMD_STD_INIT") || !filler_ok) {  // the plain loop (tests hold the bulk filler against it)
       std::normal_distribution<Real> nd;
       V.resize(nV);
       for (auto &v : V) v = nd(gen) * init_std;

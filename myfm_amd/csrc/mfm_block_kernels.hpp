@@ -11,6 +11,7 @@
 //   re-sync (:306-311, :473-480): streaming over the training rows, gathering the block record.
 #pragma once
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "mfm_common.hpp"
@@ -458,9 +459,22 @@ struct DevBlock {
     if (lean) stream_unsync = split_unsync = false;
     std::vector<int32_t> m32((size_t)N);
     std::vector<int64_t> iptr((size_t)B + 1, 0);
-    for (int64_t t = 0; t < N; t++) {
-      m32[t] = (int32_t)hmap[t];
-      iptr[hmap[t] + 1]++;
+    if (N >= ((int64_t)1 << 22) && B <= ((int64_t)1 << 21)) {  // (long maps: the 32-bit copy and the row counts on host threads)
+      std::mutex mx;
+      parallel_ranges(N, [&](int64_t lo, int64_t hi) {
+        std::vector<int32_t> cnt((size_t)B, 0);
+        for (int64_t t = lo; t < hi; t++) {
+          m32[t] = (int32_t)hmap[t];
+          cnt[hmap[t]]++;
+        }
+        std::lock_guard<std::mutex> g(mx);
+        for (int64_t i = 0; i < B; i++) iptr[i + 1] += cnt[i];
+      });
+    } else {
+      for (int64_t t = 0; t < N; t++) {
+        m32[t] = (int32_t)hmap[t];
+        iptr[hmap[t] + 1]++;
+      }
     }
     std::vector<double> hrec((size_t)B * BLOCK_REC, 0.0);
     for (int64_t i = 0; i < B; i++) {

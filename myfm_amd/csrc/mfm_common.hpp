@@ -432,17 +432,24 @@ struct DevSparse {
     rows = X.rows;
     cols = X.cols;
     nnz = X.nnz();
-    unit = nnz > 0;
-    for (double v : X.val)
-      if (v != 1.0) {
-        unit = false;
-        break;
-      }
+    // (three O(nnz) / O(rows) host passes: on host threads for long tables)
+    std::atomic<int> not_unit(0), not_ell(0);
+    parallel_ranges(nnz, [&](int64_t lo, int64_t hi) {
+      for (int64_t p = lo; p < hi && !not_unit.load(std::memory_order_relaxed); p++)
+        if (X.val[p] != 1.0) not_unit = 1;
+    });
+    unit = nnz > 0 && !not_unit;
     ell_width = rows > 0 ? (int32_t)(X.ptr[1] - X.ptr[0]) : -1;
-    for (int64_t i = 0; i < rows && ell_width >= 0; i++)
-      if (X.ptr[i + 1] - X.ptr[i] != ell_width) ell_width = -1;
     std::vector<int32_t> rp((size_t)rows + 1);
-    for (int64_t i = 0; i <= rows; i++) rp[i] = (int32_t)X.ptr[i];
+    const int32_t ew = ell_width;
+    parallel_ranges(rows, [&](int64_t lo, int64_t hi) {
+      for (int64_t i = lo; i < hi; i++) {
+        if (X.ptr[i + 1] - X.ptr[i] != ew) not_ell = 1;
+        rp[i] = (int32_t)X.ptr[i];
+      }
+    });
+    if (not_ell) ell_width = -1;
+    rp[(size_t)rows] = (int32_t)X.ptr[(size_t)rows];
     rowptr.upload(rp);
     colidx.upload(X.idx);
     rval.upload(X.val);

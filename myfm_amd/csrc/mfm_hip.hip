@@ -1560,9 +1560,13 @@ int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambd
   MFM_TRY(ctx)
   ctx->need_final();
   mfm_ctx *c = ctx;
+  // (every argument check before anything is enqueued)
+  if (f_begin < 0 || f_end > c->K) throw Error(MFM_ERR_INVALID, "factor range out of bounds");
+  if ((zw == nullptr) != (zv == nullptr)) throw Error(MFM_ERR_INVALID, "mfm_sweep_wV: give both variate arrays or none");
+  if (!zw && (c->rng.current < 0 || c->rng.n_zw != c->D || c->rng.n_zv != c->D * (int64_t)c->K))
+    throw Error(MFM_ERR_RUNTIME, "mfm_sweep_wV(z = NULL) needs an acquired device random set with D + K*D variates");
   const bool load_slots = c->e_in_slots;  // the residual is already in the launch's slot order: read it there
   c->slot_sums_valid = false;
-  if (f_begin < 0 || f_end > c->K) throw Error(MFM_ERR_INVALID, "factor range out of bounds");
   hipStream_t s = c->stream;
   // the four hyper-parameter vectors in ONE copy: [lambda_w | mu_w | lambda_V | mu_V]
   const size_t nG = (size_t)c->G, nGK = (size_t)c->G * c->K;
@@ -1575,7 +1579,6 @@ int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambd
   c->ring.upload(c->wv_pack.p, c->hs_stage.data(), c->hs_stage.size() * sizeof(double), s);
   const double *d_lam_w = c->wv_pack.p, *d_mu_w = c->wv_pack.p + nG, *d_lam = c->wv_pack.p + 2 * nG,
                *d_mu = c->wv_pack.p + 2 * nG + nGK;
-  if ((zw == nullptr) != (zv == nullptr)) throw Error(MFM_ERR_INVALID, "mfm_sweep_wV: give both variate arrays or none");
   const double *zwdev, *zbase;
   if (zw) {
     if (!c->zw_host.p) c->zw_host.alloc((size_t)c->D);
@@ -1584,8 +1587,6 @@ int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambd
     zwdev = c->zw_host.p;
     zbase = c->z.p;
   } else {
-    if (c->rng.current < 0 || c->rng.n_zw != c->D || c->rng.n_zv != c->D * (int64_t)c->K)
-      throw Error(MFM_ERR_RUNTIME, "mfm_sweep_wV(z = NULL) needs an acquired device random set with D + K*D variates");
     zwdev = c->rng.slot[c->rng.current].zw.p;
     zbase = c->rng.slot[c->rng.current].zv.p + (size_t)f_begin * c->D;
   }
