@@ -1047,51 +1047,89 @@ __global__ __launch_bounds__(CELL_NT) void k_cell_score(CellScoreArgs a) {
 #pragma unroll
   for (int s = 0; s < CELL_MAX_STREAMS; s++)
     if (s < a.n_streams && a.type[s] == CELL_I) sI = s;
+  // the same software pipeline as the sweep's pass: records and accumulators of step st + 1 are requested after the I-table
+  // gathers of step st
+  uint2 rec_n[CELL_R];
+  double acc_n[CELL_R];
+  int it_n[CELL_R];
+#pragma unroll
+  for (int k = 0; k < CELL_R; k++) {
+    const int lr = k * 64 + lane, pos = r0 + lr;
+    rec_n[k] = make_uint2(0, 0);
+    acc_n[k] = 0.0;
+    it_n[k] = 0;
+    if (lr < len) {
+      rec_n[k] = a.ix[pos];
+      if (FB > 0) acc_n[k] = __builtin_nontemporal_load(a.acc + pos);
+      if (ITEM32) it_n[k] = a.item[pos];
+    }
+  }
   for (int st = 0; st < steps; st++) {
+    uint2 rec[CELL_R];
+    double acc[CELL_R];
+    bool valid[CELL_R];
+    double q[CELL_R][TW];
 #pragma unroll
     for (int k = 0; k < CELL_R; k++) {
-      const int lr = st * WROWS + k * 64 + lane, pos = r0 + st * SROWS + k * 64 + lane;
-      if (lr >= len) continue;
-      const uint2 rec = a.ix[pos];
-      double q[TW];
+      rec[k] = rec_n[k];
+      acc[k] = acc_n[k];
+      valid[k] = st * WROWS + k * 64 + lane < len;
 #pragma unroll
-      for (int j = 0; j < TW; j++) q[j] = 0.0;
-      if (sI >= 0) {
-        const int it = ITEM32 ? a.item[pos] : cell_slot(rec, a.slot[sI]);
+      for (int j = 0; j < TW; j++) q[k][j] = 0.0;
+      if (sI >= 0 && valid[k]) {
+        const int it = ITEM32 ? it_n[k] : cell_slot(rec[k], a.slot[sI]);
         if (FB == 0) {
-          q[0] = a.LS[sI][it];
+          q[k][0] = a.LS[sI][it];
         } else {
           const double *src = a.Q[sI] + (int64_t)it * a.KS + a.f0;
 #pragma unroll
-          for (int j = 0; j < TW; j++) q[j] = j < a.nf ? src[j] : 0.0;
+          for (int j = 0; j < TW; j++) q[k][j] = j < a.nf ? src[j] : 0.0;
         }
       }
+    }
+    if (st + 1 < steps) {
+#pragma unroll
+      for (int k = 0; k < CELL_R; k++) {
+        const int lr = (st + 1) * WROWS + k * 64 + lane, pos = r0 + (st + 1) * SROWS + k * 64 + lane;
+        if (lr < len) {
+          rec_n[k] = a.ix[pos];
+          if (FB > 0) acc_n[k] = __builtin_nontemporal_load(a.acc + pos);
+          if (ITEM32) it_n[k] = a.item[pos];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CELL_R; k++) {
+      if (!valid[k]) continue;
+      const int pos = r0 + st * SROWS + k * 64 + lane;
 #pragma unroll
       for (int s = 0; s < CELL_MAX_STREAMS; s++)
         if (s < a.n_streams && a.type[s] != CELL_I) {
-          const double *t = lds + a.lds_off[s] + cell_slot(rec, a.slot[s]) * TW;
+          const double *t = lds + a.lds_off[s] + cell_slot(rec[k], a.slot[s]) * TW;
 #pragma unroll
-          for (int j = 0; j < TW; j++) q[j] += t[j];
+          for (int j = 0; j < TW; j++) q[k][j] += t[j];
         }
       if (FB == 0) {
-        a.acc[pos] = a.w0 + q[0];
+        __builtin_nontemporal_store(a.w0 + q[k][0], a.acc + pos);
       } else {
-        double acc = a.acc[pos];
+        double v = acc[k];
 #pragma unroll
-        for (int j = 0; j < TW; j++) acc += 0.5 * (q[j] * q[j]);
-        a.acc[pos] = acc;
+        for (int j = 0; j < TW; j++) v += 0.5 * (q[k][j] * q[k][j]);
+        __builtin_nontemporal_store(v, a.acc + pos);
       }
     }
   }
 }
 
-// per feature: sum_f v_jf^2 from the row-major copy of V
-__global__ __launch_bounds__(256) void k_cell_rowsumsq(const double *__restrict__ Vt, int64_t D, int K, int KS, double *__restrict__ out) {
+// per feature: sum_f v_jf^2 from the factor-major V (coalesced across the features)
+__global__ __launch_bounds__(256) void k_cell_rowsumsq(const double *__restrict__ V, int64_t D, int K, double *__restrict__ out) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= D) return;
-  const double *r = Vt + j * KS;
   double s = 0.0;
-  for (int f = 0; f < K; f++) s += r[f] * r[f];
+  for (int f = 0; f < K; f++) {
+    const double v = V[(int64_t)f * D + j];
+    s += v * v;
+  }
   out[j] = s;
 }
 __global__ void k_cell_unpack_score(const double *__restrict__ acc, const int32_t *__restrict__ perm, int64_t N,
@@ -1117,8 +1155,8 @@ static void launch_score_t(hipStream_t s, int G, size_t lds, const CellScoreArgs
     hipLaunchKernelGGL((k_cell_score<FB, false>), dim3(G), dim3(CELL_NT), lds, s, a);
 }
 
-void cell_score(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellScoreSrc> &src, const double *Vt, int64_t D, int K, int KS,
-                double w0, const double *y, double2 *eq) {
+void cell_score(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellScoreSrc> &src, const double *V, const double *Vt, int64_t D,
+                int K, int KS, double w0, const double *y, double2 *eq) {
   // tables: Q_s [card][KS], LS_s [card]
   if (cp.vss.n < (size_t)D) cp.vss.alloc((size_t)std::max<int64_t>(D, 1));
   for (size_t si = 0; si < cp.streams.size(); si++) {
@@ -1128,7 +1166,7 @@ void cell_score(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellS
   }
   {
     TimedLaunch t(tm, s, KC_CELL_SMALL, 0.0);
-    if (K > 0) hipLaunchKernelGGL(k_cell_rowsumsq, dim3(cdiv_c(D, 256)), dim3(256), 0, s, Vt, D, K, KS, cp.vss.p);
+    if (K > 0) hipLaunchKernelGGL(k_cell_rowsumsq, dim3(cdiv_c(D, 256)), dim3(256), 0, s, V, D, K, cp.vss.p);
     CellPrepArgs a;
     a.n_jobs = 0;
     int64_t maxn = 0;
@@ -1208,7 +1246,7 @@ void cell_score(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellS
     }
     return (o + 2) * sizeof(double);
   };
-  int FB = 8;
+  int FB = 4;  // (8 factors' q of 6 rows per lane do not fit 128 VGPRs)
   while (FB > 1 && layout(FB) > CELL_LDS_BYTES) FB /= 2;
   if (layout(1) > CELL_LDS_BYTES) throw Error(MFM_ERR_RUNTIME, "internal: cell scorer tables do not fit the LDS");
   const double row_bytes = (double)cp.N * (8.0 + 8.0 + 8.0 + (cp.item32 ? 4.0 : 0.0));
@@ -1223,8 +1261,7 @@ void cell_score(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellS
     a.f0 = f0;
     a.nf = std::min(FB, K - f0);
     const size_t lds = layout(FB);
-    if (FB == 8) launch_score_t<8>(s, cp.G, lds, a, cp.item32);
-    else if (FB == 4) launch_score_t<4>(s, cp.G, lds, a, cp.item32);
+    if (FB == 4) launch_score_t<4>(s, cp.G, lds, a, cp.item32);
     else if (FB == 2) launch_score_t<2>(s, cp.G, lds, a, cp.item32);
     else launch_score_t<1>(s, cp.G, lds, a, cp.item32);
   }

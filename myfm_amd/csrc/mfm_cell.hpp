@@ -141,8 +141,8 @@ void cell_sum1(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *dst, int 
 void cell_draw_main_w(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *w, const double *z, const int32_t *group, const double *lam,
                       const double *mu, double alpha);
 void cell_block_delta_w(hipStream_t s, Timing &tm, CellPlan &cp, int F, const double *rec, const double2 *saved);
-// update_e on the cell layout: eq[t].x = score_t (- y_t when y is given). Vt: row-major copy of V [D][KS]
-void cell_score(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellScoreSrc> &src, const double *Vt, int64_t D, int K, int KS,
-                double w0, const double *y, double2 *eq);
+// update_e on the cell layout: eq[t].x = score_t (- y_t when y is given). V: factor-major [K][D], Vt: its row-major copy [D][KS]
+void cell_score(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellScoreSrc> &src, const double *V, const double *Vt, int64_t D,
+                int K, int KS, double w0, const double *y, double2 *eq);
 
 }  // namespace mfm

@@ -628,7 +628,7 @@ static void score_train(mfm_ctx *c, bool subtract_y) {
         src[k].ss = B.bs.p;
       }
     }
-    cell_score(s, c->timing, c->cell, src, c->Vt.p, c->D, c->K, c->KS, c->w0, subtract_y ? c->y.p : nullptr, c->eq.p);
+    cell_score(s, c->timing, c->cell, src, c->V.p, c->Vt.p, c->D, c->K, c->KS, c->w0, subtract_y ? c->y.p : nullptr, c->eq.p);
     return;
   }
   score_design(c->stream, c->timing, 0, c->X, c->blocks, c->D, c->K, c->KS, c->w0, c->w.p, c->V.p, c->Vt.p,
