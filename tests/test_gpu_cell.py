@@ -152,3 +152,47 @@ def test_cell_linear_sweep(oracle, capi, monkeypatch, shape):
     t2, cg = _pair(oracle, capi, main, y, gi, 2, blocks)
     cg.sweep_w(1.3, lam, mu, z)
     np.testing.assert_allclose(c.get_state()[1], cg.get_state()[1], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("task", ["regression", "classification", "ordered"])
+def test_cell_path_through_the_trainer(oracle, monkeypatch, task):
+    # create_train_fm (the drop-in boundary) on an index-tuple design with the cell path forced: every kept sample and
+    # hyper-parameter draw of the three tasks against the oracle's chain. Classification / ordered probit in the host-RNG test
+    # mode (tests/test_gpu_host_rng_parity.py), so that the latent draws are the reference's, row by row: the cell path's
+    # update_w / update_V / update_e feed kernels that work on eq in row order (the residual is brought back on demand).
+    from myfm_amd import _myfm
+
+    from .test_gpu_baseline_configs import _assert_chain, _config
+    from .test_gpu_host_rng_parity import _oracle_chain
+
+    monkeypatch.setenv("MFM_CELL_MIN_ROWS", "0")
+    monkeypatch.setenv("MFM_CELL_GROUPS", "11")
+    if task != "regression":
+        monkeypatch.setenv("MYFM_AMD_HOST_RNG", "1")
+    main, blocks, score, shapes = ds.tuple_design(n_rows=25000, n_users=900, n_items=4500, ctx=(30,))
+    n = main.shape[0]
+    gi = ds.group_index_from_shapes(shapes)
+    n_iter, rank = 4, 3
+    kw, groups = {}, None
+    if task == "regression":
+        y = score
+    elif task == "classification":
+        y = np.where(score > np.median(score), 1.0, -1.0)
+        kw = dict(task=oracle.CLASSIFICATION)
+    else:
+        s = (score - score.mean()) / score.std()
+        y = np.zeros(n)
+        for c in (-0.8, 0.0, 0.9):
+            y += s > c
+        groups = [(4, np.arange(n))]
+        kw = dict(task=oracle.ORDERED, cutpoint_groups=groups)
+    rels = [_myfm.RelationBlock(np.asarray(m, dtype=np.int64), B) for m, B in blocks]
+    cfg = _config(_myfm, gi, n_iter, n_iter, task=task, **({"cutpoint_groups": groups} if groups else {}))
+    predictor, history = _myfm.create_train_fm(rank, 0.1, main, rels, y, 42, cfg, lambda *a: False)
+    samples, hypers, cuts, t = _oracle_chain(oracle, main, y, blocks, n_iter, n_groups_cut=1 if groups else 0, rank=rank,
+                                             group_index=gi, **kw)
+    _assert_chain(predictor, history, samples, hypers)
+    if groups:
+        for fm, cut in zip(predictor.samples, cuts):
+            np.testing.assert_allclose(fm.cutpoints[0], cut[0], rtol=1e-7, atol=1e-7)
+        assert list(history.n_mh_accept) == [t.mh_accept(0)]
