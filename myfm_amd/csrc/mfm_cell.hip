@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <functional>
 #include <mutex>
 #include <thread>
 
@@ -67,15 +68,42 @@ static void par_for(int64_t n, int64_t min_per_thread, F f) {
   for (auto &t : pool) t.join();
 }
 
-bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlockIn> &blocks, int n_cu, hipStream_t s) {
+bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlockIn> &blocks, int n_cu, hipStream_t s,
+                     int rank, int world, const std::function<void(std::vector<double> &)> &sum_ranks) {
+  // rank / world / sum_ranks: row-sharded mode. Every rank plans its own rows, but all of them must see the same fields (column
+  // ranges of the GLOBAL design), the same streams and the same verdict: the local findings are summed over the ranks (sum_ranks,
+  // every rank's values in its own slot where a minimum / maximum is needed) before they are used. An empty shard takes part in
+  // every sum.
   cp.ready = false;
   cp.streams.clear();
   cp.fields.clear();
   const int64_t N = X.rows;
   cp.N = N;
-  if (N <= 0 || N >= (int64_t)2147483647) return cp.fail("no rows");
-  const int64_t W = X.ptr[1] - X.ptr[0];
-  if (W < 1 || W > CELL_MAX_STREAMS || X.nnz() != N * W) return cp.fail("the main table is not a row of one-hot fields");
+  const bool shared = (bool)sum_ranks;
+  auto agree_bad = [&](int local) {  // > 0 on any rank -> the same on every rank
+    if (!shared) return local;
+    std::vector<double> v(1, local ? 1.0 : 0.0);
+    sum_ranks(v);
+    return v[0] > 0.0 ? std::max(local, 1) : 0;
+  };
+  if (N >= (int64_t)2147483647) return cp.fail("too many rows");
+  if (!shared && N <= 0) return cp.fail("no rows");
+  int64_t W = N > 0 ? X.ptr[1] - X.ptr[0] : 0;
+  std::vector<int64_t> base;
+  if (shared) {  // (every rank's rows have the same number of entries; an empty shard learns it here)
+    if (rank < 0 || rank >= world) return cp.fail("row-sharded: this rank's place among the ranks is not known");
+    std::vector<double> v((size_t)world, 0.0);
+    v[rank] = (double)W;
+    sum_ranks(v);
+    int64_t Wg = 0;
+    for (double x : v) Wg = std::max<int64_t>(Wg, (int64_t)x);
+    for (double x : v)
+      if (x != 0.0 && (int64_t)x != Wg) Wg = -1;
+    if (N == 0 && Wg > 0) W = Wg;
+    if (N > 0 && W != Wg) W = -2;
+  }
+  int bad0 = (W < 1 || W > CELL_MAX_STREAMS || X.nnz() != N * std::max<int64_t>(W, 0)) ? 1 : 0;
+  if (agree_bad(bad0)) return cp.fail("the main table is not a row of one-hot fields");
   // field p = the p-th stored entry of every row: its column range, unit values, first field sorted
   std::vector<int64_t> lo((size_t)W, (int64_t)1 << 60), hi((size_t)W, -1);
   std::atomic<int> bad(0);
@@ -98,13 +126,29 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
       hi[p] = std::max(hi[p], h[p]);
     }
   });
-  if (bad == 1) return cp.fail("the main table is not a row of unit-valued one-hot fields");
-  if (bad == 2) return cp.fail("the rows are not sorted by the first field");
-  for (int64_t p = 1; p < W; p++)
-    if (lo[p] <= hi[p - 1]) return cp.fail("the one-hot fields' column ranges overlap");
-  std::vector<int64_t> base((size_t)W + 1, 0);
+  if (shared) {  // the fields' column ranges of the GLOBAL design: every rank's (lo, hi) in its own slot of a summed vector
+    std::vector<double> v((size_t)world * 2 * W, 0.0);
+    for (int64_t p = 0; p < W; p++) {
+      v[((size_t)rank * W + p) * 2] = (double)lo[p];
+      v[((size_t)rank * W + p) * 2 + 1] = (double)hi[p];
+    }
+    sum_ranks(v);
+    for (int r = 0; r < world; r++)
+      for (int64_t p = 0; p < W; p++) {
+        lo[p] = std::min(lo[p], (int64_t)v[((size_t)r * W + p) * 2]);
+        hi[p] = std::max(hi[p], (int64_t)v[((size_t)r * W + p) * 2 + 1]);
+      }
+  }
+  for (int64_t p = 1; p < W && !bad; p++)
+    if (lo[p] <= hi[p - 1]) bad = 3;
+  base.assign((size_t)W + 1, 0);
   for (int64_t p = 1; p < W; p++) base[p] = lo[p];
   base[W] = X.cols;
+  {
+    const int b_all = agree_bad(bad.load());
+    if (b_all) return cp.fail(bad == 2 ? "the rows are not sorted by the first field"
+                                      : "the main table is not a row of unit-valued one-hot fields with disjoint column ranges");
+  }
   // streams: main fields first, then every block whose map is not one of the streams already there
   struct HostStream {
     int main_p = -1;               // main field position, or
@@ -137,7 +181,7 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
         for (int64_t t = a; t < e && !diff.load(std::memory_order_relaxed); t++)
           if (idx_of(hs[si], t) != blocks[b].map[t]) diff = 1;
       });
-      if (!diff) found = (int)si;
+      if (!agree_bad(diff.load())) found = (int)si;  // (equal on EVERY rank's rows)
     }
     if (found < 0) {
       if (hs.size() >= (size_t)CELL_MAX_STREAMS) return cp.fail("more index streams than a row record holds");
@@ -190,6 +234,13 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
   std::vector<int32_t> gu0;
   const HostStream &hU = hs[0];
   bool fits = false;
+  if (N == 0) {  // (an empty shard: no groups, no launches; it still takes part in every collective)
+    grow.assign(1, 0);
+    gu0.assign(1, 0);
+    cp.G = 0;
+    cp.umax = 0;
+    fits = true;
+  }
   for (int mult = 1; mult <= 16 && !fits; mult *= 2) {
     const int64_t G0 = (int64_t)std::max(1, n_cu) * mult;
     const int64_t target = (N + G0 - 1) / G0;
@@ -221,10 +272,14 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
     }
     fits = worst <= CELL_LDS_BYTES;
   }
-  if (!fits) return cp.fail("a group's tables do not fit the LDS (a first-field value with too many rows, or too many values per group)");
   const int G = cp.G;
   const int64_t cardI = cp.sI >= 0 ? cp.streams[cp.sI].card : 0;
-  if (cardI > 0 && (double)G * (double)cardI * 48.0 > 16e9) return cp.fail("the (group, item) partials would not fit");
+  {
+    const int lf = !fits ? 1 : (cardI > 0 && (double)G * (double)cardI * 56.0 > 16e9) ? 2 : 0;
+    if (agree_bad(lf))
+      return cp.fail(lf == 2 ? "the (group, item) partials would not fit"
+                             : "a group's tables do not fit the LDS (a first-field value with too many rows, or too many values per group)");
+  }
   // rows in cell order: inside a group by the I index (stable), the group cut into CELL_NW wave chunks between two I values.
   // Physical layout: what a workgroup touches in one step is ONE contiguous block -- position of row r of wave w's chunk =
   // group base + (r / 256) * 4096 + w * 256 + r % 256 (chunks padded to whole steps; pad rows have perm = -1) -- so that HBM
@@ -281,8 +336,8 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
   for (int g = 0; g < G; g++) {
     gbase[g] = (int32_t)npad;
     npad += (int64_t)steps[g] * SROWS;
-    if (npad >= (int64_t)2147483647) return cp.fail("padded row count exceeds 2^31");
   }
+  if (agree_bad(npad >= (int64_t)2147483647 ? 1 : 0)) return cp.fail("padded row count exceeds 2^31");
   gbase[G] = (int32_t)npad;
   cp.Npad = npad;
   std::vector<int32_t> perm((size_t)npad, -1), item;
@@ -343,6 +398,7 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
   cp.DP.alloc_zero((size_t)std::max<int64_t>(1, maxcard), s);
   cp.stat.alloc_zero((size_t)std::max<int64_t>(1, cardU * 2), s);
   cp.stat1.alloc_zero((size_t)std::max<int64_t>(1, maxcard), s);
+  cp.dense.alloc_zero((size_t)std::max<int64_t>(1, maxcard) * 4, s);
   cp.cnt_ready = false;
   for (size_t f = 0; f < cp.fields.size(); f++)
     if (cp.fields[f].kind == 0) cp.cnt[f].alloc_zero((size_t)std::max<int64_t>(1, cp.fields[f].n), s);
@@ -368,10 +424,12 @@ __global__ void k_cell_unpack(const double *__restrict__ e, const int32_t *__res
   }
 }
 void cell_pack_e(hipStream_t s, CellPlan &cp, const double2 *eq) {
+  if (cp.Npad == 0) return;
   hipLaunchKernelGGL(k_cell_pack, dim3(cdiv_c(cp.Npad, 256)), dim3(256), 0, s, eq, cp.perm.p, cp.Npad, cp.e.p);
   MFM_HIP_CHECK(hipGetLastError());
 }
 void cell_unpack_e(hipStream_t s, CellPlan &cp, double2 *eq) {
+  if (cp.Npad == 0) return;
   hipLaunchKernelGGL(k_cell_unpack, dim3(cdiv_c(cp.Npad, 256)), dim3(256), 0, s, cp.e.p, cp.perm.p, cp.Npad, eq);
   MFM_HIP_CHECK(hipGetLastError());
 }
@@ -717,7 +775,7 @@ static void launch_pass_f(hipStream_t s, int G, size_t lds, const CellPassArgs &
 }
 
 void cell_pass(hipStream_t s, Timing &tm, CellPlan &cp, int P, int F, bool sw, double *out_u, int out_stride, bool linear) {
-  if (P < 0 && F < 0) return;
+  if ((P < 0 && F < 0) || cp.G == 0) return;  // (G = 0: an empty shard)
   CellPassArgs a;
   std::memset(&a, 0, sizeof(a));
   int off[11];
@@ -864,12 +922,14 @@ __global__ __launch_bounds__(256) void k_cell_draw_groups(const double *__restri
 }
 
 void cell_draw_main(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *Vf, const double *zf, const int32_t *group, const double *lam,
-                    const double *mu, double alpha) {
+                    const double *mu, double alpha, const double *dense) {
   const CellField &f = cp.fields[F];
   const CellStream &st = cp.streams[f.stream];
   TimedLaunch t(tm, s, KC_CELL_SMALL, 0.0);
   const int n = (int)f.n;
-  if (st.type == CELL_U)
+  if (dense)  // (row-sharded: the sums of all ranks, [n][2])
+    hipLaunchKernelGGL(k_cell_draw_direct, dim3(cdiv_c(n, 256)), dim3(256), 0, s, dense, n, Vf, zf, group, lam, mu, alpha, f.base, cp.DP.p);
+  else if (st.type == CELL_U)
     hipLaunchKernelGGL(k_cell_draw_direct, dim3(cdiv_c(n, 256)), dim3(256), 0, s, cp.stat.p, n, Vf, zf, group, lam, mu, alpha, f.base,
                        cp.DP.p);
   else
@@ -914,6 +974,46 @@ void cell_block_delta(hipStream_t s, Timing &tm, CellPlan &cp, int F, const doub
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Row-sharded mode: every rank runs the passes over its own rows; a field's sums then go through ONE dense array
+// [index values][sums] that is all-reduced over the ranks (RCCL, by the caller) before the replicated draw / feature sweep.
+template <int NS>
+__global__ __launch_bounds__(256) void k_cell_group_sums_dense(const double *__restrict__ src, int G, int64_t card, int n,
+                                                               double *__restrict__ dense) {
+  double sum[NS];
+  if (!cell_group_sums<NS>(src, G, card, n, sum)) return;
+  double *o = dense + (int64_t)(blockIdx.x * 32 + (threadIdx.x & 31)) * NS;
+#pragma unroll
+  for (int j = 0; j < NS; j++) o[j] = sum[j];
+}
+void cell_stats_dense(hipStream_t s, Timing &tm, CellPlan &cp, int F, int ns, double *dense) {
+  const CellField &f = cp.fields[F];
+  const CellStream &st = cp.streams[f.stream];
+  if (st.type == CELL_U) return;  // (the pass wrote its groups' values into the dense array itself)
+  if (ns == 1) {
+    cell_sum1(s, tm, cp, F, dense, 1);
+    return;
+  }
+  TimedLaunch t(tm, s, KC_CELL_SMALL, 0.0);
+  const double *src = st.type == CELL_I ? (ns == 2 ? cp.cells2.p : cp.cells4.p) : cp.cpart.p;
+  if (ns == 2)
+    hipLaunchKernelGGL(k_cell_group_sums_dense<2>, dim3(cdiv_c(f.n, 32)), dim3(256), 0, s, src, cp.G, st.card, (int)f.n, dense);
+  else
+    hipLaunchKernelGGL(k_cell_group_sums_dense<4>, dim3(cdiv_c(f.n, 32)), dim3(256), 0, s, src, cp.G, st.card, (int)f.n, dense);
+  MFM_HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(256) void k_cell_dense_to_rec(const double *__restrict__ dense, int n, int ns, double *__restrict__ rec, int w0) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * ns) return;
+  rec[(int64_t)(i / ns) * 8 + w0 + (i % ns)] = dense[i];
+}
+void cell_dense_to_rec(hipStream_t s, Timing &tm, CellPlan &cp, int F, int ns, const double *dense, double *rec, int w0) {
+  const CellField &f = cp.fields[F];
+  TimedLaunch t(tm, s, KC_CELL_SMALL, 0.0);
+  hipLaunchKernelGGL(k_cell_dense_to_rec, dim3(cdiv_c(f.n * ns, 256)), dim3(256), 0, s, dense, (int)f.n, ns, rec, w0);
+  MFM_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // update_w on the cell layout (FMTrainer.hpp:231-313). A one-hot main column i with x = 1: S2 = n_i (the rows it occurs in: static),
 // S1 = sum_t (e_t - w_old) = sum e - n_i w_old (:242-248); a block needs e_B = sum e per block row (:271) and changes its rows by
 // q_B' - q_B (:272-273 and :306-311 together). So the linear sweep is the same pass with ONE sum per index value and no q tables.
@@ -951,7 +1051,7 @@ __global__ void k_cell_fill_ones(const int32_t *__restrict__ perm, int64_t N, do
 // n_i of every main column: the statistics pass over a residual of ones (once per plan; cp.e is scratch here)
 void cell_counts(hipStream_t s, Timing &tm, CellPlan &cp) {
   if (cp.cnt_ready) return;
-  hipLaunchKernelGGL(k_cell_fill_ones, dim3(cdiv_c(cp.Npad, 256)), dim3(256), 0, s, cp.perm.p, cp.Npad, cp.e.p);
+  if (cp.Npad > 0) hipLaunchKernelGGL(k_cell_fill_ones, dim3(cdiv_c(cp.Npad, 256)), dim3(256), 0, s, cp.perm.p, cp.Npad, cp.e.p);
   for (size_t F = 0; F < cp.fields.size(); F++) {
     if (cp.fields[F].kind != 0) continue;
     cell_pass(s, tm, cp, -1, (int)F, false, cp.cnt[F].p, 1, true);
@@ -978,10 +1078,10 @@ __global__ __launch_bounds__(256) void k_cell_draw_w(const double *__restrict__ 
   DP[i] = make_double2(fresh - old, 0.0);  // e += x (w' - w)   (:252)
 }
 void cell_draw_main_w(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *w, const double *z, const int32_t *group, const double *lam,
-                      const double *mu, double alpha) {
+                      const double *mu, double alpha, const double *se) {
   const CellField &f = cp.fields[F];
   TimedLaunch t(tm, s, KC_CELL_SMALL, 0.0);
-  hipLaunchKernelGGL(k_cell_draw_w, dim3(cdiv_c(f.n, 256)), dim3(256), 0, s, cp.stat1.p, cp.cnt[F].p, (int)f.n, w, z, group, lam, mu, alpha,
+  hipLaunchKernelGGL(k_cell_draw_w, dim3(cdiv_c(f.n, 256)), dim3(256), 0, s, se ? se : cp.stat1.p, cp.cnt[F].p, (int)f.n, w, z, group, lam, mu, alpha,
                      f.base, cp.DP.p);
   MFM_HIP_CHECK(hipGetLastError());
 }
@@ -1250,6 +1350,7 @@ void cell_score(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellS
   while (FB > 1 && layout(FB) > CELL_LDS_BYTES) FB /= 2;
   if (layout(1) > CELL_LDS_BYTES) throw Error(MFM_ERR_RUNTIME, "internal: cell scorer tables do not fit the LDS");
   const double row_bytes = (double)cp.N * (8.0 + 8.0 + 8.0 + (cp.item32 ? 4.0 : 0.0));
+  if (cp.G == 0) return;  // (an empty shard: no rows to score)
   {
     TimedLaunch t(tm, s, KC_UPDATE_E, row_bytes - 8.0 * cp.N);
     a.f0 = 0;

@@ -28,6 +28,7 @@
 // reduced over the groups in group order by the draw / reduce kernel. Small streams C (context blocks, <= a few thousand
 // values) have their whole tables in LDS. Every floating-point sum has a fixed order: the chain is bit-reproducible.
 #pragma once
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -100,6 +101,7 @@ struct CellPlan {
   DevBuf<double> packI;    // [card_I][4] = (QA, QS, d1, d2) gathered per row
   DevBuf<double2> DP;      // (d1, d2) of the pending field, by index value
   DevBuf<double> stat;     // direct statistics of a main field on U [card][2]
+  DevBuf<double> dense;    // row-sharded: a field's sums [index values][sums], all-reduced over the ranks before they are used
   DevBuf<double> stat1;    // update_w: sum e per index value of the field whose statistics were taken
   DevBuf<double> cnt[CELL_MAX_FIELDS];  // update_w: rows per column of every main field (cell_counts)
   bool cnt_ready = false;
@@ -117,7 +119,9 @@ struct CellPlan {
 };
 
 // planner (host): X = the main table in CSR (rows sorted by the first field), blocks in Gibbs order
-bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlockIn> &blocks, int n_cu, hipStream_t s);
+// row-sharded: this rank's place among `world` ranks, sum_ranks = sum a host vector over the ranks
+bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlockIn> &blocks, int n_cu, hipStream_t s, int rank = 0,
+                     int world = 1, const std::function<void(std::vector<double> &)> &sum_ranks = nullptr);
 void cell_pack_e(hipStream_t s, CellPlan &cp, const double2 *eq);
 void cell_unpack_e(hipStream_t s, CellPlan &cp, double2 *eq);
 // per-stream tables of a pass from the fields' current tables: QA = q without field exA (skipped when !doA), QS = q without
@@ -128,7 +132,10 @@ void cell_prep(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellSr
 void cell_pass(hipStream_t s, Timing &tm, CellPlan &cp, int P, int F, bool sw, double *out_u, int out_stride, bool linear = false);
 // main field F: draw its columns from the statistics the pass left (FMTrainer.hpp:357-369), write V and DP
 void cell_draw_main(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *Vf, const double *zf, const int32_t *group, const double *lam,
-                    const double *mu, double alpha);
+                    const double *mu, double alpha, const double *dense = nullptr);
+// row-sharded: a field's sums over this rank's groups -> dense [n][ns] (a U field: written by the pass); dense -> record words
+void cell_stats_dense(hipStream_t s, Timing &tm, CellPlan &cp, int F, int ns, double *dense);
+void cell_dense_to_rec(hipStream_t s, Timing &tm, CellPlan &cp, int F, int ns, const double *dense, double *rec, int w0);
 // block F on an I or C stream: sum the partials over the groups into rec[i].{c, c_S, e, e_q} (a U block: written by the pass)
 void cell_block_stats(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *rec);
 // block F after its feature sweep: DP[i] = (q' - q, (q'^2 - q^2)/2 - (q_S' - q_S)/2) from the saved and the new (q, q_S)
@@ -139,7 +146,7 @@ void cell_block_delta(hipStream_t s, Timing &tm, CellPlan &cp, int F, const doub
 void cell_counts(hipStream_t s, Timing &tm, CellPlan &cp);
 void cell_sum1(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *dst, int dst_stride);
 void cell_draw_main_w(hipStream_t s, Timing &tm, CellPlan &cp, int F, double *w, const double *z, const int32_t *group, const double *lam,
-                      const double *mu, double alpha);
+                      const double *mu, double alpha, const double *se = nullptr);
 void cell_block_delta_w(hipStream_t s, Timing &tm, CellPlan &cp, int F, const double *rec, const double2 *saved);
 // update_e on the cell layout: eq[t].x = score_t (- y_t when y is given). V: factor-major [K][D], Vt: its row-major copy [D][KS]
 void cell_score(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellScoreSrc> &src, const double *V, const double *Vt, int64_t D,

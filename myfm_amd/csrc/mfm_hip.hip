@@ -676,22 +676,34 @@ static void run_sweep_cell(mfm_ctx *c, int f_begin, int f_end, const double *zba
       const CellField &fd = cp.fields[k];
       DevBlock *B = fd.kind == 1 ? c->blocks[(size_t)fd.base].get() : nullptr;
       double *out_u = B ? B->rec.p + 2 : cp.stat.p;  // a U field's sums: (c, c_S, e, e_q) of the record / (S2, S_eh)
-      const int out_stride = B ? BLOCK_REC : 2;
+      int out_stride = B ? BLOCK_REC : 2;
       const bool split = P >= 0 && cp.lds_bytes(P, k, sw) > CELL_LDS_BYTES;
       if (sw)
         cell_prep(s, tm, cp, cur, false, -1, true, k, false);
       else
         cell_prep(s, tm, cp, cur, P >= 0, P, true, k, P >= 0 && on_I(P));
+      const bool sh = c->comm.active();
+      const int ns = B ? 4 : 2;
+      if (sh) {  // row-sharded: the sums go through one dense array that is all-reduced
+        out_u = cp.dense.p;
+        out_stride = ns;
+        MFM_HIP_CHECK(hipMemsetAsync(cp.dense.p, 0, (size_t)fd.n * ns * sizeof(double), s));
+      }
       if (!split) {
         cell_pass(s, tm, cp, P, k, sw, out_u, out_stride);
       } else {  // (both roles do not fit the LDS together)
         cell_pass(s, tm, cp, P, -1, false, nullptr, 0);
         cell_pass(s, tm, cp, -1, k, false, out_u, out_stride);
       }
+      if (sh) {
+        cell_stats_dense(s, tm, cp, k, ns, cp.dense.p);
+        c->comm.allreduce(cp.dense.p, fd.n * ns);
+        if (B) cell_dense_to_rec(s, tm, cp, k, 4, cp.dense.p, B->rec.p, 2);
+      }
       if (!B) {
-        cell_draw_main(s, tm, cp, k, Vf, zf, c->group.p, lamf, muf, alpha);  // :357-369
+        cell_draw_main(s, tm, cp, k, Vf, zf, c->group.p, lamf, muf, alpha, sh ? cp.dense.p : nullptr);  // :357-369
       } else {
-        cell_block_stats(s, tm, cp, k, B->rec.p);  // :401-407
+        if (!sh) cell_block_stats(s, tm, cp, k, B->rec.p);  // :401-407
         if (B->q_saved.n < (size_t)B->B) B->q_saved.alloc((size_t)B->B);
         hipLaunchKernelGGL(k_save_q, dim3(cdiv(std::max<int64_t>(B->B, 1), 256)), dim3(256), 0, s, B->rec.p, B->B, B->q_saved.p);
         SweepArgs a = block_args(*B, Vf, zf, c->group.p, lamf, muf, alpha);
@@ -716,9 +728,13 @@ static void run_sweep_w_cell(mfm_ctx *c, const double *zdev, double alpha) {
   CellPlan &cp = c->cell;
   Timing &tm = c->timing;
   const int m = (int)cp.fields.size();
+  const bool sh = c->comm.active();
   if (!cp.cnt_ready) {
     if (c->e_in_cell) materialize_e(c);  // (cell.e is the scratch of the one-off row count)
     cell_counts(s, tm, cp);
+    if (sh)  // (a column's rows on all ranks)
+      for (int k = 0; k < m; k++)
+        if (cp.fields[k].kind == 0) c->comm.allreduce(cp.cnt[k].p, cp.fields[k].n);
   }
   if (!c->e_in_cell) cell_pack_e(s, cp, c->eq.p);
   c->e_in_cell = true;
@@ -733,11 +749,20 @@ static void run_sweep_w_cell(mfm_ctx *c, const double *zdev, double alpha) {
       hipLaunchKernelGGL(k_save_q, dim3(cdiv(std::max<int64_t>(B->B, 1), 256)), dim3(256), 0, s, B->rec.p, B->B, B->q_saved.p);
     }
     double *sums = B ? B->rec.p + 4 : cp.stat1.p;  // e_B of the record (:271) / the draw's input
-    const int stride = B ? BLOCK_REC : 1;
+    int stride = B ? BLOCK_REC : 1;
+    if (sh) {
+      sums = cp.dense.p;
+      stride = 1;
+      MFM_HIP_CHECK(hipMemsetAsync(cp.dense.p, 0, (size_t)fd.n * sizeof(double), s));
+    }
     cell_pass(s, tm, cp, k - 1, k, false, sums, stride, true);
     cell_sum1(s, tm, cp, k, sums, stride);
+    if (sh) {
+      c->comm.allreduce(cp.dense.p, fd.n);
+      if (B) cell_dense_to_rec(s, tm, cp, k, 1, cp.dense.p, B->rec.p, 4);
+    }
     if (!B) {
-      cell_draw_main_w(s, tm, cp, k, c->w.p, zdev, c->group.p, c->lam.p, c->mu.p, alpha);  // :237-254
+      cell_draw_main_w(s, tm, cp, k, c->w.p, zdev, c->group.p, c->lam.p, c->mu.p, alpha, sh ? cp.dense.p : nullptr);  // :237-254
     } else {
       SweepArgs a = block_args(*B, c->w.p, zdev, c->group.p, c->lam.p, c->mu.p, alpha);
       run_plan<PBlockW>(s, tm, B->plan_W, a, c->ls, kc, false);  // :276-302
@@ -1005,14 +1030,34 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     // the blocks' inverse maps are never used and are not built (config 5: 1.3 s of mfm_finalize and 3 GB of HBM).
     {
       const int64_t cell_min_rows = std::getenv("MFM_CELL_MIN_ROWS") ? std::atoll(std::getenv("MFM_CELL_MIN_ROWS")) : ((int64_t)1 << 20);
-      if (!c->hblocks.empty() && !c->comm.active() && c->X.unit && c->X.ell_width >= 1 && c->N >= cell_min_rows && c->K > 0 &&
-          !std::getenv("MFM_NO_CELL")) {
+      // row-sharded: every rank plans its own rows; what must be the same everywhere (fields, streams, the verdict) is summed
+      // over the ranks inside the planner
+      const bool sh = c->comm.active();
+      auto sum_ranks = [&](std::vector<double> &v) {
+        DevBuf<double> d;
+        d.upload(v);
+        c->comm.allreduce(d.p, (int64_t)v.size());
+        MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
+        MFM_HIP_CHECK(hipMemcpy(v.data(), d.p, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+      };
+      bool try_cell = !c->hblocks.empty() && c->K > 0 && !std::getenv("MFM_NO_CELL") && (!sh || !std::getenv("MFM_NO_CELL_SHARDED"));
+      if (!sh) {
+        try_cell = try_cell && c->X.unit && c->X.ell_width >= 1 && c->N >= cell_min_rows;
+      } else if (try_cell) {  // (the same decision on every rank: the rows of all of them count, an empty shard has no say)
+        std::vector<double> v{(double)c->N, (c->N > 0 && !(c->X.unit && c->X.ell_width >= 1)) ? 1.0 : 0.0, c->comm.shard_set ? 0.0 : 1.0};
+        sum_ranks(v);
+        try_cell = v[0] >= (double)cell_min_rows && v[1] == 0.0 && v[2] == 0.0;
+      }
+      if (try_cell) {
         int n_cu = 0;
         MFM_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
         if (const char *e = std::getenv("MFM_CELL_GROUPS")) n_cu = std::max(1, std::atoi(e));
         std::vector<CellBlockIn> bin;
         for (auto &hb : c->hblocks) bin.push_back(CellBlockIn{hb.map.data(), hb.X.rows});
-        cell_plan_build(c->cell, c->hX, bin, n_cu, c->stream);
+        if (sh)
+          cell_plan_build(c->cell, c->hX, bin, n_cu, c->stream, c->comm.shard_set ? c->comm.rank : -1, c->comm.world, sum_ranks);
+        else
+          cell_plan_build(c->cell, c->hX, bin, n_cu, c->stream);
         c->cell_w = c->cell.ready && !std::getenv("MFM_NO_CELL_W");
         if (tlog)
           std::fprintf(stderr, "[mfm_finalize] cell plan: %s (G=%d umax=%lld streams=%zu fields=%zu item32=%d)\n",

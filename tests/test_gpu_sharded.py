@@ -405,3 +405,58 @@ def test_sharded_two_field_pass(oracle, world, values, monkeypatch):
         np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(ge, e[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize("world,shape", [(2, "u_i_ctx"), (3, "u_i_ctx"), (2, "no_item"), (3, "three_fields")])
+def test_cell_path_row_sharded(oracle, monkeypatch, world, shape):
+    """Index-tuple designs (mfm_cell.hpp) row-sharded over `world` lock-stepped ranks on one GPU: every rank runs the cell
+    passes over its own rows (users straddle the rank boundaries), a field's sums go through one dense array that is
+    all-reduced before the replicated draw / feature sweep (the all-reduce of the per-block sufficient statistics).
+    Must reproduce the unsharded oracle chain; the ranks' models must be identical."""
+    from myfm_amd import _capi, _myfm
+    from myfm_amd.distributed import shard_rows
+
+    from .test_gpu_cell import SHAPES
+
+    monkeypatch.setenv("MFM_CELL_MIN_ROWS", "0")
+    monkeypatch.setenv("MFM_CELL_GROUPS", "7")
+    main, blocks, y, shapes = ds.tuple_design(**SHAPES[shape])
+    gi = ds.group_index_from_shapes(shapes)
+    K, n_iter = 3, 3
+    ls = Lockstep(world)
+    levels = _capi.column_levels(main)[0]
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            Xl, yl, rel, lo, n = shard_rows(main, y, blocks, rank, world)
+            rbs = [_myfm.RelationBlock(np.asarray(m, dtype=np.int64), b) for m, b in rel]
+            s = _myfm.GibbsSession(K, 0.1, Xl, rbs, yl, 42, _config(gi), allreduce=ls.callback(rank), n_total_rows=n,
+                                   row_offset=lo, main_levels=levels, shard_rank=rank, shard_world=world)
+            assert s.plan_flags() & 512, "the cell path was not taken"
+            for it in range(n_iter):
+                s.step()
+            out[rank] = (s.fm.w0, np.asarray(s.fm.w), np.asarray(s.fm.V), s.residual(), lo, float(s.hyper.alpha))
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            ls.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=300)
+    assert not errs, errs
+    t = oracle.OracleTrainer(main, y, blocks, rank=K, group_index=gi)
+    for it in range(n_iter):
+        t.step()
+    w0, w, V = t.fm()
+    e = t.e(main.shape[0])
+    for rank in range(world):
+        gw0, gw, gV, ge, lo, galpha = out[rank]
+        assert abs(gw0 - w0) < 1e-7
+        np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(ge, e[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
+        assert abs(galpha - t.hyper()["alpha"]) < 1e-7 * galpha
+        assert np.array_equal(gV, out[0][2]) and np.array_equal(gw, out[0][1])  # replicas bit-identical
