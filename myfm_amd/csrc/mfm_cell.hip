@@ -255,6 +255,11 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
     gu0.assign((size_t)G + 1, 0);
     for (int g = 1; g < G; g++) gu0[g] = (int32_t)idx_of(hU, grow[g]);
     gu0[G] = (int32_t)cardU;
+    if (shared) {  // (a shard's groups cover its own U values only: the sums of the others come from their ranks; the dense
+                   //  array the sums go through is zeroed first, so values without a group contribute zero)
+      gu0[0] = (int32_t)idx_of(hU, 0);
+      gu0[G] = (int32_t)idx_of(hU, N - 1) + 1;
+    }
     int64_t um = 0;
     for (int g = 0; g < G; g++) um = std::max<int64_t>(um, gu0[g + 1] - gu0[g]);
     cp.G = G;
