@@ -1040,7 +1040,10 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
         MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
         MFM_HIP_CHECK(hipMemcpy(v.data(), d.p, v.size() * sizeof(double), hipMemcpyDeviceToHost));
       };
-      bool try_cell = !c->hblocks.empty() && c->K > 0 && !std::getenv("MFM_NO_CELL") && (!sh || !std::getenv("MFM_NO_CELL_SHARDED"));
+      // (also tables of three or more one-hot fields WITHOUT relation blocks on one GPU: one pass per field instead of the
+      //  row-tile passes of run_sweep_soa_multi; two-field tables keep the persistent sweep / the two-field pass)
+      const bool flat = c->hblocks.empty() && !sh && c->X.ell_width >= 3 && !std::getenv("MFM_NO_CELL_FLAT");
+      bool try_cell = (!c->hblocks.empty() || flat) && c->K > 0 && !std::getenv("MFM_NO_CELL") && (!sh || !std::getenv("MFM_NO_CELL_SHARDED"));
       if (!sh) {
         try_cell = try_cell && c->X.unit && c->X.ell_width >= 1 && c->N >= cell_min_rows;
       } else if (try_cell) {  // (the same decision on every rank: the rows of all of them count, an empty shard has no say)

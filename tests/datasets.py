@@ -271,7 +271,7 @@ def config5_like(scale=0.01, seed=2, ordered=True):
 
 
 def tuple_design(n_rows=60000, n_users=3000, n_items=5000, ctx=(50, 37), user_cols=40, item_cols=30, seed=4, third_field=0,
-                 with_item_field=True, with_item_block=True, user_block_rows=None, user_max=None):
+                 with_item_field=True, with_item_block=True, user_block_rows=None, user_max=None, with_user_block=True):
     """A design whose rows are index tuples (the shape of BASELINE configs[4], any size): main table = one-hot user field
     (rows sorted by user) [+ one-hot item field] [+ a small third one-hot field]; relation blocks: user side (mapped by the user
     column, multi-hot), item side (mapped by the item index), one context block per entry of `ctx` (own random maps).
@@ -303,7 +303,7 @@ def tuple_design(n_rows=60000, n_users=3000, n_items=5000, ctx=(50, 37), user_co
         vals = rng.uniform(0.3, 1.0, size=keep.sum())
         return sps.csr_matrix((vals, (rows[keep], c[keep])), shape=(n, n_cols))
 
-    blocks = [(u.astype(np.int64), block(user_block_rows or n_users, user_cols, 3))]
+    blocks = [(u.astype(np.int64), block(user_block_rows or n_users, user_cols, 3))] if with_user_block else []
     if with_item_block:
         blocks.append((it.astype(np.int64), block(n_items, item_cols, 3)))
     for n_c in ctx:

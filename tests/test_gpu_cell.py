@@ -29,6 +29,9 @@ SHAPES = {
     # three main fields (the third small), item block but no item-side context
     "three_fields": dict(n_rows=50000, n_users=1500, n_items=4500, ctx=(), third_field=24),
     # few items: every stream but U is an LDS table; the user block has fewer rows than the user field has columns
+    # three one-hot fields and NO relation block (the flat form; the comparison context runs the multi-level fused tile pass)
+    "flat_three_fields": dict(n_rows=50000, n_users=1500, n_items=4500, ctx=(), third_field=24, with_user_block=False,
+                              with_item_block=False),
     "small_items": dict(n_rows=30000, n_users=1200, n_items=300, ctx=(40,), user_max=1000, user_block_rows=1000),
 }
 
