@@ -487,11 +487,20 @@ void cell_prep(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellSr
       }
     maxn = std::max(maxn, (int)n);
   };
+  // a table is rebuilt only when its stream's sources changed (cell_touch) or another field is left out of it
+  auto fresh = [&](int side, size_t si, int ex) {
+    const int ex_here = (ex >= 0 && cp.fields[ex].stream == (int)si) ? ex : -1;
+    if (cp.have_ver[side][si] == cp.ver[si] && cp.have_ex[side][si] == ex_here) return true;
+    cp.have_ver[side][si] = cp.ver[si];
+    cp.have_ex[side][si] = ex_here;
+    return false;
+  };
   for (size_t si = 0; si < cp.streams.size(); si++) {
     const CellStream &st = cp.streams[si];
+    const bool needA = doA && !fresh(0, si, exA), needS = doS && !fresh(1, si, exS);
     if (st.type == CELL_I) {
-      if (doA) add(cp.packI.p + 0, 4, st.card, (int)si, exA);
-      if (doS) add(cp.packI.p + 1, 4, st.card, (int)si, exS);
+      if (needA) add(cp.packI.p + 0, 4, st.card, (int)si, exA);
+      if (needS) add(cp.packI.p + 1, 4, st.card, (int)si, exS);
       if (dp_to_I) {
         for (int k = 0; k < 2; k++) {
           add(cp.packI.p + 2 + k, 4, st.card, -1, -1);
@@ -504,8 +513,8 @@ void cell_prep(hipStream_t s, Timing &tm, CellPlan &cp, const std::vector<CellSr
         }
       }
     } else {
-      if (doA) add(cp.QA[si].p, 1, st.card, (int)si, exA);
-      if (doS) add(cp.QS[si].p, 1, st.card, (int)si, exS);
+      if (needA) add(cp.QA[si].p, 1, st.card, (int)si, exA);
+      if (needS) add(cp.QS[si].p, 1, st.card, (int)si, exS);
     }
   }
   if (!a.n_jobs || !maxn) return;

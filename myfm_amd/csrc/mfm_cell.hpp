@@ -109,6 +109,15 @@ struct CellPlan {
   DevBuf<double> cpart;    // [G][card_C][4] partial tables of a C field
   // scorer tables (cell_score)
   DevBuf<double> scoreQ[CELL_MAX_STREAMS], scoreLS[CELL_MAX_STREAMS], vss;
+  // which tables cell_prep has already built: a stream's content version (bumped by cell_touch when one of its fields' tables
+  // changes) and the field left out, per side (0: QA, 1: QS)
+  int64_t ver[CELL_MAX_STREAMS] = {1, 1, 1, 1}, ver_next = 2;
+  int64_t have_ver[2][CELL_MAX_STREAMS] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  int have_ex[2][CELL_MAX_STREAMS] = {{-2, -2, -2, -2}, {-2, -2, -2, -2}};
+  void touch(int field) { ver[fields[field].stream] = ver_next++; }  // the field's table changed
+  void touch_all() {
+    for (auto &v : ver) v = ver_next++;
+  }
   bool fail(const char *w) {
     why = w;
     ready = false;

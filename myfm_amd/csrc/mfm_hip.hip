@@ -645,7 +645,9 @@ static void run_sweep_cell(mfm_ctx *c, int f_begin, int f_end, const double *zba
   if (!c->e_in_cell) cell_pack_e(s, cp, c->eq.p);
   c->e_in_cell = true;  // (stays in cell order: materialize_e brings it back when somebody reads eq)
   std::vector<CellSrc> cur((size_t)m);
+  cp.touch_all();  // (whatever cell_prep built in an earlier call is stale)
   auto set_cur = [&](int f) {
+    cp.touch_all();
     for (int k = 0; k < m; k++) {
       const CellField &fd = cp.fields[k];
       if (fd.kind == 0) {
@@ -710,6 +712,7 @@ static void run_sweep_cell(mfm_ctx *c, int f_begin, int f_end, const double *zba
         run_plan<PBlockV>(s, tm, B->plan_V, a, c->ls, kc, false);  // :419-470
         cell_block_delta(s, tm, cp, k, B->rec.p, B->q_saved.p);
       }
+      cp.touch(k);  // (field k's table changed: the tables of its stream are rebuilt by the next cell_prep)
     }
     pending = m - 1;
   }
