@@ -129,8 +129,8 @@ constexpr int OPROBIT_BLOCKS = 512;
 // Accumulation: every thread owns a private set of n_class x 6 accumulators in LDS, laid out [accumulator][thread]
 // (conflict-free, no atomics: the sums do not depend on the execution order); at the end accumulator i is summed
 // over the threads in thread order by thread i. blockDim.x = 256 / 128 / 64 for n_class <= 5 / 10 / 32 (dynamic
-// LDS n_class * 6 * blockDim.x doubles). The kernel is bound by the fp64 erf / erfcx / exp / log chains (~550
-// instructions per row), not by the accumulation (a wave-level reduction per label measured 2x slower).
+// LDS n_class * 6 * blockDim.x doubles). The kernel is bound by the fp64 erfcx / exp / log chains, not by the
+// accumulation (a wave-level reduction per label measured 2x slower).
 // More than OPROBIT_LDS_CLASS classes (OProbitSampler.hpp:36-46 has no bound): the same private accumulators, in global
 // memory (gacc: [blocks][n_class * 6][blockDim.x], zeroed by the kernel itself).
 __global__ __launch_bounds__(WG) void k_oprobit_eval(const double2 *__restrict__ eq, const double *__restrict__ y,
@@ -150,73 +150,39 @@ __global__ __launch_bounds__(WG) void k_oprobit_eval(const double2 *__restrict__
     const int64_t t = rows ? rows[p] : p;
     const int label = (int)y[t];
     const double sc = eq[t].x;
-    double ll = 0, d_hi = 0, d_lo = 0, h_hi = 0, h_lo = 0, h_off = 0;
-    if (label == 0) {  // safe_lcdf(gamma0 - score), :183-208
-      const double x = gam[0] - sc;
-      if (x > 1) {
-        const double ef = exp(-x * x / 2), den = 1 + erf(x / SQRT2), id = 1.0 / den;
-        d_hi += C2 * ef * id;
-        ll += log(den / 2);
-        if (want_h) h_hi += -(SQRT2PI * x * den * ef + 2 * ef * ef) * (INV_PI * id * id);
-      } else {
-        const double den = d_erfcx(-x / SQRT2), id = 1.0 / den;
-        d_hi += C2 * id;
-        ll -= x * x / 2;
-        ll += log(den / 2);
-        if (want_h) h_hi += -(SQRT2PI * x * den + 2) * (INV_PI * id * id);
-      }
-    } else if (label == n_class - 1) {  // safe_lccdf(gamma_{K-2} - score), :210-236
-      const double x = gam[n_class - 2] - sc;
-      if (x > -1) {
-        const double den = d_erfcx(x / SQRT2), id = 1.0 / den;
-        d_lo -= C2 * id;
-        ll += log(den / 2);
-        ll -= x * x / 2;
-        if (want_h) h_lo += (SQRT2PI * x * den - 2) * (INV_PI * id * id);
-      } else {
-        const double den = 1 - erf(x / SQRT2), id = 1.0 / den, ef = exp(-(x * x) / 2);
-        d_lo -= C2 * ef * id;
-        ll += log(den / 2);
-        if (want_h) h_lo += -(-SQRT2PI * x * den * ef + 2 * ef * ef) * (INV_PI * id * id);
-      }
-    } else {  // safe_ldiff(x = gamma_l - score, yv = gamma_{l-1} - score), :111-181
-      const double x = gam[label] - sc, yv = gam[label - 1] - sc;
-      if (yv > 0) {
-        const double ef = exp((yv * yv - x * x) / 2);
-        const double den = d_erfcx(yv / SQRT2) - ef * d_erfcx(x / SQRT2), id = 1.0 / den, w = INV_PI * id * id;
-        ll -= yv * yv / 2;
-        ll += log(den / 2);
-        d_hi += C2 * ef * id;
-        d_lo -= C2 * id;
-        if (want_h) {
-          h_hi += -(SQRT2PI * x * den * ef + 2 * (ef * ef)) * w;  // (exp(y^2 - x^2) = ef^2)
-          h_lo += (SQRT2PI * yv * den - 2) * w;
-          h_off += 2 * ef * w;
-        }
-      } else if (x < 0) {
-        ll -= x * x / 2;
-        const double ef = exp((x * x - yv * yv) / 2);
-        const double den = d_erfcx(-x / SQRT2) - ef * d_erfcx(-yv / SQRT2), id = 1.0 / den, w = INV_PI * id * id;
-        ll += log(den / 2);
-        d_hi += C2 * id;
-        d_lo -= C2 * ef * id;
-        if (want_h) {
-          h_hi += -(SQRT2PI * x * den + 2) * w;
-          h_lo += (SQRT2PI * yv * ef * den - 2 * (ef * ef)) * w;
-          h_off += 2 * ef * w;
-        }
-      } else {
-        const double den = erf(x / SQRT2) - erf(yv / SQRT2), id = 1.0 / den, w = INV_PI * id * id;
-        const double exx = exp(-x * x / 2), eyy = exp(-yv * yv / 2);
-        d_hi += C2 * exx * id;
-        d_lo -= C2 * eyy * id;
-        ll += log(den / 2);
-        if (want_h) {
-          h_hi += -(SQRT2PI * x * den * exx + 2 * exx * exx) * w;
-          h_lo += -(-SQRT2PI * yv * den * eyy + 2 * eyy * eyy) * w;
-          h_off += 2 * exx * eyy * w;
-        }
-      }
+    // One evaluation for every row of the wavefront instead of seven divergent branches (each with its own erf / erfcx / exp /
+    // log chains: a wavefront of mixed labels used to execute nearly all of them). With x = gamma_l - score (upper bound; none
+    // for the last label) and yv = gamma_{l-1} - score (lower bound; none for label 0), E(t) = erfcx(|t| / sqrt 2) and
+    // g(t) = exp(-t^2 / 2) (1 - erf(|t| / sqrt 2) = g E), the three regimes of safe_ldiff (:111-181) -- and safe_lcdf /
+    // safe_lccdf (:183-236) as its limits yv = -inf / x = +inf -- are
+    //   A (yv > 0):       2 (Phi(x) - Phi(yv)) = g(yv) [E(yv) - ef E(x)],  ef = exp((yv^2 - x^2) / 2)     weights (ef, 1)
+    //   B (x < 0):                            = g(x)  [E(x) - ef E(yv)],  ef = exp((x^2 - yv^2) / 2)     weights (1, ef)
+    //   C (yv <= 0 <= x):                     = 2 - g(x) E(x) - g(yv) E(yv)                               weights (g(x), g(yv))
+    // with the common tail  ll = L + log(den / 2),  d_hi = C2 f_hi / den,  d_lo = -C2 f_lo / den  and the Hessian terms below
+    // ((f_hi, f_lo) = the weights, L = -yv^2/2, -x^2/2, 0). A and B are the reference's own expressions; C and the one-sided
+    // labels replace erf(t / sqrt 2) by 1 - g E (absolute error ~1e-16 in den). Heavy calls per row: 2 erfcx, 2 exp, 1 log.
+    const bool has_hi = label < n_class - 1, has_lo = label > 0;
+    const double x = has_hi ? gam[label] - sc : 0.0, yv = has_lo ? gam[label - 1] - sc : 0.0;
+    const bool cA = has_lo && yv > 0, cB = !cA && has_hi && x < 0, cC = !cA && !cB;
+    double Ex = d_erfcx_pos(has_hi ? fabs(x) / SQRT2 : 1.0), Ey = d_erfcx_pos(has_lo ? fabs(yv) / SQRT2 : 1.0);
+    Ex = has_hi ? Ex : 0.0;
+    Ey = has_lo ? Ey : 0.0;
+    const double hx = x * x / 2, hy = yv * yv / 2;
+    const double a1 = cA ? hy - hx : (cB ? 0.0 : -hx), a2 = cA ? 0.0 : (cB ? hx - hy : -hy);
+    double f_hi = exp(has_hi ? a1 : 0.0), f_lo = exp(has_lo ? a2 : 0.0);
+    f_hi = has_hi ? f_hi : 0.0;
+    f_lo = has_lo ? f_lo : 0.0;
+    const double pa = f_hi * Ex, pb = f_lo * Ey;
+    const double den = cC ? 2.0 - (pa + pb) : (cA ? pb - pa : pa - pb);
+    const double id = 1.0 / den, w = INV_PI * id * id;
+    double ll = cA ? -hy : (cB ? -hx : 0.0);
+    ll += log(den / 2);
+    const double d_hi = C2 * f_hi * id, d_lo = -(C2 * f_lo * id);
+    double h_hi = 0, h_lo = 0, h_off = 0;
+    if (want_h) {
+      h_hi = -(SQRT2PI * x * den * f_hi + 2 * (f_hi * f_hi)) * w;
+      h_lo = (SQRT2PI * yv * den * f_lo - 2 * (f_lo * f_lo)) * w;
+      h_off = 2 * f_hi * f_lo * w;
     }
     double *a = acc + (size_t)label * OPROBIT_SLOTS * NT + tid;
     a[0 * NT] += ll;
