@@ -460,3 +460,52 @@ def test_cell_path_row_sharded(oracle, monkeypatch, world, shape):
         np.testing.assert_allclose(ge, e[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
         assert abs(galpha - t.hyper()["alpha"]) < 1e-7 * galpha
         assert np.array_equal(gV, out[0][2]) and np.array_equal(gw, out[0][1])  # replicas bit-identical
+
+
+def test_cell_path_empty_shard(oracle, monkeypatch):
+    # a rank without rows on the cell path: it plans nothing, launches nothing, and still takes part in every agreement of the
+    # planner and in every all-reduce of the sweeps (its dense arrays are zero)
+    from myfm_amd import _capi, _myfm
+
+    from .test_gpu_cell import SHAPES
+
+    monkeypatch.setenv("MFM_CELL_MIN_ROWS", "0")
+    monkeypatch.setenv("MFM_CELL_GROUPS", "5")
+    main, blocks, y, shapes = ds.tuple_design(**SHAPES["u_i_ctx"])
+    n = main.shape[0]
+    gi = ds.group_index_from_shapes(shapes)
+    K, world = 2, 3
+    cuts = [0, 0, 27000, n]  # rank 0 holds no rows
+    ls = Lockstep(world)
+    levels = _capi.column_levels(main)[0]
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            lo, hi = cuts[rank], cuts[rank + 1]
+            rbs = [_myfm.RelationBlock(np.asarray(m, dtype=np.int64)[lo:hi], b) for m, b in blocks]
+            s = _myfm.GibbsSession(K, 0.1, main[lo:hi], rbs, y[lo:hi], 42, _config(gi), allreduce=ls.callback(rank), n_total_rows=n,
+                                   row_offset=lo, main_levels=levels, shard_rank=rank, shard_world=world)
+            assert s.plan_flags() & 512, "the cell path was not taken"
+            for it in range(3):
+                s.step()
+            out[rank] = (np.asarray(s.fm.w), np.asarray(s.fm.V), s.residual(), lo)
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            ls.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=300)
+    assert not errs, errs
+    t = oracle.OracleTrainer(main, y, blocks, rank=K, group_index=gi)
+    for it in range(3):
+        t.step()
+    _, w, V = t.fm()
+    for rank in range(world):
+        gw, gV, ge, lo = out[rank]
+        np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(ge, t.e(n)[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
