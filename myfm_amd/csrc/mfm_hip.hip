@@ -1297,8 +1297,21 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     int n_cu = 0;
     MFM_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
     const int n_cu_dev = n_cu;
-    if (const char *e = std::getenv("MFM_RES_CUS")) n_cu = std::max(1, std::min(n_cu, std::atoi(e)));
-    c->res.build(Xt_keep, c->plan_V.h_level, &c->hgroup, n_cu);
+    if (const char *e = std::getenv("MFM_RES_CUS")) {
+      n_cu = std::max(1, std::min(n_cu, std::atoi(e)));
+      c->res.build(Xt_keep, c->plan_V.h_level, &c->hgroup, n_cu);
+    } else {
+      // one CU per XCD stays free when the rows still fit the others (config 3: 40 323 of 40 959 slots per workgroup): the small
+      // kernels between two launches, the side stream's single-workgroup draws and the slot-order scorer's last workgroup no
+      // longer queue behind each other -- 308 -> 314-317 it/s at config 3 (MI355X, profiles/r04_q_res_cus.txt)
+      bool done = false;
+      if (n_cu >= 64 && c->N / (n_cu - 8) < 40500) {
+        c->res.build(Xt_keep, c->plan_V.h_level, &c->hgroup, n_cu - 8);
+        done = c->res.ready;
+        if (done) n_cu -= 8;
+      }
+      if (!done) c->res.build(Xt_keep, c->plan_V.h_level, &c->hgroup, n_cu);
+    }
     if (c->res.ready) {
       // all G workgroups must be resident at once: one per CU must fit (registers + LDS), and the CUs must be ours
       int per_cu = 0;
@@ -1973,7 +1986,8 @@ int mfm_rng_prefetch(mfm_ctx *ctx) {
   hipStream_t s = r.stream;
   // (the gate only where the persistent sweep fills the device: a small table's launch leaves most CUs free, and there the
   //  generator should run beside it -- ML-100k shape: 2700 it/s gated, 3000 not)
-  if (ctx->res.ready && ctx->res_fills_device) {
+  static const bool no_gate = std::getenv("MFM_RES_NO_GATE") != nullptr;  // (experiments with CUs left free by MFM_RES_CUS)
+  if (ctx->res.ready && ctx->res_fills_device && !no_gate) {
     if (!r.gate) MFM_HIP_CHECK(hipEventCreateWithFlags(&r.gate, hipEventDisableTiming));
     MFM_HIP_CHECK(hipEventRecord(r.gate, ctx->stream));
     MFM_HIP_CHECK(hipStreamWaitEvent(s, r.gate, 0));
