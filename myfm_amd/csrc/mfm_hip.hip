@@ -1001,7 +1001,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     const double need = normals * (16.0 / 3.14159265358979) * 1.02 + 6.0 * 2.4 * std::sqrt(normals + 1.0) + 4096.0 * (2 + 2.0 * c->G * (c->K + 1)) + 2e6;
     const int64_t blocks = (int64_t)(need / MT_N) + 2;
     if (blocks > MT_PAR_BLOCKS) {
-      const int64_t gblocks = blocks * mt_gen_batch();  // (the generator is asked for several iterations at a time)
+      const int64_t gblocks = blocks * mt_gen_batch(need);  // (the generator is asked for several iterations at a time)
       c->rng.par_blocks = mt_par_blocks_for(gblocks);
       mtjump::JumpCache::inst().prefetch(c->rng.par_blocks, (int)((gblocks + c->rng.par_blocks - 1) / c->rng.par_blocks) + 1);
     }
@@ -1934,7 +1934,7 @@ int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops) {
   {
     const int64_t blocks1 = (int64_t)(r.need / MT_N) + 2;
     if (blocks1 > MT_PAR_BLOCKS && !std::getenv("MFM_RNG_SERIAL")) {
-      r.need_gen = r.need * (uint64_t)mt_gen_batch();
+      r.need_gen = r.need * (uint64_t)mt_gen_batch((double)r.need);
       const int64_t blocks = (int64_t)(r.need_gen / MT_N) + 2;
       if (r.par_blocks <= 0) r.par_blocks = mt_par_blocks_for(blocks);
       const int wgs = (int)((blocks + r.par_blocks - 1) / r.par_blocks);

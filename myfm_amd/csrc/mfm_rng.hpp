@@ -148,10 +148,12 @@ constexpr int MT_PAR_BLOCKS = 512;  // blocks per workgroup at most (and the req
 // blocks per workgroup for a request of `blocks`: about 170 workgroups (each takes a CU: 87 KB of LDS for its jump), between
 // 64 and 512 blocks, multiples of 16. A workgroup's jump costs ~0.45 ms whatever it generates afterwards (0.4 us per
 // block), so the generator is asked for several iterations' worth at a time (MT_GEN_BATCH): one jump per four iterations.
-constexpr int MT_GEN_BATCH = 4;
-static inline int mt_gen_batch() {
+// Round 4: six where an iteration needs at most 2^25 outputs (config 3: 13.5 M; 316 -> 323 it/s, 8: 321, 16: 314,
+// profiles/r04_q_res_cus.txt); larger problems keep four (the ring holds the batch: 4 GB of raw words at config 5).
+constexpr int MT_GEN_BATCH = 4, MT_GEN_BATCH_SMALL = 6;
+static inline int mt_gen_batch(double outputs_per_iteration) {
   if (const char *e = std::getenv("MFM_RNG_GEN_BATCH")) return std::max(1, std::min(16, std::atoi(e)));
-  return MT_GEN_BATCH;
+  return outputs_per_iteration <= 33554432.0 ? MT_GEN_BATCH_SMALL : MT_GEN_BATCH;
 }
 static inline int mt_par_blocks_for(int64_t blocks) {
   if (const char *e = std::getenv("MFM_RNG_PAR_BLOCKS")) return std::max(32, std::min(MT_PAR_BLOCKS, std::atoi(e)));
