@@ -16,7 +16,7 @@ PYMOD = os.path.join(HERE, "_myfm" + EXT_SUFFIX)
 # translation units of libmyfm_hip.so and the headers each of them includes (a unit is recompiled when one of them is newer than
 # its object file; the objects live in csrc/_obj/, git-ignored)
 HIP_UNITS = {
-    "mfm_hip.hip": ["mfm_common.hpp", "mfm_wave.hpp", "mfm_kernels.hpp", "mfm_mf_kernels.hpp", "mfm_res.hpp", "mfm_plan.hpp",
+    "mfm_hip.hip": ["mfm_common.hpp", "mfm_wave.hpp", "mfm_kernels.hpp", "mfm_mf_kernels.hpp", "mfm_res.hpp", "mfm_res_plan.hpp", "mfm_plan.hpp",
                     "mfm_block_kernels.hpp", "mfm_tasks.hpp", "mfm_predict.hpp", "mfm_rng.hpp", "mfm_mtjump.hpp", "mfm_cell.hpp"],
     "mfm_cell.hip": ["mfm_common.hpp", "mfm_wave.hpp", "mfm_cell.hpp"],
 }

@@ -23,6 +23,7 @@
 #include "mfm_common.hpp"
 #include "mfm_kernels.hpp"
 #include "mfm_plan.hpp"
+#include "mfm_res_plan.hpp"
 #include "mfm_block_kernels.hpp"
 #include "mfm_cell.hpp"
 #include "mfm_mtjump.hpp"
@@ -156,6 +157,12 @@ struct mfm_ctx {
   bool qfree = false, soa = false, fuse_next = false;
   bool mf = false;              // two-field pass (run_sweep_mf): no q-cache in HBM during update_V
   ResPlan res;                  // ... as one persistent launch with the residual resident on chip (mfm_res.hpp)
+  // the persistent sweep's layout was built first, on the device, and took the table: X_t, the level plans and the row tiles of
+  // the per-factor passes (their fall-back) are built when a call needs them (ensure_main_plans)
+  bool main_lazy = false;
+  bool res_refused = false;  // the CUs of the persistent sweep were not ours to take
+  int res_plan_cus = 0;      // workgroups the layout was asked for
+  void ensure_main_plans();
   bool e_in_cell = false;       // the residual lives in cell.e (cell order): every reader of eq calls materialize_e first
   bool cell_w = false;          // ... and update_w runs on the cell layout too (the generic plans of the main table were not built)
   CellPlan cell;                // update_V of a design of index tuples (one-hot fields + relation blocks): no q-cache (mfm_cell.hpp)
@@ -583,6 +590,21 @@ static void score_train(mfm_ctx *c, bool subtract_y) {
   c->e_in_slots = false;  // (every residual is overwritten)
   c->e_in_cell = false;
   c->slot_sums_valid = false;
+  if (c->main_lazy) {
+    static const bool no_res_score0 = std::getenv("MFM_NO_RES_SCORE") != nullptr || std::getenv("MFM_NO_MF_SCORE") != nullptr;
+    if (subtract_y && c->res.ready && !no_res_score0 && res_score_supported(c->res, c->K)) {
+      hipStream_t s = c->stream;
+      {
+        TimedLaunch t(c->timing, s, KC_BUILD_VT, 16.0 * c->D * c->K);
+        build_vt(s, c->V.p, c->Vt.p, c->D, c->K, c->KS);
+      }
+      run_res_score(s, c->timing, c->res, KC_UPDATE_E, c->Vt.p, c->w.p, c->w0, c->K, c->y.p, c->X.nnz);
+      c->e_in_slots = true;
+      c->slot_sums_valid = true;
+      return;
+    }
+    c->ensure_main_plans();
+  }
   if (c->mf && !std::getenv("MFM_NO_MF_SCORE")) {
     // two-field table: scorer on the row tiles of the latent sweep (item rows gathered once per run, not once per row)
     hipStream_t s = c->stream;
@@ -978,106 +1000,78 @@ int mfm_set_groups(mfm_ctx *ctx, const int32_t *group_index, int64_t D, int32_t 
   MFM_CATCH(ctx)
 }
 
-int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
-  MFM_TRY(ctx)
-  if (ctx->finalized) throw Error(MFM_ERR_RUNTIME, "design already finalized");
-  if (rank < 0) throw Error(MFM_ERR_INVALID, "rank must be non-negative");
-  mfm_ctx *c = ctx;
-  c->N = c->hX.rows;
-  c->D0 = c->hX.cols;
-  c->D = c->D0;
-  for (auto &hb : c->hblocks) c->D += hb.X.cols;
-  if (c->G == 0) throw Error(MFM_ERR_RUNTIME, "mfm_set_groups has not been called");
-  if ((int64_t)c->hgroup.size() != c->D)
-    throw Error(MFM_ERR_INVALID, "group_index has " + std::to_string(c->hgroup.size()) + " entries but the design has " +
-                                     std::to_string(c->D) + " features");
-  if (c->N >= (int64_t)2147483647) throw Error(MFM_ERR_INVALID, "N must be < 2^31 per GPU");
-  c->K = rank;
-  c->KS = (rank + 1) & ~1;
-  // the parallel generator's jump polynomials (mfm_rng_set_program needs them right after this call): start computing
-  // them now on a helper thread, sized for one iteration's draws of this problem (an upper estimate of the workgroups)
-  if (!std::getenv("MFM_RNG_SERIAL")) {
-    const double normals = (double)c->D * (c->K + 1) + 4.0 * c->G * (c->K + 1) + 16;
-    const double need = normals * (16.0 / 3.14159265358979) * 1.02 + 6.0 * 2.4 * std::sqrt(normals + 1.0) + 4096.0 * (2 + 2.0 * c->G * (c->K + 1)) + 2e6;
-    const int64_t blocks = (int64_t)(need / MT_N) + 2;
-    if (blocks > MT_PAR_BLOCKS) {
-      const int64_t gblocks = blocks * mt_gen_batch(need);  // (the generator is asked for several iterations at a time)
-      c->rng.par_blocks = mt_par_blocks_for(gblocks);
-      mtjump::JumpCache::inst().prefetch(c->rng.par_blocks, (int)((gblocks + c->rng.par_blocks - 1) / c->rng.par_blocks) + 1);
+static int64_t res_min_rows(const mfm_ctx *) {
+  return std::getenv("MFM_RES_MIN_ROWS") ? std::atoll(std::getenv("MFM_RES_MIN_ROWS")) : ((int64_t)1 << 20);
+}
+
+// The persistent sweep's layout (build(plan, workgroups): the device builder of mfm_res_plan.hpp or the host builder) and the
+// claim on its CUs.
+static void plan_resident(mfm_ctx *c, const std::function<void(ResPlan &, int)> &build, bool tlog) {
+  int n_cu = 0;
+  MFM_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
+  const int n_cu_dev = n_cu;
+  if (const char *e = std::getenv("MFM_RES_CUS")) {
+    n_cu = std::max(1, std::min(n_cu, std::atoi(e)));
+    build(c->res, n_cu);
+  } else {
+    // one CU per XCD stays free when the rows still fit the others (config 3: 40 323 of 40 959 slots per workgroup): the small
+    // kernels between two launches, the side stream's single-workgroup draws and the slot-order scorer's last workgroup no
+    // longer queue behind each other -- 308 -> 314-317 it/s at config 3 (MI355X, profiles/r04_q_res_cus.txt)
+    bool done = false;
+    if (n_cu >= 64 && c->N / (n_cu - 8) < 40500) {
+      build(c->res, n_cu - 8);
+      done = c->res.ready;
+      if (done) n_cu -= 8;
+    }
+    if (!done) build(c->res, n_cu);
+  }
+  c->res_plan_cus = n_cu;
+  if (c->res.ready) {
+    // all G workgroups must be resident at once: one per CU must fit (registers + LDS), and the CUs must be ours
+    int per_cu = 0;
+    const hipError_t oe = res_occupancy(c->res, &per_cu);
+    std::string why;
+    if (oe != hipSuccess || per_cu < 1) {
+      c->res.fail("the persistent kernel does not fit a CU (occupancy query)");
+    } else if (!ResidentBudget::get().acquire(c->device, n_cu_dev, c->res.G, why)) {
+      c->res.fail(why.c_str());
+      c->res_refused = true;
+    } else {
+      c->res_claim = c->res.G;
     }
   }
+  c->res_fills_device = c->res.ready && c->res.G > n_cu - n_cu / 4;
+  if (tlog)
+    std::fprintf(stderr, "[mfm_finalize] resident plan: %s (G=%d RV=%d RL=%d umax=%d runs=%lld lds=%zu)\n",
+                 c->res.ready ? "ready" : c->res.why.c_str(), c->res.G, c->res.RV, c->res.RL, c->res.umax, (long long)c->res.n_runs,
+                 c->res.lds_bytes);
+}
+
+// Before anything else is planned: does the table take the persistent sweep? (the layout from the device CSR, mfm_res_plan.hpp)
+static void try_resident_first(mfm_ctx *c, const std::function<void(const char *)> &lap) {
+  static const char *const off[] = {"MFM_NO_RESIDENT", "MFM_RES_HOST_PLAN", "MFM_RES_PROF", "MFM_HOST_TRANSPOSE", "MFM_NO_SOA",
+                                    "MFM_NO_FUSED_QBUILD", "MFM_NO_FUSED_NEXT", "MFM_NO_MF", "MFM_NO_FUSED_TWO", "MFM_NO_FUSED_STATS",
+                                    "MFM_HOST_LEVELS", "MFM_NO_SCATTER", "MFM_TILE_BITS"};
+  for (const char *e : off)
+    if (std::getenv(e)) return;
+  if (std::getenv("MFM_QFREE") && std::atoi(std::getenv("MFM_QFREE"))) return;
+  if (c->comm.active() || !c->hblocks.empty() || !c->hlevels.empty() || !c->X.unit || c->X.ell_width != 2 || c->K < 1 ||
+      c->N < res_min_rows(c))
+    return;
   const bool tlog = std::getenv("MFM_SETUP_TIMING") != nullptr;
-  auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double t_prev = tnow();
-  auto lap = [&](const char *what) {
-    if (!tlog) return;
-    const double t = tnow();
-    std::fprintf(stderr, "[mfm_finalize] %-28s %7.3f s\n", what, t - t_prev);
-    t_prev = t;
-  };
-  // main table
-  HostCsr Xt_keep;  // (X_t outlives the planner's scope: the resident layout is built from it once the path is known)
-  {
-    HostCsr &Xt = Xt_keep;
-    if (std::getenv("MFM_HOST_TRANSPOSE")) {
-      Xt = transpose_host(c->hX);
-      lap("transpose (host)");
-      c->X.upload(c->hX, &Xt);
-      lap("upload CSR + CSC");
-    } else {
-      c->X.upload(c->hX, nullptr);
-      lap("upload CSR");
-    }
-    // a row of unit-valued one-hot fields + relation blocks on one GPU: update_w / update_V / update_e on index tuples, no
-    // q-cache (mfm_cell.hpp). Decided first: when it takes the design, X_t, the main table's level plans and row tiles and
-    // the blocks' inverse maps are never used and are not built (config 5: 1.3 s of mfm_finalize and 3 GB of HBM).
-    {
-      const int64_t cell_min_rows = std::getenv("MFM_CELL_MIN_ROWS") ? std::atoll(std::getenv("MFM_CELL_MIN_ROWS")) : ((int64_t)1 << 20);
-      // row-sharded: every rank plans its own rows; what must be the same everywhere (fields, streams, the verdict) is summed
-      // over the ranks inside the planner
-      const bool sh = c->comm.active();
-      auto sum_ranks = [&](std::vector<double> &v) {
-        DevBuf<double> d;
-        d.upload(v);
-        c->comm.allreduce(d.p, (int64_t)v.size());
-        MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
-        MFM_HIP_CHECK(hipMemcpy(v.data(), d.p, v.size() * sizeof(double), hipMemcpyDeviceToHost));
-      };
-      // (also tables of three or more one-hot fields WITHOUT relation blocks on one GPU: one pass per field instead of the
-      //  row-tile passes of run_sweep_soa_multi; two-field tables keep the persistent sweep / the two-field pass)
-      const bool flat = c->hblocks.empty() && !sh && c->X.ell_width >= 3 && !std::getenv("MFM_NO_CELL_FLAT");
-      bool try_cell = (!c->hblocks.empty() || flat) && c->K > 0 && !std::getenv("MFM_NO_CELL") && (!sh || !std::getenv("MFM_NO_CELL_SHARDED"));
-      if (!sh) {
-        try_cell = try_cell && c->X.unit && c->X.ell_width >= 1 && c->N >= cell_min_rows;
-      } else if (try_cell) {  // (the same decision on every rank: the rows of all of them count, an empty shard has no say)
-        std::vector<double> v{(double)c->N, (c->N > 0 && !(c->X.unit && c->X.ell_width >= 1)) ? 1.0 : 0.0, c->comm.shard_set ? 0.0 : 1.0};
-        sum_ranks(v);
-        try_cell = v[0] >= (double)cell_min_rows && v[1] == 0.0 && v[2] == 0.0;
-      }
-      if (try_cell) {
-        int n_cu = 0;
-        MFM_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
-        if (const char *e = std::getenv("MFM_CELL_GROUPS")) n_cu = std::max(1, std::atoi(e));
-        std::vector<CellBlockIn> bin;
-        for (auto &hb : c->hblocks) bin.push_back(CellBlockIn{hb.map.data(), hb.X.rows});
-        if (sh)
-          cell_plan_build(c->cell, c->hX, bin, n_cu, c->stream, c->comm.shard_set ? c->comm.rank : -1, c->comm.world, sum_ranks);
-        else
-          cell_plan_build(c->cell, c->hX, bin, n_cu, c->stream);
-        c->cell_w = c->cell.ready && !std::getenv("MFM_NO_CELL_W");
-        if (tlog)
-          std::fprintf(stderr, "[mfm_finalize] cell plan: %s (G=%d umax=%lld streams=%zu fields=%zu item32=%d)\n",
-                       c->cell.ready ? "ready" : c->cell.why.c_str(), c->cell.G, (long long)c->cell.umax, c->cell.streams.size(),
-                       c->cell.fields.size(), (int)c->cell.item32);
-        lap("cell plan");
-      }
-    }
-    const bool lean = c->cell_w;
-    if (!lean && !std::getenv("MFM_HOST_TRANSPOSE")) {
+  plan_resident(c, [&](ResPlan &rp, int n_cu) { res_plan_build_device(rp, c->X, &c->hgroup, n_cu, c->stream); }, tlog);
+  lap("resident plan (device)");
+  // (tests: with MFM_PLAN_CHECK everything else is built too and the host builder's layout compared)
+  c->main_lazy = c->res.ready && !std::getenv("MFM_PLAN_CHECK") && !std::getenv("MFM_EAGER_PLANS");
+}
+
+// The main table's generic structures: X_t (device transpose, copied back for the planner), the level plans of both sweeps, the
+// row tiles. Xt: filled here unless the caller already has it (MFM_HOST_TRANSPOSE).
+static void plan_main_table(mfm_ctx *c, HostCsr &Xt, const std::function<void(const char *)> &lap) {
+    if (!std::getenv("MFM_HOST_TRANSPOSE") || (int64_t)Xt.ptr.size() != c->D0 + 1) {
       Xt = transpose_device(c->X, c->stream);
       lap("transpose (device) + copy back");
     }
-    if (!lean) {
     c->plan_V.sharded = c->plan_W.sharded = c->comm.active();
     c->plan_V.given_levels = c->plan_W.given_levels = c->hlevels;
     // scattered levels: LDS row tiles of 2^tile_bits {e, q} records (64 KiB by default: two workgroups per CU)
@@ -1183,7 +1177,154 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
       c->ls.reserve_cols(c->D0);
       c->ls.reserve_stats(c->D0);
     }
-    }  // (!lean)
+}
+
+// which of the main table's sweep forms the plans support (flags of mfm_plan_flags) and their buffers
+static void decide_main_paths(mfm_ctx *c) {
+  // q-free latent sweep (PMainVe), opt-in (MFM_QFREE=1): pays off when the levels' rows are contiguous; needs
+  // short rows, no relation blocks, no sharding, single-pass PAR levels, no row-tile levels
+  c->qfree = !c->comm.active() && c->blocks.empty() && c->X.rows > 0 && c->X.avg_row_nnz <= 4.0 &&
+             plan_is_single_pass_par(c->plan_V) && std::getenv("MFM_QFREE") && std::atoi(std::getenv("MFM_QFREE"));
+  if (c->qfree) c->ec.alloc((size_t)c->N);
+  // split e / q layout for update_V (run_plan_soa)
+  c->soa = !c->qfree && !c->comm.active() && c->blocks.empty() && c->N > 0 && plan_supports_soa(c->plan_V) &&
+           !std::getenv("MFM_NO_SOA") && !std::getenv("MFM_NO_FUSED_QBUILD");
+  if (c->sharded_fused) {
+    c->ec.alloc((size_t)c->N);
+    c->qc.alloc((size_t)c->N);
+    // no first-level column straddles a rank boundary (and none is longer than ... any length is fine): the two-field pass
+    c->mf = plan_supports_mf(c->plan_V) && c->plan_V.n_special == 0 && !std::getenv("MFM_NO_MF") &&
+            !std::getenv("MFM_NO_FUSED_TWO") && !std::getenv("MFM_NO_FUSED_STATS");
+    {  // every rank must take the same path
+      double no = c->mf ? 0.0 : 1.0;
+      DevBuf<double> d;
+      d.upload(&no, 1);
+      c->comm.allreduce(d.p, 1);
+      MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
+      MFM_HIP_CHECK(hipMemcpy(&no, d.p, sizeof(double), hipMemcpyDeviceToHost));
+      c->mf = no == 0.0;
+    }
+  }
+  if (c->soa) {
+    c->ec.alloc((size_t)c->N);
+    c->qc.alloc((size_t)c->N);
+    c->fuse_next = plan_supports_fused_next(c->plan_V) && !std::getenv("MFM_NO_FUSED_NEXT");
+    c->mf = c->fuse_next && plan_supports_mf(c->plan_V) && !std::getenv("MFM_NO_MF") && !std::getenv("MFM_NO_FUSED_TWO") &&
+            !std::getenv("MFM_NO_FUSED_STATS");
+  }
+}
+
+void mfm_ctx::ensure_main_plans() {
+  if (!main_lazy) return;
+  main_lazy = false;
+  use_device();
+  HostCsr Xt;
+  plan_main_table(this, Xt, [](const char *) {});
+  ls.reserve(std::max({plan_V.max_hchunks, plan_W.max_hchunks, 1}), std::max({plan_V.max_huge, plan_W.max_huge, 1}));
+  decide_main_paths(this);
+}
+
+int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
+  MFM_TRY(ctx)
+  if (ctx->finalized) throw Error(MFM_ERR_RUNTIME, "design already finalized");
+  if (rank < 0) throw Error(MFM_ERR_INVALID, "rank must be non-negative");
+  mfm_ctx *c = ctx;
+  c->N = c->hX.rows;
+  c->D0 = c->hX.cols;
+  c->D = c->D0;
+  for (auto &hb : c->hblocks) c->D += hb.X.cols;
+  if (c->G == 0) throw Error(MFM_ERR_RUNTIME, "mfm_set_groups has not been called");
+  if ((int64_t)c->hgroup.size() != c->D)
+    throw Error(MFM_ERR_INVALID, "group_index has " + std::to_string(c->hgroup.size()) + " entries but the design has " +
+                                     std::to_string(c->D) + " features");
+  if (c->N >= (int64_t)2147483647) throw Error(MFM_ERR_INVALID, "N must be < 2^31 per GPU");
+  c->K = rank;
+  c->KS = (rank + 1) & ~1;
+  // the parallel generator's jump polynomials (mfm_rng_set_program needs them right after this call): start computing
+  // them now on a helper thread, sized for one iteration's draws of this problem (an upper estimate of the workgroups)
+  if (!std::getenv("MFM_RNG_SERIAL")) {
+    const double normals = (double)c->D * (c->K + 1) + 4.0 * c->G * (c->K + 1) + 16;
+    const double need = normals * (16.0 / 3.14159265358979) * 1.02 + 6.0 * 2.4 * std::sqrt(normals + 1.0) + 4096.0 * (2 + 2.0 * c->G * (c->K + 1)) + 2e6;
+    const int64_t blocks = (int64_t)(need / MT_N) + 2;
+    if (blocks > MT_PAR_BLOCKS) {
+      const int64_t gblocks = blocks * mt_gen_batch(need);  // (the generator is asked for several iterations at a time)
+      c->rng.par_blocks = mt_par_blocks_for(gblocks);
+      mtjump::JumpCache::inst().prefetch(c->rng.par_blocks, (int)((gblocks + c->rng.par_blocks - 1) / c->rng.par_blocks) + 1);
+    }
+  }
+  const bool tlog = std::getenv("MFM_SETUP_TIMING") != nullptr;
+  auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_prev = tnow();
+  auto lap = [&](const char *what) {
+    if (!tlog) return;
+    const double t = tnow();
+    std::fprintf(stderr, "[mfm_finalize] %-28s %7.3f s\n", what, t - t_prev);
+    t_prev = t;
+  };
+  // main table
+  HostCsr Xt_keep;  // (X_t outlives the planner's scope: the resident layout is built from it once the path is known)
+  {
+    HostCsr &Xt = Xt_keep;
+    if (std::getenv("MFM_HOST_TRANSPOSE")) {
+      Xt = transpose_host(c->hX);
+      lap("transpose (host)");
+      c->X.upload(c->hX, &Xt);
+      lap("upload CSR + CSC");
+    } else {
+      c->X.upload(c->hX, nullptr);
+      lap("upload CSR");
+    }
+    // a row of unit-valued one-hot fields + relation blocks on one GPU: update_w / update_V / update_e on index tuples, no
+    // q-cache (mfm_cell.hpp). Decided first: when it takes the design, X_t, the main table's level plans and row tiles and
+    // the blocks' inverse maps are never used and are not built (config 5: 1.3 s of mfm_finalize and 3 GB of HBM).
+    {
+      const int64_t cell_min_rows = std::getenv("MFM_CELL_MIN_ROWS") ? std::atoll(std::getenv("MFM_CELL_MIN_ROWS")) : ((int64_t)1 << 20);
+      // row-sharded: every rank plans its own rows; what must be the same everywhere (fields, streams, the verdict) is summed
+      // over the ranks inside the planner
+      const bool sh = c->comm.active();
+      auto sum_ranks = [&](std::vector<double> &v) {
+        DevBuf<double> d;
+        d.upload(v);
+        c->comm.allreduce(d.p, (int64_t)v.size());
+        MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
+        MFM_HIP_CHECK(hipMemcpy(v.data(), d.p, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+      };
+      // (also tables of three or more one-hot fields WITHOUT relation blocks on one GPU: one pass per field instead of the
+      //  row-tile passes of run_sweep_soa_multi; two-field tables keep the persistent sweep / the two-field pass)
+      const bool flat = c->hblocks.empty() && !sh && c->X.ell_width >= 3 && !std::getenv("MFM_NO_CELL_FLAT");
+      bool try_cell = (!c->hblocks.empty() || flat) && c->K > 0 && !std::getenv("MFM_NO_CELL") && (!sh || !std::getenv("MFM_NO_CELL_SHARDED"));
+      if (!sh) {
+        try_cell = try_cell && c->X.unit && c->X.ell_width >= 1 && c->N >= cell_min_rows;
+      } else if (try_cell) {  // (the same decision on every rank: the rows of all of them count, an empty shard has no say)
+        std::vector<double> v{(double)c->N, (c->N > 0 && !(c->X.unit && c->X.ell_width >= 1)) ? 1.0 : 0.0, c->comm.shard_set ? 0.0 : 1.0};
+        sum_ranks(v);
+        try_cell = v[0] >= (double)cell_min_rows && v[1] == 0.0 && v[2] == 0.0;
+      }
+      if (try_cell) {
+        int n_cu = 0;
+        MFM_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
+        if (const char *e = std::getenv("MFM_CELL_GROUPS")) n_cu = std::max(1, std::atoi(e));
+        std::vector<CellBlockIn> bin;
+        for (auto &hb : c->hblocks) bin.push_back(CellBlockIn{hb.map.data(), hb.X.rows});
+        if (sh)
+          cell_plan_build(c->cell, c->hX, bin, n_cu, c->stream, c->comm.shard_set ? c->comm.rank : -1, c->comm.world, sum_ranks);
+        else
+          cell_plan_build(c->cell, c->hX, bin, n_cu, c->stream);
+        c->cell_w = c->cell.ready && !std::getenv("MFM_NO_CELL_W");
+        if (tlog)
+          std::fprintf(stderr, "[mfm_finalize] cell plan: %s (G=%d umax=%lld streams=%zu fields=%zu item32=%d)\n",
+                       c->cell.ready ? "ready" : c->cell.why.c_str(), c->cell.G, (long long)c->cell.umax, c->cell.streams.size(),
+                       c->cell.fields.size(), (int)c->cell.item32);
+        lap("cell plan");
+      }
+    }
+    // two-field unit-valued table on one GPU: the persistent sweep's layout is built FIRST, on the device, straight from the
+    // CSR (mfm_res_plan.hpp). When it takes the table, X_t, the level plans and the row tiles of the per-factor passes (its
+    // fall-back, and what a stand-alone mfm_sweep_w runs) are built only if a call ever needs them (ensure_main_plans):
+    // config 3 0.26 s of mfm_finalize -> 0.1 s.
+    if (!c->cell.ready) try_resident_first(c, lap);
+    const bool lean = c->cell_w || c->main_lazy;
+    if (!lean) plan_main_table(c, Xt, lap);
   }
   c->y.upload(c->hy);
   c->eq.alloc_zero((size_t)c->N, c->stream);
@@ -1258,77 +1399,22 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   c->red_partial.alloc(REDUCE_BLOCKS);
   c->red_out.alloc((size_t)1 + (size_t)c->G * std::max(c->K, 1));
   c->scratch_n.alloc((size_t)std::max<int64_t>(c->N, 1));
-  // q-free latent sweep (PMainVe), opt-in (MFM_QFREE=1): pays off when the levels' rows are contiguous; needs
-  // short rows, no relation blocks, no sharding, single-pass PAR levels, no row-tile levels
-  c->qfree = !c->comm.active() && c->blocks.empty() && c->X.rows > 0 && c->X.avg_row_nnz <= 4.0 &&
-             plan_is_single_pass_par(c->plan_V) && std::getenv("MFM_QFREE") && std::atoi(std::getenv("MFM_QFREE"));
-  if (c->qfree) c->ec.alloc((size_t)c->N);
-  // split e / q layout for update_V (run_plan_soa)
-  c->soa = !c->qfree && !c->comm.active() && c->blocks.empty() && c->N > 0 && plan_supports_soa(c->plan_V) &&
-           !std::getenv("MFM_NO_SOA") && !std::getenv("MFM_NO_FUSED_QBUILD");
-  if (c->sharded_fused) {
-    c->ec.alloc((size_t)c->N);
-    c->qc.alloc((size_t)c->N);
-    // no first-level column straddles a rank boundary (and none is longer than ... any length is fine): the two-field pass
-    c->mf = plan_supports_mf(c->plan_V) && c->plan_V.n_special == 0 && !std::getenv("MFM_NO_MF") &&
-            !std::getenv("MFM_NO_FUSED_TWO") && !std::getenv("MFM_NO_FUSED_STATS");
-    {  // every rank must take the same path
-      double no = c->mf ? 0.0 : 1.0;
-      DevBuf<double> d;
-      d.upload(&no, 1);
-      c->comm.allreduce(d.p, 1);
-      MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
-      MFM_HIP_CHECK(hipMemcpy(&no, d.p, sizeof(double), hipMemcpyDeviceToHost));
-      c->mf = no == 0.0;
-    }
-  }
-  if (c->soa) {
-    c->ec.alloc((size_t)c->N);
-    c->qc.alloc((size_t)c->N);
-    c->fuse_next = plan_supports_fused_next(c->plan_V) && !std::getenv("MFM_NO_FUSED_NEXT");
-    c->mf = c->fuse_next && plan_supports_mf(c->plan_V) && !std::getenv("MFM_NO_MF") && !std::getenv("MFM_NO_FUSED_TWO") &&
-            !std::getenv("MFM_NO_FUSED_STATS");
-  }
+  decide_main_paths(c);
   // two-field unit-valued table on one GPU: the whole update_V as one persistent launch, residual resident on chip
   // (small tables stay with the per-factor passes: the launch's fixed costs -- two grid barriers per sweep, census, slot-ordered
   //  residual -- outweigh the bytes it saves; ML-100k shape: fit() 3060 it/s resident, 3950 per-factor. MFM_RES_MIN_ROWS)
-  const int64_t res_min_rows = std::getenv("MFM_RES_MIN_ROWS") ? std::atoll(std::getenv("MFM_RES_MIN_ROWS")) : ((int64_t)1 << 20);
-  if (c->soa && c->mf && c->X.unit && !c->comm.active() && c->N >= res_min_rows && !std::getenv("MFM_NO_RESIDENT")) {
-    int n_cu = 0;
-    MFM_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
-    const int n_cu_dev = n_cu;
-    if (const char *e = std::getenv("MFM_RES_CUS")) {
-      n_cu = std::max(1, std::min(n_cu, std::atoi(e)));
-      c->res.build(Xt_keep, c->plan_V.h_level, &c->hgroup, n_cu);
-    } else {
-      // one CU per XCD stays free when the rows still fit the others (config 3: 40 323 of 40 959 slots per workgroup): the small
-      // kernels between two launches, the side stream's single-workgroup draws and the slot-order scorer's last workgroup no
-      // longer queue behind each other -- 308 -> 314-317 it/s at config 3 (MI355X, profiles/r04_q_res_cus.txt)
-      bool done = false;
-      if (n_cu >= 64 && c->N / (n_cu - 8) < 40500) {
-        c->res.build(Xt_keep, c->plan_V.h_level, &c->hgroup, n_cu - 8);
-        done = c->res.ready;
-        if (done) n_cu -= 8;
-      }
-      if (!done) c->res.build(Xt_keep, c->plan_V.h_level, &c->hgroup, n_cu);
+  if (c->res.ready) {
+    // (built first, on the device) tests: the host builder on X_t must give the same layout, array for array
+    if (!c->main_lazy && std::getenv("MFM_PLAN_CHECK")) {
+      ResPlan chk;
+      chk.build(Xt_keep, c->plan_V.h_level, &c->hgroup, c->res_plan_cus);
+      const std::string diff = chk.ready ? res_plan_compare(c->res, chk, c->stream) : ("host builder: " + chk.why);
+      if (!diff.empty()) throw Error(MFM_ERR_RUNTIME, "plan check: device and host resident layouts differ (" + diff + ")");
+      lap("resident plan (host, check)");
     }
-    if (c->res.ready) {
-      // all G workgroups must be resident at once: one per CU must fit (registers + LDS), and the CUs must be ours
-      int per_cu = 0;
-      const hipError_t oe = res_occupancy(c->res, &per_cu);
-      std::string why;
-      if (oe != hipSuccess || per_cu < 1)
-        c->res.fail("the persistent kernel does not fit a CU (occupancy query)");
-      else if (!ResidentBudget::get().acquire(c->device, n_cu_dev, c->res.G, why))
-        c->res.fail(why.c_str());
-      else
-        c->res_claim = c->res.G;
-    }
-    c->res_fills_device = c->res.ready && c->res.G > n_cu - n_cu / 4;
-    if (tlog) std::fprintf(stderr, "[mfm_finalize] resident plan: %s (G=%d RV=%d RL=%d umax=%d runs=%lld lds=%zu)\n",
-                           c->res.ready ? "ready" : c->res.why.c_str(), c->res.G, c->res.RV, c->res.RL, c->res.umax,
-                           (long long)c->res.n_runs, c->res.lds_bytes);
-    lap("resident plan");
+  } else if (!c->res_refused && c->soa && c->mf && c->X.unit && !c->comm.active() && c->N >= res_min_rows(c) && !std::getenv("MFM_NO_RESIDENT")) {
+    plan_resident(c, [&](ResPlan &rp, int n_cu) { rp.build(Xt_keep, c->plan_V.h_level, &c->hgroup, n_cu); }, tlog);
+    lap("resident plan (host)");
   }
   Xt_keep = HostCsr();
   MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1345,6 +1431,11 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
 int64_t mfm_dim_all(const mfm_ctx *ctx) { return ctx->D; }
 
 int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launches_per_sweep) {
+  if (ctx->main_lazy) {  // (a two-field table on the persistent sweep: what its per-factor fall-back would be)
+    if (n_levels_main) *n_levels_main = 2;
+    if (n_launches_per_sweep) *n_launches_per_sweep = 1;
+    return MFM_OK;
+  }
   if (n_levels_main) *n_levels_main = (int64_t)ctx->plan_V.n_levels;
   if (n_launches_per_sweep) {
     int64_t n = ctx->plan_V.launches;
@@ -1594,6 +1685,7 @@ int mfm_sweep_w(mfm_ctx *ctx, double alpha, const double *lambda_w, const double
     run_sweep_w_cell(c, zdev, alpha);
     return MFM_OK;
   }
+  c->ensure_main_plans();
   SweepArgs a = main_args(c, c->w.p, zdev, c->lam.p, c->mu.p, alpha);
   const SweepClasses kcw{KC_SWEEP_W_LIGHT, KC_SWEEP_W_HEAVY, KC_SWEEP_W_COOP, KC_SWEEP_W_LSTATS, KC_SWEEP_W_LDRAW,
                          KC_SWEEP_W_LAPPLY, KC_SWEEP_W_CHAIN, KC_SWEEP_W_SCAT};
@@ -1680,6 +1772,17 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     if (c->rng.current < 0 || c->rng.n_zv != c->D * (int64_t)c->K)
       throw Error(MFM_ERR_RUNTIME, "mfm_sweep_V(z = NULL) needs an acquired device random set with K*D z_V variates");
     zbase = c->rng.slot[c->rng.current].zv.p + (size_t)f_begin * c->D;
+  }
+  if (c->main_lazy) {
+    if (c->res.ready) {
+      const bool lazy_store = !std::getenv("MFM_RES_EAGER_STORE");
+      run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq.p, c->V.p, c->D, f_begin, f_end, zbase, c->lam.p, c->mu.p,
+                         c->group.p, c->G, alpha, c->ls.error.p, lazy_store);
+      c->e_in_slots = lazy_store;
+      c->q_stale_factor = f_end - 1;
+      return MFM_OK;
+    }
+    c->ensure_main_plans();
   }
   // the first level rebuilds q from the CSR rows itself when it touches every row exactly once
   const bool first_q = !c->comm.active() && c->blocks.empty() && plan_first_level_builds_q(c->plan_V) &&

@@ -871,6 +871,89 @@ struct ResPlan {
     return v;
   }
 
+  // workgroups: contiguous user ranges (ustart: first row of every user in row order, ustart[n_users] = N) of at most cap rows;
+  // the smallest variant that fits the device. Sets G, RV, RL and the user ordinal boundaries ucut[0 .. G].
+  bool choose_layout(int64_t N, const std::vector<int64_t> &ustart, int64_t max_user, int n_cu, std::vector<int64_t> &ucut) {
+    const int64_t n_users = (int64_t)ustart.size() - 1;
+    int nv = 0;
+    const Variant *vs = variants(nv);
+    bool found = false;
+    for (int vi = 0; vi < nv && !found; vi++) {
+      const int64_t cap = (int64_t)NT * (vs[vi].rv + vs[vi].rl) - 1;  // (at least one pad slot closes the last run)
+      if (max_user > cap) continue;
+      const int64_t slack = std::min<int64_t>(cap / 8, max_user);
+      int64_t Gw = (N + (cap - slack) - 1) / (cap - slack);
+      if (Gw > n_cu && N <= (int64_t)n_cu * cap) Gw = n_cu;  // (tight: the cuts below decide whether it fits)
+      if (Gw > n_cu) continue;
+      if (const char *e = std::getenv("MFM_RES_WGS")) Gw = std::min<int64_t>(n_cu, std::max<int64_t>(Gw, std::atoll(e)));
+      Gw = std::min<int64_t>(Gw, n_users);
+      // cut g at the user boundary nearest to g N / G, never beyond cap rows
+      ucut.assign(1, 0);
+      bool ok = true;
+      for (int64_t g = 1; g <= Gw && ok; g++) {
+        const int64_t lo_u = ucut.back();
+        int64_t hi_u;
+        if (g == Gw) {
+          hi_u = n_users;
+        } else {
+          const int64_t want = (N * g) / Gw;
+          hi_u = std::upper_bound(ustart.begin(), ustart.end(), want) - ustart.begin() - 1;  // last boundary <= want
+          if (hi_u + 1 <= n_users && ustart[hi_u + 1] - want < want - ustart[hi_u]) hi_u++;
+          hi_u = std::max(hi_u, lo_u + 1);
+          // leave at least one user for each of the remaining workgroups
+          hi_u = std::min<int64_t>(hi_u, n_users - (Gw - g));
+          while (hi_u > lo_u + 1 && ustart[hi_u] - ustart[lo_u] > cap) hi_u--;
+        }
+        if (hi_u <= lo_u || ustart[hi_u] - ustart[lo_u] > cap) ok = false;
+        ucut.push_back(hi_u);
+      }
+      if (!ok) continue;
+      G = (int)Gw;
+      RV = vs[vi].rv;
+      RL = vs[vi].rl;
+      found = true;
+    }
+    if (!found) return fail("no variant fits (rows per CU, or a first-level column longer than a workgroup's capacity)");
+    return true;
+  }
+  // item draw: contiguous item ranges of about equal cost (partials + a constant per item), at most NT items each (a thread per
+  // item). slot_ptr: prefix sum of the (workgroup, item) runs per item
+  bool choose_item_slices(const std::vector<int32_t> &slot_ptr, int64_t counter, std::vector<int32_t> &iptr) {
+    iptr.assign((size_t)G + 1, 0);
+    bool ok = false;
+    for (double scale = 1.0; scale < 3.0 && !ok; scale *= 1.1) {
+      const double target = scale * ((double)counter + 16.0 * n_items) / G;
+      double acc = 0.0;
+      int gq = 0, cnt = 0;
+      for (int c = 0; c < n_items; c++) {
+        acc += (double)(slot_ptr[c + 1] - slot_ptr[c]) + 16.0;
+        cnt++;
+        if ((acc >= target || cnt == NT) && gq + 1 < G) {
+          iptr[++gq] = c + 1;
+          acc = 0.0;
+          cnt = 0;
+        }
+      }
+      ok = cnt <= NT;
+      for (gq++; gq <= G; gq++) iptr[gq] = n_items;
+    }
+    if (!ok) return fail("more second-level columns than the workgroups can draw");
+    return true;
+  }
+  // the workgroups' run ranges: global run index = run_base[g] + local; every workgroup ends with its pad run (never stored)
+  static std::vector<int32_t> run_bases(const std::vector<int32_t> &nruns) {
+    const int G = (int)nruns.size();
+    std::vector<int32_t> run_base((size_t)G + 1, 0);
+    const int run_align = std::getenv("MFM_RES_RUN_ALIGN") ? std::max(1, std::atoi(std::getenv("MFM_RES_RUN_ALIGN"))) : 1;
+    const int run_skew = std::getenv("MFM_RES_RUN_SKEW") ? std::atoi(std::getenv("MFM_RES_RUN_SKEW")) : 0;
+    for (int g = 0; g < G; g++) {
+      int64_t nb = run_base[g] + nruns[g] + 1;
+      nb = (nb + run_align - 1) / run_align * run_align + (run_align > 1 ? (int64_t)run_skew * ((g + 1) % 8) : 0);
+      run_base[g + 1] = (int32_t)nb;
+    }
+    return run_base;
+  }
+
   // csc = X_t of the table (column j: ascending rows), level[j] in {0, 1}: 0 = first field (contiguous row ranges in
   // ascending order covering every row once), 1 = second field (every row once). Unit values.
   bool build(const HostCsr &csc, const std::vector<int32_t> &level, const std::vector<int32_t> *group_of, int n_cu) {
@@ -922,47 +1005,8 @@ struct ResPlan {
       });
       if (bad) return fail("second level touches a row twice");
     }
-    // workgroups: contiguous user ranges of at most cap rows; the smallest variant that fits the device
-    int nv = 0;
-    const Variant *vs = variants(nv);
     std::vector<int64_t> ucut;  // user ordinal boundaries of the workgroups
-    bool found = false;
-    for (int vi = 0; vi < nv && !found; vi++) {
-      const int64_t cap = (int64_t)NT * (vs[vi].rv + vs[vi].rl) - 1;  // (at least one pad slot closes the last run)
-      if (max_user > cap) continue;
-      const int64_t slack = std::min<int64_t>(cap / 8, max_user);
-      int64_t Gw = (N + (cap - slack) - 1) / (cap - slack);
-      if (Gw > n_cu && N <= (int64_t)n_cu * cap) Gw = n_cu;  // (tight: the cuts below decide whether it fits)
-      if (Gw > n_cu) continue;
-      if (const char *e = std::getenv("MFM_RES_WGS")) Gw = std::min<int64_t>(n_cu, std::max<int64_t>(Gw, std::atoll(e)));
-      Gw = std::min<int64_t>(Gw, (int64_t)users.size());
-      // cut g at the user boundary nearest to g N / G, never beyond cap rows
-      ucut.assign(1, 0);
-      bool ok = true;
-      for (int64_t g = 1; g <= Gw && ok; g++) {
-        const int64_t lo_u = ucut.back();
-        int64_t hi_u;
-        if (g == Gw) {
-          hi_u = (int64_t)users.size();
-        } else {
-          const int64_t want = (N * g) / Gw;
-          hi_u = std::upper_bound(ustart.begin(), ustart.end(), want) - ustart.begin() - 1;  // last boundary <= want
-          if (hi_u + 1 <= (int64_t)users.size() && ustart[hi_u + 1] - want < want - ustart[hi_u]) hi_u++;
-          hi_u = std::max(hi_u, lo_u + 1);
-          // leave at least one user for each of the remaining workgroups
-          hi_u = std::min<int64_t>(hi_u, (int64_t)users.size() - (Gw - g));
-          while (hi_u > lo_u + 1 && ustart[hi_u] - ustart[lo_u] > cap) hi_u--;
-        }
-        if (hi_u <= lo_u || ustart[hi_u] - ustart[lo_u] > cap) ok = false;
-        ucut.push_back(hi_u);
-      }
-      if (!ok) continue;
-      G = (int)Gw;
-      RV = vs[vi].rv;
-      RL = vs[vi].rl;
-      found = true;
-    }
-    if (!found) return fail("no variant fits (rows per CU, or a first-level column longer than a workgroup's capacity)");
+    if (!choose_layout(N, ustart, max_user, n_cu, ucut)) return false;
     const int R = RV + RL;
     const int64_t cap_slots = (int64_t)NT * R;
     // users per workgroup (+ the never-occurring ones, dealt round-robin), the pad user
@@ -1034,15 +1078,8 @@ struct ResPlan {
     h_slot_ptr[n_items] = (int32_t)counter;
     n_runs = counter;
     if (counter >= ((int64_t)1 << 31) - 2) return fail("too many runs");
-    // runs, workgroup-major: global run index = run_base[g] + local; every workgroup ends with its pad run (never stored)
-    std::vector<int32_t> run_base((size_t)G + 1, 0);
-    const int run_align = std::getenv("MFM_RES_RUN_ALIGN") ? std::max(1, std::atoi(std::getenv("MFM_RES_RUN_ALIGN"))) : 1;
-    const int run_skew = std::getenv("MFM_RES_RUN_SKEW") ? std::atoi(std::getenv("MFM_RES_RUN_SKEW")) : 0;
-    for (int g = 0; g < G; g++) {
-      int64_t nb = run_base[g] + nruns[g] + 1;
-      nb = (nb + run_align - 1) / run_align * run_align + (run_align > 1 ? (int64_t)run_skew * ((g + 1) % 8) : 0);
-      run_base[g + 1] = (int32_t)nb;
-    }
+    // runs, workgroup-major
+    std::vector<int32_t> run_base = run_bases(nruns);
     const int32_t zero_run = run_base[G];  // a partial that stays (0, 0): what the padding entries of the item draw gather
     std::vector<int32_t> h_run_item((size_t)zero_run + 1, n_items);
     for (int g = 0; g < G; g++) {
@@ -1067,29 +1104,8 @@ struct ResPlan {
       for (int32_t j : wg_users[g]) h_udesc.push_back(make_int2(j, group_of && (size_t)j < group_of->size() ? (*group_of)[j] : 0));
       h_uptr[g + 1] = (int32_t)h_udesc.size();
     }
-    // item draw: contiguous item ranges of about equal cost (partials + a constant per item), at most NT items each (a thread
-    // per item)
-    std::vector<int32_t> h_iptr((size_t)G + 1, 0);
-    {
-      bool ok = false;
-      for (double scale = 1.0; scale < 3.0 && !ok; scale *= 1.1) {
-        const double target = scale * ((double)counter + 16.0 * n_items) / G;
-        double acc = 0.0;
-        int gq = 0, cnt = 0;
-        for (int c = 0; c < n_items; c++) {
-          acc += (double)(h_slot_ptr[c + 1] - h_slot_ptr[c]) + 16.0;
-          cnt++;
-          if ((acc >= target || cnt == NT) && gq + 1 < G) {
-            h_iptr[++gq] = c + 1;
-            acc = 0.0;
-            cnt = 0;
-          }
-        }
-        ok = cnt <= NT;
-        for (gq++; gq <= G; gq++) h_iptr[gq] = n_items;
-      }
-      if (!ok) return fail("more second-level columns than the workgroups can draw");
-    }
+    std::vector<int32_t> h_iptr;
+    if (!choose_item_slices(h_slot_ptr, counter, h_iptr)) return false;
     int imax = 0;
     for (int g = 0; g < G; g++) imax = std::max(imax, h_iptr[g + 1] - h_iptr[g]);
     umax = std::max(maxu, imax) + 1;  // stride of the per-wave accumulator arrays; the pad user is umax - 1

@@ -277,6 +277,38 @@ def test_resident_latent_sweep(oracle, capi, monkeypatch, cus):
     np.testing.assert_allclose(c.get_state()[2], chains[0][0], rtol=1e-9, atol=1e-10)
 
 
+def test_resident_layout_from_the_device_plans_on_demand(oracle, capi, monkeypatch):
+    # f4: the persistent sweep's slot layout is built on the device from the CSR (mfm_res_plan.hpp) BEFORE anything else is
+    # planned; when it takes the table, X_t / level plans / row tiles are built only when a call needs them. (Every other
+    # resident test runs with MFM_PLAN_CHECK=1: both builders, layouts compared array for array, nothing lazy.)
+    monkeypatch.delenv("MFM_PLAN_CHECK", raising=False)
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    n = 120001
+    X, y, shapes = ds.onehot_mf(n, 260, 140, seed=9, sort_by_user=True)
+    gi = ds.group_index_from_shapes(shapes)
+    t, c, _ = _pair(oracle, capi, X, y, gi, 3)
+    f = c.plan_flags()
+    assert f["resident"] and not f["soa"] and not f["mf"]  # nothing but the resident layout exists yet
+    drv = CapiGibbs(c, t.clone(), n, gi, fused=True)
+    for it in range(2):  # update_w0 + update_w + update_V in one launch, update_e in slot order: no generic structure needed
+        t.step()
+        drv.step()
+        np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-7, atol=1e-8, err_msg="iteration %d" % it)
+    assert not c.plan_flags()["soa"]
+    np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(c.get_q(), t.q(n), rtol=1e-7, atol=1e-8)
+    # a stand-alone mfm_sweep_w needs the level plan of the table: built now, the chain goes on
+    drv.fused = False
+    for it in range(2):
+        t.step()
+        drv.step()
+        np.testing.assert_allclose(c.get_state()[1], t.fm()[1], rtol=1e-7, atol=1e-8, err_msg="iteration %d" % it)
+        np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-7, atol=1e-8, err_msg="iteration %d" % it)
+    f = c.plan_flags()
+    assert f["resident"] and f["soa"] and f["mf"]
+    np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-7, atol=1e-7)
+
+
 @pytest.mark.parametrize("device_rng", [False, True])
 def test_resident_linear_and_latent_sweeps_in_one_launch(oracle, capi, monkeypatch, device_rng):
     # mfm_sweep_wV: update_w0's residual shift, update_w and update_V of a two-field one-hot table as ONE persistent launch
