@@ -213,6 +213,10 @@ typedef struct mfm_rng_op {
   int64_t offset; /* first index in the destination                        */
   double shape;   /* GAMMA: alpha                                          */
 } mfm_rng_op;
+/* Optional, no context needed: start computing the parallel generator's jump-ahead polynomials for a problem of this size on a
+ * helper thread (cached per process; mfm_finalize asks for the same ones, so a caller that knows (D, rank, groups) before the
+ * design is handed over hides the ~0.1-0.3 s they take behind its own setup).                                                */
+int mfm_rng_prepare(int64_t n_features, int32_t rank, int32_t n_groups);
 int mfm_rng_seed_mt19937(mfm_ctx *ctx, const uint32_t *state624, int32_t position);
 int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops);
 int mfm_rng_prefetch(mfm_ctx *ctx);

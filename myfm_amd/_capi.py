@@ -26,7 +26,7 @@ SYMBOLS = [
     "mfm_oprobit_add_group", "mfm_oprobit_eval", "mfm_oprobit_sample_z", "mfm_hyper_stats", "mfm_timing_enable", "mfm_timing_select", "mfm_timing_reset",
     "mfm_timing_n_classes", "mfm_timing_class_name", "mfm_timing_get", "mfm_design_create", "mfm_design_add_block",
     "mfm_design_destroy", "mfm_design_last_error", "mfm_design_dim_all", "mfm_design_predict",
-    "mfm_host_column_levels", "mfm_rng_seed_mt19937", "mfm_rng_set_program", "mfm_rng_prefetch", "mfm_rng_acquire",
+    "mfm_host_column_levels", "mfm_rng_prepare", "mfm_rng_seed_mt19937", "mfm_rng_set_program", "mfm_rng_prefetch", "mfm_rng_acquire",
     "mfm_rng_get_z", "mfm_design_score_ctx", "mfm_design_n_rows", "mfm_set_allreduce", "mfm_set_row_offset", "mfm_set_main_levels",
     "mfm_test_erfcx", "mfm_test_truncated_normal", "mfm_get_device", "mfm_set_shard", "mfm_comm_unique_id", "mfm_comm_init",
     "mfm_comm_stats", "mfm_comm_info", "mfm_store_create", "mfm_store_destroy", "mfm_store_last_error", "mfm_store_size", "mfm_store_push_ctx",
@@ -105,6 +105,7 @@ def lib():
     L.mfm_design_dim_all.argtypes = [vp]
     L.mfm_design_predict.argtypes = [vp, i32, i32, P, P, P, i32, i32, P, P]
     L.mfm_host_column_levels.argtypes = [i64, i64, P, P, P, C.POINTER(i32)]
+    L.mfm_rng_prepare.argtypes = [i64, i32, i32]
     L.mfm_rng_seed_mt19937.argtypes = [vp, P, i32]
     L.mfm_rng_set_program.argtypes = [vp, P, i32]
     L.mfm_rng_prefetch.argtypes = [vp]

@@ -1007,6 +1007,8 @@ struct FMTrainer {
     if (ctx) return;
     K = rank;
     SetupLap lap("build_device");
+    if (!std::getenv("MYFM_AMD_HOST_RNG"))  // (the device generator's jump polynomials: beside everything below)
+      (void)mfm_rng_prepare((int64_t)cfg.group_index.size(), (int32_t)rank, (int32_t)cfg.n_groups);
     int code = mfm_create(selected_device(), &ctx);
     if (code != MFM_OK) throw_code(code, mfm_global_error());
     if (stream_ptr) ck(ctx, mfm_set_stream(ctx, (void *)stream_ptr));

@@ -819,6 +819,40 @@ int mfm_device_count(void) {
 
 const char *mfm_global_error(void) { return g_global_error.c_str(); }
 
+// The library's code object (a few hundred kernels) is loaded by the runtime at the first launch from it -- about 40 ms on
+// MI355X. The first context of a process starts that launch on a helper thread, so the load runs beside the host's copies of
+// the design (mfm_set_main / mfm_add_block); mfm_finalize waits for it before its own first launch.
+__global__ void k_warm(int *p) {
+  if (p && threadIdx.x == 0) *p = 1;
+}
+struct CodeWarmup {
+  std::once_flag once;
+  std::mutex mu;
+  std::thread th;
+  void start(int device) {
+    std::call_once(once, [&]() {
+      if (std::getenv("MFM_NO_WARMUP")) return;
+      th = std::thread([device]() {
+        hipStream_t st = nullptr;
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return;
+        hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, st, (int *)nullptr);
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamDestroy(st);
+        (void)hipGetLastError();
+      });
+    });
+  }
+  void join() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (th.joinable()) th.join();
+  }
+  ~CodeWarmup() { join(); }
+  static CodeWarmup &get() {
+    static CodeWarmup w;
+    return w;
+  }
+};
+
 int mfm_create(int device, mfm_ctx **out) {
   *out = nullptr;
   try {
@@ -832,6 +866,7 @@ int mfm_create(int device, mfm_ctx **out) {
     c->use_device();
     MFM_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
+    CodeWarmup::get().start(device);
     *out = c.release();
     return MFM_OK;
   } catch (const mfm::Error &ex) {
@@ -1214,6 +1249,31 @@ static void decide_main_paths(mfm_ctx *c) {
   }
 }
 
+// The jump polynomials of the parallel MT19937 generator for a problem of D features, rank K, G groups, sized for one iteration's
+// draws (an upper estimate of the generating workgroups): computed on a helper thread, cached per process. Returns the
+// generator's workgroup count (par_blocks; `keep` when the serial generator serves the problem).
+static int rng_prefetch_jumps(int64_t D, int K, int G, int keep) {
+  if (std::getenv("MFM_RNG_SERIAL")) return keep;
+  const double normals = (double)D * (K + 1) + 4.0 * G * (K + 1) + 16;
+  const double need = normals * (16.0 / 3.14159265358979) * 1.02 + 6.0 * 2.4 * std::sqrt(normals + 1.0) + 4096.0 * (2 + 2.0 * G * (K + 1)) + 2e6;
+  const int64_t blocks = (int64_t)(need / MT_N) + 2;
+  if (blocks <= MT_PAR_BLOCKS) return keep;
+  const int64_t gblocks = blocks * mt_gen_batch(need);  // (the generator is asked for several iterations at a time)
+  const int par_blocks = mt_par_blocks_for(gblocks);
+  mtjump::JumpCache::inst().prefetch(par_blocks, (int)((gblocks + par_blocks - 1) / par_blocks) + 1);
+  return par_blocks;
+}
+
+int mfm_rng_prepare(int64_t n_features, int32_t rank, int32_t n_groups) {
+  try {
+    if (n_features < 0 || rank < 0 || n_groups < 1) return MFM_ERR_INVALID;
+    (void)rng_prefetch_jumps(n_features, rank, n_groups, 0);
+    return MFM_OK;
+  } catch (...) {
+    return MFM_ERR_RUNTIME;
+  }
+}
+
 void mfm_ctx::ensure_main_plans() {
   if (!main_lazy) return;
   main_lazy = false;
@@ -1241,17 +1301,9 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   c->K = rank;
   c->KS = (rank + 1) & ~1;
   // the parallel generator's jump polynomials (mfm_rng_set_program needs them right after this call): start computing
-  // them now on a helper thread, sized for one iteration's draws of this problem (an upper estimate of the workgroups)
-  if (!std::getenv("MFM_RNG_SERIAL")) {
-    const double normals = (double)c->D * (c->K + 1) + 4.0 * c->G * (c->K + 1) + 16;
-    const double need = normals * (16.0 / 3.14159265358979) * 1.02 + 6.0 * 2.4 * std::sqrt(normals + 1.0) + 4096.0 * (2 + 2.0 * c->G * (c->K + 1)) + 2e6;
-    const int64_t blocks = (int64_t)(need / MT_N) + 2;
-    if (blocks > MT_PAR_BLOCKS) {
-      const int64_t gblocks = blocks * mt_gen_batch(need);  // (the generator is asked for several iterations at a time)
-      c->rng.par_blocks = mt_par_blocks_for(gblocks);
-      mtjump::JumpCache::inst().prefetch(c->rng.par_blocks, (int)((gblocks + c->rng.par_blocks - 1) / c->rng.par_blocks) + 1);
-    }
-  }
+  // them now on a helper thread (a caller that knows the problem's size earlier has already asked: mfm_rng_prepare)
+  c->rng.par_blocks = rng_prefetch_jumps(c->D, c->K, c->G, c->rng.par_blocks);
+  CodeWarmup::get().join();
   const bool tlog = std::getenv("MFM_SETUP_TIMING") != nullptr;
   auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_prev = tnow();

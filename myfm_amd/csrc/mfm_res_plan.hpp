@@ -8,6 +8,8 @@
 // the same code as the host builder's, ResPlan::choose_*), on a few hundred KB copied back. `ResPlan::build` (host threads) stays
 // as the checker: with MFM_PLAN_CHECK=1 mfm_finalize builds both and compares every array.
 #pragma once
+#include <chrono>
+
 #include <hipcub/hipcub.hpp>
 
 #include "mfm_res.hpp"
@@ -292,6 +294,15 @@ static inline bool res_plan_build_device(ResPlan &rpn, const DevSparse &X, const
   if (N < 1 || n_cu < 1 || D0 < 2 || !X.unit || X.ell_width != 2) return rpn.fail("shape");
   if (N >= ((int64_t)1 << 31) - 1) return rpn.fail("too many rows");
   auto grid = [](int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); };
+  const bool tlog = std::getenv("MFM_SETUP_TIMING") != nullptr;
+  double t_prev = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  auto lap = [&](const char *what) {
+    if (!tlog) return;
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    const double t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    std::fprintf(stderr, "[res_plan_build_device] %-34s %7.2f ms\n", what, (t - t_prev) * 1e3);
+    t_prev = t;
+  };
   DevBuf<char> tmp;
   DevBuf<int32_t> bflag, ucnt, icnt, red, iflag, eflag, iord, eord, uord1;
   bflag.alloc((size_t)N);
@@ -306,13 +317,20 @@ static inline bool res_plan_build_device(ResPlan &rpn, const DevSparse &X, const
     const int32_t r0[4] = {-1, 0x7fffffff, 0, 0};
     red.upload(r0, 4);
   }
+  lap("allocations");
+  if (tlog) {
+    hipLaunchKernelGGL(k_fill32, dim3(1), dim3(TB), 0, s, red.p + 3, (int64_t)1, 0);
+    lap("first kernel of the library (code object load)");
+  }
   hipLaunchKernelGGL(k_rows, grid(N), dim3(TB), 0, s, X.colidx.p, N, bflag.p, ucnt.p, icnt.p, red.p);
+  lap("k_rows");
   hipLaunchKernelGGL(k_cols, grid(D0), dim3(TB), 0, s, ucnt.p, icnt.p, D0, iflag.p, eflag.p, red.p);
   MFM_HIP_CHECK(hipMemsetAsync(iflag.p + D0, 0, sizeof(int32_t), s));  // (one more element: the totals come out of the exclusive sums)
   MFM_HIP_CHECK(hipMemsetAsync(eflag.p + D0, 0, sizeof(int32_t), s));
   exclusive_sum(iflag.p, iord.p, D0 + 1, tmp, s);
   exclusive_sum(eflag.p, eord.p, D0 + 1, tmp, s);
   inclusive_sum(bflag.p, uord1.p, N, tmp, s);
+  lap("rows, columns, scans (enqueued + run)");
   int32_t h_red[4], n_items = 0, n_emp = 0, n_users = 0;
   MFM_HIP_CHECK(hipMemcpyAsync(h_red, red.p, sizeof h_red, hipMemcpyDeviceToHost, s));
   MFM_HIP_CHECK(hipMemcpyAsync(&n_items, iord.p + D0, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -370,6 +388,7 @@ static inline bool res_plan_build_device(ResPlan &rpn, const DevSparse &X, const
   val2.alloc((size_t)N);
   hipLaunchKernelGGL(k_keys, grid(N), dim3(TB), 0, s, X.colidx.p, iord.p, rowcut.p, G, rpn.item_bits, N, key.p, val.p);
   sort_pairs(key, key2, val, val2, N, rpn.item_bits + gbits, tmp, s);
+  lap("users, cuts, keys, sort");
   DevBuf<uint16_t> uid;
   uid.alloc((size_t)G * cap_slots);
   MFM_HIP_CHECK(hipMemsetAsync(uid.p, 0xff, (size_t)G * cap_slots * sizeof(uint16_t), s));
@@ -401,6 +420,7 @@ static inline bool res_plan_build_device(ResPlan &rpn, const DevSparse &X, const
                      rpn.run_item.p, runs_per_item.p);
   rpn.first_run.alloc((size_t)G * NT);
   hipLaunchKernelGGL(k_first, grid((int64_t)G * NT), dim3(TB), 0, s, hs.p, rowcut.p, hrun0.p, rpn.wg_run_ptr.p, G, R, NT, rpn.first_run.p);
+  lap("slots, heads, runs, first");
   // the item draw's slices (host: one pass over the items' run counts)
   std::vector<int32_t> h_slot_ptr((size_t)n_items + 1, 0), h_iptr;
   {
@@ -443,6 +463,7 @@ static inline bool res_plan_build_device(ResPlan &rpn, const DevSparse &X, const
                        rpn.ent_ptr.p, sstart.p, G, counter, rpn.entries.p);
     MFM_HIP_CHECK(hipStreamSynchronize(s));  // (the sort buffers go out of scope)
   }
+  lap("slices, pack, entries");
   // users, items, the scorer's tables
   DevBuf<int32_t> d_group;
   if (group_of && (int64_t)group_of->size() >= D0) d_group.upload(group_of->data(), (size_t)D0);
@@ -473,6 +494,7 @@ static inline bool res_plan_build_device(ResPlan &rpn, const DevSparse &X, const
   rpn.bar.alloc(RES_BAR_WORDS);
   MFM_HIP_CHECK(hipStreamSynchronize(s));
   MFM_HIP_CHECK(hipGetLastError());
+  lap("descriptors, buffers");
   rpn.ready = true;
   rpn.why.clear();
   return true;
