@@ -1032,7 +1032,9 @@ struct FMTrainer {
     lap("mfm_add_block (all)");
     vector<int32_t> gi(cfg.group_index.begin(), cfg.group_index.end());
     ck(ctx, mfm_set_groups(ctx, gi.data(), (int64_t)gi.size(), (int32_t)cfg.n_groups));
+    lap("mfm_set_groups");
     ck(ctx, mfm_finalize(ctx, rank));
+    lap("mfm_finalize");
   }
   void upload(const FM &fm) { ck(ctx, mfm_set_state(ctx, fm.w0, fm.w.data(), fm.V.data())); }
   void download(FM &fm) {

@@ -10,6 +10,7 @@
 //       so that every sum has one owner and a fixed order -- no atomics, deterministic;
 //   re-sync (:306-311, :473-480): streaming over the training rows, gathering the block record.
 #pragma once
+#include <chrono>
 #include <algorithm>
 #include <mutex>
 #include <vector>
@@ -409,6 +410,43 @@ __global__ __launch_bounds__(WG) void k_block_score_cache(const int32_t *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// rows of the training table per block row (cardinality, definitions.hpp:65-68) on the device: a workgroup counts a contiguous
+// stretch of the map -- in an LDS table when the block has few rows, else with one global atomic per run of equal indices inside
+// a wavefront (a map that follows the table's order hits the same block row for many consecutive rows)
+constexpr int64_t CARD_LDS_MAX = 8192;
+__global__ void k_block_card(const int32_t *__restrict__ map, int64_t N, int B, bool lds, int32_t *__restrict__ cnt) {
+  extern __shared__ int32_t card_lds[];
+  const int64_t per = (N + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = min(N, lo + per);
+  if (lds) {
+    for (int i = threadIdx.x; i < B; i += blockDim.x) card_lds[i] = 0;
+    __syncthreads();
+    for (int64_t t = lo + threadIdx.x; t < hi; t += blockDim.x) atomicAdd(&card_lds[map[t]], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += blockDim.x)
+      if (card_lds[i]) atomicAdd(&cnt[i], card_lds[i]);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  for (int64_t t0 = lo + (threadIdx.x & ~63); t0 < hi; t0 += blockDim.x) {
+    const int64_t t = t0 + lane;
+    const int32_t v = t < hi ? map[t] : -1;
+    const int32_t prev = __shfl_up(v, 1);
+    const bool head = lane == 0 || v != prev;
+    const unsigned long long heads = __ballot(head);
+    if (head && v >= 0) {
+      const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+      const int len = above ? __ffsll((long long)above) : 64 - lane;
+      // (lanes past the end of the stretch carry v = -1: they start a run of their own and are not counted)
+      atomicAdd(&cnt[v], len);
+    }
+  }
+}
+__global__ void k_block_card_rec(const int32_t *__restrict__ cnt, int64_t B, double *__restrict__ rec) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) rec[i * BLOCK_REC + 6] = (double)cnt[i];
+}
+
 struct DevBlock {
   int64_t B = 0, Db = 0, nnz = 0;
   int64_t col_off = 0;  // offset of the block's features in the global feature index
@@ -436,14 +474,28 @@ struct DevBlock {
   int n_inv_wave = 0, n_inv_wg = 0, n_inv_long = 0, n_inv_chunks = 0;
 
   // lean: the cell path (mfm_cell.hpp) takes every O(N) pass of this design -- no inverse map, no streaming tables
-  void build(const HostCsr &hX, const std::vector<int64_t> &hmap, int64_t N, int KS, hipStream_t s, bool lean = false) {
+  void build(const HostCsr &hX, const int32_t *hmap, int64_t N, int KS, hipStream_t s, bool lean = false,
+             DevBuf<int32_t> *pre_map = nullptr) {
     B = hX.rows;
     Db = hX.cols;
     nnz = hX.nnz();
+    const bool tlog = std::getenv("MFM_SETUP_TIMING") != nullptr;
+    double t_prev = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    auto lap = [&](const char *what) {
+      if (!tlog) return;
+      const double t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+      std::fprintf(stderr, "[DevBlock::build B=%lld nnz=%lld] %-24s %7.3f s\n", (long long)B, (long long)nnz, what, t - t_prev);
+      t_prev = t;
+    };
     HostCsr Xt = transpose_host(hX);
+    lap("transpose (host)");
     X.upload(hX, &Xt);
+    lap("upload");
     plan_V.build(Xt, PBlockV::R_W16, PBlockV::R_WG, coop_capacity<PBlockV>());
-    plan_W.build(Xt, PBlockW::R_W16, PBlockW::R_WG, coop_capacity<PBlockW>());
+    lap("plan_V");
+    plan_W.build(Xt, PBlockW::R_W16, PBlockW::R_WG, coop_capacity<PBlockW>(), false, false,
+                 std::getenv("MFM_NO_PLAN_TWIN") ? nullptr : &plan_V);  // (the level schedule of the same matrix: computed once)
+    lap("plan_W");
     // rows of a block row far apart in the table (lists longer than a workgroup handles at once) and a table that fits
     // in LDS: the statistics pass streams the training rows (k_unsync_stream) and needs no inverse map. (A map that is
     // sorted -- the block follows the table's row order -- has contiguous lists; those stay with the inverse-map kernels,
@@ -457,29 +509,25 @@ struct DevBlock {
     split_unsync = !sorted && !stream_unsync && N >= ((int64_t)1 << 20) && !std::getenv("MFM_NO_UNSYNC_SPLIT");
     if (const char *e = std::getenv("MFM_UNSYNC_SPLIT_FORCE")) split_unsync = std::atoi(e) != 0 && !stream_unsync;
     if (lean) stream_unsync = split_unsync = false;
-    std::vector<int32_t> m32((size_t)N);
     std::vector<int64_t> iptr((size_t)B + 1, 0);
-    if (N >= ((int64_t)1 << 22) && B <= ((int64_t)1 << 21)) {  // (long maps: the 32-bit copy and the row counts on host threads)
-      std::mutex mx;
-      parallel_ranges(N, [&](int64_t lo, int64_t hi) {
-        std::vector<int32_t> cnt((size_t)B, 0);
-        for (int64_t t = lo; t < hi; t++) {
-          m32[t] = (int32_t)hmap[t];
-          cnt[hmap[t]]++;
-        }
-        std::lock_guard<std::mutex> g(mx);
-        for (int64_t i = 0; i < B; i++) iptr[i + 1] += cnt[i];
-      });
-    } else {
-      for (int64_t t = 0; t < N; t++) {
-        m32[t] = (int32_t)hmap[t];
-        iptr[hmap[t] + 1]++;
+    std::vector<double> hrec;
+    if (!lean) {  // (lean: the rows per block row are counted on the device, below; nothing else of this is needed)
+      if (N >= ((int64_t)1 << 22) && B <= ((int64_t)1 << 21)) {  // (long maps: the row counts on host threads)
+        std::mutex mx;
+        parallel_ranges(N, [&](int64_t lo, int64_t hi) {
+          std::vector<int32_t> cnt((size_t)B, 0);
+          for (int64_t t = lo; t < hi; t++) cnt[hmap[t]]++;
+          std::lock_guard<std::mutex> g(mx);
+          for (int64_t i = 0; i < B; i++) iptr[i + 1] += cnt[i];
+        });
+      } else {
+        for (int64_t t = 0; t < N; t++) iptr[hmap[t] + 1]++;
       }
-    }
-    std::vector<double> hrec((size_t)B * BLOCK_REC, 0.0);
-    for (int64_t i = 0; i < B; i++) {
-      hrec[(size_t)i * BLOCK_REC + 6] = (double)iptr[i + 1];  // cardinality, definitions.hpp:65-68
-      iptr[i + 1] += iptr[i];
+      hrec.assign((size_t)B * BLOCK_REC, 0.0);
+      for (int64_t i = 0; i < B; i++) {
+        hrec[(size_t)i * BLOCK_REC + 6] = (double)iptr[i + 1];  // cardinality, definitions.hpp:65-68
+        iptr[i + 1] += iptr[i];
+      }
     }
     std::vector<int32_t> irows;
     if (!stream_unsync && !lean) {
@@ -507,8 +555,25 @@ struct DevBlock {
     n_inv_wg = (int)bg.size();
     n_inv_long = (int)bl_.size();
     n_inv_chunks = (int)ch.size();
-    map.upload(m32);
-    rec.upload(hrec);
+    lap("counts, inverse");
+    if (pre_map && pre_map->n == (size_t)N && N > 0)
+      map = std::move(*pre_map);  // (already on the device: the cell planner read it there)
+    else
+      map.upload(hmap, (size_t)N);
+    if (lean) {
+      rec.alloc_zero((size_t)B * BLOCK_REC, s);
+      DevBuf<int32_t> cnt;
+      cnt.alloc_zero((size_t)std::max<int64_t>(B, 1), s);
+      if (N > 0) {
+        const bool lds = B <= CARD_LDS_MAX;
+        const int wgs = (int)std::min<int64_t>(1024, (N + 4 * WG - 1) / (4 * WG));
+        hipLaunchKernelGGL(k_block_card, dim3(wgs), dim3(WG), lds ? (size_t)B * sizeof(int32_t) : 0, s, map.p, N, (int)B, lds, cnt.p);
+      }
+      if (B > 0) hipLaunchKernelGGL(k_block_card_rec, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, cnt.p, B, rec.p);
+      MFM_HIP_CHECK(hipStreamSynchronize(s));
+    } else {
+      rec.upload(hrec);
+    }
     inv_ptr.upload(iptr);
     inv_rows.upload(irows);
     inv_wave.upload(bw);
@@ -530,6 +595,7 @@ struct DevBlock {
       stream_wgs = (int)((N + stream_rows_per_wg - 1) / stream_rows_per_wg);
       stream_partial.alloc((size_t)std::max(stream_wgs, 1) * (size_t)B * 4);
     }
+    lap("uploads, buffers");
   }
   // sum record words [first, first + n) of every block row over the ranks
   void allreduce_fields(hipStream_t s, const Comm &comm, int first, int n) {

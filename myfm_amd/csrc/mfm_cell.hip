@@ -6,6 +6,8 @@
 #include <mutex>
 #include <thread>
 
+#include <hipcub/hipcub.hpp>
+
 #include "mfm_cell.hpp"
 #include "mfm_wave.hpp"
 
@@ -66,6 +68,137 @@ static void par_for(int64_t n, int64_t min_per_thread, F f) {
   for (int t = 1; t < T; t++) pool.emplace_back(f, n * t / T, n * (t + 1) / T);
   f((int64_t)0, n / T);
   for (auto &t : pool) t.join();
+}
+
+// streams and fields of the design (host decisions, no O(N) work of their own): main field p = the p-th entry of every row; a
+// block joins the stream whose indices equal its map on every row (differs(b, candidate): the O(N) comparison, on the host or
+// on the device), else it opens a stream. src: where every stream's indices come from.
+struct CellStreamSrc {
+  int main_p = -1;  // main field position, or
+  int block = -1;   // the block whose map opened the stream
+};
+static bool cell_plan_streams(CellPlan &cp, int64_t W, const std::vector<int64_t> &base, const std::vector<int64_t> &Bs,
+                              std::vector<CellStreamSrc> &src, const std::function<bool(size_t, const CellStreamSrc &)> &differs) {
+  src.clear();
+  for (int64_t p = 0; p < W; p++) {
+    CellStream st;
+    st.card = base[p + 1] - base[p];
+    st.fields.push_back((int)cp.fields.size());
+    CellField f;
+    f.stream = (int)p;
+    f.kind = 0;
+    f.n = st.card;
+    f.base = base[p];
+    cp.fields.push_back(f);
+    cp.streams.push_back(st);
+    CellStreamSrc h;
+    h.main_p = (int)p;
+    src.push_back(h);
+  }
+  for (size_t b = 0; b < Bs.size(); b++) {
+    int found = -1;
+    for (size_t si = 0; si < src.size() && found < 0; si++)
+      if (!differs(b, src[si])) found = (int)si;
+    if (found < 0) {
+      if (src.size() >= (size_t)CELL_MAX_STREAMS) return cp.fail("more index streams than a row record holds");
+      CellStreamSrc h;
+      h.block = (int)b;
+      src.push_back(h);
+      cp.streams.push_back(CellStream());
+      found = (int)src.size() - 1;
+    }
+    if (cp.fields.size() >= (size_t)CELL_MAX_FIELDS) return cp.fail("too many fields");
+    CellField f;
+    f.stream = found;
+    f.kind = 1;
+    f.n = Bs[b];
+    f.base = (int64_t)b;
+    cp.streams[found].card = std::max(cp.streams[found].card, Bs[b]);
+    cp.streams[found].fields.push_back((int)cp.fields.size());
+    cp.fields.push_back(f);
+  }
+  // stream types and record slots
+  cp.sU = 0;
+  cp.sI = -1;
+  cp.streams[0].type = CELL_U;
+  int n_slots = 1;
+  cp.streams[0].slot = 0;
+  for (size_t si = 1; si < cp.streams.size(); si++) {
+    if (cp.streams[si].card <= CELL_SMALL_MAX) {
+      cp.streams[si].type = CELL_C;
+      cp.streams[si].slot = n_slots++;
+    } else {
+      if (cp.sI >= 0) return cp.fail("more than one large scattered index stream");
+      cp.sI = (int)si;
+      cp.streams[si].type = CELL_I;
+    }
+  }
+  cp.item32 = false;
+  if (cp.sI >= 0) {
+    if (cp.streams[cp.sI].card <= 65536 && n_slots < 4)
+      cp.streams[cp.sI].slot = n_slots++;
+    else {
+      cp.streams[cp.sI].slot = -1;
+      cp.item32 = true;
+    }
+    if (cp.streams[cp.sI].card >= (int64_t)2147483647) return cp.fail("I stream too large");
+  }
+  if (n_slots > 4) return cp.fail("more small index streams than a row record holds");
+  return true;
+}
+
+// do the groups' tables fit the LDS in every pass of the sweep? (gu0: first U value of every group, then the end)
+static bool cell_plan_groups_fit(CellPlan &cp, const std::vector<int32_t> &gu0) {
+  const int G = (int)gu0.size() - 1;
+  int64_t um = 0;
+  for (int g = 0; g < G; g++) um = std::max<int64_t>(um, gu0[g + 1] - gu0[g]);
+  cp.G = G;
+  cp.umax = um;
+  if (um > 65535) return false;
+  // the passes the sweep will run: (P, F) = (last of the previous factor | none, first), (k - 1, k), (last, none)
+  const int m = (int)cp.fields.size();
+  size_t worst = 0;
+  for (int k = 0; k < m; k++) {
+    const int P = k == 0 ? m - 1 : k - 1;
+    size_t need = cp.lds_bytes(P, k, k == 0);
+    if (need > CELL_LDS_BYTES)  // (split form: apply-only pass, then statistics-only pass)
+      need = std::max(cp.lds_bytes(P, -1, false), cp.lds_bytes(-1, k, false));
+    worst = std::max(worst, need);
+  }
+  return worst <= CELL_LDS_BYTES;
+}
+
+// the plan's device buffers besides the row arrays
+static void cell_plan_buffers(CellPlan &cp, hipStream_t s) {
+  const int G = cp.G;
+  const int64_t cardI = cp.sI >= 0 ? cp.streams[cp.sI].card : 0, cardU = cp.streams[0].card;
+  cp.e.alloc((size_t)cp.Npad);
+  int64_t maxcard = 0;
+  for (size_t si = 0; si < cp.streams.size(); si++) {
+    const size_t n = (size_t)cp.streams[si].card;
+    maxcard = std::max<int64_t>(maxcard, cp.streams[si].card);
+    if (cp.streams[si].type == CELL_I) continue;
+    cp.QA[si].alloc_zero(n, s);
+    cp.QS[si].alloc_zero(n, s);
+  }
+  if (cp.sI >= 0) {
+    cp.packI.alloc_zero((size_t)cardI * 4, s);
+    cp.cells1.alloc_zero((size_t)G * cardI, s);
+    cp.cells2.alloc_zero((size_t)G * cardI * 2, s);
+    cp.cells4.alloc_zero((size_t)G * cardI * 4, s);
+  }
+  int64_t maxC = 0;
+  for (auto &st : cp.streams)
+    if (st.type == CELL_C) maxC = std::max(maxC, st.card);
+  cp.cpart.alloc_zero((size_t)std::max<int64_t>(1, (int64_t)G * maxC * 4), s);
+  cp.DP.alloc_zero((size_t)std::max<int64_t>(1, maxcard), s);
+  cp.stat.alloc_zero((size_t)std::max<int64_t>(1, cardU * 2), s);
+  cp.stat1.alloc_zero((size_t)std::max<int64_t>(1, maxcard), s);
+  cp.dense.alloc_zero((size_t)std::max<int64_t>(1, maxcard) * 4, s);
+  cp.cnt_ready = false;
+  for (size_t f = 0; f < cp.fields.size(); f++)
+    if (cp.fields[f].kind == 0) cp.cnt[f].alloc_zero((size_t)std::max<int64_t>(1, cp.fields[f].n), s);
+  MFM_HIP_CHECK(hipStreamSynchronize(s));
 }
 
 bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlockIn> &blocks, int n_cu, hipStream_t s,
@@ -152,82 +285,35 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
   // streams: main fields first, then every block whose map is not one of the streams already there
   struct HostStream {
     int main_p = -1;               // main field position, or
-    const int64_t *map = nullptr;  // a block's map
+    const int32_t *map = nullptr;  // a block's map
   };
   std::vector<HostStream> hs;
-  for (int64_t p = 0; p < W; p++) {
-    CellStream st;
-    st.card = base[p + 1] - base[p];
-    st.fields.push_back((int)cp.fields.size());
-    CellField f;
-    f.stream = (int)p;
-    f.kind = 0;
-    f.n = st.card;
-    f.base = base[p];
-    cp.fields.push_back(f);
-    cp.streams.push_back(st);
-    HostStream h;
-    h.main_p = (int)p;
-    hs.push_back(h);
-  }
   auto idx_of = [&](const HostStream &h, int64_t t) -> int64_t {
     return h.main_p >= 0 ? (int64_t)X.idx[t * W + h.main_p] - base[h.main_p] : h.map[t];
   };
-  for (size_t b = 0; b < blocks.size(); b++) {
-    int found = -1;
-    for (size_t si = 0; si < hs.size() && found < 0; si++) {
+  {
+    std::vector<int64_t> Bs;
+    for (auto &b : blocks) Bs.push_back(b.B);
+    std::vector<CellStreamSrc> src;
+    const bool ok = cell_plan_streams(cp, W, base, Bs, src, [&](size_t b, const CellStreamSrc &c) {
+      HostStream h;
+      h.main_p = c.main_p;
+      h.map = c.block >= 0 ? blocks[(size_t)c.block].map : nullptr;
       std::atomic<int> diff(0);
       par_for(N, 1 << 20, [&](int64_t a, int64_t e) {
         for (int64_t t = a; t < e && !diff.load(std::memory_order_relaxed); t++)
-          if (idx_of(hs[si], t) != blocks[b].map[t]) diff = 1;
+          if (idx_of(h, t) != blocks[b].map[t]) diff = 1;
       });
-      if (!agree_bad(diff.load())) found = (int)si;  // (equal on EVERY rank's rows)
-    }
-    if (found < 0) {
-      if (hs.size() >= (size_t)CELL_MAX_STREAMS) return cp.fail("more index streams than a row record holds");
+      return agree_bad(diff.load()) != 0;  // (equal on EVERY rank's rows)
+    });
+    if (!ok) return false;
+    for (auto &c : src) {
       HostStream h;
-      h.map = blocks[b].map;
+      h.main_p = c.main_p;
+      h.map = c.block >= 0 ? blocks[(size_t)c.block].map : nullptr;
       hs.push_back(h);
-      cp.streams.push_back(CellStream());
-      found = (int)hs.size() - 1;
-    }
-    if (cp.fields.size() >= (size_t)CELL_MAX_FIELDS) return cp.fail("too many fields");
-    CellField f;
-    f.stream = found;
-    f.kind = 1;
-    f.n = blocks[b].B;
-    f.base = (int64_t)b;
-    cp.streams[found].card = std::max(cp.streams[found].card, blocks[b].B);
-    cp.streams[found].fields.push_back((int)cp.fields.size());
-    cp.fields.push_back(f);
-  }
-  // stream types and record slots
-  cp.sU = 0;
-  cp.sI = -1;
-  cp.streams[0].type = CELL_U;
-  int n_slots = 1;
-  cp.streams[0].slot = 0;
-  for (size_t si = 1; si < cp.streams.size(); si++) {
-    if (cp.streams[si].card <= CELL_SMALL_MAX) {
-      cp.streams[si].type = CELL_C;
-      cp.streams[si].slot = n_slots++;
-    } else {
-      if (cp.sI >= 0) return cp.fail("more than one large scattered index stream");
-      cp.sI = (int)si;
-      cp.streams[si].type = CELL_I;
     }
   }
-  cp.item32 = false;
-  if (cp.sI >= 0) {
-    if (cp.streams[cp.sI].card <= 65536 && n_slots < 4)
-      cp.streams[cp.sI].slot = n_slots++;
-    else {
-      cp.streams[cp.sI].slot = -1;
-      cp.item32 = true;
-    }
-    if (cp.streams[cp.sI].card >= (int64_t)2147483647) return cp.fail("I stream too large");
-  }
-  if (n_slots > 4) return cp.fail("more small index streams than a row record holds");
   // groups of consecutive U values, rows balanced; more (smaller) groups until every pass of the sweep fits its LDS
   const int64_t cardU = cp.streams[0].card;
   std::vector<int64_t> grow;  // first row of every group, then N
@@ -260,22 +346,7 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
       gu0[0] = (int32_t)idx_of(hU, 0);
       gu0[G] = (int32_t)idx_of(hU, N - 1) + 1;
     }
-    int64_t um = 0;
-    for (int g = 0; g < G; g++) um = std::max<int64_t>(um, gu0[g + 1] - gu0[g]);
-    cp.G = G;
-    cp.umax = um;
-    if (um > 65535) continue;
-    // the passes the sweep will run: (P, F) = (last of the previous factor | none, first), (k - 1, k), (last, none)
-    const int m = (int)cp.fields.size();
-    size_t worst = 0;
-    for (int k = 0; k < m; k++) {
-      const int P = k == 0 ? m - 1 : k - 1;
-      size_t need = cp.lds_bytes(P, k, k == 0);
-      if (need > CELL_LDS_BYTES)  // (split form: apply-only pass, then statistics-only pass)
-        need = std::max(cp.lds_bytes(P, -1, false), cp.lds_bytes(-1, k, false));
-      worst = std::max(worst, need);
-    }
-    fits = worst <= CELL_LDS_BYTES;
+    fits = cell_plan_groups_fit(cp, gu0);
   }
   const int G = cp.G;
   const int64_t cardI = cp.sI >= 0 ? cp.streams[cp.sI].card : 0;
@@ -381,35 +452,390 @@ bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlock
   cp.grp_base.upload(gbase);
   cp.grp_u0.upload(gu0);
   cp.grp_steps.upload(steps);
-  cp.e.alloc((size_t)npad);
-  int64_t maxcard = 0;
-  for (size_t si = 0; si < cp.streams.size(); si++) {
-    const size_t n = (size_t)cp.streams[si].card;
-    maxcard = std::max<int64_t>(maxcard, cp.streams[si].card);
-    if (cp.streams[si].type == CELL_I) continue;
-    cp.QA[si].alloc_zero(n, s);
-    cp.QS[si].alloc_zero(n, s);
-  }
-  if (cp.sI >= 0) {
-    cp.packI.alloc_zero((size_t)cardI * 4, s);
-    cp.cells1.alloc_zero((size_t)G * cardI, s);
-    cp.cells2.alloc_zero((size_t)G * cardI * 2, s);
-    cp.cells4.alloc_zero((size_t)G * cardI * 4, s);
-  }
-  int64_t maxC = 0;
-  for (auto &st : cp.streams)
-    if (st.type == CELL_C) maxC = std::max(maxC, st.card);
-  cp.cpart.alloc_zero((size_t)std::max<int64_t>(1, (int64_t)G * maxC * 4), s);
-  cp.DP.alloc_zero((size_t)std::max<int64_t>(1, maxcard), s);
-  cp.stat.alloc_zero((size_t)std::max<int64_t>(1, cardU * 2), s);
-  cp.stat1.alloc_zero((size_t)std::max<int64_t>(1, maxcard), s);
-  cp.dense.alloc_zero((size_t)std::max<int64_t>(1, maxcard) * 4, s);
-  cp.cnt_ready = false;
-  for (size_t f = 0; f < cp.fields.size(); f++)
-    if (cp.fields[f].kind == 0) cp.cnt[f].alloc_zero((size_t)std::max<int64_t>(1, cp.fields[f].n), s);
-  MFM_HIP_CHECK(hipStreamSynchronize(s));
+  cell_plan_buffers(cp, s);
   cp.ready = true;
   return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same plan built ON THE DEVICE from the device-resident CSR and the blocks' maps (one GPU; the row-sharded planner above
+// needs its agreements over the ranks and stays on the host). O(N) work: the fields' column ranges, which block shares which
+// stream, the group cuts along the first field, the rows of every group sorted by the I index (ONE stable radix sort of
+// (group, I index) keys), the wave chunks cut between two I values, the row records. The host takes the decisions that are
+// O(fields) / O(groups) on a few KB copied back -- with the code the host planner uses (cell_plan_streams,
+// cell_plan_groups_fit). tests (MFM_PLAN_CHECK): both planners, every array compared (cell_plan_compare).
+namespace cpd {
+
+constexpr int TB = 256;
+constexpr int MAXB = CELL_MAX_FIELDS;
+
+struct Src {  // where the index streams of a row come from
+  int W;                           // entries per row of the main table
+  int nb;                          // blocks
+  int32_t base[CELL_MAX_STREAMS];  // first column of main field p
+  const int32_t *map[MAXB];
+};
+
+// per main field the smallest / largest column; red[2 W] counts rows that break the order of the first field
+__global__ void k_fields(const int32_t *__restrict__ colidx, int64_t N, int W, int32_t *__restrict__ red) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int p = 0; p < W; p++) {
+    int32_t lo = 0x7fffffff, hi = -1;
+    if (t < N) lo = hi = colidx[t * W + p];
+    for (int off = 32; off > 0; off >>= 1) {
+      lo = min(lo, __shfl_xor(lo, off));
+      hi = max(hi, __shfl_xor(hi, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&red[2 * p], lo);
+      atomicMax(&red[2 * p + 1], hi);
+    }
+  }
+  if (t > 0 && t < N && colidx[t * W] < colidx[(t - 1) * W]) atomicAdd(&red[2 * W], 1);
+}
+
+// diff[b * (W + nb) + c] != 0: block b's map differs on some row from candidate c (c < W: main field c, else block c - W)
+__global__ void k_stream_diff(const int32_t *__restrict__ colidx, Src sr, int64_t N, int32_t *__restrict__ diff) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  const int nc = sr.W + sr.nb;
+  int32_t cand[CELL_MAX_STREAMS + MAXB];
+  for (int p = 0; p < sr.W; p++) cand[p] = colidx[t * sr.W + p] - sr.base[p];
+  for (int b = 0; b < sr.nb; b++) cand[sr.W + b] = sr.map[b][t];
+  for (int b = 0; b < sr.nb; b++)
+    for (int c = 0; c < sr.W + b; c++)
+      if (cand[c] != cand[sr.W + b] && !diff[b * nc + c]) diff[b * nc + c] = 1;  // (benign race: every writer stores 1)
+}
+
+// group cut g: row g * target, moved up to the next change of the first field; its U value there
+__global__ void k_grow(const int32_t *__restrict__ colidx, int W, int64_t N, int64_t target, int G0, int32_t cardU,
+                       int32_t *__restrict__ out_r, int32_t *__restrict__ out_u) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G0) return;
+  int64_t r = min(N, (int64_t)g * target);
+  while (r < N && r > 0 && colidx[r * W] == colidx[(r - 1) * W]) r++;
+  out_r[g] = (int32_t)r;
+  out_u[g] = r < N ? colidx[r * W] : cardU;
+}
+
+__device__ __forceinline__ int find_group(const int32_t *cut, int G, int32_t x) {  // cut[g] <= x < cut[g + 1]
+  int lo = 0, hi = G;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (cut[mid] <= x)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// sort keys (group, I index) of the rows; src_p >= 0: the I stream is main field src_p, else the map
+__global__ void k_keys(const int32_t *__restrict__ colidx, int W, int src_p, int32_t base, const int32_t *__restrict__ map,
+                       const int32_t *__restrict__ grow, int G, int ibits, int64_t N, uint32_t *__restrict__ key, int32_t *__restrict__ val) {
+  extern __shared__ int32_t cut[];
+  for (int i = threadIdx.x; i <= G; i += blockDim.x) cut[i] = grow[i];
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  const int g = find_group(cut, G, (int32_t)t);
+  const uint32_t iv = map ? (uint32_t)map[t] : src_p >= 0 ? (uint32_t)(colidx[t * W + src_p] - base) : 0u;
+  key[t] = ((uint32_t)g << ibits) | iv;
+  val[t] = (int32_t)t;
+}
+
+// chunk cut j of group g (one wave each): row R0 + L j / NW of the sorted order, moved up to the next change of the I index
+__global__ void k_chunk_cuts(const uint32_t *__restrict__ key, const int32_t *__restrict__ grow, int G, bool has_i, int32_t *__restrict__ c0) {
+  const int wv = (int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (wv >= G * (CELL_NW + 1)) return;
+  const int g = wv / (CELL_NW + 1), j = wv % (CELL_NW + 1);
+  const int64_t R0 = grow[g], R1 = grow[g + 1], L = R1 - R0;
+  int64_t r = j == 0 ? R0 : j == CELL_NW ? R1 : R0 + L * j / CELL_NW;
+  if (has_i && j > 0 && j < CELL_NW) {
+    for (;;) {
+      const int64_t q = r + lane;
+      const bool same = q < R1 && q > R0 && key[q] == key[q - 1];
+      const unsigned long long m = __ballot(same);
+      if (~m) {
+        r += __ffsll((long long)~m) - 1;
+        break;
+      }
+      r += 64;
+    }
+  }
+  if (lane == 0) c0[wv] = (int32_t)r;
+}
+
+// per group: cuts made monotone, chunk lengths, steps of the longest chunk
+__global__ void k_chunk_fin(int32_t *__restrict__ c0, int G, int wrows, int32_t *__restrict__ clen, int32_t *__restrict__ steps) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  int32_t *c = c0 + (int64_t)g * (CELL_NW + 1);
+  int32_t longest = 0;
+  for (int j = 1; j <= CELL_NW; j++) {
+    c[j] = max(c[j], c[j - 1]);
+    clen[g * CELL_NW + j - 1] = c[j] - c[j - 1];
+    longest = max(longest, c[j] - c[j - 1]);
+  }
+  steps[g] = (longest + wrows - 1) / wrows;
+}
+
+struct RecSrc {  // how a row's record is put together
+  int ns;                            // streams
+  int slot[CELL_MAX_STREAMS];        // u16 slot of the record (-1: the int32 item array)
+  int main_p[CELL_MAX_STREAMS];      // main field position, or -1: map
+  int32_t base[CELL_MAX_STREAMS];
+  const int32_t *map[CELL_MAX_STREAMS];
+};
+
+// the rows in cell order: position of sorted row q, its record, perm
+__global__ void k_records(const uint32_t *__restrict__ key, const int32_t *__restrict__ val, const int32_t *__restrict__ colidx, int W, RecSrc rs,
+                          const int32_t *__restrict__ grow, const int32_t *__restrict__ c0, const int32_t *__restrict__ gbase,
+                          const int32_t *__restrict__ gu0, int G, int ibits, bool has_i, int wrows, int64_t N, uint2 *__restrict__ ix,
+                          int32_t *__restrict__ item, int32_t *__restrict__ perm) {
+  extern __shared__ int32_t cut[];
+  if (!has_i) {
+    for (int i = threadIdx.x; i <= G; i += blockDim.x) cut[i] = grow[i];
+    __syncthreads();
+  }
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= N) return;
+  const int g = has_i ? (int)(key[q] >> ibits) : find_group(cut, G, (int32_t)q);
+  const int32_t *c = c0 + (int64_t)g * (CELL_NW + 1);
+  int w = 0;
+  {  // the LAST chunk that starts at or before q (empty chunks share their start with the next one)
+    int lo = 0, hi = CELL_NW;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (c[mid] <= (int32_t)q)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    w = lo;
+  }
+  const int64_t r = q - c[w];
+  const int64_t p = (int64_t)gbase[g] + (r / wrows) * ((int64_t)wrows * CELL_NW) + (int64_t)w * wrows + (r % wrows);
+  const int32_t t = has_i ? val[q] : (int32_t)q;
+  uint32_t sl[4] = {0, 0, 0, 0};
+  for (int si = 0; si < rs.ns; si++) {
+    const int32_t v = rs.main_p[si] >= 0 ? colidx[(int64_t)t * W + rs.main_p[si]] - rs.base[si] : rs.map[si][t];
+    if (si == 0)
+      sl[0] = (uint32_t)(v - gu0[g]);
+    else if (rs.slot[si] >= 0)
+      sl[rs.slot[si]] = (uint32_t)v;
+    else
+      item[p] = v;
+  }
+  ix[p] = make_uint2(sl[0] | (sl[1] << 16), sl[2] | (sl[3] << 16));
+  perm[p] = t;
+}
+
+static int bits_for(int64_t n) {
+  int b = 1;
+  while (((int64_t)1 << b) < n) b++;
+  return b;
+}
+
+template <class T>
+static std::vector<T> download(const T *p, size_t n, hipStream_t s) {
+  std::vector<T> h(n);
+  if (n) MFM_HIP_CHECK(hipMemcpyAsync(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipStreamSynchronize(s));
+  return h;
+}
+
+}  // namespace cpd
+
+bool cell_plan_build_device(CellPlan &cp, const DevSparse &X, const std::vector<CellBlockDev> &blocks, int n_cu, hipStream_t s) {
+  using namespace cpd;
+  cp.ready = false;
+  cp.streams.clear();
+  cp.fields.clear();
+  const int64_t N = X.rows;
+  cp.N = N;
+  if (N >= (int64_t)2147483647) return cp.fail("too many rows");
+  if (N <= 0) return cp.fail("no rows");
+  const int64_t W = X.ell_width;
+  if (W < 1 || W > CELL_MAX_STREAMS || !X.unit || X.nnz != N * W) return cp.fail("the main table is not a row of one-hot fields");
+  if (blocks.size() > (size_t)MAXB) return cp.fail("too many fields");
+  auto grid = [](int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); };
+  // fields: column ranges of the W entries of a row, order of the first
+  DevBuf<int32_t> red;
+  {
+    std::vector<int32_t> r0((size_t)2 * W + 1, 0);
+    for (int64_t p = 0; p < W; p++) {
+      r0[2 * p] = 0x7fffffff;
+      r0[2 * p + 1] = -1;
+    }
+    red.upload(r0);
+  }
+  hipLaunchKernelGGL(k_fields, grid(N), dim3(TB), 0, s, X.colidx.p, N, (int)W, red.p);
+  const std::vector<int32_t> h_red = download(red.p, (size_t)2 * W + 1, s);
+  if (h_red[2 * W]) return cp.fail("the rows are not sorted by the first field");
+  for (int64_t p = 1; p < W; p++)
+    if (h_red[2 * p] <= h_red[2 * (p - 1) + 1])
+      return cp.fail("the main table is not a row of unit-valued one-hot fields with disjoint column ranges");
+  std::vector<int64_t> base((size_t)W + 1, 0);
+  for (int64_t p = 1; p < W; p++) base[p] = h_red[2 * p];
+  base[W] = X.cols;
+  // streams: which block's map equals which stream on every row (all pairs in one pass)
+  Src sr;
+  sr.W = (int)W;
+  sr.nb = (int)blocks.size();
+  for (int64_t p = 0; p < W; p++) sr.base[p] = (int32_t)base[p];
+  for (size_t b = 0; b < blocks.size(); b++) sr.map[b] = blocks[b].map;
+  const int nc = sr.W + sr.nb;
+  std::vector<int32_t> h_diff;
+  if (sr.nb) {
+    DevBuf<int32_t> diff;
+    diff.alloc_zero((size_t)sr.nb * nc, s);
+    hipLaunchKernelGGL(k_stream_diff, grid(N), dim3(TB), 0, s, X.colidx.p, sr, N, diff.p);
+    h_diff = download(diff.p, (size_t)sr.nb * nc, s);
+  }
+  std::vector<CellStreamSrc> src;
+  {
+    std::vector<int64_t> Bs;
+    for (auto &b : blocks) Bs.push_back(b.B);
+    if (!cell_plan_streams(cp, W, base, Bs, src, [&](size_t b, const CellStreamSrc &c) {
+          return h_diff[b * nc + (c.main_p >= 0 ? c.main_p : sr.W + c.block)] != 0;
+        }))
+      return false;
+  }
+  // groups of consecutive U values, rows balanced; more (smaller) groups until every pass of the sweep fits its LDS
+  const int64_t cardU = cp.streams[0].card;
+  std::vector<int32_t> h_grow, gu0;
+  bool fits = false;
+  {
+    DevBuf<int32_t> out_r, out_u;
+    const int64_t Gmax = (int64_t)std::max(1, n_cu) * 16;
+    out_r.alloc((size_t)Gmax);
+    out_u.alloc((size_t)Gmax);
+    for (int mult = 1; mult <= 16 && !fits; mult *= 2) {
+      const int64_t G0 = (int64_t)std::max(1, n_cu) * mult;
+      const int64_t target = (N + G0 - 1) / G0;
+      hipLaunchKernelGGL(k_grow, grid(G0), dim3(TB), 0, s, X.colidx.p, (int)W, N, target, (int)G0, (int32_t)cardU, out_r.p, out_u.p);
+      const std::vector<int32_t> hr = download(out_r.p, (size_t)G0, s), hu = download(out_u.p, (size_t)G0, s);
+      h_grow.assign(1, 0);
+      gu0.assign(1, 0);
+      for (int64_t g = 1; g < G0; g++)
+        if (hr[g] > h_grow.back() && hr[g] < N) {
+          h_grow.push_back(hr[g]);
+          gu0.push_back(hu[g]);
+        }
+      h_grow.push_back((int32_t)N);
+      gu0.push_back((int32_t)cardU);
+      fits = cell_plan_groups_fit(cp, gu0);
+    }
+  }
+  const int G = cp.G;
+  const int64_t cardI = cp.sI >= 0 ? cp.streams[cp.sI].card : 0;
+  if (!fits)
+    return cp.fail("a group's tables do not fit the LDS (a first-field value with too many rows, or too many values per group)");
+  if (cardI > 0 && (double)G * (double)cardI * 56.0 > 16e9) return cp.fail("the (group, item) partials would not fit");
+  const bool has_i = cp.sI >= 0;
+  const int ibits = has_i ? bits_for(cardI) : 0, gbits = bits_for(G);
+  if (ibits + gbits > 32) return cp.fail("device planner: (group, item) sort key wider than 32 bits");
+  constexpr int WROWS = 64 * CELL_R;
+  DevBuf<int32_t> grow, d_gu0, c0, steps;
+  grow.upload(h_grow);
+  d_gu0.upload(gu0);
+  // the rows of every group by I index: one stable radix sort of (group, I index)
+  DevBuf<uint32_t> key, key2;
+  DevBuf<int32_t> val, val2;
+  DevBuf<char> tmp;
+  if (has_i) {
+    key.alloc((size_t)N);
+    key2.alloc((size_t)N);
+    val.alloc((size_t)N);
+    val2.alloc((size_t)N);
+    const CellStreamSrc &ci = src[(size_t)cp.sI];
+    hipLaunchKernelGGL(k_keys, grid(N), dim3(TB), (size_t)(G + 1) * sizeof(int32_t), s, X.colidx.p, (int)W, ci.main_p,
+                       ci.main_p >= 0 ? (int32_t)base[ci.main_p] : 0, ci.block >= 0 ? blocks[(size_t)ci.block].map : nullptr, grow.p, G, ibits,
+                       N, key.p, val.p);
+    size_t bytes = 0;
+    MFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, key.p, key2.p, val.p, val2.p, (int)N, 0, ibits + gbits, s));
+    tmp.alloc(bytes);
+    MFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, key.p, key2.p, val.p, val2.p, (int)N, 0, ibits + gbits, s));
+  }
+  c0.alloc((size_t)G * (CELL_NW + 1));
+  steps.alloc((size_t)G);
+  cp.chunk_len.alloc((size_t)G * CELL_NW);
+  hipLaunchKernelGGL(k_chunk_cuts, grid((int64_t)G * (CELL_NW + 1) * 64), dim3(TB), 0, s, key2.p, grow.p, G, has_i, c0.p);
+  hipLaunchKernelGGL(k_chunk_fin, grid(G), dim3(TB), 0, s, c0.p, G, WROWS, cp.chunk_len.p, steps.p);
+  const std::vector<int32_t> h_steps = download(steps.p, (size_t)G, s);
+  std::vector<int32_t> gbase((size_t)G + 1, 0);
+  int64_t npad = 0;
+  for (int g = 0; g < G; g++) {
+    gbase[g] = (int32_t)npad;
+    npad += (int64_t)h_steps[g] * WROWS * CELL_NW;
+  }
+  if (npad >= (int64_t)2147483647) return cp.fail("padded row count exceeds 2^31");
+  gbase[G] = (int32_t)npad;
+  cp.Npad = npad;
+  cp.grp_base.upload(gbase);
+  cp.grp_u0.upload(gu0);
+  cp.grp_steps.upload(h_steps);
+  cp.perm.alloc((size_t)npad);
+  cp.ix.alloc((size_t)npad);
+  MFM_HIP_CHECK(hipMemsetAsync(cp.perm.p, 0xff, (size_t)npad * sizeof(int32_t), s));
+  MFM_HIP_CHECK(hipMemsetAsync(cp.ix.p, 0, (size_t)npad * sizeof(uint2), s));
+  if (cp.item32) {
+    cp.item.alloc((size_t)npad);
+    MFM_HIP_CHECK(hipMemsetAsync(cp.item.p, 0, (size_t)npad * sizeof(int32_t), s));
+  } else {
+    cp.item = DevBuf<int32_t>();
+  }
+  RecSrc rs;
+  rs.ns = (int)cp.streams.size();
+  for (int si = 0; si < rs.ns; si++) {
+    rs.slot[si] = cp.streams[si].slot;
+    rs.main_p[si] = src[si].main_p;
+    rs.base[si] = src[si].main_p >= 0 ? (int32_t)base[src[si].main_p] : 0;
+    rs.map[si] = src[si].block >= 0 ? blocks[(size_t)src[si].block].map : nullptr;
+  }
+  hipLaunchKernelGGL(k_records, grid(N), dim3(TB), has_i ? 0 : (size_t)(G + 1) * sizeof(int32_t), s, key2.p, val2.p, X.colidx.p, (int)W, rs,
+                     grow.p, c0.p, cp.grp_base.p, cp.grp_u0.p, G, ibits, has_i, WROWS, N, cp.ix.p, cp.item.p, cp.perm.p);
+  MFM_HIP_CHECK(hipGetLastError());
+  cell_plan_buffers(cp, s);  // (synchronises: the sort buffers go out of scope)
+  cp.ready = true;
+  return true;
+}
+
+// tests (MFM_PLAN_CHECK): every array of two plans of the same design
+std::string cell_plan_compare(const CellPlan &a, const CellPlan &b, hipStream_t s) {
+  if (a.N != b.N || a.Npad != b.Npad || a.G != b.G || a.sU != b.sU || a.sI != b.sI || a.item32 != b.item32 || a.umax != b.umax ||
+      a.streams.size() != b.streams.size() || a.fields.size() != b.fields.size())
+    return "scalars";
+  for (size_t i = 0; i < a.streams.size(); i++)
+    if (a.streams[i].type != b.streams[i].type || a.streams[i].slot != b.streams[i].slot || a.streams[i].card != b.streams[i].card ||
+        a.streams[i].fields != b.streams[i].fields)
+      return "streams";
+  for (size_t i = 0; i < a.fields.size(); i++)
+    if (a.fields[i].stream != b.fields[i].stream || a.fields[i].kind != b.fields[i].kind || a.fields[i].n != b.fields[i].n ||
+        a.fields[i].base != b.fields[i].base)
+      return "fields";
+  auto same = [&](const void *p, size_t np, const void *q, size_t nq, size_t elem) {
+    if (np != nq) return false;
+    std::vector<char> x(np * elem), y(nq * elem);
+    if (np) {
+      MFM_HIP_CHECK(hipMemcpyAsync(x.data(), p, np * elem, hipMemcpyDeviceToHost, s));
+      MFM_HIP_CHECK(hipMemcpyAsync(y.data(), q, nq * elem, hipMemcpyDeviceToHost, s));
+    }
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    return x == y;
+  };
+#define MFM_CP_CMP(f) \
+  if (!same(a.f.p, a.f.n, b.f.p, b.f.n, sizeof(*a.f.p))) return #f;
+  MFM_CP_CMP(ix)
+  MFM_CP_CMP(item)
+  MFM_CP_CMP(perm)
+  MFM_CP_CMP(chunk_len)
+  MFM_CP_CMP(grp_base)
+  MFM_CP_CMP(grp_u0)
+  MFM_CP_CMP(grp_steps)
+#undef MFM_CP_CMP
+  return "";
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -50,7 +50,7 @@ constexpr size_t CELL_LDS_BYTES = 156 * 1024;     // LDS a pass workgroup may us
 enum CellStreamType { CELL_U = 0, CELL_I = 1, CELL_C = 2 };
 
 struct CellBlockIn {  // a relation block as the planner sees it (host)
-  const int64_t *map;
+  const int32_t *map;
   int64_t B;
 };
 
@@ -131,6 +131,13 @@ struct CellPlan {
 // row-sharded: this rank's place among `world` ranks, sum_ranks = sum a host vector over the ranks
 bool cell_plan_build(CellPlan &cp, const HostCsr &X, const std::vector<CellBlockIn> &blocks, int n_cu, hipStream_t s, int rank = 0,
                      int world = 1, const std::function<void(std::vector<double> &)> &sum_ranks = nullptr);
+// the same plan built on the device (one GPU): X = the main table in device CSR, the blocks' maps as device int32 arrays
+struct CellBlockDev {
+  const int32_t *map;
+  int64_t B;
+};
+bool cell_plan_build_device(CellPlan &cp, const DevSparse &X, const std::vector<CellBlockDev> &blocks, int n_cu, hipStream_t s);
+std::string cell_plan_compare(const CellPlan &a, const CellPlan &b, hipStream_t s);  // "" or the first array that differs
 void cell_pack_e(hipStream_t s, CellPlan &cp, const double2 *eq);
 void cell_unpack_e(hipStream_t s, CellPlan &cp, double2 *eq);
 // per-stream tables of a pass from the fields' current tables: QA = q without field exA (skipped when !doA), QS = q without

@@ -418,6 +418,15 @@ struct BlockOverflow {
 
 
 // Device-resident sparse matrix: CSR (row passes: q-build, re-score) and CSC (column sweeps).
+static __global__ void k_iota_mul(int32_t *p, int64_t n, int32_t w) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (int32_t)(i * w);
+}
+static __global__ void k_fill_f64(double *p, int64_t n, double v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 struct DevSparse {
   int64_t rows = 0, cols = 0, nnz = 0;
   DevBuf<int32_t> rowptr, colidx;
@@ -428,6 +437,78 @@ struct DevSparse {
   double avg_row_nnz = 0;
   bool unit = false;      // every stored value is exactly 1.0 (one-hot designs): kernels skip the val arrays
   int32_t ell_width = -1; // every row has exactly this many entries (>= 0): kernels skip rowptr
+  // The CSR straight from the caller's arrays (scipy layout: int64 indptr, int32 indices, double data) -- validated as
+  // make_host_csr does, no host copy: the row pointers of a fixed-width table and the values of an all-ones table are written on
+  // the device, the rest is copied to it from where it lies.
+  void upload_raw(int64_t n_rows, int64_t n_cols, const int64_t *indptr, const int32_t *indices, const double *data) {
+    if (n_rows < 0 || n_cols < 0) throw Error(MFM_ERR_INVALID, "negative matrix shape");
+    if (indptr[0] != 0) throw Error(MFM_ERR_INVALID, "indptr[0] must be 0");
+    rows = n_rows;
+    cols = n_cols;
+    const int64_t w0 = rows > 0 ? indptr[1] - indptr[0] : -1;
+    std::atomic<int> bad(0), not_ell(0), not_unit(0);
+    parallel_ranges(rows, [&](int64_t lo, int64_t hi) {
+      for (int64_t i = lo; i < hi; i++) {
+        const int64_t w = indptr[i + 1] - indptr[i];
+        if (w < 0) bad = 1;
+        if (w != w0) not_ell = 1;
+      }
+    });
+    if (bad) throw Error(MFM_ERR_INVALID, "indptr must be non-decreasing");
+    nnz = indptr[rows];
+    if (nnz >= (int64_t)2147483647) throw Error(MFM_ERR_INVALID, "nnz must be < 2^31 per matrix");
+    parallel_ranges(nnz, [&](int64_t lo, int64_t hi) {
+      bool nu = false;
+      for (int64_t p = lo; p < hi; p++) {
+        if (indices[p] < 0 || indices[p] >= n_cols) bad = 1;
+        nu |= data[p] != 1.0;
+      }
+      if (nu) not_unit = 1;
+    });
+    if (bad) throw Error(MFM_ERR_INVALID, "column index out of range");
+    unit = nnz > 0 && !not_unit;
+    ell_width = rows > 0 && !not_ell ? (int32_t)w0 : -1;
+    avg_row_nnz = rows ? (double)nnz / rows : 0;
+    rowptr.alloc((size_t)rows + 1);
+    if (ell_width >= 0) {
+      hipLaunchKernelGGL(k_iota_mul, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, 0, rowptr.p, rows + 1, ell_width);
+    } else {
+      std::vector<int32_t> rp((size_t)rows + 1);
+      parallel_ranges(rows + 1, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++) rp[i] = (int32_t)indptr[i];
+      });
+      MFM_HIP_CHECK(hipMemcpy(rowptr.p, rp.data(), rp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    colidx.upload(indices, (size_t)nnz);
+    if (unit) {
+      rval.alloc((size_t)nnz);
+      hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, 0, rval.p, nnz, 1.0);
+    } else {
+      rval.upload(data, (size_t)nnz);
+    }
+    MFM_HIP_CHECK(hipDeviceSynchronize());
+  }
+  // the host copy of what upload_raw put on the device (the host planners, the checkers)
+  HostCsr download() const {
+    HostCsr X;
+    X.rows = rows;
+    X.cols = cols;
+    std::vector<int32_t> rp((size_t)rows + 1);
+    if (rows + 1 > 0) MFM_HIP_CHECK(hipMemcpy(rp.data(), rowptr.p, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    X.ptr.assign(rp.begin(), rp.end());
+    X.idx.resize((size_t)nnz);
+    X.val.resize((size_t)nnz);
+    if (nnz) {
+      MFM_HIP_CHECK(hipMemcpy(X.idx.data(), colidx.p, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+      MFM_HIP_CHECK(hipMemcpy(X.val.data(), rval.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return X;
+  }
+  void upload_csc(const HostCsr &Xt) {
+    colptr.upload(Xt.ptr);
+    rowidx.upload(Xt.idx);
+    cval.upload(Xt.val);
+  }
   void upload(const HostCsr &X, const HostCsr *Xt /* may be null: CSR only */) {
     rows = X.rows;
     cols = X.cols;
@@ -452,7 +533,13 @@ struct DevSparse {
     rp[(size_t)rows] = (int32_t)X.ptr[(size_t)rows];
     rowptr.upload(rp);
     colidx.upload(X.idx);
-    rval.upload(X.val);
+    if (unit && nnz >= ((int64_t)1 << 20)) {  // (all ones: written on the device instead of copied to it)
+      rval.alloc((size_t)nnz);
+      hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, 0, rval.p, nnz, 1.0);
+      MFM_HIP_CHECK(hipDeviceSynchronize());
+    } else {
+      rval.upload(X.val);
+    }
     avg_row_nnz = rows ? (double)nnz / rows : 0;
     if (Xt) {
       colptr.upload(Xt->ptr);

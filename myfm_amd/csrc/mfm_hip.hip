@@ -113,11 +113,19 @@ struct mfm_ctx {
   bool finalized = false;
 
   // host-side staging until finalize
-  HostCsr hX;
+  HostCsr hX;  // host copy of the main table: only when a host planner asks for it (host_main)
+  bool main_set = false, hX_valid = false;
+  const HostCsr &host_main() {
+    if (main_set && !hX_valid) {
+      hX = X.download();
+      hX_valid = true;
+    }
+    return hX;
+  }
   std::vector<double> hy;
   struct HostBlock {
     HostCsr X;
-    std::vector<int64_t> map;
+    std::unique_ptr<int32_t[]> map;  // original_to_block, 32-bit (first touched by the threads that fill it)
   };
   std::vector<HostBlock> hblocks;
   std::vector<int32_t> hgroup;
@@ -159,6 +167,7 @@ struct mfm_ctx {
   ResPlan res;                  // ... as one persistent launch with the residual resident on chip (mfm_res.hpp)
   // the persistent sweep's layout was built first, on the device, and took the table: X_t, the level plans and the row tiles of
   // the per-factor passes (their fall-back) are built when a call needs them (ensure_main_plans)
+  std::vector<DevBuf<int32_t>> pre_maps;  // the blocks' maps uploaded ahead of the blocks (mfm_finalize only)
   bool main_lazy = false;
   bool res_refused = false;  // the CUs of the persistent sweep were not ours to take
   int res_plan_cus = 0;      // workgroups the layout was asked for
@@ -996,8 +1005,17 @@ int mfm_set_main(mfm_ctx *ctx, int64_t N, int64_t D0, const int64_t *indptr, con
                  const double *y) {
   MFM_TRY(ctx)
   if (ctx->finalized) throw Error(MFM_ERR_RUNTIME, "design already finalized");
-  ctx->hX = make_host_csr(N, D0, indptr, indices, data);
-  ctx->hy.assign(y, y + N);
+  // straight to the device (validated on the way, no host copy: at config 5 the copy, its page faults and giving the 2.4 GB back
+  // cost 0.6 s); the host planners that want the table download it (host_main)
+  ctx->use_device();
+  ctx->hX = HostCsr();
+  ctx->hX_valid = false;
+  ctx->X = DevSparse();
+  ctx->X.upload_raw(N, D0, indptr, indices, data);
+  ctx->y.upload(y, (size_t)N);
+  ctx->N = N;
+  ctx->D0 = D0;
+  ctx->main_set = true;
   MFM_CATCH(ctx)
 }
 
@@ -1007,14 +1025,17 @@ int mfm_add_block(mfm_ctx *ctx, int64_t B, int64_t Db, const int64_t *indptr, co
   if (ctx->finalized) throw Error(MFM_ERR_RUNTIME, "design already finalized");
   mfm_ctx::HostBlock hb;
   hb.X = make_host_csr(B, Db, indptr, indices, data);
-  int64_t N = ctx->hX.rows;
+  int64_t N = ctx->N;
+  if (B >= (int64_t)2147483647) throw Error(MFM_ERR_INVALID, "a relation block must have fewer than 2^31 rows");
   std::atomic<int> bad(0);
+  hb.map.reset(new int32_t[(size_t)std::max<int64_t>(N, 1)]);  // (kept as 32-bit indices: half the bytes of the copy, and what the device wants)
   parallel_ranges(N, [&](int64_t lo, int64_t hi) {  // definitions.hpp:38-41
-    for (int64_t t = lo; t < hi; t++)
+    for (int64_t t = lo; t < hi; t++) {
       if (original_to_block[t] < 0 || original_to_block[t] >= B) bad = 1;
+      hb.map[t] = (int32_t)original_to_block[t];
+    }
   });
   if (bad) throw Error(MFM_ERR_RUNTIME, "index mapping points to non-existing row.");
-  hb.map.assign(original_to_block, original_to_block + N);
   ctx->hblocks.push_back(std::move(hb));
   MFM_CATCH(ctx)
 }
@@ -1289,8 +1310,11 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   if (ctx->finalized) throw Error(MFM_ERR_RUNTIME, "design already finalized");
   if (rank < 0) throw Error(MFM_ERR_INVALID, "rank must be non-negative");
   mfm_ctx *c = ctx;
-  c->N = c->hX.rows;
-  c->D0 = c->hX.cols;
+  if (!c->main_set) {  // (no main table was given: an empty one)
+    c->N = c->D0 = 0;
+    c->X.upload(HostCsr(), nullptr);
+    c->y.alloc(0);
+  }
   c->D = c->D0;
   for (auto &hb : c->hblocks) c->D += hb.X.cols;
   if (c->G == 0) throw Error(MFM_ERR_RUNTIME, "mfm_set_groups has not been called");
@@ -1303,28 +1327,26 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   // the parallel generator's jump polynomials (mfm_rng_set_program needs them right after this call): start computing
   // them now on a helper thread (a caller that knows the problem's size earlier has already asked: mfm_rng_prepare)
   c->rng.par_blocks = rng_prefetch_jumps(c->D, c->K, c->G, c->rng.par_blocks);
-  CodeWarmup::get().join();
   const bool tlog = std::getenv("MFM_SETUP_TIMING") != nullptr;
   auto tnow = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_prev = tnow();
+  CodeWarmup::get().join();
   auto lap = [&](const char *what) {
     if (!tlog) return;
     const double t = tnow();
     std::fprintf(stderr, "[mfm_finalize] %-28s %7.3f s\n", what, t - t_prev);
     t_prev = t;
   };
+  lap("(code object ready)");
   // main table
   HostCsr Xt_keep;  // (X_t outlives the planner's scope: the resident layout is built from it once the path is known)
   {
     HostCsr &Xt = Xt_keep;
     if (std::getenv("MFM_HOST_TRANSPOSE")) {
-      Xt = transpose_host(c->hX);
+      Xt = transpose_host(c->host_main());
       lap("transpose (host)");
-      c->X.upload(c->hX, &Xt);
-      lap("upload CSR + CSC");
-    } else {
-      c->X.upload(c->hX, nullptr);
-      lap("upload CSR");
+      c->X.upload_csc(Xt);
+      lap("upload CSC");
     }
     // a row of unit-valued one-hot fields + relation blocks on one GPU: update_w / update_V / update_e on index tuples, no
     // q-cache (mfm_cell.hpp). Decided first: when it takes the design, X_t, the main table's level plans and row tiles and
@@ -1357,11 +1379,50 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
         MFM_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
         if (const char *e = std::getenv("MFM_CELL_GROUPS")) n_cu = std::max(1, std::atoi(e));
         std::vector<CellBlockIn> bin;
-        for (auto &hb : c->hblocks) bin.push_back(CellBlockIn{hb.map.data(), hb.X.rows});
-        if (sh)
-          cell_plan_build(c->cell, c->hX, bin, n_cu, c->stream, c->comm.shard_set ? c->comm.rank : -1, c->comm.world, sum_ranks);
-        else
-          cell_plan_build(c->cell, c->hX, bin, n_cu, c->stream);
+        for (auto &hb : c->hblocks) bin.push_back(CellBlockIn{hb.map.get(), hb.X.rows});
+        if (sh) {
+          cell_plan_build(c->cell, c->host_main(), bin, n_cu, c->stream, c->comm.shard_set ? c->comm.rank : -1, c->comm.world, sum_ranks);
+        } else if (std::getenv("MFM_CELL_HOST_PLAN")) {
+          cell_plan_build(c->cell, c->host_main(), bin, n_cu, c->stream);
+        } else {
+          // one GPU: the plan is built on the device from the CSR and the blocks' maps (uploaded here, kept for the blocks)
+          const size_t nb = c->hblocks.size();
+          c->pre_maps.clear();
+          c->pre_maps.resize(nb);
+          {
+            std::vector<std::thread> pool;
+            std::vector<std::exception_ptr> errs(nb);
+            auto up = [&](size_t b) {
+              try {
+                MFM_HIP_CHECK(hipSetDevice(c->device));
+                c->pre_maps[b].upload(c->hblocks[b].map.get(), (size_t)c->N);
+              } catch (...) {
+                errs[b] = std::current_exception();
+              }
+            };
+            for (size_t b = 0; b + 1 < nb; b++) pool.emplace_back(up, b);
+            if (nb) up(nb - 1);
+            for (auto &t : pool) t.join();
+            for (auto &e : errs)
+              if (e) std::rethrow_exception(e);
+          }
+          lap("block maps to the device");
+          std::vector<CellBlockDev> bdev;
+          for (size_t b = 0; b < nb; b++) bdev.push_back(CellBlockDev{c->pre_maps[b].p, c->hblocks[b].X.rows});
+          cell_plan_build_device(c->cell, c->X, bdev, n_cu, c->stream);
+          if (!c->cell.ready && c->cell.why.rfind("device planner:", 0) == 0) {
+            cell_plan_build(c->cell, c->host_main(), bin, n_cu, c->stream);  // (a shape only the host planner handles)
+          } else if (std::getenv("MFM_PLAN_CHECK")) {  // tests: the host planner must give the same plan, array for array
+            lap("cell plan (device)");
+            CellPlan chk;
+            cell_plan_build(chk, c->host_main(), bin, n_cu, c->stream);
+            if (chk.ready != c->cell.ready) throw Error(MFM_ERR_RUNTIME, "plan check: device and host cell planners disagree: device '" + c->cell.why + "' host '" + chk.why + "'");
+            if (chk.ready) {
+              const std::string diff = cell_plan_compare(c->cell, chk, c->stream);
+              if (!diff.empty()) throw Error(MFM_ERR_RUNTIME, "plan check: device and host cell plans differ (" + diff + ")");
+            }
+          }
+        }
         c->cell_w = c->cell.ready && !std::getenv("MFM_NO_CELL_W");
         if (tlog)
           std::fprintf(stderr, "[mfm_finalize] cell plan: %s (G=%d umax=%lld streams=%zu fields=%zu item32=%d)\n",
@@ -1378,7 +1439,6 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     const bool lean = c->cell_w || c->main_lazy;
     if (!lean) plan_main_table(c, Xt, lap);
   }
-  c->y.upload(c->hy);
   c->eq.alloc_zero((size_t)c->N, c->stream);
   c->group.upload(c->hgroup);
   // features sorted by group (FMLearningConfig.hpp:41-46 group_vs_feature_index)
@@ -1413,7 +1473,8 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
         MFM_HIP_CHECK(hipSetDevice(c->device));
         built[b].reset(new DevBlock());
         built[b]->col_off = offs[b];
-        built[b]->build(c->hblocks[b].X, c->hblocks[b].map, c->N, c->KS, c->stream, c->cell_w);
+        built[b]->build(c->hblocks[b].X, c->hblocks[b].map.get(), c->N, c->KS, c->stream, c->cell_w,
+                        b < c->pre_maps.size() ? &c->pre_maps[b] : nullptr);
       } catch (...) {
         errs[b] = std::current_exception();
       }
@@ -1472,10 +1533,13 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
   lap("blocks, state, scratch");
   // host copies are no longer needed
+  lap("(sync)");
   c->hX = HostCsr();
-  c->hy.clear();
-  c->hy.shrink_to_fit();
+  c->hX_valid = false;
+  c->hy = std::vector<double>();
   c->hblocks.clear();
+  c->pre_maps.clear();
+  lap("host copies released");
   c->finalized = true;
   MFM_CATCH(ctx)
 }

@@ -203,6 +203,7 @@ struct JumpCache {
   int blocks = 0, n = -1;
   std::vector<uint32_t> tab;
   std::future<void> pending;
+  int pend_blocks = 0, pend_n = -1;  // what `pending` computes (under pmu)
   static JumpCache &inst() {
     static JumpCache c;
     return c;
@@ -226,13 +227,21 @@ struct JumpCache {
     // runs on a moved-out future, outside the lock
     std::unique_lock<std::mutex> pl(pmu);
     if (pending.valid()) {
+      if (pend_blocks == blocks_per_wg && pend_n >= n_entries) return;  // (already being computed: mfm_rng_prepare, then mfm_finalize)
       std::future<void> prev = std::move(pending);
       pl.unlock();
       prev.wait();
       pl.lock();
+      {
+        std::lock_guard<std::mutex> g(mu);
+        if (blocks == blocks_per_wg && n >= n_entries) return;
+      }
     }
-    if (!pending.valid())
+    if (!pending.valid()) {
+      pend_blocks = blocks_per_wg;
+      pend_n = n_entries;
       pending = std::async(std::launch::async, [this, blocks_per_wg, n_entries]() { compute(blocks_per_wg, n_entries); });
+    }
   }
   void wait_pending() {
     std::future<void> prev;
