@@ -491,11 +491,20 @@ struct DevBlock {
     lap("transpose (host)");
     X.upload(hX, &Xt);
     lap("upload");
+    // (the level schedule of the block's columns is computed on the device from its rows: column_levels_device)
+    DevCscView dev_view = DevCscView{X.colptr.p, X.rowidx.p, X.cval.p, s};
+    dev_view.rowptr = X.rowptr.p;
+    dev_view.colidx = X.colidx.p;
+    dev_view.n_rows = B;
+    dev_view.n_cols = Db;
+    dev_view.ell = (int)X.ell_width;
+    plan_V.dev_csc = plan_W.dev_csc = (B > 0 && nnz > 0 && !std::getenv("MFM_HOST_LEVELS")) ? &dev_view : nullptr;
     plan_V.build(Xt, PBlockV::R_W16, PBlockV::R_WG, coop_capacity<PBlockV>());
     lap("plan_V");
     plan_W.build(Xt, PBlockW::R_W16, PBlockW::R_WG, coop_capacity<PBlockW>(), false, false,
                  std::getenv("MFM_NO_PLAN_TWIN") ? nullptr : &plan_V);  // (the level schedule of the same matrix: computed once)
     lap("plan_W");
+    plan_V.dev_csc = plan_W.dev_csc = nullptr;  // (the view lives on this frame)
     // rows of a block row far apart in the table (lists longer than a workgroup handles at once) and a table that fits
     // in LDS: the statistics pass streams the training rows (k_unsync_stream) and needs no inverse map. (A map that is
     // sorted -- the block follows the table's row order -- has contiguous lists; those stay with the inverse-map kernels,

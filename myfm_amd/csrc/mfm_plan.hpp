@@ -296,9 +296,9 @@ struct DevCscView {
 };
 // Level schedule (level(j) = 1 + max level of earlier columns sharing a row with j) as the least fixed point of
 // level[c_k] >= level[c_{k-1}] + 1 over consecutive stored columns of every row: row-parallel relaxation passes with atomicMax
-// until nothing changes -- as many passes as there are levels, so this is for the shallow schedules of one-hot designs (deep
-// ones, e.g. multi-hot relation blocks, are scheduled on the host). flags[0]: something changed; flags[1]: a row's column
-// indices are not ascending (host schedule instead).
+// until nothing changes -- as many passes as there are levels: two or three for one-hot designs, hundreds for the deep schedules
+// of multi-hot relation blocks (still milliseconds). flags[0]: something changed; flags[1]: a row's column indices are not
+// ascending (host schedule instead).
 __global__ void k_dp_level_relax(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int64_t N, int ell,
                                  int32_t *__restrict__ level, int *__restrict__ flags) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,11 +326,18 @@ static inline bool column_levels_device(const DevCscView &dv, std::vector<int32_
   lv.alloc((size_t)dv.n_cols);
   fl.alloc(2);
   MFM_HIP_CHECK(hipMemsetAsync(lv.p, 0, (size_t)dv.n_cols * sizeof(int32_t), dv.stream));
+  MFM_HIP_CHECK(hipMemsetAsync(fl.p, 0, 2 * sizeof(int), dv.stream));
+  // (a pass settles at least one more level of every dependency path: shallow schedules are done after two or three; deep ones --
+  //  multi-hot relation blocks, hundreds of levels -- take as many passes as they have levels, a few tens of microseconds each.
+  //  The host reads the "changed" flag once per batch of passes; the batches grow, so a shallow schedule is not kept waiting.)
+  const int max_passes = std::getenv("MFM_LEVEL_PASSES") ? std::atoi(std::getenv("MFM_LEVEL_PASSES")) : 4096;
   bool done = false;
-  for (int pass = 0; pass < 16 && !done; pass++) {
-    MFM_HIP_CHECK(hipMemsetAsync(fl.p, 0, 2 * sizeof(int), dv.stream));
-    hipLaunchKernelGGL(k_dp_level_relax, dim3((unsigned)((dv.n_rows + 255) / 256)), dim3(256), 0, dv.stream, dv.rowptr, dv.colidx,
-                       dv.n_rows, dv.ell, lv.p, fl.p);
+  for (int pass = 0, batch = 1; pass < max_passes && !done; pass += batch, batch = std::min(batch * 2, 32)) {
+    for (int k = 0; k < batch; k++) {  // fl[0]: did the LAST pass of the batch change anything?
+      if (k == batch - 1) MFM_HIP_CHECK(hipMemsetAsync(fl.p, 0, sizeof(int), dv.stream));
+      hipLaunchKernelGGL(k_dp_level_relax, dim3((unsigned)((dv.n_rows + 255) / 256)), dim3(256), 0, dv.stream, dv.rowptr, dv.colidx,
+                         dv.n_rows, dv.ell, lv.p, fl.p);
+    }
     int h[2] = {0, 0};
     MFM_HIP_CHECK(hipMemcpyAsync(h, fl.p, 2 * sizeof(int), hipMemcpyDeviceToHost, dv.stream));
     MFM_HIP_CHECK(hipStreamSynchronize(dv.stream));
@@ -343,6 +350,59 @@ static inline bool column_levels_device(const DevCscView &dv, std::vector<int32_
   n_levels = 0;
   for (int32_t l : level) n_levels = std::max(n_levels, l + 1);
   return true;
+}
+// First look at a level (one wavefront per column of it, on the device CSC): entries that do not follow their predecessor's
+// row directly (0: every column is a contiguous row range), entries 8 or more rows after it (the scatter decision), rows seen
+// more than once (seen != null: does the level touch every row exactly once?). out[3], zeroed by the caller.
+__global__ __launch_bounds__(WG) void k_dp_level_scan(const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
+                                                       const int32_t *__restrict__ cols, int n_cols, int32_t *__restrict__ seen,
+                                                       unsigned long long *__restrict__ out) {
+  const int c = blockIdx.x * (WG / WAVE) + (threadIdx.x >> 6);
+  if (c >= n_cols) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t b = colptr[cols[c]], e = colptr[cols[c] + 1];
+  unsigned long long gap = 0, far = 0, twice = 0;
+  for (int64_t p = b + lane; p < e; p += WAVE) {
+    const int32_t r = rowidx[p];
+    if (p > b) {
+      const int32_t d = r - rowidx[p - 1];
+      gap += d != 1;
+      far += d >= 8;
+    }
+    if (seen) twice += atomicAdd(&seen[r], 1) > 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    gap += __shfl_xor(gap, off);
+    far += __shfl_xor(far, off);
+    twice += __shfl_xor(twice, off);
+  }
+  if (lane == 0) {
+    if (gap) atomicAdd(&out[0], gap);
+    if (far) atomicAdd(&out[1], far);
+    if (twice) atomicAdd(&out[2], twice);
+  }
+}
+struct LevelScan {
+  bool valid = false;
+  int64_t gaps = 0, far = 0, twice = 0;
+};
+static inline LevelScan level_scan_device(const DevCscView &dv, const int32_t *d_cols, int n_cols, bool want_once) {
+  LevelScan r;
+  if (!dv.colptr || !dv.rowidx || n_cols <= 0) return r;
+  DevBuf<unsigned long long> out;
+  DevBuf<int32_t> seen;
+  out.alloc_zero(3, dv.stream);
+  if (want_once) seen.alloc_zero((size_t)std::max<int64_t>(dv.n_rows, 1), dv.stream);
+  hipLaunchKernelGGL(k_dp_level_scan, dim3((unsigned)((n_cols + WG / WAVE - 1) / (WG / WAVE))), dim3(WG), 0, dv.stream, dv.colptr, dv.rowidx,
+                     d_cols, n_cols, seen.p, out.p);
+  unsigned long long h[3] = {0, 0, 0};
+  MFM_HIP_CHECK(hipMemcpyAsync(h, out.p, sizeof h, hipMemcpyDeviceToHost, dv.stream));
+  MFM_HIP_CHECK(hipStreamSynchronize(dv.stream));
+  r.valid = true;
+  r.gaps = (int64_t)h[0];
+  r.far = (int64_t)h[1];
+  r.twice = (int64_t)h[2];
+  return r;
 }
 __device__ __forceinline__ int dp_upper_tile(const int32_t *tstart, int nb, int r) {  // tile b with tstart[b] <= r < tstart[b + 1]
   int lo = 0, hi = nb;
@@ -468,15 +528,20 @@ struct StepPlan {
   // L untouched) when the level is small or its columns are mostly contiguous.
   // tile_bits > 0: row-tile variant (tiles of 2^tile_bits rows staged in LDS, packed + padded entries)
   static bool build_scattered(const HostCsr &csc, const std::vector<int32_t> &cols, int64_t lnnz, bool unit, ParLevel &L,
-                              int tile_bits = 0, const std::vector<int32_t> *bounds = nullptr, const DevCscView *dev = nullptr) {
+                              int tile_bits = 0, const std::vector<int32_t> *bounds = nullptr, const DevCscView *dev = nullptr,
+                              const LevelScan *scan = nullptr) {
     int64_t min_nnz = 1 << 16;  // (measured: the tile path and the fusions it enables win from ~10^5 entries per level on)
     if (const char *e = std::getenv("MFM_SCATTER_MIN_NNZ")) min_nnz = std::atoll(e);
     if (lnnz < min_nnz) return false;
     if (const char *e = std::getenv("MFM_NO_SCATTER"))
       if (std::atoi(e)) return false;
     int64_t far = 0;
-    for (int32_t j : cols)
-      for (int64_t p = csc.ptr[j] + 1; p < csc.ptr[j + 1]; p++) far += (csc.idx[p] - csc.idx[p - 1]) >= 8;
+    if (scan && scan->valid) {
+      far = scan->far;  // (counted on the device: level_scan_device)
+    } else {
+      for (int32_t j : cols)
+        for (int64_t p = csc.ptr[j] + 1; p < csc.ptr[j + 1]; p++) far += (csc.idx[p] - csc.idx[p - 1]) >= 8;
+    }
     if ((double)far < 0.5 * (double)lnnz) return false;
     const int64_t N = csc.cols;
     if (tile_bits > 0) {
@@ -1160,13 +1225,38 @@ struct StepPlan {
           continue;
         }
       }
+      // first look at the level -- contiguous columns? far-apart rows? every row exactly once? -- on the device when the CSC is there
+      const bool want_once = steps.size() == 1 && lnnz == csc.cols;
+      LevelScan scan;
+      if (dev_csc && !std::getenv("MFM_HOST_LEVEL_SCAN")) {
+        scan = level_scan_device(*dev_csc, L.cols_all.p, L.n_all, want_once);
+        if (scan.valid && std::getenv("MFM_PLAN_CHECK")) {  // tests: the host's counts
+          int64_t gaps = 0, far = 0, twice = 0;
+          std::vector<char> seen(want_once ? (size_t)csc.cols : 0, 0);
+          for (int32_t j : by_level[l])
+            for (int64_t p = csc.ptr[j]; p < csc.ptr[j + 1]; p++) {
+              if (p > csc.ptr[j]) {
+                gaps += csc.idx[p] != csc.idx[p - 1] + 1;
+                far += (csc.idx[p] - csc.idx[p - 1]) >= 8;
+              }
+              if (want_once) {
+                twice += seen[csc.idx[p]];
+                seen[csc.idx[p]] = 1;
+              }
+            }
+          if (gaps != scan.gaps || far != scan.far || twice != scan.twice)
+            throw Error(MFM_ERR_RUNTIME, "plan check: device and host level scans differ");
+        }
+      }
       if (allow_scatter && build_scattered(csc, by_level[l], lnnz, unit, L, (sharded && !sharded_tiles) ? 0 : tile_bits,
-                                           aligned_tiles ? &h_tile_start : nullptr, dev_csc)) {
+                                           aligned_tiles ? &h_tile_start : nullptr, dev_csc, &scan)) {
         launches += 3;
         max_cols_scat = std::max<int64_t>(max_cols_scat, csc.rows);
         continue;
       }
-      if (steps.size() == 1 && lnnz == csc.cols) {  // first step: does it touch every row exactly once?
+      if (want_once && scan.valid) {
+        L.first_and_once = scan.twice == 0;
+      } else if (want_once) {  // first step: does it touch every row exactly once?
         std::vector<char> seen((size_t)csc.cols, 0);
         bool once = true;
         for (int32_t j : by_level[l])
@@ -1179,7 +1269,8 @@ struct StepPlan {
       bin_columns(csc, by_level[l], L, cap_w1, cap_w4, cap_w16, cap_wg, coop_max);
       {
         bool contig = !std::getenv("MFM_NO_CONTIG");
-        for (size_t c = 0; contig && c < by_level[l].size(); c++) {
+        if (scan.valid) contig = contig && scan.gaps == 0;
+        for (size_t c = 0; !scan.valid && contig && c < by_level[l].size(); c++) {
           const int32_t j = by_level[l][c];
           for (int64_t p = csc.ptr[j] + 1; contig && p < csc.ptr[j + 1]; p++) contig = csc.idx[p] == csc.idx[p - 1] + 1;
         }
