@@ -119,6 +119,39 @@ struct ChainRun {
   mutable DevBuf<int32_t> col_group;             // group index of every chain column (filled at the first launch)
   mutable const int32_t *col_group_of = nullptr;  // ... from this group array
 
+  std::vector<int32_t> h_cols;  // the run's columns (a twin plan of the same matrix asks: the same run?)
+  // the other sweep's plan of the SAME matrix has this run already: non-owning views of its arrays (o outlives this)
+  void borrow(const ChainRun &o) {
+    desc.borrow(o.desc);
+    cols.borrow(o.cols);
+    n_cols = o.n_cols;
+    nnz = o.nnz;
+    batched = o.batched;
+    n_batches = o.n_batches;
+    max_hot = o.max_hot;
+    max_hot_ent = o.max_hot_ent;
+    batches.borrow(o.batches);
+    h_batches = o.h_batches;
+    h_cold_cnt = o.h_cold_cnt;
+    n_cold = o.n_cold;
+    cold_ptr.borrow(o.cold_ptr);
+    cold_row.borrow(o.cold_row);
+    cold_lcol.borrow(o.cold_lcol);
+    hot_ptr.borrow(o.hot_ptr);
+    hot_slot.borrow(o.hot_slot);
+    hot_rows.borrow(o.hot_rows);
+    cold_x.borrow(o.cold_x);
+    hot_x.borrow(o.hot_x);
+    bucketed = o.bucketed;
+    bk_ptr.borrow(o.bk_ptr);
+    bk_row.borrow(o.bk_row);
+    bk_lcol.borrow(o.bk_lcol);
+    hbk_ptr.borrow(o.hbk_ptr);
+    bk_cls.borrow(o.bk_cls);
+    bk_x.borrow(o.bk_x);
+    h_cols = o.h_cols;
+  }
+
   void build_batched(const HostCsr &csc, const std::vector<int32_t> &run, int hot_cap) {
     const int64_t n_rows = csc.cols;
     std::vector<int32_t> cnt((size_t)n_rows, 0), slot_of((size_t)n_rows, -1);
@@ -296,9 +329,8 @@ struct DevCscView {
 };
 // Level schedule (level(j) = 1 + max level of earlier columns sharing a row with j) as the least fixed point of
 // level[c_k] >= level[c_{k-1}] + 1 over consecutive stored columns of every row: row-parallel relaxation passes with atomicMax
-// until nothing changes -- as many passes as there are levels: two or three for one-hot designs, hundreds for the deep schedules
-// of multi-hot relation blocks (still milliseconds). flags[0]: something changed; flags[1]: a row's column indices are not
-// ascending (host schedule instead).
+// until nothing changes -- as many passes as there are levels: two or three for one-hot designs (deep schedules: k_dp_level_seq).
+// flags[0]: something changed; flags[1]: a row's column indices are not ascending (host schedule instead).
 __global__ void k_dp_level_relax(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int64_t N, int ell,
                                  int32_t *__restrict__ level, int *__restrict__ flags) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -319,6 +351,27 @@ __global__ void k_dp_level_relax(const int32_t *__restrict__ rowptr, const int32
     prev_l = l;
   }
 }
+// Deep schedules: the reference order itself, one workgroup walking the columns in index order -- level(j) = 1 + the
+// largest level an earlier column left on one of j's rows -- with the column's entries spread over the threads.
+__global__ __launch_bounds__(1024) void k_dp_level_seq(const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx, int n_cols,
+                                                        int32_t *rowlevel, int32_t *__restrict__ level) {
+  __shared__ int32_t red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int j = 0; j < n_cols; j++) {
+    const int64_t b = colptr[j], e = colptr[j + 1];
+    int32_t m = -1;
+    for (int64_t p = b + tid; p < e; p += 1024) m = max(m, rowlevel[rowidx[p]]);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+    if (lane == 0) red[wv] = m;
+    __syncthreads();
+    m = red[lane & 15];
+    for (int off = 8; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+    const int32_t lv = m + 1;
+    for (int64_t p = b + tid; p < e; p += 1024) rowlevel[rowidx[p]] = lv;
+    if (tid == 0) level[j] = lv;
+    __syncthreads();
+  }
+}
 static inline bool column_levels_device(const DevCscView &dv, std::vector<int32_t> &level, int32_t &n_levels) {
   if (!dv.colidx || dv.n_cols <= 0 || dv.n_rows <= 0 || (dv.ell < 0 && !dv.rowptr)) return false;
   DevBuf<int32_t> lv;
@@ -327,12 +380,11 @@ static inline bool column_levels_device(const DevCscView &dv, std::vector<int32_
   fl.alloc(2);
   MFM_HIP_CHECK(hipMemsetAsync(lv.p, 0, (size_t)dv.n_cols * sizeof(int32_t), dv.stream));
   MFM_HIP_CHECK(hipMemsetAsync(fl.p, 0, 2 * sizeof(int), dv.stream));
-  // (a pass settles at least one more level of every dependency path: shallow schedules are done after two or three; deep ones --
-  //  multi-hot relation blocks, hundreds of levels -- take as many passes as they have levels, a few tens of microseconds each.
-  //  The host reads the "changed" flag once per batch of passes; the batches grow, so a shallow schedule is not kept waiting.)
-  const int max_passes = std::getenv("MFM_LEVEL_PASSES") ? std::atoi(std::getenv("MFM_LEVEL_PASSES")) : 4096;
+  // (a pass settles at least one more level of every dependency path: the shallow schedules of one-hot designs are done after two
+  //  or three. A schedule that is still moving after 8 passes is a deep one -- multi-hot relation blocks: up to a level per
+  //  column -- and goes to the column-sequential kernel below: one launch, exact, a few microseconds per column.)
   bool done = false;
-  for (int pass = 0, batch = 1; pass < max_passes && !done; pass += batch, batch = std::min(batch * 2, 32)) {
+  for (int pass = 0, batch = 2; pass < 8 && !done; pass += batch, batch = 6) {
     for (int k = 0; k < batch; k++) {  // fl[0]: did the LAST pass of the batch change anything?
       if (k == batch - 1) MFM_HIP_CHECK(hipMemsetAsync(fl.p, 0, sizeof(int), dv.stream));
       hipLaunchKernelGGL(k_dp_level_relax, dim3((unsigned)((dv.n_rows + 255) / 256)), dim3(256), 0, dv.stream, dv.rowptr, dv.colidx,
@@ -344,7 +396,14 @@ static inline bool column_levels_device(const DevCscView &dv, std::vector<int32_
     if (h[1]) return false;
     done = h[0] == 0;
   }
-  if (!done) return false;
+  if (!done) {
+    if (!dv.colptr || !dv.rowidx || dv.n_cols > ((int64_t)1 << 17)) return false;  // (host schedule)
+    DevBuf<int32_t> rowlevel;
+    rowlevel.alloc((size_t)dv.n_rows);
+    MFM_HIP_CHECK(hipMemsetAsync(rowlevel.p, 0xff, (size_t)dv.n_rows * sizeof(int32_t), dv.stream));
+    hipLaunchKernelGGL(k_dp_level_seq, dim3(1), dim3(1024), 0, dv.stream, dv.colptr, dv.rowidx, (int)dv.n_cols, rowlevel.p, lv.p);
+    MFM_HIP_CHECK(hipStreamSynchronize(dv.stream));
+  }
   level.resize((size_t)dv.n_cols);
   MFM_HIP_CHECK(hipMemcpy(level.data(), lv.p, (size_t)dv.n_cols * sizeof(int32_t), hipMemcpyDeviceToHost));
   n_levels = 0;
@@ -1182,6 +1241,18 @@ struct StepPlan {
       steps.emplace_back();
       Step &s = steps.back();
       s.is_chain = true;
+      {  // the twin has the same run at the same place: its arrays serve both sweeps
+        const size_t si = steps.size() - 1;
+        const Step *tw = twin && si < twin->steps.size() && twin->steps[si].is_chain ? &twin->steps[si] : nullptr;
+        if (tw && !sharded && !twin->sharded && tw->chain.h_cols == run && !std::getenv("MFM_NO_CHAIN_TWIN")) {
+          s.chain.borrow(tw->chain);
+          launches += 1;
+          run.clear();
+          run_nnz = 0;
+          return;
+        }
+      }
+      s.chain.h_cols = run;
       s.chain.n_cols = (int)run.size();
       s.chain.nnz = run_nnz;
       s.chain.cols.upload(run);
