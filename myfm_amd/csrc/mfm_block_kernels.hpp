@@ -410,6 +410,86 @@ __global__ __launch_bounds__(WG) void k_block_score_cache(const int32_t *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
+static inline int cdiv_i(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- X_t = X.transpose() (BaseFMTrainer.hpp:61) on the device: a stable radix sort of the stored entries by column.
+// Entry order inside a column = ascending entry index = ascending row, exactly the host transpose. The planner (host)
+// receives the result by one bulk copy instead of building it with a 20-million-element scatter.
+__global__ void k_iota_u32(uint32_t *__restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (uint32_t)i;
+}
+__global__ void k_csc_fill(const uint32_t *__restrict__ perm, const int32_t *__restrict__ rowptr, const double *__restrict__ rval,
+                           int64_t nnz, int64_t n_rows, int ell, int32_t *__restrict__ rowidx, double *__restrict__ cval) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nnz) return;
+  const uint32_t p = perm[q];
+  int64_t row;
+  if (ell > 0) {
+    row = p / (uint32_t)ell;
+  } else {  // last row whose first entry is <= p
+    int64_t lo = 0, hi = n_rows;
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((uint32_t)rowptr[mid] <= p) lo = mid; else hi = mid;
+    }
+    row = lo;
+  }
+  rowidx[q] = (int32_t)row;
+  cval[q] = rval[p];
+}
+__global__ void k_colptr(const int32_t *__restrict__ keys_sorted, int64_t nnz, int64_t D, int64_t *__restrict__ colptr) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > D) return;
+  int64_t lo = 0, hi = nnz;  // first position with key >= j
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys_sorted[mid] < (int32_t)j) lo = mid + 1; else hi = mid;
+  }
+  colptr[j] = lo;
+}
+
+// fills X.colptr / rowidx / cval on the device from X's CSR and returns the host copy the planner reads
+static inline HostCsr transpose_device(DevSparse &X, hipStream_t s) {
+  HostCsr T;
+  T.rows = X.cols;
+  T.cols = X.rows;
+  const int64_t nnz = X.nnz, D = X.cols;
+  X.colptr.alloc((size_t)D + 1);
+  X.rowidx.alloc((size_t)std::max<int64_t>(nnz, 1));
+  X.cval.alloc((size_t)std::max<int64_t>(nnz, 1));
+  T.ptr.assign((size_t)D + 1, 0);
+  T.idx.resize((size_t)nnz);
+  T.val.resize((size_t)nnz);
+  if (nnz == 0) {
+    MFM_HIP_CHECK(hipMemsetAsync(X.colptr.p, 0, ((size_t)D + 1) * sizeof(int64_t), s));
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    return T;
+  }
+  DevBuf<int32_t> keys_out;
+  DevBuf<uint32_t> iota, perm;
+  keys_out.alloc((size_t)nnz);
+  iota.alloc((size_t)nnz);
+  perm.alloc((size_t)nnz);
+  hipLaunchKernelGGL(k_iota_u32, dim3(cdiv_i(nnz, 256)), dim3(256), 0, s, iota.p, nnz);
+  int end_bit = 1;
+  while (((int64_t)1 << end_bit) < std::max<int64_t>(D, 2)) end_bit++;
+  size_t tmp_bytes = 0;
+  MFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, X.colidx.p, keys_out.p, iota.p, perm.p, (int)nnz, 0, end_bit, s));
+  DevBuf<char> tmp;
+  tmp.alloc(tmp_bytes);
+  MFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, X.colidx.p, keys_out.p, iota.p, perm.p, (int)nnz, 0, end_bit, s));
+  hipLaunchKernelGGL(k_csc_fill, dim3(cdiv_i(nnz, 256)), dim3(256), 0, s, perm.p, X.rowptr.p, X.rval.p, nnz, X.rows,
+                     (int)(X.ell_width > 0 ? X.ell_width : 0), X.rowidx.p, X.cval.p);
+  hipLaunchKernelGGL(k_colptr, dim3(cdiv_i(D + 1, 256)), dim3(256), 0, s, keys_out.p, nnz, D, X.colptr.p);
+  MFM_HIP_CHECK(hipGetLastError());
+  MFM_HIP_CHECK(hipMemcpyAsync(T.ptr.data(), X.colptr.p, ((size_t)D + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipMemcpyAsync(T.idx.data(), X.rowidx.p, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipMemcpyAsync(T.val.data(), X.cval.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipStreamSynchronize(s));
+  return T;
+}
+
 // rows of the training table per block row (cardinality, definitions.hpp:65-68) on the device: a workgroup counts a contiguous
 // stretch of the map -- in an LDS table when the block has few rows, else with one global atomic per run of equal indices inside
 // a wavefront (a map that follows the table's order hits the same block row for many consecutive rows)
@@ -441,6 +521,12 @@ __global__ void k_block_card(const int32_t *__restrict__ map, int64_t N, int B, 
       atomicAdd(&cnt[v], len);
     }
   }
+}
+// descents of the map (0: it is sorted, the block follows the table's row order)
+__global__ void k_map_descents(const int32_t *__restrict__ map, int64_t N, int32_t *__restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool d = t > 0 && t < N && map[t] < map[t - 1];
+  if (__ballot(d) && (threadIdx.x & 63) == 0) atomicAdd(out, 1);
 }
 __global__ void k_block_card_rec(const int32_t *__restrict__ cnt, int64_t B, double *__restrict__ rec) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -487,10 +573,16 @@ struct DevBlock {
       std::fprintf(stderr, "[DevBlock::build B=%lld nnz=%lld] %-24s %7.3f s\n", (long long)B, (long long)nnz, what, t - t_prev);
       t_prev = t;
     };
-    HostCsr Xt = transpose_host(hX);
-    lap("transpose (host)");
-    X.upload(hX, &Xt);
-    lap("upload");
+    // X_B^T: on the device (a stable sort of the entries by column, one bulk copy back for the planner) unless the block is tiny
+    HostCsr Xt;
+    if (nnz >= ((int64_t)1 << 16) && !std::getenv("MFM_HOST_TRANSPOSE")) {
+      X.upload(hX, nullptr);
+      Xt = transpose_device(X, s);
+    } else {
+      Xt = transpose_host(hX);
+      X.upload(hX, &Xt);
+    }
+    lap("upload, transpose");
     // (the level schedule of the block's columns is computed on the device from its rows: column_levels_device)
     DevCscView dev_view = DevCscView{X.colptr.p, X.rowidx.p, X.cval.p, s};
     dev_view.rowptr = X.rowptr.p;
@@ -509,8 +601,34 @@ struct DevBlock {
     // in LDS: the statistics pass streams the training rows (k_unsync_stream) and needs no inverse map. (A map that is
     // sorted -- the block follows the table's row order -- has contiguous lists; those stay with the inverse-map kernels,
     // which then stream as well.)
+    // the map goes to the device first: everything that is O(N) about it -- is it sorted, the rows per block row (cardinality,
+    // definitions.hpp:65-68), the training rows of every block row (inverse map: a stable sort of the rows by block row) -- is
+    // done there; the host keeps what is O(B): list offsets, the length classes of the lists
+    if (pre_map && pre_map->n == (size_t)N && N > 0)
+      map = std::move(*pre_map);  // (already on the device: the cell planner read it there)
+    else
+      map.upload(hmap, (size_t)N);
+    DevBuf<int32_t> cnt;
+    cnt.alloc_zero((size_t)std::max<int64_t>(B, 1) + 1, s);  // (+ 1: the number of descents of the map)
+    if (N > 0) {
+      const bool lds = B <= CARD_LDS_MAX;
+      const int wgs = (int)std::min<int64_t>(1024, (N + 4 * WG - 1) / (4 * WG));
+      hipLaunchKernelGGL(k_block_card, dim3(wgs), dim3(WG), lds ? (size_t)B * sizeof(int32_t) : 0, s, map.p, N, (int)B, lds, cnt.p);
+      if (!lean) hipLaunchKernelGGL(k_map_descents, dim3(cdiv_i(N, 256)), dim3(256), 0, s, map.p, N, cnt.p + std::max<int64_t>(B, 1));
+    }
+    rec.alloc_zero((size_t)B * BLOCK_REC, s);
+    if (B > 0) hipLaunchKernelGGL(k_block_card_rec, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, cnt.p, B, rec.p);
+    std::vector<int64_t> iptr((size_t)B + 1, 0);
     bool sorted = true;
-    for (int64_t t = 1; t < N && sorted && !lean; t++) sorted = hmap[t] >= hmap[t - 1];
+    if (!lean) {
+      std::vector<int32_t> hc((size_t)std::max<int64_t>(B, 1) + 1);
+      MFM_HIP_CHECK(hipMemcpyAsync(hc.data(), cnt.p, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      MFM_HIP_CHECK(hipStreamSynchronize(s));
+      for (int64_t i = 0; i < B; i++) iptr[i + 1] = iptr[i] + hc[i];
+      sorted = hc[(size_t)std::max<int64_t>(B, 1)] == 0;
+    } else {
+      MFM_HIP_CHECK(hipStreamSynchronize(s));
+    }
     stream_unsync = !sorted && B >= 1 && B <= UNSYNC_STREAM_MAX_B && N >= 64 * B && N >= ((int64_t)1 << 20) &&
                     !std::getenv("MFM_NO_UNSYNC_STREAM");  // (short tables: too few workgroups to stream with)
     if (const char *e = std::getenv("MFM_UNSYNC_STREAM_FORCE")) stream_unsync = std::atoi(e) != 0 && B >= 1 && B <= UNSYNC_STREAM_MAX_B;
@@ -518,31 +636,30 @@ struct DevBlock {
     split_unsync = !sorted && !stream_unsync && N >= ((int64_t)1 << 20) && !std::getenv("MFM_NO_UNSYNC_SPLIT");
     if (const char *e = std::getenv("MFM_UNSYNC_SPLIT_FORCE")) split_unsync = std::atoi(e) != 0 && !stream_unsync;
     if (lean) stream_unsync = split_unsync = false;
-    std::vector<int64_t> iptr((size_t)B + 1, 0);
-    std::vector<double> hrec;
-    if (!lean) {  // (lean: the rows per block row are counted on the device, below; nothing else of this is needed)
-      if (N >= ((int64_t)1 << 22) && B <= ((int64_t)1 << 21)) {  // (long maps: the row counts on host threads)
-        std::mutex mx;
-        parallel_ranges(N, [&](int64_t lo, int64_t hi) {
-          std::vector<int32_t> cnt((size_t)B, 0);
-          for (int64_t t = lo; t < hi; t++) cnt[hmap[t]]++;
-          std::lock_guard<std::mutex> g(mx);
-          for (int64_t i = 0; i < B; i++) iptr[i + 1] += cnt[i];
-        });
-      } else {
-        for (int64_t t = 0; t < N; t++) iptr[hmap[t] + 1]++;
+    if (!stream_unsync && !lean && N > 0) {
+      // inverse map: the training rows ordered by block row, ascending inside a block row (a stable sort of (block row, t))
+      inv_rows.alloc((size_t)N);
+      DevBuf<int32_t> keys_out, iota;
+      keys_out.alloc((size_t)N);
+      iota.alloc((size_t)N);
+      hipLaunchKernelGGL(k_iota_u32, dim3(cdiv_i(N, 256)), dim3(256), 0, s, (uint32_t *)iota.p, N);
+      int end_bit = 1;
+      while (((int64_t)1 << end_bit) < std::max<int64_t>(B, 2)) end_bit++;
+      size_t tmp_bytes = 0;
+      MFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, map.p, keys_out.p, iota.p, inv_rows.p, (int)N, 0, end_bit, s));
+      DevBuf<char> tmp;
+      tmp.alloc(tmp_bytes);
+      MFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, map.p, keys_out.p, iota.p, inv_rows.p, (int)N, 0, end_bit, s));
+      MFM_HIP_CHECK(hipStreamSynchronize(s));
+      if (std::getenv("MFM_PLAN_CHECK") && hmap) {  // tests: the host's counting sort
+        std::vector<int32_t> want((size_t)N), got((size_t)N);
+        std::vector<int64_t> cur(iptr.begin(), iptr.end() - 1);
+        for (int64_t t = 0; t < N; t++) want[cur[hmap[t]]++] = (int32_t)t;
+        MFM_HIP_CHECK(hipMemcpy(got.data(), inv_rows.p, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (want != got) throw Error(MFM_ERR_RUNTIME, "plan check: device and host inverse block maps differ");
       }
-      hrec.assign((size_t)B * BLOCK_REC, 0.0);
-      for (int64_t i = 0; i < B; i++) {
-        hrec[(size_t)i * BLOCK_REC + 6] = (double)iptr[i + 1];  // cardinality, definitions.hpp:65-68
-        iptr[i + 1] += iptr[i];
-      }
-    }
-    std::vector<int32_t> irows;
-    if (!stream_unsync && !lean) {
-      irows.resize((size_t)N);
-      std::vector<int64_t> cur(iptr.begin(), iptr.end() - 1);
-      for (int64_t t = 0; t < N; t++) irows[cur[hmap[t]]++] = (int32_t)t;
+    } else {
+      inv_rows.alloc(0);
     }
     std::vector<int32_t> bw, bg, bl_, cptr;
     std::vector<InvChunk> ch;
@@ -564,27 +681,8 @@ struct DevBlock {
     n_inv_wg = (int)bg.size();
     n_inv_long = (int)bl_.size();
     n_inv_chunks = (int)ch.size();
-    lap("counts, inverse");
-    if (pre_map && pre_map->n == (size_t)N && N > 0)
-      map = std::move(*pre_map);  // (already on the device: the cell planner read it there)
-    else
-      map.upload(hmap, (size_t)N);
-    if (lean) {
-      rec.alloc_zero((size_t)B * BLOCK_REC, s);
-      DevBuf<int32_t> cnt;
-      cnt.alloc_zero((size_t)std::max<int64_t>(B, 1), s);
-      if (N > 0) {
-        const bool lds = B <= CARD_LDS_MAX;
-        const int wgs = (int)std::min<int64_t>(1024, (N + 4 * WG - 1) / (4 * WG));
-        hipLaunchKernelGGL(k_block_card, dim3(wgs), dim3(WG), lds ? (size_t)B * sizeof(int32_t) : 0, s, map.p, N, (int)B, lds, cnt.p);
-      }
-      if (B > 0) hipLaunchKernelGGL(k_block_card_rec, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, cnt.p, B, rec.p);
-      MFM_HIP_CHECK(hipStreamSynchronize(s));
-    } else {
-      rec.upload(hrec);
-    }
+    lap("map: counts, inverse (device)");
     inv_ptr.upload(iptr);
-    inv_rows.upload(irows);
     inv_wave.upload(bw);
     inv_wg.upload(bg);
     inv_long.upload(bl_);
@@ -617,7 +715,6 @@ struct DevBlock {
   }
 };
 
-static inline int cdiv_i(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // q_B (and q_S) for one coefficient vector theta (already offset to the block's first feature)
 static void block_rowcache(hipStream_t s, Timing &tm, DevBlock &B, const double *theta, bool with_qs) {

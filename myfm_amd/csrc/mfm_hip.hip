@@ -326,84 +326,6 @@ struct mfm_ctx {
 // =============================================================================================
 namespace mfm {
 
-// ---- X_t = X.transpose() (BaseFMTrainer.hpp:61) on the device: a stable radix sort of the stored entries by column.
-// Entry order inside a column = ascending entry index = ascending row, exactly the host transpose. The planner (host)
-// receives the result by one bulk copy instead of building it with a 20-million-element scatter.
-__global__ void k_iota_u32(uint32_t *__restrict__ p, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = (uint32_t)i;
-}
-__global__ void k_csc_fill(const uint32_t *__restrict__ perm, const int32_t *__restrict__ rowptr, const double *__restrict__ rval,
-                           int64_t nnz, int64_t n_rows, int ell, int32_t *__restrict__ rowidx, double *__restrict__ cval) {
-  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nnz) return;
-  const uint32_t p = perm[q];
-  int64_t row;
-  if (ell > 0) {
-    row = p / (uint32_t)ell;
-  } else {  // last row whose first entry is <= p
-    int64_t lo = 0, hi = n_rows;
-    while (hi - lo > 1) {
-      const int64_t mid = (lo + hi) >> 1;
-      if ((uint32_t)rowptr[mid] <= p) lo = mid; else hi = mid;
-    }
-    row = lo;
-  }
-  rowidx[q] = (int32_t)row;
-  cval[q] = rval[p];
-}
-__global__ void k_colptr(const int32_t *__restrict__ keys_sorted, int64_t nnz, int64_t D, int64_t *__restrict__ colptr) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j > D) return;
-  int64_t lo = 0, hi = nnz;  // first position with key >= j
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (keys_sorted[mid] < (int32_t)j) lo = mid + 1; else hi = mid;
-  }
-  colptr[j] = lo;
-}
-
-// fills X.colptr / rowidx / cval on the device from X's CSR and returns the host copy the planner reads
-static HostCsr transpose_device(DevSparse &X, hipStream_t s) {
-  HostCsr T;
-  T.rows = X.cols;
-  T.cols = X.rows;
-  const int64_t nnz = X.nnz, D = X.cols;
-  X.colptr.alloc((size_t)D + 1);
-  X.rowidx.alloc((size_t)std::max<int64_t>(nnz, 1));
-  X.cval.alloc((size_t)std::max<int64_t>(nnz, 1));
-  T.ptr.assign((size_t)D + 1, 0);
-  T.idx.resize((size_t)nnz);
-  T.val.resize((size_t)nnz);
-  if (nnz == 0) {
-    MFM_HIP_CHECK(hipMemsetAsync(X.colptr.p, 0, ((size_t)D + 1) * sizeof(int64_t), s));
-    MFM_HIP_CHECK(hipStreamSynchronize(s));
-    return T;
-  }
-  DevBuf<int32_t> keys_out;
-  DevBuf<uint32_t> iota, perm;
-  keys_out.alloc((size_t)nnz);
-  iota.alloc((size_t)nnz);
-  perm.alloc((size_t)nnz);
-  hipLaunchKernelGGL(k_iota_u32, dim3(cdiv(nnz, 256)), dim3(256), 0, s, iota.p, nnz);
-  int end_bit = 1;
-  while (((int64_t)1 << end_bit) < std::max<int64_t>(D, 2)) end_bit++;
-  size_t tmp_bytes = 0;
-  MFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, X.colidx.p, keys_out.p, iota.p, perm.p, (int)nnz, 0, end_bit, s));
-  DevBuf<char> tmp;
-  tmp.alloc(tmp_bytes);
-  MFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, X.colidx.p, keys_out.p, iota.p, perm.p, (int)nnz, 0, end_bit, s));
-  hipLaunchKernelGGL(k_csc_fill, dim3(cdiv(nnz, 256)), dim3(256), 0, s, perm.p, X.rowptr.p, X.rval.p, nnz, X.rows,
-                     (int)(X.ell_width > 0 ? X.ell_width : 0), X.rowidx.p, X.cval.p);
-  hipLaunchKernelGGL(k_colptr, dim3(cdiv(D + 1, 256)), dim3(256), 0, s, keys_out.p, nnz, D, X.colptr.p);
-  MFM_HIP_CHECK(hipGetLastError());
-  MFM_HIP_CHECK(hipMemcpyAsync(T.ptr.data(), X.colptr.p, ((size_t)D + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-  MFM_HIP_CHECK(hipMemcpyAsync(T.idx.data(), X.rowidx.p, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MFM_HIP_CHECK(hipMemcpyAsync(T.val.data(), X.cval.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost, s));
-  MFM_HIP_CHECK(hipStreamSynchronize(s));
-  return T;
-}
-
 static void fill_gather_args(std::vector<std::unique_ptr<DevBlock>> &blocks, BlockGatherArgs &g, BlockOverflow &ov, PinnedRing &ring,
                              hipStream_t s) {
   std::memset(&g, 0, sizeof(g));
