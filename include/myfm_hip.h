@@ -97,7 +97,8 @@ int mfm_set_main_levels(mfm_ctx *ctx, const int32_t *level, int64_t D0);
  * classification / ordered probit do not depend on how the rows are sharded.                         */
 int mfm_set_row_offset(mfm_ctx *ctx, int64_t first_global_row);
 
-/* main table X (N x D0) and targets y[N]; D0 may be 0 (base.py:230-233).                  */
+/* main table X (N x D0) and targets y[N]; D0 may be 0 (base.py:230-233). The arrays are validated and copied to the device
+ * before the call returns (no host copy is kept); the caller may free them afterwards.                                      */
 int mfm_set_main(mfm_ctx *ctx, int64_t N, int64_t D0, const int64_t *indptr, const int32_t *indices,
                  const double *data, const double *y);
 /* RelationBlock (definitions.hpp:30-52): block CSR (B x Db) + original_to_block[N].
