@@ -97,6 +97,274 @@ struct ParLevel {
   }
 };
 
+struct DevCscView {
+  const int64_t *colptr = nullptr;
+  const int32_t *rowidx = nullptr;
+  const double *cval = nullptr;
+  hipStream_t stream = nullptr;
+  // the same table by rows (level schedule on the device)
+  const int32_t *rowptr = nullptr;
+  const int32_t *colidx = nullptr;
+  int64_t n_rows = 0, n_cols = 0;
+  int ell = -1;  // >= 0: every row has exactly this many entries (rowptr not read)
+};
+
+// ---- conflict batches of a chain run built ON THE DEVICE (ChainRun::build_batched is the host form and the checker) ---
+// Device-scope accesses of the scratch counters (other waves of the workgroup wrote them through L2: never a stale L1 line)
+__device__ __forceinline__ int32_t cbb_ld(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cbb_st(int32_t *p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Batch boundaries: ONE workgroup walks the run's columns in order (the greedy is sequential: a column joins the batch while the
+// rows touched by more than one of its columns -- and their entries -- stay within the LDS budget), the entries of a column spread
+// over the threads. cnt[n_rows]: zero on entry and on exit. bstart[0 .. n_batches]: first column of every batch, then n_run.
+__global__ __launch_bounds__(1024) void k_cbb_bounds(const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
+                                                      const int32_t *__restrict__ run, int n_run, int hot_cap, int32_t *cnt,
+                                                      int32_t *__restrict__ bstart, int32_t *__restrict__ n_batches) {
+  __shared__ int ra[16], re[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int c = 0, n_hot = 0, n_ent = 0, nb = 0;
+  auto close = [&](int c1) {  // the batch [c, c1): counters back to zero
+    for (int k = c; k < c1; k++) {
+      const int64_t b = colptr[run[k]], e = colptr[run[k] + 1];
+      for (int64_t p = b + tid; p < e; p += 1024) cbb_st(&cnt[rowidx[p]], 0);
+    }
+    if (tid == 0) bstart[nb] = c;
+    nb++;
+    c = c1;
+    n_hot = n_ent = 0;
+    __syncthreads();
+  };
+  for (int e = 0; e < n_run; e++) {
+    if (e - c == CHAINB_MAXCOLS) close(e);
+    const int64_t b = colptr[run[e]], en = colptr[run[e] + 1];
+    int add = 0, ent = 0;
+    for (int64_t p = b + tid; p < en; p += 1024) {
+      const int k = cbb_ld(&cnt[rowidx[p]]);
+      add += k == 1;
+      ent += k == 1 ? 2 : (k > 1 ? 1 : 0);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      add += __shfl_xor(add, off);
+      ent += __shfl_xor(ent, off);
+    }
+    if (lane == 0) {
+      ra[wv] = add;
+      re[wv] = ent;
+    }
+    __syncthreads();
+    add = ent = 0;
+    for (int w = 0; w < 16; w++) {
+      add += ra[w];
+      ent += re[w];
+    }
+    __syncthreads();
+    if (e > c && (n_hot + add > hot_cap || n_ent + ent > (5 * hot_cap) / 2)) {
+      close(e);
+      add = ent = 0;  // (no counter is set any more: the column opens the next batch)
+    }
+    for (int64_t p = b + tid; p < en; p += 1024) {
+      int32_t *q = &cnt[rowidx[p]];
+      cbb_st(q, cbb_ld(q) + 1);  // (a column's rows are distinct: one writer per counter)
+    }
+    n_hot += add;
+    n_ent += ent;
+    __syncthreads();
+  }
+  close(n_run);
+  if (tid == 0) {
+    bstart[nb] = n_run;
+    *n_batches = nb;
+  }
+}
+
+// Per batch (a workgroup takes batches b = blockIdx.x, + gridDim.x, ... with its own scratch counters): rows touched by more than
+// one column of the batch = hot, numbered in ascending row order; every column's entries split, in order, into cold (row, local
+// column, value) and hot (slot, value). WRITE = false: only the counts (hot rows per batch, cold / hot entries per column).
+constexpr int CBB_MAX_HOT = 2048;
+template <bool WRITE>
+__global__ __launch_bounds__(1024) void k_cbb_batches(const int64_t *__restrict__ colptr, const int32_t *__restrict__ rowidx,
+                                                       const double *__restrict__ cval, const int32_t *__restrict__ run,
+                                                       const int32_t *__restrict__ bstart, int nb, int32_t *cnt_scr, int32_t *slot_scr,
+                                                       int64_t n_rows, int32_t *__restrict__ n_hot_out, int32_t *__restrict__ ccnt,
+                                                       int32_t *__restrict__ hcnt, const int32_t *__restrict__ cptr,
+                                                       const int32_t *__restrict__ hptr, const int32_t *__restrict__ hot_row0,
+                                                       int32_t *__restrict__ crow, int32_t *__restrict__ clcol, double *__restrict__ cx,
+                                                       int32_t *__restrict__ hslot, double *__restrict__ hx, int32_t *__restrict__ hrows,
+                                                       int *__restrict__ err) {
+  __shared__ int32_t hl[CBB_MAX_HOT];
+  __shared__ int n_hl;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int32_t *cnt = cnt_scr + (int64_t)blockIdx.x * n_rows, *slot = slot_scr + (int64_t)blockIdx.x * n_rows;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+    const int c0 = bstart[b], c1 = bstart[b + 1];
+    if (tid == 0) n_hl = 0;
+    for (int i = tid; i < CBB_MAX_HOT; i += 1024) hl[i] = 0x7fffffff;
+    __syncthreads();
+    for (int k = c0 + wv; k < c1; k += 16) {
+      const int64_t pb = colptr[run[k]], pe = colptr[run[k] + 1];
+      for (int64_t p = pb + lane; p < pe; p += 64) atomicAdd(&cnt[rowidx[p]], 1);
+    }
+    __syncthreads();
+    for (int k = c0 + wv; k < c1; k += 16) {
+      const int64_t pb = colptr[run[k]], pe = colptr[run[k] + 1];
+      for (int64_t p = pb + lane; p < pe; p += 64) {
+        const int32_t r = rowidx[p];
+        if (cbb_ld(&cnt[r]) > 1 && atomicCAS(&slot[r], -1, -2) == -1) {
+          const int i = atomicAdd(&n_hl, 1);
+          if (i < CBB_MAX_HOT) hl[i] = r;
+        }
+      }
+    }
+    __syncthreads();
+    const int nh = min(n_hl, CBB_MAX_HOT);
+    if (n_hl > CBB_MAX_HOT && tid == 0) *err = 1;
+    // hot rows in ascending order: bitonic sort of the padded list
+    for (int size = 2; size <= CBB_MAX_HOT; size <<= 1)
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = tid; t < CBB_MAX_HOT / 2; t += 1024) {
+          const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+          const bool up = (i & size) == 0;
+          const int32_t x = hl[i], y = hl[j];
+          if ((x > y) == up) {
+            hl[i] = y;
+            hl[j] = x;
+          }
+        }
+        __syncthreads();
+      }
+    for (int i = tid; i < nh; i += 1024) {
+      cbb_st(&slot[hl[i]], i);
+      if (WRITE) hrows[hot_row0[b] + i] = hl[i];
+    }
+    if (!WRITE && tid == 0) n_hot_out[b] = nh;
+    __syncthreads();
+    for (int k = c0 + wv; k < c1; k += 16) {
+      const int64_t pb = colptr[run[k]], pe = colptr[run[k] + 1];
+      int cb = 0, hb = 0;
+      for (int64_t p0 = pb; p0 < pe; p0 += 64) {
+        const int64_t p = p0 + lane;
+        const bool valid = p < pe;
+        const int32_t r = valid ? rowidx[p] : 0;
+        const bool hot = valid && cbb_ld(&cnt[r]) > 1;
+        const unsigned long long m = __ballot(hot), v = __ballot(valid);
+        if (WRITE) {
+          if (hot) {
+            const int q = hptr[k] + hb + __popcll(m & lt);
+            hslot[q] = cbb_ld(&slot[r]);
+            hx[q] = cval[p];
+          } else if (valid) {
+            const int q = cptr[k] + cb + __popcll(~m & v & lt);
+            crow[q] = r;
+            clcol[q] = k - c0;
+            cx[q] = cval[p];
+          }
+        }
+        hb += __popcll(m);
+        cb += __popcll(~m & v);
+      }
+      if (!WRITE && lane == 0) {
+        ccnt[k] = cb;
+        hcnt[k] = hb;
+      }
+    }
+    __syncthreads();
+    for (int k = c0 + wv; k < c1; k += 16) {
+      const int64_t pb = colptr[run[k]], pe = colptr[run[k] + 1];
+      for (int64_t p = pb + lane; p < pe; p += 64) cbb_st(&cnt[rowidx[p]], 0);
+    }
+    for (int i = tid; i < nh; i += 1024) cbb_st(&slot[hl[i]], -1);
+    __syncthreads();
+  }
+}
+
+// Row-bucketed copies for the grid form (k_cb_step / k_cb_persist): per batch the cold entries ordered by (row range, class,
+// column) -- class = (statistics near / far, update near / far): is the entry's row touched by the batch before / after? -- and the
+// hot slots' row ranges. ONE workgroup, batch by batch (the neighbours' rows are stamped as the host form stamps them).
+__global__ __launch_bounds__(1024) void k_cbb_buckets(const ChainBatch *__restrict__ bt, int nb, const int32_t *__restrict__ crow,
+                                                       const int32_t *__restrict__ clcol, const double *__restrict__ cx,
+                                                       const int32_t *__restrict__ hrows, int64_t n_rows, int split, int32_t *seen_prev,
+                                                       int32_t *seen_next, int32_t *__restrict__ bptr, int32_t *__restrict__ hbptr,
+                                                       int32_t *__restrict__ bcls, int32_t *__restrict__ brow, int32_t *__restrict__ blcol,
+                                                       double *__restrict__ bx) {
+  constexpr int NB = CB_BUCKETS, NK = NB * 4;
+  __shared__ int cntk[NK + 1], cur[NK], wcnt[16][NK], hc[NB + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int64_t nr = n_rows > 0 ? n_rows : 1;
+  auto stamp = [&](int32_t *seen, int b) {
+    const ChainBatch B = bt[b];
+    for (int p = B.cold_b + tid; p < B.cold_e; p += 1024) cbb_st(&seen[crow[p]], b);
+    for (int k = tid; k < B.n_hot; k += 1024) cbb_st(&seen[hrows[B.hot_row0 + k]], b);
+  };
+  for (int b = 0; b < nb; b++) {
+    const ChainBatch B = bt[b];
+    const int cb = B.cold_b, ce = B.cold_e;
+    if (b + 1 < nb) stamp(seen_next, b + 1);
+    for (int i = tid; i <= NK; i += 1024) cntk[i] = 0;
+    for (int i = tid; i <= NB; i += 1024) hc[i] = 0;
+    __syncthreads();
+    auto key_of = [&](int32_t r) {
+      const bool sn = b == 0 || cbb_ld(&seen_prev[r]) == b - 1 || !(split & 1);
+      const bool un = b + 1 == nb || cbb_ld(&seen_next[r]) == b + 1 || !(split & 2);
+      const int ord = sn ? (un ? 1 : 2) : (un ? 0 : 3);
+      return (int)(((int64_t)r * NB) / nr) * 4 + ord;
+    };
+    for (int p = cb + tid; p < ce; p += 1024) atomicAdd(&cntk[key_of(crow[p]) + 1], 1);
+    for (int k = tid; k < B.n_hot; k += 1024) atomicAdd(&hc[(int)(((int64_t)hrows[B.hot_row0 + k] * NB) / nr) + 1], 1);
+    __syncthreads();
+    if (tid == 0) {
+      cur[0] = cb;
+      for (int k = 1; k < NK; k++) cur[k] = cur[k - 1] + cntk[k];
+      int32_t *bp = bptr + (int64_t)b * (NB + 1);
+      for (int k = 0; k < NB; k++) {
+        bp[k] = cur[k * 4];
+        for (int q = 0; q < 3; q++) bcls[((int64_t)b * NB + k) * 3 + q] = cur[k * 4 + q + 1];
+      }
+      bp[NB] = ce;
+      int32_t *hp = hbptr + (int64_t)b * (NB + 1);
+      hp[0] = 0;
+      for (int k = 0; k < NB; k++) hp[k + 1] = hp[k] + hc[k + 1];  // (slots are in ascending row order)
+    }
+    __syncthreads();
+    // entries arrive ordered by column: a stable scatter by key gives (range, class, column) order
+    for (int base = cb; base < ce; base += 1024) {
+      const int p = base + tid;
+      const bool valid = p < ce;
+      const int32_t r = valid ? crow[p] : 0;
+      const int key = valid ? key_of(r) : -1;
+      wcnt[wv][lane] = 0;
+      int rank = 0;
+      unsigned long long rem = __ballot(valid);
+      while (rem) {
+        const int l0 = __ffsll((long long)rem) - 1;
+        const int k0 = __shfl(key, l0);
+        const unsigned long long m = __ballot(valid && key == k0);
+        if (valid && key == k0) rank = __popcll(m & lt);
+        if (lane == l0) wcnt[wv][k0] = __popcll(m);
+        rem &= ~m;
+      }
+      __syncthreads();
+      if (valid) {
+        int pos = cur[key] + rank;
+        for (int w = 0; w < wv; w++) pos += wcnt[w][key];
+        brow[pos] = r;
+        blcol[pos] = clcol[p];
+        bx[pos] = cx[p];
+      }
+      __syncthreads();
+      if (tid < NK) {
+        int t = 0;
+        for (int w = 0; w < 16; w++) t += wcnt[w][tid];
+        cur[tid] += t;
+      }
+      __syncthreads();
+    }
+    stamp(seen_prev, b);
+    __syncthreads();
+  }
+}
+
 struct ChainRun {
   DevBuf<ChainDesc> desc;  // (first CSC entry, length, column) per chain column, for k_chain_lds
   DevBuf<int32_t> cols;
@@ -150,6 +418,155 @@ struct ChainRun {
     bk_cls.borrow(o.bk_cls);
     bk_x.borrow(o.bk_x);
     h_cols = o.h_cols;
+  }
+
+  // the same structures built on the device from the device CSC (dv.colptr / rowidx / cval); false: not built (the caller takes
+  // the host form)
+  bool build_batched_device(const DevCscView &dv, const std::vector<int32_t> &run, int hot_cap) {
+    const int64_t n_rows = dv.n_rows;
+    const int n_run = (int)run.size();
+    if (!dv.colptr || !dv.rowidx || !dv.cval || !cols.p || n_run < 1 || n_rows < 1 || hot_cap > CBB_MAX_HOT) return false;
+    if (n_rows * 8 > ((int64_t)1 << 30)) return false;  // (scratch counters: 8 bytes per row and workgroup)
+    hipStream_t s = dv.stream;
+    auto dl = [&](const int32_t *p, size_t n) {
+      std::vector<int32_t> h(n);
+      if (n) MFM_HIP_CHECK(hipMemcpyAsync(h.data(), p, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      MFM_HIP_CHECK(hipStreamSynchronize(s));
+      return h;
+    };
+    // 1. batch boundaries
+    DevBuf<int32_t> cnt1, bstart, nbat;
+    cnt1.alloc_zero((size_t)n_rows, s);
+    bstart.alloc((size_t)n_run + 2);
+    nbat.alloc_zero(1, s);
+    hipLaunchKernelGGL(k_cbb_bounds, dim3(1), dim3(1024), 0, s, dv.colptr, dv.rowidx, cols.p, n_run, hot_cap, cnt1.p, bstart.p, nbat.p);
+    const int nb = dl(nbat.p, 1)[0];
+    const std::vector<int32_t> h_bstart = dl(bstart.p, (size_t)nb + 1);
+    // 2. per batch: counts, then the lists
+    const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)nb, 64, ((int64_t)1 << 28) / (8 * n_rows)}));
+    DevBuf<int32_t> cnt_scr, slot_scr, d_nhot, ccnt, hcnt;
+    DevBuf<int> err;
+    cnt_scr.alloc_zero((size_t)nwg * n_rows, s);
+    slot_scr.alloc((size_t)nwg * n_rows);
+    MFM_HIP_CHECK(hipMemsetAsync(slot_scr.p, 0xff, (size_t)nwg * n_rows * sizeof(int32_t), s));
+    d_nhot.alloc((size_t)nb);
+    ccnt.alloc((size_t)n_run);
+    hcnt.alloc((size_t)n_run);
+    err.alloc_zero(1, s);
+    hipLaunchKernelGGL((k_cbb_batches<false>), dim3(nwg), dim3(1024), 0, s, dv.colptr, dv.rowidx, dv.cval, cols.p, bstart.p, nb, cnt_scr.p,
+                       slot_scr.p, n_rows, d_nhot.p, ccnt.p, hcnt.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, err.p);
+    const std::vector<int32_t> h_nhot = dl(d_nhot.p, (size_t)nb), h_cc = dl(ccnt.p, (size_t)n_run), h_hc = dl(hcnt.p, (size_t)n_run);
+    {
+      int h_err = 0;
+      MFM_HIP_CHECK(hipMemcpy(&h_err, err.p, sizeof(int), hipMemcpyDeviceToHost));
+      if (h_err) return false;
+    }
+    std::vector<int32_t> cptr((size_t)n_run + 1, 0), hptr((size_t)n_run + 1, 0), hot_row0((size_t)nb + 1, 0);
+    for (int k = 0; k < n_run; k++) {
+      const int64_t c = (int64_t)cptr[k] + h_cc[k], h = (int64_t)hptr[k] + h_hc[k];
+      if (c >= (int64_t)2147483647 || h >= (int64_t)2147483647) return false;
+      cptr[k + 1] = (int32_t)c;
+      hptr[k + 1] = (int32_t)h;
+    }
+    std::vector<ChainBatch> bt((size_t)nb);
+    max_hot = max_hot_ent = 0;
+    for (int b = 0; b < nb; b++) {
+      hot_row0[b + 1] = hot_row0[b] + h_nhot[b];
+      ChainBatch &B = bt[b];
+      B.col0 = h_bstart[b];
+      B.ncols = h_bstart[b + 1] - h_bstart[b];
+      B.hot_row0 = hot_row0[b];
+      B.n_hot = h_nhot[b];
+      B.cold_b = cptr[B.col0];
+      B.cold_e = cptr[B.col0 + B.ncols];
+      B.hot_b = hptr[B.col0];
+      B.hot_e = hptr[B.col0 + B.ncols];
+      max_hot = std::max(max_hot, B.n_hot);
+      max_hot_ent = std::max(max_hot_ent, B.hot_e - B.hot_b);
+    }
+    n_batches = nb;
+    h_batches = bt;
+    h_cold_cnt.clear();
+    for (const ChainBatch &B : bt) h_cold_cnt.push_back(B.cold_e - B.cold_b);
+    n_cold = cptr[n_run];
+    const int64_t n_hot_ent = hptr[n_run];
+    batches.upload(bt.data(), bt.size());
+    cold_ptr.upload(cptr);
+    hot_ptr.upload(hptr);
+    DevBuf<int32_t> d_hot_row0;
+    d_hot_row0.upload(hot_row0);
+    cold_row.alloc((size_t)n_cold);
+    cold_lcol.alloc((size_t)n_cold);
+    cold_x.alloc((size_t)n_cold);
+    hot_slot.alloc((size_t)n_hot_ent);
+    hot_x.alloc((size_t)n_hot_ent);
+    hot_rows.alloc((size_t)hot_row0[nb]);
+    hipLaunchKernelGGL((k_cbb_batches<true>), dim3(nwg), dim3(1024), 0, s, dv.colptr, dv.rowidx, dv.cval, cols.p, bstart.p, nb, cnt_scr.p,
+                       slot_scr.p, n_rows, nullptr, nullptr, nullptr, cold_ptr.p, hot_ptr.p, d_hot_row0.p, cold_row.p, cold_lcol.p, cold_x.p,
+                       hot_slot.p, hot_x.p, hot_rows.p, err.p);
+    MFM_HIP_CHECK(hipGetLastError());
+    batched = true;
+    bucketed = false;
+    // 3. the grid form's row-bucketed copies
+    const int64_t grid_min = std::getenv("MFM_CHAIN_GRID_MIN") ? std::atoll(std::getenv("MFM_CHAIN_GRID_MIN")) : 4096;
+    if (n_batches > 0 && n_cold / n_batches >= grid_min && !std::getenv("MFM_NO_CHAIN_GRID") && !std::getenv("MFM_NO_CB_MERGE")) {
+      constexpr int NB = CB_BUCKETS;
+      const int split = std::getenv("MFM_NO_CB_PERSIST") ? 0 : std::getenv("MFM_CB_SPLIT") ? std::atoi(std::getenv("MFM_CB_SPLIT")) : 3;
+      DevBuf<int32_t> seen_prev, seen_next;
+      seen_prev.alloc((size_t)n_rows);
+      seen_next.alloc((size_t)n_rows);
+      MFM_HIP_CHECK(hipMemsetAsync(seen_prev.p, 0xff, (size_t)n_rows * sizeof(int32_t), s));
+      MFM_HIP_CHECK(hipMemsetAsync(seen_next.p, 0xff, (size_t)n_rows * sizeof(int32_t), s));
+      bk_ptr.alloc((size_t)n_batches * (NB + 1));
+      hbk_ptr.alloc((size_t)n_batches * (NB + 1));
+      bk_cls.alloc((size_t)n_batches * NB * 3);
+      bk_row.alloc((size_t)n_cold);
+      bk_lcol.alloc((size_t)n_cold);
+      bk_x.alloc((size_t)n_cold);
+      hipLaunchKernelGGL(k_cbb_buckets, dim3(1), dim3(1024), 0, s, batches.p, n_batches, cold_row.p, cold_lcol.p, cold_x.p, hot_rows.p, n_rows,
+                         split, seen_prev.p, seen_next.p, bk_ptr.p, hbk_ptr.p, bk_cls.p, bk_row.p, bk_lcol.p, bk_x.p);
+      MFM_HIP_CHECK(hipGetLastError());
+      MFM_HIP_CHECK(hipStreamSynchronize(s));
+      bucketed = true;
+    }
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    return true;
+  }
+  // tests (MFM_PLAN_CHECK): every array of two builds of the same run
+  std::string compare_batched(const ChainRun &o, hipStream_t s) const {
+    if (batched != o.batched || n_batches != o.n_batches || max_hot != o.max_hot || max_hot_ent != o.max_hot_ent || n_cold != o.n_cold ||
+        bucketed != o.bucketed || h_cold_cnt != o.h_cold_cnt)
+      return "scalars";
+    auto same = [&](const void *p, size_t np, const void *q, size_t nq, size_t elem) {
+      if (np != nq) return false;
+      std::vector<char> x(np * elem), y(nq * elem);
+      if (np) {
+        MFM_HIP_CHECK(hipMemcpyAsync(x.data(), p, np * elem, hipMemcpyDeviceToHost, s));
+        MFM_HIP_CHECK(hipMemcpyAsync(y.data(), q, nq * elem, hipMemcpyDeviceToHost, s));
+      }
+      MFM_HIP_CHECK(hipStreamSynchronize(s));
+      return x == y;
+    };
+#define MFM_CB_CMP(f) \
+  if (!same(f.p, f.n, o.f.p, o.f.n, sizeof(*f.p))) return #f;
+    MFM_CB_CMP(batches)
+    MFM_CB_CMP(cold_ptr)
+    MFM_CB_CMP(cold_row)
+    MFM_CB_CMP(cold_lcol)
+    MFM_CB_CMP(cold_x)
+    MFM_CB_CMP(hot_ptr)
+    MFM_CB_CMP(hot_slot)
+    MFM_CB_CMP(hot_x)
+    MFM_CB_CMP(hot_rows)
+    MFM_CB_CMP(bk_ptr)
+    MFM_CB_CMP(hbk_ptr)
+    MFM_CB_CMP(bk_cls)
+    MFM_CB_CMP(bk_row)
+    MFM_CB_CMP(bk_lcol)
+    MFM_CB_CMP(bk_x)
+#undef MFM_CB_CMP
+    return "";
   }
 
   void build_batched(const HostCsr &csc, const std::vector<int32_t> &run, int hot_cap) {
@@ -316,17 +733,6 @@ struct Step {
 // whole wavefronts, runs per wave tile, column-major slot positions), from the device-resident CSC: a stable radix sort of
 // (tile << cbits | column) keys over the level's entries in (column, row) order, lower bounds for the tile / column
 // boundaries, an exclusive scan of the runs per wave tile, a second stable sort of the runs by column.
-struct DevCscView {
-  const int64_t *colptr = nullptr;
-  const int32_t *rowidx = nullptr;
-  const double *cval = nullptr;
-  hipStream_t stream = nullptr;
-  // the same table by rows (level schedule on the device)
-  const int32_t *rowptr = nullptr;
-  const int32_t *colidx = nullptr;
-  int64_t n_rows = 0, n_cols = 0;
-  int ell = -1;  // >= 0: every row has exactly this many entries (rowptr not read)
-};
 // Level schedule (level(j) = 1 + max level of earlier columns sharing a row with j) as the least fixed point of
 // level[c_k] >= level[c_{k-1}] + 1 over consecutive stored columns of every row: row-parallel relaxation passes with atomicMax
 // until nothing changes -- as many passes as there are levels: two or three for one-hot designs (deep schedules: k_dp_level_seq).
@@ -1262,8 +1668,23 @@ struct StepPlan {
         s.chain.desc.upload(d.data(), d.size());
       }
       // state too large for the LDS chain of any policy: also keep the conflict-batched form
-      if ((csc.cols > 1900 || std::getenv("MFM_CHAIN_FORCE_BATCHED")) && run.size() >= 2 && !std::getenv("MFM_NO_CHAIN_BATCHED"))
-        s.chain.build_batched(csc, run, std::getenv("MFM_CHAIN_HOT_CAP") ? std::max(64, std::atoi(std::getenv("MFM_CHAIN_HOT_CAP"))) : 1200);
+      if ((csc.cols > 1900 || std::getenv("MFM_CHAIN_FORCE_BATCHED")) && run.size() >= 2 && !std::getenv("MFM_NO_CHAIN_BATCHED")) {
+        const int hot_cap = std::getenv("MFM_CHAIN_HOT_CAP") ? std::max(64, std::atoi(std::getenv("MFM_CHAIN_HOT_CAP"))) : 1200;
+        // on the device when the matrix's CSC is there (relation blocks, the main table): the host form is the fall-back and,
+        // under MFM_PLAN_CHECK, the checker
+        const bool on_dev = dev_csc && !std::getenv("MFM_HOST_CHAIN_BATCHES") && s.chain.build_batched_device(*dev_csc, run, hot_cap);
+        if (std::getenv("MFM_SETUP_TIMING"))
+          std::fprintf(stderr, "[plan] conflict batches of a %zu-column chain run: %s (%d batches, %lld cold entries)\n", run.size(),
+                       on_dev ? "device" : "host", on_dev ? s.chain.n_batches : -1, on_dev ? (long long)s.chain.n_cold : -1ll);
+        if (!on_dev) {
+          s.chain.build_batched(csc, run, hot_cap);
+        } else if (std::getenv("MFM_PLAN_CHECK")) {
+          ChainRun chk;
+          chk.build_batched(csc, run, hot_cap);
+          const std::string diff = s.chain.compare_batched(chk, dev_csc->stream);
+          if (!diff.empty()) throw Error(MFM_ERR_RUNTIME, "plan check: device and host conflict batches differ (" + diff + ")");
+        }
+      }
       launches += 1;
       run.clear();
       run_nnz = 0;
