@@ -766,14 +766,14 @@ __global__ __launch_bounds__(1024) void k_dp_level_seq(const int64_t *__restrict
   for (int j = 0; j < n_cols; j++) {
     const int64_t b = colptr[j], e = colptr[j + 1];
     int32_t m = -1;
-    for (int64_t p = b + tid; p < e; p += 1024) m = max(m, rowlevel[rowidx[p]]);
+    for (int64_t p = b + tid; p < e; p += 1024) m = max(m, cbb_ld(&rowlevel[rowidx[p]]));  // (written by other waves: device scope)
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
     if (lane == 0) red[wv] = m;
     __syncthreads();
     m = red[lane & 15];
     for (int off = 8; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
     const int32_t lv = m + 1;
-    for (int64_t p = b + tid; p < e; p += 1024) rowlevel[rowidx[p]] = lv;
+    for (int64_t p = b + tid; p < e; p += 1024) cbb_st(&rowlevel[rowidx[p]], lv);
     if (tid == 0) level[j] = lv;
     __syncthreads();
   }
