@@ -88,6 +88,17 @@ int mfm_comm_stats(const mfm_ctx *ctx, int64_t *calls, int64_t *doubles);
  * (resolution order: one already mapped into the process, the directory of the HIP runtime in use, the loader's search
  * path, /opt/rocm/lib). n_ranks = 0 and an empty path when the ctx has no native communicator.                         */
 int mfm_comm_info(const mfm_ctx *ctx, int32_t *n_ranks, char *path, int64_t path_cap);
+/* Row-sharded persistent sweep (two-field one-hot table, shards cut between users): mfm_finalize builds the sweep's layout on every
+ * rank and allocates the rank's exchange buffers; the sweep goes live once every rank knows every rank's buffers -- until then the
+ * per-factor passes run. Inside the launch a rank writes its item sums into every peer's buffer and raises a flag there (no
+ * collective between the launches; SURVEY 8e "one-shot all-reduce"). mfm_peer_info: is a layout waiting (pending), this rank's
+ * buffers. mfm_peer_set: all ranks' device pointers, valid on THIS device (ranks in one process, or mapped by the caller).
+ * mfm_peer_export / mfm_peer_import: the same through IPC handles for one process per GPU (128 bytes per rank, exchanged by the
+ * caller over any channel). Every rank must make the same calls between the same two sweeps.                                  */
+int mfm_peer_info(mfm_ctx *ctx, int32_t *pending, void **sum_buf, void **flag_buf, int64_t *sum_bytes, int64_t *flag_bytes);
+int mfm_peer_set(mfm_ctx *ctx, int32_t world, int32_t rank, void *const *sum_bufs, void *const *flag_bufs);
+int mfm_peer_export(mfm_ctx *ctx, void *handles128);
+int mfm_peer_import(mfm_ctx *ctx, int32_t world, int32_t rank, const void *all_handles);
 /* The level schedule of the main table's columns (mfm_host_column_levels of the GLOBAL design): in the
  * row-sharded mode it must be identical on every rank (a conflict may exist only in another rank's
  * rows), so the caller computes it before sharding. Checked against the local rows at mfm_finalize.

@@ -936,6 +936,7 @@ struct FMTrainer {
   uint64_t stream_ptr = 0;
   vector<int32_t> main_levels;  // level schedule of the GLOBAL main table (sharded mode)
   static int allreduce_trampoline(void *user, void *buf, int64_t count) {
+    py::gil_scoped_acquire gil;  // (GibbsSession.step runs without the GIL: sessions of several threads run side by side)
     try {
       (*static_cast<py::object *>(user))((uintptr_t)buf, count);
       return 0;
@@ -1750,7 +1751,7 @@ PYBIND11_MODULE(_myfm, m) {
              return py::make_tuple((int)n, std::string(path));
            },
            "(ranks of the library's own RCCL communicator (ncclCommCount), path of the librccl.so it bound); (0, '') without one")
-      .def("step", &GibbsSession::step)
+      .def("step", &GibbsSession::step, py::call_guard<py::gil_scoped_release>())
       .def("synchronize", &GibbsSession::synchronize)
       .def("residual", &GibbsSession::residual)
       .def("timing_enable", &GibbsSession::timing_enable)
@@ -1759,6 +1760,34 @@ PYBIND11_MODULE(_myfm, m) {
       .def("timing", &GibbsSession::timing)
       .def("plan_info", &GibbsSession::plan_info)
       .def("plan_flags", [](GibbsSession &s) { return mfm_plan_flags(s.trainer->ctx); })
+      // row-sharded persistent sweep (myfm_hip.h: mfm_peer_*): this rank's exchange buffers, every rank's buffers
+      .def("peer_info",
+           [](GibbsSession &s) {
+             int32_t pending = 0;
+             void *sum = nullptr, *flag = nullptr;
+             int64_t sb = 0, fb = 0;
+             ck(s.trainer->ctx, mfm_peer_info(s.trainer->ctx, &pending, &sum, &flag, &sb, &fb));
+             return py::make_tuple(pending != 0, (uintptr_t)sum, (uintptr_t)flag, sb, fb);
+           })
+      .def("peer_set",
+           [](GibbsSession &s, int world, int rank, const std::vector<uintptr_t> &sums, const std::vector<uintptr_t> &flags) {
+             if ((int)sums.size() != world || (int)flags.size() != world) throw std::invalid_argument("peer_set: one buffer pair per rank");
+             std::vector<void *> a, b;
+             for (auto v : sums) a.push_back((void *)v);
+             for (auto v : flags) b.push_back((void *)v);
+             ck(s.trainer->ctx, mfm_peer_set(s.trainer->ctx, world, rank, a.data(), b.data()));
+           })
+      .def("peer_export",
+           [](GibbsSession &s) {
+             char h[128];
+             ck(s.trainer->ctx, mfm_peer_export(s.trainer->ctx, h));
+             return py::bytes(h, 128);
+           })
+      .def("peer_import",
+           [](GibbsSession &s, int world, int rank, const std::string &all) {
+             if ((int)all.size() != world * 128) throw std::invalid_argument("peer_import: 128 bytes per rank");
+             ck(s.trainer->ctx, mfm_peer_import(s.trainer->ctx, world, rank, all.data()));
+           })
       .def_property_readonly("fm", [](GibbsSession &s) -> FM & { return s.fm; }, py::return_value_policy::reference_internal)
       .def_property_readonly("hyper", [](GibbsSession &s) -> Hyper & { return s.hyper; },
                              py::return_value_policy::reference_internal)

@@ -168,6 +168,7 @@ struct mfm_ctx {
   // the persistent sweep's layout was built first, on the device, and took the table: X_t, the level plans and the row tiles of
   // the per-factor passes (their fall-back) are built when a call needs them (ensure_main_plans)
   std::vector<DevBuf<int32_t>> pre_maps;  // the blocks' maps uploaded ahead of the blocks (mfm_finalize only)
+  bool res_sharded_pending = false;  // row-sharded: the persistent sweep's layout is built on every rank, waiting for mfm_peer_set
   bool main_lazy = false;
   bool res_refused = false;  // the CUs of the persistent sweep were not ours to take
   int res_plan_cus = 0;      // workgroups the layout was asked for
@@ -258,6 +259,9 @@ struct mfm_ctx {
   void use_device() { MFM_HIP_CHECK(hipSetDevice(device)); }
   // give the persistent sweep up (claim released): every later sweep runs the per-factor passes
   void drop_resident() {
+    for (void *m : res.peer_mapped) (void)hipIpcCloseMemHandle(m);
+    res.peer_mapped.clear();
+    res_sharded_pending = false;
     if (res_claim) ResidentBudget::get().release(device, res_claim);
     res_claim = 0;
     res.ready = false;
@@ -275,6 +279,7 @@ struct mfm_ctx {
     throw Error(MFM_ERR_RUNTIME,
                 std::string("co-resident workgroups timed out waiting for each other (long-column sweep / conflict-batched chain / "
                             "resident latent sweep): the state of this fit is invalid") +
+                    (flag == 2 ? " [a peer rank's sums did not arrive inside the row-sharded persistent sweep]" : "") +
                     (had ? "; the persistent sweep is switched off for this context" : ""));
   }
   void sync_and_check() {
@@ -1451,6 +1456,44 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     plan_resident(c, [&](ResPlan &rp, int n_cu) { rp.build(Xt_keep, c->plan_V.h_level, &c->hgroup, n_cu); }, tlog);
     lap("resident plan (host)");
   }
+  // Row-sharded with the shards cut between users (the two-field pass runs sharded, c->mf): the persistent sweep runs on every rank
+  // over its own rows, the ranks' item sums meet inside the launch (mfm_res.hpp, XCH). The layout is built here -- items = the
+  // level-1 columns of the GLOBAL design, so every rank numbers them alike -- and goes live when the caller has handed over the
+  // peers' exchange buffers (mfm_peer_set); until then, and if any rank cannot take part, the per-factor passes run.
+  if (c->comm.active() && c->sharded_fused && c->mf && c->comm.shard_set && c->comm.world <= RES_MAX_PEERS && c->comm.world > 1 &&
+      !std::getenv("MFM_NO_RESIDENT") && !std::getenv("MFM_NO_SHARDED_RESIDENT")) {
+    const int64_t min_rows = res_min_rows(c);
+    const bool want = c->X.unit && c->X.ell_width == 2 && c->N >= std::max<int64_t>(1, min_rows / c->comm.world) && c->K > 0;
+    bool mine = false;
+    if (want) {
+      std::vector<char> draw_empty((size_t)c->D0, 0);
+      for (int64_t j = 0; j < c->D0; j++) draw_empty[j] = (size_t)j < c->plan_V.special.size() && c->plan_V.special[j] == 2;
+      plan_resident(c, [&](ResPlan &rp, int n_cu) { res_plan_build_device(rp, c->X, &c->hgroup, n_cu, c->stream, &c->hlevels, &draw_empty); }, tlog);
+      if (c->res.ready && std::getenv("MFM_PLAN_CHECK")) {
+        ResPlan chk;
+        chk.build(Xt_keep, c->hlevels, &c->hgroup, c->res_plan_cus, &draw_empty);
+        const std::string diff = chk.ready ? res_plan_compare(c->res, chk, c->stream) : ("host builder: " + chk.why);
+        if (!diff.empty()) throw Error(MFM_ERR_RUNTIME, "plan check: device and host resident layouts differ (sharded; " + diff + ")");
+      }
+      mine = c->res.ready;
+      c->res.ready = false;
+    }
+    double bad = mine ? 0.0 : 1.0;
+    {
+      DevBuf<double> d;
+      d.upload(&bad, 1);
+      c->comm.allreduce(d.p, 1);
+      MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
+      MFM_HIP_CHECK(hipMemcpy(&bad, d.p, sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (bad == 0.0) {
+      c->res.alloc_exchange(c->comm.world, c->comm.rank, c->stream);
+      c->res_sharded_pending = true;
+    } else {
+      c->drop_resident();
+    }
+    lap("resident plan (row-sharded)");
+  }
   Xt_keep = HostCsr();
   MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
   lap("blocks, state, scratch");
@@ -1463,6 +1506,78 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
   c->pre_maps.clear();
   lap("host copies released");
   c->finalized = true;
+  MFM_CATCH(ctx)
+}
+
+// ---- row-sharded persistent sweep: the ranks' exchange buffers ---------------------------------------------------------------
+int mfm_peer_info(mfm_ctx *ctx, int32_t *pending, void **sum_buf, void **flag_buf, int64_t *sum_bytes, int64_t *flag_bytes) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  const bool p = ctx->res_sharded_pending;
+  if (pending) *pending = p ? 1 : 0;
+  if (sum_buf) *sum_buf = p ? (void *)ctx->res.xsum.p : nullptr;
+  if (flag_buf) *flag_buf = p ? (void *)ctx->res.xflag.p : nullptr;
+  if (sum_bytes) *sum_bytes = p ? (int64_t)(ctx->res.xsum.n * sizeof(double)) : 0;
+  if (flag_bytes) *flag_bytes = p ? (int64_t)(ctx->res.xflag.n * sizeof(unsigned long long)) : 0;
+  MFM_CATCH(ctx)
+}
+
+int mfm_peer_set(mfm_ctx *ctx, int32_t world, int32_t rank, void *const *sum_bufs, void *const *flag_bufs) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  mfm_ctx *c = ctx;
+  if (!c->res_sharded_pending) throw Error(MFM_ERR_RUNTIME, "mfm_peer_set: this context has no row-sharded persistent sweep waiting for its peers");
+  if (world != c->res.xworld || rank != c->res.xrank) throw Error(MFM_ERR_INVALID, "mfm_peer_set: world / rank differ from the communicator's");
+  for (int r = 0; r < world; r++) {
+    if (!sum_bufs[r] || !flag_bufs[r]) throw Error(MFM_ERR_INVALID, "mfm_peer_set: null buffer");
+    c->res.peer_sum[r] = (double *)sum_bufs[r];
+    c->res.peer_flag[r] = (unsigned long long *)flag_bufs[r];
+  }
+  if (c->res.peer_sum[rank] != c->res.xsum.p || c->res.peer_flag[rank] != c->res.xflag.p)
+    throw Error(MFM_ERR_INVALID, "mfm_peer_set: this rank's own entry must be the buffers of mfm_peer_info");
+  MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
+  c->res.peers_set = true;
+  c->res.ready = true;
+  c->res_sharded_pending = false;
+  MFM_CATCH(ctx)
+}
+
+// one process per GPU: the buffers as two 64-byte IPC handles (sum, flags) ...
+int mfm_peer_export(mfm_ctx *ctx, void *handles128) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  if (!ctx->res_sharded_pending) throw Error(MFM_ERR_RUNTIME, "mfm_peer_export: no row-sharded persistent sweep waiting for its peers");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+  hipIpcMemHandle_t h[2];
+  MFM_HIP_CHECK(hipIpcGetMemHandle(&h[0], ctx->res.xsum.p));
+  MFM_HIP_CHECK(hipIpcGetMemHandle(&h[1], ctx->res.xflag.p));
+  std::memcpy(handles128, h, sizeof h);
+  MFM_CATCH(ctx)
+}
+
+// ... and every rank's handles ([world][128] bytes, rank order) opened and installed
+int mfm_peer_import(mfm_ctx *ctx, int32_t world, int32_t rank, const void *all_handles) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  mfm_ctx *c = ctx;
+  if (!c->res_sharded_pending) throw Error(MFM_ERR_RUNTIME, "mfm_peer_import: no row-sharded persistent sweep waiting for its peers");
+  if (world != c->res.xworld || rank != c->res.xrank) throw Error(MFM_ERR_INVALID, "mfm_peer_import: world / rank differ from the communicator's");
+  void *sums[RES_MAX_PEERS], *flags[RES_MAX_PEERS];
+  for (int r = 0; r < world; r++) {
+    if (r == rank) {
+      sums[r] = c->res.xsum.p;
+      flags[r] = c->res.xflag.p;
+      continue;
+    }
+    hipIpcMemHandle_t h[2];
+    std::memcpy(h, (const char *)all_handles + (size_t)r * 128, sizeof h);
+    MFM_HIP_CHECK(hipIpcOpenMemHandle(&sums[r], h[0], hipIpcMemLazyEnablePeerAccess));
+    c->res.peer_mapped.push_back(sums[r]);
+    MFM_HIP_CHECK(hipIpcOpenMemHandle(&flags[r], h[1], hipIpcMemLazyEnablePeerAccess));
+    c->res.peer_mapped.push_back(flags[r]);
+  }
+  const int rc = mfm_peer_set(ctx, world, rank, sums, flags);
+  if (rc != MFM_OK) return rc;
   MFM_CATCH(ctx)
 }
 
@@ -1648,7 +1763,7 @@ int mfm_hyper_stats(mfm_ctx *ctx, int32_t need_e, const double *mu_w, const doub
   mfm_ctx *c = ctx;
   // the slot-order scorer has left sum e / sum e^2 as one partial per workgroup: no pass over the residual, which stays in
   // slot order for the next persistent launch
-  const bool slot_sums = need_e && c->e_in_slots && c->slot_sums_valid && !c->comm.active();
+  const bool slot_sums = need_e && c->e_in_slots && c->slot_sums_valid;
   if (need_e && !slot_sums) materialize_e(ctx);
   hipStream_t s = c->stream;
   const int G = c->G, K = c->K, n_ch = std::max(1, c->gs_chunks);
@@ -1665,6 +1780,7 @@ int mfm_hyper_stats(mfm_ctx *ctx, int32_t need_e, const double *mu_w, const doub
   if (slot_sums) {
     TimedLaunch t(c->timing, s, KC_REDUCE_E, 16.0 * c->res.G);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, s, c->res.sums.p, c->res.G, c->hs_out.p);
+    c->comm.allreduce(c->hs_out.p, 2);
   } else if (need_e) {
     TimedLaunch t(c->timing, s, KC_REDUCE_E, 8.0 * c->N);
     hipLaunchKernelGGL(k_reduce_e_partial, dim3(REDUCE_BLOCKS), dim3(WG), 0, s, c->eq.p, c->N, c->red_partial.p);
@@ -1700,6 +1816,22 @@ int mfm_hyper_stats(mfm_ctx *ctx, int32_t need_e, const double *mu_w, const doub
     ssd_V[i] = h[1 + G + i].y;
   }
   MFM_CATCH(ctx)
+}
+
+// Row-sharded persistent sweep: a first-level coefficient was drawn where its rows live -- make the replicas identical again
+// (every rank zeroes what it does not contribute, one all-reduce each for w and for the swept factors of V)
+static void sync_model_sharded(mfm_ctx *c, bool with_w, int f_begin, int f_end) {
+  hipStream_t s = c->stream;
+  if (with_w) {
+    hipLaunchKernelGGL(k_mask_rows, dim3(cdiv(c->D, 256)), dim3(256), 0, s, c->w.p, c->sync_mask.p, c->D, c->D);
+    c->comm.allreduce(c->w.p, c->D);
+  }
+  if (f_end > f_begin) {
+    const int64_t n = (int64_t)(f_end - f_begin) * c->D;
+    double *Vb = c->V.p + (size_t)f_begin * c->D;
+    hipLaunchKernelGGL(k_mask_rows, dim3(cdiv(n, 256)), dim3(256), 0, s, Vb, c->sync_mask.p, c->D, n);
+    c->comm.allreduce(Vb, n);
+  }
 }
 
 // ---- sweeps -----------------------------------------------------------------------------------
@@ -1789,6 +1921,7 @@ int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambd
                      c->group.p, c->G, alpha, c->ls.error.p, lazy_store, c->w.p, zwdev, d_lam_w, d_mu_w, e_shift, load_slots);
   c->e_in_slots = lazy_store;
   c->q_stale_factor = f_end - 1;
+  if (c->comm.active()) sync_model_sharded(c, true, f_begin, f_end);
   MFM_CATCH(ctx)
 }
 
@@ -1844,6 +1977,15 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
     c->q_stale_factor = f_end - 1;  // q_train as the reference leaves it (FMTrainer.hpp:373): rebuilt when asked for
     MFM_HIP_CHECK(hipGetLastError());
+    return MFM_OK;
+  }
+  if (c->sharded_fused && c->res.ready) {  // (row-sharded persistent sweep: the peers' buffers are set)
+    const bool lazy_store = !std::getenv("MFM_RES_EAGER_STORE");
+    run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq.p, c->V.p, c->D, f_begin, f_end, zbase, c->lam.p, c->mu.p,
+                       c->group.p, c->G, alpha, c->ls.error.p, lazy_store);
+    c->e_in_slots = lazy_store;
+    c->q_stale_factor = f_end - 1;
+    sync_model_sharded(c, false, f_begin, f_end);
     return MFM_OK;
   }
   if (c->sharded_fused) {

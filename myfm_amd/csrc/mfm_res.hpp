@@ -37,6 +37,8 @@
 
 namespace mfm {
 
+constexpr int RES_MAX_PEERS = 8;
+
 struct ResArgs {
   double2 *eq;               // residual: read at [row].x at the start, written back at the end ...
   const double *e_in;        // set: the residual is read from this slot-ordered copy (what the previous launch or the slot-order
@@ -85,6 +87,15 @@ struct ResArgs {
   int n_wg;
   int *error;                // set on a spin timeout
   unsigned long long *prof;  // MFM_RES_PROF: [G][factors][8] s_memrealtime stamps of thread 0 (100 MHz), else null
+  // row-sharded, one process per GPU (k_mf_resident<.., XCH = true>): the ranks' item sums meet INSIDE the launch. Every rank
+  // owns an exchange array xsum[r] = [source rank][parity of the sweep][n_items + 1][2] and a flag word per source rank; a
+  // workgroup writes its slice's sums into EVERY rank's array (its own rank's slot), the last workgroup of a rank to do so
+  // raises the rank's flag on every peer, and whoever has seen all flags of the sweep adds the ranks' sums in rank order.
+  int xworld, xrank;
+  unsigned long long xepoch0;                 // sweeps of the launches before this one (the flags and the counter never go back)
+  double *xsum[RES_MAX_PEERS];
+  unsigned long long *xflag[RES_MAX_PEERS];   // [source rank] 16 words apart
+  unsigned long long *xarrive;                // this rank's workgroups that have published the sweep
   int rot;                   // workgroup g runs as block (g - rot) mod G (MFM_RES_ROT: placement experiments)
   int dbg;                   // timing experiments only (MFM_RES_DBG; results are wrong when set): 4 no grid barriers, 32 no item
                              // draw, 64 no sweep A, 128 no sweep B, 4096 no partial stores inside sweep B
@@ -117,6 +128,23 @@ __device__ __forceinline__ bool res_spin(const ResArgs &a, const unsigned long l
       if (spins > (1u << 22) || __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         __hip_atomic_store(a.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         dead = true;  // (every later barrier of this workgroup falls through: the launch ends, the host reports)
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
+// the same wait on a word another GPU writes (system scope)
+__device__ __forceinline__ bool res_spin_sys(const ResArgs &a, const unsigned long long *w, unsigned long long target, bool &dead) {
+  unsigned spins = 0;
+  while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
+    __builtin_amdgcn_s_sleep(2);
+    if ((++spins & 1023u) == 0u) {
+      const int seen = __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (spins > (1u << 23) || seen != 0) {
+        if (seen == 0) __hip_atomic_store(a.error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (2: a peer rank did not show up)
+        dead = true;
         return false;
       }
     }
@@ -181,7 +209,7 @@ typedef unsigned res_u4_t __attribute__((ext_vector_type(4)));
 // carries the previous slot's value. The item of a run comes from run_item[run] -- the head bits give the run index of
 // every slot without a memory access -- gathered the same way. Both chains are software-pipelined by hand: while batch b
 // computes, the dv gathers of batch b + 1 and the run_item gathers of batch b + 2 are in flight.
-template <int NT, int NGV, int NGL>
+template <int NT, int NGV, int NGL, bool XCH = false>
 __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) char res_smem[];
   constexpr int NW = NT / WAVE, NG = NGV + NGL, R = 16 * NG, RL = 16 * NGL;
@@ -550,8 +578,8 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
         }
       }
       __syncthreads();
+      double S1 = 0.0, S2 = 0.0;
       if (tid < ni) {
-        double S1 = 0.0, S2 = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; w++) {
           S1 += acc1[w * U + tid];
@@ -559,6 +587,43 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
           acc1[w * U + tid] = 0.0;
           acc2[w * U + tid] = 0.0;
         }
+      }
+      if (XCH) {
+        // the other ranks' rows of these items: publish this rank's sums to every rank, wait for everybody's, add in rank order
+        const unsigned long long E = a.xepoch0 + (unsigned long long)(f - f_first) + 1ull;
+        const int64_t stride = 2 * ((int64_t)a.n_items + 1), par = (int64_t)(E & 1ull);
+        if (tid < ni) {
+          const int64_t off = ((int64_t)a.xrank * 2 + par) * stride + 2 * (int64_t)(i0 + tid);
+          for (int r = 0; r < a.xworld; r++) {
+            __hip_atomic_store(a.xsum[r] + off, S1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.xsum[r] + off + 1, S2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0 && !dead) {
+          const unsigned long long old = __hip_atomic_fetch_add(a.xarrive, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+          if (old + 1 == (unsigned long long)a.n_wg * E) {  // every workgroup of this rank has published: tell the peers
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int r = 0; r < a.xworld; r++)
+              __hip_atomic_store(a.xflag[r] + 16 * a.xrank, E, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+          for (int r = 0; r < a.xworld && !dead; r++) res_spin_sys(a, a.xflag[a.xrank] + 16 * r, E, dead);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        }
+        __syncthreads();
+        if (tid < ni) {
+          S1 = S2 = 0.0;
+          for (int r = 0; r < a.xworld; r++) {
+            const int64_t off = ((int64_t)r * 2 + par) * stride + 2 * (int64_t)(i0 + tid);
+            S1 += __hip_atomic_load(a.xsum[a.xrank] + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            S2 += __hip_atomic_load(a.xsum[a.xrank] + off + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+      }
+      if (tid < ni) {
         const double fresh = PMainV::draw(S1, S2, iold, a.alpha, ilam, imu, iz);
         Vf[ij] = fresh;
         res_store2(a.dv + 2 * (int64_t)(i0 + tid), fresh - iold, ivn);
@@ -852,6 +917,25 @@ struct ResPlan {
   DevBuf<double> y_slots;             // y in slot order, built at the first scoring
   DevBuf<double2> sums;               // [G] {sum e, sum e^2} of the last scoring
   int maxu_rows = 0;                  // users of the largest workgroup (+ the pad user)
+  // row-sharded: this rank's exchange array and flags (allocated with the layout), every rank's (mfm_peer_set), sweeps so far
+  int xworld = 1, xrank = 0;
+  bool peers_set = false;
+  DevBuf<double> xsum;
+  DevBuf<unsigned long long> xflag, xarrive;
+  double *peer_sum[RES_MAX_PEERS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned long long *peer_flag[RES_MAX_PEERS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned long long xepoch = 0;
+  std::vector<void *> peer_mapped;  // IPC mappings to close (mfm_peer_import)
+  size_t xsum_bytes(int world) const { return (size_t)world * 2 * 2 * ((size_t)n_items + 1) * sizeof(double); }
+  void alloc_exchange(int world, int rank, hipStream_t s) {
+    xworld = world;
+    xrank = rank;
+    peers_set = false;
+    xepoch = 0;
+    xsum.alloc_zero(xsum_bytes(world) / sizeof(double), s);
+    xflag.alloc_zero((size_t)16 * RES_MAX_PEERS, s);
+    xarrive.alloc_zero(16, s);
+  }
   std::string why;  // why the layout was not built (diagnostics)
   std::vector<int32_t> h_nruns;  // runs per workgroup (diagnostics)
   std::vector<std::string> h_diag;  // per workgroup (MFM_RES_PROF only)
@@ -956,7 +1040,10 @@ struct ResPlan {
 
   // csc = X_t of the table (column j: ascending rows), level[j] in {0, 1}: 0 = first field (contiguous row ranges in
   // ascending order covering every row once), 1 = second field (every row once). Unit values.
-  bool build(const HostCsr &csc, const std::vector<int32_t> &level, const std::vector<int32_t> *group_of, int n_cu) {
+  // draw_empty (row-sharded): level-0 columns without rows HERE are drawn by this rank only when flagged (= without rows on
+  // every rank: all ranks draw them alike); the others belong to the rank that holds their rows
+  bool build(const HostCsr &csc, const std::vector<int32_t> &level, const std::vector<int32_t> *group_of, int n_cu,
+             const std::vector<char> *draw_empty = nullptr) {
     ready = false;
     const int64_t N = csc.cols, D0 = csc.rows;
     n_rows = N;
@@ -964,7 +1051,10 @@ struct ResPlan {
     std::vector<int32_t> users, items, empties;
     for (int64_t j = 0; j < D0; j++) {
       if (level[j] == 0) {
-        (csc.ptr[j + 1] > csc.ptr[j] ? users : empties).push_back((int32_t)j);
+        if (csc.ptr[j + 1] > csc.ptr[j])
+          users.push_back((int32_t)j);
+        else if (!draw_empty || (*draw_empty)[(size_t)j])
+          empties.push_back((int32_t)j);
       } else if (level[j] == 1) {
         items.push_back((int32_t)j);
       } else {
@@ -1308,6 +1398,16 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   a.error = error;
   a.dbg = std::getenv("MFM_RES_DBG") ? std::atoi(std::getenv("MFM_RES_DBG")) : 0;
   a.rot = std::getenv("MFM_RES_ROT") ? std::atoi(std::getenv("MFM_RES_ROT")) : 0;
+  const bool xch = rp.xworld > 1;
+  a.xworld = rp.xworld;
+  a.xrank = rp.xrank;
+  a.xepoch0 = rp.xepoch;
+  a.xarrive = rp.xarrive.p;
+  for (int r = 0; r < RES_MAX_PEERS; r++) {
+    a.xsum[r] = rp.peer_sum[r];
+    a.xflag[r] = rp.peer_flag[r];
+  }
+  if (xch && !rp.peers_set) throw Error(MFM_ERR_RUNTIME, "row-sharded persistent sweep: the peers' exchange buffers are not set (mfm_peer_set)");
   // MFM_RES_PROF=n: the n-th launch of the process records the phase stamps of every workgroup and prints a summary
   static int prof_launch = 0;
   const bool prof = std::getenv("MFM_RES_PROF") && ++prof_launch == std::atoi(std::getenv("MFM_RES_PROF"));
@@ -1335,7 +1435,17 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                             \
       raised.mark();                                                                                                          \
     }                                                                                                                         \
-    hipLaunchKernelGGL((k_mf_resident<512, RV_ / 16, RL_ / 16>), dim3(rp.G), dim3(512), rp.lds_bytes, s, a);                    \
+    if (xch) {                                                                                                                \
+      static DeviceOnce raised_x;                                                                                             \
+      if (raised_x.need()) {                                                                                                  \
+        MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_resident<512, RV_ / 16, RL_ / 16, true>,                          \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                           \
+        raised_x.mark();                                                                                                      \
+      }                                                                                                                       \
+      hipLaunchKernelGGL((k_mf_resident<512, RV_ / 16, RL_ / 16, true>), dim3(rp.G), dim3(512), rp.lds_bytes, s, a);            \
+    } else {                                                                                                                  \
+      hipLaunchKernelGGL((k_mf_resident<512, RV_ / 16, RL_ / 16>), dim3(rp.G), dim3(512), rp.lds_bytes, s, a);                  \
+    }                                                                                                                         \
   } while (0)
   if (rp.RV == 16 && rp.RL == 0)
     MFM_RES_LAUNCH(16, 0);
@@ -1347,6 +1457,7 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
     throw Error(MFM_ERR_RUNTIME, "internal: no resident kernel variant for this plan");
 #undef MFM_RES_LAUNCH
   MFM_HIP_CHECK(hipGetLastError());
+  if (xch) rp.xepoch += (unsigned long long)a.n_sw;  // (every rank runs the same launches: the epochs agree)
   if (prof) {
     MFM_HIP_CHECK(hipStreamSynchronize(s));
     const int K2 = a.n_sw;

@@ -56,6 +56,19 @@ __global__ void k_cols(const int32_t *__restrict__ ucnt, const int32_t *__restri
   eflag[j] = u == 0 && i == 0;
 }
 
+// row-sharded: the levels of the GLOBAL design decide (level 1 = item whether or not this rank has rows of it), and a level-0
+// column without rows here is drawn by this rank only when it has rows nowhere (draw_empty)
+__global__ void k_cols_given(const int32_t *__restrict__ ucnt, const int32_t *__restrict__ icnt, const int32_t *__restrict__ level,
+                             const int32_t *__restrict__ draw_empty, int64_t D0, int32_t *__restrict__ iflag, int32_t *__restrict__ eflag,
+                             int32_t *__restrict__ red) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= D0) return;
+  const int32_t u = ucnt[j], i = icnt[j], l = level[j];
+  if (u > 1 || (u > 0 && l != 0) || (i > 0 && l != 1) || l < 0 || l > 1) atomicAdd(&red[2], 1);
+  iflag[j] = l == 1;
+  eflag[j] = l == 0 && u == 0 && draw_empty[j] != 0;
+}
+
 __global__ void k_col_lists(const int32_t *__restrict__ iflag, const int32_t *__restrict__ eflag, const int32_t *__restrict__ iord,
                             const int32_t *__restrict__ eord, int64_t D0, int32_t *__restrict__ scols, int32_t *__restrict__ empties) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,7 +298,8 @@ static inline void sort_pairs(DevBuf<uint32_t> &k_in, DevBuf<uint32_t> &k_out, D
 }  // namespace rp
 
 // X: the main table on the device (CSR; every row two unit entries in ascending column order), group_of: host, may be null
-static inline bool res_plan_build_device(ResPlan &rpn, const DevSparse &X, const std::vector<int32_t> *group_of, int n_cu, hipStream_t s) {
+static inline bool res_plan_build_device(ResPlan &rpn, const DevSparse &X, const std::vector<int32_t> *group_of, int n_cu, hipStream_t s,
+                                         const std::vector<int32_t> *glevel = nullptr, const std::vector<char> *draw_empty = nullptr) {
   using namespace rp;
   rpn.ready = false;
   const int64_t N = X.rows, D0 = X.cols;
@@ -324,7 +338,18 @@ static inline bool res_plan_build_device(ResPlan &rpn, const DevSparse &X, const
   }
   hipLaunchKernelGGL(k_rows, grid(N), dim3(TB), 0, s, X.colidx.p, N, bflag.p, ucnt.p, icnt.p, red.p);
   lap("k_rows");
-  hipLaunchKernelGGL(k_cols, grid(D0), dim3(TB), 0, s, ucnt.p, icnt.p, D0, iflag.p, eflag.p, red.p);
+  const bool given = glevel && draw_empty && (int64_t)glevel->size() == D0 && (int64_t)draw_empty->size() == D0;
+  if ((glevel || draw_empty) && !given) return rpn.fail("shape");
+  if (given) {
+    DevBuf<int32_t> d_level, d_de;
+    d_level.upload(*glevel);
+    std::vector<int32_t> de32(draw_empty->begin(), draw_empty->end());
+    d_de.upload(de32);
+    hipLaunchKernelGGL(k_cols_given, grid(D0), dim3(TB), 0, s, ucnt.p, icnt.p, d_level.p, d_de.p, D0, iflag.p, eflag.p, red.p);
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+  } else {
+    hipLaunchKernelGGL(k_cols, grid(D0), dim3(TB), 0, s, ucnt.p, icnt.p, D0, iflag.p, eflag.p, red.p);
+  }
   MFM_HIP_CHECK(hipMemsetAsync(iflag.p + D0, 0, sizeof(int32_t), s));  // (one more element: the totals come out of the exclusive sums)
   MFM_HIP_CHECK(hipMemsetAsync(eflag.p + D0, 0, sizeof(int32_t), s));
   exclusive_sum(iflag.p, iord.p, D0 + 1, tmp, s);
@@ -337,7 +362,7 @@ static inline bool res_plan_build_device(ResPlan &rpn, const DevSparse &X, const
   MFM_HIP_CHECK(hipMemcpyAsync(&n_emp, eord.p + D0, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MFM_HIP_CHECK(hipMemcpyAsync(&n_users, uord1.p + (N - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MFM_HIP_CHECK(hipStreamSynchronize(s));
-  if (h_red[0] >= h_red[1]) return rpn.fail("the two fields' column ranges overlap");
+  if (!given && h_red[0] >= h_red[1]) return rpn.fail("the two fields' column ranges overlap");
   if (h_red[2] != 0) return rpn.fail("first level not contiguous");
   if (n_users < 1 || n_items < 1) return rpn.fail("empty level");
   rpn.n_items = n_items;

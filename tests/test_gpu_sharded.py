@@ -407,6 +407,72 @@ def test_sharded_two_field_pass(oracle, world, values, monkeypatch):
         np.testing.assert_allclose(ge, e[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_persistent_sweep_in_launch_exchange(oracle, world, monkeypatch):
+    """The persistent sweep row-sharded (mfm_res.hpp XCH): every rank keeps the residual of ITS rows on chip for all
+    factors, the ranks' item sums meet INSIDE the launch -- each workgroup writes its slice's sums into every rank's exchange
+    buffer, the last workgroup of a rank raises the rank's flag on the peers, everybody adds the ranks' sums in rank order -- so
+    there is no collective between the sweeps of an iteration (one model synchronisation after the launch). Here the ranks
+    are sessions of one process on ONE GPU, each claiming a share of the CUs, running their launches side by side; the peers'
+    buffers are plain device pointers (mfm_peer_set). Must reproduce the unsharded oracle chain; replicas identical."""
+    from myfm_amd import _capi, _myfm
+    from myfm_amd.distributed import shard_cuts
+
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    monkeypatch.setenv("MFM_RES_CUS", str(240 // world))
+    n = 120001
+    X, y, shapes = ds.onehot_mf(n, 300, 170, seed=13, sort_by_user=True)
+    gi = ds.group_index_from_shapes(shapes)
+    K = 3
+    cuts = shard_cuts(X.indices[X.indptr[:-1]], world)
+    ls = Lockstep(world)
+    levels = _capi.column_levels(X)[0]
+    out, errs, peers = {}, [], {}
+    meet = threading.Barrier(world)
+
+    def run(rank):
+        try:
+            lo, hi = cuts[rank], cuts[rank + 1]
+            s = _myfm.GibbsSession(K, 0.1, X[lo:hi], [], y[lo:hi], 42, _config(gi), allreduce=ls.callback(rank), n_total_rows=n,
+                                   row_offset=lo, main_levels=levels, shard_rank=rank, shard_world=world)
+            pending, sum_p, flag_p, sum_b, flag_b = s.peer_info()
+            assert pending and sum_p and flag_p and sum_b > 0, (pending, sum_p, flag_p)
+            assert not (s.plan_flags() & 256)  # not live before every rank knows every rank's buffers
+            peers[rank] = (sum_p, flag_p)
+            meet.wait()
+            s.peer_set(world, rank, [peers[r][0] for r in range(world)], [peers[r][1] for r in range(world)])
+            flags = s.plan_flags()
+            calls0 = ls.counts[rank]
+            for it in range(3):
+                s.step()
+            out[rank] = (s.fm.w0, np.asarray(s.fm.w), np.asarray(s.fm.V), s.residual(), lo, flags, ls.counts[rank] - calls0)
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            ls.bar.abort()
+            meet.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=300)
+    assert not errs, errs
+    t = oracle.OracleTrainer(X, y, rank=K, group_index=gi)
+    for it in range(3):
+        t.step()
+    w0, w, V = t.fm()
+    e = t.e(n)
+    for rank in range(world):
+        gw0, gw, gV, ge, lo, flags, calls = out[rank]
+        assert flags & 256 and flags & 8, flags  # persistent sweep, row-sharded
+        assert calls <= 3 * 6, calls  # per iteration: sum e, w and V synchronisation, a few scalars -- nothing per factor
+        assert abs(gw0 - w0) < 1e-7
+        np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(ge, e[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
+        assert np.array_equal(gV, out[0][2]) and np.array_equal(gw, out[0][1])
+
+
 @pytest.mark.parametrize("world,shape", [(2, "u_i_ctx"), (3, "u_i_ctx"), (2, "no_item"), (3, "three_fields")])
 def test_cell_path_row_sharded(oracle, monkeypatch, world, shape):
     """Index-tuple designs (mfm_cell.hpp) row-sharded over `world` lock-stepped ranks on one GPU: every rank runs the cell
