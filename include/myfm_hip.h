@@ -99,6 +99,8 @@ int mfm_peer_info(mfm_ctx *ctx, int32_t *pending, void **sum_buf, void **flag_bu
 int mfm_peer_set(mfm_ctx *ctx, int32_t world, int32_t rank, void *const *sum_bufs, void *const *flag_bufs);
 int mfm_peer_export(mfm_ctx *ctx, void *handles128);
 int mfm_peer_import(mfm_ctx *ctx, int32_t world, int32_t rank, const void *all_handles);
+/* give it up (waiting or live): the per-factor passes from the next sweep on; every rank alike */
+int mfm_peer_drop(mfm_ctx *ctx);
 /* The level schedule of the main table's columns (mfm_host_column_levels of the GLOBAL design): in the
  * row-sharded mode it must be identical on every rank (a conflict may exist only in another rank's
  * rows), so the caller computes it before sharding. Checked against the local rows at mfm_finalize.

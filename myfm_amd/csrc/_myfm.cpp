@@ -1783,6 +1783,7 @@ PYBIND11_MODULE(_myfm, m) {
              ck(s.trainer->ctx, mfm_peer_export(s.trainer->ctx, h));
              return py::bytes(h, 128);
            })
+      .def("peer_drop", [](GibbsSession &s) { ck(s.trainer->ctx, mfm_peer_drop(s.trainer->ctx)); })
       .def("peer_import",
            [](GibbsSession &s, int world, int rank, const std::string &all) {
              if ((int)all.size() != world * 128) throw std::invalid_argument("peer_import: 128 bytes per rank");

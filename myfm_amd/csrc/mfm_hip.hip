@@ -1581,6 +1581,16 @@ int mfm_peer_import(mfm_ctx *ctx, int32_t world, int32_t rank, const void *all_h
   MFM_CATCH(ctx)
 }
 
+// give the row-sharded persistent sweep up (pending or live): the per-factor passes from the next sweep on. Every rank alike.
+int mfm_peer_drop(mfm_ctx *ctx) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  materialize_e(ctx);
+  ctx->drop_resident();
+  MFM_CATCH(ctx)
+}
+
 int64_t mfm_dim_all(const mfm_ctx *ctx) { return ctx->D; }
 
 int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launches_per_sweep) {

@@ -932,8 +932,23 @@ struct ResPlan {
     xrank = rank;
     peers_set = false;
     xepoch = 0;
-    xsum.alloc_zero(xsum_bytes(world) / sizeof(double), s);
-    xflag.alloc_zero((size_t)16 * RES_MAX_PEERS, s);
+    // (what other GPUs write and this one reads inside a running kernel: uncached device memory, coherent for every agent --
+    //  plain device memory if the runtime refuses the flag)
+    auto alloc_shared = [&](auto &buf, size_t count) {
+      buf.release();
+      void *p = nullptr;
+      const size_t bytes = count * sizeof(*buf.p);
+      if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        MFM_HIP_CHECK(hipMalloc(&p, bytes));
+      }
+      buf.p = (decltype(buf.p))p;
+      buf.n = count;
+      buf.owned = true;
+      MFM_HIP_CHECK(hipMemsetAsync(p, 0, bytes, s));
+    };
+    alloc_shared(xsum, xsum_bytes(world) / sizeof(double));
+    alloc_shared(xflag, (size_t)16 * RES_MAX_PEERS);
     xarrive.alloc_zero(16, s);
   }
   std::string why;  // why the layout was not built (diagnostics)

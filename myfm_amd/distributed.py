@@ -154,3 +154,38 @@ def shard_cuts(first_col, world):
         cuts.append(max(int(best), cuts[-1]))
     cuts.append(n)
     return cuts
+
+
+def connect_peers(session, group=None):
+    """Row-sharded persistent sweep: when `mfm_finalize` has built the sweep's layout on every rank
+    (`session.peer_info()[0]`), exchange the ranks' IPC handles of their exchange buffers over `torch.distributed` and install
+    them (`mfm_peer_export` / `mfm_peer_import`). Every rank must call this at the same point. Returns True when the persistent
+    sweep is live on all ranks; on any failure every rank stays with the per-factor passes (same chain)."""
+    import torch.distributed as dist
+
+    pending = bool(session.peer_info()[0])
+    if not pending:  # (the same on every rank: mfm_finalize agrees on it)
+        return False
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    try:
+        mine, err = session.peer_export(), ""
+    except Exception as ex:  # noqa: BLE001 -- every rank must take part in the gather below
+        mine, err = b"", "%s: %s" % (type(ex).__name__, ex)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine, group=group)
+    ok = all(len(h) == 128 for h in gathered)
+    if ok:
+        try:
+            session.peer_import(world, rank, b"".join(gathered))
+        except Exception as ex:  # noqa: BLE001
+            ok, err = False, "%s: %s" % (type(ex).__name__, ex)
+    oks = [None] * world
+    dist.all_gather_object(oks, bool(ok), group=group)
+    if not all(oks):
+        if err:
+            import sys
+
+            print("myfm_amd.distributed.connect_peers: rank %d: %s" % (rank, err), file=sys.stderr)
+        session.peer_drop()
+        return False
+    return True

@@ -309,6 +309,23 @@ def test_two_processes_one_gpu_sharded_fit():
     assert r.returncode == 0 and "mp_fit_worker ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+def test_two_processes_one_gpu_persistent_sweep():
+    # the row-sharded persistent sweep with its ranks in two PROCESSES (one GPU: both on device 0, each with a share of the CUs):
+    # IPC handles of the exchange buffers over torch.distributed, the launches of the two processes side by side, item sums
+    # exchanged inside the launch; oracle chain on every rank, replicas bit-identical (tests/mp_peer_worker.py)
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29643", os.path.join(root, "tests", "mp_peer_worker.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MFM_RES_NO_PROCESS_LOCK="1", MFM_RES_CUS="100", MFM_RES_MIN_ROWS="0",
+               MFM_SCATTER_MIN_NNZ="1000")
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "mp_peer_worker ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_empty_shard_does_not_hang_or_corrupt(oracle, monkeypatch):
     # a rank without rows must take part in every collective of mfm_finalize and of the sweeps, and the owner of
     # the replicated columns is rank 0 of the communicator, not "the rank whose first row is global row 0"
