@@ -250,30 +250,69 @@ def main():
         cuts = mdist.shard_cuts(X.indices[X.indptr[:-1]], world)
         lo, hi = cuts[rank], cuts[rank + 1]
         rels = [_myfm.RelationBlock(np.asarray(m, dtype=np.int64)[lo:hi], B) for m, B in blocks]
-        cfg = make_config(_myfm, gi, a.steps + a.warmup + 8, 0, W["task"], hi - lo)
-        sess, err = None, ""
-        if not os.environ.get("MYFM_BENCH_TORCH_ALLREDUCE"):
-            try:
-                cid = mdist.native_comm_id()
-                sess = _myfm.GibbsSession(K, 0.1, X[lo:hi], rels, y[lo:hi], 42, cfg, n_total_rows=N, row_offset=lo, main_levels=levels,
-                                          comm_id=cid, shard_rank=rank, shard_world=world)
-            except Exception as ex:  # noqa: BLE001 -- reported below; every rank must take the same branch
-                err = "%s: %s" % (type(ex).__name__, ex)
-        ok = torch.tensor([1 if sess is not None else 0], device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        how = "RCCL all-reduce called by libmyfm_hip.so on its stream"
-        if int(ok.item()) == 0:
-            # the library could not open its own communicator on some rank: the same all-reduces through torch.distributed
-            # (the same librccl, called back from the library on a torch stream)
-            print("bench.py rank %d: native RCCL communicator unavailable (%s); using the torch.distributed callback" % (rank, err),
-                  file=sys.stderr)
-            sess = None
-            ar = mdist.TorchAllReduce()
-            sess = _myfm.GibbsSession(K, 0.1, X[lo:hi], rels, y[lo:hi], 42, cfg, allreduce=ar, n_total_rows=N, row_offset=lo,
-                                      stream=ar.stream_ptr, main_levels=levels, shard_rank=rank, shard_world=world)
-            how = "all-reduce through torch.distributed (%s) called back from libmyfm_hip.so on a shared stream" % backend
-        parallelism = ("one chain over the same %d rows, sharded over %d GPUs at user boundaries (%d rows on rank 0); %s: per factor "
-                       "the item level's statistics, per sweep one model synchronisation" % (N, world, hi - lo, how))
+        cfg = make_config(_myfm, gi, a.steps + a.warmup + 12, 0, W["task"], hi - lo)
+
+        def make_session():
+            sess, err = None, ""
+            if not os.environ.get("MYFM_BENCH_TORCH_ALLREDUCE"):
+                try:
+                    cid = mdist.native_comm_id()
+                    sess = _myfm.GibbsSession(K, 0.1, X[lo:hi], rels, y[lo:hi], 42, cfg, n_total_rows=N, row_offset=lo,
+                                              main_levels=levels, comm_id=cid, shard_rank=rank, shard_world=world)
+                except Exception as ex:  # noqa: BLE001 -- reported below; every rank must take the same branch
+                    err = "%s: %s" % (type(ex).__name__, ex)
+            ok = torch.tensor([1 if sess is not None else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            how = "RCCL all-reduce called by libmyfm_hip.so on its stream"
+            if int(ok.item()) == 0:
+                # the library could not open its own communicator on some rank: the same all-reduces through torch.distributed
+                # (the same librccl, called back from the library on a torch stream)
+                print("bench.py rank %d: native RCCL communicator unavailable (%s); using the torch.distributed callback" % (rank, err),
+                      file=sys.stderr)
+                sess = None
+                ar = mdist.TorchAllReduce()
+                sess = _myfm.GibbsSession(K, 0.1, X[lo:hi], rels, y[lo:hi], 42, cfg, allreduce=ar, n_total_rows=N, row_offset=lo,
+                                          stream=ar.stream_ptr, main_levels=levels, shard_rank=rank, shard_world=world)
+                how = "all-reduce through torch.distributed (%s) called back from libmyfm_hip.so on a shared stream" % backend
+            return sess, how
+
+        sess, how = make_session()
+        # The persistent sweep row-sharded: every rank keeps the residual of its rows on chip, the ranks' item sums
+        # meet INSIDE the launch through IPC-mapped exchange buffers (no collective between the sweeps of an iteration). It has
+        # been tested with ranks side by side on ONE GPU only, so two trial iterations decide here: a rank that times out, or
+        # replicas that differ, send every rank back to the per-factor passes on a fresh session. MYFM_BENCH_NO_PEER_EXCHANGE=1: off.
+        peer_live = False
+        if not blocks and not os.environ.get("MYFM_BENCH_NO_PEER_EXCHANGE"):
+            peer_live = mdist.connect_peers(sess)
+            if peer_live:
+                good, chk = 1.0, 0.0
+                try:
+                    for _ in range(2):
+                        sess.step()
+                    sess.synchronize()
+                    chk = float(np.abs(np.asarray(sess.fm.V)).sum())
+                    good = 1.0 if np.isfinite(chk) else 0.0
+                except Exception as ex:  # noqa: BLE001 -- every rank takes part in the agreement below
+                    print("bench.py rank %d: row-sharded persistent sweep failed its trial (%s: %s)" % (rank, type(ex).__name__, ex),
+                          file=sys.stderr)
+                    good = 0.0
+                t = torch.tensor([good, chk, -chk], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                if float(t[0]) < 1.0 or float(t[1]) != -float(t[2]):
+                    peer_live = False
+                    sess = None
+                    import gc
+
+                    gc.collect()
+                    os.environ["MFM_NO_SHARDED_RESIDENT"] = "1"
+                    sess, how = make_session()
+        if peer_live:
+            parallelism = ("one chain over the same %d rows, sharded over %d GPUs at user boundaries (%d rows on rank 0); persistent sweep "
+                           "on every rank, the ranks' item sums exchanged inside the launch through IPC-mapped buffers over xGMI; %s: per "
+                           "iteration the residual sums and one model synchronisation" % (N, world, hi - lo, how))
+        else:
+            parallelism = ("one chain over the same %d rows, sharded over %d GPUs at user boundaries (%d rows on rank 0); %s: per factor "
+                           "the item level's statistics, per sweep one model synchronisation" % (N, world, hi - lo, how))
     t_setup = time.time() - t0
 
     def sync():
@@ -542,6 +581,7 @@ def main():
         out["config"]["rows_this_rank"] = hi - lo
         # evidence that the collective spans the ranks: ncclCommCount of the communicator libmyfm_hip.so opened itself, and the
         # librccl it bound (0 / "": the torch.distributed callback carried the all-reduces instead, see `parallelism`)
+        out["config"]["peer_exchange"] = bool(peer_live)
         out["config"]["rccl_ranks"] = int(rccl_ranks)
         out["config"]["rccl_path"] = rccl_path
         out["config"]["torch_world_size"] = world

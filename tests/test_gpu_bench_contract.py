@@ -57,6 +57,20 @@ def test_bench_starts_its_own_ranks():
     assert d["weak_scaling"]["it_per_s"] > 0
 
 
+def test_bench_two_ranks_persistent_sweep_with_in_launch_exchange():
+    """`python bench.py --gpus 2` with the row-sharded persistent sweep: both ranks on device 0 with a share of the CUs each
+    (MFM_RES_CUS, no cross-process CU lock), exchange buffers through IPC handles; the line says so (`peer_exchange`) and the
+    collectives per step are the per-iteration ones only."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MYFM_BENCH_BACKEND="gloo", MYFM_BENCH_DEVICE="0", MFM_RES_NO_PROCESS_LOCK="1", MFM_RES_CUS="100", MFM_RES_MIN_ROWS="0")
+    d = _run("--gpus", "2", "--rows", "300000", "--users", "3000", "--items", "2000", "--steps", "3", "--warmup", "1", "--weak-steps", "0",
+             env=env)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and c["peer_exchange"] is True, c
+    assert c["plan_flags"] & 256 and c["plan_flags"] & 8
+    assert c["allreduce_calls_per_step"] <= 6, c["allreduce_calls_per_step"]
+
+
 def test_bench_sharded_world1_reports_the_rccl_communicator():
     """world = 1 through the library's own RCCL communicator: the line proves which librccl carried the all-reduces."""
     env = dict(os.environ, MYFM_BENCH_FORCE_SHARDED="1")
