@@ -908,6 +908,29 @@ struct SetupLap {
   }
 };
 
+// what myfm_amd.distributed.connect_peers needs of a training context (GibbsSession has the same four methods): handed to the
+// `peer_connect` callable of create_train_fm_sharded between mfm_finalize and the first iteration
+struct PeerHandle {
+  mfm_ctx *ctx = nullptr;
+  py::tuple peer_info() {
+    int32_t pending = 0;
+    void *sum = nullptr, *flag = nullptr;
+    int64_t sb = 0, fb = 0;
+    ck(ctx, mfm_peer_info(ctx, &pending, &sum, &flag, &sb, &fb));
+    return py::make_tuple(pending != 0, (uintptr_t)sum, (uintptr_t)flag, sb, fb);
+  }
+  py::bytes peer_export() {
+    char h[128];
+    ck(ctx, mfm_peer_export(ctx, h));
+    return py::bytes(h, 128);
+  }
+  void peer_import(int world, int rank, const std::string &all) {
+    if ((int)all.size() != world * 128) throw std::invalid_argument("peer_import: 128 bytes per rank");
+    ck(ctx, mfm_peer_import(ctx, world, rank, all.data()));
+  }
+  void peer_drop() { ck(ctx, mfm_peer_drop(ctx)); }
+};
+
 struct FMTrainer {
   mfm_ctx *ctx = nullptr;
   int64_t N = 0, D0 = 0;
@@ -933,6 +956,7 @@ struct FMTrainer {
   int shard_rank = 0, shard_world = 1;
   std::string comm_id;  // 128-byte RCCL unique id: the library calls ncclAllReduce itself (mfm_comm_init)
   py::object allreduce;
+  py::object peer_connect;  // callable(PeerHandle) or none
   uint64_t stream_ptr = 0;
   vector<int32_t> main_levels;  // level schedule of the GLOBAL main table (sharded mode)
   static int allreduce_trampoline(void *user, void *buf, int64_t count) {
@@ -1322,6 +1346,11 @@ struct FMTrainer {
     SetupLap lap("learn_with_callback");
     build_device(fm.n_factors);
     lap("build_device (set_main, blocks, finalize)");
+    if (peer_connect.ptr() != nullptr && !peer_connect.is_none()) {  // row-sharded persistent sweep: the ranks' exchange buffers
+      PeerHandle h;
+      h.ctx = ctx;
+      peer_connect(py::cast(h));
+    }
     upload(fm);
     initialize_hyper(hyper);
     initialize_e(fm);
@@ -1405,9 +1434,10 @@ std::pair<Predictor, LearningHistory> create_train_fm_sharded(size_t n_factor, R
                                                               std::function<bool(int, FM *, Hyper *, LearningHistory *)> cb,
                                                               int rank, int world, int64_t n_total_rows, int64_t row_offset,
                                                               const py::object &main_levels, const std::string &comm_id,
-                                                              py::object allreduce, uint64_t stream) {
+                                                              py::object allreduce, uint64_t stream, py::object peer_connect) {
   FMTrainer t(X, relations, y, random_seed, config);
   t.allreduce = allreduce;
+  t.peer_connect = peer_connect;
   t.comm_id = comm_id;
   t.shard_rank = rank;
   t.shard_world = world;
@@ -1797,7 +1827,12 @@ PYBIND11_MODULE(_myfm, m) {
         py::arg("rank"), py::arg("init_std"), py::arg("X"), py::arg("relations"), py::arg("y"), py::arg("random_seed"),
         py::arg("config"), py::arg("callback"), py::arg("shard_rank"), py::arg("shard_world"), py::arg("n_total_rows"),
         py::arg("row_offset"), py::arg("main_levels"), py::arg("comm_id") = py::bytes(""), py::arg("allreduce") = py::none(),
-        py::arg("stream") = 0, py::return_value_policy::move);
+        py::arg("stream") = 0, py::arg("peer_connect") = py::none(), py::return_value_policy::move);
+  py::class_<PeerHandle>(m, "PeerHandle", "The exchange buffers of a row-sharded training context (myfm_amd.distributed.connect_peers).")
+      .def("peer_info", &PeerHandle::peer_info)
+      .def("peer_export", &PeerHandle::peer_export)
+      .def("peer_import", &PeerHandle::peer_import)
+      .def("peer_drop", &PeerHandle::peer_drop);
   // fit()'s row sort without numpy's argsort + fancy indexing (6 s for 1e7 shuffled rows): a stable counting
   // sort of the rows by their first stored column, and a threaded gather of the CSR rows in that order
   m.def("row_order_by_first_column",

@@ -79,23 +79,27 @@ class TorchAllReduce:
 
 
 # ---- native provider: the library calls RCCL itself (mfm_comm_init) -------------------------------------------------
-_STATE = {"on": False, "group": None, "native": True}
+_STATE = {"on": False, "group": None, "native": True, "peer_exchange": False}
 
 
-def enable(group=None, set_device=True, native=True):
+def enable(group=None, set_device=True, native=True, peer_exchange=False):
     """Make `MyFM*.fit()` row-sharded over the ranks of `group` (default: the world group of an initialised
     torch.distributed): every rank calls fit() with the SAME full data, trains on its contiguous slice of the rows on its
     own GPU (LOCAL_RANK) with the all-reduces issued by libmyfm_hip.so through RCCL, and ends with the same samples.
 
     native=False: the library calls back into `torch.distributed.all_reduce` of `group` instead of opening its own RCCL
-    communicator (any backend -- e.g. gloo with several ranks on one GPU, which RCCL refuses)."""
+    communicator (any backend -- e.g. gloo with several ranks on one GPU, which RCCL refuses).
+
+    peer_exchange=True: two-field one-hot tables train with the persistent sweep on every rank, the ranks' item sums exchanged
+    inside the launch through IPC-mapped buffers (`connect_peers`) instead of one all-reduce per factor. Opt-in:
+    the path has been tested with the ranks side by side on one GPU only."""
     import os
 
     import torch.distributed as dist
 
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised (init_process_group first)")
-    _STATE.update(on=True, group=group, native=bool(native))
+    _STATE.update(on=True, group=group, native=bool(native), peer_exchange=bool(peer_exchange))
     if set_device and "MYFM_AMD_DEVICE" not in os.environ:
         os.environ["MYFM_AMD_DEVICE"] = os.environ.get("LOCAL_RANK", "0")
 
@@ -114,10 +118,12 @@ def active():
 
 def comm_kwargs():
     """Keyword arguments of `_myfm.create_train_fm_sharded` that select the all-reduce provider."""
+    group = _STATE["group"]
+    extra = dict(peer_connect=lambda handle: connect_peers(handle, group)) if _STATE["peer_exchange"] else {}
     if _STATE["native"]:
-        return dict(comm_id=native_comm_id(_STATE["group"]))
-    ar = TorchAllReduce(group=_STATE["group"])
-    return dict(allreduce=ar, stream=ar.stream_ptr)
+        return dict(comm_id=native_comm_id(group), **extra)
+    ar = TorchAllReduce(group=group)
+    return dict(allreduce=ar, stream=ar.stream_ptr, **extra)
 
 
 def rank_world():
@@ -163,6 +169,7 @@ def connect_peers(session, group=None):
     sweep is live on all ranks; on any failure every rank stays with the per-factor passes (same chain)."""
     import torch.distributed as dist
 
+    _STATE["last_connect"] = False
     pending = bool(session.peer_info()[0])
     if not pending:  # (the same on every rank: mfm_finalize agrees on it)
         return False
@@ -188,4 +195,5 @@ def connect_peers(session, group=None):
             print("myfm_amd.distributed.connect_peers: rank %d: %s" % (rank, err), file=sys.stderr)
         session.peer_drop()
         return False
+    _STATE["last_connect"] = True  # (diagnostics: did the last fit / session take the in-launch exchange?)
     return True

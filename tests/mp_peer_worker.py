@@ -59,6 +59,18 @@ def main():
     s.step()
     t.step()
     np.testing.assert_allclose(np.asarray(s.fm.V), t.fm()[2], rtol=1e-7, atol=1e-8)
+    del s
+    # MyFMRegressor.fit() row-sharded with the same hand-over (distributed.enable(peer_exchange=True))
+    import myfm_amd
+
+    D.enable(native=False, peer_exchange=True)
+    fm = myfm_amd.MyFMRegressor(K).fit(X, y, group_shapes=shapes, n_iter=4, n_kept_samples=2)
+    samples, _, _ = O.fit(X, y, rank=K, group_index=gi, n_iter=4, n_kept_samples=2)
+    for got, (w0_, w_, V_) in zip(fm.predictor_.samples, samples):
+        np.testing.assert_allclose(got.V, V_, rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(got.w, w_, rtol=1e-7, atol=1e-7)
+    assert fm.history_ is not None and D._STATE.get("last_connect") is True  # (the fit did take the in-launch exchange)
+    D.disable()
     dist.barrier()
     if rank == 0:
         print("mp_peer_worker ok: world", world)
