@@ -424,6 +424,51 @@ def test_sharded_two_field_pass(oracle, world, values, monkeypatch):
         np.testing.assert_allclose(ge, e[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
 
 
+def test_sharded_persistent_sweep_refused_on_one_rank_falls_back_everywhere(oracle, monkeypatch):
+    """Two ranks on one GPU that each ask for 200 of its 256 CUs: the second claim is refused, mfm_finalize's agreement sends
+    BOTH ranks to the per-factor passes (no layout waiting for peers anywhere), and the chain is the oracle's."""
+    from myfm_amd import _capi, _myfm
+    from myfm_amd.distributed import shard_cuts
+
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    monkeypatch.setenv("MFM_RES_CUS", "200")
+    monkeypatch.setenv("MFM_RES_WGS", "200")  # (as many workgroups as allowed, so that the claims collide)
+    n, world, K = 120001, 2, 3
+    X, y, shapes = ds.onehot_mf(n, 300, 170, seed=13, sort_by_user=True)
+    gi = ds.group_index_from_shapes(shapes)
+    cuts = shard_cuts(X.indices[X.indptr[:-1]], world)
+    ls = Lockstep(world)
+    levels = _capi.column_levels(X)[0]
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            lo, hi = cuts[rank], cuts[rank + 1]
+            s = _myfm.GibbsSession(K, 0.1, X[lo:hi], [], y[lo:hi], 42, _config(gi), allreduce=ls.callback(rank), n_total_rows=n,
+                                   row_offset=lo, main_levels=levels, shard_rank=rank, shard_world=world)
+            pending = s.peer_info()[0]
+            for it in range(2):
+                s.step()
+            out[rank] = (pending, s.plan_flags(), np.asarray(s.fm.V))
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            ls.bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=300)
+    assert not errs, errs
+    t = oracle.OracleTrainer(X, y, rank=K, group_index=gi)
+    for it in range(2):
+        t.step()
+    for rank in range(world):
+        pending, flags, V = out[rank]
+        assert not pending and not (flags & 256) and flags & 128, (pending, flags)
+        np.testing.assert_allclose(V, t.fm()[2], rtol=1e-7, atol=1e-8)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_persistent_sweep_in_launch_exchange(oracle, world, monkeypatch):
     """The persistent sweep row-sharded (mfm_res.hpp XCH): every rank keeps the residual of ITS rows on chip for all
