@@ -393,6 +393,9 @@ def main():
     weak = None
     if sharded and a.config == 3 and a.weak_steps > 0 and not blocks:
         del sess
+        import gc
+
+        gc.collect()  # (the context gives its CUs back before the weak-scaling session asks for them)
         Xw, yw, shw, lo_w, total_w = ds.movielens_like_shard(a.rows, rank, world, a.users, a.items)
         levels_w = np.concatenate([np.zeros(a.users, np.int32), np.ones(a.items, np.int32)])
         gi_w = ds.group_index_from_shapes(shw)
@@ -404,6 +407,8 @@ def main():
         else:
             sw = _myfm.GibbsSession(K, 0.1, Xw, [], yw, 42, cfg_w, n_total_rows=total_w, row_offset=lo_w, main_levels=levels_w,
                                     comm_id=mdist.native_comm_id(), shard_rank=rank, shard_world=world)
+        # (the strong leg's trial has shown that the in-launch exchange works between these ranks: the weak leg takes it too)
+        peer_w = bool(peer_live) and mdist.connect_peers(sw)
         for _ in range(3):
             sw.step()
         sw.synchronize()
@@ -429,6 +434,7 @@ def main():
         weak = {"rows_total": int(total_w), "rows_per_gpu": int(a.rows), "steps": a.weak_steps, "it_per_s": round(a.weak_steps / tw, 3),
                 "allreduce_calls_per_step": round(sw.comm_stats()[0] / (a.weak_steps + 3), 1),
                 "ms_per_step": round(tw / a.weak_steps * 1e3, 3), "row_iterations_per_s": round(total_w * a.weak_steps / tw),
+                "peer_exchange": bool(peer_w),
                 "note": "ONE chain over a user-sorted table of world x rows_per_gpu rows (same users / items), every rank holds a "
                         "contiguous range of users; timing as for `value` (barrier + synchronize, max over ranks)"}
         del sw

@@ -63,12 +63,13 @@ def test_bench_two_ranks_persistent_sweep_with_in_launch_exchange():
     collectives per step are the per-iteration ones only."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(MYFM_BENCH_BACKEND="gloo", MYFM_BENCH_DEVICE="0", MFM_RES_NO_PROCESS_LOCK="1", MFM_RES_CUS="100", MFM_RES_MIN_ROWS="0")
-    d = _run("--gpus", "2", "--rows", "300000", "--users", "3000", "--items", "2000", "--steps", "3", "--warmup", "1", "--weak-steps", "0",
+    d = _run("--gpus", "2", "--rows", "300000", "--users", "3000", "--items", "2000", "--steps", "3", "--warmup", "1", "--weak-steps", "2",
              env=env)
     c = d["config"]
     assert d["n_gpus"] == 2 and d["value"] > 0 and c["peer_exchange"] is True, c
     assert c["plan_flags"] & 256 and c["plan_flags"] & 8
     assert c["allreduce_calls_per_step"] <= 6, c["allreduce_calls_per_step"]
+    assert d["weak_scaling"]["peer_exchange"] is True and d["weak_scaling"]["it_per_s"] > 0
 
 
 def test_bench_sharded_world1_reports_the_rccl_communicator():
