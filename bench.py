@@ -279,7 +279,7 @@ def main():
         sess, how = make_session()
         # The persistent sweep row-sharded: every rank keeps the residual of its rows on chip, the ranks' item sums
         # meet INSIDE the launch through IPC-mapped exchange buffers (no collective between the sweeps of an iteration). It has
-        # been tested with ranks side by side on ONE GPU only, so two trial iterations decide here: a rank that times out, or
+        # been tested with ranks side by side on ONE GPU only, so a trial iteration decides here: a rank that times out, or
         # replicas that differ, send every rank back to the per-factor passes on a fresh session. MYFM_BENCH_NO_PEER_EXCHANGE=1: off.
         peer_live = False
         if not blocks and not os.environ.get("MYFM_BENCH_NO_PEER_EXCHANGE"):
@@ -287,8 +287,10 @@ def main():
             if peer_live:
                 good, chk = 1.0, 0.0
                 try:
-                    for _ in range(2):
-                        sess.step()
+                    # (ONE iteration = 33 sweeps with an exchange each, then the stream is checked: a rank whose launch timed out
+                    #  raises here, after it has issued the same collectives as everybody else -- a second iteration could leave
+                    #  the others waiting in a collective the failed rank never enters)
+                    sess.step()
                     sess.synchronize()
                     chk = float(np.abs(np.asarray(sess.fm.V)).sum())
                     good = 1.0 if np.isfinite(chk) else 0.0

@@ -607,7 +607,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
           if (old + 1 == (unsigned long long)a.n_wg * E) {  // every workgroup of this rank has published: tell the peers
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            for (int r = 0; r < a.xworld; r++)
+            for (int r = 0; r < a.xworld && !(a.dbg & 8192); r++)  // (8192: a test of the time-out path -- the flags stay down)
               __hip_atomic_store(a.xflag[r] + 16 * a.xrank, E, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
           }
           for (int r = 0; r < a.xworld && !dead; r++) res_spin_sys(a, a.xflag[a.xrank] + 16 * r, E, dead);
@@ -1414,6 +1414,7 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   a.dbg = std::getenv("MFM_RES_DBG") ? std::atoi(std::getenv("MFM_RES_DBG")) : 0;
   a.rot = std::getenv("MFM_RES_ROT") ? std::atoi(std::getenv("MFM_RES_ROT")) : 0;
   const bool xch = rp.xworld > 1;
+  if (xch && rp.xrank == 1 && std::getenv("MFM_RES_XCH_BREAK")) a.dbg |= 8192;  // tests: rank 1 never raises its flags
   a.xworld = rp.xworld;
   a.xrank = rp.xrank;
   a.xepoch0 = rp.xepoch;

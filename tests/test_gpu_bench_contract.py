@@ -72,6 +72,19 @@ def test_bench_two_ranks_persistent_sweep_with_in_launch_exchange():
     assert d["weak_scaling"]["peer_exchange"] is True and d["weak_scaling"]["it_per_s"] > 0
 
 
+def test_bench_two_ranks_fall_back_when_the_exchange_fails_its_trial():
+    """The same run with rank 1's flags held down (MFM_RES_XCH_BREAK): the persistent launches time out inside the trial iteration,
+    every rank agrees to drop the path, and the line comes from fresh sessions on the per-factor passes."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MYFM_BENCH_BACKEND="gloo", MYFM_BENCH_DEVICE="0", MFM_RES_NO_PROCESS_LOCK="1", MFM_RES_CUS="100", MFM_RES_MIN_ROWS="0",
+               MFM_RES_XCH_BREAK="1")
+    d = _run("--gpus", "2", "--rows", "300000", "--users", "3000", "--items", "2000", "--steps", "3", "--warmup", "1", "--weak-steps", "0",
+             env=env)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and c["peer_exchange"] is False, c
+    assert not (c["plan_flags"] & 256) and c["allreduce_calls_per_step"] > 6
+
+
 def test_bench_sharded_world1_reports_the_rccl_communicator():
     """world = 1 through the library's own RCCL communicator: the line proves which librccl carried the all-reduces."""
     env = dict(os.environ, MYFM_BENCH_FORCE_SHARDED="1")
