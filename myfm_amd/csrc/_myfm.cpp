@@ -210,23 +210,52 @@ struct ConfigBuilder {
 };
 
 // ---- RelationBlock (definitions.hpp:30-52) ---------------------------------------------------------
+// [0, n) in contiguous ranges on host threads (copies of 10^7..10^8-element index arrays: bound by the first-touch page faults of
+// one thread otherwise); f(lo, hi) must not throw
+template <class F>
+static void host_ranges(int64_t n, F f) {
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>({n >> 20, 16, hw > 0 ? hw : 1}));
+  if (T <= 1) {
+    f((int64_t)0, n);
+    return;
+  }
+  vector<std::thread> pool;
+  for (int t = 1; t < T; t++) pool.emplace_back(f, n * t / T, n * (t + 1) / T);
+  f((int64_t)0, n / T);
+  for (auto &t : pool) t.join();
+}
+
 struct RelationBlock {
-  vector<size_t> original_to_block;
+  // original_to_block (definitions.hpp:33) as a plain int64 array: what the C ABI takes, filled (and first touched) by several
+  // threads -- 5e7 entries per block at config 5; the Python attribute makes a list of it when somebody asks
+  std::unique_ptr<int64_t[]> map;
   size_t mapper_size;
   Csr X;
   size_t block_size, feature_size;
-  RelationBlock(vector<size_t> o2b, Csr X_)
-      : original_to_block(std::move(o2b)), mapper_size(original_to_block.size()), X(std::move(X_)),
-        block_size((size_t)X.rows), feature_size((size_t)X.cols) {
-    for (auto c : original_to_block)
-      if (c >= block_size) throw std::runtime_error("index mapping points to non-existing row.");
+  // src: n int64 indices (validated here: definitions.hpp:38-41)
+  RelationBlock(const int64_t *src, size_t n, Csr X_)
+      : map(new int64_t[std::max<size_t>(n, 1)]), mapper_size(n), X(std::move(X_)), block_size((size_t)X.rows),
+        feature_size((size_t)X.cols) {
+    std::atomic<int> bad(0);
+    int64_t *dst = map.get();
+    const int64_t B = (int64_t)block_size;
+    host_ranges((int64_t)n, [&](int64_t lo, int64_t hi) {
+      bool b = false;
+      for (int64_t i = lo; i < hi; i++) {
+        b |= src[i] < 0 || src[i] >= B;
+        dst[i] = src[i];
+      }
+      if (b) bad = 1;
+    });
+    if (bad) throw std::runtime_error("index mapping points to non-existing row.");
   }
-  // the map as int64 for the C ABI: size_t and int64_t have the same width and the entries are validated < block_size
-  // (definitions.hpp:39-41), so the array is handed over in place (5e7 entries per block at config 5)
-  const int64_t *map64() const {
+  RelationBlock(const vector<size_t> &o2b, Csr X_)
+      : RelationBlock(reinterpret_cast<const int64_t *>(o2b.data()), o2b.size(), std::move(X_)) {
     static_assert(sizeof(size_t) == sizeof(int64_t), "original_to_block is reinterpreted as int64");
-    return reinterpret_cast<const int64_t *>(original_to_block.data());
   }
+  const int64_t *map64() const { return map.get(); }
+  vector<size_t> original_to_block() const { return vector<size_t>(map.get(), map.get() + mapper_size); }
 };
 typedef vector<std::shared_ptr<RelationBlock>> Relations;
 
@@ -242,9 +271,9 @@ size_t check_row_consistency_return_column(const M &X, const Relations &relation
   size_t row = (size_t)X.rows, col = (size_t)X.cols;
   int i = 0;
   for (const auto &rel : relations) {
-    if (row != rel->original_to_block.size()) {
+    if (row != rel->mapper_size) {
       std::ostringstream ss;
-      ss << "main table has size " << row << " but the relation[" << i << "] has size " << rel->original_to_block.size();
+      ss << "main table has size " << row << " but the relation[" << i << "] has size " << rel->mapper_size;
       throw std::runtime_error(ss.str());
     }
     col += rel->feature_size;
@@ -413,7 +442,7 @@ struct FM {
   void check(const Csr &X, const Relations &relations) {
     size_t case_size = (size_t)X.rows, feature_size_all = (size_t)X.cols;
     for (auto const &rel : relations) {
-      if (case_size != rel->original_to_block.size())
+      if (case_size != rel->mapper_size)
         throw std::invalid_argument("Relation blocks have inconsistent mapper size with case_size");
       feature_size_all += rel->feature_size;
     }
@@ -991,7 +1020,20 @@ struct FMTrainer {
     }
     if (cfg.task_type == TaskType::ORDERED) {
       const size_t rows = (size_t)X_.rows;
-      vector<bool> existence(rows, false);
+      // (the usual case -- ONE group listing every row in order -- is checked by threads without the marker array)
+      bool identity = cfg.cutpoint_groups.size() == 1 && cfg.cutpoint_groups[0].second.size() == rows;
+      if (identity) {
+        const size_t *idx = cfg.cutpoint_groups[0].second.data();
+        std::atomic<int> off(0);
+        host_ranges((int64_t)rows, [&](int64_t lo, int64_t hi) {
+          bool b = false;
+          for (int64_t k = lo; k < hi; k++) b |= idx[k] != (size_t)k;
+          if (b) off = 1;
+        });
+        identity = !off;
+      }
+      vector<bool> existence(identity ? 0 : rows, false);
+      if (!identity)
       for (auto &gc : cfg.cutpoint_groups)
         for (size_t k : gc.second) {
           if (k >= rows) throw std::invalid_argument("out of range for cutpoint group config.");
@@ -1002,7 +1044,7 @@ struct FMTrainer {
           }
           existence[k] = true;
         }
-      for (size_t i = 0; i < rows; i++)
+      for (size_t i = 0; i < rows && !identity; i++)
         if (!existence[i]) {
           std::stringstream ss;
           ss << "cutpoint group not specified for " << i << ".";
@@ -1548,23 +1590,16 @@ PYBIND11_MODULE(_myfm, m) {
              if (py::isinstance<py::array>(o2b)) {
                auto arr = py::array_t<int64_t, py::array::c_style | py::array::forcecast>::ensure(o2b);
                if (!arr || arr.ndim() != 1) throw std::invalid_argument("original_to_block must be a 1-d integer array");
-               vector<size_t> v((size_t)arr.size());
-               const int64_t *p = arr.data();
-               for (py::ssize_t i = 0; i < arr.size(); i++) {
-                 if (p[i] < 0) throw std::runtime_error("index mapping points to non-existing row.");
-                 v[(size_t)i] = (size_t)p[i];
-               }
-               return std::make_shared<RelationBlock>(std::move(v), csr_from_py(data));
+               return std::make_shared<RelationBlock>(arr.data(), (size_t)arr.size(), csr_from_py(data));
              }
              return std::make_shared<RelationBlock>(o2b.cast<vector<size_t>>(), csr_from_py(data));
            }),
            py::arg("original_to_block"), py::arg("data"))
-      .def_readonly("original_to_block", &RelationBlock::original_to_block)
+      .def_property_readonly("original_to_block", &RelationBlock::original_to_block)
       .def_property_readonly("original_to_block_array",  // (extension: the map as an int64 array, no Python list)
                              [](const RelationBlock &b) {
-                               py::array_t<int64_t> a((py::ssize_t)b.original_to_block.size());
-                               int64_t *p = a.mutable_data();
-                               for (size_t i = 0; i < b.original_to_block.size(); i++) p[i] = (int64_t)b.original_to_block[i];
+                               py::array_t<int64_t> a((py::ssize_t)b.mapper_size);
+                               if (b.mapper_size) std::memcpy(a.mutable_data(), b.map.get(), b.mapper_size * sizeof(int64_t));
                                return a;
                              })
       .def_property_readonly("data", [](const RelationBlock &b) { return csr_to_py(b.X); })
@@ -1578,7 +1613,7 @@ PYBIND11_MODULE(_myfm, m) {
                 << ", feature size = " << b.feature_size << ">";
              return ss.str();
            })
-      .def(py::pickle([](const RelationBlock &b) { return py::make_tuple(b.original_to_block, csr_to_py(b.X)); },
+      .def(py::pickle([](const RelationBlock &b) { return py::make_tuple(b.original_to_block(), csr_to_py(b.X)); },
                       [](py::tuple t) {
                         if (t.size() != 2) throw std::runtime_error("invalid state for Relationblock.");
                         return std::make_shared<RelationBlock>(t[0].cast<vector<size_t>>(), csr_from_py(t[1]));
@@ -1614,12 +1649,15 @@ PYBIND11_MODULE(_myfm, m) {
                if (py::isinstance<py::array>(rows)) {
                  auto a = py::array_t<int64_t, py::array::c_style | py::array::forcecast>::ensure(rows);
                  if (!a) throw std::invalid_argument("cutpoint group: integer row indices expected");
-                 v.resize((size_t)a.size());
                  const int64_t *p = a.data();
-                 for (size_t k = 0; k < v.size(); k++) {
-                   if (p[k] < 0) throw std::invalid_argument("cutpoint group: negative row index");
-                   v[k] = (size_t)p[k];
-                 }
+                 std::atomic<int> neg(0);
+                 host_ranges((int64_t)a.size(), [&](int64_t lo, int64_t hi) {
+                   bool b = false;
+                   for (int64_t k = lo; k < hi; k++) b |= p[k] < 0;
+                   if (b) neg = 1;
+                 });
+                 if (neg) throw std::invalid_argument("cutpoint group: negative row index");
+                 v.assign(p, p + a.size());  // (one pass: no zero fill before the copy)
                } else {
                  v = rows.cast<vector<size_t>>();
                }
