@@ -93,11 +93,15 @@ int mfm_comm_info(const mfm_ctx *ctx, int32_t *n_ranks, char *path, int64_t path
  * per-factor passes run. Inside the launch a rank writes its item sums into every peer's buffer and raises a flag there (no
  * collective between the launches; SURVEY 8e "one-shot all-reduce"). mfm_peer_info: is a layout waiting (pending), this rank's
  * buffers. mfm_peer_set: all ranks' device pointers, valid on THIS device (ranks in one process, or mapped by the caller).
- * mfm_peer_export / mfm_peer_import: the same through IPC handles for one process per GPU (128 bytes per rank, exchanged by the
+ * mfm_peer_export / mfm_peer_import: the same through IPC handles for one process per GPU (256 bytes per rank: sums, flags, w, V; exchanged by the
  * caller over any channel). Every rank must make the same calls between the same two sweeps.                                  */
 int mfm_peer_info(mfm_ctx *ctx, int32_t *pending, void **sum_buf, void **flag_buf, int64_t *sum_bytes, int64_t *flag_bytes);
 int mfm_peer_set(mfm_ctx *ctx, int32_t world, int32_t rank, void *const *sum_bufs, void *const *flag_bufs);
-int mfm_peer_export(mfm_ctx *ctx, void *handles128);
+/* optional, after mfm_peer_set: every rank's w / V (mfm_peer_model_info gives this rank's). A first-level coefficient is then written
+ * to every replica where and when it is drawn, and the model synchronisation after the launch (an all-reduce of w and V) is dropped. */
+int mfm_peer_model_info(mfm_ctx *ctx, void **w_buf, void **V_buf);
+int mfm_peer_set_model(mfm_ctx *ctx, int32_t world, int32_t rank, void *const *w_bufs, void *const *V_bufs);
+int mfm_peer_export(mfm_ctx *ctx, void *handles256);
 int mfm_peer_import(mfm_ctx *ctx, int32_t world, int32_t rank, const void *all_handles);
 /* give it up (waiting or live): the per-factor passes from the next sweep on; every rank alike */
 int mfm_peer_drop(mfm_ctx *ctx);

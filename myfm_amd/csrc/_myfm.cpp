@@ -949,12 +949,12 @@ struct PeerHandle {
     return py::make_tuple(pending != 0, (uintptr_t)sum, (uintptr_t)flag, sb, fb);
   }
   py::bytes peer_export() {
-    char h[128];
+    char h[256];
     ck(ctx, mfm_peer_export(ctx, h));
-    return py::bytes(h, 128);
+    return py::bytes(h, 256);
   }
   void peer_import(int world, int rank, const std::string &all) {
-    if ((int)all.size() != world * 128) throw std::invalid_argument("peer_import: 128 bytes per rank");
+    if ((int)all.size() != world * 256) throw std::invalid_argument("peer_import: 256 bytes per rank");
     ck(ctx, mfm_peer_import(ctx, world, rank, all.data()));
   }
   void peer_drop() { ck(ctx, mfm_peer_drop(ctx)); }
@@ -1845,16 +1845,30 @@ PYBIND11_MODULE(_myfm, m) {
              for (auto v : flags) b.push_back((void *)v);
              ck(s.trainer->ctx, mfm_peer_set(s.trainer->ctx, world, rank, a.data(), b.data()));
            })
+      .def("peer_model_info",
+           [](GibbsSession &s) {
+             void *w = nullptr, *V = nullptr;
+             ck(s.trainer->ctx, mfm_peer_model_info(s.trainer->ctx, &w, &V));
+             return py::make_tuple((uintptr_t)w, (uintptr_t)V);
+           })
+      .def("peer_set_model",
+           [](GibbsSession &s, int world, int rank, const std::vector<uintptr_t> &ws, const std::vector<uintptr_t> &Vs) {
+             if ((int)ws.size() != world || (int)Vs.size() != world) throw std::invalid_argument("peer_set_model: one buffer pair per rank");
+             std::vector<void *> a, b;
+             for (auto v : ws) a.push_back((void *)v);
+             for (auto v : Vs) b.push_back((void *)v);
+             ck(s.trainer->ctx, mfm_peer_set_model(s.trainer->ctx, world, rank, a.data(), b.data()));
+           })
       .def("peer_export",
            [](GibbsSession &s) {
-             char h[128];
+             char h[256];
              ck(s.trainer->ctx, mfm_peer_export(s.trainer->ctx, h));
-             return py::bytes(h, 128);
+             return py::bytes(h, 256);
            })
       .def("peer_drop", [](GibbsSession &s) { ck(s.trainer->ctx, mfm_peer_drop(s.trainer->ctx)); })
       .def("peer_import",
            [](GibbsSession &s, int world, int rank, const std::string &all) {
-             if ((int)all.size() != world * 128) throw std::invalid_argument("peer_import: 128 bytes per rank");
+             if ((int)all.size() != world * 256) throw std::invalid_argument("peer_import: 256 bytes per rank");
              ck(s.trainer->ctx, mfm_peer_import(s.trainer->ctx, world, rank, all.data()));
            })
       .def_property_readonly("fm", [](GibbsSession &s) -> FM & { return s.fm; }, py::return_value_policy::reference_internal)

@@ -262,6 +262,7 @@ struct mfm_ctx {
     for (void *m : res.peer_mapped) (void)hipIpcCloseMemHandle(m);
     res.peer_mapped.clear();
     res_sharded_pending = false;
+    res.peers_model = false;
     if (res_claim) ResidentBudget::get().release(device, res_claim);
     res_claim = 0;
     res.ready = false;
@@ -1542,41 +1543,83 @@ int mfm_peer_set(mfm_ctx *ctx, int32_t world, int32_t rank, void *const *sum_buf
   MFM_CATCH(ctx)
 }
 
-// one process per GPU: the buffers as two 64-byte IPC handles (sum, flags) ...
-int mfm_peer_export(mfm_ctx *ctx, void *handles128) {
+// the peers' replicas of (w, V): with them a first-level coefficient goes to every replica inside the launch and the model
+// synchronisation after it is dropped. After mfm_peer_set, before the next sweep; every rank alike.
+int mfm_peer_set_model(mfm_ctx *ctx, int32_t world, int32_t rank, void *const *w_bufs, void *const *V_bufs) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  mfm_ctx *c = ctx;
+  if (!c->res.ready || !c->res.peers_set) throw Error(MFM_ERR_RUNTIME, "mfm_peer_set_model: mfm_peer_set comes first");
+  if (world != c->res.xworld || rank != c->res.xrank) throw Error(MFM_ERR_INVALID, "mfm_peer_set_model: world / rank differ from the communicator's");
+  for (int r = 0; r < world; r++) {
+    if (!w_bufs[r] || (c->K > 0 && !V_bufs[r])) throw Error(MFM_ERR_INVALID, "mfm_peer_set_model: null buffer");
+    c->res.peer_w[r] = (double *)w_bufs[r];
+    c->res.peer_V[r] = (double *)V_bufs[r];
+  }
+  if (c->res.peer_w[rank] != c->w.p || c->res.peer_V[rank] != c->V.p)
+    throw Error(MFM_ERR_INVALID, "mfm_peer_set_model: this rank's own entry must be its own w / V (mfm_peer_model_info)");
+  MFM_HIP_CHECK(hipStreamSynchronize(c->stream));
+  c->res.peers_model = !std::getenv("MFM_NO_PEER_MODEL");
+  MFM_CATCH(ctx)
+}
+
+int mfm_peer_model_info(mfm_ctx *ctx, void **w_buf, void **V_buf) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  if (w_buf) *w_buf = ctx->w.p;
+  if (V_buf) *V_buf = ctx->V.p;
+  MFM_CATCH(ctx)
+}
+
+// one process per GPU: the buffers as four 64-byte IPC handles (sums, flags, w, V) ...
+int mfm_peer_export(mfm_ctx *ctx, void *handles256) {
   MFM_TRY(ctx)
   ctx->need_final();
   if (!ctx->res_sharded_pending) throw Error(MFM_ERR_RUNTIME, "mfm_peer_export: no row-sharded persistent sweep waiting for its peers");
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
-  hipIpcMemHandle_t h[2];
+  hipIpcMemHandle_t h[4];
+  std::memset(h, 0, sizeof h);
   MFM_HIP_CHECK(hipIpcGetMemHandle(&h[0], ctx->res.xsum.p));
   MFM_HIP_CHECK(hipIpcGetMemHandle(&h[1], ctx->res.xflag.p));
-  std::memcpy(handles128, h, sizeof h);
+  MFM_HIP_CHECK(hipIpcGetMemHandle(&h[2], ctx->w.p));
+  if (ctx->K > 0) MFM_HIP_CHECK(hipIpcGetMemHandle(&h[3], ctx->V.p));
+  std::memcpy(handles256, h, sizeof h);
   MFM_CATCH(ctx)
 }
 
-// ... and every rank's handles ([world][128] bytes, rank order) opened and installed
+// ... and every rank's handles ([world][256] bytes, rank order) opened and installed
 int mfm_peer_import(mfm_ctx *ctx, int32_t world, int32_t rank, const void *all_handles) {
   MFM_TRY(ctx)
   ctx->need_final();
   mfm_ctx *c = ctx;
   if (!c->res_sharded_pending) throw Error(MFM_ERR_RUNTIME, "mfm_peer_import: no row-sharded persistent sweep waiting for its peers");
   if (world != c->res.xworld || rank != c->res.xrank) throw Error(MFM_ERR_INVALID, "mfm_peer_import: world / rank differ from the communicator's");
-  void *sums[RES_MAX_PEERS], *flags[RES_MAX_PEERS];
+  void *sums[RES_MAX_PEERS], *flags[RES_MAX_PEERS], *ws[RES_MAX_PEERS], *Vs[RES_MAX_PEERS];
   for (int r = 0; r < world; r++) {
     if (r == rank) {
       sums[r] = c->res.xsum.p;
       flags[r] = c->res.xflag.p;
+      ws[r] = c->w.p;
+      Vs[r] = c->V.p;
       continue;
     }
-    hipIpcMemHandle_t h[2];
-    std::memcpy(h, (const char *)all_handles + (size_t)r * 128, sizeof h);
+    hipIpcMemHandle_t h[4];
+    std::memcpy(h, (const char *)all_handles + (size_t)r * 256, sizeof h);
     MFM_HIP_CHECK(hipIpcOpenMemHandle(&sums[r], h[0], hipIpcMemLazyEnablePeerAccess));
     c->res.peer_mapped.push_back(sums[r]);
     MFM_HIP_CHECK(hipIpcOpenMemHandle(&flags[r], h[1], hipIpcMemLazyEnablePeerAccess));
     c->res.peer_mapped.push_back(flags[r]);
+    MFM_HIP_CHECK(hipIpcOpenMemHandle(&ws[r], h[2], hipIpcMemLazyEnablePeerAccess));
+    c->res.peer_mapped.push_back(ws[r]);
+    Vs[r] = nullptr;
+    if (c->K > 0) {
+      MFM_HIP_CHECK(hipIpcOpenMemHandle(&Vs[r], h[3], hipIpcMemLazyEnablePeerAccess));
+      c->res.peer_mapped.push_back(Vs[r]);
+    }
   }
-  const int rc = mfm_peer_set(ctx, world, rank, sums, flags);
+  int rc = mfm_peer_set(ctx, world, rank, sums, flags);
+  if (rc != MFM_OK) return rc;
+  rc = mfm_peer_set_model(ctx, world, rank, ws, Vs);
   if (rc != MFM_OK) return rc;
   MFM_CATCH(ctx)
 }
@@ -1744,6 +1787,9 @@ static int group_stats(mfm_ctx *ctx, const double *theta, int nf, const double *
       hipLaunchKernelGGL(k_group_stats_final, dim3(cdiv(G * nf, 64)), dim3(64), 0, s, ctx->gs_partial.p, G * nf, n_ch,
                          ctx->red_out.p + 1);
     }
+    // (peers write first-level coefficients into this rank's model inside their launches: nobody may start the next one before
+    //  every rank has read the model here -- an all-reduce of one double orders that, see mfm_hyper_stats)
+    if (ctx->res.peers_model && ctx->comm.active()) ctx->comm.allreduce(ctx->red_out.p, 1);
     double2 *h = ctx->readback((size_t)G * nf + 1);
     MFM_HIP_CHECK(hipMemcpyAsync(h, ctx->red_out.p + 1, (size_t)G * nf * sizeof(double2), hipMemcpyDeviceToHost, s));
     MFM_HIP_CHECK(hipStreamSynchronize(s));
@@ -1787,16 +1833,9 @@ int mfm_hyper_stats(mfm_ctx *ctx, int32_t need_e, const double *mu_w, const doub
     if (K) std::memcpy(c->hs_stage.data() + G, mu_V, (size_t)G * K * sizeof(double));
     c->ring.upload(c->hs_mu.p, c->hs_stage.data(), c->hs_stage.size() * sizeof(double), s);
   }
-  if (slot_sums) {
-    TimedLaunch t(c->timing, s, KC_REDUCE_E, 16.0 * c->res.G);
-    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, s, c->res.sums.p, c->res.G, c->hs_out.p);
-    c->comm.allreduce(c->hs_out.p, 2);
-  } else if (need_e) {
-    TimedLaunch t(c->timing, s, KC_REDUCE_E, 8.0 * c->N);
-    hipLaunchKernelGGL(k_reduce_e_partial, dim3(REDUCE_BLOCKS), dim3(WG), 0, s, c->eq.p, c->N, c->red_partial.p);
-    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, s, c->red_partial.p, REDUCE_BLOCKS, c->hs_out.p);
-    c->comm.allreduce(c->hs_out.p, 2);
-  }
+  // (the group sums of w / V FIRST, the residual sums and their all-reduce behind them: with the row-sharded persistent sweep a
+  //  peer writes the first-level coefficients it draws straight into this rank's w / V (mfm_peer_set_model), and it can start its
+  //  next launch only behind this all-reduce -- which this rank enters after its group sums have read the model)
   {
     TimedLaunch t(c->timing, s, KC_GROUP_STATS, 12.0 * c->D * (K + 1));
     hipLaunchKernelGGL(k_group_stats, dim3(G, 1, n_ch), dim3(WG), 0, s, c->w.p, c->D, c->feat_sorted.p, c->group_ptr.p,
@@ -1807,6 +1846,17 @@ int mfm_hyper_stats(mfm_ctx *ctx, int32_t need_e, const double *mu_w, const doub
     hipLaunchKernelGGL(k_group_stats_final, dim3(cdiv(G * (K + 1), 64)), dim3(64), 0, s, c->gs_partial.p, G * (K + 1), n_ch,
                        c->hs_out.p + 1);
   }
+  if (slot_sums) {
+    TimedLaunch t(c->timing, s, KC_REDUCE_E, 16.0 * c->res.G);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, s, c->res.sums.p, c->res.G, c->hs_out.p);
+    c->comm.allreduce(c->hs_out.p, 2);
+  } else if (need_e) {
+    TimedLaunch t(c->timing, s, KC_REDUCE_E, 8.0 * c->N);
+    hipLaunchKernelGGL(k_reduce_e_partial, dim3(REDUCE_BLOCKS), dim3(WG), 0, s, c->eq.p, c->N, c->red_partial.p);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, s, c->red_partial.p, REDUCE_BLOCKS, c->hs_out.p);
+    c->comm.allreduce(c->hs_out.p, 2);
+  }
+  if (!need_e && c->res.peers_model && c->comm.active()) c->comm.allreduce(c->hs_out.p, 1);  // (ordering only, see above)
   MFM_HIP_CHECK(hipGetLastError());
   double2 *h = c->readback(n_out + 1);
   MFM_HIP_CHECK(hipMemcpyAsync(h, c->hs_out.p, n_out * sizeof(double2), hipMemcpyDeviceToHost, s));
@@ -1931,7 +1981,7 @@ int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambd
                      c->group.p, c->G, alpha, c->ls.error.p, lazy_store, c->w.p, zwdev, d_lam_w, d_mu_w, e_shift, load_slots);
   c->e_in_slots = lazy_store;
   c->q_stale_factor = f_end - 1;
-  if (c->comm.active()) sync_model_sharded(c, true, f_begin, f_end);
+  if (c->comm.active() && !c->res.peers_model) sync_model_sharded(c, true, f_begin, f_end);
   MFM_CATCH(ctx)
 }
 
@@ -1995,7 +2045,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
                        c->group.p, c->G, alpha, c->ls.error.p, lazy_store);
     c->e_in_slots = lazy_store;
     c->q_stale_factor = f_end - 1;
-    sync_model_sharded(c, false, f_begin, f_end);
+    if (!c->res.peers_model) sync_model_sharded(c, false, f_begin, f_end);
     return MFM_OK;
   }
   if (c->sharded_fused) {

@@ -96,6 +96,11 @@ struct ResArgs {
   double *xsum[RES_MAX_PEERS];
   unsigned long long *xflag[RES_MAX_PEERS];   // [source rank] 16 words apart
   unsigned long long *xarrive;                // this rank's workgroups that have published the sweep
+  // ... and the first-level coefficients: a user is drawn where its rows live and written into every rank's w / V there and then
+  // (xmodel; the sweep's flag covers them: it is raised after every workgroup's stores), so the replicas need no
+  // synchronisation after the launch
+  int xmodel;
+  double *xw[RES_MAX_PEERS], *xV[RES_MAX_PEERS];
   int rot;                   // workgroup g runs as block (g - rot) mod G (MFM_RES_ROT: placement experiments)
   int dbg;                   // timing experiments only (MFM_RES_DBG; results are wrong when set): 4 no grid barriers, 32 no item
                              // draw, 64 no sweep A, 128 no sweep B, 4096 no partial stores inside sweep B
@@ -395,6 +400,11 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       }
       const double fresh = PMainV::draw(S1, S2, uold, a.alpha, ulam, umu, uz);
       Vf[uj] = fresh;
+      if (XCH && a.xmodel) {  // the other ranks' replicas of this coefficient
+        for (int r = 0; r < a.xworld; r++)
+          if (r != a.xrank)
+            __hip_atomic_store((lin ? a.xw[r] : a.xV[r] + (int64_t)f * a.D) + uj, fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       utab[tid] = d2_t{lin ? 1.0 : fresh, fresh - uold};  // {h of the item level, delta}
     }
     __syncthreads();
@@ -925,12 +935,16 @@ struct ResPlan {
   double *peer_sum[RES_MAX_PEERS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned long long *peer_flag[RES_MAX_PEERS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned long long xepoch = 0;
+  bool peers_model = false;  // the peers' w / V are known too: first-level coefficients are written to every replica in the launch
+  double *peer_w[RES_MAX_PEERS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double *peer_V[RES_MAX_PEERS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   std::vector<void *> peer_mapped;  // IPC mappings to close (mfm_peer_import)
   size_t xsum_bytes(int world) const { return (size_t)world * 2 * 2 * ((size_t)n_items + 1) * sizeof(double); }
   void alloc_exchange(int world, int rank, hipStream_t s) {
     xworld = world;
     xrank = rank;
     peers_set = false;
+    peers_model = false;
     xepoch = 0;
     // (what other GPUs write and this one reads inside a running kernel: uncached device memory, coherent for every agent --
     //  plain device memory if the runtime refuses the flag)
@@ -1419,9 +1433,12 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   a.xrank = rp.xrank;
   a.xepoch0 = rp.xepoch;
   a.xarrive = rp.xarrive.p;
+  a.xmodel = xch && rp.peers_model ? 1 : 0;
   for (int r = 0; r < RES_MAX_PEERS; r++) {
     a.xsum[r] = rp.peer_sum[r];
     a.xflag[r] = rp.peer_flag[r];
+    a.xw[r] = rp.peer_w[r];
+    a.xV[r] = rp.peer_V[r];
   }
   if (xch && !rp.peers_set) throw Error(MFM_ERR_RUNTIME, "row-sharded persistent sweep: the peers' exchange buffers are not set (mfm_peer_set)");
   // MFM_RES_PROF=n: the n-th launch of the process records the phase stamps of every workgroup and prints a summary

@@ -180,7 +180,7 @@ def connect_peers(session, group=None):
         mine, err = b"", "%s: %s" % (type(ex).__name__, ex)
     gathered = [None] * world
     dist.all_gather_object(gathered, mine, group=group)
-    ok = all(len(h) == 128 for h in gathered)
+    ok = all(len(h) == 256 for h in gathered)
     if ok:
         try:
             session.peer_import(world, rank, b"".join(gathered))

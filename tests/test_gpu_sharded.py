@@ -469,14 +469,17 @@ def test_sharded_persistent_sweep_refused_on_one_rank_falls_back_everywhere(orac
         np.testing.assert_allclose(V, t.fm()[2], rtol=1e-7, atol=1e-8)
 
 
+@pytest.mark.parametrize("model", [True, False])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_persistent_sweep_in_launch_exchange(oracle, world, monkeypatch):
+def test_sharded_persistent_sweep_in_launch_exchange(oracle, world, model, monkeypatch):
     """The persistent sweep row-sharded (mfm_res.hpp XCH): every rank keeps the residual of ITS rows on chip for all
     factors, the ranks' item sums meet INSIDE the launch -- each workgroup writes its slice's sums into every rank's exchange
     buffer, the last workgroup of a rank raises the rank's flag on the peers, everybody adds the ranks' sums in rank order -- so
     there is no collective between the sweeps of an iteration (one model synchronisation after the launch). Here the ranks
     are sessions of one process on ONE GPU, each claiming a share of the CUs, running their launches side by side; the peers'
-    buffers are plain device pointers (mfm_peer_set). Must reproduce the unsharded oracle chain; replicas identical."""
+    buffers are plain device pointers (mfm_peer_set). model: the peers' w / V are known as well (mfm_peer_set_model) -- a user's
+    coefficient is written to every replica where it is drawn, and the only collective left in an iteration is the residual sum.
+    Must reproduce the unsharded oracle chain; replicas identical."""
     from myfm_amd import _capi, _myfm
     from myfm_amd.distributed import shard_cuts
 
@@ -500,9 +503,11 @@ def test_sharded_persistent_sweep_in_launch_exchange(oracle, world, monkeypatch)
             pending, sum_p, flag_p, sum_b, flag_b = s.peer_info()
             assert pending and sum_p and flag_p and sum_b > 0, (pending, sum_p, flag_p)
             assert not (s.plan_flags() & 256)  # not live before every rank knows every rank's buffers
-            peers[rank] = (sum_p, flag_p)
+            peers[rank] = (sum_p, flag_p) + tuple(s.peer_model_info())
             meet.wait()
             s.peer_set(world, rank, [peers[r][0] for r in range(world)], [peers[r][1] for r in range(world)])
+            if model:
+                s.peer_set_model(world, rank, [peers[r][2] for r in range(world)], [peers[r][3] for r in range(world)])
             flags = s.plan_flags()
             calls0 = ls.counts[rank]
             for it in range(3):
@@ -527,7 +532,8 @@ def test_sharded_persistent_sweep_in_launch_exchange(oracle, world, monkeypatch)
     for rank in range(world):
         gw0, gw, gV, ge, lo, flags, calls = out[rank]
         assert flags & 256 and flags & 8, flags  # persistent sweep, row-sharded
-        assert calls <= 3 * 6, calls  # per iteration: sum e, w and V synchronisation, a few scalars -- nothing per factor
+        # per iteration: the residual sums, and without the peers' replicas the w and V synchronisation -- nothing per factor
+        assert calls <= (3 * 2 if model else 3 * 6), calls
         assert abs(gw0 - w0) < 1e-7
         np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
