@@ -146,3 +146,76 @@ def test_fit_sharding_plan_two_ranks():
     for p_ in ps:
         p_.join(60)
     assert got == [(0, "ok"), (1, "ok")]
+
+
+class _FakePeerSession:
+    """what myfm_amd.distributed.connect_peers needs of a training context, without a GPU"""
+
+    def __init__(self, rank, pending=True, fail_export=False, fail_import=False):
+        self.rank, self.pending, self.fail_export, self.fail_import = rank, pending, fail_export, fail_import
+        self.imported, self.dropped = None, False
+
+    def peer_info(self):
+        return (self.pending, 1, 2, 64, 1024)
+
+    def peer_export(self):
+        if self.fail_export:
+            raise RuntimeError("no handle on this rank")
+        return bytes([self.rank]) * 256
+
+    def peer_import(self, world, rank, blob):
+        if self.fail_import:
+            raise RuntimeError("cannot map the peers")
+        self.imported = (world, rank, blob)
+
+    def peer_drop(self):
+        self.dropped = True
+
+
+def _peers_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from myfm_amd.distributed import connect_peers
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = []
+    # every rank has a layout: the handles arrive in rank order on every rank
+    s = _FakePeerSession(rank)
+    live = connect_peers(s)
+    res.append((live, s.imported == (world, rank, b"".join(bytes([r]) * 256 for r in range(world))), s.dropped))
+    # nothing waiting (mfm_finalize's agreement said no): no traffic, nothing installed
+    s = _FakePeerSession(rank, pending=False)
+    res.append((connect_peers(s), s.imported is None, s.dropped))
+    # one rank cannot export / cannot map: EVERY rank gives the path up
+    s = _FakePeerSession(rank, fail_export=(rank == 1))
+    res.append((connect_peers(s), s.imported is None, s.dropped))
+    s = _FakePeerSession(rank, fail_import=(rank == 0))
+    res.append((connect_peers(s), True, s.dropped))
+    out.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_connect_peers_protocol_world2_gloo():
+    """the hand-over of the row-sharded persistent sweep's exchange buffers (myfm_amd.distributed.connect_peers): all ranks install
+    all ranks' handles, or all ranks drop the path -- two gloo processes, no GPU"""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29500 + ((os.getpid() + 137) % 500)
+    procs = [ctx.Process(target=_peers_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        ok, none, fe, fi = res[rank]
+        assert ok == (True, True, False), (rank, ok)
+        assert none == (False, True, False), (rank, none)
+        assert fe == (False, True, True), (rank, fe)
+        assert fi[0] is False and fi[2] is True, (rank, fi)
