@@ -170,3 +170,63 @@ def test_config5_full_size_n50m_rank64(capi, oracle):
     cp = runs[0][3]
     assert cp.shape == (4,) and np.isfinite(cp).all() and np.all(np.diff(cp) > 0)
     assert np.isfinite(runs[0][0]).all()
+
+
+def test_config3_full_size_two_ranks_persistent_sweep(oracle, design, monkeypatch):
+    """BASELINE configs[2] at full size (N = 10 M, rank 32) row-sharded over TWO ranks that share this GPU (124 CUs each, sessions of
+    one process): the persistent sweep on both, item sums and first-level coefficients exchanged inside the launches (mfm_res.hpp
+    XCH), one collective per iteration. Two full iterations of the trainer against the CPU oracle's unsharded chain (the
+    oracle takes ~6 s per iteration here); replicas bit-identical."""
+    import threading
+
+    from myfm_amd import _capi, _myfm
+    from myfm_amd.distributed import shard_cuts
+
+    from .test_gpu_sharded import Lockstep, _config
+
+    monkeypatch.setenv("MFM_RES_CUS", "124")
+    X, y, gi = design
+    world, iters = 2, 2
+    cuts = shard_cuts(X.indices[X.indptr[:-1]], world)
+    ls = Lockstep(world)
+    levels = _capi.column_levels(X)[0]
+    out, errs, peers = {}, [], {}
+    meet = threading.Barrier(world)
+
+    def run(rank):
+        try:
+            lo, hi = cuts[rank], cuts[rank + 1]
+            s = _myfm.GibbsSession(K, 0.1, X[lo:hi], [], y[lo:hi], 42, _config(gi), allreduce=ls.callback(rank), n_total_rows=N,
+                                   row_offset=lo, main_levels=levels, shard_rank=rank, shard_world=world)
+            info = s.peer_info()
+            assert info[0], "no layout waiting for the peers"
+            peers[rank] = (info[1], info[2]) + tuple(s.peer_model_info())
+            meet.wait()
+            s.peer_set(world, rank, [peers[r][0] for r in range(world)], [peers[r][1] for r in range(world)])
+            s.peer_set_model(world, rank, [peers[r][2] for r in range(world)], [peers[r][3] for r in range(world)])
+            calls0 = ls.counts[rank]
+            for it in range(iters):
+                s.step()
+            out[rank] = (s.plan_flags(), s.fm.w0, np.asarray(s.fm.w), np.asarray(s.fm.V), float(s.hyper.alpha), ls.counts[rank] - calls0)
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            ls.bar.abort()
+            meet.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=900)
+    assert not errs, errs
+    t = oracle.OracleTrainer(X, y, rank=K, group_index=gi)
+    for it in range(iters):
+        t.step()
+    w0, w, V = t.fm()
+    for rank in range(world):
+        flags, gw0, gw, gV, alpha, calls = out[rank]
+        assert flags & 256 and flags & 8 and calls <= 2 * iters, (flags, calls)
+        assert abs(gw0 - w0) < 1e-7 and abs(alpha - t.hyper()["alpha"]) < 1e-7 * alpha
+        np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
+        assert np.array_equal(gV, out[0][3]) and np.array_equal(gw, out[0][2])
