@@ -474,8 +474,10 @@ def main():
             "avg_launch_us": round(us, 2), "launches": int(launches), "alg_bytes_per_launch": round(alg_bytes / launches),
             "note": "achieved = the kernel's OWN algorithmic bytes / HIP-event time of its launches in the timed region. "
                     "sweep_V_resident = update_w0's shift + update_w + update_V of a two-field table as ONE persistent launch, "
-                    "the residual on chip for all K + 1 sweeps: e read once (8 B / row + its 4-byte slot map) and left once in "
-                    "slot order (8 B / row), per sweep one 16-byte statistics partial per (workgroup, item) run written + read, "
+                    "the residual on chip for all K + 1 sweeps: e read once (8 B / row, in slot order) and NOT written back -- "
+                    "update_e, which follows, recomputes it (FMTrainer.hpp:494), so the launch's copy would be a dead store "
+                    "(mfm_set_residual_policy; MYFM_AMD_KEEP_RESIDUAL=1 keeps it: + 8 B / row) --, per sweep one 16-byte "
+                    "statistics partial per (workgroup, item) run written + read, "
                     "its 8-byte list entry and two 4-byte item reads. The launch is bound by instruction issue, LDS atomics "
                     "and two grid barriers per sweep, not by HBM: its fraction of the HBM roofline is low BECAUSE the bytes are "
                     "gone (r02's per-factor pass moved 289 MB per factor, this one 98 MB); see DESIGN.md 4.3b. "

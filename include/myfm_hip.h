@@ -124,6 +124,10 @@ int mfm_add_block(mfm_ctx *ctx, int64_t B, int64_t Db, const int64_t *indptr, co
                   const double *data, const int64_t *original_to_block);
 /* group_index over ALL D = D0 + sum Db features (FMLearningConfig.hpp:83), G groups.      */
 int mfm_set_groups(mfm_ctx *ctx, const int32_t *group_index, int64_t D, int32_t G);
+/* recomputable = 1 (regression): outside the sweeps the residual is always e = score - y -- mfm_update_e_regression follows every
+ * update_V (FMTrainer.hpp:494) -- so a sweep that keeps the residual on chip need not write its copy back; whoever reads the
+ * residual between the sweep and the update gets it recomputed (equal up to rounding). Default 0: every sweep leaves its residual. */
+int mfm_set_residual_policy(mfm_ctx *ctx, int32_t recomputable);
 /* Builds the device-side design: CSC (= X_t, BaseFMTrainer.hpp:61), the conflict-free level
  * schedule of the columns, the residual/q-cache vectors. rank = n_factors (may be 0).      */
 int mfm_finalize(mfm_ctx *ctx, int32_t rank);

@@ -20,7 +20,7 @@ TASK_REGRESSION, TASK_CLASSIFICATION, TASK_ORDERED = 0, 1, 2
 SYMBOLS = [
     "mfm_version", "mfm_device_count", "mfm_global_error", "mfm_create", "mfm_destroy", "mfm_last_error",
     "mfm_set_stream", "mfm_synchronize", "mfm_set_main", "mfm_add_block", "mfm_set_groups", "mfm_finalize",
-    "mfm_peer_info", "mfm_peer_set", "mfm_peer_model_info", "mfm_peer_set_model", "mfm_peer_export", "mfm_peer_import", "mfm_peer_drop", "mfm_dim_all", "mfm_plan_info", "mfm_plan_flags", "mfm_set_state", "mfm_get_state", "mfm_set_w0", "mfm_zero_w", "mfm_get_e",
+    "mfm_peer_info", "mfm_peer_set", "mfm_peer_model_info", "mfm_peer_set_model", "mfm_peer_export", "mfm_peer_import", "mfm_peer_drop", "mfm_set_residual_policy", "mfm_dim_all", "mfm_plan_info", "mfm_plan_flags", "mfm_set_state", "mfm_get_state", "mfm_set_w0", "mfm_zero_w", "mfm_get_e",
     "mfm_get_q", "mfm_set_e", "mfm_reduce_e", "mfm_shift_e", "mfm_group_stats_w", "mfm_group_stats_V",
     "mfm_sweep_w", "mfm_sweep_V", "mfm_sweep_wV", "mfm_update_e_regression", "mfm_update_e_classification", "mfm_score_train",
     "mfm_oprobit_add_group", "mfm_oprobit_eval", "mfm_oprobit_sample_z", "mfm_hyper_stats", "mfm_timing_enable", "mfm_timing_select", "mfm_timing_reset",
@@ -71,6 +71,7 @@ def lib():
     L.mfm_peer_export.argtypes = [vp, P]
     L.mfm_peer_import.argtypes = [vp, i32, i32, P]
     L.mfm_peer_drop.argtypes = [vp]
+    L.mfm_set_residual_policy.argtypes = [vp, i32]
     L.mfm_dim_all.restype = i64
     L.mfm_dim_all.argtypes = [vp]
     L.mfm_plan_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
@@ -386,6 +387,9 @@ class Context:
         zw, zv = np.empty(self.D), np.empty((max(self.K, 1), self.D))
         self._ck(lib().mfm_rng_get_z(self.h, _p(zw), _p(zv)))
         return zw, zv[: self.K]
+
+    def set_residual_policy(self, recomputable):
+        self._ck(lib().mfm_set_residual_policy(self.h, 1 if recomputable else 0))
 
     def plan_flags(self):
         f = lib().mfm_plan_flags(self.h)

@@ -1102,6 +1102,8 @@ struct FMTrainer {
     lap("mfm_set_groups");
     ck(ctx, mfm_finalize(ctx, rank));
     lap("mfm_finalize");
+    // regression: update_e recomputes the residual after every update_V (:494), nothing reads it in between
+    if (cfg.task_type == TaskType::REGRESSION && !std::getenv("MYFM_AMD_KEEP_RESIDUAL")) ck(ctx, mfm_set_residual_policy(ctx, 1));
   }
   void upload(const FM &fm) { ck(ctx, mfm_set_state(ctx, fm.w0, fm.w.data(), fm.V.data())); }
   void download(FM &fm) {

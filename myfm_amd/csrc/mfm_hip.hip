@@ -168,6 +168,9 @@ struct mfm_ctx {
   // the persistent sweep's layout was built first, on the device, and took the table: X_t, the level plans and the row tiles of
   // the per-factor passes (their fall-back) are built when a call needs them (ensure_main_plans)
   std::vector<DevBuf<int32_t>> pre_maps;  // the blocks' maps uploaded ahead of the blocks (mfm_finalize only)
+  // regression: outside the sweeps the residual IS score - y (update_e recomputes it after every update_V, FMTrainer.hpp:494), so
+  // the persistent launch need not write its copy back (mfm_set_residual_policy); whoever asks for it in between gets it recomputed
+  bool e_recomputable = false, e_lost = false;
   bool res_sharded_pending = false;  // row-sharded: the persistent sweep's layout is built on every rank, waiting for mfm_peer_set
   bool main_lazy = false;
   bool res_refused = false;  // the CUs of the persistent sweep were not ours to take
@@ -510,7 +513,15 @@ static SweepArgs main_args(mfm_ctx *c, double *theta, const double *z, const dou
 
 // the residual the resident latent sweep left in slot order -> eq (only when somebody reads it: in the Gibbs loop update_e
 // follows and recomputes it)
+static void score_train(mfm_ctx *c, bool subtract_y);
+// the persistent launch did not write the residual back (e_recomputable): here it is again, e = score - y
+static void ensure_e(mfm_ctx *c) {
+  if (!c->e_lost) return;
+  c->e_lost = false;
+  score_train(c, true);
+}
 static void materialize_e(mfm_ctx *c) {
+  ensure_e(c);
   c->slot_sums_valid = false;  // (whoever asks for the residual in row order may change it)
   if (c->e_in_cell) {  // (the cell path's sweeps leave it in cell order; update_e, which follows in the Gibbs loop, just drops it)
     cell_unpack_e(c->stream, c->cell, c->eq.p);
@@ -524,6 +535,7 @@ static void materialize_e(mfm_ctx *c) {
 }
 
 static void score_train(mfm_ctx *c, bool subtract_y) {
+  c->e_lost = false;
   c->e_in_slots = false;  // (every residual is overwritten)
   c->e_in_cell = false;
   c->slot_sums_valid = false;
@@ -1634,6 +1646,12 @@ int mfm_peer_drop(mfm_ctx *ctx) {
   MFM_CATCH(ctx)
 }
 
+int mfm_set_residual_policy(mfm_ctx *ctx, int32_t recomputable) {
+  if (!ctx) return MFM_ERR_INVALID;
+  ctx->e_recomputable = recomputable != 0;
+  return MFM_OK;
+}
+
 int64_t mfm_dim_all(const mfm_ctx *ctx) { return ctx->D; }
 
 int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launches_per_sweep) {
@@ -1727,6 +1745,7 @@ int mfm_get_q(mfm_ctx *ctx, double *q) {
 int mfm_set_e(mfm_ctx *ctx, const double *e) {
   MFM_TRY(ctx)
   ctx->need_final();
+  ctx->e_lost = false;  // (every residual is overwritten)
   materialize_e(ctx);
   if (ctx->N) {
     MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1951,6 +1970,7 @@ int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambd
   if ((zw == nullptr) != (zv == nullptr)) throw Error(MFM_ERR_INVALID, "mfm_sweep_wV: give both variate arrays or none");
   if (!zw && (c->rng.current < 0 || c->rng.n_zw != c->D || c->rng.n_zv != c->D * (int64_t)c->K))
     throw Error(MFM_ERR_RUNTIME, "mfm_sweep_wV(z = NULL) needs an acquired device random set with D + K*D variates");
+  ensure_e(c);
   const bool load_slots = c->e_in_slots;  // the residual is already in the launch's slot order: read it there
   c->slot_sums_valid = false;
   hipStream_t s = c->stream;
@@ -1977,9 +1997,12 @@ int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambd
     zbase = c->rng.slot[c->rng.current].zv.p + (size_t)f_begin * c->D;
   }
   const bool lazy_store = !std::getenv("MFM_RES_EAGER_STORE");
+  // (regression, all factors swept: update_e follows and recomputes the residual -- the launch's copy would be a dead store, 64 us)
+  const bool no_store = c->e_recomputable && lazy_store && f_begin == 0 && f_end == c->K && !std::getenv("MFM_RES_ALWAYS_STORE");
   run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq.p, c->V.p, c->D, f_begin, f_end, zbase, d_lam, d_mu,
-                     c->group.p, c->G, alpha, c->ls.error.p, lazy_store, c->w.p, zwdev, d_lam_w, d_mu_w, e_shift, load_slots);
-  c->e_in_slots = lazy_store;
+                     c->group.p, c->G, alpha, c->ls.error.p, lazy_store, c->w.p, zwdev, d_lam_w, d_mu_w, e_shift, load_slots, no_store);
+  c->e_in_slots = lazy_store && !no_store;
+  c->e_lost = no_store;
   c->q_stale_factor = f_end - 1;
   if (c->comm.active() && !c->res.peers_model) sync_model_sharded(c, true, f_begin, f_end);
   MFM_CATCH(ctx)

@@ -101,6 +101,7 @@ struct ResArgs {
   // synchronisation after the launch
   int xmodel;
   double *xw[RES_MAX_PEERS], *xV[RES_MAX_PEERS];
+  int no_store;              // the residual is not written back at the end (the caller recomputes it: update_e follows, FMTrainer.hpp:494)
   int rot;                   // workgroup g runs as block (g - rot) mod G (MFM_RES_ROT: placement experiments)
   int dbg;                   // timing experiments only (MFM_RES_DBG; results are wrong when set): 4 no grid barriers, 32 no item
                              // draw, 64 no sweep A, 128 no sweep B, 4096 no partial stores inside sweep B
@@ -644,8 +645,8 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   }
 #undef RES_STAMP
   RES_STAMP0(3);
-  // the last factor's item update, then the residual goes back
-  {
+  // the last factor's item update, then the residual goes back -- unless nobody will read it (no_store)
+  if (!a.no_store) {
     int run_last = run0;
 #pragma unroll
     for (int j = 0; j < NG; j++) {
@@ -1380,11 +1381,13 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
                                       int f_begin, int f_end, const double *zbase, const double *lam, const double *mu,
                                       const int32_t *group, int n_groups, double alpha, int *error, bool lazy_store,
                                       double *w = nullptr, const double *zw = nullptr, const double *lam_w = nullptr,
-                                      const double *mu_w = nullptr, double e_shift = 0.0, bool load_slots = false) {
+                                      const double *mu_w = nullptr, double e_shift = 0.0, bool load_slots = false,
+                                      bool no_store = false) {
   ResArgs a;
   std::memset(&a, 0, sizeof(a));
   a.eq = eq;
   a.e_slots = lazy_store ? rp.e_slots.p : nullptr;
+  a.no_store = no_store ? 1 : 0;
   a.e_in = load_slots ? rp.e_slots.p : nullptr;
   a.linear = w ? 1 : 0;
   a.n_sw = f_end - f_begin + a.linear;
@@ -1453,7 +1456,7 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   // algorithmic bytes of the launch: e read once (8 B) with its slot map (4 B) and the static slot words (11 bits), written
   // once (8 B: slot order, or scattered to eq); per sweep one 16-byte partial per (workgroup, item) run written and read,
   // its 8-byte list entry, its item read by both sweeps (2 x 4 B)
-  const double bytes = (8.0 + (load_slots ? 0.0 : 4.0) + 1.4 + 8.0) * rp.n_rows + K * 48.0 * rp.n_runs;  // (slot order: no map)
+  const double bytes = (8.0 + (load_slots ? 0.0 : 4.0) + 1.4 + (no_store ? 0.0 : 8.0)) * rp.n_rows + K * 48.0 * rp.n_runs;  // (slot order: no map; no_store: not written back)
   (void)lazy_store;
   hipLaunchKernelGGL(k_res_init_dv, dim3((rp.n_items + 256) / 256), dim3(256), 0, s,
                      w ? (const double *)nullptr : V + (int64_t)f_begin * D, rp.scols.p, rp.n_items,

@@ -309,6 +309,31 @@ def test_resident_layout_from_the_device_plans_on_demand(oracle, capi, monkeypat
     np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-7, atol=1e-7)
 
 
+def test_resident_sweep_leaves_no_residual_when_update_e_follows(oracle, capi, monkeypatch):
+    # regression (mfm_set_residual_policy(1)): update_e recomputes e = score - y after every update_V (FMTrainer.hpp:494), so the
+    # persistent launch does not write its on-chip residual back; whoever reads the residual between the sweep and update_e gets
+    # it recomputed. The chain is the oracle's; the residual read right after the sweep is the oracle's incrementally updated
+    # one up to rounding; a second sweep without update_e in between starts from the same residual.
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    n = 120001
+    X, y, shapes = ds.onehot_mf(n, 260, 140, seed=5, sort_by_user=True)
+    gi = ds.group_index_from_shapes(shapes)
+    t, c, _ = _pair(oracle, capi, X, y, gi, 4)
+    assert c.plan_flags()["resident"]
+    c.set_residual_policy(True)
+    drv = CapiGibbs(c, t.clone(), n, gi, fused=True)
+    seen = {}
+    for it in range(3):
+        t.step()
+        drv.step(before_update_e=lambda: seen.update(e=c.get_e()))
+        np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-7, atol=1e-8, err_msg="iteration %d" % it)
+        np.testing.assert_allclose(c.get_state()[1], t.fm()[1], rtol=1e-7, atol=1e-8)
+        # between the sweep and update_e: recomputed == what update_e is about to write
+        np.testing.assert_allclose(seen["e"], c.get_e(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-7, atol=1e-7)
+    assert "sweep_V_resident" in _timing_classes(c, drv)
+
+
 @pytest.mark.parametrize("device_rng", [False, True])
 def test_resident_linear_and_latent_sweeps_in_one_launch(oracle, capi, monkeypatch, device_rng):
     # mfm_sweep_wV: update_w0's residual shift, update_w and update_V of a two-field one-hot table as ONE persistent launch
