@@ -1254,11 +1254,6 @@ struct FMTrainer {
     const size_t G = cfg.n_groups;
     const int Kf = fm.n_factors;
     htl.start();
-    if (device_rng) {
-      ck(ctx, mfm_rng_acquire(ctx, hv.data(), (int64_t)hv.size()));  // this iteration's variates
-      hv_pos = 0;
-    }
-    htl.mark(0);
     // every reduction the hyper-parameter updates need, one host synchronisation: sum e / sum e^2 (update_alpha,
     // FMTrainer.hpp:127-145, update_w0 :218-229) and the group sums of w and V (:150-216) -- the latter are taken
     // before update_w / update_V touch w / V, which is where the reference takes them too
@@ -1268,6 +1263,14 @@ struct FMTrainer {
     ck(ctx, mfm_hyper_stats(ctx, (need_alpha || cfg.fit_w0) ? 1 : 0, hyper.mu_w.data(), hyper.mu_V.data(), &sum_e, &sum_e2,
                             sum.data(), ssd.data(), sumV.data(), ssdV.data()));
     htl.mark(1);
+    // this iteration's variates -- asked for AFTER the statistics: those do not need them, and the set is produced behind the
+    // previous launch on a side stream (waiting for it first kept the statistics kernels, 0.12 ms with their read-back, off the
+    // GPU until the set was there)
+    if (device_rng) {
+      ck(ctx, mfm_rng_acquire(ctx, hv.data(), (int64_t)hv.size()));
+      hv_pos = 0;
+    }
+    htl.mark(0);
     if (need_alpha) {
       Real exponent = (cfg.alpha_0 + N_total) / 2;
       Real variance = (cfg.beta_0 + sum_e2) / 2;
