@@ -647,51 +647,111 @@ static std::vector<T> download(const T *p, size_t n, hipStream_t s) {
 
 }  // namespace cpd
 
-bool cell_plan_build_device(CellPlan &cp, const DevSparse &X, const std::vector<CellBlockDev> &blocks, int n_cu, hipStream_t s) {
+bool cell_plan_build_device(CellPlan &cp, const DevSparse &X, const std::vector<CellBlockDev> &blocks, int n_cu, hipStream_t s, int rank,
+                            int world, const std::function<void(std::vector<double> &)> &sum_ranks) {
+  // rank / world / sum_ranks: row-sharded, as in cell_plan_build -- every rank plans its own rows on its own device; what must be
+  // the same everywhere (entries per row, the fields' column ranges of the GLOBAL design, which block shares which stream, the
+  // verdicts) is summed over the ranks. Every rank makes the SAME sequence of sums whatever its rows look like (an empty shard too).
   using namespace cpd;
   cp.ready = false;
   cp.streams.clear();
   cp.fields.clear();
   const int64_t N = X.rows;
   cp.N = N;
+  const bool shared = (bool)sum_ranks;
+  auto agree_bad = [&](int local) {  // > 0 on any rank -> the same on every rank
+    if (!shared) return local;
+    std::vector<double> v(1, local ? 1.0 : 0.0);
+    sum_ranks(v);
+    return v[0] > 0.0 ? std::max(local, 1) : 0;
+  };
   if (N >= (int64_t)2147483647) return cp.fail("too many rows");
-  if (N <= 0) return cp.fail("no rows");
-  const int64_t W = X.ell_width;
-  if (W < 1 || W > CELL_MAX_STREAMS || !X.unit || X.nnz != N * W) return cp.fail("the main table is not a row of one-hot fields");
+  if (!shared && N <= 0) return cp.fail("no rows");
   if (blocks.size() > (size_t)MAXB) return cp.fail("too many fields");
+  int64_t W = N > 0 ? X.ell_width : 0;
+  if (shared) {  // (every rank's rows have the same number of entries; an empty shard learns it here)
+    if (rank < 0 || rank >= world) return cp.fail("row-sharded: this rank's place among the ranks is not known");
+    std::vector<double> v((size_t)world, 0.0);
+    v[rank] = (double)std::max<int64_t>(W, 0);
+    sum_ranks(v);
+    int64_t Wg = 0;
+    for (double x : v) Wg = std::max<int64_t>(Wg, (int64_t)x);
+    for (double x : v)
+      if (x != 0.0 && (int64_t)x != Wg) Wg = -1;
+    if (N == 0 && Wg > 0) W = Wg;
+    if (N > 0 && W != Wg) W = -2;
+  }
+  const int bad0 = (W < 1 || W > CELL_MAX_STREAMS || (N > 0 && (!X.unit || X.nnz != N * W))) ? 1 : 0;
+  if (agree_bad(bad0)) return cp.fail("the main table is not a row of one-hot fields");
   auto grid = [](int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); };
   // fields: column ranges of the W entries of a row, order of the first
-  DevBuf<int32_t> red;
-  {
+  std::vector<int64_t> lo((size_t)W, (int64_t)1 << 60), hi((size_t)W, -1);
+  int bad = 0;
+  if (N > 0) {
+    DevBuf<int32_t> red;
     std::vector<int32_t> r0((size_t)2 * W + 1, 0);
     for (int64_t p = 0; p < W; p++) {
       r0[2 * p] = 0x7fffffff;
       r0[2 * p + 1] = -1;
     }
     red.upload(r0);
+    hipLaunchKernelGGL(k_fields, grid(N), dim3(TB), 0, s, X.colidx.p, N, (int)W, red.p);
+    const std::vector<int32_t> h_red = download(red.p, (size_t)2 * W + 1, s);
+    if (h_red[2 * W]) bad = 2;
+    for (int64_t p = 0; p < W; p++) {
+      lo[p] = h_red[2 * p];
+      hi[p] = h_red[2 * p + 1];
+    }
   }
-  hipLaunchKernelGGL(k_fields, grid(N), dim3(TB), 0, s, X.colidx.p, N, (int)W, red.p);
-  const std::vector<int32_t> h_red = download(red.p, (size_t)2 * W + 1, s);
-  if (h_red[2 * W]) return cp.fail("the rows are not sorted by the first field");
-  for (int64_t p = 1; p < W; p++)
-    if (h_red[2 * p] <= h_red[2 * (p - 1) + 1])
-      return cp.fail("the main table is not a row of unit-valued one-hot fields with disjoint column ranges");
+  if (shared) {  // the fields' column ranges of the GLOBAL design: every rank's (lo, hi) in its own slot of a summed vector
+    std::vector<double> v((size_t)world * 2 * W, 0.0);
+    for (int r = 0; r < world; r++)
+      for (int64_t p = 0; p < W; p++) {  // (neutral elements in the slots of the others; an empty shard's own slot too)
+        v[((size_t)r * W + p) * 2] = 0.0;
+        v[((size_t)r * W + p) * 2 + 1] = 0.0;
+      }
+    for (int64_t p = 0; p < W; p++) {
+      v[((size_t)rank * W + p) * 2] = (double)lo[p];
+      v[((size_t)rank * W + p) * 2 + 1] = (double)hi[p];
+    }
+    sum_ranks(v);
+    for (int r = 0; r < world; r++)
+      for (int64_t p = 0; p < W; p++) {
+        lo[p] = std::min(lo[p], (int64_t)v[((size_t)r * W + p) * 2]);
+        hi[p] = std::max(hi[p], (int64_t)v[((size_t)r * W + p) * 2 + 1]);
+      }
+  }
+  for (int64_t p = 1; p < W && !bad; p++)
+    if (lo[p] <= hi[p - 1]) bad = 3;
+  {
+    const int b_all = agree_bad(bad);
+    if (b_all) return cp.fail(bad == 2 ? "the rows are not sorted by the first field"
+                                      : "the main table is not a row of unit-valued one-hot fields with disjoint column ranges");
+  }
   std::vector<int64_t> base((size_t)W + 1, 0);
-  for (int64_t p = 1; p < W; p++) base[p] = h_red[2 * p];
+  for (int64_t p = 1; p < W; p++) base[p] = lo[p];
   base[W] = X.cols;
-  // streams: which block's map equals which stream on every row (all pairs in one pass)
+  // streams: which block's map equals which stream on every row (all pairs in one pass; row-sharded: the matrix summed over the
+  // ranks -- a pair differs if it differs on any rank's rows)
   Src sr;
   sr.W = (int)W;
   sr.nb = (int)blocks.size();
   for (int64_t p = 0; p < W; p++) sr.base[p] = (int32_t)base[p];
   for (size_t b = 0; b < blocks.size(); b++) sr.map[b] = blocks[b].map;
   const int nc = sr.W + sr.nb;
-  std::vector<int32_t> h_diff;
+  std::vector<int32_t> h_diff((size_t)sr.nb * nc, 0);
   if (sr.nb) {
-    DevBuf<int32_t> diff;
-    diff.alloc_zero((size_t)sr.nb * nc, s);
-    hipLaunchKernelGGL(k_stream_diff, grid(N), dim3(TB), 0, s, X.colidx.p, sr, N, diff.p);
-    h_diff = download(diff.p, (size_t)sr.nb * nc, s);
+    if (N > 0) {
+      DevBuf<int32_t> diff;
+      diff.alloc_zero((size_t)sr.nb * nc, s);
+      hipLaunchKernelGGL(k_stream_diff, grid(N), dim3(TB), 0, s, X.colidx.p, sr, N, diff.p);
+      h_diff = download(diff.p, (size_t)sr.nb * nc, s);
+    }
+    if (shared) {
+      std::vector<double> v(h_diff.begin(), h_diff.end());
+      sum_ranks(v);
+      for (size_t i = 0; i < v.size(); i++) h_diff[i] = v[i] > 0.0 ? 1 : 0;
+    }
   }
   std::vector<CellStreamSrc> src;
   {
@@ -700,13 +760,19 @@ bool cell_plan_build_device(CellPlan &cp, const DevSparse &X, const std::vector<
     if (!cell_plan_streams(cp, W, base, Bs, src, [&](size_t b, const CellStreamSrc &c) {
           return h_diff[b * nc + (c.main_p >= 0 ? c.main_p : sr.W + c.block)] != 0;
         }))
-      return false;
+      return false;  // (decided from agreed inputs: the same on every rank)
   }
   // groups of consecutive U values, rows balanced; more (smaller) groups until every pass of the sweep fits its LDS
   const int64_t cardU = cp.streams[0].card;
   std::vector<int32_t> h_grow, gu0;
   bool fits = false;
-  {
+  if (N == 0) {  // (an empty shard: no groups, no launches; it still takes part in every sum)
+    h_grow.assign(1, 0);
+    gu0.assign(1, 0);
+    cp.G = 0;
+    cp.umax = 0;
+    fits = true;
+  } else {
     DevBuf<int32_t> out_r, out_u;
     const int64_t Gmax = (int64_t)std::max(1, n_cu) * 16;
     out_r.alloc((size_t)Gmax);
@@ -725,16 +791,27 @@ bool cell_plan_build_device(CellPlan &cp, const DevSparse &X, const std::vector<
         }
       h_grow.push_back((int32_t)N);
       gu0.push_back((int32_t)cardU);
+      if (shared) {  // (a shard's groups cover its own U values only: the sums of the others come from their ranks)
+        int32_t u_first = 0, u_last = 0;
+        MFM_HIP_CHECK(hipMemcpy(&u_first, X.colidx.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+        MFM_HIP_CHECK(hipMemcpy(&u_last, X.colidx.p + (N - 1) * W, sizeof(int32_t), hipMemcpyDeviceToHost));
+        gu0.front() = u_first;
+        gu0.back() = u_last + 1;
+      }
       fits = cell_plan_groups_fit(cp, gu0);
     }
   }
   const int G = cp.G;
   const int64_t cardI = cp.sI >= 0 ? cp.streams[cp.sI].card : 0;
-  if (!fits)
-    return cp.fail("a group's tables do not fit the LDS (a first-field value with too many rows, or too many values per group)");
-  if (cardI > 0 && (double)G * (double)cardI * 56.0 > 16e9) return cp.fail("the (group, item) partials would not fit");
+  {
+    const int lf = !fits ? 1 : (cardI > 0 && (double)G * (double)cardI * 56.0 > 16e9) ? 2 : 0;
+    if (agree_bad(lf))
+      return cp.fail(lf == 2 ? "the (group, item) partials would not fit"
+                             : "a group's tables do not fit the LDS (a first-field value with too many rows, or too many values per group)");
+  }
   const bool has_i = cp.sI >= 0;
-  const int ibits = has_i ? bits_for(cardI) : 0, gbits = bits_for(G);
+  // (the key width is judged on the most groups any rank may form, so that every rank takes the same planner)
+  const int ibits = has_i ? bits_for(cardI) : 0, gbits = bits_for(shared ? std::max<int64_t>(G, (int64_t)std::max(1, n_cu) * 16) : G);
   if (ibits + gbits > 32) return cp.fail("device planner: (group, item) sort key wider than 32 bits");
   constexpr int WROWS = 64 * CELL_R;
   DevBuf<int32_t> grow, d_gu0, c0, steps;
@@ -744,7 +821,7 @@ bool cell_plan_build_device(CellPlan &cp, const DevSparse &X, const std::vector<
   DevBuf<uint32_t> key, key2;
   DevBuf<int32_t> val, val2;
   DevBuf<char> tmp;
-  if (has_i) {
+  if (has_i && N > 0) {
     key.alloc((size_t)N);
     key2.alloc((size_t)N);
     val.alloc((size_t)N);
@@ -761,8 +838,10 @@ bool cell_plan_build_device(CellPlan &cp, const DevSparse &X, const std::vector<
   c0.alloc((size_t)G * (CELL_NW + 1));
   steps.alloc((size_t)G);
   cp.chunk_len.alloc((size_t)G * CELL_NW);
-  hipLaunchKernelGGL(k_chunk_cuts, grid((int64_t)G * (CELL_NW + 1) * 64), dim3(TB), 0, s, key2.p, grow.p, G, has_i, c0.p);
-  hipLaunchKernelGGL(k_chunk_fin, grid(G), dim3(TB), 0, s, c0.p, G, WROWS, cp.chunk_len.p, steps.p);
+  if (G > 0) {
+    hipLaunchKernelGGL(k_chunk_cuts, grid((int64_t)G * (CELL_NW + 1) * 64), dim3(TB), 0, s, key2.p, grow.p, G, has_i, c0.p);
+    hipLaunchKernelGGL(k_chunk_fin, grid(G), dim3(TB), 0, s, c0.p, G, WROWS, cp.chunk_len.p, steps.p);
+  }
   const std::vector<int32_t> h_steps = download(steps.p, (size_t)G, s);
   std::vector<int32_t> gbase((size_t)G + 1, 0);
   int64_t npad = 0;
@@ -770,7 +849,7 @@ bool cell_plan_build_device(CellPlan &cp, const DevSparse &X, const std::vector<
     gbase[g] = (int32_t)npad;
     npad += (int64_t)h_steps[g] * WROWS * CELL_NW;
   }
-  if (npad >= (int64_t)2147483647) return cp.fail("padded row count exceeds 2^31");
+  if (agree_bad(npad >= (int64_t)2147483647 ? 1 : 0)) return cp.fail("padded row count exceeds 2^31");
   gbase[G] = (int32_t)npad;
   cp.Npad = npad;
   cp.grp_base.upload(gbase);
@@ -794,8 +873,9 @@ bool cell_plan_build_device(CellPlan &cp, const DevSparse &X, const std::vector<
     rs.base[si] = src[si].main_p >= 0 ? (int32_t)base[src[si].main_p] : 0;
     rs.map[si] = src[si].block >= 0 ? blocks[(size_t)src[si].block].map : nullptr;
   }
-  hipLaunchKernelGGL(k_records, grid(N), dim3(TB), has_i ? 0 : (size_t)(G + 1) * sizeof(int32_t), s, key2.p, val2.p, X.colidx.p, (int)W, rs,
-                     grow.p, c0.p, cp.grp_base.p, cp.grp_u0.p, G, ibits, has_i, WROWS, N, cp.ix.p, cp.item.p, cp.perm.p);
+  if (N > 0)
+    hipLaunchKernelGGL(k_records, grid(N), dim3(TB), has_i ? 0 : (size_t)(G + 1) * sizeof(int32_t), s, key2.p, val2.p, X.colidx.p, (int)W, rs,
+                       grow.p, c0.p, cp.grp_base.p, cp.grp_u0.p, G, ibits, has_i, WROWS, N, cp.ix.p, cp.item.p, cp.perm.p);
   MFM_HIP_CHECK(hipGetLastError());
   cell_plan_buffers(cp, s);  // (synchronises: the sort buffers go out of scope)
   cp.ready = true;

@@ -136,7 +136,8 @@ struct CellBlockDev {
   const int32_t *map;
   int64_t B;
 };
-bool cell_plan_build_device(CellPlan &cp, const DevSparse &X, const std::vector<CellBlockDev> &blocks, int n_cu, hipStream_t s);
+bool cell_plan_build_device(CellPlan &cp, const DevSparse &X, const std::vector<CellBlockDev> &blocks, int n_cu, hipStream_t s, int rank = 0,
+                            int world = 1, const std::function<void(std::vector<double> &)> &sum_ranks = nullptr);
 std::string cell_plan_compare(const CellPlan &a, const CellPlan &b, hipStream_t s);  // "" or the first array that differs
 void cell_pack_e(hipStream_t s, CellPlan &cp, const double2 *eq);
 void cell_unpack_e(hipStream_t s, CellPlan &cp, double2 *eq);

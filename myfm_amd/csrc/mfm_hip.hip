@@ -1320,10 +1320,12 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
         if (const char *e = std::getenv("MFM_CELL_GROUPS")) n_cu = std::max(1, std::atoi(e));
         std::vector<CellBlockIn> bin;
         for (auto &hb : c->hblocks) bin.push_back(CellBlockIn{hb.map.get(), hb.X.rows});
-        if (sh) {
-          cell_plan_build(c->cell, c->host_main(), bin, n_cu, c->stream, c->comm.shard_set ? c->comm.rank : -1, c->comm.world, sum_ranks);
-        } else if (std::getenv("MFM_CELL_HOST_PLAN")) {
-          cell_plan_build(c->cell, c->host_main(), bin, n_cu, c->stream);
+        const int sh_rank = c->comm.shard_set ? c->comm.rank : -1;
+        if (std::getenv("MFM_CELL_HOST_PLAN")) {
+          if (sh)
+            cell_plan_build(c->cell, c->host_main(), bin, n_cu, c->stream, sh_rank, c->comm.world, sum_ranks);
+          else
+            cell_plan_build(c->cell, c->host_main(), bin, n_cu, c->stream);
         } else {
           // one GPU: the plan is built on the device from the CSR and the blocks' maps (uploaded here, kept for the blocks)
           const size_t nb = c->hblocks.size();
@@ -1349,13 +1351,23 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
           lap("block maps to the device");
           std::vector<CellBlockDev> bdev;
           for (size_t b = 0; b < nb; b++) bdev.push_back(CellBlockDev{c->pre_maps[b].p, c->hblocks[b].X.rows});
-          cell_plan_build_device(c->cell, c->X, bdev, n_cu, c->stream);
+          // (row-sharded: every rank plans its own rows on its own device, the agreements are summed over the ranks inside)
+          auto host_plan = [&](CellPlan &cp) {
+            if (sh)
+              cell_plan_build(cp, c->host_main(), bin, n_cu, c->stream, sh_rank, c->comm.world, sum_ranks);
+            else
+              cell_plan_build(cp, c->host_main(), bin, n_cu, c->stream);
+          };
+          if (sh)
+            cell_plan_build_device(c->cell, c->X, bdev, n_cu, c->stream, sh_rank, c->comm.world, sum_ranks);
+          else
+            cell_plan_build_device(c->cell, c->X, bdev, n_cu, c->stream);
           if (!c->cell.ready && c->cell.why.rfind("device planner:", 0) == 0) {
-            cell_plan_build(c->cell, c->host_main(), bin, n_cu, c->stream);  // (a shape only the host planner handles)
+            host_plan(c->cell);  // (a shape only the host planner handles: the same verdict on every rank)
           } else if (std::getenv("MFM_PLAN_CHECK")) {  // tests: the host planner must give the same plan, array for array
             lap("cell plan (device)");
             CellPlan chk;
-            cell_plan_build(chk, c->host_main(), bin, n_cu, c->stream);
+            host_plan(chk);
             if (chk.ready != c->cell.ready) throw Error(MFM_ERR_RUNTIME, "plan check: device and host cell planners disagree: device '" + c->cell.why + "' host '" + chk.why + "'");
             if (chk.ready) {
               const std::string diff = cell_plan_compare(c->cell, chk, c->stream);
