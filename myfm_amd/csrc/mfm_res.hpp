@@ -37,6 +37,9 @@
 
 namespace mfm {
 
+#ifndef MFM_RES_CH
+#define MFM_RES_CH 4
+#endif
 constexpr int RES_MAX_PEERS = 8;
 
 struct ResArgs {
@@ -129,7 +132,9 @@ struct ResBar {
 __device__ __forceinline__ bool res_spin(const ResArgs &a, const unsigned long long *w, unsigned long long target, bool &dead) {
   unsigned spins = 0;
   while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+#ifndef MFM_RES_NO_SLEEP
     __builtin_amdgcn_s_sleep(1);
+#endif
     if ((++spins & 1023u) == 0u) {
       if (spins > (1u << 22) || __hip_atomic_load(a.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         __hip_atomic_store(a.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
     RES_STAMP(3);
     // everything of the item draw that does not depend on the partials is requested before the barrier: this thread's item
     // (coefficient, variate, hyper-parameters, the next factor's coefficient) and the wave's first list entries
-    constexpr int CH = 4;
+    constexpr int CH = MFM_RES_CH;
     const int c0 = a.ent_ptr[g] >> 6, c1 = a.ent_ptr[g + 1] >> 6;
     const int per = (c1 - c0 + NW - 1) / NW;
     const int wb = c0 + wv * per, we = wb + per < c1 ? wb + per : c1;
