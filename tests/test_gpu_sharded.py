@@ -541,6 +541,74 @@ def test_sharded_persistent_sweep_in_launch_exchange(oracle, world, model, monke
         assert np.array_equal(gV, out[0][2]) and np.array_equal(gw, out[0][1])
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_sharded_persistent_sweep_awkward_shards(oracle, seed, monkeypatch):
+    """The same path on tables with columns that never occur (in both fields: drawn from the prior by every rank alike), items
+    that have rows on one rank only, and uneven shards: oracle chain, identical replicas."""
+    from myfm_amd import _capi, _myfm
+
+    from .test_gpu_planner_fuzz import _two_field
+
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    world = 3
+    monkeypatch.setenv("MFM_RES_CUS", str(240 // world))
+    rng = np.random.default_rng(50 + seed)
+    n = int(rng.integers(60000, 140000))
+    X, y, shapes = _two_field(rng, n, int(rng.integers(40, 400)), int(rng.integers(30, 300)), float(rng.uniform(0.3, 1.4)), 0.3)
+    gi = ds.group_index_from_shapes(shapes)
+    K = 2
+    first = X.indices[X.indptr[:-1]]
+    users = np.unique(first)
+    # rank 0: a small shard (the first sixth of the users); the rest split in two at a user boundary
+    b0 = int(np.searchsorted(first, users[max(3, len(users) // 6)]))
+    b1 = int(np.searchsorted(first, users[(len(users) + 3) // 2]))
+    cuts = [0, b0, max(b1, b0 + 1), n]
+    ls = Lockstep(world)
+    levels = _capi.column_levels(X)[0]
+    out, errs, peers = {}, [], {}
+    meet = threading.Barrier(world)
+
+    def run(rank):
+        try:
+            lo, hi = cuts[rank], cuts[rank + 1]
+            s = _myfm.GibbsSession(K, 0.1, X[lo:hi], [], y[lo:hi], 42, _config(gi), allreduce=ls.callback(rank), n_total_rows=n,
+                                   row_offset=lo, main_levels=levels, shard_rank=rank, shard_world=world)
+            info = s.peer_info()
+            peers[rank] = (info[0], info[1], info[2]) + tuple(s.peer_model_info())
+            meet.wait()
+            assert all(peers[r][0] for r in range(world)) == bool(info[0])  # the same verdict on every rank
+            if info[0]:
+                s.peer_set(world, rank, [peers[r][1] for r in range(world)], [peers[r][2] for r in range(world)])
+                s.peer_set_model(world, rank, [peers[r][3] for r in range(world)], [peers[r][4] for r in range(world)])
+            for it in range(3):
+                s.step()
+            out[rank] = (bool(info[0]), s.plan_flags(), np.asarray(s.fm.w), np.asarray(s.fm.V), s.residual(), lo)
+        except BaseException as ex:  # noqa
+            errs.append(ex)
+            ls.bar.abort()
+            meet.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=300)
+    assert not errs, errs
+    t = oracle.OracleTrainer(X, y, rank=K, group_index=gi)
+    for it in range(3):
+        t.step()
+    w0, w, V = t.fm()
+    e = t.e(n)
+    assert out[0][0], "the layout was refused: the test does not reach the exchange"
+    for rank in range(world):
+        live, flags, gw, gV, ge, lo = out[rank]
+        assert flags & 256
+        np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(ge, e[lo:lo + ge.shape[0]], rtol=1e-7, atol=1e-7)
+        assert np.array_equal(gV, out[0][3]) and np.array_equal(gw, out[0][2])
+
+
 @pytest.mark.parametrize("world,shape", [(2, "u_i_ctx"), (3, "u_i_ctx"), (2, "no_item"), (3, "three_fields")])
 def test_cell_path_row_sharded(oracle, monkeypatch, world, shape):
     """Index-tuple designs (mfm_cell.hpp) row-sharded over `world` lock-stepped ranks on one GPU: every rank runs the cell
