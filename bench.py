@@ -571,6 +571,9 @@ def main():
             "row_iterations_per_s": round(N * it_per_s),
             "setup_s": round(t_setup, 2), "datagen_s": round(t_data, 2),
             "plan_flags": plan_flags,
+            # regression: update_e recomputes e = score - y after every update_V (FMTrainer.hpp:494), so the persistent sweep does not
+            # write its on-chip residual back (a dead store); MYFM_AMD_KEEP_RESIDUAL=1 restores the write-back (- 2.5 % at config 3)
+            "residual_write_back": bool(os.environ.get("MYFM_AMD_KEEP_RESIDUAL")) or W["task"] != "regression",
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
