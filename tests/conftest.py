@@ -12,8 +12,8 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # every row-tile layout the planner packs on the device is also packed on the host and compared array by array
     # (mfm_plan.hpp build_scattered): a mismatch fails mfm_finalize of the test that built it
-    # (MYFM_TEST_NO_PLAN_CHECK=1: the suite in production mode -- device planners only, generic plans built on demand; a few tests
-    #  that assert checker-mode plan flags are expected to differ)
+    # (MYFM_TEST_NO_PLAN_CHECK=1: the suite in production mode -- device planners only, generic plans built on demand; the planner
+    #  fuzz tests, which ARE the comparison, skip themselves)
     if os.environ.get("MYFM_TEST_NO_PLAN_CHECK"):
         os.environ.pop("MFM_PLAN_CHECK", None)
     else:

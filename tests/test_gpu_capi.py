@@ -39,6 +39,12 @@ def _designs():
 DESIGNS = _designs()
 
 
+def _checked():
+    import os
+
+    return os.environ.get("MFM_PLAN_CHECK") is not None  # (tests/conftest.py: the default; MYFM_TEST_NO_PLAN_CHECK=1 turns it off)
+
+
 def _pair(oracle, capi, X, y, gi, rank, blocks=(), **kw):
     t = oracle.OracleTrainer(X, y, blocks, rank=rank, group_index=gi, **kw)
     n = X.shape[0]
@@ -228,7 +234,9 @@ def test_split_layout_latent_sweep(oracle, capi, monkeypatch, n_fields, fused):
         if scale:
             Xs.data = np.where(np.arange(Xs.nnz) % 3 == 0, scale, 1.5)
         t, c, _ = _pair(oracle, capi, Xs, y, gi, 3)
-        assert c.plan_flags()["soa"] and c.plan_flags()["fused_next"] == fused and c.plan_flags()["mf"] == want_mf
+        f_ = c.plan_flags()
+        # (production mode -- no MFM_PLAN_CHECK: a two-field table takes the persistent sweep before the generic plans exist)
+        assert (f_["soa"] and f_["fused_next"] == fused and f_["mf"] == want_mf) or (f_["resident"] and not _checked())
         drv = CapiGibbs(c, t.clone(), n, gi)
         for it in range(3):
             t.step()
@@ -255,7 +263,7 @@ def test_resident_latent_sweep(oracle, capi, monkeypatch, cus):
     chains = []
     for rep in range(2):
         t, c, _ = _pair(oracle, capi, X, y, gi, 3)
-        assert c.plan_flags()["resident"] and c.plan_flags()["mf"]
+        assert c.plan_flags()["resident"] and (c.plan_flags()["mf"] or not _checked())
         drv = CapiGibbs(c, t.clone(), n, gi)
         for it in range(3):
             t.step()
@@ -422,7 +430,7 @@ def test_split_layout_factor_subranges(oracle, capi, monkeypatch, n_fields):
         shapes = shapes + [23]
     gi = ds.group_index_from_shapes(shapes)
     t, c, _ = _pair(oracle, capi, X, y, gi, K)
-    assert c.plan_flags()["fused_next"]
+    assert c.plan_flags()["fused_next"] or (c.plan_flags()["resident"] and not _checked())
     G, D = t.G, t.D
     rng = np.random.default_rng(8)
     lam = rng.uniform(0.5, 2.0, size=(G, K))
