@@ -151,6 +151,15 @@ struct FMLearningConfig {
   size_t n_groups = 0;
   vector<vector<size_t>> group_vs_feature_index;
   CutpointGroupType cutpoint_groups;
+  // Not in the reference (it has ONE generator and nothing to choose): true keeps the trainer's std::mt19937 on the host for the
+  // whole fit, so that every variate -- the hyper-parameter / w / V draws AND the latent draws of probit classification and
+  // ordered probit, which consume the generator in data-dependent rejection loops row after row (FMTrainer.hpp:498-521,
+  // OProbitSampler.hpp:238-272, util.hpp:15-78) -- is the reference's own under the same seed. false (default): the generator is
+  // handed to the device; regression chains are still the reference's draw for draw, the latent draws of the other two tasks
+  // come from per-row Philox streams (same law, different numbers). ConfigBuilder.set_exact_latent_draws; the environment
+  // variable MYFM_AMD_HOST_RNG=1 forces it for every fit of the process.
+  bool exact_latent_draws = false;
+  bool host_rng() const { return exact_latent_draws || std::getenv("MYFM_AMD_HOST_RNG") != nullptr; }
 
   // FMLearningConfig.hpp:17-57
   FMLearningConfig(Real alpha_0, Real beta_0, Real gamma_0, Real mu_0, Real reg_0, TaskType task_type, Real nu_oprobit,
@@ -187,7 +196,9 @@ struct ConfigBuilder {
   vector<size_t> group_index;
   Real cutpoint_scale = 10;
   CutpointGroupType cutpoint_groups;
+  bool exact_latent_draws = false;  // (see FMLearningConfig::exact_latent_draws)
 
+  ConfigBuilder &set_exact_latent_draws(bool a) { exact_latent_draws = a; return *this; }
   ConfigBuilder &set_alpha_0(Real a) { alpha_0 = a; return *this; }
   ConfigBuilder &set_beta_0(Real a) { beta_0 = a; return *this; }
   ConfigBuilder &set_gamma_0(Real a) { gamma_0 = a; return *this; }
@@ -204,8 +215,10 @@ struct ConfigBuilder {
   ConfigBuilder &set_cutpoint_scale(Real a) { cutpoint_scale = a; return *this; }
   ConfigBuilder &set_cutpoint_groups(const CutpointGroupType &a) { cutpoint_groups = a; return *this; }
   FMLearningConfig build() {
-    return FMLearningConfig(alpha_0, beta_0, gamma_0, mu_0, reg_0, task_type, nu_oprobit, fit_w0, fit_linear, group_index,
-                            n_iter, n_kept_samples, cutpoint_scale, cutpoint_groups);
+    FMLearningConfig c(alpha_0, beta_0, gamma_0, mu_0, reg_0, task_type, nu_oprobit, fit_w0, fit_linear, group_index, n_iter,
+                       n_kept_samples, cutpoint_scale, cutpoint_groups);
+    c.exact_latent_draws = exact_latent_draws;
+    return c;
   }
 };
 
@@ -650,7 +663,7 @@ Real norm2(const vector<Real> &v) {
 // run on the device; the (K-1)-dimensional reparametrisation, damped Newton search and the
 // multivariate-t Metropolis step stay here.
 // ---- truncated-normal samplers on the trainer's own std::mt19937 (util.hpp:15-78), for the parity mode
-// MYFM_AMD_HOST_RNG=1 ONLY: there the latent draws of probit classification / ordered probit consume the generator row
+// exact_latent_draws (ConfigBuilder.set_exact_latent_draws / MYFM_AMD_HOST_RNG=1) ONLY: there the latent draws of probit classification / ordered probit consume the generator row
 // after row exactly as the reference does (FMTrainer.hpp:498-521, OProbitSampler.hpp:238-272), so that those chains can
 // be compared with the CPU sampler draw for draw. The product path draws them on the device (mfm_tasks.hpp).
 static Real host_tn_left(std::mt19937 &gen, Real mu_minus) {  // util.hpp:15-38
@@ -894,7 +907,7 @@ struct OprobitSampler {
     }
     return false;
   }
-  // parity mode (MYFM_AMD_HOST_RNG=1): the group's rows in the reference's order and the targets
+  // exact_latent_draws: the group's rows in the reference's order and the targets
   const vector<size_t> *host_rows = nullptr;
   const vector<Real> *host_y = nullptr;
   int64_t host_n = 0;
@@ -1074,7 +1087,7 @@ struct FMTrainer {
     if (ctx) return;
     K = rank;
     SetupLap lap("build_device");
-    if (!std::getenv("MYFM_AMD_HOST_RNG"))  // (the device generator's jump polynomials: beside everything below)
+    if (!cfg.host_rng())  // (the device generator's jump polynomials: beside everything below)
       (void)mfm_rng_prepare((int64_t)cfg.group_index.size(), (int32_t)rank, (int32_t)cfg.n_groups);
     int code = mfm_create(selected_device(), &ctx);
     if (code != MFM_OK) throw_code(code, mfm_global_error());
@@ -1131,7 +1144,7 @@ struct FMTrainer {
   // generator (gen_mh_, forked from gen_ before the hand-over): for those tasks parity with the
   // reference is distributional anyway.
   void start_device_rng(int Kf) {
-    if (std::getenv("MYFM_AMD_HOST_RNG")) return;
+    if (cfg.host_rng()) return;
     std::ostringstream os;
     os << gen_;
     std::istringstream is(os.str());
@@ -1207,9 +1220,9 @@ struct FMTrainer {
         vector<int64_t> rows;
         if (!all_rows) rows.assign(c.second.begin(), c.second.end());
         ck(ctx, mfm_oprobit_add_group(ctx, (int32_t)c.first, all_rows ? nullptr : rows.data(), (int64_t)c.second.size(), &g));
-        cutpoint_sampler.emplace_back(ctx, g, (int)c.first, std::getenv("MYFM_AMD_HOST_RNG") ? gen_ : gen_mh_, cfg.reg_0,
+        cutpoint_sampler.emplace_back(ctx, g, (int)c.first, cfg.host_rng() ? gen_ : gen_mh_, cfg.reg_0,
                                       cfg.nu_oprobit);
-        if (std::getenv("MYFM_AMD_HOST_RNG")) {  // parity mode: latent draws on the host, in the reference's row order
+        if (cfg.host_rng()) {  // exact_latent_draws: latent draws on the host, in the reference's row order
           cutpoint_sampler[i].host_rows = &c.second;
           cutpoint_sampler[i].host_y = &y;
           cutpoint_sampler[i].host_n = N;
@@ -1359,7 +1372,7 @@ struct FMTrainer {
     if (cfg.task_type == TaskType::REGRESSION) {
       ck(ctx, mfm_update_e_regression(ctx));
     } else if (cfg.task_type == TaskType::CLASSIFICATION) {
-      if (std::getenv("MYFM_AMD_HOST_RNG")) {  // parity mode: FMTrainer.hpp:498-512 on the trainer's generator, row by row
+      if (cfg.host_rng()) {  // exact_latent_draws: FMTrainer.hpp:498-512 on the trainer's generator, row by row
         ck(ctx, mfm_score_train(ctx));
         vector<Real> e((size_t)N);
         ck(ctx, mfm_get_e(ctx, e.data()));
@@ -1640,6 +1653,7 @@ PYBIND11_MODULE(_myfm, m) {
       .def("set_group_index", &ConfigBuilder::set_group_index)
       .def("set_identical_groups", &ConfigBuilder::set_identical_groups)
       .def("set_cutpoint_scale", &ConfigBuilder::set_cutpoint_scale)
+      .def("set_exact_latent_draws", &ConfigBuilder::set_exact_latent_draws, py::return_value_policy::reference_internal)
       .def("set_cutpoint_groups",
            // [(n_class, row indices)]: the reference's list-of-lists (declare_module.hpp:139-156), and numpy index arrays
            // without a per-element Python conversion (5e7 rows at config 5)

@@ -14,13 +14,17 @@ def pytest_configure(config):
     # (mfm_plan.hpp build_scattered): a mismatch fails mfm_finalize of the test that built it
     # (MYFM_TEST_NO_PLAN_CHECK=1: the suite in production mode -- device planners only, generic plans built on demand; the planner
     #  fuzz tests, which ARE the comparison, skip themselves)
-    if os.environ.get("MYFM_TEST_NO_PLAN_CHECK"):
+    # MYFM_TEST_PRODUCTION=1 (tests/test_gpu_production_mode.py re-runs a slice of the suite this way): neither of the two -- the
+    # environment of a user's process and of bench.py
+    production = bool(os.environ.get("MYFM_TEST_PRODUCTION"))
+    if os.environ.get("MYFM_TEST_NO_PLAN_CHECK") or production:
         os.environ.pop("MFM_PLAN_CHECK", None)
     else:
         os.environ.setdefault("MFM_PLAN_CHECK", "1")
     # the persistent latent sweep (mfm_res.hpp) is the default only from 2^20 rows on; the tests' small two-field tables take it
     # too, so that every chain test of such a table also covers it (tests that want the per-factor passes set MFM_NO_RESIDENT)
-    os.environ.setdefault("MFM_RES_MIN_ROWS", "0")
+    if not production:
+        os.environ.setdefault("MFM_RES_MIN_ROWS", "0")
     # a fresh checkout has no built extension yet (the .so files are git-ignored): build in-tree once
     pkg = os.path.join(ROOT, "myfm_amd")
     if not any(f.startswith("_myfm.") and f.endswith(".so") for f in os.listdir(pkg)):

@@ -233,3 +233,76 @@ def test_config3_full_size_two_ranks_persistent_sweep(oracle, design, monkeypatc
         np.testing.assert_allclose(gw, w, rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(gV, V, rtol=1e-7, atol=1e-8)
         assert np.array_equal(gV, out[0][3]) and np.array_equal(gw, out[0][2])
+
+
+def test_config3_full_size_one_rank_vs_oracle(oracle, design):
+    """The exact call bench.py times -- `GibbsSession` on ONE rank (device variates, residual policy 1: the launch does not
+    write the residual back, `update_e` recomputes it; bench.py's own `make_config`) -- at BASELINE configs[2]'s full size
+    (N = 10 M, rank 32), two `update_all` iterations (BaseFMTrainer.hpp:135-152) against the CPU oracle's chain. The oracle
+    needs ~6 s per iteration here. `plan_flags` must be the ones the bench line reports for a one-GPU run."""
+    import gc
+
+    import bench
+    from myfm_amd import _myfm
+
+    X, y, gi = design
+    cfg = bench.make_config(_myfm, gi, 10, 0, "regression", N)
+    sess = _myfm.GibbsSession(K, 0.1, X, [], y, 42, cfg)
+    flags = int(sess.plan_flags())
+    assert flags & 256, flags  # the persistent sweep (mfm_res.hpp) -- what bench.py's config 3 line runs on one GPU
+    import os
+
+    if os.environ.get("MFM_PLAN_CHECK") is None:
+        assert flags == 262, flags  # production mode: generic plans on demand -- the bench line's `plan_flags`
+    t = oracle.OracleTrainer(X, y, rank=K, group_index=gi)
+    for it in range(2):
+        sess.step()
+        t.step()
+        sess.synchronize()
+        w0, w, V = t.fm()
+        hy = t.hyper()
+        assert abs(sess.fm.w0 - w0) < 1e-7 and abs(sess.hyper.alpha - hy["alpha"]) < 1e-7 * hy["alpha"]
+        np.testing.assert_allclose(np.asarray(sess.fm.w), w, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(np.asarray(sess.fm.V), V, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(np.asarray(sess.hyper.lambda_V), hy["lambda_V"], rtol=1e-7)
+        np.testing.assert_allclose(np.asarray(sess.hyper.mu_V), hy["mu_V"], rtol=1e-7, atol=1e-8)
+    # the residual after update_e, in row order, against the oracle's
+    np.testing.assert_allclose(np.asarray(sess.residual()), t.e(N), rtol=1e-7, atol=1e-7)
+    del sess
+    gc.collect()
+
+
+def test_config5_own_task_scale01_vs_oracle(oracle):
+    """BASELINE configs[4]'s OWN task -- ordered probit, rank 64, two one-hot fields + 4 relation blocks -- at scale 0.1
+    (N = 5 M rows, nnz = 10 M) draw for draw against the CPU oracle: `exact_latent_draws` keeps the trainer's std::mt19937 on
+    the host, so that the latent draws (OProbitSampler.hpp:238-272), the cutpoint Metropolis step (:359-387) and every
+    hyper-parameter / w / V variate are the reference's own, while every O(N) and O(nnz) step runs on the device. Two
+    iterations (the oracle needs ~11 s each): kept samples, cutpoints, hyper-parameter draws and the Metropolis accept count."""
+    from myfm_amd import _myfm
+
+    from .test_gpu_baseline_configs import _assert_chain
+
+    Kc, n_iter = 64, 2
+    main, blocks, y, shapes = ds.config5_like(0.1, ordered=True)
+    n = main.shape[0]
+    assert n == 5_000_000 and len(blocks) == 4
+    gi = ds.group_index_from_shapes(shapes)
+    rels = [_myfm.RelationBlock(np.asarray(m, dtype=np.int64), B) for m, B in blocks]
+    b = _myfm.ConfigBuilder()
+    b.set_alpha_0(1.0).set_beta_0(1.0).set_gamma_0(1.0).set_mu_0(0.0).set_reg_0(1.0)
+    b.set_group_index([int(g) for g in gi]).set_n_iter(n_iter).set_n_kept_samples(n_iter)
+    b.set_task_type(_myfm.TaskType.ORDERED)
+    b.set_cutpoint_groups([(5, np.arange(n))])
+    b.set_exact_latent_draws(True)
+    predictor, history = _myfm.create_train_fm(Kc, 0.1, main, rels, y, 42, b.build(), lambda *a: False)
+    t = oracle.OracleTrainer(main, y, blocks, rank=Kc, group_index=gi, task=oracle.ORDERED, cutpoint_groups=[(5, np.arange(n))])
+    samples, hypers, cuts = [], [], []
+    for it in range(n_iter):
+        t.step()
+        samples.append(t.fm())
+        hypers.append(t.hyper())
+        cuts.append(t.cutpoints(0))
+    _assert_chain(predictor, history, samples, hypers)
+    for fm, cut in zip(predictor.samples, cuts):
+        np.testing.assert_allclose(fm.cutpoints[0], cut, rtol=1e-7, atol=1e-7)
+    assert list(history.n_mh_accept) == [t.mh_accept(0)]
