@@ -141,7 +141,9 @@ int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launche
  * bit 3 = row-sharded (mfm_set_allreduce), bit 4 = split e / q arrays during update_V,
  * bit 5 = the last level's apply pass also runs the next factor's first level (k_tile_apply_next),
  * bit 6 = row-sharded with the fused tile path (first-level columns swept where their rows live),
- * bit 7 = two-field pass (two one-hot-like levels: one pass over the residual per factor, no q-cache in HBM). */
+ * bit 7 = two-field pass (two one-hot-like levels: one pass over the residual per factor, no q-cache in HBM),
+ * bit 8 = persistent latent sweep (residual on chip for update_w + update_V), bit 9 = index-tuple designs (cell passes),
+ * bit 10 = a relation block's feature chain (FMTrainer.hpp:276-302, :419-470) runs as the streamed one-launch form. */
 int mfm_plan_flags(const mfm_ctx *ctx);
 
 /* ---- model state (FM.hpp:164-168) ------------------------------------------------------ */
@@ -313,6 +315,15 @@ int mfm_test_truncated_normal(int device, int32_t kind, double lo, double hi, ui
  * of levels in *n_levels.                                                                   */
 int mfm_host_column_levels(int64_t n_rows, int64_t n_cols, const int64_t *indptr, const int32_t *indices,
                            int32_t *level, int32_t *n_levels);
+/* The plan of the streamed block-feature sweep of a large relation block (FMTrainer.hpp:276-302, :419-470 as ONE pipelined launch,
+ * csrc/mfm_chain_plan.hpp) for the chain over ALL n_cols columns of the block's CSC (colptr / rowidx / val: column j -> ascending block
+ * rows), steps of cg columns, a window of lw steps, nb row ranges, slot reuse delay rd, at most cap LDS slots -- and an emulation of the
+ * launch's data flow on the host (every actor on its own copy of what it can see, in the earliest order its flags allow) against the
+ * plain sequential sweep: *max_rel_diff = the largest relative difference of coefficients / records (rounding level when the plan is
+ * right). info[8]: built (0 / 1: the hot rows did not fit), slots, most entering / leaving rows of a step, cold entries, hot entries,
+ * most hot entries of a column, steps.                                                                                          */
+int mfm_cs_plan_selftest(int64_t n_rows, int32_t n_cols, const int64_t *colptr, const int32_t *rowidx, const double *val, int32_t cg,
+                         int32_t lw, int32_t nb, int32_t rd, int32_t cap, double *max_rel_diff, int64_t *info);
 
 #ifdef __cplusplus
 }

@@ -16,9 +16,11 @@ PYMOD = os.path.join(HERE, "_myfm" + EXT_SUFFIX)
 # translation units of libmyfm_hip.so and the headers each of them includes (a unit is recompiled when one of them is newer than
 # its object file; the objects live in csrc/_obj/, git-ignored)
 HIP_UNITS = {
-    "mfm_hip.hip": ["mfm_common.hpp", "mfm_wave.hpp", "mfm_kernels.hpp", "mfm_mf_kernels.hpp", "mfm_res.hpp", "mfm_res_plan.hpp", "mfm_plan.hpp",
-                    "mfm_block_kernels.hpp", "mfm_tasks.hpp", "mfm_predict.hpp", "mfm_rng.hpp", "mfm_mtjump.hpp", "mfm_cell.hpp"],
+    "mfm_hip.hip": ["mfm_common.hpp", "mfm_wave.hpp", "mfm_policies.hpp", "mfm_kernels.hpp", "mfm_mf_kernels.hpp", "mfm_res.hpp", "mfm_res_plan.hpp",
+                    "mfm_plan.hpp", "mfm_block_kernels.hpp", "mfm_tasks.hpp", "mfm_predict.hpp", "mfm_rng.hpp", "mfm_mtjump.hpp", "mfm_cell.hpp",
+                    "mfm_chain_api.hpp"],
     "mfm_cell.hip": ["mfm_common.hpp", "mfm_wave.hpp", "mfm_cell.hpp"],
+    "mfm_chain.hip": ["mfm_common.hpp", "mfm_wave.hpp", "mfm_policies.hpp", "mfm_chain_api.hpp", "mfm_chain_plan.hpp", "mfm_chain_stream.hpp"],
 }
 OBJ_DIR = os.path.join(CSRC, "_obj")
 PYMOD_HEADERS = ["mfm_hostnormals.hpp", "mfm_mtjump.hpp"]
@@ -50,10 +52,10 @@ def build_hip(force=False, verbose=False):
             cmd = [_hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            jobs.append((src, subprocess.Popen(cmd)))
-    for src, pr in jobs:  # (the units compile side by side)
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, "hipcc -c " + src)
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    failed = [(cmd, pr.returncode) for cmd, pr in jobs if pr.wait() != 0]  # (the units compile side by side; every job is waited for)
+    if failed:
+        raise subprocess.CalledProcessError(failed[0][1], " ".join(failed[0][0]))
     if jobs or not os.path.exists(HIP_LIB) or _newer(HIP_LIB, objs):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", HIP_LIB]
         if verbose:

@@ -30,7 +30,7 @@ SYMBOLS = [
     "mfm_rng_get_z", "mfm_design_score_ctx", "mfm_design_n_rows", "mfm_set_allreduce", "mfm_set_row_offset", "mfm_set_main_levels",
     "mfm_test_erfcx", "mfm_test_truncated_normal", "mfm_get_device", "mfm_set_shard", "mfm_comm_unique_id", "mfm_comm_init",
     "mfm_comm_stats", "mfm_comm_info", "mfm_store_create", "mfm_store_destroy", "mfm_store_last_error", "mfm_store_size", "mfm_store_push_ctx",
-    "mfm_store_push_host", "mfm_store_get", "mfm_design_predict_store", "mfm_store_reserve",
+    "mfm_store_push_host", "mfm_store_get", "mfm_design_predict_store", "mfm_store_reserve", "mfm_cs_plan_selftest",
 ]
 
 _lib = None
@@ -394,7 +394,7 @@ class Context:
     def plan_flags(self):
         f = lib().mfm_plan_flags(self.h)
         return {"qfree": bool(f & 1), "unit": bool(f & 2), "ell": bool(f & 4), "sharded": bool(f & 8), "soa": bool(f & 16),
-                "fused_next": bool(f & 32), "sharded_fused": bool(f & 64), "mf": bool(f & 128), "resident": bool(f & 256), "cell": bool(f & 512)}
+                "fused_next": bool(f & 32), "sharded_fused": bool(f & 64), "mf": bool(f & 128), "resident": bool(f & 256), "cell": bool(f & 512), "streamed_chain": bool(f & 1024)}
 
     def plan_info(self):
         a, b = C.c_int64(), C.c_int64()

@@ -1682,7 +1682,10 @@ int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launche
 }
 
 int mfm_plan_flags(const mfm_ctx *ctx) {
-  return (ctx->qfree ? 1 : 0) | (ctx->X.unit ? 2 : 0) | (ctx->X.ell_width >= 0 ? 4 : 0) | (ctx->comm.active() ? 8 : 0) |
+  bool streamed = false;  // a relation block's feature chain runs as the streamed one-launch form (mfm_chain_stream.hpp)
+  for (auto &B : ctx->blocks)
+    for (const Step &st : B->plan_V.steps) streamed = streamed || (st.is_chain && st.chain.stream);
+  return (streamed ? 1024 : 0) | (ctx->qfree ? 1 : 0) | (ctx->X.unit ? 2 : 0) | (ctx->X.ell_width >= 0 ? 4 : 0) | (ctx->comm.active() ? 8 : 0) |
          (ctx->soa ? 16 : 0) | (ctx->fuse_next ? 32 : 0) | (ctx->sharded_fused ? 64 : 0) | (ctx->mf ? 128 : 0) |
          (ctx->res.ready ? 256 : 0) | (ctx->cell.ready ? 512 : 0);
 }

@@ -24,6 +24,7 @@
 #include <dlfcn.h>
 #include <hipcub/hipcub.hpp>
 
+#include "mfm_chain_api.hpp"
 #include "mfm_common.hpp"
 #include "mfm_kernels.hpp"
 #include "mfm_mf_kernels.hpp"
@@ -386,6 +387,9 @@ struct ChainRun {
   DevBuf<double> bk_x;
   mutable DevBuf<int32_t> col_group;             // group index of every chain column (filled at the first launch)
   mutable const int32_t *col_group_of = nullptr;  // ... from this group array
+  // the streamed conflict-window form (k_cs_stream, mfm_chain_stream.hpp; round 5): the whole run as one pipelined launch without
+  // batch boundaries -- built when the grid form applies and a window fits the walker's LDS; the two sweeps' plans share it
+  std::shared_ptr<CsStream> stream;
 
   std::vector<int32_t> h_cols;  // the run's columns (a twin plan of the same matrix asks: the same run?)
   // the other sweep's plan of the SAME matrix has this run already: non-owning views of its arrays (o outlives this)
@@ -417,6 +421,7 @@ struct ChainRun {
     hbk_ptr.borrow(o.hbk_ptr);
     bk_cls.borrow(o.bk_cls);
     bk_x.borrow(o.bk_x);
+    stream = o.stream;
     h_cols = o.h_cols;
   }
 
@@ -1684,6 +1689,19 @@ struct StepPlan {
           const std::string diff = s.chain.compare_batched(chk, dev_csc->stream);
           if (!diff.empty()) throw Error(MFM_ERR_RUNTIME, "plan check: device and host conflict batches differ (" + diff + ")");
         }
+        // chains whose cold parts run on the whole GPU (relation blocks with 10^5..10^6 rows): the streamed form
+        if (s.chain.bucketed && !std::getenv("MFM_NO_CB_STREAM") && !std::getenv("MFM_NO_CB_PERSIST")) {
+          CsStreamInfo ci;
+          s.chain.stream = cs_stream_build(csc, run, &ci);
+          if (std::getenv("MFM_SETUP_TIMING")) {
+            if (s.chain.stream)
+              std::fprintf(stderr, "[plan] streamed chain of %zu columns: steps of %d columns, window %d steps, %d ranges, %d LDS slots, %lld cold + %lld "
+                                   "hot entries (<= %d hot per column), <= %d entering / %d leaving rows per step, planned in %.3f s\n",
+                           run.size(), ci.Cg, ci.Lw, ci.NB, ci.n_slots, ci.n_cold, ci.n_hot, ci.max_hot_col, ci.max_enter, ci.max_exit, ci.plan_seconds);
+            else
+              std::fprintf(stderr, "[plan] streamed chain of %zu columns: no window fits the LDS, conflict batches kept\n", run.size());
+          }
+        }
       }
       launches += 1;
       run.clear();
@@ -1951,6 +1969,12 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
           }
           const size_t lds_h = (size_t)std::max(C.max_hot, 1) * rec2_l * sizeof(double2) + 5 * CHAINB_MAXCOLS * sizeof(double) +
                                (size_t)CHAINB_MAXCOLS * sizeof(double2) + (size_t)mhe * 12 + (CHAINB_MAXCOLS + 2) * sizeof(int);
+          if (C.stream && ls.error.p) {  // one pipelined launch for the whole run (mfm_chain_stream.hpp)
+            if constexpr (std::is_same<P, PBlockV>::value || std::is_same<P, PBlockW>::value) {
+              cs_stream_launch(s, a, *C.stream, std::is_same<P, PBlockV>::value, ls.error.p);
+              continue;
+            }
+          }
           if (C.bucketed) {
             // two launches per batch: k_cb_step = cold update of the batch before + cold statistics of this one, by row range
             if (ls.cb_hot2.n < hot16) ls.cb_hot2.alloc(hot16);
