@@ -28,19 +28,40 @@ static int env_int(const char *name, int dflt) {
 std::shared_ptr<CsStream> cs_stream_build(const HostCsr &csc, const std::vector<int32_t> &run, CsStreamInfo *info) {
   const auto t0 = std::chrono::steady_clock::now();
   CsParams prm;
-  prm.Cg = std::max(1, std::min(CS_MAX_CG, env_int("MFM_CS_CG", 4)));
-  prm.NB = std::max(1, std::min(CS_MAX_NB, env_int("MFM_CS_NB", 16)));
-  prm.RD = std::max(1, std::min(2, env_int("MFM_CS_RD", 2)));  // (the walker keeps the hot entry lists of two steps)
+  prm.NB = std::max(1, std::min(CS_MAX_NB, env_int("MFM_CS_NB", 32)));
+  prm.RD = std::max(1, std::min(CS_ER, env_int("MFM_CS_RD", 2)));  // (the walker keeps the hot entry lists of CS_ER steps)
   prm.cap = std::max(16, env_int("MFM_CS_CAP", 1 << 20));
-  const int lw_max = std::max(1, std::min(CS_MAX_LW, env_int("MFM_CS_LW", 4)));
+  const int cg_forced = env_int("MFM_CS_CG", 0);
+  const int lw_max = std::max(1, std::min(CS_MAX_LW, env_int("MFM_CS_LW", CS_MAX_LW)));
   const int lw_min = std::max(1, std::min(lw_max, env_int("MFM_CS_LW_MIN", 2)));
-  // the largest window whose hot rows (80 bytes each) and hot entry lists (two steps) fit the walker's LDS
+  // Steps of Cg columns, a window of Lw steps: the walker never waits when the hop walker -> ranges -> walker (~12 us, measured:
+  // profiles/r05_*) fits Lw steps, and the hot rows (56 bytes each) + the hot entry lists of CS_ER steps must fit its LDS -- both
+  // want Cg * Lw large, the LDS need grows with its square. Per step width the largest window that fits; of those the one with the
+  // shortest predicted time per column, the wider step on a tie (fewer hand-overs).
   CsPlanHost P;
-  for (int lw = lw_max; lw >= lw_min; lw--) {
-    prm.Lw = lw;
-    P = cs_build_plan(csc.ptr.data(), csc.idx.data(), csc.val.data(), csc.cols, run, prm);
-    if (P.ok && (cs_lds_bytes(P.n_slots, prm.Cg, P.max_hot_col) > CS_LDS_MAX || cs_ecap(P.max_hot_col) > 1024)) P.ok = false;
-    if (P.ok) break;
+  double best = 1e30;
+  for (int cg = CS_MAX_CG; cg >= 2; cg--) {
+    if (cg_forced > 0 && cg != std::max(1, std::min(CS_MAX_CG, cg_forced))) continue;
+    prm.Cg = cg;
+    for (int lw = lw_max; lw >= lw_min; lw--) {
+      prm.Lw = lw;
+      CsPlanHost Q = cs_build_plan(csc.ptr.data(), csc.idx.data(), csc.val.data(), csc.cols, run, prm);
+      if (!Q.ok || cs_lds_bytes(Q.n_slots, cg, Q.max_hot_col) > CS_LDS_MAX || cs_ecap(Q.max_hot_col) > 1024) continue;
+      const double per_col = std::max(0.8, (12.0 + 0.8 * cg) / ((double)lw * cg)) + 0.15 / cg;  // (+ the step's fixed hand-over cost)
+      if (per_col < best - 1e-9) {
+        best = per_col;
+        P = std::move(Q);
+      }
+      break;
+    }
+  }
+  if (cg_forced == 1 && !P.ok) {
+    prm.Cg = 1;
+    for (int lw = lw_max; lw >= lw_min && !P.ok; lw--) {
+      prm.Lw = lw;
+      P = cs_build_plan(csc.ptr.data(), csc.idx.data(), csc.val.data(), csc.cols, run, prm);
+      if (P.ok && cs_lds_bytes(P.n_slots, 1, P.max_hot_col) > CS_LDS_MAX) P.ok = false;
+    }
   }
   if (!P.ok) return nullptr;
   auto st = std::make_shared<CsStream>();
@@ -113,6 +134,7 @@ void cs_stream_launch(hipStream_t s, const SweepArgs &a, const CsStream &st, boo
   g.max_exit = I.max_exit;
   g.n_slots = I.n_slots;
   g.ecap = cs_ecap(I.max_hot_col);
+  g.dbg = env_int("MFM_CS_DBG", 0);
   g.cols = st.cols.p;
   g.col_group = st.col_group.p;
   g.cold_ptr = st.cold_ptr.p;
@@ -145,11 +167,38 @@ void cs_stream_launch(hipStream_t s, const SweepArgs &a, const CsStream &st, boo
     }
     g.prof = prof_buf.p;
   }
+  // MFM_CS_TRACE=file (with MFM_CB_PROF): raw stamps of every actor and step of the MFM_CS_TRACE_LAUNCH-th launch (default 40)
+  static const char *trace_file = std::getenv("MFM_CS_TRACE");
+  static const long trace_launch = env_int("MFM_CS_TRACE_LAUNCH", 40);
+  static long n_launch = 0;
+  DevBuf<unsigned long long> trace_buf;
+  g.trace = nullptr;
+  const bool tracing = trace_file && g.prof && ++n_launch == trace_launch;
+  const size_t trace_n = (size_t)(3 + 2 * I.NB) * I.n_steps * 4;
+  if (tracing) {
+    trace_buf.alloc_zero(trace_n, s);
+    g.trace = trace_buf.p;
+  }
   if (latent)
     hipLaunchKernelGGL((k_cs_stream<PBlockV>), dim3(1 + I.NB), dim3(CS_NT), lds, s, a, g);
   else
     hipLaunchKernelGGL((k_cs_stream<PBlockW>), dim3(1 + I.NB), dim3(CS_NT), lds, s, a, g);
   MFM_HIP_CHECK(hipGetLastError());
+  if (tracing) {
+    std::vector<unsigned long long> h(trace_n);
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    MFM_HIP_CHECK(hipMemcpy(h.data(), trace_buf.p, trace_n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (FILE *f = std::fopen(trace_file, "w")) {
+      std::fprintf(f, "# k_cs_stream launch %ld: n_steps %d Cg %d Lw %d NB %d RD %d slots %d; rows: actor step t0 t1 t2 (10 ns ticks; actors: 0 walker, 1 X, "
+                      "2 Y, 3.. U per range, %d.. S per range)\n", n_launch, I.n_steps, I.Cg, I.Lw, I.NB, I.RD, I.n_slots, 3 + I.NB);
+      for (int ac = 0; ac < 3 + 2 * I.NB; ac++)
+        for (int st_ = 0; st_ < I.n_steps; st_++) {
+          const unsigned long long *r = &h[((size_t)ac * I.n_steps + st_) * 4];
+          std::fprintf(f, "%d %d %llu %llu %llu\n", ac, st_, r[0], r[1], r[2]);
+        }
+      std::fclose(f);
+    }
+  }
   if (cb_prof > 0 && ++prof_launches % cb_prof == 0) {
     unsigned long long h[16];
     MFM_HIP_CHECK(hipStreamSynchronize(s));
@@ -157,9 +206,9 @@ void cs_stream_launch(hipStream_t s, const SweepArgs &a, const CsStream &st, boo
     MFM_HIP_CHECK(hipMemset(prof_buf.p, 0, sizeof(h)));
     const double nsx = (double)std::max<unsigned long long>(h[2], 1) * 100.0;
     std::fprintf(stderr,
-                 "[k_cs_stream] %ld launches (Cg %d, Lw %d, NB %d, %d slots), us per step -- walker: waits %.2f, walks %.2f | Y: waits %.2f, "
+                 "[k_cs_stream] %ld launches (Cg %d, Lw %d, NB %d, %d slots), us per step -- walker: waits %.2f, walks %.2f | X: waits %.2f, works %.2f | Y: waits %.2f, "
                  "stages %.2f | U (range 0): waits %.2f, works %.2f | S (range 0): waits %.2f, works %.2f\n",
-                 prof_launches, I.Cg, I.Lw, I.NB, I.n_slots, h[0] / nsx, h[1] / nsx, h[4] / nsx, h[5] / nsx, h[8] / nsx, h[9] / nsx, h[12] / nsx,
+                 prof_launches, I.Cg, I.Lw, I.NB, I.n_slots, h[0] / nsx, h[1] / nsx, h[6] / nsx, h[7] / nsx, h[4] / nsx, h[5] / nsx, h[8] / nsx, h[9] / nsx, h[12] / nsx,
                  h[13] / nsx);
   }
 }

@@ -25,7 +25,7 @@
 
 namespace mfm {
 
-constexpr int CS_MAX_CG = 8;       // columns per step
+constexpr int CS_MAX_CG = 4;       // columns per step
 constexpr int CS_RING = 8;         // ring slots of everything the two sides exchange (>= Lw + 1)
 constexpr int CS_MAX_LW = CS_RING - 1;
 constexpr int CS_LCOL_SHIFT = 27;  // cold entry word: row | (column inside the step) << 27

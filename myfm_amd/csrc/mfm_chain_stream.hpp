@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mfm_chain_plan.hpp"
 #include "mfm_policies.hpp"
 #include "mfm_wave.hpp"
@@ -31,6 +33,7 @@ constexpr int CS_MAX_NB = 32;    // row ranges at most
 constexpr int CS_SR = 4;         // LDS ring of per-step scalars in the walker (>= RD + 1)
 constexpr int CS_U = 8;          // 64-entry rounds of a column's hot entries kept in registers
 constexpr int CS_NX = 2, CS_NY = 4;
+constexpr int CS_ER = 2;         // steps of hot entry lists in the walker's LDS (>= RD)
 constexpr size_t CS_LDS_MAX = 156 * 1024;  // of the CU's 160 KiB
 
 struct CsSync {  // zeroed before every launch
@@ -42,6 +45,7 @@ struct CsSync {  // zeroed before every launch
 struct CsArgs {
   int n_cols, n_steps, Cg, Lw, NB, RD, max_enter, max_exit, n_slots;
   int ecap;  // hot entries of a column at most, rounded up to whole wavefronts
+  int dbg;   // MFM_CS_DBG (experiments): 1 Y waits for the published exits instead of the read ones, 2 Y polls the ranges after the slots
   const int32_t *cols, *col_group;
   const int32_t *cold_ptr, *cold_rc;
   const double *cold_x;
@@ -55,6 +59,7 @@ struct CsArgs {
   double2 *oldnew;    // [CS_RING][CS_MAX_CG]
   CsSync *sync;
   int *error;
+  unsigned long long *trace;  // MFM_CS_TRACE: [3 + 2 NB actors][n_steps][4] raw s_memrealtime stamps of one launch (walker, X, Y, U and S of every range)
   unsigned long long *prof;  // MFM_CB_PROF: [16] s_memrealtime sums (100 MHz): 0 walker waits for Y, 1 walks, 2 steps; 4 Y waits for the
                              // ranges, 5 Y stages; 8 U (range 0, wave 4) waits for X, 9 works; 12 S (range 0, wave 0) waits for U, 13 works
 };
@@ -73,7 +78,9 @@ __device__ __forceinline__ void cs_st16(double2 *p, double2 v) {
   d2v w;
   w.x = v.x;
   w.y = v.y;
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
+  // (s_nop 1: a store of more than 8 bytes reads its data registers up to two cycles after issue; the compiler's hazard recogniser
+  //  covers its own stores, not this one -- without the wait states the next VALU write to those registers raced the store)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(w) : "memory");
 }
 // a wavefront waits until *w >= target: lane 0 polls (global: agent scope; LDS: workgroup scope), bounded -- a lost partner
 // raises *error, and every later wait of everybody falls through (the results are then garbage and the host raises)
@@ -102,12 +109,55 @@ __device__ __forceinline__ void cs_wait(const void *w, long long target, int *er
   asm volatile("" ::: "memory");
 }
 
+// The hot rows' records in the walker's LDS, WORD-MAJOR: three 16-byte arrays {q, q_S}, {c, c_S}, {e, e_q} and an 8-byte array of
+// cardinalities, indexed by slot -- 56 bytes per row instead of the 80 of a padded 64-byte record (a window one step wider fits),
+// and a wavefront's 16-byte gathers of random slots spread over all banks. Same arithmetic as ChainOps<P> (fused multiply-adds).
+struct CsSlots {
+  d2_t *W0, *W1, *W2;
+  double *K;
+};
+template <class P>
+struct CsOps;
+template <>
+struct CsOps<PBlockV> {
+  static __device__ __forceinline__ BlockRec load(const CsSlots &L, int slot) {
+    BlockRec s;
+    s.qq = L.W0[slot];
+    s.cc = L.W1[slot];
+    s.ee = L.W2[slot];
+    s.kk.x = L.K[slot];
+    s.kk.y = 0.0;
+    return s;
+  }
+  static __device__ __forceinline__ void apply(const CsSlots &L, int slot, double x, BlockRec s, double old, double fresh) {
+    const double delta = fresh - old, dx = delta * x;
+    const double h_B = __builtin_fma(-x, old, s.qq.x);
+    s.qq.x = __builtin_fma(delta, x, s.qq.x);
+    s.qq.y = __builtin_fma(delta * (fresh + old), x * x, s.qq.y);
+    s.ee.x = __builtin_fma(dx, __builtin_fma(h_B, s.kk.x, s.cc.x), s.ee.x);
+    s.ee.y = __builtin_fma(dx, __builtin_fma(h_B, s.cc.x, s.cc.y), s.ee.y);
+    L.W0[slot] = s.qq;
+    L.W2[slot] = s.ee;
+  }
+};
+template <>
+struct CsOps<PBlockW> {
+  static __device__ __forceinline__ PBlockW::St load(const CsSlots &L, int slot) {
+    PBlockW::St s;
+    s.e = L.W2[slot].x;
+    s.card = L.K[slot];
+    return s;
+  }
+  static __device__ __forceinline__ void apply(const CsSlots &L, int slot, double x, PBlockW::St s, double old, double fresh) {
+    ((double *)(L.W2 + slot))[0] = __builtin_fma(x * s.card, fresh - old, s.e);
+  }
+};
+
 template <class P>
 __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
   extern __shared__ double2 cs_lds[];
   constexpr int MC = CS_MAX_CG, R = CS_RING, SR = CS_SR, U = CS_U;
   constexpr int rec2_g = P::REC_DOUBLES / 2;  // 4
-  constexpr int rec2_l = rec2_g + 1;          // LDS stride of a record in 16-byte words (bank spread)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = g.n_cols, ns = g.n_steps, Cg = g.Cg, Lw = g.Lw, NB = g.NB, RD = g.RD;
   const int NP = NB * CS_NWS;
@@ -116,36 +166,47 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
   if (blockIdx.x == 0) {
     // ================================================== the walker workgroup ==================================================
     const int ecap = g.ecap;                                         // hot entries of a column at most (a multiple of 64)
-    double2 *recs = cs_lds;                                          // [n_slots][rec2_l]
-    double2 *csum = recs + (size_t)max(g.n_slots, 1) * rec2_l;       // [SR][MC]
+    const int nsl = max(g.n_slots, 1);
+    CsSlots L;                                                       // the hot rows' records, word-major (56 bytes per slot)
+    L.W0 = (d2_t *)cs_lds;
+    L.W1 = L.W0 + nsl;
+    L.W2 = L.W1 + nsl;
+    L.K = (double *)(L.W2 + nsl);
+    double2 *csum = (double2 *)(L.K + nsl + (nsl & 1));              // [SR][MC]
     double *c_old = (double *)(csum + SR * MC);                      // [SR][MC] each
     double *c_z = c_old + SR * MC, *c_lam = c_z + SR * MC, *c_mu = c_lam + SR * MC, *c_new = c_mu + SR * MC;
-    double *e_x = c_new + SR * MC;                                   // [2][Cg][ecap] the hot entries of two steps: value ...
-    int *e_slot = (int *)(e_x + (size_t)2 * Cg * ecap);              // ... and slot
-    int *h_cnt = e_slot + (size_t)2 * Cg * ecap;                     // [SR][MC] hot entries per column
-    int *w_steps = h_cnt + SR * MC;                                  // [1] steps walked
-    int *y_count = w_steps + 1;                                      // [1] += 1 per Y wavefront and step staged
-    int *x_steps = y_count + 1;                                      // [CS_NX] steps whose exits are out
-    if (tid < 2 + CS_NX) w_steps[tid] = 0;
+    double *e_x = c_new + SR * MC;                                   // [CS_ER][Cg][ecap] the hot entries of CS_ER steps: value ...
+    int *e_slot = (int *)(e_x + (size_t)CS_ER * Cg * ecap);              // ... and slot
+    int *h_cnt = e_slot + (size_t)CS_ER * Cg * ecap;                     // [SR][MC] hot entries per column
+    int *y_steps = h_cnt + SR * MC;                                  // [CS_NY] steps staged, per Y wavefront (16-byte aligned: one read)
+    int *w_steps = y_steps + CS_NY;                                  // [1] steps walked
+    int *x_steps = w_steps + 1;                                      // [CS_NX] steps whose exits are out (published)
+    int *x_read = x_steps + CS_NX;                                   // [CS_NX] steps whose leaving records have been read out of their slots
+    if (tid < CS_NY + 1 + 2 * CS_NX) y_steps[tid] = 0;
     __syncthreads();  // (the only barrier: before the roles part)
-    SweepArgs al = a;
-    al.state = recs;
-    al.rec2 = rec2_l;
-    if (wv == 0) {
+    // Roles by wavefront. A workgroup's wavefronts go round the CU's four SIMDs (wavefront w on SIMD w % 4): the walker (wavefront 0)
+    // shares its SIMD only with the idle wavefront 4 -- a helper next to it was starved of issue slots and became the slowest Y
+    // wavefront the walker then waited for. X = wavefronts 1, 5; Y = 2, 3, 6, 7.
+    const int role = wv == 0 ? 0 : wv == 4 ? 3 : (wv == 1 || wv == 5) ? 1 : 2;
+    const int xw_of = wv == 1 ? 0 : 1, yw_of = wv == 2 ? 0 : wv == 3 ? 1 : wv == 6 ? 2 : 3;
+    if (role == 0) {
+      __builtin_amdgcn_s_setprio(3);
       // ---- wavefront 0: the columns in order over their hot entries ----
       const bool pf = g.prof != nullptr && lane == 0;
       struct Col {
         int cnt, sl[U];
         double hx[U], S1c, S2c, old, lam, mu, z;
       };
-      auto load_col = [&](Col &C, int k) {
-        const int s = k / Cg, c = k - s * Cg, q = (s % SR) * MC + c, base = ((s & 1) * Cg + c) * ecap;
+      // a column's staged entries and scalars into registers: every round the lists can hold is requested (no dependence on the
+      // column's count: rounds past it read staged zeros or another column's entries and are never used)
+      auto load_col = [&](Col &C, int s, int c) {
+        const int q = (s % SR) * MC + c, base = ((s % CS_ER) * Cg + c) * ecap;
         C.cnt = h_cnt[q];
 #pragma unroll
         for (int u = 0; u < U; u++) {
           C.sl[u] = 0;
           C.hx[u] = 0.0;
-          if (u * WAVE < C.cnt) {  // (rounds past the column's entries read staged zeros)
+          if (u * WAVE < ecap) {  // (uniform, the same for every column)
             C.sl[u] = e_slot[base + u * WAVE + lane];
             C.hx[u] = e_x[base + u * WAVE + lane];
           }
@@ -158,66 +219,102 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
         C.mu = c_mu[q];
         C.z = c_z[q];
       };
+      // NR rounds of 64 hot entries, straight-line: only the last round is predicated
+      auto body = [&](auto nr_tag, const Col &C, int cnt) -> double {
+        constexpr int NR = decltype(nr_tag)::value;
+        typename P::St st[NR];
+        const bool last_ok = (NR - 1) * WAVE + lane < cnt;
+#pragma unroll
+        for (int u = 0; u < NR - 1; u++) st[u] = CsOps<P>::load(L, C.sl[u]);
+        if (last_ok) st[NR - 1] = CsOps<P>::load(L, C.sl[NR - 1]);
+        double h1 = 0.0, h2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < NR - 1; u++) ChainOps<P>::stats(C.hx[u], st[u], C.old, h1, h2);
+        if (last_ok) ChainOps<P>::stats(C.hx[NR - 1], st[NR - 1], C.old, h1, h2);
+        wave_allreduce_sum2(h1, h2);
+        const double fresh = P::template draw<true>(C.S1c + h1, C.S2c + h2, C.old, a.alpha, C.lam, C.mu, C.z);
+#pragma unroll
+        for (int u = 0; u < NR - 1; u++) CsOps<P>::apply(L, C.sl[u], C.hx[u], st[u], C.old, fresh);
+        if (last_ok) CsOps<P>::apply(L, C.sl[NR - 1], C.hx[NR - 1], st[NR - 1], C.old, fresh);
+        return fresh;
+      };
       unsigned long long t_wait = 0, t_walk = 0;
       bool have = false;
+      int s = 0, c = 0;  // step and column inside the step of the column at hand
       auto column = [&](int k, Col &C, Col &N) {
-        const int s = k / Cg, c = k - s * Cg, q = (s % SR) * MC + c;
+        const int q = (s % SR) * MC + c;
         if (c == 0) {
           unsigned long long t0 = 0;
           if (pf) t0 = __builtin_amdgcn_s_memrealtime();
-          cs_wait<true>(y_count, (long long)CS_NY * (s + 1), g.error, dead);
+          // both Y wavefronts of the step's pair have staged it (a COUNT of arrivals would not do: a fast wavefront runs ahead)
+          if (!dead) {
+            unsigned spins = 0;
+            for (;;) {
+              const int y0 = __hip_atomic_load(&y_steps[(s & 1) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              const int y1 = __hip_atomic_load(&y_steps[(s & 1) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (min(y0, y1) >= s + 1) break;
+              __builtin_amdgcn_s_sleep(1);
+              if ((++spins & 1023u) == 0u) {
+                if (spins > (1u << 23) || __hip_atomic_load(g.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                  __hip_atomic_store(g.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  dead = true;
+                  break;
+                }
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            asm volatile("" ::: "memory");
+          }
           if (pf) {
             const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
             t_wait += t1 - t0;
             t_walk -= t1;
+            if (g.trace) {
+              g.trace[((size_t)0 * ns + s) * 4 + 0] = t0;
+              g.trace[((size_t)0 * ns + s) * 4 + 1] = t1;
+            }
           }
         }
-        if (!have) load_col(C, k);
+        if (!have) load_col(C, s, c);
         have = c + 1 < Cg && k + 1 < n;  // the next column of the SAME step: its entries and scalars are requested now
-        if (have) load_col(N, k + 1);
-        const int cnt = C.cnt;
-        const double old = C.old;
+        if (have) load_col(N, s, c + 1);
+        const int cnt = __builtin_amdgcn_readfirstlane(C.cnt);
         double fresh;
-        if (cnt <= U * WAVE) {
-          typename P::St st[U];
-          double h1 = 0.0, h2 = 0.0;
-#pragma unroll
-          for (int u = 0; u < U; u++)
-            if (u * WAVE < cnt && u * WAVE + lane < cnt) st[u] = P::load(al, C.sl[u]);
-#pragma unroll
-          for (int u = 0; u < U; u++)
-            if (u * WAVE < cnt) {
-              double t1 = 0.0, t2 = 0.0;
-              if (u * WAVE + lane < cnt) ChainOps<P>::stats(C.hx[u], st[u], old, t1, t2);
-              h1 += t1;
-              h2 += t2;
+        switch ((cnt + WAVE - 1) / WAVE) {
+          case 0: fresh = P::template draw<true>(C.S1c, C.S2c, C.old, a.alpha, C.lam, C.mu, C.z); break;
+          case 1: fresh = body(std::integral_constant<int, 1>(), C, cnt); break;
+          case 2: fresh = body(std::integral_constant<int, 2>(), C, cnt); break;
+          case 3: fresh = body(std::integral_constant<int, 3>(), C, cnt); break;
+          case 4: fresh = body(std::integral_constant<int, 4>(), C, cnt); break;
+          case 5: fresh = body(std::integral_constant<int, 5>(), C, cnt); break;
+          case 6: fresh = body(std::integral_constant<int, 6>(), C, cnt); break;
+          case 7: fresh = body(std::integral_constant<int, 7>(), C, cnt); break;
+          case 8: fresh = body(std::integral_constant<int, 8>(), C, cnt); break;
+          default: {  // (more hot entries than the registers hold: from the staged lists, twice)
+            const int base = ((s % CS_ER) * Cg + c) * ecap;
+            double h1 = 0.0, h2 = 0.0;
+            for (int i = lane; i < cnt; i += WAVE) ChainOps<P>::stats(e_x[base + i], CsOps<P>::load(L, e_slot[base + i]), C.old, h1, h2);
+            wave_allreduce_sum2(h1, h2);
+            fresh = P::template draw<true>(C.S1c + h1, C.S2c + h2, C.old, a.alpha, C.lam, C.mu, C.z);
+            for (int i = lane; i < cnt; i += WAVE) {
+              const int slot = e_slot[base + i];
+              CsOps<P>::apply(L, slot, e_x[base + i], CsOps<P>::load(L, slot), C.old, fresh);
             }
-          wave_allreduce_sum2(h1, h2);
-          fresh = P::template draw<true>(C.S1c + h1, C.S2c + h2, old, a.alpha, C.lam, C.mu, C.z);
-#pragma unroll
-          for (int u = 0; u < U; u++)
-            if (u * WAVE < cnt && u * WAVE + lane < cnt) ChainOps<P>::apply(al, C.sl[u], C.hx[u], st[u], old, fresh);
-        } else {  // (more hot entries than the registers hold: from the staged lists, twice)
-          const int base = ((s & 1) * Cg + c) * ecap;
-          double h1 = 0.0, h2 = 0.0;
-          for (int i = lane; i < cnt; i += WAVE) {
-            double t1 = 0.0, t2 = 0.0;
-            ChainOps<P>::stats(e_x[base + i], P::load(al, e_slot[base + i]), old, t1, t2);
-            h1 += t1;
-            h2 += t2;
-          }
-          wave_allreduce_sum2(h1, h2);
-          fresh = P::template draw<true>(C.S1c + h1, C.S2c + h2, old, a.alpha, C.lam, C.mu, C.z);
-          for (int i = lane; i < cnt; i += WAVE) {
-            const int slot = e_slot[base + i];
-            ChainOps<P>::apply(al, slot, e_x[base + i], P::load(al, slot), old, fresh);
           }
         }
         if (lane == 0) c_new[q] = fresh;
         // (a wavefront's LDS operations execute in order: the next column's gathers see this column's updates)
         if (c == Cg - 1 || k == n - 1) {
           if (lane == 0) __hip_atomic_store(w_steps, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (pf) t_walk += __builtin_amdgcn_s_memrealtime();
+          if (pf) {
+            const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+            t_walk += t2;
+            if (g.trace) g.trace[((size_t)0 * ns + s) * 4 + 2] = t2;
+          }
+          s++;
+          c = 0;
+        } else {
+          c++;
         }
       };
       Col A, B;
@@ -232,9 +329,10 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
       }
       return;
     }
-    if (wv <= CS_NX) {
+    if (role == 1) {
       // ---- X: what leaves the LDS after step j, and the step's (old, new) pairs ----
-      const int xw = wv - 1;
+      const int xw = xw_of;
+      const bool xpf = g.prof != nullptr && lane == 0 && xw == 0;
       for (int j = 0; j < ns; j++) {
         const int x0 = g.exit_ptr[(size_t)j * NB], x1 = g.exit_ptr[(size_t)(j + 1) * NB];
         const int ncs = min(Cg, n - j * Cg), sl = (j % SR) * MC;
@@ -247,20 +345,42 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
           const int x = x0 + (t * CS_NX + xw) * WAVE + lane;
           slot_p[t] = x < x1 ? g.exit_slot[x] : -1;
         }
+        unsigned long long xt0 = 0, xt1 = 0;
+        if (xpf) xt0 = __builtin_amdgcn_s_memrealtime();
         cs_wait<true>(w_steps, j + 1, g.error, dead);
+        if (xpf) xt1 = __builtin_amdgcn_s_memrealtime();
         double2 *dst = g.out_ring + (size_t)(j % R) * max(g.max_exit, 1) * 2;
+        // the leaving records out of their slots first (the slots are free for the rows entering RD steps later as soon as they
+        // have been READ), then the write-through stores
+        double2 r0[XP], r2[XP];
+#pragma unroll
+        for (int t = 0; t < XP; t++) {
+          r0[t] = r2[t] = make_double2(0.0, 0.0);
+          if (slot_p[t] >= 0) {
+            r0[t] = ((const double2 *)L.W0)[slot_p[t]];
+            r2[t] = ((const double2 *)L.W2)[slot_p[t]];
+          }
+        }
+        const bool more = x0 + XP * CS_NX * WAVE < x1;  // (uniform; rare: the rest goes slot by slot before the flag)
+        for (int x = x0 + (XP * CS_NX + xw) * WAVE + lane; more && x < x1; x += CS_NX * WAVE) {
+          const int slot = g.exit_slot[x];
+          cs_st16(dst + (size_t)(x - x0) * 2, ((const double2 *)L.W0)[slot]);
+          cs_st16(dst + (size_t)(x - x0) * 2 + 1, ((const double2 *)L.W2)[slot]);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the records are in registers
+        if (lane == 0) __hip_atomic_store(&x_read[xw], j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int t = 0; t < XP; t++) {
           const int x = x0 + (t * CS_NX + xw) * WAVE + lane;
           if (x < x1) {
-            cs_st16(dst + (size_t)(x - x0) * 2, recs[(size_t)slot_p[t] * rec2_l]);
-            cs_st16(dst + (size_t)(x - x0) * 2 + 1, recs[(size_t)slot_p[t] * rec2_l + 2]);
+            if (g.dbg & 4) {
+              cs_st16(dst + (size_t)(x - x0) * 2, ((const double2 *)L.W0)[slot_p[t]]);
+              cs_st16(dst + (size_t)(x - x0) * 2 + 1, ((const double2 *)L.W2)[slot_p[t]]);
+            } else {
+              cs_st16(dst + (size_t)(x - x0) * 2, r0[t]);
+              cs_st16(dst + (size_t)(x - x0) * 2 + 1, r2[t]);
+            }
           }
-        }
-        for (int x = x0 + (XP * CS_NX + xw) * WAVE + lane; x < x1; x += CS_NX * WAVE) {
-          const int slot = g.exit_slot[x];
-          cs_st16(dst + (size_t)(x - x0) * 2, recs[(size_t)slot * rec2_l]);
-          cs_st16(dst + (size_t)(x - x0) * 2 + 1, recs[(size_t)slot * rec2_l + 2]);
         }
         if (col >= 0) {
           cs_st16(g.oldnew + (size_t)(j % R) * MC + lane, make_double2(c_old[sl + lane], c_new[sl + lane]));
@@ -273,51 +393,68 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
           if (lane == 0)
             __hip_atomic_store(&g.sync->walk_done, (unsigned long long)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (xpf) {
+          const unsigned long long xt2 = __builtin_amdgcn_s_memrealtime();
+          g.prof[6] += xt1 - xt0;
+          g.prof[7] += xt2 - xt1;
+          if (g.trace) {
+            g.trace[((size_t)1 * ns + j) * 4 + 0] = xt0;
+            g.trace[((size_t)1 * ns + j) * 4 + 1] = xt1;
+            g.trace[((size_t)1 * ns + j) * 4 + 2] = xt2;
+          }
+        }
       }
       return;
     }
-    if (wv <= CS_NX + CS_NY) {
+    if (role == 2) {
       // ---- Y: what enters the LDS before step s, the step's cold statistics, per-column scalars and hot entry lists ----
-      const int yw = wv - 1 - CS_NX;
+      // Two pairs of wavefronts take the steps in turn (pair s & 1 stages step s; inside a pair, wavefront i takes the columns
+      // i, i + 2, .. and every second wavefront-tile of the entering rows): a step's staging is a chain of three or four memory round
+      // trips, longer than the walker needs for the step -- with two steps in flight it is off the critical path. Everything static
+      // (column ids, groups, list offsets) is requested one own step ahead, so that no load waits for another inside a step.
+      const int yw = yw_of, grp = yw >> 1, yi = yw & 1;
       const bool pf = g.prof != nullptr && lane == 0 && yw == 0;
       unsigned long long t_wait = 0, t_work = 0;
-      constexpr int YC = (CS_MAX_CG + CS_NY - 1) / CS_NY;  // columns of a step per Y wavefront at most
-      // first / end of this wavefront's columns' hot entries, one step ahead (lane t holds column yw + t * CS_NY)
-      int hb_n = 0, he_n = 0;
-      if (lane < YC && yw + lane * CS_NY < min(Cg, n)) {
-        hb_n = g.hot_ptr[yw + lane * CS_NY];
-        he_n = g.hot_ptr[yw + lane * CS_NY + 1];
-      }
-      for (int s = 0; s < ns; s++) {
+      constexpr int YC = (CS_MAX_CG + 1) / 2;  // columns of a step per Y wavefront at most
+      // lane t < YC holds, for column yi + 2 t of the wavefront's NEXT step: first / end of its hot entries, its id and its group
+      int hb_n = 0, he_n = 0, j_n = 0, gr_n = 0;
+      auto prefetch_static = [&](int s) {
+        hb_n = he_n = j_n = gr_n = 0;
+        if (s < ns && lane < YC && yi + 2 * lane < min(Cg, n - s * Cg)) {
+          const int k = s * Cg + yi + 2 * lane;
+          hb_n = g.hot_ptr[k];
+          he_n = g.hot_ptr[k + 1];
+          j_n = g.cols[k];
+          gr_n = g.col_group[k];
+        }
+      };
+      prefetch_static(grp);
+      for (int s = grp; s < ns; s += 2) {
         const int e0 = g.enter_ptr[(size_t)s * NB], e1 = g.enter_ptr[(size_t)(s + 1) * NB];
         const int ncs = min(Cg, n - s * Cg), sl = (s % SR) * MC;
-        const int hb_v = hb_n, he_v = he_n;
-        hb_n = he_n = 0;
-        if (lane < YC && s + 1 < ns && yw + lane * CS_NY < min(Cg, n - (s + 1) * Cg)) {
-          hb_n = g.hot_ptr[(s + 1) * Cg + yw + lane * CS_NY];
-          he_n = g.hot_ptr[(s + 1) * Cg + yw + lane * CS_NY + 1];
-        }
-        constexpr int EP = 3;  // entering rows per lane whose slots are requested before the wait
+        const int hb_v = hb_n, he_v = he_n, j_v = j_n, gr_v = gr_n;
+        prefetch_static(s + 2);
+        constexpr int EP = 3;  // entering rows per lane and batch
         int slot_p[EP];
 #pragma unroll
         for (int t = 0; t < EP; t++) {
-          const int e = e0 + (t * CS_NY + yw) * WAVE + lane;
+          const int e = e0 + (t * 2 + yi) * WAVE + lane;
           slot_p[t] = e < e1 ? g.enter_slot[e] : -1;
         }
-        // the scalars and the hot entries of this wavefront's columns (static data: requested before the wait)
+        // the scalars and the hot entries of this wavefront's columns (static data: requested before the waits)
         double s_old[YC], s_z[YC], s_lam[YC], s_mu[YC];
         int en_sl[YC][U], en_cnt[YC];
         double en_x[YC][U];
 #pragma unroll
         for (int t = 0; t < YC; t++) {
-          const int c = yw + t * CS_NY;
+          const int c = yi + 2 * t;
           s_old[t] = s_z[t] = s_lam[t] = s_mu[t] = 0.0;
           en_cnt[t] = 0;
           if (c < ncs) {
             const int hb = __builtin_amdgcn_readlane(hb_v, t), he = __builtin_amdgcn_readlane(he_v, t);
+            const int j = __builtin_amdgcn_readlane(j_v, t), gr = __builtin_amdgcn_readlane(gr_v, t);
             en_cnt[t] = he - hb;
             if (lane == 0) {
-              const int k = s * Cg + c, j = g.cols[k], gr = g.col_group[k];
               s_old[t] = a.theta[j];
               s_z[t] = a.z[j];
               s_lam[t] = a.lambda[gr];
@@ -337,14 +474,57 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
         }
         unsigned long long t0 = 0, t1 = 0;
         if (pf) t0 = __builtin_amdgcn_s_memrealtime();
-        // slot reuse (and the rings of per-step data): the exits of step s - RD are out
-        for (int x = 0; x < CS_NX; x++) cs_wait<true>(&x_steps[x], s - RD + 1, g.error, dead);
-        // the hot entry lists do not need the ranges: into the LDS now
+        // every range's S wavefronts have published step s (first: they run ahead of the walker, the poll's round trip hides
+        // behind the wait for the slots below)
+        if (!dead) {
+          unsigned spins = 0;
+          for (;;) {
+            bool ok = true;
+            for (int p = lane; p < NB * 2; p += WAVE)  // (the two S wavefronts of every range that took step s)
+              ok = ok && __hip_atomic_load(&g.sync->s_flag[(p >> 1) * CS_NWS + (s & 1) * 2 + (p & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >=
+                             (unsigned long long)(s + 1);
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0u) {
+              if (spins > (1u << 23) || __hip_atomic_load(g.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __hip_atomic_store(g.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dead = true;
+                break;
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          asm volatile("" ::: "memory");
+        }
+        // the ranges' partial statistics and the first batch of entering records: one round trip for all of them
+        double2 pv[YC][(CS_MAX_NB * 2) / WAVE];
+#pragma unroll
+        for (int t = 0; t < YC; t++)
+#pragma unroll
+          for (int pp = 0; pp < (CS_MAX_NB * 2) / WAVE; pp++) {
+            const int c = yi + 2 * t, p = pp * WAVE + lane;
+            pv[t][pp] = make_double2(0.0, 0.0);
+            if (c < ncs && p < NB * 2) pv[t][pp] = cs_ld2(g.part + ((size_t)(s % R) * (NB * 2) + p) * MC + c);
+          }
+        const double2 *src = g.in_ring + (size_t)(s % R) * max(g.max_enter, 1) * rec2_g;
+        double2 r[EP][rec2_g];
+#pragma unroll
+        for (int t = 0; t < EP; t++) {
+          const int e = e0 + (t * 2 + yi) * WAVE + lane;
+          if (e < e1) {
+#pragma unroll
+            for (int w = 0; w < rec2_g; w++) r[t][w] = cs_ld2(src + (size_t)(e - e0) * rec2_g + w);
+          }
+        }
+        // slot reuse (and the rings of per-step data): the leaving records of step s - RD have been read out of their slots
+        for (int x = 0; x < CS_NX; x++) cs_wait<true>(&x_read[x], s - RD + 1, g.error, dead);
+        if (pf) t1 = __builtin_amdgcn_s_memrealtime();
+        // the hot entry lists and the scalars into the LDS
 #pragma unroll
         for (int t = 0; t < YC; t++) {
-          const int c = yw + t * CS_NY;
+          const int c = yi + 2 * t;
           if (c < ncs) {
-            const int base = ((s & 1) * Cg + c) * ecap;
+            const int base = ((s % CS_ER) * Cg + c) * ecap;
 #pragma unroll
             for (int u = 0; u < U; u++)
               if (u * WAVE < en_cnt[t]) {
@@ -359,64 +539,41 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
             if (lane == 0) h_cnt[sl + c] = en_cnt[t];
           }
         }
-        // every range's S wavefronts have published step s
-        if (!dead) {
-          unsigned spins = 0;
-          for (;;) {
-            bool ok = true;
-            for (int p = lane; p < NP; p += WAVE)
-              ok = ok && __hip_atomic_load(&g.sync->s_flag[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)(s + 1);
-            if (__all(ok)) break;
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 1023u) == 0u) {
-              if (spins > (1u << 23) || __hip_atomic_load(g.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                __hip_atomic_store(g.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                dead = true;
-                break;
-              }
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          asm volatile("" ::: "memory");
-        }
-        if (pf) t1 = __builtin_amdgcn_s_memrealtime();
-        const double2 *src = g.in_ring + (size_t)(s % R) * max(g.max_enter, 1) * rec2_g;
-        {
-          double2 r[EP][rec2_g];
 #pragma unroll
-          for (int t = 0; t < EP; t++) {
-            const int e = e0 + (t * CS_NY + yw) * WAVE + lane;
-            if (e < e1) {
+        for (int t = 0; t < EP; t++) {
+          const int e = e0 + (t * 2 + yi) * WAVE + lane;
+          if (e < e1) {
 #pragma unroll
-              for (int w = 0; w < rec2_g; w++) r[t][w] = cs_ld2(src + (size_t)(e - e0) * rec2_g + w);
-            }
-          }
-#pragma unroll
-          for (int t = 0; t < EP; t++) {
-            const int e = e0 + (t * CS_NY + yw) * WAVE + lane;
-            if (e < e1) {
-#pragma unroll
-              for (int w = 0; w < rec2_g; w++) recs[(size_t)slot_p[t] * rec2_l + w] = r[t][w];
+            for (int w = 0; w < 1; w++) {
+              ((double2 *)L.W0)[slot_p[t]] = r[t][0];
+              ((double2 *)L.W1)[slot_p[t]] = r[t][1];
+              ((double2 *)L.W2)[slot_p[t]] = r[t][2];
+              L.K[slot_p[t]] = r[t][3].x;
             }
           }
         }
-        for (int e = e0 + (EP * CS_NY + yw) * WAVE + lane; e < e1; e += CS_NY * WAVE) {
+        for (int e = e0 + (EP * 2 + yi) * WAVE + lane; e < e1; e += 2 * WAVE) {  // (beyond the first batch)
           const int slot = g.enter_slot[e];
-          double2 r[rec2_g];
+          double2 rr[rec2_g];
 #pragma unroll
-          for (int w = 0; w < rec2_g; w++) r[w] = cs_ld2(src + (size_t)(e - e0) * rec2_g + w);
+          for (int w = 0; w < rec2_g; w++) rr[w] = cs_ld2(src + (size_t)(e - e0) * rec2_g + w);
 #pragma unroll
-          for (int w = 0; w < rec2_g; w++) recs[(size_t)slot * rec2_l + w] = r[w];
+          for (int w = 0; w < 1; w++) {
+            ((double2 *)L.W0)[slot] = rr[0];
+            ((double2 *)L.W1)[slot] = rr[1];
+            ((double2 *)L.W2)[slot] = rr[2];
+            L.K[slot] = rr[3].x;
+          }
         }
 #pragma unroll
         for (int t = 0; t < YC; t++) {
-          const int c = yw + t * CS_NY;
+          const int c = yi + 2 * t;
           if (c < ncs) {  // (wave-uniform)
             double S1 = 0.0, S2 = 0.0;
-            for (int p = lane; p < NP; p += WAVE) {  // (partials p, p + 64, ... of a lane in order; then the fixed tree over the lanes)
-              const double2 v = cs_ld2(g.part + ((size_t)(s % R) * NP + p) * MC + c);
-              S1 += v.x;
-              S2 += v.y;
+#pragma unroll
+            for (int pp = 0; pp < (CS_MAX_NB * 2) / WAVE; pp++) {  // (a lane's partials in order; then the fixed tree over the lanes)
+              S1 += pv[t][pp].x;
+              S2 += pv[t][pp].y;
             }
             wave_allreduce_sum2(S1, S2);
             if (lane == 0) {
@@ -429,10 +586,16 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
           }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-        if (lane == 0) __hip_atomic_fetch_add(y_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(&y_steps[yw], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (pf) {
+          const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
           t_wait += t1 - t0;
-          t_work += __builtin_amdgcn_s_memrealtime() - t1;
+          t_work += t2 - t1;
+          if (g.trace) {
+            g.trace[((size_t)2 * ns + s) * 4 + 0] = t0;
+            g.trace[((size_t)2 * ns + s) * 4 + 1] = t1;
+            g.trace[((size_t)2 * ns + s) * 4 + 2] = t2;
+          }
         }
       }
       if (pf) {
@@ -452,17 +615,19 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
   __syncthreads();  // (the only barrier)
   if (wv < CS_NWS) {
     // ---- S: cold statistics of step v from the records in global memory, the rows entering at v packed for the walker ----
-    const int sw = wv;
-    const bool pf = g.prof != nullptr && lane == 0 && sw == 0 && b == 0;
+    // Two pairs of wavefronts take the steps in turn (pair v & 1 does step v, each of its two wavefronts half of the range's entries):
+    // a step costs a gather of the records, the write-through stores and their drain -- more than the walker needs for the step.
+    const int sw = wv, grp = sw >> 1, si = sw & 1;
+    const bool pf = g.prof != nullptr && lane == 0 && sw == 0 && (b == 0 || g.trace != nullptr);
     unsigned long long t_wait = 0, t_work = 0;
     double2 *pw = part_w + sw * MC;
     double *co = c_old_w + sw * MC;
-    for (int v = 0; v < ns; v++) {
+    for (int v = grp; v < ns; v += 2) {
       const int lo = g.cold_ptr[(size_t)v * NB + b], hi = g.cold_ptr[(size_t)v * NB + b + 1];
       const int ncs = min(Cg, n - v * Cg);
-      const int chunk = (((hi - lo + CS_NWS - 1) / CS_NWS + WAVE - 1) / WAVE) * WAVE;
-      const int mylo = lo + sw * chunk, myhi = min(hi, mylo + chunk);
-      constexpr int T = 2;  // tiles whose entries are requested before the wait
+      const int chunk = (((hi - lo + 1) / 2 + WAVE - 1) / WAVE) * WAVE;
+      const int mylo = lo + si * chunk, myhi = min(hi, mylo + chunk);
+      constexpr int T = 3;  // tiles whose entries are requested before the wait and whose records are gathered together
       int rc[T];
       double xv[T];
 #pragma unroll
@@ -482,26 +647,33 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
       const int en0 = g.enter_ptr[(size_t)v * NB], en_lo = g.enter_ptr[(size_t)v * NB + b], en_hi = g.enter_ptr[(size_t)v * NB + b + 1];
       int en_row = -1;
       {
-        const int e = en_lo + sw * WAVE + lane;
+        const int e = en_lo + si * WAVE + lane;
         if (e < en_hi) en_row = g.enter_row[e];
       }
       unsigned long long t0 = 0, t1 = 0;
       if (pf) t0 = __builtin_amdgcn_s_memrealtime();
       for (int u = 0; u < 4; u++) cs_wait<true>(&u_steps[u], v - Lw + 1, g.error, dead);
       if (pf) t1 = __builtin_amdgcn_s_memrealtime();
-      auto tile = [&](int rcv, double x) {
+      // every record this step needs, requested together: the first tiles' rows and the first entering row of the lane
+      typename P::St st[T];
+#pragma unroll
+      for (int t = 0; t < T; t++)
+        if (rc[t] >= 0) st[t] = P::load(a, rc[t] & ((1 << CS_LCOL_SHIFT) - 1));
+      double2 er[rec2_g];
+      if (en_row >= 0) {
+        const double2 *src = (const double2 *)a.state + (int64_t)en_row * rec2_global;
+#pragma unroll
+        for (int w = 0; w < rec2_g; w++) er[w] = src[w];
+      }
+      auto tile = [&](int rcv, double x, const typename P::St &stv) {
         const int lc = rcv < 0 ? -1 - lane : (rcv >> CS_LCOL_SHIFT);
-        const int row = rcv < 0 ? -1 : (rcv & ((1 << CS_LCOL_SHIFT) - 1));
         double s1 = 0.0, s2 = 0.0;
-        if (row >= 0) {
-          const typename P::St st = P::load(a, row);
-          P::stats(x, st, co[lc], s1, s2);
-        }
+        if (rcv >= 0) P::stats(x, stv, co[lc], s1, s2);
         const int lp = dpp_i32<0x138, 0xf>(lc, 0), ln = dpp_i32<0x130, 0xf>(lc, 0);
         const bool head = lane == 0 || lp != lc, tail = lane == 63 || ln != lc;
         int f = head ? 1 : 0;
         wave_segscan2(s1, s2, f);
-        if (row >= 0 && tail) {  // one lane per column of this tile; a wavefront adds its tiles in program order
+        if (rcv >= 0 && tail) {  // one lane per column of this tile; a wavefront adds its tiles in program order
           double2 &q = pw[lc];
           q.x += s1;
           q.y += s2;
@@ -509,16 +681,23 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
       };
 #pragma unroll
       for (int t = 0; t < T; t++)
-        if (mylo + t * WAVE < myhi) tile(rc[t], xv[t]);
-      for (int base = mylo + T * WAVE; base < myhi; base += WAVE) {
+        if (mylo + t * WAVE < myhi) tile(rc[t], xv[t], st[t]);
+      for (int base = mylo + T * WAVE; base < myhi; base += WAVE) {  // (beyond the first tiles: rare)
         const int p = base + lane;
-        tile(p < myhi ? g.cold_rc[p] : -1, p < myhi ? g.cold_x[p] : 0.0);
+        const int rcv = p < myhi ? g.cold_rc[p] : -1;
+        typename P::St stv;
+        if (rcv >= 0) stv = P::load(a, rcv & ((1 << CS_LCOL_SHIFT) - 1));
+        tile(rcv, p < myhi ? g.cold_x[p] : 0.0, stv);
       }
       // rows entering the walker's LDS at step v: their records as they are now
       double2 *dst = g.in_ring + (size_t)(v % R) * max(g.max_enter, 1) * rec2_g;
-      for (int e = en_lo + sw * WAVE + lane; e < en_hi; e += CS_NWS * WAVE) {
-        const int row = e == en_lo + sw * WAVE + lane ? en_row : g.enter_row[e];
-        const double2 *src = (const double2 *)a.state + (int64_t)row * rec2_global;
+      if (en_row >= 0) {
+        const int e = en_lo + si * WAVE + lane;
+#pragma unroll
+        for (int w = 0; w < rec2_g; w++) cs_st16(dst + (size_t)(e - en0) * rec2_g + w, er[w]);
+      }
+      for (int e = en_lo + (2 + si) * WAVE + lane; e < en_hi; e += 2 * WAVE) {  // (beyond the first: rare)
+        const double2 *src = (const double2 *)a.state + (int64_t)g.enter_row[e] * rec2_global;
         double2 r[rec2_g];
 #pragma unroll
         for (int w = 0; w < rec2_g; w++) r[w] = src[w];
@@ -526,16 +705,22 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
         for (int w = 0; w < rec2_g; w++) cs_st16(dst + (size_t)(e - en0) * rec2_g + w, r[w]);
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the tails' LDS adds
-      if (lane < MC) cs_st16(g.part + ((size_t)(v % R) * NP + b * CS_NWS + sw) * MC + lane, pw[lane]);
+      if (lane < MC) cs_st16(g.part + ((size_t)(v % R) * (NB * 2) + b * 2 + si) * MC + lane, pw[lane]);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0)
         __hip_atomic_store(&g.sync->s_flag[b * CS_NWS + sw], (unsigned long long)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (pf) {
+        const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
         t_wait += t1 - t0;
-        t_work += __builtin_amdgcn_s_memrealtime() - t1;
+        t_work += t2 - t1;
+        if (g.trace) {
+          g.trace[((size_t)(3 + NB + b) * ns + v) * 4 + 0] = t0;
+          g.trace[((size_t)(3 + NB + b) * ns + v) * 4 + 1] = t1;
+          g.trace[((size_t)(3 + NB + b) * ns + v) * 4 + 2] = t2;
+        }
       }
     }
-    if (pf) {
+    if (pf && b == 0) {
       g.prof[12] += t_wait;
       g.prof[13] += t_work;
     }
@@ -544,7 +729,7 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
   {
     // ---- U: cold updates of step u with the walker's (old, new), the leaving rows' records back to their rows ----
     const int uw = wv - CS_NWS;
-    const bool pf = g.prof != nullptr && lane == 0 && uw == 0 && b == 0;
+    const bool pf = g.prof != nullptr && lane == 0 && uw == 0 && (b == 0 || g.trace != nullptr);
     unsigned long long t_wait = 0, t_work = 0;
     for (int u = 0; u < ns; u++) {
       const int lo = g.cold_ptr[(size_t)u * NB + b], hi = g.cold_ptr[(size_t)u * NB + b + 1];
@@ -579,12 +764,33 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
         const typename P::St st = P::load(a, row);
         P::apply(a, row, x, st, o.x, o.y);
       };
-#pragma unroll
-      for (int t = 0; t < T; t++) upd(rc[t], xv[t]);
-      for (int p = lo + (T * 4 + uw) * WAVE + lane; p < hi; p += 4 * WAVE) upd(g.cold_rc[p], g.cold_x[p]);
+      // the leaving record of this lane (requested together with the cold entries' records)
       const double2 *src = g.out_ring + (size_t)(u % R) * max(g.max_exit, 1) * 2;
-      for (int x = x_lo + uw * WAVE + lane; x < x_hi; x += 4 * WAVE) {
-        const int row = x == x_lo + uw * WAVE + lane ? ex_row : g.exit_row[x];
+      double2 xr0 = make_double2(0.0, 0.0), xr2 = xr0;
+      if (ex_row >= 0) {
+        const int x = x_lo + uw * WAVE + lane;
+        xr0 = cs_ld2(src + (size_t)(x - x0) * 2);
+        xr2 = cs_ld2(src + (size_t)(x - x0) * 2 + 1);
+      }
+      double2 o_[T];
+      typename P::St st_[T];
+#pragma unroll
+      for (int t = 0; t < T; t++)
+        if (rc[t] >= 0) {
+          o_[t] = cs_ld2(on + (rc[t] >> CS_LCOL_SHIFT));
+          st_[t] = P::load(a, rc[t] & ((1 << CS_LCOL_SHIFT) - 1));
+        }
+#pragma unroll
+      for (int t = 0; t < T; t++)
+        if (rc[t] >= 0) P::apply(a, rc[t] & ((1 << CS_LCOL_SHIFT) - 1), xv[t], st_[t], o_[t].x, o_[t].y);
+      for (int p = lo + (T * 4 + uw) * WAVE + lane; p < hi; p += 4 * WAVE) upd(g.cold_rc[p], g.cold_x[p]);
+      if (ex_row >= 0) {
+        double2 *rec = (double2 *)a.state + (int64_t)ex_row * rec2_global;
+        rec[0] = xr0;
+        rec[2] = xr2;
+      }
+      for (int x = x_lo + (4 + uw) * WAVE + lane; x < x_hi; x += 4 * WAVE) {  // (beyond the first: rare)
+        const int row = g.exit_row[x];
         const double2 r0 = cs_ld2(src + (size_t)(x - x0) * 2), r2 = cs_ld2(src + (size_t)(x - x0) * 2 + 1);
         double2 *rec = (double2 *)a.state + (int64_t)row * rec2_global;
         rec[0] = r0;
@@ -593,11 +799,17 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(&u_steps[uw], u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (pf) {
+        const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
         t_wait += t1 - t0;
-        t_work += __builtin_amdgcn_s_memrealtime() - t1;
+        t_work += t2 - t1;
+        if (g.trace) {
+          g.trace[((size_t)(3 + b) * ns + u) * 4 + 0] = t0;
+          g.trace[((size_t)(3 + b) * ns + u) * 4 + 1] = t1;
+          g.trace[((size_t)(3 + b) * ns + u) * 4 + 2] = t2;
+        }
       }
     }
-    if (pf) {
+    if (pf && b == 0) {
       g.prof[8] += t_wait;
       g.prof[9] += t_work;
     }
@@ -607,8 +819,8 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
 // LDS of a launch (the walker's need; the ranges use a few hundred bytes of it)
 inline int cs_ecap(int max_hot_col) { return std::max(WAVE, ((max_hot_col + WAVE - 1) / WAVE) * WAVE); }
 inline size_t cs_lds_bytes(int n_slots, int Cg, int max_hot_col) {
-  return (size_t)std::max(n_slots, 1) * 5 * sizeof(double2) + (size_t)CS_SR * CS_MAX_CG * (sizeof(double2) + 5 * sizeof(double) + sizeof(int)) +
-         (size_t)2 * Cg * cs_ecap(max_hot_col) * (sizeof(double) + sizeof(int)) + (2 + CS_NX) * sizeof(int) + 64;
+  return (size_t)(std::max(n_slots, 1) + 1) * 56 + (size_t)CS_SR * CS_MAX_CG * (sizeof(double2) + 5 * sizeof(double) + sizeof(int)) +
+         (size_t)CS_ER * Cg * cs_ecap(max_hot_col) * (sizeof(double) + sizeof(int)) + (CS_NY + 1 + 2 * CS_NX) * sizeof(int) + 64;
 }
 
 }  // namespace mfm

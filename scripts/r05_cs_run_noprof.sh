@@ -1,0 +1,9 @@
+# usage: bash scripts/r05_cs_run_noprof.sh <tag> "name ENV=.. ENV=.." ...   -- config 5 at full size, no in-kernel stamps
+cd $GRAFT_REPO_ROOT
+T=$1; shift
+C5="--config 5 --scale 1.0 --steps 4 --warmup 1 --cpu-iters 0 --fit-iters 0 --long-seconds 0"
+for spec in "$@"; do
+  set -- $spec; name=$1; shift
+  env "$@" python bench.py $C5 > gpurun_out/${T}_$name.json 2> gpurun_out/${T}_$name.err
+  echo "== $name: $(python -c "import json; d=json.loads(open('gpurun_out/${T}_$name.json').read().strip().splitlines()[-1]); print(d['value'], 'it/s', d['ms_per_step'], 'ms', 'setup', d['config'].get('setup_s'), {k: round(v.get('ms_per_step', 0), 1) for k, v in (d.get('kernel_classes') or {}).items()})" 2>&1 | tail -1)"
+done

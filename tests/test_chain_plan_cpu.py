@@ -38,7 +38,7 @@ def _block(n_rows, n_cols, per_row, seed):
     return B
 
 
-@pytest.mark.parametrize("cg,lw,nb,rd", [(4, 3, 16, 2), (4, 4, 16, 2), (2, 5, 8, 1), (1, 6, 3, 2), (8, 2, 32, 3), (3, 1, 5, 2), (4, 7, 16, 3)])
+@pytest.mark.parametrize("cg,lw,nb,rd", [(4, 3, 16, 2), (4, 4, 16, 2), (2, 5, 8, 1), (1, 6, 3, 2), (4, 2, 32, 3), (3, 1, 5, 2), (4, 7, 16, 3)])
 def test_plan_data_flow_matches_the_sequential_sweep(cg, lw, nb, rd):
     B = _block(20000, 300, 6, seed=cg * 100 + lw)
     rc, diff, info = _selftest(B, cg, lw, nb, rd, 1 << 20)
