@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 #include "mfm_chain_api.hpp"
 #include "mfm_chain_stream.hpp"
@@ -32,36 +33,59 @@ std::shared_ptr<CsStream> cs_stream_build(const HostCsr &csc, const std::vector<
   prm.RD = std::max(1, std::min(CS_ER, env_int("MFM_CS_RD", 2)));  // (the walker keeps the hot entry lists of CS_ER steps)
   prm.cap = std::max(16, env_int("MFM_CS_CAP", 1 << 20));
   const int cg_forced = env_int("MFM_CS_CG", 0);
-  const int lw_max = std::max(1, std::min(CS_MAX_LW, env_int("MFM_CS_LW", CS_MAX_LW)));
-  const int lw_min = std::max(1, std::min(lw_max, env_int("MFM_CS_LW_MIN", 2)));
+  const int lw_max = std::max(2, std::min(CS_MAX_LW, env_int("MFM_CS_LW", CS_MAX_LW)));
+  // (a window of at least two steps: the U wavefront pairs take the steps in turn, and two cold touches of one row in consecutive steps
+  //  -- possible only with a window of one -- would then race)
+  const int lw_min = std::max(2, std::min(lw_max, env_int("MFM_CS_LW_MIN", 2)));
   // Steps of Cg columns, a window of Lw steps: the walker never waits when the hop walker -> ranges -> walker (~12 us, measured:
   // profiles/r05_*) fits Lw steps, and the hot rows (56 bytes each) + the hot entry lists of CS_ER steps must fit its LDS -- both
   // want Cg * Lw large, the LDS need grows with its square. Per step width the largest window that fits; of those the one with the
   // shortest predicted time per column, the wider step on a tie (fewer hand-overs).
   CsPlanHost P;
-  double best = 1e30;
-  for (int cg = CS_MAX_CG; cg >= 2; cg--) {
-    if (cg_forced > 0 && cg != std::max(1, std::min(CS_MAX_CG, cg_forced))) continue;
-    prm.Cg = cg;
-    for (int lw = lw_max; lw >= lw_min; lw--) {
-      prm.Lw = lw;
-      CsPlanHost Q = cs_build_plan(csc.ptr.data(), csc.idx.data(), csc.val.data(), csc.cols, run, prm);
-      if (!Q.ok || cs_lds_bytes(Q.n_slots, cg, Q.max_hot_col) > CS_LDS_MAX || cs_ecap(Q.max_hot_col) > 1024) continue;
-      const double per_col = std::max(0.8, (12.0 + 0.8 * cg) / ((double)lw * cg)) + 0.15 / cg;  // (+ the step's fixed hand-over cost)
-      if (per_col < best - 1e-9) {
-        best = per_col;
-        P = std::move(Q);
+  {
+    const CsTouches T = cs_touches(csc.ptr.data(), csc.idx.data(), csc.cols, run);
+    const int n = (int)run.size();
+    struct Cand {
+      int cg = 0, lw = 0;
+      double per_col = 1e30;
+    };
+    std::vector<Cand> cands((size_t)CS_MAX_CG + 1);
+    auto fits = [&](int cg, int lw, CsNeed &N) {
+      N = cs_estimate(T, cg, lw, prm.RD);
+      return N.n_slots <= prm.cap && cs_lds_bytes(N.n_slots, cg, N.max_hot_col) <= CS_LDS_MAX && cs_ecap(N.max_hot_col) <= 1024;
+    };
+    auto search = [&](int cg) {  // the best window for this step width (the LDS need grows with the window: bisection)
+      Cand &C = cands[(size_t)cg];
+      CsNeed N;
+      if (!fits(cg, lw_min, N)) return;
+      int lo = lw_min, hi = lw_max;  // lo fits
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (fits(cg, mid, N)) lo = mid; else hi = mid - 1;
       }
-      break;
+      // predicted time per column (calibrated on MI355X, profiles/r05_*): the walker needs 0.62 us + 1.3 ns per hot entry for a
+      // column; it never waits when the hop walker -> ranges -> walker (~11 us) fits the window; + the step's hand-over costs
+      for (int lw = lo; lw >= std::max(lw_min, lo - 3); lw--) {
+        fits(cg, lw, N);
+        const double walk = 0.62 + 0.0013 * (double)N.n_hot / std::max(n, 1);
+        const double per_col = std::max(walk, (11.0 + walk * cg) / ((double)lw * cg)) + 0.1 / cg;
+        if (per_col < C.per_col - 1e-9) C = Cand{cg, lw, per_col};
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int cg = CS_MAX_CG; cg >= 1; cg--) {
+      if (cg_forced > 0 ? cg != std::max(1, std::min(CS_MAX_CG, cg_forced)) : cg < 2) continue;
+      pool.emplace_back(search, cg);
     }
-  }
-  if (cg_forced == 1 && !P.ok) {
-    prm.Cg = 1;
-    for (int lw = lw_max; lw >= lw_min && !P.ok; lw--) {
-      prm.Lw = lw;
-      P = cs_build_plan(csc.ptr.data(), csc.idx.data(), csc.val.data(), csc.cols, run, prm);
-      if (P.ok && cs_lds_bytes(P.n_slots, 1, P.max_hot_col) > CS_LDS_MAX) P.ok = false;
-    }
+    for (auto &t : pool) t.join();
+    Cand best;
+    for (int cg = CS_MAX_CG; cg >= 1; cg--)
+      if (cands[(size_t)cg].per_col < best.per_col - 1e-9) best = cands[(size_t)cg];  // (the wider step on a tie)
+    if (best.cg == 0) return nullptr;
+    prm.Cg = best.cg;
+    prm.Lw = best.lw;
+    P = cs_build_plan(csc.ptr.data(), csc.idx.data(), csc.val.data(), csc.cols, run, prm);
+    if (P.ok && cs_lds_bytes(P.n_slots, prm.Cg, P.max_hot_col) > CS_LDS_MAX) P.ok = false;
   }
   if (!P.ok) return nullptr;
   auto st = std::make_shared<CsStream>();

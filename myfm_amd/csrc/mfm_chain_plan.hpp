@@ -220,6 +220,71 @@ inline CsPlanHost cs_build_plan(const int64_t *csc_ptr, const int32_t *csc_idx, 
   return P;
 }
 
+// What a plan with steps of Cg columns, a window of Lw steps and slot reuse delay RD would need, without building it: LDS slots, most
+// hot entries of a column, hot entries in all (one pass over the entries; the touches are taken once per run by cs_touches).
+struct CsTouches {
+  std::vector<int32_t> eptr;        // [n + 1] entries per column position
+  std::vector<int32_t> prev, next;  // per entry: column POSITION of the row's touch before / after (-2^30 / 2^30: none)
+};
+inline CsTouches cs_touches(const int64_t *csc_ptr, const int32_t *csc_idx, int64_t n_rows, const std::vector<int32_t> &run) {
+  CsTouches T;
+  const int n = (int)run.size();
+  T.eptr.assign((size_t)n + 1, 0);
+  for (int k = 0; k < n; k++) T.eptr[k + 1] = T.eptr[k] + (int32_t)(csc_ptr[run[k] + 1] - csc_ptr[run[k]]);
+  const int32_t NONE = 1 << 30;
+  T.prev.resize((size_t)T.eptr[n]);
+  T.next.resize((size_t)T.eptr[n]);
+  std::vector<int32_t> last((size_t)n_rows, -NONE);
+  for (int k = 0; k < n; k++) {
+    const int64_t b = csc_ptr[run[k]];
+    for (int32_t q = T.eptr[k]; q < T.eptr[k + 1]; q++) {
+      const int32_t r = csc_idx[b + (q - T.eptr[k])];
+      T.prev[q] = last[r];
+      last[r] = k;
+    }
+  }
+  std::fill(last.begin(), last.end(), NONE);
+  for (int k = n - 1; k >= 0; k--) {
+    const int64_t b = csc_ptr[run[k]];
+    for (int32_t q = T.eptr[k + 1] - 1; q >= T.eptr[k]; q--) {
+      const int32_t r = csc_idx[b + (q - T.eptr[k])];
+      T.next[q] = last[r];
+      last[r] = k;
+    }
+  }
+  return T;
+}
+struct CsNeed {
+  int n_slots = 0, max_hot_col = 0;
+  int64_t n_hot = 0;
+};
+inline CsNeed cs_estimate(const CsTouches &T, int Cg, int Lw, int RD) {
+  CsNeed N;
+  const int n = (int)T.eptr.size() - 1, ns = (n + Cg - 1) / Cg;
+  const int32_t NONE = 1 << 30;
+  std::vector<int32_t> en((size_t)ns + 1, 0), ex((size_t)ns + RD + 1, 0);
+  for (int k = 0; k < n; k++) {
+    const int s = k / Cg;
+    int hot = 0;
+    for (int32_t q = T.eptr[k]; q < T.eptr[k + 1]; q++) {
+      const bool near_prev = T.prev[q] > -NONE && s - T.prev[q] / Cg < Lw, near_next = T.next[q] < NONE && T.next[q] / Cg - s < Lw;
+      if (near_prev || near_next) {
+        hot++;
+        if (!near_prev) en[s]++;
+        if (!near_next) ex[s + RD]++;  // (the slot comes back RD steps later)
+      }
+    }
+    N.n_hot += hot;
+    N.max_hot_col = std::max(N.max_hot_col, hot);
+  }
+  int live = 0;
+  for (int s = 0; s < ns; s++) {
+    live += en[s] - ex[s];
+    N.n_slots = std::max(N.n_slots, live);
+  }
+  return N;
+}
+
 // The largest window (in steps) whose hot rows fit, for the given step width: Lw = lw_max, lw_max - 1, ... 1.
 inline CsPlanHost cs_build_plan_fit(const int64_t *csc_ptr, const int32_t *csc_idx, const double *csc_val, int64_t n_rows,
                                     const std::vector<int32_t> &run, CsParams prm, int lw_max, int lw_min = 1) {

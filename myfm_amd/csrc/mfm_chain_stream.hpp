@@ -45,7 +45,7 @@ struct CsSync {  // zeroed before every launch
 struct CsArgs {
   int n_cols, n_steps, Cg, Lw, NB, RD, max_enter, max_exit, n_slots;
   int ecap;  // hot entries of a column at most, rounded up to whole wavefronts
-  int dbg;   // MFM_CS_DBG (experiments): 1 Y waits for the published exits instead of the read ones, 2 Y polls the ranges after the slots
+  int dbg;   // MFM_CS_DBG (experiments): 8 / 16 the walker sees no / at most 64 hot entries per column (wrong results: timing only)
   const int32_t *cols, *col_group;
   const int32_t *cold_ptr, *cold_rc;
   const double *cold_x;
@@ -81,6 +81,21 @@ __device__ __forceinline__ void cs_st16(double2 *p, double2 v) {
   // (s_nop 1: a store of more than 8 bytes reads its data registers up to two cycles after issue; the compiler's hazard recogniser
   //  covers its own stores, not this one -- without the wait states the next VALU write to those registers raced the store)
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(w) : "memory");
+}
+// 16-byte agent-scope load as ONE instruction (an 8-byte sc1 access runs at about half the rate per byte). The compiler does not know
+// that the result is still in flight: cs_ld16_wait must sit between the loads and the first use of ANY of their results -- the values
+// are passed through it, so no use can be scheduled above the wait.
+typedef double cs_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cs_d2v cs_ld16_issue(const double2 *p) {
+  cs_d2v v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void cs_ld16_wait(cs_d2v (&v)[N]) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < N; i++) asm volatile("" : "+v"(v[i]));
 }
 // a wavefront waits until *w >= target: lane 0 polls (global: agent scope; LDS: workgroup scope), bounded -- a lost partner
 // raises *error, and every later wait of everybody falls through (the results are then garbage and the host raises)
@@ -278,7 +293,9 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
         if (!have) load_col(C, s, c);
         have = c + 1 < Cg && k + 1 < n;  // the next column of the SAME step: its entries and scalars are requested now
         if (have) load_col(N, s, c + 1);
-        const int cnt = __builtin_amdgcn_readfirstlane(C.cnt);
+        int cnt = __builtin_amdgcn_readfirstlane(C.cnt);
+        if (g.dbg & 8) cnt = 0;              // (timing experiments only, wrong results: no hot entries at all ...
+        if (g.dbg & 16) cnt = min(cnt, 64);  //  ... one round at most)
         double fresh;
         switch ((cnt + WAVE - 1) / WAVE) {
           case 0: fresh = P::template draw<true>(C.S1c, C.S2c, C.old, a.alpha, C.lam, C.mu, C.z); break;
@@ -331,20 +348,36 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
     }
     if (role == 1) {
       // ---- X: what leaves the LDS after step j, and the step's (old, new) pairs ----
+      // The two X wavefronts take the steps in turn (wavefront j & 1 publishes step j): reading the leaving records out of their
+      // slots, the write-through stores and their drain are a chain of round trips longer than a step of the walker; what is static
+      // (list offsets, slots, column ids) is requested one own step ahead. Steps are PUBLISHED in order (walk_done counts them).
       const int xw = xw_of;
       const bool xpf = g.prof != nullptr && lane == 0 && xw == 0;
-      for (int j = 0; j < ns; j++) {
-        const int x0 = g.exit_ptr[(size_t)j * NB], x1 = g.exit_ptr[(size_t)(j + 1) * NB];
-        const int ncs = min(Cg, n - j * Cg), sl = (j % SR) * MC;
-        int col = -1;
-        if (xw == 0 && lane < ncs) col = g.cols[j * Cg + lane];
-        constexpr int XP = 4;  // exits per lane requested before the wait
+      constexpr int XP = 8;  // exits per lane kept in registers (beyond: slot by slot)
+      int x0_n = 0, x1_n = 0, col_n = -1, slot_n[XP];
+      auto prefetch_static = [&](int j) {
+        x0_n = x1_n = 0;
+        col_n = -1;
+#pragma unroll
+        for (int t = 0; t < XP; t++) slot_n[t] = -1;
+        if (j < ns) {
+          x0_n = g.exit_ptr[(size_t)j * NB];
+          x1_n = g.exit_ptr[(size_t)(j + 1) * NB];
+          if (lane < min(Cg, n - j * Cg)) col_n = g.cols[j * Cg + lane];
+#pragma unroll
+          for (int t = 0; t < XP; t++) {
+            const int x = x0_n + t * WAVE + lane;
+            if (x < x1_n) slot_n[t] = g.exit_slot[x];
+          }
+        }
+      };
+      prefetch_static(xw);
+      for (int j = xw; j < ns; j += 2) {
+        const int x0 = x0_n, x1 = x1_n, col = col_n, sl = (j % SR) * MC;
         int slot_p[XP];
 #pragma unroll
-        for (int t = 0; t < XP; t++) {
-          const int x = x0 + (t * CS_NX + xw) * WAVE + lane;
-          slot_p[t] = x < x1 ? g.exit_slot[x] : -1;
-        }
+        for (int t = 0; t < XP; t++) slot_p[t] = slot_n[t];
+        prefetch_static(j + 2);
         unsigned long long xt0 = 0, xt1 = 0;
         if (xpf) xt0 = __builtin_amdgcn_s_memrealtime();
         cs_wait<true>(w_steps, j + 1, g.error, dead);
@@ -361,37 +394,33 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
             r2[t] = ((const double2 *)L.W2)[slot_p[t]];
           }
         }
-        const bool more = x0 + XP * CS_NX * WAVE < x1;  // (uniform; rare: the rest goes slot by slot before the flag)
-        for (int x = x0 + (XP * CS_NX + xw) * WAVE + lane; more && x < x1; x += CS_NX * WAVE) {
+        for (int x = x0 + XP * WAVE + lane; x < x1; x += WAVE) {  // (rare: the rest goes slot by slot before the flag)
           const int slot = g.exit_slot[x];
           cs_st16(dst + (size_t)(x - x0) * 2, ((const double2 *)L.W0)[slot]);
           cs_st16(dst + (size_t)(x - x0) * 2 + 1, ((const double2 *)L.W2)[slot]);
         }
+        double2 on = make_double2(0.0, 0.0);
+        if (col >= 0) on = make_double2(c_old[sl + lane], c_new[sl + lane]);
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the records are in registers
         if (lane == 0) __hip_atomic_store(&x_read[xw], j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (col >= 0) {
+          cs_st16(g.oldnew + (size_t)(j % R) * MC + lane, on);
+          a.theta[col] = on.y;
+        }
 #pragma unroll
         for (int t = 0; t < XP; t++) {
-          const int x = x0 + (t * CS_NX + xw) * WAVE + lane;
+          const int x = x0 + t * WAVE + lane;
           if (x < x1) {
-            if (g.dbg & 4) {
-              cs_st16(dst + (size_t)(x - x0) * 2, ((const double2 *)L.W0)[slot_p[t]]);
-              cs_st16(dst + (size_t)(x - x0) * 2 + 1, ((const double2 *)L.W2)[slot_p[t]]);
-            } else {
-              cs_st16(dst + (size_t)(x - x0) * 2, r0[t]);
-              cs_st16(dst + (size_t)(x - x0) * 2 + 1, r2[t]);
-            }
+            cs_st16(dst + (size_t)(x - x0) * 2, r0[t]);
+            cs_st16(dst + (size_t)(x - x0) * 2 + 1, r2[t]);
           }
         }
-        if (col >= 0) {
-          cs_st16(g.oldnew + (size_t)(j % R) * MC + lane, make_double2(c_old[sl + lane], c_new[sl + lane]));
-          a.theta[col] = c_new[sl + lane];
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&x_steps[xw], j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (xw == 0) {
-          for (int o = 1; o < CS_NX; o++) cs_wait<true>(&x_steps[o], j + 1, g.error, dead);
-          if (lane == 0)
-            __hip_atomic_store(&g.sync->walk_done, (unsigned long long)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // published in step order: behind the other wavefront's step j - 1
+        cs_wait<true>(&x_steps[xw ^ 1], j, g.error, dead);
+        if (lane == 0) {
+          __hip_atomic_store(&g.sync->walk_done, (unsigned long long)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&x_steps[xw], j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (xpf) {
           const unsigned long long xt2 = __builtin_amdgcn_s_memrealtime();
@@ -496,28 +525,42 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           asm volatile("" ::: "memory");
         }
-        // the ranges' partial statistics and the first batch of entering records: one round trip for all of them
-        double2 pv[YC][(CS_MAX_NB * 2) / WAVE];
+        // the ranges' partial statistics and the first batch of entering records: one round trip for all of them (16-byte loads)
+        constexpr int NPV = (CS_MAX_NB * 2) / WAVE;
+        cs_d2v ld[YC * NPV + EP * rec2_g];
+        // (every load is issued unconditionally, from a clamped address: a conditional one would leave the compiler a copy of the
+        //  not-yet-arrived value to make between the load and the wait)
 #pragma unroll
         for (int t = 0; t < YC; t++)
 #pragma unroll
-          for (int pp = 0; pp < (CS_MAX_NB * 2) / WAVE; pp++) {
-            const int c = yi + 2 * t, p = pp * WAVE + lane;
-            pv[t][pp] = make_double2(0.0, 0.0);
-            if (c < ncs && p < NB * 2) pv[t][pp] = cs_ld2(g.part + ((size_t)(s % R) * (NB * 2) + p) * MC + c);
+          for (int pp = 0; pp < NPV; pp++) {
+            const int c = min(yi + 2 * t, MC - 1), p = min(pp * WAVE + lane, NB * 2 - 1);
+            ld[t * NPV + pp] = cs_ld16_issue(g.part + ((size_t)(s % R) * (NB * 2) + p) * MC + c);
           }
         const double2 *src = g.in_ring + (size_t)(s % R) * max(g.max_enter, 1) * rec2_g;
-        double2 r[EP][rec2_g];
 #pragma unroll
         for (int t = 0; t < EP; t++) {
-          const int e = e0 + (t * 2 + yi) * WAVE + lane;
-          if (e < e1) {
+          const int e = min(e0 + (t * 2 + yi) * WAVE + lane, max(e1 - 1, e0));
 #pragma unroll
-            for (int w = 0; w < rec2_g; w++) r[t][w] = cs_ld2(src + (size_t)(e - e0) * rec2_g + w);
-          }
+          for (int w = 0; w < rec2_g; w++) ld[YC * NPV + t * rec2_g + w] = cs_ld16_issue(src + (size_t)(e - e0) * rec2_g + w);
         }
+        cs_ld16_wait(ld);
+        double2 pv[YC][NPV], r[EP][rec2_g];
+#pragma unroll
+        for (int t = 0; t < YC; t++)
+#pragma unroll
+          for (int pp = 0; pp < NPV; pp++) {
+            const bool ok = yi + 2 * t < ncs && pp * WAVE + lane < NB * 2;
+            pv[t][pp] = ok ? make_double2(ld[t * NPV + pp].x, ld[t * NPV + pp].y) : make_double2(0.0, 0.0);
+          }
+#pragma unroll
+        for (int t = 0; t < EP; t++)
+#pragma unroll
+          for (int w = 0; w < rec2_g; w++) r[t][w] = make_double2(ld[YC * NPV + t * rec2_g + w].x, ld[YC * NPV + t * rec2_g + w].y);
         // slot reuse (and the rings of per-step data): the leaving records of step s - RD have been read out of their slots
-        for (int x = 0; x < CS_NX; x++) cs_wait<true>(&x_read[x], s - RD + 1, g.error, dead);
+        // (the X wavefront that took step s - RD, and the other one's step before it: both Y pairs reuse slots of either)
+        cs_wait<true>(&x_read[(s - RD) & 1], s - RD + 1, g.error, dead);
+        cs_wait<true>(&x_read[(s - RD - 1) & 1], s - RD, g.error, dead);
         if (pf) t1 = __builtin_amdgcn_s_memrealtime();
         // the hot entry lists and the scalars into the LDS
 #pragma unroll
@@ -652,7 +695,10 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
       }
       unsigned long long t0 = 0, t1 = 0;
       if (pf) t0 = __builtin_amdgcn_s_memrealtime();
-      for (int u = 0; u < 4; u++) cs_wait<true>(&u_steps[u], v - Lw + 1, g.error, dead);
+      for (int u = 0; u < 4; u++) {  // (U wavefront u takes the steps of parity u >> 1: its last one that is <= v - Lw)
+        const int last = v - Lw - (((v - Lw) - (u >> 1)) & 1);
+        cs_wait<true>(&u_steps[u], last + 1, g.error, dead);
+      }
       if (pf) t1 = __builtin_amdgcn_s_memrealtime();
       // every record this step needs, requested together: the first tiles' rows and the first entering row of the lane
       typename P::St st[T];
@@ -728,17 +774,32 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
   }
   {
     // ---- U: cold updates of step u with the walker's (old, new), the leaving rows' records back to their rows ----
-    const int uw = wv - CS_NWS;
+    // Two pairs of wavefronts take the steps in turn (pair u & 1 does step u, each of its two wavefronts half of the range's entries and
+    // leaving rows); list offsets are requested one own step ahead, so that the entries' loads do not wait for them.
+    const int uw = wv - CS_NWS, up = uw >> 1, ui = uw & 1;
     const bool pf = g.prof != nullptr && lane == 0 && uw == 0 && (b == 0 || g.trace != nullptr);
     unsigned long long t_wait = 0, t_work = 0;
-    for (int u = 0; u < ns; u++) {
-      const int lo = g.cold_ptr[(size_t)u * NB + b], hi = g.cold_ptr[(size_t)u * NB + b + 1];
-      constexpr int T = 2;
+    int lo_n = 0, hi_n = 0, x0_n = 0, xlo_n = 0, xhi_n = 0;
+    auto prefetch_static = [&](int u) {
+      lo_n = hi_n = x0_n = xlo_n = xhi_n = 0;
+      if (u < ns) {
+        lo_n = g.cold_ptr[(size_t)u * NB + b];
+        hi_n = g.cold_ptr[(size_t)u * NB + b + 1];
+        x0_n = g.exit_ptr[(size_t)u * NB];
+        xlo_n = g.exit_ptr[(size_t)u * NB + b];
+        xhi_n = g.exit_ptr[(size_t)u * NB + b + 1];
+      }
+    };
+    prefetch_static(up);
+    for (int u = up; u < ns; u += 2) {
+      const int lo = lo_n, hi = hi_n, x0 = x0_n, x_lo = xlo_n, x_hi = xhi_n;
+      prefetch_static(u + 2);
+      constexpr int T = 3;
       int rc[T];
       double xv[T];
 #pragma unroll
       for (int t = 0; t < T; t++) {
-        const int p = lo + (t * 4 + uw) * WAVE + lane;
+        const int p = lo + (t * 2 + ui) * WAVE + lane;
         rc[t] = -1;
         xv[t] = 0.0;
         if (p < hi) {
@@ -746,10 +807,9 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
           xv[t] = g.cold_x[p];
         }
       }
-      const int x0 = g.exit_ptr[(size_t)u * NB], x_lo = g.exit_ptr[(size_t)u * NB + b], x_hi = g.exit_ptr[(size_t)u * NB + b + 1];
       int ex_row = -1;
       {
-        const int x = x_lo + uw * WAVE + lane;
+        const int x = x_lo + ui * WAVE + lane;
         if (x < x_hi) ex_row = g.exit_row[x];
       }
       unsigned long long t0 = 0, t1 = 0;
@@ -768,7 +828,7 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
       const double2 *src = g.out_ring + (size_t)(u % R) * max(g.max_exit, 1) * 2;
       double2 xr0 = make_double2(0.0, 0.0), xr2 = xr0;
       if (ex_row >= 0) {
-        const int x = x_lo + uw * WAVE + lane;
+        const int x = x_lo + ui * WAVE + lane;
         xr0 = cs_ld2(src + (size_t)(x - x0) * 2);
         xr2 = cs_ld2(src + (size_t)(x - x0) * 2 + 1);
       }
@@ -783,13 +843,13 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
 #pragma unroll
       for (int t = 0; t < T; t++)
         if (rc[t] >= 0) P::apply(a, rc[t] & ((1 << CS_LCOL_SHIFT) - 1), xv[t], st_[t], o_[t].x, o_[t].y);
-      for (int p = lo + (T * 4 + uw) * WAVE + lane; p < hi; p += 4 * WAVE) upd(g.cold_rc[p], g.cold_x[p]);
+      for (int p = lo + (T * 2 + ui) * WAVE + lane; p < hi; p += 2 * WAVE) upd(g.cold_rc[p], g.cold_x[p]);
       if (ex_row >= 0) {
         double2 *rec = (double2 *)a.state + (int64_t)ex_row * rec2_global;
         rec[0] = xr0;
         rec[2] = xr2;
       }
-      for (int x = x_lo + (4 + uw) * WAVE + lane; x < x_hi; x += 4 * WAVE) {  // (beyond the first: rare)
+      for (int x = x_lo + (2 + ui) * WAVE + lane; x < x_hi; x += 2 * WAVE) {  // (beyond the first: rare)
         const int row = g.exit_row[x];
         const double2 r0 = cs_ld2(src + (size_t)(x - x0) * 2), r2 = cs_ld2(src + (size_t)(x - x0) * 2 + 1);
         double2 *rec = (double2 *)a.state + (int64_t)row * rec2_global;

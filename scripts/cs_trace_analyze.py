@@ -24,19 +24,27 @@ for s in range(s0, min(ns, s0 + n)):
     print("%4d | %7.2f %7.2f %7.2f | %7.2f %7.2f | %7.2f %7.2f %7.2f | %7.2f..%7.2f %7.2f..%7.2f | %7.2f..%7.2f %7.2f..%7.2f" % (
         s, *(T[0, s] - base), *(T[1, s, 1:] - base), *(T[2, s] - base), U[:, 1].min() - base, U[:, 1].max() - base, U[:, 2].min() - base,
         U[:, 2].max() - base, S[:, 1].min() - base, S[:, 1].max() - base, S[:, 2].min() - base, S[:, 2].max() - base))
-# steady state: mean period, and mean lags along the loop walker(s - Lw) end -> X -> U -> S(s) -> Y(s) -> walker(s)
+# steady state (the helpers' stamps exist for EVEN steps only: wavefront pairs take the steps in turn, the first of each pair stamps)
 ss = np.arange(max(Lw + 2, ns // 4), ns - 2)
 per = np.diff(T[0, ss, 1]).mean()
-print("mean period %.2f us/step; walker busy %.2f" % (per, (T[0, ss, 2] - T[0, ss, 1]).mean()))
-wl_end = T[0, ss - Lw, 2]
-x_end = T[1, ss - Lw, 2]
-u_end = T[3:3 + NB, :, 2][:, ss - Lw].max(axis=0)
-u_aw = T[3:3 + NB, :, 1][:, ss - Lw].max(axis=0)
-s_aw = T[3 + NB:, :, 1][:, ss].max(axis=0)
-s_end = T[3 + NB:, :, 2][:, ss].max(axis=0)
-y_g, y_end = T[2, ss, 1], T[2, ss, 2]
-w_start = T[0, ss, 1]
-print("loop (means, us): walker(s-Lw) end -> X end %.2f -> U wake (max over ranges) %.2f -> U end (max) %.2f -> S wake (max) %.2f -> S end (max) %.2f -> Y gated %.2f "
-      "-> Y end %.2f -> walker(s) start %.2f" % ((x_end - wl_end).mean(), (u_aw - x_end).mean(), (u_end - u_aw).mean(), (s_aw - u_end).mean(),
-                                                   (s_end - s_aw).mean(), (y_g - s_end).mean(), (y_end - y_g).mean(), (w_start - y_end).mean()))
-print("slack of S(s): S end (max) - walker(s) start: %.2f; Y(s) begin - walker(s-RD) end: %.2f" % ((s_end - w_start).mean(), (T[2, ss, 0] - T[0, ss - RD, 2]).mean()))
+print("mean period %.2f us/step; walker busy %.2f, waits %.2f" % (per, (T[0, ss, 2] - T[0, ss, 1]).mean(), (T[0, ss, 1] - T[0, ss, 0]).mean()))
+ev = ss[(ss % 2 == 0) & ((ss - Lw) % 2 == 0)] if Lw % 2 == 0 else None
+def lag(name, a, b):
+    print("  %-46s %6.2f" % (name, (b - a).mean()))
+se = ss[ss % 2 == 0]
+print("chain of an even step s (means, us):")
+lag("walker(s) end -> X(s) sees it", T[0, se, 2], T[1, se, 1])
+lag("X(s): reads, stores, drain, publish", T[1, se, 1], T[1, se, 2])
+lag("X(s) end -> U(s) wakes (max over ranges)", T[1, se, 2], T[3:3 + NB, :, 1][:, se].max(axis=0))
+lag("U(s) wake -> end (max over ranges)", T[3:3 + NB, :, 1][:, se].max(axis=0), T[3:3 + NB, :, 2][:, se].max(axis=0))
+if Lw % 2 == 0:
+    sl = se[se + Lw < ns]
+    lag("U(s) end (max) -> S(s + Lw) wakes (max)", T[3:3 + NB, :, 2][:, sl].max(axis=0), T[3 + NB:, :, 1][:, sl + Lw].max(axis=0))
+lag("S(s) wake -> end (max over ranges)", T[3 + NB:, :, 1][:, se].max(axis=0), T[3 + NB:, :, 2][:, se].max(axis=0))
+lag("S(s) end (max) -> Y(s) has its data", T[3 + NB:, :, 2][:, se].max(axis=0), T[2, se, 1])
+lag("Y(s) data -> staged", T[2, se, 1], T[2, se, 2])
+lag("Y(s) staged -> walker(s) starts", T[2, se, 2], T[0, se, 1])
+lag("walker(s - 1) end -> walker(s) starts", T[0, se - 1, 2], T[0, se, 1])
+lag("S(s) begin -> wake (waits for U)", T[3 + NB:, :, 0][:, se].max(axis=0), T[3 + NB:, :, 1][:, se].max(axis=0))
+lag("U(s) begin -> wake (waits for X)", T[3:3 + NB, :, 0][:, se].max(axis=0), T[3:3 + NB, :, 1][:, se].max(axis=0))
+lag("Y(s) begin -> data (waits)", T[2, se, 0], T[2, se, 1])

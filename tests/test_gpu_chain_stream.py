@@ -55,7 +55,7 @@ def _chain(oracle, capi, design, rank=3, iters=2):
     return t, c
 
 
-@pytest.mark.parametrize("cg,lw,nb,cap", [(4, 3, 16, 0), (4, 4, 16, 0), (2, 5, 8, 0), (1, 6, 4, 0), (4, 2, 32, 0), (3, 1, 5, 0), (4, 3, 16, 700), (2, 5, 16, 0), (4, 5, 8, 0), (2, 3, 8, 0), (2, 6, 32, 0), (1, 7, 16, 0)])
+@pytest.mark.parametrize("cg,lw,nb,cap", [(4, 3, 16, 0), (4, 4, 16, 0), (2, 5, 8, 0), (1, 6, 4, 0), (4, 2, 32, 0), (3, 2, 5, 0), (4, 3, 16, 700), (2, 5, 16, 0), (4, 5, 8, 0), (2, 3, 8, 0), (2, 6, 32, 0), (1, 7, 16, 0)])
 def test_streamed_chain_matches_oracle(oracle, capi, monkeypatch, cg, lw, nb, cap):
     monkeypatch.setenv("MFM_CHAIN_GRID_MIN", "0")  # (the test's blocks are small: their cold parts would not go to the grid otherwise)
     monkeypatch.setenv("MFM_NO_CELL", "1")         # the generic relation-block path (the cell path has its own tests)
