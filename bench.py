@@ -44,7 +44,7 @@ def b_iter_bytes(N, nnz, D, K):
 
 def workload(cfg, a):
     """-> dict(X, blocks [(map, csr)], y, shapes, rank, task, name)"""
-    from tests import datasets as ds
+    from myfm_amd.utils import synthetic as ds
 
     if cfg == 3:
         X, y, shapes = ds.movielens_like(a.rows, a.users, a.items, rank_true=32, seed=1)
@@ -94,6 +94,19 @@ def cpu_baseline(W, gi, min_seconds, max_iters):
     if r.returncode != 0:
         return {"error": (r.stderr or r.stdout)[-400:]}
     return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def replica_digest(sess):
+    """64-bit digest of everything a rank's replica of the chain holds (w0, w, V, every hyper-parameter): replicas are compared
+    bit for bit, not through a sum that could hide a swapped pair of coefficients."""
+    import hashlib
+
+    fm, hy = sess.fm, sess.hyper
+    h = hashlib.blake2b(digest_size=8)
+    for arr in (np.float64(fm.w0), np.asarray(fm.w), np.asarray(fm.V), np.float64(hy.alpha), np.asarray(hy.mu_w), np.asarray(hy.lambda_w),
+                np.asarray(hy.mu_V), np.asarray(hy.lambda_V)):
+        h.update(np.ascontiguousarray(arr, dtype=np.float64).tobytes())
+    return int.from_bytes(h.digest(), "little")
 
 
 def self_launch(n_gpus):
@@ -168,6 +181,8 @@ def main():
     ap.add_argument("--weak-steps", type=int, default=20, help="N > 1: timed iterations of the weak-scaling leg (0 disables)")
     ap.add_argument("--long-seconds", type=float, default=2.0, help="when the timed region is shorter than 1 s: also time the same loop "
                     "for about this long and report it as value_long (0 disables)")
+    ap.add_argument("--peer-exchange", action="store_true", help="N > 1, config 3: the persistent sweep row-sharded with the ranks' item sums "
+                    "exchanged inside the launch (never run on two physical GPUs yet: opt-in; a trial of three iterations decides)")
     ap.add_argument("--no-other-configs", action="store_true", help="default run (config 3, 1 GPU): skip the other_configs legs")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -218,7 +233,7 @@ def main():
 
         _g.build()
     from myfm_amd import _capi, _myfm
-    from tests import datasets as ds
+    from myfm_amd.utils import synthetic as ds
 
     t0 = time.time()
     W = workload(a.config, a)
@@ -279,28 +294,36 @@ def main():
         sess, how = make_session()
         # The persistent sweep row-sharded: every rank keeps the residual of its rows on chip, the ranks' item sums
         # meet INSIDE the launch through IPC-mapped exchange buffers (no collective between the sweeps of an iteration). It has
-        # been tested with ranks side by side on ONE GPU only, so a trial iteration decides here: a rank that times out, or
-        # replicas that differ, send every rank back to the per-factor passes on a fresh session. MYFM_BENCH_NO_PEER_EXCHANGE=1: off.
+        # only ever run with the ranks side by side on ONE GPU (one L2, no xGMI), so it is OPT-IN here as in distributed.enable():
+        # --peer-exchange / MYFM_BENCH_PEER_EXCHANGE=1. Even then a trial decides: three iterations, after each of which every rank's
+        # 64-bit digest of (w0, w, V, every hyper-parameter) must be the same; a rank that times out, or replicas that differ, send
+        # every rank back to the per-factor passes (RCCL all-reduce per level) on a fresh session.
         peer_live = False
-        if not blocks and not os.environ.get("MYFM_BENCH_NO_PEER_EXCHANGE"):
+        want_peer = a.peer_exchange or os.environ.get("MYFM_BENCH_PEER_EXCHANGE", "") not in ("", "0")
+        if not blocks and want_peer and not os.environ.get("MYFM_BENCH_NO_PEER_EXCHANGE"):
             peer_live = mdist.connect_peers(sess)
             if peer_live:
-                good, chk = 1.0, 0.0
-                try:
-                    # (ONE iteration = 33 sweeps with an exchange each, then the stream is checked: a rank whose launch timed out
-                    #  raises here, after it has issued the same collectives as everybody else -- a second iteration could leave
-                    #  the others waiting in a collective the failed rank never enters)
-                    sess.step()
-                    sess.synchronize()
-                    chk = float(np.abs(np.asarray(sess.fm.V)).sum())
-                    good = 1.0 if np.isfinite(chk) else 0.0
-                except Exception as ex:  # noqa: BLE001 -- every rank takes part in the agreement below
-                    print("bench.py rank %d: row-sharded persistent sweep failed its trial (%s: %s)" % (rank, type(ex).__name__, ex),
-                          file=sys.stderr)
-                    good = 0.0
-                t = torch.tensor([good, chk, -chk], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                if float(t[0]) < 1.0 or float(t[1]) != -float(t[2]):
+                good = 1.0
+                for _trial in range(3):
+                    dig = 0
+                    try:
+                        # (after every iteration the stream is checked: a rank whose launch timed out raises here, after it has
+                        #  issued the same collectives as everybody else)
+                        sess.step()
+                        sess.synchronize()
+                        dig = replica_digest(sess)
+                    except Exception as ex:  # noqa: BLE001 -- every rank takes part in the agreement below
+                        print("bench.py rank %d: row-sharded persistent sweep failed its trial (%s: %s)" % (rank, type(ex).__name__, ex),
+                              file=sys.stderr)
+                        good = 0.0
+                    # (the digest as two 32-bit halves: exact in float64)
+                    t = torch.tensor([good, float(dig >> 32), -float(dig >> 32), float(dig & 0xFFFFFFFF), -float(dig & 0xFFFFFFFF)],
+                                     dtype=torch.float64, device="cuda")
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                    if float(t[0]) < 1.0 or float(t[1]) != -float(t[2]) or float(t[3]) != -float(t[4]):
+                        good = 0.0
+                        break
+                if good < 1.0:
                     peer_live = False
                     sess = None
                     import gc
@@ -347,7 +370,7 @@ def main():
         sess.timing_select(dom_name)
         sess.timing_enable(True)
         sess.timing_reset()
-    calls0 = sess.comm_stats()[0] if sharded else 0
+    calls0, doubles0 = (sess.comm_stats()[0], sess.comm_stats()[1]) if sharded else (0, 0)
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -363,6 +386,14 @@ def main():
         sess.timing_enable(False)
         sess.timing_select("")
     calls = (sess.comm_stats()[0] - calls0) if sharded else 0
+    doubles = (sess.comm_stats()[1] - doubles0) if sharded else 0
+    per_rank = None
+    if dist is not None and world > 1:  # every rank's own collective count and volume (a first multi-GPU run must be readable)
+        mine = torch.tensor([float(rank), float(hi - lo), calls / a.steps, 8.0 * doubles / a.steps], dtype=torch.float64, device="cuda")
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": int(v[0]), "rows": int(v[1]), "allreduce_calls_per_step": round(float(v[2]), 1),
+                     "allreduce_bytes_per_step": round(float(v[3]))} for v in allr]
     # a short timed region (the driver's 20 steps at config 3 are 65 ms) gets an in-line cross-check: the same loop for >= 2 s
     long_run = None
     if world == 1 and elapsed < 1.0 and a.long_seconds > 0:
@@ -379,18 +410,17 @@ def main():
     alpha = sess.hyper.alpha
     assert np.isfinite(alpha) and alpha > 0, alpha
     if dist is not None and world > 1:
-        fm = sess.fm
-        mine = torch.tensor([float(fm.w0), float(alpha), float(np.abs(np.asarray(fm.V)).sum()), float(np.asarray(fm.w).sum())],
-                            dtype=torch.float64, device="cuda")
+        dig = replica_digest(sess)
+        mine = torch.tensor([float(dig >> 32), float(dig & 0xFFFFFFFF)], dtype=torch.float64, device="cuda")
         allv = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
         for v in allv[1:]:
-            assert torch.allclose(v, allv[0], rtol=1e-12, atol=0), ("replicas diverged", [x.tolist() for x in allv])
+            assert torch.equal(v, allv[0]), ("replicas diverged (64-bit digests of w0, w, V and the hyper-parameters)", [x.tolist() for x in allv])
 
     plan_flags = int(sess.plan_flags())
     rccl_ranks, rccl_path = sess.comm_info() if sharded else (0, "")
     # Weak-scaling leg (N > 1, config 3): the table grows with the GPUs -- rank r holds ~a.rows rows of ONE user-sorted table of
-    # world * a.rows rows over the same users / items (tests/datasets.py::movielens_like_shard). Reported as an extra field;
+    # world * a.rows rows over the same users / items (myfm_amd/utils/synthetic.py::movielens_like_shard). Reported as an extra field;
     # `value` stays the strong-scaling rate of config 3 itself.
     weak = None
     if sharded and a.config == 3 and a.weak_steps > 0 and not blocks:
@@ -591,6 +621,8 @@ def main():
         out["other_configs"] = other_configs(budget_s=100.0)
     if sharded:
         out["config"]["allreduce_calls_per_step"] = round(calls / a.steps, 1)
+        out["config"]["allreduce_bytes_per_step"] = round(8.0 * doubles / a.steps)
+        out["config"]["per_rank"] = per_rank  # [{rank, rows, allreduce_calls_per_step, allreduce_bytes_per_step}]: every rank's own count
         out["config"]["rows_this_rank"] = hi - lo
         # evidence that the collective spans the ranks: ncclCommCount of the communicator libmyfm_hip.so opened itself, and the
         # librccl it bound (0 / "": the torch.distributed callback carried the all-reduces instead, see `parallelism`)

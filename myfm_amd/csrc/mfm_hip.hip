@@ -4,9 +4,11 @@
 // level schedule), launches the kernels of mfm_kernels.hpp / mfm_block_kernels.hpp on one HIP
 // stream and exposes them as the entry points the pybind11 host layer (csrc/_myfm.cpp) binds.
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -16,6 +18,7 @@
 
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <hipcub/hipcub.hpp>
@@ -76,15 +79,25 @@ struct ResidentBudget {
     if (d.lock_fd < 0 && !std::getenv("MFM_RES_NO_PROCESS_LOCK")) {
       const char *dir = std::getenv("MFM_LOCK_DIR");
       const std::string path = std::string(dir && *dir ? dir : "/tmp") + "/myfm_amd_resident_" + k + ".lock";
-      const int fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-      if (fd >= 0) {
-        if (::flock(fd, LOCK_EX | LOCK_NB) != 0) {
-          ::close(fd);
-          why = "another process runs a persistent sweep on this GPU (" + path + ")";
-          return false;
-        }
-        d.lock_fd = fd;
-      }  // (no writable lock directory: in-process accounting only)
+      // The file is shared by every user of the machine: never follow a planted link (O_NOFOLLOW), make it 0666 whatever the
+      // creator's umask was, and if it belongs to somebody else and cannot be opened for writing, open it read-only -- flock
+      // works on a read-only descriptor. No descriptor at all: exclusivity cannot be established, so the persistent sweep is
+      // refused (the per-factor passes assume nothing); MFM_RES_NO_PROCESS_LOCK=1 is the explicit way to do without the lock.
+      int fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
+      if (fd >= 0)
+        (void)::fchmod(fd, 0666);
+      else if (errno == EACCES || errno == EPERM || errno == EROFS)
+        fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC | O_NOFOLLOW);
+      if (fd < 0) {
+        why = "the lock file of this GPU's persistent sweeps cannot be opened (" + path + ": " + std::strerror(errno) + ")";
+        return false;
+      }
+      if (::flock(fd, LOCK_EX | LOCK_NB) != 0) {
+        ::close(fd);
+        why = "another process runs a persistent sweep on this GPU (" + path + ")";
+        return false;
+      }
+      d.lock_fd = fd;
     }
     d.claimed += want;
     return true;
@@ -171,6 +184,10 @@ struct mfm_ctx {
   // regression: outside the sweeps the residual IS score - y (update_e recomputes it after every update_V, FMTrainer.hpp:494), so
   // the persistent launch need not write its copy back (mfm_set_residual_policy); whoever asks for it in between gets it recomputed
   bool e_recomputable = false, e_lost = false;
+  // the residual is (score of the current model) - y, maintained by the sweeps: true after score_train(subtract_y), false once the
+  // caller has installed his own residual (mfm_set_e, mfm_shift_e, the latent draws of classification / ordered probit). Only
+  // such a residual may be dropped by the sweep and recomputed on demand.
+  bool e_is_residual = false;
   bool res_sharded_pending = false;  // row-sharded: the persistent sweep's layout is built on every rank, waiting for mfm_peer_set
   bool main_lazy = false;
   bool res_refused = false;  // the CUs of the persistent sweep were not ours to take
@@ -536,6 +553,7 @@ static void materialize_e(mfm_ctx *c) {
 
 static void score_train(mfm_ctx *c, bool subtract_y) {
   c->e_lost = false;
+  c->e_is_residual = subtract_y;
   c->e_in_slots = false;  // (every residual is overwritten)
   c->e_in_cell = false;
   c->slot_sums_valid = false;
@@ -1503,6 +1521,13 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
       mine = c->res.ready;
       c->res.ready = false;
     }
+    if (mine) {  // the exchange buffers BEFORE the ranks agree: a rank that gets no uncached memory votes against the layout
+      try {
+        c->res.alloc_exchange(c->comm.world, c->comm.rank, c->stream);
+      } catch (const Error &) {
+        mine = false;
+      }
+    }
     double bad = mine ? 0.0 : 1.0;
     {
       DevBuf<double> d;
@@ -1512,7 +1537,6 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
       MFM_HIP_CHECK(hipMemcpy(&bad, d.p, sizeof(double), hipMemcpyDeviceToHost));
     }
     if (bad == 0.0) {
-      c->res.alloc_exchange(c->comm.world, c->comm.rank, c->stream);
       c->res_sharded_pending = true;
     } else {
       c->drop_resident();
@@ -1643,8 +1667,18 @@ int mfm_peer_import(mfm_ctx *ctx, int32_t world, int32_t rank, const void *all_h
   }
   int rc = mfm_peer_set(ctx, world, rank, sums, flags);
   if (rc != MFM_OK) return rc;
-  rc = mfm_peer_set_model(ctx, world, rank, ws, Vs);
-  if (rc != MFM_OK) return rc;
+  // The peers' w / V (first-level coefficients written into every replica where they are drawn, no model all-reduce after the
+  // launch) only on request, MYFM_PEER_MODEL=1: w and V are ordinary cached device memory which this GPU's later kernels read
+  // through its L2 -- that a peer's write over xGMI is seen there rests on the L2 not holding the line (no kernel of an
+  // iteration reads a first-level coefficient between its draw and the next launch ... on ONE GPU, where this was tested). Until
+  // it has run on two GPUs the default keeps the model all-reduce after the launch (sync_model_sharded): the only memory another
+  // GPU writes is then the exchange buffers, which are uncached (MYFM_PEER_MODEL=0 / 1 also separates "exchange wrong" from "model
+  // write wrong" on a first real run).
+  const char *pm = std::getenv("MYFM_PEER_MODEL");
+  if (pm && std::atoi(pm) != 0) {
+    rc = mfm_peer_set_model(ctx, world, rank, ws, Vs);
+    if (rc != MFM_OK) return rc;
+  }
   MFM_CATCH(ctx)
 }
 
@@ -1714,8 +1748,12 @@ int mfm_get_state(mfm_ctx *ctx, double *w0, double *w, double *V) {
 }
 
 int mfm_set_w0(mfm_ctx *ctx, double w0) {
+  MFM_TRY(ctx)
+  // a residual the sweep dropped is recomputed from the model AND this intercept: materialise it first with the intercept it
+  // belongs to (a following mfm_shift_e would otherwise count the change twice)
+  if (ctx->e_lost && w0 != ctx->w0) ensure_e(ctx);
   ctx->w0 = w0;
-  return MFM_OK;
+  MFM_CATCH(ctx)
 }
 
 int mfm_zero_w(mfm_ctx *ctx) {
@@ -1761,6 +1799,7 @@ int mfm_set_e(mfm_ctx *ctx, const double *e) {
   MFM_TRY(ctx)
   ctx->need_final();
   ctx->e_lost = false;  // (every residual is overwritten)
+  ctx->e_is_residual = false;  // (the caller's own numbers: never dropped and recomputed)
   materialize_e(ctx);
   if (ctx->N) {
     MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1797,6 +1836,7 @@ int mfm_shift_e(mfm_ctx *ctx, double delta) {
   MFM_TRY(ctx)
   ctx->need_final();
   materialize_e(ctx);
+  ctx->e_is_residual = false;  // (shifted by hand: no longer score - y of the stored model and intercept)
   if (ctx->N) {
     TimedLaunch t(ctx->timing, ctx->stream, KC_SHIFT_E, 16.0 * ctx->N);
     hipLaunchKernelGGL(k_shift_e, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq.p, ctx->N, delta);
@@ -2013,7 +2053,8 @@ int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambd
   }
   const bool lazy_store = !std::getenv("MFM_RES_EAGER_STORE");
   // (regression, all factors swept: update_e follows and recomputes the residual -- the launch's copy would be a dead store, 64 us)
-  const bool no_store = c->e_recomputable && lazy_store && f_begin == 0 && f_end == c->K && !std::getenv("MFM_RES_ALWAYS_STORE");
+  const bool no_store =
+      c->e_recomputable && c->e_is_residual && lazy_store && f_begin == 0 && f_end == c->K && !std::getenv("MFM_RES_ALWAYS_STORE");
   run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq.p, c->V.p, c->D, f_begin, f_end, zbase, d_lam, d_mu,
                      c->group.p, c->G, alpha, c->ls.error.p, lazy_store, c->w.p, zwdev, d_lam_w, d_mu_w, e_shift, load_slots, no_store);
   c->e_in_slots = lazy_store && !no_store;

@@ -623,8 +623,13 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
         if (tid == 0 && !dead) {
           const unsigned long long old = __hip_atomic_fetch_add(a.xarrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (old + 1 == (unsigned long long)a.n_wg * E) {  // every workgroup of this rank has published: tell the peers
+            // Ordering. Every workgroup's sums were written with system-scope (sc0 sc1: write-through, no line kept in any L2)
+            // stores into uncached memory and acknowledged (s_waitcnt vmcnt(0)) before its arrival above; this thread has seen all
+            // arrivals. The flag itself is a system-scope RELEASE store (one per rank and sweep: buffer_wbl2 sc0 sc1 + the store),
+            // so that the hand-over is a release / acquire pair in the memory model as well; the readers poll relaxed and read
+            // the sums with system-scope loads, which bypass the non-coherent caches (no acquire fence: it would drop the XCD's L2).
             for (int r = 0; r < a.xworld && !(a.dbg & 8192); r++)  // (8192: a test of the time-out path -- the flags stay down)
-              __hip_atomic_store(a.xflag[r] + 16 * a.xrank, E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store(a.xflag[r] + 16 * a.xrank, E, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
           }
           for (int r = 0; r < a.xworld && !dead; r++) res_spin_sys(a, a.xflag[a.xrank] + 16 * r, E, dead);
         }
@@ -951,15 +956,16 @@ struct ResPlan {
     peers_set = false;
     peers_model = false;
     xepoch = 0;
-    // (what other GPUs write and this one reads inside a running kernel: uncached device memory, coherent for every agent --
-    //  plain device memory if the runtime refuses the flag)
+    // (what other GPUs write and this one reads inside a running kernel: uncached device memory, coherent for every agent. No
+    //  fall-back to ordinary cached memory: a stale line in this GPU's L2 would be read as a peer's sum. A refusal throws, the
+    //  layout is not taken and every rank runs the per-factor passes.)
     auto alloc_shared = [&](auto &buf, size_t count) {
       buf.release();
       void *p = nullptr;
       const size_t bytes = count * sizeof(*buf.p);
       if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
         (void)hipGetLastError();
-        MFM_HIP_CHECK(hipMalloc(&p, bytes));
+        throw Error(MFM_ERR_DEVICE, "no uncached device memory for the ranks' exchange buffers (hipExtMallocWithFlags(hipDeviceMallocUncached))");
       }
       buf.p = (decltype(buf.p))p;
       buf.n = count;

@@ -173,7 +173,11 @@ __global__ __launch_bounds__(WG) void k_oprobit_eval(const double2 *__restrict__
     f_hi = has_hi ? f_hi : 0.0;
     f_lo = has_lo ? f_lo : 0.0;
     const double pa = f_hi * Ex, pb = f_lo * Ey;
-    const double den = cC ? 2.0 - (pa + pb) : (cA ? pb - pa : pa - pb);
+    double den = cC ? 2.0 - (pa + pb) : (cA ? pb - pa : pa - pb);
+    // A narrow interval around the score (yv <= 0 <= x, both small): 2 - (gE(x) + gE(yv)) cancels to an absolute error of ~1e-16,
+    // i.e. a RELATIVE error of 1e-16 / den in ll, the gradient and (squared) the Hessian. There the reference's own form
+    // erf(x / sqrt 2) - erf(yv / sqrt 2) (OProbitSampler.hpp:185-196) keeps full relative accuracy.
+    if (cC && has_hi && has_lo && fmax(fabs(x), fabs(yv)) < 0.5) den = erf(x / SQRT2) - erf(yv / SQRT2);
     const double id = 1.0 / den, w = INV_PI * id * id;
     double ll = cA ? -hy : (cB ? -hx : 0.0);
     ll += log(den / 2);

@@ -1,6 +1,6 @@
 import time, numpy as np, sys
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from tests import datasets as ds
+from myfm_amd.utils import synthetic as ds
 import myfm_amd
 X, y, shapes = ds.movielens_like(10_000_000, 69878, 10677)
 n_test = 1_000_000

@@ -9,7 +9,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import myfm_amd  # noqa: E402
-from tests import datasets as ds  # noqa: E402
+from myfm_amd.utils import synthetic as ds  # noqa: E402
 
 X, y, shapes = ds.movielens_like(10_000_000, 69878, 10677, rank_true=32, seed=1)
 Xt = X[np.sort(np.random.default_rng(0).choice(X.shape[0], size=1_000_000, replace=False))]

@@ -4,7 +4,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from myfm_amd import _myfm
-from tests import datasets as ds
+from myfm_amd.utils import synthetic as ds
 
 for world in (2, 4, 8):
     X, y, shapes, lo, total = ds.movielens_like_shard(10_000_000, world // 2, world, 69878, 10677)

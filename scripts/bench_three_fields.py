@@ -4,7 +4,7 @@ import numpy as np
 import scipy.sparse as sps
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from myfm_amd import _myfm
-from tests import datasets as ds
+from myfm_amd.utils import synthetic as ds
 
 N, nu, ni, nc = 10_000_000, 69878, 10677, 1000
 X, y, shapes = ds.movielens_like(N, nu, ni, rank_true=32, seed=1)

@@ -9,7 +9,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from myfm_amd import _capi
-from tests import datasets as ds
+from myfm_amd.utils import synthetic as ds
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=10_000_000)

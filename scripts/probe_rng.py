@@ -3,7 +3,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from myfm_amd import _capi
-from tests import datasets as ds
+from myfm_amd.utils import synthetic as ds
 
 X, y, shapes = ds.onehot_mf(100000, 69878, 10677, seed=1)
 K, D = 32, X.shape[1]

@@ -1,7 +1,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from tests import datasets as ds
+from myfm_amd.utils import synthetic as ds
 import myfm_amd
 X, y, shapes = ds.movielens_like(10_000_000, 69878, 10677)
 task = sys.argv[1] if len(sys.argv) > 1 else "classification"

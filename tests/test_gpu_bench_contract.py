@@ -55,6 +55,10 @@ def test_bench_starts_its_own_ranks():
     assert c["torch_world_size"] == 2 and c["allreduce_calls_per_step"] > 0 and c["rows_this_rank"] < c["rows"]
     assert c["rccl_ranks"] == 0 and c["rccl_path"] == ""  # (gloo carried the collectives here; on N GPUs: rccl_ranks == N)
     assert d["weak_scaling"]["it_per_s"] > 0
+    # the in-launch exchange is opt-in (--peer-exchange); every rank's own collective count and volume are in the line
+    assert c["peer_exchange"] is False
+    assert [r["rank"] for r in c["per_rank"]] == [0, 1] and all(r["allreduce_calls_per_step"] > 0 and r["allreduce_bytes_per_step"] > 0 for r in c["per_rank"])
+    assert sum(r["rows"] for r in c["per_rank"]) == c["rows"]
 
 
 def test_bench_two_ranks_persistent_sweep_with_in_launch_exchange():
@@ -63,8 +67,8 @@ def test_bench_two_ranks_persistent_sweep_with_in_launch_exchange():
     collectives per step are the per-iteration ones only."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(MYFM_BENCH_BACKEND="gloo", MYFM_BENCH_DEVICE="0", MFM_RES_NO_PROCESS_LOCK="1", MFM_RES_CUS="100", MFM_RES_MIN_ROWS="0")
-    d = _run("--gpus", "2", "--rows", "300000", "--users", "3000", "--items", "2000", "--steps", "3", "--warmup", "1", "--weak-steps", "2",
-             env=env)
+    d = _run("--gpus", "2", "--peer-exchange", "--rows", "300000", "--users", "3000", "--items", "2000", "--steps", "3", "--warmup", "1",
+             "--weak-steps", "2", env=env)
     c = d["config"]
     assert d["n_gpus"] == 2 and d["value"] > 0 and c["peer_exchange"] is True, c
     assert c["plan_flags"] & 256 and c["plan_flags"] & 8
@@ -73,13 +77,13 @@ def test_bench_two_ranks_persistent_sweep_with_in_launch_exchange():
 
 
 def test_bench_two_ranks_fall_back_when_the_exchange_fails_its_trial():
-    """The same run with rank 1's flags held down (MFM_RES_XCH_BREAK): the persistent launches time out inside the trial iteration,
+    """The same run with rank 1's flags held down (MFM_RES_XCH_BREAK): the persistent launches time out inside the trial iterations,
     every rank agrees to drop the path, and the line comes from fresh sessions on the per-factor passes."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(MYFM_BENCH_BACKEND="gloo", MYFM_BENCH_DEVICE="0", MFM_RES_NO_PROCESS_LOCK="1", MFM_RES_CUS="100", MFM_RES_MIN_ROWS="0",
                MFM_RES_XCH_BREAK="1")
-    d = _run("--gpus", "2", "--rows", "300000", "--users", "3000", "--items", "2000", "--steps", "3", "--warmup", "1", "--weak-steps", "0",
-             env=env)
+    d = _run("--gpus", "2", "--peer-exchange", "--rows", "300000", "--users", "3000", "--items", "2000", "--steps", "3", "--warmup", "1",
+             "--weak-steps", "0", env=env)
     c = d["config"]
     assert d["n_gpus"] == 2 and d["value"] > 0 and c["peer_exchange"] is False, c
     assert not (c["plan_flags"] & 256) and c["allreduce_calls_per_step"] > 6

@@ -309,7 +309,8 @@ def test_two_processes_one_gpu_sharded_fit():
     assert r.returncode == 0 and "mp_fit_worker ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
-def test_two_processes_one_gpu_persistent_sweep():
+@pytest.mark.parametrize("peer_model", ["0", "1"])
+def test_two_processes_one_gpu_persistent_sweep(peer_model):
     # the row-sharded persistent sweep with its ranks in two PROCESSES (one GPU: both on device 0, each with a share of the CUs):
     # IPC handles of the exchange buffers over torch.distributed, the launches of the two processes side by side, item sums
     # exchanged inside the launch; oracle chain on every rank, replicas bit-identical (tests/mp_peer_worker.py)
@@ -320,8 +321,10 @@ def test_two_processes_one_gpu_persistent_sweep():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29643", os.path.join(root, "tests", "mp_peer_worker.py")]
+    # MYFM_PEER_MODEL=0 (the default): the ranks' item sums meet inside the launch, the first-level coefficients are made equal by the
+    # model all-reduce after it; =1: a coefficient is also written into every replica where it is drawn (no model all-reduce)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MFM_RES_NO_PROCESS_LOCK="1", MFM_RES_CUS="100", MFM_RES_MIN_ROWS="0",
-               MFM_SCATTER_MIN_NNZ="1000")
+               MFM_SCATTER_MIN_NNZ="1000", MYFM_PEER_MODEL=peer_model)
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "mp_peer_worker ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
