@@ -116,6 +116,10 @@ struct ResidentBudget {
 };
 }  // namespace mfm
 
+struct mfm_ctx;
+namespace mfm {
+static void materialize_e(::mfm_ctx *c);  // (brings the residual back to row order: mfm_ctx::eq_rows)
+}
 using namespace mfm;
 
 struct mfm_ctx {
@@ -155,7 +159,17 @@ struct mfm_ctx {
   int64_t row_offset = 0;  // global index of local row 0 (keys the per-row Philox streams)
   std::vector<std::unique_ptr<DevBlock>> blocks;
   DevBuf<double> y;
-  DevBuf<double2> eq;
+  // {e_t, q_t} in ROW order. Between the sweeps the residual may live elsewhere -- in the persistent sweep's slot order
+  // (e_in_slots), in the cell path's order (e_in_cell), or nowhere at all (e_lost: recomputed on demand) -- so nobody touches the
+  // buffer directly: eq_rows() first brings the residual home (materialize_e) and is what every reader and read-modify-writer
+  // in row order uses; eq_raw() is for the code that manages those states itself (the scorers that overwrite every residual, the
+  // sweeps that take it from / leave it in another order, materialize_e).
+  DevBuf<double2> eq_;
+  double2 *eq_raw() const { return eq_.p; }
+  double2 *eq_rows() {
+    mfm::materialize_e(this);
+    return eq_.p;
+  }
   DevBuf<int32_t> group;
   DevBuf<int32_t> feat_sorted;
   DevBuf<int64_t> group_ptr;
@@ -394,7 +408,7 @@ static void launch_qbuild(mfm_ctx *c, const double *vf, DevBlock *pending = null
     const bool ell = c->X.ell_width >= 0;
     dim3 grid(cdiv(c->N, WG)), block(WG);
 #define MFM_QB(U, E) \
-  hipLaunchKernelGGL((k_qbuild_rows<U, E>), grid, block, 0, s, c->X.rowptr.p, c->X.colidx.p, c->X.rval.p, vf, c->eq.p, c->N, \
+  hipLaunchKernelGGL((k_qbuild_rows<U, E>), grid, block, 0, s, c->X.rowptr.p, c->X.colidx.p, c->X.rval.p, vf, c->eq_rows(), c->N, \
                      (int)c->X.ell_width, g, pending ? pending->map.p : (const int32_t *)nullptr,                          \
                      pending ? pending->q_saved.p : (const double2 *)nullptr)
     if (c->X.unit) {
@@ -405,7 +419,7 @@ static void launch_qbuild(mfm_ctx *c, const double *vf, DevBlock *pending = null
 #undef MFM_QB
   } else {
     hipLaunchKernelGGL(k_qbuild_wave, dim3(cdiv(c->N, WG / WAVE)), dim3(WG), 0, s, c->X.rowptr.p, c->X.colidx.p,
-                       c->X.rval.p, vf, c->eq.p, c->N, g);
+                       c->X.rval.p, vf, c->eq_rows(), c->N, g);
   }
   MFM_HIP_CHECK(hipGetLastError());
 }
@@ -518,7 +532,7 @@ static SweepArgs main_args(mfm_ctx *c, double *theta, const double *z, const dou
   a.colptr = c->X.colptr.p;
   a.rowidx = c->X.rowidx.p;
   a.val = c->X.cval.p;
-  a.state = c->eq.p;
+  a.state = c->eq_raw();
   a.theta = theta;
   a.z = z;
   a.group = c->group.p;
@@ -541,13 +555,13 @@ static void materialize_e(mfm_ctx *c) {
   ensure_e(c);
   c->slot_sums_valid = false;  // (whoever asks for the residual in row order may change it)
   if (c->e_in_cell) {  // (the cell path's sweeps leave it in cell order; update_e, which follows in the Gibbs loop, just drops it)
-    cell_unpack_e(c->stream, c->cell, c->eq.p);
+    cell_unpack_e(c->stream, c->cell, c->eq_raw());
     c->e_in_cell = false;
   }
   if (!c->e_in_slots) return;
   const int64_t n_slots = (int64_t)c->res.G * c->res.NT * (c->res.RV + c->res.RL);
   hipLaunchKernelGGL(k_res_unpermute, dim3((unsigned)cdiv(n_slots, 256)), dim3(256), 0, c->stream, c->res.e_slots.p, c->res.perm.p,
-                     n_slots, c->eq.p);
+                     n_slots, c->eq_raw());
   c->e_in_slots = false;
 }
 
@@ -590,9 +604,9 @@ static void score_train(mfm_ctx *c, bool subtract_y) {
     TimedLaunch t(c->timing, s, KC_UPDATE_E, 12.0 * c->X.nnz + 16.0 * c->X.rows + 8.0 * c->D * (c->K + 1));
     SweepArgs a = main_args(c, c->w.p, nullptr, nullptr, nullptr, 0.0);
     const bool done = c->X.unit ? launch_mf_score<true>(s, c->plan_V, a, c->Vt.p, c->w.p, c->w0, c->K, c->KS,
-                                                        subtract_y ? c->y.p : nullptr, c->eq.p)
+                                                        subtract_y ? c->y.p : nullptr, c->eq_raw())
                                 : launch_mf_score<false>(s, c->plan_V, a, c->Vt.p, c->w.p, c->w0, c->K, c->KS,
-                                                         subtract_y ? c->y.p : nullptr, c->eq.p);
+                                                         subtract_y ? c->y.p : nullptr, c->eq_raw());
     if (done) return;
   }
   static const bool no_cell_score = std::getenv("MFM_NO_CELL_SCORE") != nullptr;
@@ -617,11 +631,11 @@ static void score_train(mfm_ctx *c, bool subtract_y) {
         src[k].ss = B.bs.p;
       }
     }
-    cell_score(s, c->timing, c->cell, src, c->V.p, c->Vt.p, c->D, c->K, c->KS, c->w0, subtract_y ? c->y.p : nullptr, c->eq.p);
+    cell_score(s, c->timing, c->cell, src, c->V.p, c->Vt.p, c->D, c->K, c->KS, c->w0, subtract_y ? c->y.p : nullptr, c->eq_raw());
     return;
   }
   score_design(c->stream, c->timing, 0, c->X, c->blocks, c->D, c->K, c->KS, c->w0, c->w.p, c->V.p, c->Vt.p,
-               subtract_y ? c->y.p : nullptr, c->eq.p, nullptr);
+               subtract_y ? c->y.p : nullptr, c->eq_raw(), nullptr);
 }
 
 // update_V (FMTrainer.hpp:315-482) of factors [f_begin, f_end) on the cell layout: per factor one streaming pass per field
@@ -631,7 +645,7 @@ static void run_sweep_cell(mfm_ctx *c, int f_begin, int f_end, const double *zba
   CellPlan &cp = c->cell;
   Timing &tm = c->timing;
   const int m = (int)cp.fields.size();
-  if (!c->e_in_cell) cell_pack_e(s, cp, c->eq.p);
+  if (!c->e_in_cell) cell_pack_e(s, cp, c->eq_raw());
   c->e_in_cell = true;  // (stays in cell order: materialize_e brings it back when somebody reads eq)
   std::vector<CellSrc> cur((size_t)m);
   cp.touch_all();  // (whatever cell_prep built in an earlier call is stale)
@@ -728,7 +742,7 @@ static void run_sweep_w_cell(mfm_ctx *c, const double *zdev, double alpha) {
       for (int k = 0; k < m; k++)
         if (cp.fields[k].kind == 0) c->comm.allreduce(cp.cnt[k].p, cp.fields[k].n);
   }
-  if (!c->e_in_cell) cell_pack_e(s, cp, c->eq.p);
+  if (!c->e_in_cell) cell_pack_e(s, cp, c->eq_raw());
   c->e_in_cell = true;
   const SweepClasses kc{KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP, KC_BLOCK_SWEEP,
                         KC_BLOCK_SWEEP, KC_BLOCK_SWEEP};
@@ -1409,7 +1423,7 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     const bool lean = c->cell_w || c->main_lazy;
     if (!lean) plan_main_table(c, Xt, lap);
   }
-  c->eq.alloc_zero((size_t)c->N, c->stream);
+  c->eq_.alloc_zero((size_t)c->N, c->stream);
   c->group.upload(c->hgroup);
   // features sorted by group (FMLearningConfig.hpp:41-46 group_vs_feature_index)
   {
@@ -1768,7 +1782,7 @@ static int get_eq(mfm_ctx *ctx, double *dst, int which) {
   ctx->need_final();
   materialize_e(ctx);
   if (ctx->N) {
-    hipLaunchKernelGGL(k_get_eq, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq.p, ctx->scratch_n.p, ctx->N,
+    hipLaunchKernelGGL(k_get_eq, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq_rows(), ctx->scratch_n.p, ctx->N,
                        which);
     MFM_HIP_CHECK(
         hipMemcpyAsync(dst, ctx->scratch_n.p, (size_t)ctx->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1804,7 +1818,7 @@ int mfm_set_e(mfm_ctx *ctx, const double *e) {
   if (ctx->N) {
     MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     MFM_HIP_CHECK(hipMemcpy(ctx->scratch_n.p, e, (size_t)ctx->N * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_set_eq, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq.p, ctx->scratch_n.p, ctx->N, 0);
+    hipLaunchKernelGGL(k_set_eq, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq_rows(), ctx->scratch_n.p, ctx->N, 0);
     MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   }
   MFM_CATCH(ctx)
@@ -1818,7 +1832,7 @@ int mfm_reduce_e(mfm_ctx *ctx, double *sum_e, double *sum_e2) {
   hipStream_t s = ctx->stream;
   {
     TimedLaunch t(ctx->timing, s, KC_REDUCE_E, 8.0 * ctx->N);
-    hipLaunchKernelGGL(k_reduce_e_partial, dim3(REDUCE_BLOCKS), dim3(WG), 0, s, ctx->eq.p, ctx->N, ctx->red_partial.p);
+    hipLaunchKernelGGL(k_reduce_e_partial, dim3(REDUCE_BLOCKS), dim3(WG), 0, s, ctx->eq_rows(), ctx->N, ctx->red_partial.p);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, s, ctx->red_partial.p, REDUCE_BLOCKS, ctx->red_out.p);
   }
   ctx->comm.allreduce(ctx->red_out.p, 2);
@@ -1839,7 +1853,7 @@ int mfm_shift_e(mfm_ctx *ctx, double delta) {
   ctx->e_is_residual = false;  // (shifted by hand: no longer score - y of the stored model and intercept)
   if (ctx->N) {
     TimedLaunch t(ctx->timing, ctx->stream, KC_SHIFT_E, 16.0 * ctx->N);
-    hipLaunchKernelGGL(k_shift_e, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq.p, ctx->N, delta);
+    hipLaunchKernelGGL(k_shift_e, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq_rows(), ctx->N, delta);
     MFM_HIP_CHECK(hipGetLastError());
   }
   MFM_CATCH(ctx)
@@ -1926,7 +1940,7 @@ int mfm_hyper_stats(mfm_ctx *ctx, int32_t need_e, const double *mu_w, const doub
     c->comm.allreduce(c->hs_out.p, 2);
   } else if (need_e) {
     TimedLaunch t(c->timing, s, KC_REDUCE_E, 8.0 * c->N);
-    hipLaunchKernelGGL(k_reduce_e_partial, dim3(REDUCE_BLOCKS), dim3(WG), 0, s, c->eq.p, c->N, c->red_partial.p);
+    hipLaunchKernelGGL(k_reduce_e_partial, dim3(REDUCE_BLOCKS), dim3(WG), 0, s, c->eq_rows(), c->N, c->red_partial.p);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, s, c->red_partial.p, REDUCE_BLOCKS, c->hs_out.p);
     c->comm.allreduce(c->hs_out.p, 2);
   }
@@ -1998,7 +2012,7 @@ int mfm_sweep_w(mfm_ctx *ctx, double alpha, const double *lambda_w, const double
   else
     run_plan<PMainW>(s, c->timing, c->plan_W, a, c->ls, kcw, c->X.unit);
   for (auto &B : c->blocks)
-    block_sweep_w(s, c->timing, c->ls, *B, c->N, c->eq.p, c->w.p, zdev, c->group.p, c->lam.p, c->mu.p, alpha, c->comm);
+    block_sweep_w(s, c->timing, c->ls, *B, c->N, c->eq_rows(), c->w.p, zdev, c->group.p, c->lam.p, c->mu.p, alpha, c->comm);
   MFM_CATCH(ctx)
 }
 
@@ -2055,7 +2069,7 @@ int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambd
   // (regression, all factors swept: update_e follows and recomputes the residual -- the launch's copy would be a dead store, 64 us)
   const bool no_store =
       c->e_recomputable && c->e_is_residual && lazy_store && f_begin == 0 && f_end == c->K && !std::getenv("MFM_RES_ALWAYS_STORE");
-  run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq.p, c->V.p, c->D, f_begin, f_end, zbase, d_lam, d_mu,
+  run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq_raw(), c->V.p, c->D, f_begin, f_end, zbase, d_lam, d_mu,
                      c->group.p, c->G, alpha, c->ls.error.p, lazy_store, c->w.p, zwdev, d_lam_w, d_mu_w, e_shift, load_slots, no_store);
   c->e_in_slots = lazy_store && !no_store;
   c->e_lost = no_store;
@@ -2086,7 +2100,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
   if (c->main_lazy) {
     if (c->res.ready) {
       const bool lazy_store = !std::getenv("MFM_RES_EAGER_STORE");
-      run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq.p, c->V.p, c->D, f_begin, f_end, zbase, c->lam.p, c->mu.p,
+      run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq_raw(), c->V.p, c->D, f_begin, f_end, zbase, c->lam.p, c->mu.p,
                          c->group.p, c->G, alpha, c->ls.error.p, lazy_store);
       c->e_in_slots = lazy_store;
       c->q_stale_factor = f_end - 1;
@@ -2099,7 +2113,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
                        !std::getenv("MFM_NO_FUSED_QBUILD");
   if (c->qfree) {
     // compact e for the duration of the factor loop; q is never materialised inside it
-    hipLaunchKernelGGL(k_e_pack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
+    hipLaunchKernelGGL(k_e_pack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq_rows(), c->ec.p, c->N);
     const SweepClasses kcv{KC_SWEEP_V_LIGHT, KC_SWEEP_V_HEAVY, KC_SWEEP_V_COOP, KC_SWEEP_V_LSTATS, KC_SWEEP_V_LDRAW,
                            KC_SWEEP_V_LAPPLY, KC_SWEEP_V_CHAIN, KC_SWEEP_V_SCAT};
     for (int f = f_begin; f < f_end; f++) {
@@ -2113,14 +2127,14 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       a.r_ell = (int)c->X.ell_width;
       run_plan_qfree(s, c->timing, c->plan_V, a, c->ls, kcv, c->X.unit);
     }
-    hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
+    hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq_rows(), c->ec.p, c->N);
     c->q_stale_factor = f_end - 1;  // q_train as the reference leaves it (FMTrainer.hpp:373): rebuilt when asked for
     MFM_HIP_CHECK(hipGetLastError());
     return MFM_OK;
   }
   if (c->sharded_fused && c->res.ready) {  // (row-sharded persistent sweep: the peers' buffers are set)
     const bool lazy_store = !std::getenv("MFM_RES_EAGER_STORE");
-    run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq.p, c->V.p, c->D, f_begin, f_end, zbase, c->lam.p, c->mu.p,
+    run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq_raw(), c->V.p, c->D, f_begin, f_end, zbase, c->lam.p, c->mu.p,
                        c->group.p, c->G, alpha, c->ls.error.p, lazy_store);
     c->e_in_slots = lazy_store;
     c->q_stale_factor = f_end - 1;
@@ -2136,7 +2150,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
                               c->lam.p + (size_t)f * c->G, c->mu.p + (size_t)f * c->G, alpha);
       a.state = c->ec.p;
       a.state2 = c->qc.p;
-      a.aos = c->eq.p;
+      a.aos = c->eq_rows();
       a.r_rowptr = c->X.rowptr.p;
       a.r_colidx = c->X.colidx.p;
       a.r_val = c->X.rval.p;
@@ -2179,7 +2193,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
                               c->lam.p + (size_t)f * c->G, c->mu.p + (size_t)f * c->G, alpha);
       a.state = c->ec.p;
       a.state2 = c->qc.p;
-      a.aos = c->eq.p;
+      a.aos = c->eq_rows();
       a.r_rowptr = c->X.rowptr.p;
       a.r_colidx = c->X.colidx.p;
       a.r_val = c->X.rval.p;
@@ -2189,7 +2203,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     const bool fuse = c->fuse_next;
     if (c->res.ready) {
       const bool lazy_store = !std::getenv("MFM_RES_EAGER_STORE");
-      run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq.p, c->V.p, c->D, f_begin, f_end, zbase, c->lam.p, c->mu.p,
+      run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq_raw(), c->V.p, c->D, f_begin, f_end, zbase, c->lam.p, c->mu.p,
                          c->group.p, c->G, alpha, c->ls.error.p, lazy_store);
       c->e_in_slots = lazy_store;
       c->q_stale_factor = f_end - 1;
@@ -2205,7 +2219,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
     else
       run_sweep_soa<false>(s, c->timing, c->plan_V, args, f_begin, f_end, c->ls, kcv, fuse);
     if (!c->plan_V.steps.back().par.tiled)
-      hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq.p, c->ec.p, c->N);
+      hipLaunchKernelGGL(k_e_unpack, dim3(cdiv(c->N, 256)), dim3(256), 0, s, c->eq_rows(), c->ec.p, c->N);
     c->q_stale_factor = f_end - 1;  // q_train as the reference leaves it (FMTrainer.hpp:373): rebuilt when asked for
     MFM_HIP_CHECK(hipGetLastError());
     return MFM_OK;
@@ -2250,7 +2264,7 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
       const bool defer = fuse_resync && c->N > 0 &&
                          (last ? (f + 1 < f_end && !first_q && qbuild_by_rows(c))
                                : (c->blocks[bi + 1]->stream_unsync || c->blocks[bi + 1]->split_unsync));
-      block_sweep_V(s, c->timing, c->ls, B, c->N, c->eq.p, Vf, zf, c->group.p, lamf, muf, alpha, c->comm, pending, defer);  // :378-482
+      block_sweep_V(s, c->timing, c->ls, B, c->N, c->eq_rows(), Vf, zf, c->group.p, lamf, muf, alpha, c->comm, pending, defer);  // :378-482
       pending = defer ? &B : nullptr;
     }
     carry = pending;

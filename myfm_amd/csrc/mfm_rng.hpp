@@ -309,8 +309,17 @@ struct RawReader {
   const uint32_t *win = nullptr;
   uint64_t wbase = 0;
   uint32_t wlen = 0;
+  // outputs from `limit` on do not exist yet (the speculative gamma candidates start at positions the chain may never reach):
+  // they are not read -- a fixed word comes back (uniform = 0.75: every rejection loop accepts) and `past` is raised, which ends
+  // the draw's loops; the candidate is then marked unusable
+  uint64_t limit = ~0ull;
+  bool past = false;
   __device__ __forceinline__ uint32_t next() {
     const uint64_t i = p++;
+    if (i >= limit) {
+      past = true;
+      return 0xC0000000u;
+    }
     const uint64_t o = i - wbase;
     if (o < (uint64_t)wlen) return win[o];
     return mt_temper(raw[i & mask]);
@@ -371,7 +380,7 @@ __device__ __forceinline__ double gamma_unit(RawReader &g, double alpha) {
           x = 2.0 * g.uniform() - 1.0;
           y = 2.0 * g.uniform() - 1.0;
           r2 = x * x + y * y;
-        } while (r2 > 1.0 || r2 == 0.0);
+        } while ((r2 > 1.0 || r2 == 0.0) && !g.past);
         const double mult = sqrt(-2 * log(r2) / r2);
         saved = x * mult;
         have_saved = 1;
@@ -380,16 +389,16 @@ __device__ __forceinline__ double gamma_unit(RawReader &g, double alpha) {
       asm volatile("" : "+v"(have_saved));
       n = n * 1.0 + 0.0;
       v = 1.0 + a2 * n;
-      if (v > 0.0) break;
+      if (v > 0.0 || g.past) break;
     }
     v = v * v * v;
     u = g.uniform();
     const bool again = u > 1.0 - 0.0331 * n * n * n * n && (log(u) > (0.5 * n * n + a1 * (1.0 - v + log(v))));
-    if (!again) break;
+    if (!again || g.past) break;
   }
   if (alpha == malpha) return a1 * v;
   do u = g.uniform();
-  while (u == 0.0);
+  while (u == 0.0 && !g.past);
   return pow(u, 1.0 / alpha) * a1 * v;
 }
 
@@ -408,6 +417,7 @@ __global__ __launch_bounds__(RNG_CONSUME_THREADS) void k_rng_consume(RngState *_
   __shared__ int s_gend[NW][64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   uint64_t p = st->p_cons;
+  const uint64_t p_gen_at_start = st->p_gen;
   uint64_t wbase = 0;
   uint32_t wlen = 0;
   for (int oi = op_begin; oi < op_end; oi++) {
@@ -434,9 +444,9 @@ __global__ __launch_bounds__(RNG_CONSUME_THREADS) void k_rng_consume(RngState *_
         const int batch = min(MFM_RNG_SPEC < NW ? MFM_RNG_SPEC : NW, n_run - done_ops);
         if (wid < batch && (MFM_RNG_SPEC > 1 || lane == 0)) {
           const RngOp oj = ops[oi + done_ops + wid];
-          RawReader g{raw, mask, p + (uint64_t)(6 * wid + 2 * lane), s_win, wbase, wlen};
+          RawReader g{raw, mask, p + (uint64_t)(6 * wid + 2 * lane), s_win, wbase, wlen, p_gen_at_start};
           s_gval[wid][lane] = gamma_unit(g, oj.shape);
-          s_gend[wid][lane] = (int)(g.p - p);
+          s_gend[wid][lane] = g.past ? -1 : (int)(g.p - p);  // (-1: the candidate ran into outputs that do not exist yet)
         }
         __syncthreads();
         if (tid == 0) {
@@ -447,7 +457,12 @@ __global__ __launch_bounds__(RNG_CONSUME_THREADS) void k_rng_consume(RngState *_
             const RngOp oj = ops[oi + done_ops + j];
             double *dj = (oj.dest == 0 ? hv : (oj.dest == 1 ? zw : zv)) + oj.offset;
             dj[0] = s_gval[j][l2 >> 1];
-            pos = s_gend[j][l2 >> 1];
+            if (s_gend[j][l2 >> 1] < 0) {  // a draw ON the chain needs outputs that were never generated: the set is invalid
+              st->error = 1;
+              pos += 6;
+            } else {
+              pos = s_gend[j][l2 >> 1];
+            }
           }
           s_p = p + (uint64_t)pos;
           s_kstar = j;  // draws resolved (>= 1: the first one's start is candidate 0)

@@ -292,7 +292,7 @@ int mfm_update_e_classification(mfm_ctx *ctx, uint64_t seed, uint64_t draw_index
   score_train(ctx, false);
   if (ctx->N) {
     TimedLaunch t(ctx->timing, ctx->stream, KC_TN_SAMPLE, 24.0 * ctx->N);
-    hipLaunchKernelGGL(k_tn_classification, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq.p, ctx->y.p, ctx->N,
+    hipLaunchKernelGGL(k_tn_classification, dim3(cdiv(ctx->N, WG)), dim3(WG), 0, ctx->stream, ctx->eq_rows(), ctx->y.p, ctx->N,
                        seed, draw_index, ctx->row_offset);
     MFM_HIP_CHECK(hipGetLastError());
   }
@@ -359,7 +359,7 @@ int mfm_oprobit_eval(mfm_ctx *ctx, int32_t group, const double *gamma, double *l
   const int nb = (int)std::min<int64_t>(nb_cap, std::max<int64_t>(1, cdiv(g.n_rows, nt)));
   {
     TimedLaunch t(ctx->timing, s, KC_OPROBIT_EVAL, 16.0 * g.n_rows);
-    hipLaunchKernelGGL(k_oprobit_eval, dim3(nb), dim3(nt), lds, s, ctx->eq.p, ctx->y.p, g.rows.p, g.n_rows, C, dgam,
+    hipLaunchKernelGGL(k_oprobit_eval, dim3(nb), dim3(nt), lds, s, ctx->eq_rows(), ctx->y.p, g.rows.p, g.n_rows, C, dgam,
                        H ? 1 : 0, ctx->opartial.p, in_lds ? (double *)nullptr : ctx->oacc.p);
     MFM_HIP_CHECK(hipGetLastError());
   }
@@ -409,7 +409,7 @@ int mfm_oprobit_sample_z(mfm_ctx *ctx, int32_t group, const double *gamma, uint6
   ctx->ring.upload(dgam, gamma, (size_t)(g.n_class - 1) * sizeof(double), s);
   if (g.n_rows) {
     TimedLaunch t(ctx->timing, s, KC_TN_SAMPLE, 24.0 * g.n_rows);
-    hipLaunchKernelGGL(k_oprobit_sample_z, dim3(cdiv(g.n_rows, WG)), dim3(WG), 0, s, ctx->eq.p, ctx->y.p, g.rows.p,
+    hipLaunchKernelGGL(k_oprobit_sample_z, dim3(cdiv(g.n_rows, WG)), dim3(WG), 0, s, ctx->eq_rows(), ctx->y.p, g.rows.p,
                        g.n_rows, g.n_class, dgam, seed, draw_index, ctx->row_offset);
     MFM_HIP_CHECK(hipGetLastError());
   }
