@@ -143,7 +143,8 @@ int mfm_plan_info(const mfm_ctx *ctx, int64_t *n_levels_main, int64_t *n_launche
  * bit 6 = row-sharded with the fused tile path (first-level columns swept where their rows live),
  * bit 7 = two-field pass (two one-hot-like levels: one pass over the residual per factor, no q-cache in HBM),
  * bit 8 = persistent latent sweep (residual on chip for update_w + update_V), bit 9 = index-tuple designs (cell passes),
- * bit 10 = a relation block's feature chain (FMTrainer.hpp:276-302, :419-470) runs as the streamed one-launch form. */
+ * bit 10 = a relation block's feature chain (FMTrainer.hpp:276-302, :419-470) runs as the streamed one-launch form,
+ * bit 11 = the persistent sweep holds more rows per CU than fit on chip (the rest of the residual is streamed every sweep). */
 int mfm_plan_flags(const mfm_ctx *ctx);
 
 /* ---- model state (FM.hpp:164-168) ------------------------------------------------------ */

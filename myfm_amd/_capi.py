@@ -394,7 +394,7 @@ class Context:
     def plan_flags(self):
         f = lib().mfm_plan_flags(self.h)
         return {"qfree": bool(f & 1), "unit": bool(f & 2), "ell": bool(f & 4), "sharded": bool(f & 8), "soa": bool(f & 16),
-                "fused_next": bool(f & 32), "sharded_fused": bool(f & 64), "mf": bool(f & 128), "resident": bool(f & 256), "cell": bool(f & 512), "streamed_chain": bool(f & 1024)}
+                "fused_next": bool(f & 32), "sharded_fused": bool(f & 64), "mf": bool(f & 128), "resident": bool(f & 256), "cell": bool(f & 512), "streamed_chain": bool(f & 1024), "resident_overflow": bool(f & 2048)}
 
     def plan_info(self):
         a, b = C.c_int64(), C.c_int64()

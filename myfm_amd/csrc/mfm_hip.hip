@@ -559,7 +559,7 @@ static void materialize_e(mfm_ctx *c) {
     c->e_in_cell = false;
   }
   if (!c->e_in_slots) return;
-  const int64_t n_slots = (int64_t)c->res.G * c->res.NT * (c->res.RV + c->res.RL);
+  const int64_t n_slots = (int64_t)c->res.G * c->res.NT * c->res.R();
   hipLaunchKernelGGL(k_res_unpermute, dim3((unsigned)cdiv(n_slots, 256)), dim3(256), 0, c->stream, c->res.e_slots.p, c->res.perm.p,
                      n_slots, c->eq_raw());
   c->e_in_slots = false;
@@ -1525,9 +1525,13 @@ int mfm_finalize(mfm_ctx *ctx, int32_t rank) {
     if (want) {
       std::vector<char> draw_empty((size_t)c->D0, 0);
       for (int64_t j = 0; j < c->D0; j++) draw_empty[j] = (size_t)j < c->plan_V.special.size() && c->plan_V.special[j] == 2;
-      plan_resident(c, [&](ResPlan &rp, int n_cu) { res_plan_build_device(rp, c->X, &c->hgroup, n_cu, c->stream, &c->hlevels, &draw_empty); }, tlog);
+      plan_resident(c, [&](ResPlan &rp, int n_cu) {
+        rp.allow_overflow = false;
+        res_plan_build_device(rp, c->X, &c->hgroup, n_cu, c->stream, &c->hlevels, &draw_empty);
+      }, tlog);
       if (c->res.ready && std::getenv("MFM_PLAN_CHECK")) {
         ResPlan chk;
+        chk.allow_overflow = false;
         chk.build(Xt_keep, c->hlevels, &c->hgroup, c->res_plan_cus, &draw_empty);
         const std::string diff = chk.ready ? res_plan_compare(c->res, chk, c->stream) : ("host builder: " + chk.why);
         if (!diff.empty()) throw Error(MFM_ERR_RUNTIME, "plan check: device and host resident layouts differ (sharded; " + diff + ")");
@@ -1733,7 +1737,7 @@ int mfm_plan_flags(const mfm_ctx *ctx) {
   bool streamed = false;  // a relation block's feature chain runs as the streamed one-launch form (mfm_chain_stream.hpp)
   for (auto &B : ctx->blocks)
     for (const Step &st : B->plan_V.steps) streamed = streamed || (st.is_chain && st.chain.stream);
-  return (streamed ? 1024 : 0) | (ctx->qfree ? 1 : 0) | (ctx->X.unit ? 2 : 0) | (ctx->X.ell_width >= 0 ? 4 : 0) | (ctx->comm.active() ? 8 : 0) |
+  return (streamed ? 1024 : 0) | (ctx->res.ready && ctx->res.RX > 0 ? 2048 : 0) | (ctx->qfree ? 1 : 0) | (ctx->X.unit ? 2 : 0) | (ctx->X.ell_width >= 0 ? 4 : 0) | (ctx->comm.active() ? 8 : 0) |
          (ctx->soa ? 16 : 0) | (ctx->fuse_next ? 32 : 0) | (ctx->sharded_fused ? 64 : 0) | (ctx->mf ? 128 : 0) |
          (ctx->res.ready ? 256 : 0) | (ctx->cell.ready ? 512 : 0);
 }

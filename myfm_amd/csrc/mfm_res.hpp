@@ -104,6 +104,7 @@ struct ResArgs {
   // synchronisation after the launch
   int xmodel;
   double *xw[RES_MAX_PEERS], *xV[RES_MAX_PEERS];
+  int ngx;                   // OVF: overflow groups of 16 slots per thread (their residual lives in e_slots, which must be set)
   int no_store;              // the residual is not written back at the end (the caller recomputes it: update_e follows, FMTrainer.hpp:494)
   int rot;                   // workgroup g runs as block (g - rot) mod G (MFM_RES_ROT: placement experiments)
   int dbg;                   // timing experiments only (MFM_RES_DBG; results are wrong when set): 4 no grid barriers, 32 no item
@@ -220,7 +221,11 @@ typedef unsigned res_u4_t __attribute__((ext_vector_type(4)));
 // carries the previous slot's value. The item of a run comes from run_item[run] -- the head bits give the run index of
 // every slot without a memory access -- gathered the same way. Both chains are software-pipelined by hand: while batch b
 // computes, the dv gathers of batch b + 1 and the run_item gathers of batch b + 2 are in flight.
-template <int NT, int NGV, int NGL, bool XCH = false>
+// OVF (tables beyond the on-chip capacity, 40 960 rows per CU): a thread owns a.ngx MORE groups of 16 slots whose residual stays in
+// the slot-ordered buffer in global memory (e_slots: 8 bytes read + 8 written per slot and sweep, coalesced) and whose static
+// words are read again every sweep; they run through the same batch steps behind the on-chip groups (the run / dv gather
+// pipelines carry straight on), so the sums, partials and draws are those of the all-on-chip form.
+template <int NT, int NGV, int NGL, bool XCH = false, bool OVF = false>
 __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   extern __shared__ __attribute__((aligned(16))) char res_smem[];
   constexpr int NW = NT / WAVE, NG = NGV + NGL, R = 16 * NG, RL = 16 * NGL;
@@ -228,13 +233,14 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   const int g = (int)((blockIdx.x + (unsigned)a.rot) % gridDim.x), tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int U = a.umax;
+  const int ngx = OVF ? a.ngx : 0, NGt = NG + ngx, Rt = 16 * NGt;  // groups / slots of a thread in all (the layout arrays' strides)
   double *elds = (double *)res_smem;      // [RL][NT] residual of the LDS-resident slots
   double *acc1 = elds + (size_t)RL * NT;  // [NW][U]  sum of -e h per (wave, user) / (wave, item of the slice)
   double *acc2 = acc1 + NW * U;           // [NW][U]  sum of h^2
   d2_t *utab = (d2_t *)(acc2 + NW * U);   // [U] {new coefficient, new - old}
   d2_t *wcarry = utab + U;                // [NW]
   int *wflag = (int *)(wcarry + NW);      // [NW]
-  const int32_t *perm_g = a.perm + (int64_t)g * R * NT;
+  const int32_t *perm_g = a.perm + (int64_t)g * Rt * NT;
   const d2_t *dv2 = (const d2_t *)a.dv;
   const int u0 = a.wg_user_ptr[g], nu = a.wg_user_ptr[g + 1] - u0;
   const int rb0 = a.wg_run_ptr[g];
@@ -264,15 +270,21 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
 #pragma unroll
   for (int j = 0; j < NG; j++) {
 #pragma unroll
-    for (int w = 0; w < 4; w++) uw[j][w] = a.uidw[((int64_t)g * (5 * NG) + 5 * j + w) * NT + tid];
-    ux[j] = a.uidw[((int64_t)g * (5 * NG) + 5 * j + 4) * NT + tid];
-    hbv[j] = a.headw[((int64_t)g * NG + j) * NT + tid];
+    for (int w = 0; w < 4; w++) uw[j][w] = a.uidw[((int64_t)g * (5 * NGt) + 5 * j + w) * NT + tid];
+    ux[j] = a.uidw[((int64_t)g * (5 * NGt) + 5 * j + 4) * NT + tid];
+    hbv[j] = a.headw[((int64_t)g * NGt + j) * NT + tid];
     nbv[j] = hbv[j] | (j == 0 ? 1u : 0u);
   }
+  // OVF: the head bits of the first overflow group (the last on-chip group's gathers look two batches ahead), the overflow
+  // groups' residuals in the slot-ordered buffer, their static words
+  const unsigned nbx0 = OVF && ngx > 0 ? a.headw[((int64_t)g * NGt + NG) * NT + tid] : 0u;
+  double *eog = OVF ? a.e_slots + ((int64_t)g * Rt + 16 * NG) * NT + tid : nullptr;
+  const uint32_t *uidw_x = a.uidw + ((int64_t)g * (5 * NGt) + 5 * NG) * NT + tid;  // word w of overflow group jx: [(5 jx + w) NT]
+  const uint32_t *headw_x = a.headw + ((int64_t)g * NGt + NG) * NT + tid;          // [jx NT]
   const int run0 = a.first_run[g * NT + tid];  // the run containing this thread's first slot
   const bool head0 = (hbv[0] & 1u) != 0u;
   // gather bits of batch q of group j; q may run past the group (0 .. 5)
-#define RES_NIB(j, q) ((((nbv[j]) | ((j) + 1 < NG ? nbv[(j) + 1 < NG ? (j) + 1 : (j)] << 16 : 0u)) >> (4 * (q))) & 15u)
+#define RES_NIB(j, q) ((((nbv[j]) | ((j) + 1 < NG ? nbv[(j) + 1 < NG ? (j) + 1 : (j)] << 16 : nbx0 << 16)) >> (4 * (q))) & 15u)
   // the four users of batch bb of group j
 #define RES_UIDS(j, bb, uid)                                                     \
   {                                                                              \
@@ -281,6 +293,15 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
     uid[1] = (int)((lo_ >> 10) & 0x3ffu);                                        \
     uid[2] = (int)((lo_ >> 20) & 0x3ffu);                                        \
     uid[3] = (int)((lo_ >> 30) | (((ux[j] >> (8 * (bb))) & 0xffu) << 2));        \
+  }
+
+#define RES_UIDSX(bb, uid)                                                       \
+  {                                                                              \
+    const unsigned lo_ = uwx[bb];                                                \
+    uid[0] = (int)(lo_ & 0x3ffu);                                                \
+    uid[1] = (int)((lo_ >> 10) & 0x3ffu);                                        \
+    uid[2] = (int)((lo_ >> 20) & 0x3ffu);                                        \
+    uid[3] = (int)((lo_ >> 30) | (((uxx >> (8 * (bb))) & 0xffu) << 2));          \
   }
 
   // Pad slots carry (pad item, pad user): an item whose dv entry stays (0, 0) and a user slot nobody draws, so that every slot
@@ -295,11 +316,22 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       for (int k = 0; k < B; k++) row[k] = a.e_in ? 0 : perm_g[(16 * j + 4 * bb + k) * NT + tid];
 #pragma unroll
       for (int k = 0; k < B; k++) {
-        const double x = (a.e_in ? a.e_in[((int64_t)g * R + 16 * j + 4 * bb + k) * NT + tid] : a.eq[row[k] < 0 ? 0 : row[k]].x) + a.e_shift;
+        const double x = (a.e_in ? a.e_in[((int64_t)g * Rt + 16 * j + 4 * bb + k) * NT + tid] : a.eq[row[k] < 0 ? 0 : row[k]].x) + a.e_shift;
         if (j < NGV)
           ev[j < NGV ? j : 0][4 * bb + k] = x;
         else
           elds[(16 * (j - NGV) + 4 * bb + k) * NT + tid] = x;
+      }
+    }
+  }
+  if (OVF) {  // the overflow slots: into (or shifted inside) the slot-ordered buffer they live in for the launch
+    for (int jx = 0; jx < ngx; jx++) {
+#pragma unroll 4
+      for (int i = 0; i < 16; i++) {
+        const int64_t sl = 16 * (NG + jx) + i;
+        const int row = a.e_in ? 0 : perm_g[sl * NT + tid];
+        const double x = (a.e_in ? a.e_in[((int64_t)g * Rt + sl) * NT + tid] : a.eq[row < 0 ? 0 : row].x) + a.e_shift;
+        eog[(16 * jx + i) * NT] = x;
       }
     }
   }
@@ -382,6 +414,32 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       __hip_atomic_fetch_add(&acc2[wv * U + uid[k]], c * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);               \
     }                                                                                                                      \
   }
+#define RES_STEP_AX(bb, iti, ito, ddi, ddo)                                                                                 \
+  {                                                                                                                        \
+    const unsigned n4 = ((nbw >> (4 * (bb))) & 15u), n4a = ((nbw >> (4 * ((bb) + 1))) & 15u), n4b = ((nbw >> (4 * ((bb) + 2))) & 15u);                            \
+    _Pragma("unroll") for (int k = 0; k < B; k++) {                                                                        \
+      rc += (int)((n4b >> k) & 1u);                                                                                        \
+      ito[k] = a.run_item[(n4b >> k) & 1u ? rc : rb0];                                                                     \
+    }                                                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < B; k++) ddo[k] = dv2[(n4a >> k) & 1u ? iti[k] : pad_item];                       \
+    int uid[B];                                                                                                            \
+    RES_UIDSX(bb, uid);                                                                                                      \
+    double up[B], ex[B];                                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < B; k++) {                                                                        \
+      up[k] = utab[uid[k]][0];                                                                                             \
+      ex[k] = eo[4 * (bb) + k];              \
+    }                                                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < B; k++) {                                                                        \
+      const bool need = ((n4 >> k) & 1u) != 0u;                                                                            \
+      ddc[0] = need ? ddi[k][0] : ddc[0];                                                                                  \
+      ddc[1] = need ? ddi[k][1] : ddc[1];                                                                                  \
+      const double er = ex[k] + up[k] * ddc[0];                                                                            \
+      eo[4 * (bb) + k] = er;                                                             \
+      const double c = ddc[1];                                                                                             \
+      __hip_atomic_fetch_add(&acc1[wv * U + uid[k]], (-er) * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);           \
+      __hip_atomic_fetch_add(&acc2[wv * U + uid[k]], c * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);               \
+    }                                                                                                                      \
+  }
 #pragma unroll
       for (int j = 0; j < NG; j++) {
 #pragma unroll 1
@@ -390,7 +448,30 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
           RES_STEP_A(j, 2 * bp + 1, itB, itA, ddB, ddA);
         }
       }
+      if (OVF) {  // the overflow groups: static words and residuals from global memory, group by group
+        unsigned hb_c = nbx0;
+        for (int jx = 0; jx < ngx; jx++) {
+          res_u4_t uwx;
+#pragma unroll
+          for (int w = 0; w < 4; w++) uwx[w] = uidw_x[(5 * jx + w) * NT];
+          const unsigned uxx = uidw_x[(5 * jx + 4) * NT];
+          const unsigned hb_n = jx + 1 < ngx ? headw_x[(jx + 1) * NT] : 0u;
+          const unsigned nbw = hb_c | (hb_n << 16);
+          res_d16_t eo;
+#pragma unroll
+          for (int i = 0; i < 16; i++) eo[i] = eog[(16 * jx + i) * NT];
+#pragma unroll 1
+          for (int bp = 0; bp < 2; bp++) {
+            RES_STEP_AX(2 * bp, itA, itB, ddA, ddB);
+            RES_STEP_AX(2 * bp + 1, itB, itA, ddB, ddA);
+          }
+#pragma unroll
+          for (int i = 0; i < 16; i++) eog[(16 * jx + i) * NT] = eo[i];
+          hb_c = hb_n;
+        }
+      }
 #undef RES_STEP_A
+#undef RES_STEP_AX
     }
     __syncthreads();
     RES_STAMP(1);
@@ -485,6 +566,39 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       s2 = (head ? 0.0 : s2) + ut[k][0] * ut[k][0];                                                                        \
     }                                                                                                                      \
   }
+#define RES_STEP_BX(bb, iti, ito, cci, cco)                                                                                 \
+  {                                                                                                                        \
+    const unsigned n4 = ((nbw >> (4 * (bb))) & 15u), n4a = ((nbw >> (4 * ((bb) + 1))) & 15u), n4b = ((nbw >> (4 * ((bb) + 2))) & 15u);                            \
+    const unsigned h4 = (hb_c >> (4 * (bb))) & 15u;                                                                       \
+    _Pragma("unroll") for (int k = 0; k < B; k++) {                                                                        \
+      rc += (int)((n4b >> k) & 1u);                                                                                        \
+      ito[k] = a.run_item[(n4b >> k) & 1u ? rc : rb0];                                                                     \
+    }                                                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < B; k++) cco[k] = a.dv[2 * (int64_t)((n4a >> k) & 1u ? iti[k] : pad_item) + 1];   \
+    int uid[B];                                                                                                            \
+    RES_UIDSX(bb, uid);                                                                                                      \
+    d2_t ut[B];                                                                                                            \
+    double ex[B];                                                                                                          \
+    _Pragma("unroll") for (int k = 0; k < B; k++) {                                                                        \
+      ut[k] = utab[uid[k]];                                                                                                \
+      ex[k] = eo[4 * (bb) + k];              \
+    }                                                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < B; k++) {                                                                        \
+      const bool need = ((n4 >> k) & 1u) != 0u;                                                                            \
+      const bool head = ((h4 >> k) & 1u) != 0u;                                                                            \
+      ccc = need ? cci[k] : ccc;                                                                                           \
+      rcC += need ? 1 : 0; /* the run of this slot */                                                                      \
+      /* a run that began and ended in this thread: the slot before this head closed run rcC - 1 */                        \
+      RES_PARTIAL_STORE();                                                                                                 \
+      f1 = head && !have_head ? s1 : f1;                                                                                   \
+      f2 = head && !have_head ? s2 : f2;                                                                                   \
+      have_head = have_head || head;                                                                                       \
+      const double er = ex[k] + ccc * ut[k][1];                                                                            \
+      eo[4 * (bb) + k] = er;                                                             \
+      s1 = (head ? 0.0 : s1) + (-er) * ut[k][0];                                                                           \
+      s2 = (head ? 0.0 : s2) + ut[k][0] * ut[k][0];                                                                        \
+    }                                                                                                                      \
+  }
 #pragma unroll
         for (int j = 0; j < NG; j++) {
 #pragma unroll 1
@@ -499,7 +613,30 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
                   __builtin_amdgcn_s_memrealtime();
           }
         }
+        if (OVF) {
+          unsigned hb_c = nbx0;
+          for (int jx = 0; jx < ngx; jx++) {
+            res_u4_t uwx;
+#pragma unroll
+            for (int w = 0; w < 4; w++) uwx[w] = uidw_x[(5 * jx + w) * NT];
+            const unsigned uxx = uidw_x[(5 * jx + 4) * NT];
+            const unsigned hb_n = jx + 1 < ngx ? headw_x[(jx + 1) * NT] : 0u;
+            const unsigned nbw = hb_c | (hb_n << 16);
+            res_d16_t eo;
+#pragma unroll
+            for (int i = 0; i < 16; i++) eo[i] = eog[(16 * jx + i) * NT];
+#pragma unroll 1
+            for (int bp = 0; bp < 2; bp++) {
+              RES_STEP_BX(2 * bp, itA, itB, ccA, ccB);
+              RES_STEP_BX(2 * bp + 1, itB, itA, ccB, ccA);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) eog[(16 * jx + i) * NT] = eo[i];
+            hb_c = hb_n;
+          }
+        }
 #undef RES_STEP_B
+#undef RES_STEP_BX
 #undef RES_PARTIAL_STORE
       }
       if (a.prof && lane == 0)  // (per wave: the end of its own sweep B)
@@ -678,15 +815,42 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
           const double ex = j < NGV ? ev[j < NGV ? j : 0][4 * bb + k] : elds[(16 * (j - NGV) + 4 * bb + k) * NT + tid];
           const double ef = ex + utab[uid[k]][0] * dl;
           if (a.e_slots)
-            a.e_slots[((int64_t)g * R + 16 * j + 4 * bb + k) * NT + tid] = ef;
+            a.e_slots[((int64_t)g * Rt + 16 * j + 4 * bb + k) * NT + tid] = ef;
           else if (row[k] >= 0)
             a.eq[row[k]].x = ef;
+        }
+      }
+    }
+    if (OVF) {
+      for (int jx = 0; jx < ngx; jx++) {
+        res_u4_t uwx;
+#pragma unroll
+        for (int w = 0; w < 4; w++) uwx[w] = uidw_x[(5 * jx + w) * NT];
+        const unsigned uxx = uidw_x[(5 * jx + 4) * NT];
+        const unsigned hbx = headw_x[jx * NT];
+#pragma unroll 1
+        for (int bb = 0; bb < 4; bb++) {
+          const unsigned h4 = (hbx >> (4 * bb)) & 15u;
+          int it[B], uid[B];
+#pragma unroll
+          for (int k = 0; k < B; k++) {
+            run_last += (int)((h4 >> k) & 1u);
+            it[k] = a.run_item[run_last];
+          }
+          RES_UIDSX(bb, uid);
+#pragma unroll
+          for (int k = 0; k < B; k++) {
+            const double dl = a.dv[2 * (int64_t)it[k]];
+            double *ep = eog + (16 * jx + 4 * bb + k) * NT;
+            *ep = *ep + utab[uid[k]][0] * dl;
+          }
         }
       }
     }
   }
 #undef RES_NIB
 #undef RES_UIDS
+#undef RES_UIDSX
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   RES_STAMP0(4);
 #undef RES_STAMP0
@@ -923,6 +1087,9 @@ static inline void res_parallel_for(int n, F f) {
 struct ResPlan {
   bool ready = false;
   int G = 0, NT = 512, RV = 0, RL = 0, umax = 0, item_bits = 0, n_items = 0;
+  int RX = 0;  // slots per thread beyond the on-chip ones (a multiple of 16): their residual stays in e_slots (k_mf_resident<.., OVF>)
+  int R() const { return RV + RL + RX; }
+  bool allow_overflow = true;  // (false: row-sharded -- the exchange variant of the kernel has no overflow form)
   int64_t n_rows = 0, n_runs = 0;  // (workgroup, item) pairs
   size_t lds_bytes = 0;
   DevBuf<int32_t> perm, first_run, wg_run_ptr, wg_nruns, wg_user_ptr, wg_item_ptr, ent_ptr, scols;
@@ -1037,6 +1204,42 @@ struct ResPlan {
       RL = vs[vi].rl;
       found = true;
     }
+    // Tables beyond the on-chip capacity (512 x 80 slots per CU): the largest variant plus RX slots per thread whose residual is
+    // streamed from / to the slot-ordered buffer every sweep (k_mf_resident<.., OVF>), up to twice the capacity -- beyond that the
+    // per-factor passes. Not row-sharded (the exchange variant has no overflow form), not with MFM_RES_EAGER_STORE.
+    RX = 0;
+    if (!found && allow_overflow && !std::getenv("MFM_RES_EAGER_STORE") && !std::getenv("MFM_RES_NO_OVERFLOW")) {
+      const Variant big = vs[nv - 1];
+      for (int rx = 16; rx <= 80 && !found; rx += 16) {
+        const int64_t cap = (int64_t)NT * (big.rv + big.rl + rx) - 1;
+        if (max_user > cap || N > (int64_t)n_cu * cap) continue;
+        int64_t Gw = std::min<int64_t>(n_cu, n_users);
+        ucut.assign(1, 0);
+        bool ok = true;
+        for (int64_t g = 1; g <= Gw && ok; g++) {
+          const int64_t lo_u = ucut.back();
+          int64_t hi_u;
+          if (g == Gw) {
+            hi_u = n_users;
+          } else {
+            const int64_t want = (N * g) / Gw;
+            hi_u = std::upper_bound(ustart.begin(), ustart.end(), want) - ustart.begin() - 1;
+            if (hi_u + 1 <= n_users && ustart[hi_u + 1] - want < want - ustart[hi_u]) hi_u++;
+            hi_u = std::max(hi_u, lo_u + 1);
+            hi_u = std::min<int64_t>(hi_u, n_users - (Gw - g));
+            while (hi_u > lo_u + 1 && ustart[hi_u] - ustart[lo_u] > cap) hi_u--;
+          }
+          if (hi_u <= lo_u || ustart[hi_u] - ustart[lo_u] > cap) ok = false;
+          ucut.push_back(hi_u);
+        }
+        if (!ok) continue;
+        G = (int)Gw;
+        RV = big.rv;
+        RL = big.rl;
+        RX = rx;
+        found = true;
+      }
+    }
     if (!found) return fail("no variant fits (rows per CU, or a first-level column longer than a workgroup's capacity)");
     return true;
   }
@@ -1137,7 +1340,7 @@ struct ResPlan {
     }
     std::vector<int64_t> ucut;  // user ordinal boundaries of the workgroups
     if (!choose_layout(N, ustart, max_user, n_cu, ucut)) return false;
-    const int R = RV + RL;
+    const int R = RV + RL + RX;
     const int64_t cap_slots = (int64_t)NT * R;
     // users per workgroup (+ the never-occurring ones, dealt round-robin), the pad user
     std::vector<std::vector<int32_t>> wg_users((size_t)G);
@@ -1379,7 +1582,7 @@ static inline hipError_t res_occupancy(const ResPlan &rp, int *per_cu) {
   else if (rp.RV == 32 && rp.RL == 0)
     fn = (const void *)k_mf_resident<512, 2, 0>;
   else if (rp.RV == 64 && rp.RL == 16)
-    fn = (const void *)k_mf_resident<512, 4, 1>;
+    fn = rp.RX ? (const void *)k_mf_resident<512, 4, 1, false, true> : (const void *)k_mf_resident<512, 4, 1>;
   else
     return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1397,7 +1600,8 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   ResArgs a;
   std::memset(&a, 0, sizeof(a));
   a.eq = eq;
-  a.e_slots = lazy_store ? rp.e_slots.p : nullptr;
+  a.e_slots = (lazy_store || rp.RX) ? rp.e_slots.p : nullptr;  // (overflow slots live there)
+  a.ngx = rp.RX / 16;
   a.no_store = no_store ? 1 : 0;
   a.e_in = load_slots ? rp.e_slots.p : nullptr;
   a.linear = w ? 1 : 0;
@@ -1467,7 +1671,8 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
   // algorithmic bytes of the launch: e read once (8 B) with its slot map (4 B) and the static slot words (11 bits), written
   // once (8 B: slot order, or scattered to eq); per sweep one 16-byte partial per (workgroup, item) run written and read,
   // its 8-byte list entry, its item read by both sweeps (2 x 4 B)
-  const double bytes = (8.0 + (load_slots ? 0.0 : 4.0) + 1.4 + (no_store ? 0.0 : 8.0)) * rp.n_rows + K * 48.0 * rp.n_runs;  // (slot order: no map; no_store: not written back)
+  double bytes = (8.0 + (load_slots ? 0.0 : 4.0) + 1.4 + (no_store ? 0.0 : 8.0)) * rp.n_rows + K * 48.0 * rp.n_runs;  // (slot order: no map; no_store: not written back)
+  if (rp.RX) bytes += (double)K * (16.0 + 1.75) * (double)rp.G * rp.NT * rp.RX;  // overflow slots: residual read + written, static words, per sweep
   (void)lazy_store;
   hipLaunchKernelGGL(k_res_init_dv, dim3((rp.n_items + 256) / 256), dim3(256), 0, s,
                      w ? (const double *)nullptr : V + (int64_t)f_begin * D, rp.scols.p, rp.n_items,
@@ -1497,7 +1702,15 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
     MFM_RES_LAUNCH(16, 0);
   else if (rp.RV == 32 && rp.RL == 0)
     MFM_RES_LAUNCH(32, 0);
-  else if (rp.RV == 64 && rp.RL == 16)
+  else if (rp.RV == 64 && rp.RL == 16 && rp.RX > 0) {
+    if (xch) throw Error(MFM_ERR_RUNTIME, "internal: no row-sharded resident kernel with overflow slots");
+    static DeviceOnce raised_o;
+    if (raised_o.need()) {
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_mf_resident<512, 4, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      raised_o.mark();
+    }
+    hipLaunchKernelGGL((k_mf_resident<512, 4, 1, false, true>), dim3(rp.G), dim3(512), rp.lds_bytes, s, a);
+  } else if (rp.RV == 64 && rp.RL == 16)
     MFM_RES_LAUNCH(64, 16);
   else
     throw Error(MFM_ERR_RUNTIME, "internal: no resident kernel variant for this plan");
@@ -1609,7 +1822,7 @@ static inline bool res_score_supported(const ResPlan &rp, int K) {
 static inline void run_res_score(hipStream_t s, Timing &tm, ResPlan &rp, int kernel_class, const double *Vt, const double *w,
                                  double w0, int K, const double *y, int64_t nnz) {
   const int KS = (K + 1) & ~1;
-  const int64_t n_slots = (int64_t)rp.G * (rp.RV + rp.RL) * 512;
+  const int64_t n_slots = (int64_t)rp.G * rp.R() * 512;
   if (!rp.y_slots.p) {
     rp.y_slots.alloc((size_t)n_slots);
     hipLaunchKernelGGL(k_res_permute_y, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, y, rp.perm.p, n_slots,
@@ -1654,13 +1867,23 @@ static inline void run_res_score(hipStream_t s, Timing &tm, ResPlan &rp, int ker
     }                                                                                                                   \
     hipLaunchKernelGGL((k_res_score<512, NG_, 16>), dim3(rp.G), dim3(512), lds, s, a);                                   \
   } while (0)
-  const int NG = (rp.RV + rp.RL) / 16;
+  const int NG = rp.R() / 16;
   if (NG == 1)
     MFM_RES_SCORE(1);
   else if (NG == 2)
     MFM_RES_SCORE(2);
   else if (NG == 5)
     MFM_RES_SCORE(5);
+  else if (NG == 6)
+    MFM_RES_SCORE(6);
+  else if (NG == 7)
+    MFM_RES_SCORE(7);
+  else if (NG == 8)
+    MFM_RES_SCORE(8);
+  else if (NG == 9)
+    MFM_RES_SCORE(9);
+  else if (NG == 10)
+    MFM_RES_SCORE(10);
   else
     throw Error(MFM_ERR_RUNTIME, "internal: no slot-order scorer for this plan");
 #undef MFM_RES_SCORE

@@ -382,7 +382,7 @@ static inline bool res_plan_build_device(ResPlan &rpn, const DevSparse &X, const
     for (int32_t u = 0; u < n_users; u++) max_user = std::max(max_user, ustart[u + 1] - ustart[u]);
   }
   if (!rpn.choose_layout(N, ustart, max_user, n_cu, ucut)) return false;
-  const int G = rpn.G, R = rpn.RV + rpn.RL;
+  const int G = rpn.G, R = rpn.R();
   const int64_t cap_slots = (int64_t)NT * R;
   if (G > 1024) return rpn.fail("more than 1024 workgroups");
   std::vector<int32_t> h_rowcut((size_t)G + 1), h_ucut((size_t)G + 1), h_uptr((size_t)G + 1, 0);
@@ -527,7 +527,7 @@ static inline bool res_plan_build_device(ResPlan &rpn, const DevSparse &X, const
 
 // tests (MFM_PLAN_CHECK): every array of the device-built layout against the host-built one
 static inline std::string res_plan_compare(const ResPlan &a, const ResPlan &b, hipStream_t s) {
-  if (a.G != b.G || a.RV != b.RV || a.RL != b.RL || a.umax != b.umax || a.item_bits != b.item_bits || a.n_items != b.n_items ||
+  if (a.G != b.G || a.RV != b.RV || a.RL != b.RL || a.RX != b.RX || a.umax != b.umax || a.item_bits != b.item_bits || a.n_items != b.n_items ||
       a.n_rows != b.n_rows || a.n_runs != b.n_runs || a.lds_bytes != b.lds_bytes)
     return "scalars";
   auto same = [&](const void *p, size_t np, const void *q, size_t nq, size_t elem) {

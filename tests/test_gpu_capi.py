@@ -769,3 +769,37 @@ def test_slot_order_scorer_residual_and_sums(capi, monkeypatch):
     np.testing.assert_array_equal(a_state[1], b_state[1])
     np.testing.assert_array_equal(a_state[2], b_state[2])
     np.testing.assert_array_equal(a_e, b_e)
+
+
+@pytest.mark.parametrize("cus,store", [(2, True), (2, False), (3, True)])
+def test_resident_sweep_beyond_the_on_chip_capacity(oracle, capi, monkeypatch, cus, store):
+    # Tables with more rows per CU than the 512 x 80 on-chip slots (the 10.48 M-row cliff of round 4): the persistent sweep keeps
+    # 80 slots per thread on chip and streams the others' residual from / to the slot-ordered buffer every sweep
+    # (k_mf_resident<.., OVF>, ResPlan::RX). Here 120 001 rows on 2 (3) "CUs": 60 000 (40 001 + ...) rows per workgroup. The chain of
+    # mfm_sweep_wV + update_e against the oracle draw for draw, with the residual written back (ctypes default) and with the
+    # trainer's policy (not written back: recomputed on demand), and the residual itself after the last sweep.
+    monkeypatch.setenv("MFM_SCATTER_MIN_NNZ", "1000")
+    monkeypatch.setenv("MFM_RES_CUS", str(cus))
+    n = 120001 if cus == 2 else 150001
+    X, y, shapes = ds.onehot_mf(n, 260, 140, seed=5, sort_by_user=True)
+    gi = ds.group_index_from_shapes(shapes)
+    t, c, _ = _pair(oracle, capi, X, y, gi, 4)
+    assert c.plan_flags()["resident"] and c.plan_flags()["resident_overflow"]
+    if not store:
+        c.set_residual_policy(True)
+    drv = CapiGibbs(c, t.clone(), n, gi, fused=True)
+    seen = {}
+    for it in range(3):
+        t.step()
+        drv.step(before_update_e=lambda: seen.update(e=c.get_e()))
+        np.testing.assert_allclose(c.get_state()[2], t.fm()[2], rtol=1e-7, atol=1e-8, err_msg="iteration %d" % it)
+        np.testing.assert_allclose(c.get_state()[1], t.fm()[1], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(seen["e"], c.get_e(), rtol=0, atol=1e-9)  # the sweeps' residual == the recomputed one
+    np.testing.assert_allclose(c.get_e(), t.e(n), rtol=1e-7, atol=1e-7)
+    assert "sweep_V_resident" in _timing_classes(c, drv)
+    # separate sweeps (mfm_sweep_w, then mfm_sweep_V factor by factor) take the same path
+    t2, c2, _ = _pair(oracle, capi, X, y, gi, 4)
+    drv2 = CapiGibbs(c2, t2.clone(), n, gi, fused=False)
+    t2.step()
+    drv2.step()
+    np.testing.assert_allclose(c2.get_state()[2], t2.fm()[2], rtol=1e-7, atol=1e-8)

@@ -306,3 +306,45 @@ def test_config5_own_task_scale01_vs_oracle(oracle):
     for fm, cut in zip(predictor.samples, cuts):
         np.testing.assert_allclose(fm.cutpoints[0], cut, rtol=1e-7, atol=1e-7)
     assert list(history.n_mh_accept) == [t.mh_accept(0)]
+
+
+def test_beyond_on_chip_capacity_full_size_invariants(capi, oracle):
+    """A table LARGER than the persistent sweep's on-chip capacity (10.48 M rows per GPU): BASELINE configs[2]'s users / items with
+    N = 14 M rows. The sweep keeps 80 slots per thread on chip and streams the residual of the others every sweep (`resident_overflow`).
+    Size-independent properties over two full iterations of the call bench.py times: the incrementally maintained residual == the
+    one recomputed from scratch, == the closed-form FM score - y on a row sample; finite state; a second context bit for bit."""
+    import gc
+
+    n = 14_000_000
+    X, y, shapes = ds.movielens_like(n, NU, NI, rank_true=32, seed=1)
+    gi = ds.group_index_from_shapes(shapes)
+
+    def start():
+        t = oracle.OracleTrainer(X[:1000], y[:1000], rank=2, seed=3)  # (only a seeded mt19937 state to hand to the device)
+        c = capi.Context(X, y, rank=K, group_index=gi)
+        rng = np.random.default_rng(0)
+        c.set_state(0.1, rng.normal(size=c.D) * 0.1, rng.normal(size=(c.D, K)) * 0.1)
+        c.update_e_regression()
+        drv = CapiGibbs(c, None, n, gi, fused=True)
+        drv.use_device_rng(*t.rng_state())
+        return c, drv
+
+    c, drv = start()
+    flags = c.plan_flags()
+    assert flags["resident"] and flags["resident_overflow"], flags
+    seen = {}
+    for it in range(2):
+        drv.step(before_update_e=lambda: seen.update(e=c.get_e()))
+        e_new = c.get_e()
+        w0, w, V = c.get_state()
+        assert np.abs(seen["e"] - e_new).max() < 1e-9 * max(np.abs(e_new).max(), 1.0)
+        rows = np.sort(np.random.default_rng(it).choice(n, size=100_000, replace=False))
+        np.testing.assert_allclose(e_new[rows], ds.fm_score(X[rows], w0, w, V) - y[rows], rtol=1e-10, atol=1e-10)
+        assert np.isfinite(V).all() and drv.alpha > 0
+    v_first = V
+    del c, drv, seen
+    gc.collect()
+    c2, drv2 = start()
+    for it in range(2):
+        drv2.step()
+    assert np.array_equal(c2.get_state()[2], v_first)
