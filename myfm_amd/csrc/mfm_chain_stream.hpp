@@ -2,19 +2,25 @@
 // for V; block state beyond one CU's LDS, columns that pairwise share rows) as ONE pipelined launch without batch boundaries.
 // Plan and the exactness argument: mfm_chain_plan.hpp. This file: the device side.
 //
-// Workgroup 0 is the WALKER (512 threads): wavefront 0 walks the columns in order over their hot entries, on the hot rows'
-// records in LDS; wavefronts 1-2 (X) copy the records of rows that leave the LDS and the step's (old, new) pairs out;
-// wavefronts 3-6 (Y) stage the rows that enter and the cold statistics of the coming step. Workgroups 1..NB own a contiguous
-// range of block rows each: wavefronts 0-3 (S) take the cold statistics of step v and pack the rows entering at v, wavefronts 4-7
-// (U) apply the cold updates of step u and put the leaving rows' records back. Nobody ever executes a workgroup barrier: every
-// wavefront runs its own loop over the steps and waits on monotonic counters only --
-//   walker(s)  <-  Y(s)  <-  S(s) of every range (global flags) and X(s - RD) (LDS: slot reuse)
+// Workgroup 0 is the WALKER workgroup (512 threads, roles placed by SIMD -- wavefront w runs on SIMD w % 4):
+//   wavefront 0       the walker: the columns in order over their hot entries, on the hot rows' records in LDS (raised priority;
+//                     its SIMD mate, wavefront 4, stays idle -- a helper there was starved and became what the walker waited for)
+//   wavefronts 1, 5   X: copy the records of rows that leave the LDS and the step's (old, new) pairs out; the two alternate steps
+//   wavefronts 2,3,6,7  Y: stage the rows that enter, the cold statistics and the hot entry lists of the coming step; two pairs,
+//                     alternating steps, each with the step's static data prefetched one own step ahead
+// Workgroups 1..NB own a contiguous range of block rows each: wavefronts 0-3 (S, two pairs alternating steps) take the cold
+// statistics of step v and pack the rows entering at v, wavefronts 4-7 (U, two pairs alternating steps: Lw >= 2) apply the cold
+// updates of step u and put the leaving rows' records back. Nobody executes a workgroup barrier after the prologue: every
+// wavefront runs its own loop over its steps and waits on monotonic per-wavefront counters only --
+//   walker(s)  <-  Y(s)  <-  S(s) of every range (global flags) and X(s - RD), X(s - RD - 1) (LDS: slot reuse)
 //   S(v)       <-  U(v - Lw) of the same workgroup (LDS)
 //   U(u)       <-  X(u) (global counter)             X(u) <- walker(u) (LDS)
 // Everything that crosses workgroups (ring slots of entering / leaving records, per-(range, wavefront) partial statistics, the
-// (old, new) pairs, the flags) is written with agent-scope (write-through) stores, drained with s_waitcnt vmcnt(0) before the
-// flag, and read with agent-scope loads; the block-row records themselves are only ever touched by their range's workgroup
-// (one CU: its L1 sees its own stores). The sums have a fixed association: a second run is bit-identical.
+// (old, new) pairs, the flags; CS_RING steps deep) is written with agent-scope (write-through) stores, 16 bytes an instruction,
+// drained with s_waitcnt vmcnt(0) before the flag, and read with 16-byte agent-scope loads; the block-row records themselves are
+// only ever touched by their range's workgroup (one CU: its L1 sees its own stores). The sums have a fixed association: a second
+// run is bit-identical. What bounds it (profiles/r05_m_cs_stream_timeline.txt): the walker at 0.9-1.0 us a column and the
+// S -> Y -> walker -> X -> U -> S round trip of about 11 us over Lw steps are within 5% of each other at the planner's choice.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -16,4 +16,8 @@ t = df.pivot_table(index="k", columns="Counter_Name", values="Counter_Value", ag
 t["launches"] = df.groupby("k").Dispatch_Id.nunique()
 pd.set_option("display.width", 250)
 pd.set_option("display.max_columns", 50)
+import os
+keep = os.environ.get("SQ_KERNEL")
+if keep:
+    t = t[[keep in str(i) for i in t.index]]
 print(t.sort_values(t.columns[0], ascending=False).head(12).to_string())

@@ -16,6 +16,7 @@ fetch_dir, write_dir, out_prefix = sys.argv[1], sys.argv[2], sys.argv[3]
 
 CLASS = [  # kernel-name pattern -> bench.py kernel class
     (r"k_mf_resident", "sweep_V_resident"),
+    (r"k_cs_stream", "block_chain_stream"),
     (r"k_mf_pass", "sweep_V_fused_next"),
     (r"k_mf_draw", "sweep_V_scattered"),
     (r"k_mf_score", "update_e_score"),
