@@ -510,7 +510,7 @@ def main():
                     "statistics partial per (workgroup, item) run written + read, "
                     "its 8-byte list entry and two 4-byte item reads. The launch is bound by instruction issue, LDS atomics "
                     "and two grid barriers per sweep, not by HBM: its fraction of the HBM roofline is low BECAUSE the bytes are "
-                    "gone (r02's per-factor pass moved 289 MB per factor, this one 98 MB); see DESIGN.md 4.3b. "
+                    "gone (r02's per-factor pass moved 289 MB per factor, this one 98 MB); see DESIGN.md 4.3. "
                     "sweep_V_fused_next (other shapes) = one per-factor pass of the two-field latent sweep.",
             "kernel_ms_per_step": round(sum(v[0] for v in breakdown.values()), 3),
             "by_kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
@@ -533,7 +533,7 @@ def main():
                     "wave_cycles_waiting_frac": cnt["wave_wait_any_frac"], "lds_active_frac": cnt["lds_active_frac"],
                     "lds_bank_conflict_frac_of_active": cnt["lds_bank_conflict_frac_of_active"], "counters_source": sq[-1], "counters_measured_live": False,
                     "note": "no throughput unit of the launch is near its peak (HBM, VALU issue, LDS each <= 0.3): it is bound by dependent "
-                            "latency inside the sweeps and by its grid barriers (62 % of the wave-cycles wait), DESIGN.md 4.3b"}
+                            "latency inside the sweeps and by its grid barriers (62 % of the wave-cycles wait), DESIGN.md 4.3"}
         if a.config in (2, 3) and not blocks:
             B_iter = b_iter_bytes(N, nnz, D, K)
             unfused = 56.0 * nnz + 8.0 * N + 8.0 * D

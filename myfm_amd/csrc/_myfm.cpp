@@ -1904,7 +1904,7 @@ PYBIND11_MODULE(_myfm, m) {
       .def("peer_export", &PeerHandle::peer_export)
       .def("peer_import", &PeerHandle::peer_import)
       .def("peer_drop", &PeerHandle::peer_drop);
-  // fit()'s row sort (DESIGN 4.7) without numpy's argsort + fancy indexing (6 s for 1e7 shuffled rows): a stable counting
+  // fit()'s row sort (DESIGN 4.10) without numpy's argsort + fancy indexing (6 s for 1e7 shuffled rows): a stable counting
   // sort of the rows by their first stored column, and a threaded gather of the CSR rows in that order
   m.def("row_order_by_first_column",
         [](py::array_t<int64_t, py::array::c_style | py::array::forcecast> indptr,
