@@ -1673,7 +1673,31 @@ struct StepPlan {
         s.chain.desc.upload(d.data(), d.size());
       }
       // state too large for the LDS chain of any policy: also keep the conflict-batched form
-      if ((csc.cols > 1900 || std::getenv("MFM_CHAIN_FORCE_BATCHED")) && run.size() >= 2 && !std::getenv("MFM_NO_CHAIN_BATCHED")) {
+      const bool stream_allowed = !std::getenv("MFM_NO_CB_STREAM") && !std::getenv("MFM_NO_CB_PERSIST") && !std::getenv("MFM_NO_CHAIN_GRID");
+      auto try_stream = [&]() {
+        CsStreamInfo ci;
+        s.chain.stream = cs_stream_build(csc, run, &ci);
+        if (std::getenv("MFM_SETUP_TIMING")) {
+          if (s.chain.stream)
+            std::fprintf(stderr, "[plan] streamed chain of %zu columns: steps of %d columns, window %d steps, %d ranges, %d LDS slots, %lld cold + %lld "
+                                 "hot entries (<= %d hot per column), <= %d entering / %d leaving rows per step, planned in %.3f s\n",
+                         run.size(), ci.Cg, ci.Lw, ci.NB, ci.n_slots, ci.n_cold, ci.n_hot, ci.max_hot_col, ci.max_enter, ci.max_exit, ci.plan_seconds);
+          else
+            std::fprintf(stderr, "[plan] streamed chain of %zu columns: no window fits the LDS, conflict batches kept\n", run.size());
+        }
+      };
+      const bool chain_batched_wanted =
+          (csc.cols > 1900 || std::getenv("MFM_CHAIN_FORCE_BATCHED")) && run.size() >= 2 && !std::getenv("MFM_NO_CHAIN_BATCHED");
+      // Long columns (the cold parts of a batch would run on the whole GPU: relation blocks with 10^5..10^6 rows): the streamed form is
+      // tried FIRST, and when it can be built the conflict batches -- then never launched -- are not built at all (0.06 s of device
+      // work and ~100 MB per big block at config 5). The checker mode builds both: the batches' device / host comparison stays tested.
+      bool stream_tried = false;
+      if (chain_batched_wanted && stream_allowed && !std::getenv("MFM_PLAN_CHECK") && !std::getenv("MFM_CHAIN_FORCE_BATCHED") &&
+          run_nnz >= (int64_t)256 * (int64_t)run.size()) {
+        try_stream();
+        stream_tried = true;
+      }
+      if (chain_batched_wanted && !s.chain.stream) {
         const int hot_cap = std::getenv("MFM_CHAIN_HOT_CAP") ? std::max(64, std::atoi(std::getenv("MFM_CHAIN_HOT_CAP"))) : 1200;
         // on the device when the matrix's CSC is there (relation blocks, the main table): the host form is the fall-back and,
         // under MFM_PLAN_CHECK, the checker
@@ -1689,19 +1713,8 @@ struct StepPlan {
           const std::string diff = s.chain.compare_batched(chk, dev_csc->stream);
           if (!diff.empty()) throw Error(MFM_ERR_RUNTIME, "plan check: device and host conflict batches differ (" + diff + ")");
         }
-        // chains whose cold parts run on the whole GPU (relation blocks with 10^5..10^6 rows): the streamed form
-        if (s.chain.bucketed && !std::getenv("MFM_NO_CB_STREAM") && !std::getenv("MFM_NO_CB_PERSIST")) {
-          CsStreamInfo ci;
-          s.chain.stream = cs_stream_build(csc, run, &ci);
-          if (std::getenv("MFM_SETUP_TIMING")) {
-            if (s.chain.stream)
-              std::fprintf(stderr, "[plan] streamed chain of %zu columns: steps of %d columns, window %d steps, %d ranges, %d LDS slots, %lld cold + %lld "
-                                   "hot entries (<= %d hot per column), <= %d entering / %d leaving rows per step, planned in %.3f s\n",
-                           run.size(), ci.Cg, ci.Lw, ci.NB, ci.n_slots, ci.n_cold, ci.n_hot, ci.max_hot_col, ci.max_enter, ci.max_exit, ci.plan_seconds);
-            else
-              std::fprintf(stderr, "[plan] streamed chain of %zu columns: no window fits the LDS, conflict batches kept\n", run.size());
-          }
-        }
+        // chains whose cold parts run on the whole GPU: the streamed form (unless it was tried above)
+        if (s.chain.bucketed && stream_allowed && !stream_tried) try_stream();
       }
       launches += 1;
       run.clear();
@@ -1937,6 +1950,10 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
       if (plan.n_state_rows > 0 && lds_bytes <= CHAIN_LDS_MAX && !force_batched) {
         hipLaunchKernelGGL((k_chain_lds<P>), dim3(1), dim3(WAVE), lds_bytes, s, a, st.chain.desc.p, st.chain.n_cols,
                            plan.n_state_rows, (int)P::REC_DOUBLES);
+      } else if (st.chain.stream && ls.error.p && (std::is_same<P, PBlockV>::value || std::is_same<P, PBlockW>::value)) {
+        // one pipelined launch for the whole run (mfm_chain_stream.hpp)
+        if constexpr (std::is_same<P, PBlockV>::value || std::is_same<P, PBlockW>::value)
+          cs_stream_launch(s, a, *st.chain.stream, std::is_same<P, PBlockV>::value, ls.error.p);
       } else if (st.chain.batched) {
         const ChainRun &C = st.chain;
         constexpr int rec2_l = P::REC_DOUBLES > 2 ? P::REC_DOUBLES / 2 + 1 : P::REC_DOUBLES / 2;
@@ -1969,12 +1986,6 @@ static void run_plan_t(hipStream_t s, Timing &tm, const StepPlan &plan, const Sw
           }
           const size_t lds_h = (size_t)std::max(C.max_hot, 1) * rec2_l * sizeof(double2) + 5 * CHAINB_MAXCOLS * sizeof(double) +
                                (size_t)CHAINB_MAXCOLS * sizeof(double2) + (size_t)mhe * 12 + (CHAINB_MAXCOLS + 2) * sizeof(int);
-          if (C.stream && ls.error.p) {  // one pipelined launch for the whole run (mfm_chain_stream.hpp)
-            if constexpr (std::is_same<P, PBlockV>::value || std::is_same<P, PBlockW>::value) {
-              cs_stream_launch(s, a, *C.stream, std::is_same<P, PBlockV>::value, ls.error.p);
-              continue;
-            }
-          }
           if (C.bucketed) {
             // two launches per batch: k_cb_step = cold update of the batch before + cold statistics of this one, by row range
             if (ls.cb_hot2.n < hot16) ls.cb_hot2.alloc(hot16);

@@ -282,8 +282,15 @@ struct mfm_store {
   int K = 0;
   std::string err;
   std::vector<double> w0;
-  std::vector<std::unique_ptr<DevBuf<double>>> wv;  // per sample: w[D] then V[K][D] (factor-major, the ctx layout)
-  std::vector<std::unique_ptr<DevBuf<double>>> spare;  // buffers allocated ahead (mfm_store_reserve): no hipMalloc in the loop
+  struct Sample {
+    double *p = nullptr;  // w[D] then V[K][D] (factor-major, the ctx layout): inside a slab, or `own`
+    DevBuf<double> own;
+  };
+  std::vector<std::unique_ptr<Sample>> wv;     // per sample
+  std::vector<std::unique_ptr<Sample>> spare;  // buffers allocated ahead (mfm_store_reserve): no hipMalloc in the loop
+  std::vector<std::unique_ptr<DevBuf<double>>> slabs;  // what the reserved samples are cut from (one allocation per <= 4 GB, not one
+                                                       // per sample: a hipMalloc costs up to 0.4 ms on some boxes, 295 of them showed
+                                                       // up as 12 % of a 300-iteration fit)
   hipEvent_t pushed = nullptr;  // recorded on the training stream behind the latest snapshot: readers wait for IT, not for
                                 // the whole device (hipDeviceSynchronize would stall every other stream and context)
   bool pushed_valid = false;
@@ -322,14 +329,15 @@ void mfm_store_destroy(mfm_store *st) {
 const char *mfm_store_last_error(const mfm_store *st) { return st ? st->err.c_str() : g_global_error.c_str(); }
 int32_t mfm_store_size(const mfm_store *st) { return (int32_t)st->wv.size(); }
 
-static DevBuf<double> *store_new_sample(mfm_store *st) {
-  std::unique_ptr<DevBuf<double>> b;
+static mfm_store::Sample *store_new_sample(mfm_store *st) {
+  std::unique_ptr<mfm_store::Sample> b;
   if (!st->spare.empty()) {
     b = std::move(st->spare.back());
     st->spare.pop_back();
   } else {
-    b.reset(new DevBuf<double>());
-    b->alloc((size_t)std::max<int64_t>(st->D * (st->K + 1), 1));
+    b.reset(new mfm_store::Sample());
+    b->own.alloc((size_t)std::max<int64_t>(st->D * (st->K + 1), 1));
+    b->p = b->own.p;
   }
   st->wv.push_back(std::move(b));
   return st->wv.back().get();
@@ -349,10 +357,23 @@ int mfm_store_reserve(mfm_store *st, int32_t n_samples) {
     if (need > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > frac * (double)free_b)
       throw Error(MFM_ERR_RUNTIME, "sample store: the reservation exceeds MFM_STORE_MAX_FRACTION of the free device memory");
   }
-  while ((int)(st->wv.size() + st->spare.size()) < n_samples) {
-    std::unique_ptr<DevBuf<double>> b(new DevBuf<double>());
-    b->alloc((size_t)std::max<int64_t>(st->D * (st->K + 1), 1));
-    st->spare.push_back(std::move(b));
+  {
+    const size_t per = ((size_t)std::max<int64_t>(st->D * (st->K + 1), 1) + 31) & ~(size_t)31;  // doubles per sample, 256-byte multiples
+    const size_t slab_max = std::max<size_t>(((size_t)4 << 30) / (per * sizeof(double)), 1);    // samples per slab
+    int64_t missing = (int64_t)n_samples - (int64_t)(st->wv.size() + st->spare.size());
+    while (missing > 0) {
+      const size_t n = std::min<size_t>((size_t)missing, slab_max);
+      std::unique_ptr<DevBuf<double>> slab(new DevBuf<double>());
+      slab->alloc(n * per);
+      // (handed out back to front by store_new_sample: push them so that the first sample taken is the slab's first)
+      for (size_t i = n; i-- > 0;) {
+        std::unique_ptr<mfm_store::Sample> b(new mfm_store::Sample());
+        b->p = slab->p + i * per;
+        st->spare.push_back(std::move(b));
+      }
+      st->slabs.push_back(std::move(slab));
+      missing -= (int64_t)n;
+    }
   }
   MFM_CATCH(st)
 }
@@ -362,7 +383,7 @@ int mfm_store_push_ctx(mfm_store *st, mfm_ctx *ctx) {
   ctx->need_final();
   if (ctx->device != st->device) throw Error(MFM_ERR_INVALID, "store and training context live on different devices");
   if (ctx->D != st->D || ctx->K != st->K) throw Error(MFM_ERR_INVALID, "store and training context differ in size");
-  DevBuf<double> *b = store_new_sample(st);
+  mfm_store::Sample *b = store_new_sample(st);
   const size_t D = (size_t)st->D;
   hipError_t e1 = D ? hipMemcpyAsync(b->p, ctx->w.p, D * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) : hipSuccess;
   hipError_t e2 = (D && st->K && e1 == hipSuccess)
@@ -382,7 +403,7 @@ int mfm_store_push_ctx(mfm_store *st, mfm_ctx *ctx) {
 
 int mfm_store_push_host(mfm_store *st, double w0, const double *w, const double *V) {
   MFM_TRY(st)
-  DevBuf<double> *b = store_new_sample(st);
+  mfm_store::Sample *b = store_new_sample(st);
   const size_t D = (size_t)st->D;
   hipError_t e1 = D ? hipMemcpy(b->p, w, D * sizeof(double), hipMemcpyHostToDevice) : hipSuccess;
   hipError_t e2 = (D && st->K && e1 == hipSuccess) ? hipMemcpy(b->p + D, V, D * st->K * sizeof(double), hipMemcpyHostToDevice) : hipSuccess;
