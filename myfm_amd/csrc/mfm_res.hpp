@@ -256,6 +256,19 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   if (tid == 0) res_bar_init(a, rbar, dead);
   RES_STAMP0(1);
   const bool nost = (a.dbg & 4096) != 0;  // (4096: no partial stores inside sweep B)
+  // The two wavefronts of a SIMD (w and w + 4) take turns at the higher issue priority, group by group: the arbiter otherwise
+  // prefers the older one throughout, which then finishes a sweep 5 us ahead and leaves the younger to run alone (MFM_RES_PROF:
+  // waves 0-3 at 20 us, waves 4-7 at 25 us of sweep B; with the turns 19.0 and 19.7, config 3 333.4 -> 338-341 it/s in one box;
+  // changing turns every half group gains nothing more). a.dbg & 262144 switches it off (A/B).
+  const bool prio_swap = !(a.dbg & 262144);
+  const int wv_hi = wv >> 2;
+#define RES_PRIO(j)                              \
+  if (prio_swap) {                               \
+    if ((((j) & 1) ^ wv_hi) != 0)                \
+      __builtin_amdgcn_s_setprio(1);             \
+    else                                         \
+      __builtin_amdgcn_s_setprio(0);             \
+  }
   const int trash_run = a.wg_run_ptr[g] + a.wg_nruns[g];
 #define RES_STAMP(k)                                                                                      \
   if (a.prof && tid == 0) a.prof[((int64_t)g * a.n_sw + (f - f_first)) * 64 + (k)] = __builtin_amdgcn_s_memrealtime()
@@ -442,6 +455,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   }
 #pragma unroll
       for (int j = 0; j < NG; j++) {
+        RES_PRIO(j);
 #pragma unroll 1
         for (int bp = 0; bp < 2; bp++) {
           RES_STEP_A(j, 2 * bp, itA, itB, ddA, ddB);
@@ -601,9 +615,10 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   }
 #pragma unroll
         for (int j = 0; j < NG; j++) {
+          RES_PRIO(j);
 #pragma unroll 1
           for (int bp = 0; bp < 2; bp++) {
-            RES_STEP_B(j, 2 * bp, itA, itB, ccA, ccB);
+              RES_STEP_B(j, 2 * bp, itA, itB, ccA, ccB);
             if (a.prof && lane == 0 && (wv == 4 || wv == 7))  // (waves 4 and 7: every batch)
               a.prof[((int64_t)g * a.n_sw + (f - f_first)) * 64 + 16 + (wv == 4 ? 0 : 20) + 4 * j + 2 * bp] =
                   __builtin_amdgcn_s_memrealtime();
@@ -848,6 +863,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       }
     }
   }
+#undef RES_PRIO
 #undef RES_NIB
 #undef RES_UIDS
 #undef RES_UIDSX
