@@ -189,6 +189,27 @@ int mfm_sweep_V(mfm_ctx *ctx, int32_t f_begin, int32_t f_end, double alpha, cons
  * two-field one-hot table it is one persistent launch. zw / zv: both NULL (the acquired device random set) or both given. */
 int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambda_w, const double *mu_w, const double *zw,
                  int32_t f_begin, int32_t f_end, const double *lambda_V, const double *mu_V, const double *zv);
+
+/* One WHOLE regression iteration (GibbsFMTrainer::update_all, BaseFMTrainer.hpp:135-152) enqueued without a host round trip inside
+ * it: the reductions update_alpha / update_w0 / update_lambda_* / update_mu_* need (FMTrainer.hpp:127-229), those conditionals
+ * themselves on the device (k_hyper_regression: the trainer's arithmetic, operation for operation, on the unit variates of the
+ * acquired random set -- draw program [gamma: alpha][normal: w0 if fit_w0][G gammas: lambda_w][G normals: mu_w][K G gammas:
+ * lambda_V][K G normals: mu_V] + the w and V sweep normals), update_w0's shift + update_w + update_V as the persistent launch
+ * (:231-486), the request for the set after the next, update_e (:493-497). With the host in the loop (mfm_hyper_stats -> host
+ * draws -> mfm_sweep_wV) every iteration paid ~0.1 ms of read-back / upload / dispatch latency between two launches.
+ *   prior: alpha_0, beta_0, gamma_0, mu_0, reg_0 of FMLearningConfig, n_total = training rows, fit_w0; n_in_group: [G] features
+ *   per group. In: *w0, mu_w, mu_V = the current values. Out: this iteration's draws (the call returns when they have arrived,
+ *   i.e. early in the iteration's device work: w / V / e are still being swept, like after mfm_sweep_wV).
+ * mfm_regression_iteration_ready: 1 when the context can do this now (finalized two-field table on the persistent sweep, one GPU,
+ * the residual in the sweep's slot order with its sums from the last mfm_update_e_regression, a device random stream programmed
+ * as above); else 0 and the caller runs the iteration step by step. */
+typedef struct mfm_hyper_prior {
+  double alpha_0, beta_0, gamma_0, mu_0, reg_0, n_total;
+  int32_t fit_w0, reserved;
+} mfm_hyper_prior;
+int mfm_regression_iteration_ready(mfm_ctx *ctx);
+int mfm_regression_iteration(mfm_ctx *ctx, const mfm_hyper_prior *prior, const double *n_in_group, double *alpha, double *w0,
+                             double *lambda_w, double *mu_w, double *lambda_V, double *mu_V);
 /* update_e (FMTrainer.hpp:493-522), regression: e = predict_score(X_train) - y.             */
 int mfm_update_e_regression(mfm_ctx *ctx);
 /* update_e, probit classification (:498-512): e_t = score_t - z_t, z_t ~ TN(score_t, 1) on

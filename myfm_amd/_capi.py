@@ -31,6 +31,7 @@ SYMBOLS = [
     "mfm_test_erfcx", "mfm_test_truncated_normal", "mfm_get_device", "mfm_set_shard", "mfm_comm_unique_id", "mfm_comm_init",
     "mfm_comm_stats", "mfm_comm_info", "mfm_store_create", "mfm_store_destroy", "mfm_store_last_error", "mfm_store_size", "mfm_store_push_ctx",
     "mfm_store_push_host", "mfm_store_get", "mfm_design_predict_store", "mfm_store_reserve", "mfm_cs_plan_selftest",
+    "mfm_regression_iteration_ready", "mfm_regression_iteration",
 ]
 
 _lib = None
@@ -71,6 +72,8 @@ def lib():
     L.mfm_peer_export.argtypes = [vp, P]
     L.mfm_peer_import.argtypes = [vp, i32, i32, P]
     L.mfm_peer_drop.argtypes = [vp]
+    L.mfm_regression_iteration_ready.argtypes = [vp]
+    L.mfm_regression_iteration.argtypes = [vp, P, P, P, P, P, P, P, P]
     L.mfm_set_residual_policy.argtypes = [vp, i32]
     L.mfm_dim_all.restype = i64
     L.mfm_dim_all.argtypes = [vp]

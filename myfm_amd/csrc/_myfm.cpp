@@ -35,6 +35,9 @@
 #include "myfm_hip.h"
 
 namespace py = pybind11;
+
+// iterations of this process that took mfm_regression_iteration (tests assert the path they mean to test)
+static long g_device_hyper_iterations = 0;
 using std::vector;
 typedef double Real;
 typedef py::array_t<double, py::array::c_style | py::array::forcecast> NpF64;
@@ -1267,6 +1270,33 @@ struct FMTrainer {
     const size_t G = cfg.n_groups;
     const int Kf = fm.n_factors;
     htl.start();
+    // MYFM_AMD_DEVICE_HYPERS=1, regression on the persistent sweep: the whole iteration is enqueued at once and its
+    // hyper-parameters are drawn on the device (mfm_regression_iteration: the same arithmetic on the same variates as below, the
+    // chains are bit-identical) -- no read-back / host draws / upload between update_e and the next launch. Opt-in: it does not
+    // shorten the iteration (config 3: 335-338 against 338 it/s). What fills the 0.29 ms between two launches is the random
+    // stream, not the host: the evaluation of a set's 2.6 M sweep normals runs starved beside the launch on the CUs it leaves free,
+    // and the set's single-workgroup draw kernels (0.26 ms in a row) then take the whole gap.
+    static const bool host_hypers = std::getenv("MYFM_AMD_DEVICE_HYPERS") == nullptr;
+    if (!host_hypers && device_rng && cfg.task_type == TaskType::REGRESSION && cfg.fit_linear && dim_all && Kf > 0 && !comm_active() &&
+        mfm_regression_iteration_ready(ctx) == 1) {
+      mfm_hyper_prior pr;
+      pr.alpha_0 = cfg.alpha_0;
+      pr.beta_0 = cfg.beta_0;
+      pr.gamma_0 = cfg.gamma_0;
+      pr.mu_0 = cfg.mu_0;
+      pr.reg_0 = cfg.reg_0;
+      pr.n_total = (double)N_total;
+      pr.fit_w0 = cfg.fit_w0 ? 1 : 0;
+      pr.reserved = 0;
+      Real w0 = cfg.fit_w0 ? fm.w0 : 0;
+      ck(ctx, mfm_regression_iteration(ctx, &pr, n_in_group.data(), &hyper.alpha, &w0, hyper.lambda_w.data(), hyper.mu_w.data(),
+                                       hyper.lambda_V.data(), hyper.mu_V.data()));
+      fm.w0 = w0;
+      g_device_hyper_iterations++;
+      htl.mark(3);
+      htl.end();
+      return;
+    }
     // every reduction the hyper-parameter updates need, one host synchronisation: sum e / sum e^2 (update_alpha,
     // FMTrainer.hpp:127-145, update_w0 :218-229) and the group sums of w and V (:150-216) -- the latter are taken
     // before update_w / update_V touch w / V, which is where the reference takes them too
@@ -1978,6 +2008,8 @@ PYBIND11_MODULE(_myfm, m) {
   // host-only self-test of the jump-ahead polynomials the parallel generator uses (csrc/mfm_mtjump.hpp) against
   // std::mt19937 itself: tempering is linear, so the relation x_{m+J} = XOR_{g_i = 1} x_{m+i} holds for the
   // engine's outputs too. Returns the number of mismatching outputs among 624 (0 = correct).
+  m.def("device_hyper_iterations", []() { return g_device_hyper_iterations; },
+        "Gibbs iterations of this process whose hyper-parameters were drawn on the device (MYFM_AMD_DEVICE_HYPERS=1)");
   m.def("mt_jump_selftest", [](int blocks_per_wg, int p, unsigned seed) {
     std::vector<uint32_t> tab;
     if (!mfm::mtjump::build_jump_table(blocks_per_wg, p, tab)) return -1;

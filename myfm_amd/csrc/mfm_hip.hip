@@ -214,6 +214,12 @@ struct mfm_ctx {
   int q_stale_factor = -1;      // >= 0: the stored q column is stale, mfm_get_q rebuilds it for this factor first
   BlockOverflow gather_overflow;       // q-cache build: pointers of the relation blocks beyond MAX_BLOCKS
   DevBuf<double> wv_pack, zw_host;  // mfm_sweep_wV: [lambda_w | mu_w | lambda_V | mu_V] of the launch / host-given variates
+  // mfm_regression_iteration: the iteration's hyper-parameters drawn on the device: [alpha, w0, e_shift, -][lambda_w][mu_w]
+  // [lambda_V][mu_V]; what the host hands in ([w0 | mu_w | mu_V] before the draws), the group sizes, the event behind the read-back
+  DevBuf<double> hyp, hyp_in, hyp_ng;
+  std::vector<double> hyp_ng_host;
+  hipEvent_t hyp_ev = nullptr;
+  const double *w0_dev = nullptr;  // non-null while score_train should read the intercept from device memory
   std::vector<double> hs_stage;     // host staging of the packed hyper-parameter copies
   bool slot_sums_valid = false;     // res.sums holds sum e / sum e^2 of the residual that is in slot order right now
   bool res_fills_device = false;  // the persistent sweep takes (nearly) every CU: nothing runs beside it
@@ -579,7 +585,7 @@ static void score_train(mfm_ctx *c, bool subtract_y) {
         TimedLaunch t(c->timing, s, KC_BUILD_VT, 16.0 * c->D * c->K);
         build_vt(s, c->V.p, c->Vt.p, c->D, c->K, c->KS);
       }
-      run_res_score(s, c->timing, c->res, KC_UPDATE_E, c->Vt.p, c->w.p, c->w0, c->K, c->y.p, c->X.nnz);
+      run_res_score(s, c->timing, c->res, KC_UPDATE_E, c->Vt.p, c->w.p, c->w0, c->K, c->y.p, c->X.nnz, c->w0_dev);
       c->e_in_slots = true;
       c->slot_sums_valid = true;
       return;
@@ -596,7 +602,7 @@ static void score_train(mfm_ctx *c, bool subtract_y) {
     // regression on a table that takes the persistent sweep: e = score - y straight in the sweep's slot order, with its sums
     static const bool no_res_score = std::getenv("MFM_NO_RES_SCORE") != nullptr;
     if (subtract_y && c->res.ready && !no_res_score && res_score_supported(c->res, c->K)) {
-      run_res_score(s, c->timing, c->res, KC_UPDATE_E, c->Vt.p, c->w.p, c->w0, c->K, c->y.p, c->X.nnz);
+      run_res_score(s, c->timing, c->res, KC_UPDATE_E, c->Vt.p, c->w.p, c->w0, c->K, c->y.p, c->X.nnz, c->w0_dev);
       c->e_in_slots = true;
       c->slot_sums_valid = true;
       return;
@@ -2079,6 +2085,137 @@ int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambd
   c->e_lost = no_store;
   c->q_stale_factor = f_end - 1;
   if (c->comm.active() && !c->res.peers_model) sync_model_sharded(c, true, f_begin, f_end);
+  MFM_CATCH(ctx)
+}
+
+// ---- a whole regression iteration without the host in its loop (include/myfm_hip.h) -------------------------------------------
+static bool regression_iteration_ready(mfm_ctx *c) {
+  if (!c || !c->finalized || !c->res.ready || c->comm.active() || c->K <= 0 || c->D <= 0) return false;
+  if (std::getenv("MFM_RES_NO_LINEAR") || std::getenv("MFM_RES_EAGER_STORE")) return false;
+  static const bool no_res_score = std::getenv("MFM_NO_RES_SCORE") != nullptr || std::getenv("MFM_NO_MF_SCORE") != nullptr;
+  if (no_res_score || !res_score_supported(c->res, c->K)) return false;
+  if (!(c->e_in_slots && c->slot_sums_valid && c->e_is_residual && !c->e_lost)) return false;  // (update_e's slot-order sums)
+  const auto &r = c->rng;
+  if (!r.programmed || r.produced <= r.acquired || r.n_zw != c->D || r.n_zv != c->D * (int64_t)c->K) return false;
+  return true;
+}
+
+int mfm_regression_iteration_ready(mfm_ctx *ctx) { return regression_iteration_ready(ctx) ? 1 : 0; }
+
+int mfm_regression_iteration(mfm_ctx *ctx, const mfm_hyper_prior *prior, const double *n_in_group, double *alpha, double *w0,
+                             double *lambda_w, double *mu_w, double *lambda_V, double *mu_V) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  mfm_ctx *c = ctx;
+  if (!regression_iteration_ready(c)) throw Error(MFM_ERR_RUNTIME, "mfm_regression_iteration: the context is not ready for it");
+  auto &r = c->rng;
+  const int G = c->G, K = c->K;
+  const size_t nG = (size_t)G, nGK = (size_t)G * K, n_hyp = 4 + 2 * nG + 2 * nGK;
+  if (r.n_hv != (int64_t)(1 + (prior->fit_w0 ? 1 : 0) + 2 * nG + 2 * nGK))
+    throw Error(MFM_ERR_INVALID, "mfm_regression_iteration: the draw program does not have this iteration's hyper variates");
+  hipStream_t s = c->stream;
+  if (c->hyp.n < n_hyp) c->hyp.alloc(n_hyp);
+  if (c->hyp_in.n < 1 + nG + nGK) c->hyp_in.alloc(1 + nG + nGK);
+  if (!c->hyp_ev) MFM_HIP_CHECK(hipEventCreateWithFlags(&c->hyp_ev, hipEventDisableTiming));
+  if (c->hyp_ng.n < nG || c->hyp_ng_host.size() != nG || std::memcmp(c->hyp_ng_host.data(), n_in_group, nG * sizeof(double)) != 0) {
+    c->hyp_ng.alloc(nG);
+    c->hyp_ng_host.assign(n_in_group, n_in_group + nG);
+    MFM_HIP_CHECK(hipMemcpyAsync(c->hyp_ng.p, c->hyp_ng_host.data(), nG * sizeof(double), hipMemcpyHostToDevice, s));
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  // 1. this iteration's random set: the main stream waits for it (no host wait: it was finished an iteration ago)
+  if (r.current >= 0) {
+    auto &prev = r.slot[r.current];
+    MFM_HIP_CHECK(hipEventRecord(prev.free_ev, s));
+    prev.free_valid = true;
+  }
+  auto &sl = r.slot[r.acquired % mfm_ctx::RngEngine::N_SLOTS];
+  MFM_HIP_CHECK(hipStreamWaitEvent(s, sl.ready, 0));
+  r.current = (int)(r.acquired % mfm_ctx::RngEngine::N_SLOTS);
+  r.acquired++;
+  // 2. what the conditionals start from: [w0 | mu_w | mu_V]
+  c->hs_stage.resize(1 + nG + nGK);
+  c->hs_stage[0] = *w0;
+  std::memcpy(c->hs_stage.data() + 1, mu_w, nG * sizeof(double));
+  std::memcpy(c->hs_stage.data() + 1 + nG, mu_V, nGK * sizeof(double));
+  c->ring.upload(c->hyp_in.p, c->hs_stage.data(), c->hs_stage.size() * sizeof(double), s);
+  // 3. the reductions (mfm_hyper_stats without its read-back)
+  const int n_ch = std::max(1, c->gs_chunks);
+  const size_t n_out = 1 + nG * (K + 1);
+  if (c->hs_out.n < n_out) c->hs_out.alloc(n_out);
+  if (c->gs_partial.n < nG * (K + 1) * n_ch) c->gs_partial.alloc(nG * (K + 1) * n_ch);
+  {
+    TimedLaunch t(c->timing, s, KC_GROUP_STATS, 12.0 * c->D * (K + 1));
+    hipLaunchKernelGGL(k_group_stats, dim3(G, 1, n_ch), dim3(WG), 0, s, c->w.p, c->D, c->feat_sorted.p, c->group_ptr.p,
+                       c->hyp_in.p + 1, G, c->gs_partial.p);
+    hipLaunchKernelGGL(k_group_stats, dim3(G, K, n_ch), dim3(WG), 0, s, c->V.p, c->D, c->feat_sorted.p, c->group_ptr.p,
+                       c->hyp_in.p + 1 + nG, G, c->gs_partial.p + nG * n_ch);
+    hipLaunchKernelGGL(k_group_stats_final, dim3(cdiv(G * (K + 1), 64)), dim3(64), 0, s, c->gs_partial.p, G * (K + 1), n_ch,
+                       c->hs_out.p + 1);
+  }
+  {
+    TimedLaunch t(c->timing, s, KC_REDUCE_E, 16.0 * c->res.G);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, s, c->res.sums.p, c->res.G, c->hs_out.p);
+  }
+  // 4. the conditionals
+  HyperPrior P;
+  P.alpha_0 = prior->alpha_0;
+  P.beta_0 = prior->beta_0;
+  P.gamma_0 = prior->gamma_0;
+  P.mu_0 = prior->mu_0;
+  P.reg_0 = prior->reg_0;
+  P.n_total = prior->n_total;
+  P.fit_w0 = prior->fit_w0 ? 1 : 0;
+  P.G = G;
+  P.K = K;
+  P.pad = 0;
+  hipLaunchKernelGGL(k_hyper_regression, dim3(1), dim3(256), 0, s, P, c->hs_out.p, sl.hv.p, c->hyp_ng.p, c->hyp_in.p, c->hyp.p);
+  // 5. their read-back (behind it on the stream: the sweeps -- the host has the draws while those run)
+  double2 *h = c->readback((n_hyp + 3) / 2 + 2);
+  double *hd = (double *)h;
+  MFM_HIP_CHECK(hipMemcpyAsync(hd, c->hyp.p, n_hyp * sizeof(double), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipMemcpyAsync(hd + n_hyp, c->ls.error.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipEventRecord(c->hyp_ev, s));
+  // 6. update_w0's shift + update_w + update_V: the persistent launch with alpha / e_shift read from c->hyp
+  {
+    const bool load_slots = c->e_in_slots;
+    c->slot_sums_valid = false;
+    const double *d_lam_w = c->hyp.p + 4, *d_mu_w = d_lam_w + nG, *d_lam = d_mu_w + nG, *d_mu = d_lam + nGK;
+    const bool no_store = c->e_recomputable && c->e_is_residual && !std::getenv("MFM_RES_ALWAYS_STORE");
+    run_sweep_resident(s, c->timing, c->res, KC_SWEEP_V_RESIDENT, c->eq_raw(), c->V.p, c->D, 0, K, sl.zv.p, d_lam, d_mu, c->group.p,
+                       c->G, 0.0, c->ls.error.p, true, c->w.p, sl.zw.p, d_lam_w, d_mu_w, 0.0, load_slots, no_store, c->hyp.p);
+    c->e_in_slots = !no_store;
+    c->e_lost = no_store;
+    c->q_stale_factor = K - 1;
+  }
+  // 7. the set after the next (gated behind the launch), 8. update_e with the intercept the device has drawn
+  {
+    const int rc = mfm_rng_prefetch(ctx);
+    if (rc != MFM_OK) return rc;
+  }
+  c->w0_dev = c->hyp.p + 1;
+  try {
+    score_train(c, true);
+  } catch (...) {
+    c->w0_dev = nullptr;
+    throw;
+  }
+  c->w0_dev = nullptr;
+  // 9. the draws
+  MFM_HIP_CHECK(hipEventSynchronize(c->hyp_ev));
+  c->check_coresident(*(const int *)(hd + n_hyp));
+  {
+    RngState hdr;
+    std::memcpy(&hdr, sl.h_hv + r.n_hv, 3 * sizeof(double));
+    if (hdr.error) throw Error(MFM_ERR_RUNTIME, "device random stream underflow (generated range exhausted)");
+  }
+  *alpha = hd[0];
+  *w0 = hd[1];
+  c->w0 = hd[1];
+  std::memcpy(lambda_w, hd + 4, nG * sizeof(double));
+  std::memcpy(mu_w, hd + 4 + nG, nG * sizeof(double));
+  std::memcpy(lambda_V, hd + 4 + 2 * nG, nGK * sizeof(double));
+  std::memcpy(mu_V, hd + 4 + 2 * nG + nGK, nGK * sizeof(double));
   MFM_CATCH(ctx)
 }
 

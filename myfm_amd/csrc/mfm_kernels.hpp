@@ -2710,6 +2710,61 @@ __global__ void k_group_stats_final(const double2 *__restrict__ partial, int n, 
   out[i] = make_double2(s, ss);
 }
 
+// The hyper-parameter conditionals of one regression iteration on the device (mfm_regression_iteration): update_alpha
+// (FMTrainer.hpp:127-145), update_w0 (:218-229), update_lambda_w / update_mu_w (:150-200), update_lambda_V / update_mu_V (:202-216)
+// in the order of BaseFMTrainer.hpp:137-148, from the statistics the reduction kernels left in `st` and the iteration's unit
+// variates `hv` (draw program of the trainer: [gamma: alpha][normal: w0][G gammas: lambda_w][G normals: mu_w][K G gammas:
+// lambda_V, factor outer][K G normals: mu_V]). The arithmetic is the host trainer's, operation for operation (a gamma draw is
+// the unit variate times the scale, a normal draw `first / quad + z / sqrt(quad)`), so a chain does not depend on where its
+// hyper-parameters are drawn. out: [alpha, w0', w0' - w0, -][lambda_w][mu_w][lambda_V][mu_V].
+struct HyperPrior {
+  double alpha_0, beta_0, gamma_0, mu_0, reg_0, n_total;
+  int fit_w0, G, K, pad;
+};
+__global__ void k_hyper_regression(HyperPrior P, const double2 *__restrict__ st, const double *__restrict__ hv,
+                                   const double *__restrict__ n_in_group, const double *__restrict__ w0_old,
+                                   double *__restrict__ out) {
+  const int G = P.G, GK = P.G * P.K, t = threadIdx.x;
+  const int o_w0 = 1, o_lw = o_w0 + (P.fit_w0 ? 1 : 0), o_mw = o_lw + G, o_lv = o_mw + G, o_mv = o_lv + GK;
+  double *lam_w = out + 4, *mu_w = lam_w + G, *lam_V = mu_w + G, *mu_V = lam_V + GK;
+  __shared__ double alpha_s;
+  if (t == 0) {
+    const double variance = (P.beta_0 + st[0].y) / 2;  // (exponent (alpha_0 + N) / 2 is the unit variate's shape)
+    alpha_s = hv[0] * (1 / variance);
+    out[0] = alpha_s;
+  }
+  for (int i = t; i < G + GK; i += blockDim.x) {  // lambda: gamma((alpha_0 + n_g) / 2, 2 / (beta_0 + ssd))
+    const bool isw = i < G;
+    const int k = isw ? i : i - G;
+    const double beta = P.beta_0 + st[1 + i].y;
+    const double lam = hv[(isw ? o_lw : o_lv) + k] * (2 / beta);
+    (isw ? lam_w : lam_V)[k] = lam;
+  }
+  __syncthreads();
+  if (t == 0) {
+    const double w0 = w0_old[0];
+    double w0_new = 0.0, shift = 0.0;
+    if (P.fit_w0) {
+      const double lin = alpha_s * (P.n_total * w0 - st[0].x);
+      const double quad = alpha_s * P.n_total + P.reg_0;
+      w0_new = (lin / quad) + hv[o_w0] / sqrt(quad);
+      shift = w0_new - w0;
+    }
+    out[1] = w0_new;
+    out[2] = shift;
+    out[3] = 0.0;
+  }
+  for (int i = t; i < G + GK; i += blockDim.x) {  // mu: normal(lam (gamma_0 + n_g), lam (gamma_0 mu_0 + sum))
+    const bool isw = i < G;
+    const int k = isw ? i : i - G, g = isw ? i : (i - G) % G;
+    const double lam = (isw ? lam_w : lam_V)[k];
+    const double square = lam * (P.gamma_0 + n_in_group[g]);
+    double linear = P.gamma_0 * P.mu_0 + st[1 + i].x;
+    linear *= lam;
+    (isw ? mu_w : mu_V)[k] = (linear / square) + hv[(isw ? o_mw : o_mv) + k] / sqrt(square);
+  }
+}
+
 __global__ void k_set_eq(double2 *__restrict__ eq, const double *__restrict__ src, int64_t N, int which) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) {

@@ -85,6 +85,8 @@ struct ResArgs {
   const int32_t *group;      // per feature
   int n_groups;
   double alpha;
+  const double *scal;        // non-null: alpha = scal[0] and e_shift = scal[2] are read from device memory (mfm_regression_iteration: the
+                             // hyper-parameter draws were made on the device, the host has not seen them when the launch is enqueued)
   int n_items, umax;         // umax: LDS stride of the per-wave accumulator arrays (> users of any workgroup, > items of any slice)
   unsigned long long *bar;   // barrier state (RES_BAR_*), zeroed before the launch
   int n_wg;
@@ -233,6 +235,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
   const int g = (int)((blockIdx.x + (unsigned)a.rot) % gridDim.x), tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int U = a.umax;
+  const double alpha_k = a.scal ? a.scal[0] : a.alpha, e_shift_k = a.scal ? a.scal[2] : a.e_shift;
   const int ngx = OVF ? a.ngx : 0, NGt = NG + ngx, Rt = 16 * NGt;  // groups / slots of a thread in all (the layout arrays' strides)
   double *elds = (double *)res_smem;      // [RL][NT] residual of the LDS-resident slots
   double *acc1 = elds + (size_t)RL * NT;  // [NW][U]  sum of -e h per (wave, user) / (wave, item of the slice)
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       for (int k = 0; k < B; k++) row[k] = a.e_in ? 0 : perm_g[(16 * j + 4 * bb + k) * NT + tid];
 #pragma unroll
       for (int k = 0; k < B; k++) {
-        const double x = (a.e_in ? a.e_in[((int64_t)g * Rt + 16 * j + 4 * bb + k) * NT + tid] : a.eq[row[k] < 0 ? 0 : row[k]].x) + a.e_shift;
+        const double x = (a.e_in ? a.e_in[((int64_t)g * Rt + 16 * j + 4 * bb + k) * NT + tid] : a.eq[row[k] < 0 ? 0 : row[k]].x) + e_shift_k;
         if (j < NGV)
           ev[j < NGV ? j : 0][4 * bb + k] = x;
         else
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
       for (int i = 0; i < 16; i++) {
         const int64_t sl = 16 * (NG + jx) + i;
         const int row = a.e_in ? 0 : perm_g[sl * NT + tid];
-        const double x = (a.e_in ? a.e_in[((int64_t)g * Rt + sl) * NT + tid] : a.eq[row < 0 ? 0 : row].x) + a.e_shift;
+        const double x = (a.e_in ? a.e_in[((int64_t)g * Rt + sl) * NT + tid] : a.eq[row < 0 ? 0 : row].x) + e_shift_k;
         eog[(16 * jx + i) * NT] = x;
       }
     }
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
         acc1[w * U + tid] = 0.0;
         acc2[w * U + tid] = 0.0;
       }
-      const double fresh = PMainV::draw(S1, S2, uold, a.alpha, ulam, umu, uz);
+      const double fresh = PMainV::draw(S1, S2, uold, alpha_k, ulam, umu, uz);
       Vf[uj] = fresh;
       if (XCH && a.xmodel) {  // the other ranks' replicas of this coefficient
         for (int r = 0; r < a.xworld; r++)
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(NT) void k_mf_resident(ResArgs a) {
         }
       }
       if (tid < ni) {
-        const double fresh = PMainV::draw(S1, S2, iold, a.alpha, ilam, imu, iz);
+        const double fresh = PMainV::draw(S1, S2, iold, alpha_k, ilam, imu, iz);
         Vf[ij] = fresh;
         res_store2(a.dv + 2 * (int64_t)(i0 + tid), fresh - iold, ivn);
       }
@@ -910,6 +913,7 @@ struct ResScoreArgs {
   int umax, KS;
   const double *Vt, *w;
   double w0;
+  const double *w0p;  // non-null: the intercept is read from device memory (see ResArgs::scal)
   const double *y_slots;
   double *e_slots;
   double2 *sums;  // [G] {sum e, sum e^2}
@@ -924,6 +928,7 @@ __global__ __launch_bounds__(NT) void k_res_score(ResScoreArgs a) {
   constexpr int US = 2 * KPT + 2;  // doubles per user row in LDS (16-byte aligned, rows shifted by 4 banks)
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int KP = a.KS >> 1;
+  const double w0_k = a.w0p ? *a.w0p : a.w0;
   double *uV = (double *)res_smem;         // [umax][US]
   double *uW = uV + (size_t)a.umax * US;   // [umax]
   double2 *wsum = (double2 *)(uW + ((a.umax + 1) & ~1));  // [NW]
@@ -1038,7 +1043,7 @@ __global__ __launch_bounds__(NT) void k_res_score(ResScoreArgs a) {
           d0 += x0.x * vi[p].x + x0.y * vi[p].y;
           d1 += x1.x * vi[p + 1].x + x1.y * vi[p + 1].y;
         }
-        const double pred = a.w0 + (uW[uid[k]] + wi) + (d0 + d1);
+        const double pred = w0_k + (uW[uid[k]] + wi) + (d0 + d1);
         const bool real = (int64_t)tid * R + slot < fill;
         const double e = real ? pred - yv[k] : 0.0;  // (pads stay finite: 0 * NaN would poison the sweeps' statistics)
         eb[k] = e;
@@ -1612,9 +1617,10 @@ static inline void run_sweep_resident(hipStream_t s, Timing &tm, ResPlan &rp, in
                                       const int32_t *group, int n_groups, double alpha, int *error, bool lazy_store,
                                       double *w = nullptr, const double *zw = nullptr, const double *lam_w = nullptr,
                                       const double *mu_w = nullptr, double e_shift = 0.0, bool load_slots = false,
-                                      bool no_store = false) {
+                                      bool no_store = false, const double *scal = nullptr) {
   ResArgs a;
   std::memset(&a, 0, sizeof(a));
+  a.scal = scal;
   a.eq = eq;
   a.e_slots = (lazy_store || rp.RX) ? rp.e_slots.p : nullptr;  // (overflow slots live there)
   a.ngx = rp.RX / 16;
@@ -1836,7 +1842,7 @@ static inline bool res_score_supported(const ResPlan &rp, int K) {
 }
 
 static inline void run_res_score(hipStream_t s, Timing &tm, ResPlan &rp, int kernel_class, const double *Vt, const double *w,
-                                 double w0, int K, const double *y, int64_t nnz) {
+                                 double w0, int K, const double *y, int64_t nnz, const double *w0p = nullptr) {
   const int KS = (K + 1) & ~1;
   const int64_t n_slots = (int64_t)rp.G * rp.R() * 512;
   if (!rp.y_slots.p) {
@@ -1857,6 +1863,7 @@ static inline void run_res_score(hipStream_t s, Timing &tm, ResPlan &rp, int ker
   a.Vt = Vt;
   a.w = w;
   a.w0 = w0;
+  a.w0p = w0p;
   a.y_slots = rp.y_slots.p;
   a.e_slots = rp.e_slots.p;
   a.sums = rp.sums.p;

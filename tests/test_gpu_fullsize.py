@@ -127,6 +127,7 @@ def test_config5_full_size_n50m_rank64(capi, oracle):
     X_rows = sps.hstack([main[rows]] + [B[m[rows]] for m, B in blocks]).tocsr()
     np.testing.assert_allclose(e_new[rows], ds.fm_score(X_rows, w0, w, V) - y[rows], rtol=1e-9, atol=1e-9)
     assert c.plan_flags()["cell"]  # update_V on index tuples (mfm_cell.hpp)
+    assert c.plan_flags()["streamed_chain"]  # the big blocks' feature sweeps as one pipelined launch each (mfm_chain_stream.hpp)
     del drv, seen, e_new
     # ---- the same twin against the ORACLE at this size: a whole oracle iteration is ~2 minutes, but update_w and the first
     # factor of update_V (FMTrainer.hpp:231-313, :315-482 for f = 0) are seconds after the oracle's ~40 s of setup
