@@ -14,6 +14,13 @@ from .gibbs_driver import CapiGibbs
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _small_tables_take_the_persistent_sweep(monkeypatch):
+    """The persistent sweep is the default from 2^20 rows on; these tests mean to cover it on small tables whatever mode the suite
+    runs in (conftest sets the same for the checker mode; MYFM_TEST_PRODUCTION=1 does not)."""
+    monkeypatch.setenv("MFM_RES_MIN_ROWS", "0")
+
+
 @pytest.fixture(scope="module")
 def capi():
     from myfm_amd import _capi

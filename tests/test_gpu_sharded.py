@@ -13,6 +13,13 @@ from . import datasets as ds
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _small_tables_take_the_persistent_sweep(monkeypatch):
+    """The persistent sweep is the default from 2^20 rows on; these tests mean to cover it on small tables whatever mode the suite
+    runs in (conftest sets the same for the checker mode; MYFM_TEST_PRODUCTION=1 does not)."""
+    monkeypatch.setenv("MFM_RES_MIN_ROWS", "0")
+
+
 def _config(gi, n_iter=8, task=None):
     from myfm_amd import _myfm
 
