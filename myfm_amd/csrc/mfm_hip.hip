@@ -2561,6 +2561,15 @@ int mfm_rng_prefetch(mfm_ctx *ctx) {
     throw Error(MFM_ERR_RUNTIME, "every random set is in use (one acquired, the others in flight): acquire the next one first");
   auto &sl = r.slot[r.produced % mfm_ctx::RngEngine::N_SLOTS];
   hipStream_t s = r.stream;
+  {  // (timing experiment, wrong results: after the first sets nothing is generated any more -- what the iteration costs without the
+     //  random stream's work)
+    static const bool reuse = std::getenv("MFM_RNG_DBG_REUSE") != nullptr;
+    if (reuse && r.produced >= 2 * mfm_ctx::RngEngine::N_SLOTS) {
+      MFM_HIP_CHECK(hipEventRecord(sl.ready, s));
+      r.produced++;
+      return MFM_OK;
+    }
+  }
   // (the gate only where the persistent sweep fills the device: a small table's launch leaves most CUs free, and there the
   //  generator should run beside it -- ML-100k shape: 2700 it/s gated, 3000 not)
   static const bool no_gate = std::getenv("MFM_RES_NO_GATE") != nullptr;  // (experiments with CUs left free by MFM_RES_CUS)
