@@ -66,16 +66,40 @@ def workload(cfg, a):
     raise SystemExit("--config must be 2, 3, 4 or 5")
 
 
-def make_config(_myfm, gi, n_iter, n_kept, task, n_rows):
+def make_config(_myfm, gi, n_iter, n_kept, task, n_rows, latent=None):
     b = _myfm.ConfigBuilder()
     b.set_alpha_0(1.0).set_beta_0(1.0).set_gamma_0(1.0).set_mu_0(0.0).set_reg_0(1.0)
     b.set_group_index([int(g) for g in gi]).set_n_iter(n_iter).set_n_kept_samples(n_kept)
     if task == "ordered":
         b.set_task_type(_myfm.TaskType.ORDERED)
         b.set_cutpoint_groups([(5, np.arange(n_rows))])
+    elif task == "classification":
+        b.set_task_type(_myfm.TaskType.CLASSIFICATION)
     else:
         b.set_task_type(_myfm.TaskType.REGRESSION)
+    if latent is not None:  # the latent-draw mode of classification / ordered probit: "exact" | "host" | "philox"
+        b.set_latent_mode(latent)
     return b.build()
+
+
+def retarget(W, task):
+    """--task: the same design with the target of another task type (BASELINE.md 1 quotes classification and ordered-probit
+    rates of the reference next to regression): probit labels y > 3.5, ordered classes round(y) - 1 in 0..4."""
+    if task is None or task == W["task"]:
+        return W
+    y = np.asarray(W["y"], dtype=np.float64)
+    if W["task"] != "regression":
+        raise SystemExit("--task: only the regression workloads (configs 2, 3, 4) can be retargeted")
+    W = dict(W)
+    if task == "classification":
+        W["y"] = np.where(y > 3.5, 1.0, -1.0)
+    elif task == "ordered":
+        W["y"] = (np.clip(np.round(y), 1, 5) - 1).astype(np.float64)
+    else:
+        raise SystemExit("--task must be regression, classification or ordered")
+    W["task"] = task
+    W["name"] = W["name"] + " [target of task %s]" % task
+    return W
 
 
 def cpu_baseline(W, gi, min_seconds, max_iters):
@@ -184,6 +208,9 @@ def main():
     ap.add_argument("--peer-exchange", action="store_true", help="N > 1, config 3: the persistent sweep row-sharded with the ranks' item sums "
                     "exchanged inside the launch (never run on two physical GPUs yet: opt-in; a trial of three iterations decides)")
     ap.add_argument("--no-other-configs", action="store_true", help="default run (config 3, 1 GPU): skip the other_configs legs")
+    ap.add_argument("--task", default=None, help="regression | classification | ordered: the config's design with another task's target")
+    ap.add_argument("--latent", default=None, help="latent draws of classification / ordered probit: exact (the reference's own stream, "
+                    "draw for draw, evaluated on the device) | host (the same on the host) | philox (per-row streams)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(a.gpus))
@@ -236,7 +263,7 @@ def main():
     from myfm_amd.utils import synthetic as ds
 
     t0 = time.time()
-    W = workload(a.config, a)
+    W = retarget(workload(a.config, a), a.task)
     X, y, blocks, K = W["X"], W["y"], W["blocks"], W["rank"]
     gi = ds.group_index_from_shapes(W["shapes"])
     N, D0, nnz = X.shape[0], X.shape[1], X.nnz
@@ -250,7 +277,7 @@ def main():
     if not sharded:
         rels = [_myfm.RelationBlock(np.asarray(m, dtype=np.int64), B) for m, B in blocks]
         t1 = time.time()
-        cfg1 = make_config(_myfm, gi, a.steps + a.warmup + 8, 0, W["task"], N)
+        cfg1 = make_config(_myfm, gi, a.steps + a.warmup + 8, 0, W["task"], N, a.latent)
         t2 = time.time()
         sess = _myfm.GibbsSession(K, 0.1, X, rels, y, 42, cfg1)
         if os.environ.get("MFM_SETUP_TIMING"):
@@ -265,7 +292,7 @@ def main():
         cuts = mdist.shard_cuts(X.indices[X.indptr[:-1]], world)
         lo, hi = cuts[rank], cuts[rank + 1]
         rels = [_myfm.RelationBlock(np.asarray(m, dtype=np.int64)[lo:hi], B) for m, B in blocks]
-        cfg = make_config(_myfm, gi, a.steps + a.warmup + 12, 0, W["task"], hi - lo)
+        cfg = make_config(_myfm, gi, a.steps + a.warmup + 12, 0, W["task"], hi - lo, a.latent)
 
         def make_session():
             sess, err = None, ""

@@ -162,7 +162,14 @@ struct FMLearningConfig {
   // come from per-row Philox streams (same law, different numbers). ConfigBuilder.set_exact_latent_draws; the environment
   // variable MYFM_AMD_HOST_RNG=1 forces it for every fit of the process.
   bool exact_latent_draws = false;
-  bool host_rng() const { return exact_latent_draws || std::getenv("MYFM_AMD_HOST_RNG") != nullptr; }
+  // latent_mode (ConfigBuilder.set_latent_mode): 0 "philox" = per-row Philox streams (distributional parity); 1 "host" = the
+  // trainer's std::mt19937 stays on the host for every variate of the fit; 2 "exact" = the generator lives on the device as for
+  // regression and the latent draws consume ITS stream in the reference's order, evaluated in parallel on the device
+  // (csrc/mfm_latent.hpp: coalescing flows) -- the same chain as mode 1 draw for draw. set_exact_latent_draws(true) selects
+  // mode 2 (MYFM_AMD_EXACT_ON_HOST=1: mode 1).
+  int latent_mode = 0;
+  bool host_rng() const { return latent_mode == 1 || std::getenv("MYFM_AMD_HOST_RNG") != nullptr; }
+  bool exact_dev() const { return latent_mode == 2 && !host_rng() && task_type != TaskType::REGRESSION; }
 
   // FMLearningConfig.hpp:17-57
   FMLearningConfig(Real alpha_0, Real beta_0, Real gamma_0, Real mu_0, Real reg_0, TaskType task_type, Real nu_oprobit,
@@ -200,8 +207,16 @@ struct ConfigBuilder {
   Real cutpoint_scale = 10;
   CutpointGroupType cutpoint_groups;
   bool exact_latent_draws = false;  // (see FMLearningConfig::exact_latent_draws)
+  int latent_mode = -1;             // -1: follows exact_latent_draws
 
   ConfigBuilder &set_exact_latent_draws(bool a) { exact_latent_draws = a; return *this; }
+  ConfigBuilder &set_latent_mode(const std::string &m) {
+    if (m == "philox") latent_mode = 0;
+    else if (m == "host") latent_mode = 1;
+    else if (m == "exact") latent_mode = 2;
+    else throw std::invalid_argument("latent mode must be \"philox\", \"host\" or \"exact\"");
+    return *this;
+  }
   ConfigBuilder &set_alpha_0(Real a) { alpha_0 = a; return *this; }
   ConfigBuilder &set_beta_0(Real a) { beta_0 = a; return *this; }
   ConfigBuilder &set_gamma_0(Real a) { gamma_0 = a; return *this; }
@@ -221,6 +236,7 @@ struct ConfigBuilder {
     FMLearningConfig c(alpha_0, beta_0, gamma_0, mu_0, reg_0, task_type, nu_oprobit, fit_w0, fit_linear, group_index, n_iter,
                        n_kept_samples, cutpoint_scale, cutpoint_groups);
     c.exact_latent_draws = exact_latent_draws;
+    c.latent_mode = latent_mode >= 0 ? latent_mode : (exact_latent_draws ? (std::getenv("MYFM_AMD_EXACT_ON_HOST") ? 1 : 2) : 0);
     return c;
   }
 };
@@ -1684,6 +1700,7 @@ PYBIND11_MODULE(_myfm, m) {
       .def("set_identical_groups", &ConfigBuilder::set_identical_groups)
       .def("set_cutpoint_scale", &ConfigBuilder::set_cutpoint_scale)
       .def("set_exact_latent_draws", &ConfigBuilder::set_exact_latent_draws, py::return_value_policy::reference_internal)
+      .def("set_latent_mode", &ConfigBuilder::set_latent_mode, py::return_value_policy::reference_internal)
       .def("set_cutpoint_groups",
            // [(n_class, row indices)]: the reference's list-of-lists (declare_module.hpp:139-156), and numpy index arrays
            // without a per-element Python conversion (5e7 rows at config 5)

@@ -26,9 +26,10 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "mfm_rng_state.hpp"
+
 namespace mfm {
 
-constexpr int MT_N = 624, MT_M = 397;
 #ifndef MFM_RNG_CONSUME_THREADS
 #define MFM_RNG_CONSUME_THREADS 1024
 #endif
@@ -46,21 +47,6 @@ struct RngOp {
   double shape;   // GAMMA: alpha
 };
 
-struct RngState {
-  uint64_t p_gen;   // absolute index of the next output to generate
-  uint64_t p_cons;  // absolute index of the next output to consume
-  int32_t error;    // 1: the consumer ran past the generated range
-  int32_t mt_pos;   // libstdc++ _M_p
-  uint32_t mt[MT_N];
-};
-
-__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
-  y ^= (y >> 11);
-  y ^= (y << 7) & 0x9d2c5680u;
-  y ^= (y << 15) & 0xefc60000u;
-  y ^= (y >> 18);
-  return y;
-}
 __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c) {
   const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
   return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
@@ -291,14 +277,6 @@ __global__ void k_mt_commit(RngState *__restrict__ st, const RngState *__restric
     st->mt_pos = st_next->mt_pos;
     st->p_gen = st_next->p_gen;
   }
-}
-
-// generate_canonical<double, 53>(mt19937): low word first, sum rounded to nearest, / 2^64
-__device__ __forceinline__ double canonical(uint32_t lo, uint32_t hi) {
-  const double sum = (double)lo + (double)hi * 4294967296.0;
-  double ret = sum * (1.0 / 18446744073709551616.0);
-  if (ret >= 1.0) ret = 0.99999999999999988898;  // nextafter(1, 0)
-  return ret;
 }
 
 struct RawReader {
