@@ -252,8 +252,11 @@ int mfm_oprobit_sample_z(mfm_ctx *ctx, int32_t group, const double *gamma, uint6
  *     make its z buffers the ones mfm_sweep_w / mfm_sweep_V use when called with z == NULL.      */
 #define MFM_RNG_NORMALS 0
 #define MFM_RNG_GAMMA 1
+/* MFM_RNG_LATENT(count = rows): not a draw of the set -- tells the generator that every iteration also consumes about 6 outputs per
+ * row through mfm_update_e_classification_exact / mfm_oprobit_sample_z_exact (sizes the ring and the parallel generator).        */
+#define MFM_RNG_LATENT 2
 typedef struct mfm_rng_op {
-  int32_t kind;   /* MFM_RNG_NORMALS | MFM_RNG_GAMMA                       */
+  int32_t kind;   /* MFM_RNG_NORMALS | MFM_RNG_GAMMA | MFM_RNG_LATENT      */
   int32_t dest;   /* 0 hyper variates, 1 z_w, 2 z_V                        */
   int64_t count;  /* NORMALS: number of draws; GAMMA: 1                    */
   int64_t offset; /* first index in the destination                        */
@@ -269,6 +272,27 @@ int mfm_rng_prefetch(mfm_ctx *ctx);
 int mfm_rng_acquire(mfm_ctx *ctx, double *hyper_variates, int64_t n_hyper_variates);
 /* test hook: the z buffers of the acquired set (zw[D], zv[K*D]); either pointer may be NULL. */
 int mfm_rng_get_z(mfm_ctx *ctx, double *zw, double *zv);
+
+/* ---- the draws the reference makes in a state-dependent order, on the SAME device stream ("exact" latent mode) ----
+ * The latent z of probit classification (FMTrainer.hpp:498-512) and ordered probit (OProbitSampler.hpp:238-272) consume the
+ * generator row after row inside rejection loops (util.hpp:15-60). These two entry points make exactly those draws from the
+ * stream's current position -- same variates for the same rows, same number of engine outputs consumed -- evaluated in parallel
+ * (csrc/mfm_latent.hip). No set may be in flight (acquire what was prefetched first); the next mfm_rng_prefetch starts where
+ * the draw ended. *status: 0 = done. Otherwise NOTHING was drawn or consumed (e still holds the scores) and the caller makes
+ * the draws sequentially through mfm_rng_host_read / mfm_rng_host_advance: 1 = the true path left a chunk's window of
+ * candidate rows (probability ~1e-6 per call), 2 / 3 = scratch space, 4 = more engine outputs needed than prepared.
+ * mfm_update_e_classification_exact = FM::predict_score_write_target + the draws (the exact twin of
+ * mfm_update_e_classification); mfm_oprobit_sample_z_exact = sample_z_given_cutpoint for one cutpoint group on the current e. */
+int mfm_update_e_classification_exact(mfm_ctx *ctx, int32_t *status);
+int mfm_oprobit_sample_z_exact(mfm_ctx *ctx, int32_t group, const double *gamma, int32_t *status);
+/* diagnostics of the last exact draw: {status, chunks, sub-chunks per chunk, quads per chunk, quads consumed, walkers started} */
+int mfm_latent_stats(mfm_ctx *ctx, int64_t *out6);
+/* The host's window into the device stream: out[0..n) = the engine outputs (tempered, as std::mt19937::operator() returns them)
+ * number offset .. offset + n - 1 counted from the stream's position; mfm_rng_host_advance moves the position by `words` outputs.
+ * For the few draws the host makes itself between two sets (the cutpoint sampler's Metropolis step, OProbitSampler.hpp:55-72,
+ * :378) and for the sequential fall-back of the two calls above. No set may be in flight.                                      */
+int mfm_rng_host_read(mfm_ctx *ctx, uint64_t offset, int64_t n, uint32_t *out);
+int mfm_rng_host_advance(mfm_ctx *ctx, uint64_t words);
 
 /* ---- per-kernel timing (HIP events on the ctx stream) for bench.py's roofline block ---- */
 int mfm_timing_enable(mfm_ctx *ctx, int on);

@@ -18,7 +18,8 @@ PYMOD = os.path.join(HERE, "_myfm" + EXT_SUFFIX)
 HIP_UNITS = {
     "mfm_hip.hip": ["mfm_common.hpp", "mfm_wave.hpp", "mfm_policies.hpp", "mfm_kernels.hpp", "mfm_mf_kernels.hpp", "mfm_res.hpp", "mfm_res_plan.hpp",
                     "mfm_plan.hpp", "mfm_block_kernels.hpp", "mfm_tasks.hpp", "mfm_predict.hpp", "mfm_rng.hpp", "mfm_mtjump.hpp", "mfm_cell.hpp",
-                    "mfm_chain_api.hpp"],
+                    "mfm_chain_api.hpp", "mfm_rng_state.hpp", "mfm_latent_api.hpp", "mfm_latent_host.hpp"],
+    "mfm_latent.hip": ["mfm_common.hpp", "mfm_rng_state.hpp", "mfm_latent_api.hpp"],
     "mfm_cell.hip": ["mfm_common.hpp", "mfm_wave.hpp", "mfm_cell.hpp"],
     "mfm_chain.hip": ["mfm_common.hpp", "mfm_wave.hpp", "mfm_policies.hpp", "mfm_chain_api.hpp", "mfm_chain_plan.hpp", "mfm_chain_stream.hpp"],
 }

@@ -32,6 +32,7 @@ SYMBOLS = [
     "mfm_comm_stats", "mfm_comm_info", "mfm_store_create", "mfm_store_destroy", "mfm_store_last_error", "mfm_store_size", "mfm_store_push_ctx",
     "mfm_store_push_host", "mfm_store_get", "mfm_design_predict_store", "mfm_store_reserve", "mfm_cs_plan_selftest",
     "mfm_regression_iteration_ready", "mfm_regression_iteration",
+    "mfm_update_e_classification_exact", "mfm_oprobit_sample_z_exact", "mfm_latent_stats", "mfm_rng_host_read", "mfm_rng_host_advance",
 ]
 
 _lib = None
@@ -122,6 +123,11 @@ def lib():
     L.mfm_rng_prefetch.argtypes = [vp]
     L.mfm_rng_acquire.argtypes = [vp, P, i64]
     L.mfm_rng_get_z.argtypes = [vp, P, P]
+    L.mfm_update_e_classification_exact.argtypes = [vp, C.POINTER(i32)]
+    L.mfm_oprobit_sample_z_exact.argtypes = [vp, i32, P, C.POINTER(i32)]
+    L.mfm_latent_stats.argtypes = [vp, P]
+    L.mfm_rng_host_read.argtypes = [vp, u64, i64, P]
+    L.mfm_rng_host_advance.argtypes = [vp, u64]
     L.mfm_design_score_ctx.argtypes = [vp, vp, P]
     L.mfm_design_n_rows.restype = i64
     L.mfm_design_n_rows.argtypes = [vp]
@@ -390,6 +396,31 @@ class Context:
         zw, zv = np.empty(self.D), np.empty((max(self.K, 1), self.D))
         self._ck(lib().mfm_rng_get_z(self.h, _p(zw), _p(zv)))
         return zw, zv[: self.K]
+
+    # --- the state-dependent draws on the same stream (latent mode "exact")
+    def update_e_classification_exact(self):
+        st = C.c_int32()
+        self._ck(lib().mfm_update_e_classification_exact(self.h, C.byref(st)))
+        return st.value
+
+    def oprobit_sample_z_exact(self, group, gamma):
+        gamma = _f64(gamma)
+        st = C.c_int32()
+        self._ck(lib().mfm_oprobit_sample_z_exact(self.h, group, _p(gamma), C.byref(st)))
+        return st.value
+
+    def latent_stats(self):
+        out = np.zeros(6, dtype=np.int64)
+        self._ck(lib().mfm_latent_stats(self.h, _p(out)))
+        return dict(zip(("status", "chunks", "subs", "lq", "quads", "walkers"), (int(v) for v in out)))
+
+    def rng_host_read(self, offset, n):
+        out = np.empty(max(int(n), 1), dtype=np.uint32)
+        self._ck(lib().mfm_rng_host_read(self.h, int(offset), int(n), _p(out)))
+        return out[: int(n)]
+
+    def rng_host_advance(self, words):
+        self._ck(lib().mfm_rng_host_advance(self.h, int(words)))
 
     def set_residual_policy(self, recomputable):
         self._ck(lib().mfm_set_residual_policy(self.h, 1 if recomputable else 0))

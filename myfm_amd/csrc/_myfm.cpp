@@ -685,7 +685,47 @@ Real norm2(const vector<Real> &v) {
 // exact_latent_draws (ConfigBuilder.set_exact_latent_draws / MYFM_AMD_HOST_RNG=1) ONLY: there the latent draws of probit classification / ordered probit consume the generator row
 // after row exactly as the reference does (FMTrainer.hpp:498-521, OProbitSampler.hpp:238-272), so that those chains can
 // be compared with the CPU sampler draw for draw. The product path draws them on the device (mfm_tasks.hpp).
-static Real host_tn_left(std::mt19937 &gen, Real mu_minus) {  // util.hpp:15-38
+// The host's window into the DEVICE random stream (latent mode "exact", include/myfm_hip.h mfm_rng_host_read / _advance): the engine
+// outputs from the stream's position on, fetched in growing pieces; commit() moves the device position past what was consumed.
+struct DeviceStreamWindow {
+  mfm_ctx *ctx = nullptr;
+  vector<uint32_t> buf;
+  size_t pos = 0;
+  uint64_t base = 0;   // outputs consumed before buf[0]
+  size_t piece = 4096;
+  explicit DeviceStreamWindow(mfm_ctx *c) : ctx(c) {}
+  uint32_t next() {
+    if (pos == buf.size()) {
+      base += buf.size();
+      buf.resize(piece);
+      ck(ctx, mfm_rng_host_read(ctx, base, (int64_t)piece, buf.data()));
+      pos = 0;
+      piece = std::min<size_t>(piece * 4, (size_t)1 << 24);
+    }
+    return buf[pos++];
+  }
+  uint64_t consumed() const { return base + pos; }
+  void commit() {
+    ck(ctx, mfm_rng_host_advance(ctx, consumed()));
+    buf.clear();
+    pos = 0;
+    base = 0;
+    piece = 4096;
+  }
+};
+// UniformRandomBitGenerator over the trainer's host std::mt19937 or over the device stream: libstdc++'s distributions take two
+// 32-bit outputs per generate_canonical<double, 53> from either (same range as std::mt19937), so the variates are the same.
+struct StreamEngine {
+  typedef uint32_t result_type;
+  static constexpr result_type min() { return 0u; }
+  static constexpr result_type max() { return 0xffffffffu; }
+  std::mt19937 *host = nullptr;
+  DeviceStreamWindow *dev = nullptr;
+  result_type operator()() { return host ? (result_type)(*host)() : dev->next(); }
+};
+
+template <class Gen>
+static Real host_tn_left(Gen &gen, Real mu_minus) {  // util.hpp:15-38
   if (mu_minus < 0) {
     std::normal_distribution<Real> dist(0, 1);
     for (;;) {
@@ -702,7 +742,8 @@ static Real host_tn_left(std::mt19937 &gen, Real mu_minus) {  // util.hpp:15-38
     if (u < rho) return z;
   }
 }
-static Real host_tn_twoside(std::mt19937 &gen, Real mu_minus, Real mu_plus) {  // util.hpp:40-62
+template <class Gen>
+static Real host_tn_twoside(Gen &gen, Real mu_minus, Real mu_plus) {  // util.hpp:40-62
   std::uniform_real_distribution<Real> proposal(mu_minus, mu_plus);
   std::uniform_real_distribution<Real> acceptance(0, 1);
   for (;;) {
@@ -718,11 +759,14 @@ static Real host_tn_twoside(std::mt19937 &gen, Real mu_minus, Real mu_plus) {  /
     if (u < rho) return z;
   }
 }
-static Real host_tn_left(std::mt19937 &gen, Real mean, Real sd, Real mu_minus) {  // :63-68
+template <class Gen>
+static Real host_tn_left(Gen &gen, Real mean, Real sd, Real mu_minus) {  // :63-68
   return mean + sd * host_tn_left(gen, (mu_minus - mean) / sd);
 }
-static Real host_tn_right(std::mt19937 &gen, Real mu_plus) { return -host_tn_left(gen, -mu_plus); }  // :70-73
-static Real host_tn_right(std::mt19937 &gen, Real mean, Real sd, Real mu_plus) {                      // :75-79
+template <class Gen>
+static Real host_tn_right(Gen &gen, Real mu_plus) { return -host_tn_left(gen, -mu_plus); }  // :70-73
+template <class Gen>
+static Real host_tn_right(Gen &gen, Real mean, Real sd, Real mu_plus) {                      // :75-79
   return mean + sd * host_tn_right(gen, (mu_plus - mean) / sd);
 }
 
@@ -731,12 +775,12 @@ struct OprobitSampler {
   int group;  // device-side cutpoint group
   int K;
   Real reg, nu;
-  std::mt19937 *rng;
+  StreamEngine rng;  // the trainer's host generator, or the device stream (latent mode "exact")
   vector<Real> alpha_now, gamma_now, H;
   size_t accept_count = 0;
 
-  OprobitSampler(mfm_ctx *ctx, int group, int K, std::mt19937 &rng, Real reg, Real nu)
-      : ctx(ctx), group(group), K(K), reg(reg), nu(nu), rng(&rng) {
+  OprobitSampler(mfm_ctx *ctx, int group, int K, StreamEngine rng, Real reg, Real nu)
+      : ctx(ctx), group(group), K(K), reg(reg), nu(nu), rng(rng) {
     alpha_now.assign(K - 1, 0);
     gamma_now.assign(K - 1, 0);
     alpha_to_gamma(gamma_now, alpha_now);
@@ -773,7 +817,7 @@ struct OprobitSampler {
     vector<Real> result(m);
     std::normal_distribution<Real> base_dist(0, 1);
     std::gamma_distribution<Real> chi_gen(nu_ / 2);
-    for (int i = 0; i < m; i++) result[i] = base_dist(*rng);
+    for (int i = 0; i < m; i++) result[i] = base_dist(rng);
     vector<Real> L;
     cholesky_lower(Si, m, L);
     for (int i = m - 1; i >= 0; i--) {
@@ -781,7 +825,7 @@ struct OprobitSampler {
       for (int k = i + 1; k < m; k++) s -= L[(size_t)k * m + i] * result[k];
       result[i] = s / L[(size_t)i * m + i];
     }
-    Real denom = std::sqrt(chi_gen(*rng) * 2 / nu_);
+    Real denom = std::sqrt(chi_gen(rng) * 2 / nu_);
     for (auto &r : result) r /= denom;
     return result;
   }
@@ -917,7 +961,7 @@ struct OprobitSampler {
     Real lpc = log_p_mvt(H, alpha_hat, nu, alpha_candidate);
     Real lpo = log_p_mvt(H, alpha_hat, nu, alpha_now);
     Real test_ratio = std::exp(ll_candidate - lpc - ll_old + lpo);
-    Real u = std::uniform_real_distribution<Real>{0, 1}(*rng);
+    Real u = std::uniform_real_distribution<Real>{0, 1}(rng);
     if (u < test_ratio) {
       alpha_now = alpha_candidate;
       alpha_to_gamma(gamma_now, alpha_now);
@@ -926,12 +970,19 @@ struct OprobitSampler {
     }
     return false;
   }
-  // exact_latent_draws: the group's rows in the reference's order and the targets
+  // exact latent draws: the group's rows in the reference's order and the targets
   const vector<size_t> *host_rows = nullptr;
   const vector<Real> *host_y = nullptr;
   int64_t host_n = 0;
+  bool exact_dev = false;         // latent mode "exact": the draws are made on the device from its own stream
+  int64_t exact_fallbacks = 0;    // ... draws that took the sequential loop instead (a window of the parallel evaluation missed)
   void sample_z_given_cutpoint(uint64_t seed, uint64_t draw) {  // :238-272
-    if (!host_rows) {  // on the device
+    if (exact_dev) {
+      int32_t st = 0;
+      ck(ctx, mfm_oprobit_sample_z_exact(ctx, group, gamma_now.data(), &st));
+      if (st == 0) return;
+      exact_fallbacks++;  // nothing was drawn or consumed: the same draws row after row, below, from the same stream position
+    } else if (!host_rows) {  // per-row Philox streams on the device
       ck(ctx, mfm_oprobit_sample_z(ctx, group, gamma_now.data(), seed, draw));
       return;
     }
@@ -943,14 +994,15 @@ struct OprobitSampler {
       const Real pred = e[t];
       Real z_new;
       if (c == 0)
-        z_new = deviation * host_tn_right(*rng, (gamma_now[c] - pred) / deviation) + pred;
+        z_new = deviation * host_tn_right(rng, (gamma_now[c] - pred) / deviation) + pred;
       else if (c == K - 1)
-        z_new = deviation * host_tn_left(*rng, (gamma_now[K - 2] - pred) / deviation) + pred;
+        z_new = deviation * host_tn_left(rng, (gamma_now[K - 2] - pred) / deviation) + pred;
       else
-        z_new = deviation * host_tn_twoside(*rng, (gamma_now[c - 1] - pred) / deviation, (gamma_now[c] - pred) / deviation) + pred;
+        z_new = deviation * host_tn_twoside(rng, (gamma_now[c - 1] - pred) / deviation, (gamma_now[c] - pred) / deviation) + pred;
       e[t] -= z_new;
     }
     ck(ctx, mfm_set_e(ctx, e.data()));
+    if (exact_dev) rng.dev->commit();
   }
 };
 
@@ -1004,6 +1056,8 @@ struct FMTrainer {
   vector<Real> n_in_group;
   vector<OprobitSampler> cutpoint_sampler;
   uint64_t latent_draws = 0;  // Philox draw index of the device-side truncated-normal draws
+  std::unique_ptr<DeviceStreamWindow> dwin;  // latent mode "exact": the host's draws from the device stream
+  int64_t exact_fallbacks = 0;               // ... classification draws that took the sequential loop
   int K = -1;
   vector<Real> zbuf;
   // device-side random stream (include/myfm_hip.h "device-side random stream"): the generator is handed
@@ -1163,7 +1217,7 @@ struct FMTrainer {
   // generator (gen_mh_, forked from gen_ before the hand-over): for those tasks parity with the
   // reference is distributional anyway.
   void start_device_rng(int Kf) {
-    if (cfg.host_rng()) return;
+    if (cfg.host_rng() || device_rng) return;
     std::ostringstream os;
     os << gen_;
     std::istringstream is(os.str());
@@ -1193,11 +1247,18 @@ struct FMTrainer {
       normals_hv((int64_t)G * Kf);                                                // update_mu_V
       if (dim_all) ops.push_back(mfm_rng_op{MFM_RNG_NORMALS, 2, (int64_t)dim_all * Kf, 0, 0.0});  // update_V
     }
+    // latent mode "exact": the latent draws consume the same stream after every set (about 1.4 quads of 4 outputs per row)
+    if (cfg.exact_dev()) ops.push_back(mfm_rng_op{MFM_RNG_LATENT, 0, N, 0, 0.0});
     ck(ctx, mfm_rng_set_program(ctx, ops.data(), (int32_t)ops.size()));
     hv.assign((size_t)n, 0);
+    device_rng = true;
+    if (cfg.exact_dev()) return;     // (the first set starts where initialize_e's draws end: first_set())
     ck(ctx, mfm_rng_prefetch(ctx));  // the first iteration's set and the second's (update_all keeps two ahead)
     ck(ctx, mfm_rng_prefetch(ctx));
-    device_rng = true;
+  }
+  // latent mode "exact": ONE set in flight, requested where the stream stands after the state-dependent draws
+  void first_set() {
+    if (cfg.exact_dev() && device_rng) ck(ctx, mfm_rng_prefetch(ctx));
   }
 
   void initialize_hyper(Hyper &hyper) {  // FMTrainer.hpp:89-97
@@ -1239,12 +1300,19 @@ struct FMTrainer {
         vector<int64_t> rows;
         if (!all_rows) rows.assign(c.second.begin(), c.second.end());
         ck(ctx, mfm_oprobit_add_group(ctx, (int32_t)c.first, all_rows ? nullptr : rows.data(), (int64_t)c.second.size(), &g));
-        cutpoint_sampler.emplace_back(ctx, g, (int)c.first, cfg.host_rng() ? gen_ : gen_mh_, cfg.reg_0,
-                                      cfg.nu_oprobit);
-        if (cfg.host_rng()) {  // exact_latent_draws: latent draws on the host, in the reference's row order
+        StreamEngine eng;
+        if (cfg.exact_dev()) {  // the cutpoint sampler's own draws come from the device stream too (between two sets)
+          if (!dwin) dwin.reset(new DeviceStreamWindow(ctx));
+          eng.dev = dwin.get();
+        } else {
+          eng.host = cfg.host_rng() ? &gen_ : &gen_mh_;
+        }
+        cutpoint_sampler.emplace_back(ctx, g, (int)c.first, eng, cfg.reg_0, cfg.nu_oprobit);
+        if (cfg.host_rng() || cfg.exact_dev()) {  // exact latent draws: the rows in the reference's order (host loop / its fall-back)
           cutpoint_sampler[i].host_rows = &c.second;
           cutpoint_sampler[i].host_y = &y;
           cutpoint_sampler[i].host_n = N;
+          cutpoint_sampler[i].exact_dev = cfg.exact_dev();
         }
         cutpoint_sampler[i].start_sample();
         OprobitSampler::alpha_to_gamma(fm.cutpoints[i], cutpoint_sampler[i].alpha_now);
@@ -1412,22 +1480,37 @@ struct FMTrainer {
     // the variates of the iteration after the next: generated on the side stream from the end of this iteration's latent
     // sweep on (the persistent sweep leaves no CU to anything else), next to update_e and the start of the next iteration
     htl.mark(3);
-    if (device_rng) ck(ctx, mfm_rng_prefetch(ctx));
+    const bool exact = cfg.exact_dev() && device_rng;
+    if (device_rng && !exact) ck(ctx, mfm_rng_prefetch(ctx));
     htl.mark(4);
     // update_e (:493-522)
     if (cfg.task_type == TaskType::REGRESSION) {
       ck(ctx, mfm_update_e_regression(ctx));
     } else if (cfg.task_type == TaskType::CLASSIFICATION) {
-      if (cfg.host_rng()) {  // exact_latent_draws: FMTrainer.hpp:498-512 on the trainer's generator, row by row
-        ck(ctx, mfm_score_train(ctx));
+      int32_t st = 1;
+      if (exact) {  // FMTrainer.hpp:498-512 on the device stream, evaluated in parallel (csrc/mfm_latent.hip)
+        ck(ctx, mfm_update_e_classification_exact(ctx, &st));
+        if (st != 0) exact_fallbacks++;  // (nothing drawn or consumed, e holds the scores: row by row below)
+      }
+      if (exact && st == 0) {
+      } else if (cfg.host_rng() || exact) {  // FMTrainer.hpp:498-512 row by row, on the trainer's generator / the device stream
+        if (!exact) ck(ctx, mfm_score_train(ctx));
         vector<Real> e((size_t)N);
         ck(ctx, mfm_get_e(ctx, e.data()));
+        StreamEngine eng;
+        if (exact) {
+          if (!dwin) dwin.reset(new DeviceStreamWindow(ctx));
+          eng.dev = dwin.get();
+        } else {
+          eng.host = &gen_;
+        }
         for (int64_t t = 0; t < N; t++) {
           const Real pred = e[(size_t)t];
-          const Real n = y[(size_t)t] > 0 ? host_tn_left(gen_, pred, (Real)1, (Real)0) : host_tn_right(gen_, pred, (Real)1, (Real)0);
+          const Real n = y[(size_t)t] > 0 ? host_tn_left(eng, pred, (Real)1, (Real)0) : host_tn_right(eng, pred, (Real)1, (Real)0);
           e[(size_t)t] -= n;
         }
         ck(ctx, mfm_set_e(ctx, e.data()));
+        if (exact) dwin->commit();
       } else {
         ck(ctx, mfm_update_e_classification(ctx, (uint64_t)random_seed, latent_draws++));
       }
@@ -1436,11 +1519,13 @@ struct FMTrainer {
       int i = 0;
       for (auto &s : cutpoint_sampler) {
         s.step();
+        if (exact) dwin->commit();  // (the Metropolis draws came from the device stream: it moves past them)
         OprobitSampler::alpha_to_gamma(fm.cutpoints[i], s.alpha_now);
         s.sample_z_given_cutpoint((uint64_t)random_seed, latent_draws++);
         i++;
       }
     }
+    if (exact) ck(ctx, mfm_rng_prefetch(ctx));  // the next iteration's set, from where the latent draws ended
     htl.mark(5);
     htl.end();
   }
@@ -1459,9 +1544,11 @@ struct FMTrainer {
     }
     upload(fm);
     initialize_hyper(hyper);
+    if (cfg.exact_dev()) start_device_rng(fm.n_factors);  // (initialize_e's latent draws already come from the device stream)
     initialize_e(fm);
     lap("state upload + initialize_e");
     start_device_rng(fm.n_factors);
+    first_set();
     lap("device RNG hand-over");
     fm.fetch = [this](FM &f) { this->download(f); };
     fm.live_ctx = ctx;
@@ -1589,9 +1676,11 @@ struct GibbsSession {
     lap("build_device (set_main, blocks, finalize)");
     trainer->upload(fm);
     trainer->initialize_hyper(hyper);
+    if (trainer->cfg.exact_dev()) trainer->start_device_rng(fm.n_factors);
     trainer->initialize_e(fm);
     lap("state upload + initialize_e");
     trainer->start_device_rng(fm.n_factors);
+    trainer->first_set();
     lap("device RNG hand-over");
     fm.fetch = [this](FM &f) { this->trainer->download(f); };
     fm.live_ctx = trainer->ctx;
@@ -1633,6 +1722,23 @@ struct GibbsSession {
     int64_t a = 0, b = 0;
     mfm_plan_info(trainer->ctx, &a, &b);
     return py::make_tuple(a, b);
+  }
+  // latent mode "exact": geometry of the last parallel draw and how many draws took the sequential loop instead
+  py::dict latent_info() {
+    int64_t v[6] = {0, 0, 0, 0, 0, 0};
+    ck(trainer->ctx, mfm_latent_stats(trainer->ctx, v));
+    int64_t fb = trainer->exact_fallbacks;
+    for (auto &cs : trainer->cutpoint_sampler) fb += cs.exact_fallbacks;
+    py::dict d;
+    d["mode"] = trainer->cfg.exact_dev() ? "exact" : (trainer->cfg.host_rng() ? "host" : "philox");
+    d["status"] = v[0];
+    d["chunks"] = v[1];
+    d["sub_chunks"] = v[2];
+    d["quads_per_chunk"] = v[3];
+    d["quads_consumed"] = v[4];
+    d["walkers_started"] = v[5];
+    d["sequential_fallbacks"] = fb;
+    return d;
   }
 };
 
@@ -1893,6 +1999,7 @@ PYBIND11_MODULE(_myfm, m) {
       .def("timing_reset", &GibbsSession::timing_reset)
       .def("timing", &GibbsSession::timing)
       .def("plan_info", &GibbsSession::plan_info)
+      .def("latent_info", &GibbsSession::latent_info)
       .def("plan_flags", [](GibbsSession &s) { return mfm_plan_flags(s.trainer->ctx); })
       // row-sharded persistent sweep (myfm_hip.h: mfm_peer_*): this rank's exchange buffers, every rank's buffers
       .def("peer_info",

@@ -31,6 +31,7 @@
 #include "mfm_cell.hpp"
 #include "mfm_mtjump.hpp"
 #include "mfm_rng.hpp"
+#include "mfm_latent_api.hpp"
 
 namespace mfm {
 static thread_local std::string g_global_error;
@@ -255,6 +256,10 @@ struct mfm_ctx {
     } slot[3];
     static constexpr int N_SLOTS = 3;
     hipEvent_t gate = nullptr;  // recorded on the main stream at every prefetch: the side stream starts behind it
+    // latent mode "exact": the main stream moved the stream's position (mfm_latent_host.hpp); the next set starts behind that
+    bool latent_pending = false;
+    hipEvent_t latent_ev = nullptr;
+    DevBuf<uint32_t> host_win;  // staging of mfm_rng_host_read
     int64_t produced = 0, acquired = 0;
     int current = -1;
     // big NORMALS ops run as eval / scan / scatter over the whole GPU
@@ -275,9 +280,14 @@ struct mfm_ctx {
         if (sl.free_ev) (void)hipEventDestroy(sl.free_ev);
       }
       if (gate) (void)hipEventDestroy(gate);
+      if (latent_ev) (void)hipEventDestroy(latent_ev);
       if (stream) (void)hipStreamDestroy(stream);
     }
   } rng;
+
+  // exact latent draws of classification / ordered probit on the device stream (mfm_latent.hip)
+  std::unique_ptr<LatentEngine> latent;
+  LatentStats latent_stats;
 
   // ordered probit groups
   struct OGroup {
@@ -2464,8 +2474,16 @@ int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops) {
   int64_t n_dest[3] = {0, 0, 0};
   double normals = 0, gammas = 0;
   int n_normal_ops = 0;
-  for (int i = 0; i < n_ops; i++) {
-    const mfm_rng_op &o = ops[i];
+  int64_t latent_rows = 0;
+  int n_kept = 0;
+  for (int k = 0; k < n_ops; k++) {
+    const mfm_rng_op &o = ops[k];
+    if (o.kind == MFM_RNG_LATENT) {  // (not a draw of the set: only sizes the generator, below)
+      if (o.count < 0) throw Error(MFM_ERR_INVALID, "bad rng op");
+      latent_rows += o.count;
+      continue;
+    }
+    const int i = n_kept++;
     if (o.kind != MFM_RNG_NORMALS && o.kind != MFM_RNG_GAMMA) throw Error(MFM_ERR_INVALID, "bad rng op kind");
     if (o.dest < 0 || o.dest > 2 || o.count < 0 || o.offset < 0) throw Error(MFM_ERR_INVALID, "bad rng op");
     if (o.kind == MFM_RNG_GAMMA && !(o.shape > 0)) throw Error(MFM_ERR_INVALID, "gamma shape must be positive");
@@ -2482,6 +2500,8 @@ int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops) {
       n_normal_ops++;
     }
   }
+  h.resize((size_t)n_kept);
+  n_ops = n_kept;
   r.n_hv = n_dest[0];
   r.n_zw = n_dest[1];
   r.n_zv = n_dest[2];
@@ -2502,6 +2522,8 @@ int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops) {
   const double per_normal = 4.0 * 4.0 / 3.14159265358979;
   r.need = (uint64_t)(normals * per_normal * 1.02 + 6.0 * 2.4 * std::sqrt(normals + 1.0) + gammas * 4096.0 +
                       4.0 * RNG_ATT * RNG_CONSUME_THREADS * (n_normal_ops + 1) + 65536.0);
+  // the exact latent draws: ~1.3-1.5 quads of 4 outputs per row (what is missing at run time is generated then)
+  if (latent_rows > 0) r.need += (uint64_t)(4.0 * (1.6 * (double)latent_rows + 6.0 * std::sqrt((double)latent_rows) + 1024.0));
   for (auto &o : h)  // the evaluation window of a big op reaches past its last accept
     if (o.kind == MFM_RNG_NORMALS && o.count > 16384)
       r.need += (uint64_t)(4 * (mfm_ctx::RngEngine::attempts_for(o.count) - (int64_t)((double)o.count * 1.2732)));
@@ -2511,7 +2533,7 @@ int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops) {
   {
     const int64_t blocks1 = (int64_t)(r.need / MT_N) + 2;
     if (blocks1 > MT_PAR_BLOCKS && !std::getenv("MFM_RNG_SERIAL")) {
-      r.need_gen = r.need * (uint64_t)mt_gen_batch((double)r.need);
+      r.need_gen = r.need * (uint64_t)(latent_rows > (1 << 22) ? 2 : mt_gen_batch((double)r.need));
       const int64_t blocks = (int64_t)(r.need_gen / MT_N) + 2;
       if (r.par_blocks <= 0) r.par_blocks = mt_par_blocks_for(blocks);
       const int wgs = (int)((blocks + r.par_blocks - 1) / r.par_blocks);
@@ -2579,6 +2601,12 @@ int mfm_rng_prefetch(mfm_ctx *ctx) {
     MFM_HIP_CHECK(hipStreamWaitEvent(s, r.gate, 0));
   }
   if (sl.free_valid) MFM_HIP_CHECK(hipStreamWaitEvent(s, sl.free_ev, 0));
+  if (r.latent_pending) {  // the main stream consumed engine outputs (exact latent draws): this set starts where they ended
+    if (!r.latent_ev) MFM_HIP_CHECK(hipEventCreateWithFlags(&r.latent_ev, hipEventDisableTiming));
+    MFM_HIP_CHECK(hipEventRecord(r.latent_ev, ctx->stream));
+    MFM_HIP_CHECK(hipStreamWaitEvent(s, r.latent_ev, 0));
+    r.latent_pending = false;
+  }
   if (r.par_wgs > 1) {
     if (std::getenv("MFM_RNG_FUSED_JUMP")) {
       hipLaunchKernelGGL(k_mt_generate_par<0>, dim3(r.par_wgs), dim3(MT_GEN_THREADS),
@@ -2714,4 +2742,5 @@ int mfm_host_column_levels(int64_t n_rows, int64_t n_cols, const int64_t *indptr
 }  // extern "C"
 
 #include "mfm_tasks.hpp"    // classification / ordered-probit entry points
+#include "mfm_latent_host.hpp"  // ... their exact latent draws on the device stream
 #include "mfm_predict.hpp"  // mfm_design_* entry points

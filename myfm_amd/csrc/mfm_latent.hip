@@ -1,0 +1,964 @@
+// mfm_latent.hip -- the latent draws of probit classification / ordered probit on the reference's OWN random stream, evaluated in
+// parallel on the device (FMTrainer.hpp:498-521, OProbitSampler.hpp:238-272, util.hpp:15-60). See mfm_latent_api.hpp for the
+// formulation (one monotone lattice path over (row, quad); coalescing flows). Passes:
+//   k_lat_rows     per row of the group: the standardised truncation bounds as a 16-byte record, the acceptance probability p of
+//                  one quad (closed form) -> expected quads 1/p and variance (1 - p)/p^2, block sums
+//   k_lat_scan     prefix sums of the blocks (expected position of every 1024-th row, its variance)
+//   k_lat_quads    per quad j: (u1, log u2, -log u1, the polar pair's two normals) from the ring of MT19937 outputs
+//   k_lat_windows  per chunk c of Lq quads: the rows [lo, hi] that can be in service at quad c Lq (mean +- k sigma)
+//   k_lat_round    every live walker of every chunk walks R quads: t += A(t, j)
+//   k_lat_compact  per chunk: walkers that met (equal t, they are sorted) are merged; at sub-chunk boundaries the list
+//                  (first entering row of the merged range, current row) is kept as a snapshot
+//   k_lat_resident the same two steps for the rest of the chunk in one launch once a chunk's walkers fit a workgroup
+//   k_lat_resolve  the true entering row of every chunk: T(c + 1) = map_c(T(c)), T(0) = 0
+//   k_lat_final    one thread per sub-chunk walks the ONE true path of its quads from the snapshot's row and writes
+//                  e = score - z for the rows it accepts; the thread that serves the last row moves the stream's position
+// Acceptance is decided in the log domain on the quad table (u2 < exp(a) <=> log u2 < a) and, inside a relative band of 1e-9
+// around equality, by the reference's own expression (exp) -- the same function in the flows and in the final pass, so the two
+// cannot disagree; against libm the decision can differ only where exp / log differ in the last place (as for the sweep
+// normals, mfm_rng.hpp).
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "mfm_common.hpp"
+#include "mfm_latent_api.hpp"
+
+namespace mfm {
+
+namespace {
+
+constexpr int LAT_RB = 1024;     // rows per block of the row pass
+constexpr int LAT_TILE = 256;    // walkers per workgroup of k_lat_round
+constexpr int LAT_RES_NT = 512;  // threads (= walkers at most) of the resident kernel
+constexpr int LAT_QW = 5;        // doubles per quad record
+
+struct LatStatus {
+  int32_t fail;        // first failure code (0: none)
+  int32_t fail_chunk;
+  int64_t end_quads;   // quads consumed by the whole draw (-1: the path did not end inside the prepared quads)
+  int64_t walkers;     // sum of the windows
+  int64_t snap_need;   // snapshot entries the caps add up to
+  double total_m, total_v;
+};
+
+__device__ __forceinline__ void lat_fail(LatStatus *st, int code, int chunk) {
+  if (atomicCAS(&st->fail, 0, code) == 0) st->fail_chunk = chunk;
+}
+
+// ---- acceptance probability of one quad (anchors the windows: must be unbiased to ~1e-7) ----
+__device__ __forceinline__ double lat_erfcx(double x) {  // x >= 0
+  if (x < 25.0) return exp(x * x) * erfc(x);
+  const double r = 1.0 / (x * x);
+  return 0.56418958354775628695 / x * (1.0 + r * (-0.5 + r * (0.75 + r * (-1.875 + r * 6.5625))));
+}
+__device__ __forceinline__ double lat_accept_prob(double A, double B) {
+  const double SQRT1_2 = 0.70710678118654752440, SQRT_2PI = 2.50662827463100050242;
+  double p;
+  if (B != B) {  // polar attempt + tail test: a pair exists with probability pi / 4, both normals fail with Phi(mu)^2
+    const double Phi = 0.5 * erfc(-A * SQRT1_2);
+    p = 0.78539816339744830962 * (1.0 - Phi * Phi);
+  } else if (A > B) {  // translated-exponential proposal (Robert 1995): alpha = A, mu = B
+    const double d = A - B;
+    p = A * 1.25331413731550025121 * exp(-0.5 * d * d) * lat_erfcx(B * SQRT1_2);
+  } else {  // uniform proposal on [a, b]
+    const double w = B - A;
+    if (!(w > 1e-12)) return 1.0;
+    if (A <= 0.0 && B >= 0.0) {
+      p = SQRT_2PI * 0.5 * (erf(B * SQRT1_2) - erf(A * SQRT1_2)) / w;
+    } else {
+      const double x1 = (B < 0.0 ? -B : A) * SQRT1_2, x2 = (B < 0.0 ? -A : B) * SQRT1_2;
+      p = SQRT_2PI * 0.5 * (lat_erfcx(x1) - exp((x1 - x2) * (x1 + x2)) * lat_erfcx(x2)) / w;
+    }
+  }
+  if (!(p > 1e-12)) p = 1e-12;
+  if (p > 1.0) p = 1.0;
+  return p;
+}
+
+// ---- the row's standardised bounds (OProbitSampler.hpp:246-270, FMTrainer.hpp:503-511 with std = 1) ----
+// record (A, B):  one-sided, mu < 0: (mu, NaN);  one-sided, mu >= 0: (alpha*, mu), alpha* > mu;  two-sided: (a, b), a <= b.
+// sgn: the draw is sgn * value (right truncation = -left(-mu), util.hpp:70-73); value + score is the latent z.
+__device__ __forceinline__ double2 lat_record(double pred, double yv, int n_class, const double *__restrict__ gamma, int *sgn) {
+  double mu;
+  if (n_class == 0) {
+    if (yv > 0) {
+      mu = (0.0 - pred) / 1.0;
+      *sgn = 1;
+    } else {
+      mu = -((0.0 - pred) / 1.0);
+      *sgn = -1;
+    }
+  } else {
+    const int cls = (int)yv;
+    if (cls == 0) {
+      mu = -((gamma[0] - pred) / 1.0);
+      *sgn = -1;
+    } else if (cls == n_class - 1) {
+      mu = (gamma[n_class - 2] - pred) / 1.0;
+      *sgn = 1;
+    } else {
+      *sgn = 1;
+      return make_double2((gamma[cls - 1] - pred) / 1.0, (gamma[cls] - pred) / 1.0);
+    }
+  }
+  if (mu < 0) return make_double2(mu, __builtin_nan(""));
+  const double alpha = (mu + sqrt(mu * mu + 4)) / 2;
+  return make_double2(alpha, mu);
+}
+
+struct LatRow {  // what a walker keeps of its row
+  double s, o, sh, c;  // E / T: z = X s + o, a = (c - (z - sh)^2) / 2;  N: o = mu
+  double tol;          // relative half-width of the band decided by the exact expression
+  int kind;            // 0 N, 1 E, 2 T
+};
+__device__ __forceinline__ LatRow lat_derive(double A, double B) {
+  LatRow r;
+  if (B != B) {
+    r.kind = 0;
+    r.o = A;
+    r.s = r.sh = r.c = 0.0;
+    r.tol = 0.0;
+  } else if (A > B) {
+    r.kind = 1;
+    r.s = A - B;  // = 1 / alpha* up to rounding ((sqrt(mu^2 + 4) - mu) / 2); the band absorbs the difference
+    r.o = B;
+    r.sh = A;
+    r.c = 0.0;
+    r.tol = A < 1e3 ? 1e-9 : __builtin_inf();
+  } else {
+    r.kind = 2;
+    r.s = B - A;
+    r.o = A;
+    r.sh = 0.0;
+    r.c = (A <= 0.0 && B >= 0.0) ? 0.0 : (B < 0.0 ? B * B : A * A);
+    r.tol = 1e-9;
+  }
+  return r;
+}
+
+struct LatQuad {
+  double u1, l2, nl1, n1, n2;
+};
+
+// u2 < rho by the reference's own expressions (util.hpp:29-35, :46-59)
+__device__ __noinline__ bool lat_accept_exact(double A, double B, double u1, double nl1, double u2) {
+  double rho;
+  if (A > B) {
+    const double z = nl1 / A + B;
+    rho = exp(-(z - A) * (z - A) / 2);
+  } else {
+    const double z = u1 * (B - A) + A;
+    if (A <= 0.0 && B >= 0.0)
+      rho = exp(-z * z / 2);
+    else if (B < 0.0)
+      rho = exp((B * B - z * z) / 2);
+    else
+      rho = exp((A * A - z * z) / 2);
+  }
+  return u2 < rho;
+}
+
+__device__ __forceinline__ double lat_u2(const uint32_t *__restrict__ raw, uint64_t mask, uint64_t p0, int64_t j) {
+  const uint64_t b = p0 + 4ull * (uint64_t)j;
+  return canonical(mt_temper(raw[(b + 2) & mask]), mt_temper(raw[(b + 3) & mask]));
+}
+
+// does row (A, B) accept quad j?
+__device__ __forceinline__ bool lat_accept(const LatRow &r, double A, double B, const LatQuad &q, const uint32_t *__restrict__ raw,
+                                           uint64_t mask, uint64_t p0, int64_t j) {
+  if (r.kind == 0) return (q.n1 > r.o) || (q.n2 > r.o);
+  const double X = r.kind == 1 ? q.nl1 : q.u1;
+  const double z = X * r.s + r.o;
+  const double d = z - r.sh;
+  const double a = (r.c - d * d) * 0.5;
+  const double diff = q.l2 - a;
+  if (fabs(diff) > r.tol * (1.0 + fabs(a))) return diff < 0.0;  // (NaN: inf - inf -> the exact expression)
+  return lat_accept_exact(A, B, q.u1, q.nl1, lat_u2(raw, mask, p0, j));
+}
+// the accepted value (util.hpp:21-23, :29, :45)
+__device__ __forceinline__ double lat_value(const LatRow &r, double A, double B, const LatQuad &q) {
+  if (r.kind == 0) return q.n1 > r.o ? q.n1 : q.n2;
+  if (r.kind == 1) return q.nl1 / A + B;
+  return q.u1 * (B - A) + A;
+}
+__device__ __forceinline__ LatQuad lat_load_quad(const double *__restrict__ qt, int64_t j) {
+  const double *p = qt + (size_t)j * LAT_QW;
+  LatQuad q;
+  q.u1 = p[0];
+  q.l2 = p[1];
+  q.nl1 = p[2];
+  q.n1 = p[3];
+  q.n2 = p[4];
+  return q;
+}
+
+// ---- row pass ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lat_rows(const int32_t *__restrict__ rows, const double2 *__restrict__ eq,
+                                                  const double *__restrict__ y, int64_t n, int n_class,
+                                                  const double *__restrict__ gamma, double2 *__restrict__ rec, float *__restrict__ mf,
+                                                  double *__restrict__ blkM, double *__restrict__ blkV) {
+  __shared__ double s_m[4], s_v[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  double sm = 0.0, sv = 0.0;
+#pragma unroll
+  for (int r = 0; r < LAT_RB / 256; r++) {
+    const int64_t i = (int64_t)blockIdx.x * LAT_RB + r * 256 + tid;
+    if (i < n) {
+      const int64_t t = rows ? (int64_t)rows[i] : i;
+      int sgn;
+      const double2 ab = lat_record(eq[t].x, y[t], n_class, gamma, &sgn);
+      rec[i] = ab;
+      const double p = lat_accept_prob(ab.x, ab.y);
+      const double m = 1.0 / p;
+      mf[i] = (float)m;
+      sm += m;
+      sv += (1.0 - p) * m * m;
+    } else if (i == n) {
+      rec[i] = make_double2(__builtin_inf(), __builtin_nan(""));  // the row after the last one accepts nothing
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    sm += __shfl_down(sm, d, 64);
+    sv += __shfl_down(sv, d, 64);
+  }
+  if (lane == 0) {
+    s_m[wid] = sm;
+    s_v[wid] = sv;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    blkM[blockIdx.x] = (s_m[0] + s_m[1]) + (s_m[2] + s_m[3]);
+    blkV[blockIdx.x] = (s_v[0] + s_v[1]) + (s_v[2] + s_v[3]);
+  }
+}
+
+// exclusive prefix sums of blkM / blkV -> PM / PV [nb + 1]; one workgroup
+__global__ __launch_bounds__(1024) void k_lat_scan(const double *__restrict__ blkM, const double *__restrict__ blkV, int64_t nb,
+                                                   double *__restrict__ PM, double *__restrict__ PV, LatStatus *__restrict__ st,
+                                                   const RngState *__restrict__ rs, uint64_t *__restrict__ pos_out) {
+  __shared__ double s_m[1024], s_v[1024];
+  const int tid = threadIdx.x;
+  const int64_t seg = (nb + 1023) / 1024;
+  const int64_t b0 = min(nb, (int64_t)tid * seg), b1 = min(nb, b0 + seg);
+  double sm = 0.0, sv = 0.0;
+  for (int64_t b = b0; b < b1; b++) {
+    sm += blkM[b];
+    sv += blkV[b];
+  }
+  s_m[tid] = sm;
+  s_v[tid] = sv;
+  __syncthreads();
+  if (tid == 0) {  // (1024 additions: nothing next to the row pass)
+    double am = 0.0, av = 0.0;
+    for (int i = 0; i < 1024; i++) {
+      const double m = s_m[i], v = s_v[i];
+      s_m[i] = am;
+      s_v[i] = av;
+      am += m;
+      av += v;
+    }
+    PM[nb] = am;
+    PV[nb] = av;
+    st->total_m = am;
+    st->total_v = av;
+    st->fail = 0;
+    st->fail_chunk = -1;
+    st->end_quads = -1;
+    st->walkers = 0;
+    st->snap_need = 0;
+    pos_out[0] = rs->p_cons;
+    pos_out[1] = rs->p_gen;
+  }
+  __syncthreads();
+  double am = s_m[tid], av = s_v[tid];
+  for (int64_t b = b0; b < b1; b++) {
+    PM[b] = am;
+    PV[b] = av;
+    am += blkM[b];
+    av += blkV[b];
+  }
+}
+
+// ---- quad table ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lat_quads(const RngState *__restrict__ rs, const uint32_t *__restrict__ raw, uint64_t mask,
+                                                   int64_t nq, double *__restrict__ qt) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= nq) return;
+  const uint64_t b = rs->p_cons + 4ull * (uint64_t)j;
+  const uint32_t w0 = mt_temper(raw[(b + 0) & mask]), w1 = mt_temper(raw[(b + 1) & mask]);
+  const uint32_t w2 = mt_temper(raw[(b + 2) & mask]), w3 = mt_temper(raw[(b + 3) & mask]);
+  const double u1 = canonical(w0, w1), u2 = canonical(w2, w3);
+  // Marsaglia polar attempt of normal_distribution (random.tcc:1811-1826): returns y * mult first, keeps x * mult
+  const double x = 2.0 * u1 - 1.0, yy = 2.0 * u2 - 1.0;
+  const double r2 = x * x + yy * yy;
+  double n1 = __builtin_nan(""), n2 = __builtin_nan("");
+  if (!(r2 > 1.0 || r2 == 0.0)) {
+    const double mult = sqrt(-2 * log(r2) / r2);
+    n1 = (yy * mult) * 1.0 + 0.0;
+    n2 = (x * mult) * 1.0 + 0.0;
+  }
+  double *p = qt + (size_t)j * LAT_QW;
+  p[0] = u1;
+  p[1] = log(u2);
+  p[2] = -log(u1);
+  p[3] = n1;
+  p[4] = n2;
+}
+
+// snapshot entries a chunk with W entering rows may write: its walkers at every sub-chunk boundary, about K W / sqrt(quads walked) with
+// K = 1.1 (independent rows) ... 3.3 (probit classification with well separated classes: most decisions are the quad's alone)
+__host__ __device__ inline int64_t lat_snap_cap(int64_t W, int nsub, int64_t Lq, int subq) {
+  return 8 * (int64_t)nsub + (int64_t)(8.0 * (double)W * sqrt((double)Lq) / (double)subq);
+}
+
+// ---- windows ------------------------------------------------------------------------------------------
+// smallest i in [0, n] whose expected position M_i (quads consumed before row i) is >= target
+__device__ int64_t lat_find_row(const double *__restrict__ PM, const float *__restrict__ mf, int64_t n, int64_t nb, double target) {
+  if (!(target > 0.0)) return 0;
+  if (target >= PM[nb]) return n;
+  int64_t lo = 0, hi = nb - 1;  // largest b with PM[b] <= target
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (PM[mid] <= target)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  double acc = PM[lo];
+  int64_t i = lo * LAT_RB;
+  const int64_t e = min(n, (lo + 1) * LAT_RB);
+  while (i < e && acc < target) acc += (double)mf[i++];
+  return i;
+}
+
+__global__ __launch_bounds__(1024) void k_lat_windows(const double *__restrict__ PM, const double *__restrict__ PV,
+                                                      const float *__restrict__ mf, int64_t n, int64_t nb, int C, int64_t Lq,
+                                                      int subq, double ksig, int32_t *__restrict__ win_lo, int32_t *__restrict__ win_hi,
+                                                      int64_t *__restrict__ list_off, int64_t *__restrict__ snap_off,
+                                                      int32_t *__restrict__ live, int64_t list_cap, int64_t snap_cap,
+                                                      LatStatus *__restrict__ st) {
+  __shared__ int64_t s_w[1024], s_s[1024];
+  const int tid = threadIdx.x;
+  const int nsub = (int)(Lq / subq);
+  const int per = (C + 1023) / 1024;
+  const int c0 = min(C, tid * per), c1 = min(C, c0 + per);
+  int64_t sw = 0, ss = 0;
+  for (int c = c0; c < c1; c++) {
+    int64_t lo = 0, hi = 0;
+    if (c > 0) {
+      const double J = (double)c * (double)Lq;
+      const int64_t ts = lat_find_row(PM, mf, n, nb, J);
+      const int64_t b = min(nb - 1, ts / LAT_RB);
+      const double sd = sqrt(PV[b + 1]);
+      lo = max((int64_t)0, lat_find_row(PM, mf, n, nb, J - ksig * sd) - 2);
+      hi = min(n, lat_find_row(PM, mf, n, nb, J + ksig * sd) + 2);
+    }
+    win_lo[c] = (int32_t)lo;
+    win_hi[c] = (int32_t)hi;
+    const int64_t W = hi - lo + 1;
+    live[c] = (int32_t)W;
+    sw += W;
+    ss += lat_snap_cap(W, nsub, Lq, subq);
+  }
+  s_w[tid] = sw;
+  s_s[tid] = ss;
+  __syncthreads();
+  if (tid == 0) {
+    int64_t aw = 0, as = 0;
+    for (int i = 0; i < 1024; i++) {
+      const int64_t w = s_w[i], s = s_s[i];
+      s_w[i] = aw;
+      s_s[i] = as;
+      aw += w;
+      as += s;
+    }
+    st->walkers = aw;
+    st->snap_need = as;
+    if (aw > list_cap) lat_fail(st, 3, -1);
+    if (as > snap_cap) lat_fail(st, 2, -1);
+    list_off[C] = aw;
+    snap_off[C] = as;
+  }
+  __syncthreads();
+  int64_t aw = s_w[tid], as = s_s[tid];
+  for (int c = c0; c < c1; c++) {
+    list_off[c] = aw;
+    snap_off[c] = as;
+    const int64_t W = (int64_t)win_hi[c] - win_lo[c] + 1;
+    aw += W;
+    as += lat_snap_cap(W, nsub, Lq, subq);
+  }
+}
+
+// ---- a walker's R steps -------------------------------------------------------------------------------
+struct LatWalker {
+  int32_t t;
+  double2 r, nx;  // records of row t and row t + 1
+  LatRow w;
+};
+__device__ __forceinline__ void lat_walker_load(LatWalker &k, const double2 *__restrict__ rec, int64_t n) {
+  k.r = rec[k.t];
+  k.nx = rec[min((int64_t)k.t + 1, n)];
+  k.w = lat_derive(k.r.x, k.r.y);
+}
+__device__ __forceinline__ void lat_walk(LatWalker &k, const double2 *__restrict__ rec, int64_t n, const double *__restrict__ qt,
+                                         int64_t j0, int R, const uint32_t *__restrict__ raw, uint64_t mask, uint64_t p0) {
+  for (int s = 0; s < R; s++) {
+    const LatQuad q = lat_load_quad(qt, j0 + s);  // (wave-uniform address)
+    if (lat_accept(k.w, k.r.x, k.r.y, q, raw, mask, p0, j0 + s)) {
+      k.t++;
+      k.r = k.nx;
+      k.w = lat_derive(k.r.x, k.r.y);
+      k.nx = rec[min((int64_t)k.t + 1, n)];
+    }
+  }
+}
+
+// every live walker of every chunk: R quads from quad c Lq + done. grid (tiles, C)
+__global__ __launch_bounds__(LAT_TILE) void k_lat_round(const double2 *__restrict__ rec, const double *__restrict__ qt,
+                                                        const uint32_t *__restrict__ raw, uint64_t mask,
+                                                        const RngState *__restrict__ rs, int64_t n, int64_t Lq, int done, int R,
+                                                        const int32_t *__restrict__ win_lo, const int32_t *__restrict__ live,
+                                                        const int64_t *__restrict__ list_off, int32_t *cur, int first) {
+  const int c = blockIdx.y;
+  const int i = blockIdx.x * LAT_TILE + threadIdx.x;
+  if (i >= live[c]) return;
+  LatWalker k;
+  int32_t *pc = cur + list_off[c] + i;
+  k.t = first ? win_lo[c] + i : *pc;
+  lat_walker_load(k, rec, n);
+  lat_walk(k, rec, n, qt, (int64_t)c * Lq + done, R, raw, mask, rs->p_cons);
+  *pc = k.t;
+}
+
+// per chunk: merge the walkers that met, compact (src -> dst), optionally keep the list as snapshot `snap_k`
+__global__ __launch_bounds__(1024) void k_lat_compact(const int32_t *__restrict__ win_lo, int32_t *__restrict__ live,
+                                                      const int64_t *__restrict__ list_off, const int32_t *__restrict__ scur,
+                                                      const int32_t *__restrict__ sfin, int32_t *__restrict__ dcur,
+                                                      int32_t *__restrict__ dfin, int first, int snap_k, int nsub,
+                                                      const int64_t *__restrict__ snap_off, int64_t *__restrict__ snap_pos,
+                                                      int2 *__restrict__ snap, int64_t *__restrict__ snap_idx,
+                                                      int32_t *__restrict__ snap_cnt, int32_t *__restrict__ max_live,
+                                                      LatStatus *__restrict__ st) {
+  __shared__ int s_cnt[16];
+  __shared__ int s_out;
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int nl = live[c];
+  const int64_t off = list_off[c];
+  const int lo = win_lo[c];
+  const bool do_snap = snap_k >= 0;
+  int64_t sp = 0;
+  bool snap_ok = false;
+  if (do_snap) {
+    sp = snap_k == 0 ? snap_off[c] : snap_pos[c];
+    snap_ok = true;
+  }
+  if (tid == 0) s_out = 0;
+  __syncthreads();
+  for (int base = 0; base < nl; base += 1024) {
+    const int i = base + tid;
+    const bool act = i < nl;
+    int t = 0, f = 0, prev = -1;
+    if (act) {
+      t = scur[off + i];
+      f = first ? lo + i : sfin[off + i];
+      if (i > 0) prev = scur[off + i - 1];
+    }
+    const bool keep = act && t != prev;
+    const unsigned long long b = __ballot(keep);
+    if (lane == 0) s_cnt[wid] = __popcll(b);
+    __syncthreads();
+    int before = s_out, tot = 0;
+    for (int w = 0; w < 16; w++) {
+      const int cw = s_cnt[w];
+      if (w < wid) before += cw;
+      tot += cw;
+    }
+    if (keep) {
+      const int r = before + __popcll(b & ((1ull << lane) - 1ull));
+      dcur[off + r] = t;
+      dfin[off + r] = f;
+      if (snap_ok && sp + r < snap_off[c + 1]) snap[sp + r] = make_int2(f, t);
+    }
+    __syncthreads();
+    if (tid == 0) s_out += tot;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int out = s_out;
+    live[c] = out;
+    atomicMax(max_live, out);
+    if (do_snap) {
+      if (sp + out > snap_off[c + 1]) lat_fail(st, 2, c);
+      snap_idx[(size_t)c * nsub + snap_k] = sp;
+      snap_cnt[(size_t)c * nsub + snap_k] = out;
+      snap_pos[c] = sp + out;
+    }
+  }
+}
+
+// ---- the rest of a chunk in one launch: a workgroup per chunk, a walker per thread -------------------------------------
+// Waves work on their own 64 walkers without workgroup barriers: after every round a wave merges the walkers that met among its own
+// (sorted, so a compare with the lane below) through a private LDS strip; at every sub-chunk boundary the workgroup gathers all
+// walkers, merges across the wave borders, writes the snapshot and hands the survivors out again (full waves first).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__ rec, const double *__restrict__ qt,
+                                                     const uint32_t *__restrict__ raw, uint64_t mask,
+                                                     const RngState *__restrict__ rs, int64_t n, int64_t Lq, int done0, int R, int subq,
+                                                     int nsub, const int32_t *__restrict__ live, const int64_t *__restrict__ list_off,
+                                                     const int32_t *__restrict__ scur, const int32_t *__restrict__ sfin,
+                                                     const int64_t *__restrict__ snap_off, const int64_t *__restrict__ snap_pos,
+                                                     int2 *__restrict__ snap, int64_t *__restrict__ snap_idx,
+                                                     int32_t *__restrict__ snap_cnt, LatStatus *__restrict__ st) {
+  constexpr int NW = NT / 64;
+  __shared__ int s_t[2][NT], s_f[2][NT];
+  __shared__ double2 s_r[2][NT], s_n[2][NT];
+  __shared__ int s_cnt[NW];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint64_t p0 = rs->p_cons;
+  const int64_t J0 = (int64_t)c * Lq;
+  int nl = live[c];
+  if (nl > NT) {
+    if (tid == 0) lat_fail(st, 3, c);
+    return;
+  }
+  const int64_t off = list_off[c];
+  int64_t sp = done0 >= subq ? snap_pos[c] : snap_off[c];
+  const int64_t sp_end = snap_off[c + 1];
+  // this wave's walkers: lanes [0, wl)
+  int wl = max(0, min(64, nl - wid * 64));
+  LatWalker k;
+  int f = 0;
+  k.t = 0;
+  if (lane < wl) {
+    k.t = scur[off + tid];
+    f = sfin[off + tid];
+  }
+  k.t = lane < wl ? k.t : (int32_t)n;
+  lat_walker_load(k, rec, n);
+  int done = done0;
+  while (done < (int)Lq) {
+    const int to_boundary = subq - (done % subq);
+    const int Rr = min(R, to_boundary);
+    if (wl > 0) {
+      lat_walk(k, rec, n, qt, J0 + done, Rr, raw, mask, p0);
+      // merge inside the wave
+      const int prev = __shfl_up(k.t, 1, 64);
+      const bool keep = lane < wl && (lane == 0 || k.t != prev);
+      const unsigned long long b = __ballot(keep);
+      const int cnt = __popcll(b);
+      if (cnt != wl) {
+        const int r = __popcll(b & ((1ull << lane) - 1ull));
+        const int base = wid * 64;
+        if (keep) {
+          s_t[0][base + r] = k.t;
+          s_f[0][base + r] = f;
+          s_r[0][base + r] = k.r;
+          s_n[0][base + r] = k.nx;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wl = cnt;
+        if (lane < wl) {
+          k.t = s_t[0][base + lane];
+          f = s_f[0][base + lane];
+          k.r = s_r[0][base + lane];
+          k.nx = s_n[0][base + lane];
+        } else {
+          k.t = (int32_t)n;
+          k.r = rec[n];
+          k.nx = k.r;
+        }
+        k.w = lat_derive(k.r.x, k.r.y);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    done += Rr;
+    if (done % subq == 0) {
+      // workgroup-wide: gather, merge across wave borders, snapshot, redistribute
+      __syncthreads();
+      if (lane == 0) s_cnt[wid] = wl;
+      __syncthreads();
+      int before = 0, tot = 0;
+      for (int w = 0; w < NW; w++) {
+        const int cw = s_cnt[w];
+        if (w < wid) before += cw;
+        tot += cw;
+      }
+      if (lane < wl) {
+        s_t[0][before + lane] = k.t;
+        s_f[0][before + lane] = f;
+        s_r[0][before + lane] = k.r;
+        s_n[0][before + lane] = k.nx;
+      }
+      __syncthreads();
+      bool keep = false;
+      int t2 = 0, f2 = 0;
+      double2 r2 = make_double2(0, 0), n2 = r2;
+      if (tid < tot) {
+        t2 = s_t[0][tid];
+        keep = tid == 0 || t2 != s_t[0][tid - 1];
+        f2 = s_f[0][tid];
+        r2 = s_r[0][tid];
+        n2 = s_n[0][tid];
+      }
+      const unsigned long long b = __ballot(keep);
+      __syncthreads();
+      if (lane == 0) s_cnt[wid] = __popcll(b);
+      __syncthreads();
+      int before2 = 0, tot2 = 0;
+      for (int w = 0; w < NW; w++) {
+        const int cw = s_cnt[w];
+        if (w < wid) before2 += cw;
+        tot2 += cw;
+      }
+      const int sk = done / subq - 1;
+      if (keep) {
+        const int r = before2 + __popcll(b & ((1ull << lane) - 1ull));
+        s_t[1][r] = t2;
+        s_f[1][r] = f2;
+        s_r[1][r] = r2;
+        s_n[1][r] = n2;
+        if (sp + r < sp_end) snap[sp + r] = make_int2(f2, t2);
+      }
+      if (tid == 0) {
+        if (sp + tot2 > sp_end) lat_fail(st, 2, c);
+        snap_idx[(size_t)c * nsub + sk] = sp;
+        snap_cnt[(size_t)c * nsub + sk] = tot2;
+      }
+      sp += tot2;
+      __syncthreads();
+      nl = tot2;
+      wl = max(0, min(64, nl - wid * 64));
+      if (lane < wl) {
+        k.t = s_t[1][tid];
+        f = s_f[1][tid];
+        k.r = s_r[1][tid];
+        k.nx = s_n[1][tid];
+      } else {
+        k.t = (int32_t)n;
+        k.r = rec[n];
+        k.nx = k.r;
+      }
+      k.w = lat_derive(k.r.x, k.r.y);
+      __syncthreads();
+    }
+  }
+}
+
+// ---- resolution: T(c + 1) = map_c(T(c)) -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lat_resolve(int C, int nsub, int n, const int32_t *__restrict__ win_lo,
+                                                     const int32_t *__restrict__ win_hi, const int2 *__restrict__ snap,
+                                                     const int64_t *__restrict__ snap_idx, const int32_t *__restrict__ snap_cnt,
+                                                     int32_t *__restrict__ Tc, LatStatus *__restrict__ st) {
+  __shared__ int s_T;
+  const int tid = threadIdx.x;
+  if (st->fail != 0) return;
+  int T = 0;
+  for (int c = 0; c < C; c++) {
+    if (tid == 0) Tc[c] = T;
+    if (T < win_lo[c] || T > win_hi[c]) {
+      if (tid == 0) lat_fail(st, 1, c);
+      return;
+    }
+    const int64_t sp = snap_idx[(size_t)c * nsub + nsub - 1];
+    const int cnt = snap_cnt[(size_t)c * nsub + nsub - 1];
+    for (int i = tid; i < cnt; i += 256) {
+      const int2 e = snap[sp + i];
+      const bool last = i + 1 == cnt;
+      const int fn = last ? 0x7fffffff : snap[sp + i + 1].x;
+      if (e.x <= T && (last || fn > T)) s_T = e.y;
+    }
+    __syncthreads();
+    T = s_T;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    Tc[C] = T;
+    if (T != n) lat_fail(st, 4, C);  // the last row is not served inside the prepared quads: nothing is written
+  }
+}
+
+// ---- final pass: the one true path, a thread per sub-chunk ---------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_lat_final(const double2 *__restrict__ rec, const double *__restrict__ qt,
+                                                  const uint32_t *__restrict__ raw, uint64_t mask, RngState *__restrict__ rs, int64_t n,
+                                                  int64_t Lq, int subq, int nsub, int C, const int32_t *__restrict__ Tc,
+                                                  const int2 *__restrict__ snap, const int64_t *__restrict__ snap_idx,
+                                                  const int32_t *__restrict__ snap_cnt, const int32_t *__restrict__ rows,
+                                                  double2 *__restrict__ eq, const double *__restrict__ y, int n_class,
+                                                  LatStatus *__restrict__ st) {
+  const int64_t g = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (g >= (int64_t)C * nsub) return;
+  if (st->fail != 0) return;
+  const int c = (int)(g / nsub), ks = (int)(g % nsub);
+  const int T = Tc[c];
+  int t = T;
+  if (ks > 0) {  // the walker of snapshot ks - 1 that carries entering row T: the last entry with first_in <= T
+    const int64_t sp = snap_idx[(size_t)c * nsub + ks - 1];
+    int lo = 0, hi = snap_cnt[(size_t)c * nsub + ks - 1] - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (snap[sp + mid].x <= T)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    t = snap[sp + lo].y;
+  }
+  if (t >= n) return;
+  const uint64_t p0 = rs->p_cons;
+  const int64_t j0 = (int64_t)c * Lq + (int64_t)ks * subq;
+  double2 r = rec[t];
+  LatRow w = lat_derive(r.x, r.y);
+  for (int s = 0; s < subq; s++) {
+    const LatQuad q = lat_load_quad(qt, j0 + s);
+    if (lat_accept(w, r.x, r.y, q, raw, mask, p0, j0 + s)) {
+      const double val = lat_value(w, r.x, r.y, q);
+      const int64_t row = rows ? (int64_t)rows[t] : (int64_t)t;
+      const double pred = eq[row].x;
+      // the side of a one-sided draw (right truncation = -left(-mu)); z = 1 * draw + score, e = score - z
+      int sgn = 1;
+      if (n_class == 0)
+        sgn = y[row] > 0 ? 1 : -1;
+      else if ((int)y[row] == 0)
+        sgn = -1;
+      const double draw = sgn > 0 ? val : -val;
+      const double z = 1.0 * draw + pred;
+      eq[row].x = pred - z;
+      t++;
+      if (t >= n) {
+        st->end_quads = j0 + s + 1;
+        return;
+      }
+      r = rec[t];
+      w = lat_derive(r.x, r.y);
+    }
+  }
+}
+
+// the stream moves past the quads the draw consumed (only when every pass succeeded)
+__global__ void k_lat_commit(RngState *__restrict__ rs, LatStatus *__restrict__ st) {
+  if (st->fail == 0 && st->end_quads < 0) st->fail = 4;
+  if (st->fail == 0) {
+    rs->p_cons += 4ull * (uint64_t)st->end_quads;
+    if (rs->p_cons > rs->p_gen) rs->error = 1;
+  }
+}
+
+static double env_double(const char *name, double dflt) {
+  const char *e = std::getenv(name);
+  return e ? std::atof(e) : dflt;
+}
+static int env_int(const char *name, int dflt) {
+  const char *e = std::getenv(name);
+  return e ? std::atoi(e) : dflt;
+}
+
+}  // namespace
+
+struct LatentEngine::Impl {
+  DevBuf<double2> rec;
+  DevBuf<float> mf;
+  DevBuf<double> blkM, blkV, PM, PV, qt;
+  DevBuf<int32_t> win_lo, win_hi, live, cur0, fin0, cur1, fin1, snap_cnt, Tc, max_live;
+  DevBuf<int64_t> list_off, snap_off, snap_pos, snap_idx;
+  DevBuf<int2> snap;
+  DevBuf<LatStatus> status;
+  DevBuf<uint64_t> pos;
+  LatStatus *h_status = nullptr;  // pinned
+  uint64_t *h_pos = nullptr;
+  int32_t *h_max = nullptr;
+  double ksig = 5.0;
+  // geometry of the prepared draw
+  int64_t n = -1, Lq = 0, Wmax = 0;
+  int C = 0, nsub = 0, subq = 0;
+  ~Impl() {
+    if (h_status) (void)hipHostFree(h_status);
+    if (h_pos) (void)hipHostFree(h_pos);
+    if (h_max) (void)hipHostFree(h_max);
+  }
+  template <class T>
+  static void ensure(DevBuf<T> &b, size_t count) {
+    if (b.n < count) b.alloc(count + count / 8 + 16);
+  }
+};
+
+LatentEngine::LatentEngine() : im(new Impl()) {}
+LatentEngine::~LatentEngine() { delete im; }
+
+constexpr int LAT_MAX_ROUNDS = 8192;
+
+void LatentEngine::prepare(const LatentJob &job, LatentPrep *prep) {
+  Impl &m = *im;
+  if (job.n >= 0x7ffffff0ll) throw Error(MFM_ERR_INVALID, "exact latent draws: more than 2^31 rows in a group");
+  hipStream_t s = job.stream;
+  if (!m.h_status) {
+    MFM_HIP_CHECK(hipHostMalloc((void **)&m.h_status, sizeof(LatStatus), hipHostMallocDefault));
+    MFM_HIP_CHECK(hipHostMalloc((void **)&m.h_pos, 2 * sizeof(uint64_t), hipHostMallocDefault));
+    MFM_HIP_CHECK(hipHostMalloc((void **)&m.h_max, sizeof(int32_t), hipHostMallocDefault));
+    m.status.alloc(1);
+    m.pos.alloc(2);
+    m.max_live.alloc(LAT_MAX_ROUNDS);
+  }
+  m.ksig = env_double("MFM_LAT_KSIGMA", 5.0);
+  const int64_t n = job.n, nb = (n + LAT_RB - 1) / LAT_RB;
+  // (the block that holds row n writes the record of "the row after the last one": one more block when n fills its blocks)
+  const int64_t grid = (n + 1 + LAT_RB - 1) / LAT_RB;
+  Impl::ensure(m.rec, (size_t)n + 1);
+  Impl::ensure(m.mf, (size_t)n + 1);
+  Impl::ensure(m.blkM, (size_t)grid);
+  Impl::ensure(m.blkV, (size_t)grid);
+  Impl::ensure(m.PM, (size_t)nb + 1);
+  Impl::ensure(m.PV, (size_t)nb + 1);
+  hipLaunchKernelGGL(k_lat_rows, dim3((unsigned)grid), dim3(256), 0, s, job.rows, job.eq, job.y, n, job.n_class, job.gamma, m.rec.p,
+                     m.mf.p, m.blkM.p, m.blkV.p);
+  hipLaunchKernelGGL(k_lat_scan, dim3(1), dim3(1024), 0, s, m.blkM.p, m.blkV.p, nb, m.PM.p, m.PV.p, m.status.p, job.state, m.pos.p);
+  MFM_HIP_CHECK(hipGetLastError());
+  MFM_HIP_CHECK(hipMemcpyAsync(m.h_status, m.status.p, sizeof(LatStatus), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipMemcpyAsync(m.h_pos, m.pos.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipStreamSynchronize(s));
+  prep->mean_quads = m.h_status->total_m;
+  prep->var_quads = m.h_status->total_v;
+  prep->p_cons = m.h_pos[0];
+  prep->p_gen = m.h_pos[1];
+  const double cap = prep->mean_quads + (m.ksig + 1.0) * std::sqrt(prep->var_quads) + 256.0;
+  // (a row whose bounds are NaN, or whose acceptance probability is ~0, never accepts: the reference would spin for ever)
+  if (!(cap == cap) || cap > 64.0 * (double)n + 1e6)
+    throw Error(MFM_ERR_RUNTIME, "exact latent draws: a score is not finite, or a truncation region has (almost) no mass");
+  // geometry: C chunks of Lq quads, sub-chunks of subq quads
+  m.subq = std::max(64, env_int("MFM_LAT_SUBQ", 512) / 64 * 64);
+  const int target_chunks = std::max(1, env_int("MFM_LAT_CHUNKS", 512));
+  int64_t Lq = ((int64_t)cap + target_chunks - 1) / target_chunks;
+  Lq = std::max<int64_t>(Lq, env_int("MFM_LAT_MIN_LQ", 4096));
+  Lq = (Lq + m.subq - 1) / m.subq * m.subq;
+  if (Lq > 0x3fffffff) throw Error(MFM_ERR_RUNTIME, "exact latent draws: chunk too long");
+  m.Lq = Lq;
+  m.C = (int)(((int64_t)cap + Lq - 1) / Lq);
+  m.nsub = (int)(Lq / m.subq);
+  m.n = n;
+  m.Wmax = std::min<int64_t>(n + 1, (int64_t)(2.0 * m.ksig * std::sqrt(prep->var_quads)) + 8);
+  prep->q_cap = (int64_t)m.C * Lq;
+}
+
+int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats *stats) {
+  Impl &m = *im;
+  hipStream_t s = job.stream;
+  const int64_t n = job.n;
+  LatentStats S;
+  if (n == 0) {
+    if (stats) *stats = S;
+    return 0;
+  }
+  if (n != m.n) throw Error(MFM_ERR_RUNTIME, "exact latent draws: run() without the matching prepare()");
+  const bool timing = std::getenv("MFM_LATENT_TIMING") != nullptr;
+  hipEvent_t ev[4];
+  if (timing)
+    for (auto &e : ev) MFM_HIP_CHECK(hipEventCreate(&e));
+  const int subq = m.subq, C = m.C, nsub = m.nsub;
+  const int64_t Lq = m.Lq, nq = prep.q_cap, Wmax = m.Wmax;
+  const int R = std::max(1, std::min(subq, env_int("MFM_LAT_ROUND", 16)));
+  const int64_t nb = (n + LAT_RB - 1) / LAT_RB;
+  const int64_t list_cap = (int64_t)C * Wmax;
+  const int64_t snap_cap = (int64_t)C * (lat_snap_cap(Wmax, nsub, Lq, subq) + 1);
+  Impl::ensure(m.qt, (size_t)nq * LAT_QW);
+  Impl::ensure(m.win_lo, (size_t)C);
+  Impl::ensure(m.win_hi, (size_t)C);
+  Impl::ensure(m.live, (size_t)C);
+  Impl::ensure(m.list_off, (size_t)C + 1);
+  Impl::ensure(m.snap_off, (size_t)C + 1);
+  Impl::ensure(m.snap_pos, (size_t)C);
+  Impl::ensure(m.snap_idx, (size_t)C * nsub);
+  Impl::ensure(m.snap_cnt, (size_t)C * nsub);
+  Impl::ensure(m.Tc, (size_t)C + 1);
+  Impl::ensure(m.cur0, (size_t)list_cap);
+  Impl::ensure(m.fin0, (size_t)list_cap);
+  Impl::ensure(m.cur1, (size_t)list_cap);
+  Impl::ensure(m.fin1, (size_t)list_cap);
+  Impl::ensure(m.snap, (size_t)snap_cap);
+
+  MFM_HIP_CHECK(hipMemsetAsync(m.max_live.p, 0, sizeof(int32_t) * LAT_MAX_ROUNDS, s));
+  if (timing) MFM_HIP_CHECK(hipEventRecord(ev[0], s));
+  hipLaunchKernelGGL(k_lat_quads, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, job.state, job.raw, job.mask, nq, m.qt.p);
+  hipLaunchKernelGGL(k_lat_windows, dim3(1), dim3(1024), 0, s, m.PM.p, m.PV.p, m.mf.p, n, nb, C, Lq, subq, m.ksig, m.win_lo.p,
+                     m.win_hi.p, m.list_off.p, m.snap_off.p, m.live.p, list_cap, snap_cap, m.status.p);
+  if (timing) MFM_HIP_CHECK(hipEventRecord(ev[1], s));
+  // Rounds over all chunks' walkers as grid-wide launches (16, 16, 32, ... quads up to the first sub-chunk boundary, then a sub-chunk
+  // per round) while some chunk still has more walkers than a workgroup of the resident kernel; the host reads the largest list back
+  // after every round (4 bytes) to size the next launch and to decide the hand-over.
+  int done = 0, round = 0;
+  bool first = true;
+  int32_t *sc = m.cur0.p, *sf = m.fin0.p, *dc = m.cur1.p, *df = m.fin1.p;
+  int64_t max_live = Wmax;
+  int Rr = R;
+  const bool no_resident = std::getenv("MFM_LAT_NO_RESIDENT") != nullptr;
+  while (done < Lq) {
+    if (!first && max_live <= LAT_RES_NT && !no_resident) break;
+    if (round >= LAT_MAX_ROUNDS) throw Error(MFM_ERR_RUNTIME, "exact latent draws: too many rounds");
+    int step = (int)std::min<int64_t>(Rr, Lq - done);
+    if (done % subq + step > subq) step = subq - done % subq;
+    const unsigned tiles = (unsigned)((max_live + LAT_TILE - 1) / LAT_TILE);
+    hipLaunchKernelGGL(k_lat_round, dim3(tiles, (unsigned)C), dim3(LAT_TILE), 0, s, m.rec.p, m.qt.p, job.raw, job.mask, job.state, n, Lq,
+                       done, step, m.win_lo.p, m.live.p, m.list_off.p, sc, first ? 1 : 0);
+    done += step;
+    const int snap_k = done % subq == 0 ? done / subq - 1 : -1;
+    hipLaunchKernelGGL(k_lat_compact, dim3((unsigned)C), dim3(1024), 0, s, m.win_lo.p, m.live.p, m.list_off.p, sc, sf, dc, df,
+                       first ? 1 : 0, snap_k, nsub, m.snap_off.p, m.snap_pos.p, m.snap.p, m.snap_idx.p, m.snap_cnt.p,
+                       m.max_live.p + round, m.status.p);
+    MFM_HIP_CHECK(hipMemcpyAsync(m.h_max, m.max_live.p + round, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    max_live = *m.h_max;
+    round++;
+    std::swap(sc, dc);
+    std::swap(sf, df);
+    first = false;
+    if (done >= subq)
+      Rr = subq;
+    else if (done >= 2 * Rr)
+      Rr = std::min(subq, 2 * Rr);
+  }
+  const int rounds_done = round, handover = done;
+  if (done < Lq) {
+    hipLaunchKernelGGL((k_lat_resident<LAT_RES_NT>), dim3((unsigned)C), dim3(LAT_RES_NT), 0, s, m.rec.p, m.qt.p, job.raw, job.mask,
+                       job.state, n, Lq, done, R, subq, nsub, m.live.p, m.list_off.p, sc, sf, m.snap_off.p, m.snap_pos.p, m.snap.p,
+                       m.snap_idx.p, m.snap_cnt.p, m.status.p);
+  }
+  if (timing) MFM_HIP_CHECK(hipEventRecord(ev[2], s));
+  hipLaunchKernelGGL(k_lat_resolve, dim3(1), dim3(256), 0, s, C, nsub, (int)n, m.win_lo.p, m.win_hi.p, m.snap.p, m.snap_idx.p,
+                     m.snap_cnt.p, m.Tc.p, m.status.p);
+  hipLaunchKernelGGL(k_lat_final, dim3((unsigned)(((int64_t)C * nsub + 63) / 64)), dim3(64), 0, s, m.rec.p, m.qt.p, job.raw, job.mask,
+                     job.state, n, Lq, subq, nsub, C, m.Tc.p, m.snap.p, m.snap_idx.p, m.snap_cnt.p, job.rows, job.eq, job.y, job.n_class,
+                     m.status.p);
+  hipLaunchKernelGGL(k_lat_commit, dim3(1), dim3(1), 0, s, job.state, m.status.p);
+  if (timing) MFM_HIP_CHECK(hipEventRecord(ev[3], s));
+  MFM_HIP_CHECK(hipGetLastError());
+  MFM_HIP_CHECK(hipMemcpyAsync(m.h_status, m.status.p, sizeof(LatStatus), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipStreamSynchronize(s));
+  S.status = m.h_status->fail;
+  S.chunks = C;
+  S.subs = nsub;
+  S.lq = Lq;
+  S.quads_used = m.h_status->end_quads;
+  S.walkers = m.h_status->walkers;
+  if (timing) {
+    float a = 0, b = 0, c2 = 0;
+    (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+    (void)hipEventElapsedTime(&c2, ev[2], ev[3]);
+    S.ms_quads = a;
+    S.ms_flow = b;
+    S.ms_final = c2;
+    std::fprintf(stderr,
+                 "[latent] n %lld quads %lld (cap %lld) chunks %d x %lld (sub %d) walkers %lld, %d rounds then resident from quad %d "
+                 "(largest list %lld), status %d (chunk %d) | quads+windows %.3f ms, flows %.3f ms, resolve+final %.3f ms\n",
+                 (long long)n, (long long)S.quads_used, (long long)prep.q_cap, C, (long long)Lq, subq, (long long)S.walkers, rounds_done,
+                 handover, (long long)max_live, S.status, m.h_status->fail_chunk, a, b, c2);
+    for (auto &e : ev) (void)hipEventDestroy(e);
+  }
+  if (stats) *stats = S;
+  return S.status;
+}
+
+}  // namespace mfm

@@ -1,0 +1,216 @@
+"""Latent mode "exact": the latent draws of probit classification / ordered probit (FMTrainer.hpp:498-521,
+OProbitSampler.hpp:238-272, util.hpp:15-60) made ON THE DEVICE from the reference's own random stream (csrc/mfm_latent.hip:
+coalescing flows over (row, quad)), the cutpoint sampler's Metropolis draws (OProbitSampler.hpp:55-72, :378) served from the same
+device stream. Every chain below is held against the CPU oracle draw for draw: kept samples, hyper-parameters, cutpoints,
+Metropolis accept counts at 1e-7 -- the same bar as the regression chains.
+"""
+import numpy as np
+import pytest
+
+from . import datasets as ds
+from .test_gpu_baseline_configs import _assert_chain
+from .test_gpu_host_rng_parity import _blocks_design, _oracle_chain
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from myfm_amd import _capi, _myfm
+
+    if _myfm.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests need a real MI355X")
+    return _myfm, _capi
+
+
+def _config(_myfm, gi, n_iter, task, cutpoint_groups=None, latent="exact"):
+    b = _myfm.ConfigBuilder()
+    b.set_alpha_0(1.0).set_beta_0(1.0).set_gamma_0(1.0).set_mu_0(0.0).set_reg_0(1.0)
+    b.set_group_index([int(g) for g in gi]).set_n_iter(n_iter).set_n_kept_samples(n_iter)
+    b.set_task_type({"classification": _myfm.TaskType.CLASSIFICATION, "ordered": _myfm.TaskType.ORDERED}[task])
+    if cutpoint_groups is not None:
+        b.set_cutpoint_groups([(int(c), [int(r) for r in rows]) for c, rows in cutpoint_groups])
+    b.set_latent_mode(latent)
+    return b.build()
+
+
+def _run_session(_myfm, rank, X, rels, y, cfg, n_iter):
+    """the same loop as create_train_fm, steppable: returns (samples, hypers, cutpoints per iteration, session)"""
+    sess = _myfm.GibbsSession(rank, 0.1, X, rels, y, 42, cfg)
+    samples, hypers, cuts = [], [], []
+    for _ in range(n_iter):
+        sess.step()
+        fm = sess.fm
+        samples.append((fm.w0, np.array(fm.w), np.array(fm.V)))
+        h = sess.hyper  # (a reference to the session's live object: copy the values)
+        hypers.append(dict(lambda_w=np.array(h.lambda_w), mu_w=np.array(h.mu_w), lambda_V=np.array(h.lambda_V), mu_V=np.array(h.mu_V)))
+        cuts.append([np.array(c) for c in fm.cutpoints])
+    return samples, hypers, cuts, sess
+
+
+def _assert_session(samples, hypers, want_samples, want_hypers, tol=1e-7):
+    for (w0, w, V), (w0o, wo, Vo) in zip(samples, want_samples):
+        assert abs(w0 - w0o) <= tol * max(1.0, abs(w0o))
+        np.testing.assert_allclose(w, wo, rtol=tol, atol=tol)
+        np.testing.assert_allclose(V, Vo, rtol=tol, atol=tol)
+    for hd, ho in zip(hypers, want_hypers):
+        for k in ("lambda_w", "lambda_V"):
+            np.testing.assert_allclose(hd[k], ho[k], rtol=tol)
+        for k in ("mu_w", "mu_V"):
+            np.testing.assert_allclose(hd[k], ho[k], rtol=tol, atol=tol)
+
+
+def _classification_case(design):
+    if design == "onehot":
+        X, score, shapes = ds.onehot_mf(30000, 400, 150, seed=4, sort_by_user=True)
+        blocks = []
+        score = score - np.median(score)
+    else:
+        X, blocks, score, shapes = _blocks_design()
+    return X, blocks, np.where(score > 0, 1.0, -1.0), shapes
+
+
+def _ordered_case(design):
+    if design == "blocks":
+        X, blocks, score, shapes = _blocks_design(seed=2)
+        n = X.shape[0]
+    else:
+        n = 20000
+        X, score, shapes = ds.onehot_mf(n, 300, 100, seed=9, sort_by_user=True)
+        blocks = []
+    score = (score - score.mean()) / score.std()
+    if design == "two_groups":
+        rows_a, rows_b = np.arange(0, n, 2), np.arange(1, n, 2)
+        y = np.zeros(n)
+        for c in (-0.4, 0.5):
+            y[rows_a] += score[rows_a] > c
+        for c in (-0.8, 0.0, 0.9):
+            y[rows_b] += score[rows_b] > c
+        groups = [(3, rows_a), (4, rows_b)]
+    else:
+        y = np.zeros(n)
+        for c in (-0.9, -0.2, 0.4, 1.1):
+            y += score > c
+        groups = [(5, np.arange(n))]
+    return X, blocks, y, shapes, groups
+
+
+@pytest.mark.parametrize("design", ["onehot", "blocks"])
+def test_classification_chain_exact_on_device(mods, oracle, design):
+    _myfm, _ = mods
+    X, blocks, y, shapes = _classification_case(design)
+    gi = ds.group_index_from_shapes(shapes)
+    n_iter, rank = 5, 4
+    rels = [_myfm.RelationBlock(np.asarray(m, dtype=np.int64), B) for m, B in blocks]
+    predictor, history = _myfm.create_train_fm(rank, 0.1, X, rels, y, 42, _config(_myfm, gi, n_iter, "classification"), lambda *a: False)
+    samples, hypers, _, _ = _oracle_chain(oracle, X, y, blocks, n_iter, rank=rank, group_index=gi, task=oracle.CLASSIFICATION)
+    _assert_chain(predictor, history, samples, hypers)
+    # ... and it was the parallel evaluation that made the draws, not its sequential fall-back
+    got, gh, _, sess = _run_session(_myfm, rank, X, rels, y, _config(_myfm, gi, n_iter, "classification"), n_iter)
+    _assert_session(got, gh, samples, hypers)
+    info = sess.latent_info()
+    assert info["mode"] == "exact" and info["sequential_fallbacks"] == 0 and info["status"] == 0, info
+    assert info["quads_consumed"] >= X.shape[0]
+
+
+@pytest.mark.parametrize("design", ["one_group", "two_groups", "blocks"])
+def test_ordered_probit_chain_exact_on_device(mods, oracle, design):
+    _myfm, _ = mods
+    X, blocks, y, shapes, groups = _ordered_case(design)
+    gi = ds.group_index_from_shapes(shapes)
+    n_iter, rank = 5, 3
+    rels = [_myfm.RelationBlock(np.asarray(m, dtype=np.int64), B) for m, B in blocks]
+    cfg = _config(_myfm, gi, n_iter, "ordered", cutpoint_groups=groups)
+    predictor, history = _myfm.create_train_fm(rank, 0.1, X, rels, y, 42, cfg, lambda *a: False)
+    samples, hypers, cuts, t = _oracle_chain(oracle, X, y, blocks, n_iter, n_groups_cut=len(groups), rank=rank, group_index=gi,
+                                             task=oracle.ORDERED, cutpoint_groups=groups)
+    _assert_chain(predictor, history, samples, hypers)
+    for fm, cut in zip(predictor.samples, cuts):
+        for g in range(len(groups)):
+            np.testing.assert_allclose(fm.cutpoints[g], cut[g], rtol=1e-7, atol=1e-7)
+    assert list(history.n_mh_accept) == [t.mh_accept(g) for g in range(len(groups))]
+    _, _, _, sess = _run_session(_myfm, rank, X, rels, y, cfg, 2)
+    info = sess.latent_info()
+    assert info["mode"] == "exact" and info["sequential_fallbacks"] == 0, info
+
+
+@pytest.mark.parametrize("env", [
+    {"MFM_LAT_CHUNKS": "64", "MFM_LAT_MIN_LQ": "256", "MFM_LAT_SUBQ": "64", "MFM_LAT_ROUND": "4"},      # many short chunks
+    {"MFM_LAT_CHUNKS": "7", "MFM_LAT_MIN_LQ": "1024", "MFM_LAT_SUBQ": "128", "MFM_LAT_NO_RESIDENT": "1"},  # launches only
+    {"MFM_LAT_CHUNKS": "1"},                                                                               # one chunk: one walker
+    {"MFM_LAT_CHUNKS": "200", "MFM_LAT_MIN_LQ": "128", "MFM_LAT_SUBQ": "128", "MFM_LAT_ROUND": "128"},
+])
+def test_every_geometry_gives_the_same_draws(mods, oracle, monkeypatch, env):
+    """chunk length, sub-chunk length, round length and the hand-over to the resident kernel only change HOW the one sequential
+    path is found: the chain is the oracle's for every choice"""
+    _myfm, _ = mods
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    X, blocks, y, shapes, groups = _ordered_case("one_group")
+    gi = ds.group_index_from_shapes(shapes)
+    n_iter, rank = 3, 3
+    cfg = _config(_myfm, gi, n_iter, "ordered", cutpoint_groups=groups)
+    got, gh, gc, sess = _run_session(_myfm, rank, X, [], y, cfg, n_iter)
+    samples, hypers, cuts, _ = _oracle_chain(oracle, X, y, [], n_iter, n_groups_cut=1, rank=rank, group_index=gi, task=oracle.ORDERED,
+                                             cutpoint_groups=groups)
+    _assert_session(got, gh, samples, hypers)
+    for a, b in zip(gc, cuts):
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-7, atol=1e-7)
+    info = sess.latent_info()
+    assert info["sequential_fallbacks"] == 0, info
+
+
+def test_a_missed_window_falls_back_to_the_same_draws(mods, oracle, monkeypatch):
+    """windows of +-0.02 sigma cannot hold the path: the parallel evaluation reports it without having drawn or consumed anything,
+    and the sequential loop makes the same draws from the same stream position (host window into the device stream)"""
+    _myfm, _ = mods
+    monkeypatch.setenv("MFM_LAT_KSIGMA", "0.02")
+    monkeypatch.setenv("MFM_LAT_CHUNKS", "16")
+    monkeypatch.setenv("MFM_LAT_MIN_LQ", "512")
+    for task in ("classification", "ordered"):
+        if task == "classification":
+            X, blocks, y, shapes = _classification_case("onehot")
+            groups = None
+        else:
+            X, blocks, y, shapes, groups = _ordered_case("one_group")
+        gi = ds.group_index_from_shapes(shapes)
+        n_iter, rank = 3, 3
+        cfg = _config(_myfm, gi, n_iter, task, cutpoint_groups=groups)
+        got, gh, gc, sess = _run_session(_myfm, rank, X, [], y, cfg, n_iter)
+        samples, hypers, cuts, _ = _oracle_chain(oracle, X, y, [], n_iter, n_groups_cut=1 if groups else 0, rank=rank, group_index=gi,
+                                                 task=oracle.ORDERED if groups else oracle.CLASSIFICATION, cutpoint_groups=groups)
+        _assert_session(got, gh, samples, hypers)
+        info = sess.latent_info()
+        assert info["sequential_fallbacks"] >= n_iter, info
+
+
+def test_exact_equals_host_mode_on_two_million_rows(mods):
+    """2 M rows, 5 classes: the device evaluation against the host loop over the same scores (latent mode "host" keeps the whole
+    generator on the host): residual after every iteration to 1e-9, hyper-parameters, cutpoints"""
+    _myfm, _ = mods
+    from myfm_amd.utils import synthetic as syn
+
+    X, y, shapes = syn.movielens_like(2_000_000, 20000, 3000, rank_true=8, seed=3)
+    yo = (np.clip(np.round(y), 1, 5) - 1).astype(np.float64)
+    gi = syn.group_index_from_shapes(shapes)
+    groups = [(5, np.arange(X.shape[0]))]
+    n_iter, rank = 3, 4
+
+    def cfg(latent):
+        b = _myfm.ConfigBuilder()
+        b.set_alpha_0(1.0).set_beta_0(1.0).set_gamma_0(1.0).set_mu_0(0.0).set_reg_0(1.0)
+        b.set_group_index([int(g) for g in gi]).set_n_iter(n_iter).set_n_kept_samples(0)
+        b.set_task_type(_myfm.TaskType.ORDERED).set_cutpoint_groups([(5, np.arange(X.shape[0]))])
+        b.set_latent_mode(latent)
+        return b.build()
+
+    a = _myfm.GibbsSession(rank, 0.1, X, [], yo, 42, cfg("exact"))
+    b = _myfm.GibbsSession(rank, 0.1, X, [], yo, 42, cfg("host"))
+    for _ in range(n_iter):
+        a.step()
+        b.step()
+        np.testing.assert_allclose(a.residual(), b.residual(), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(np.array(a.fm.cutpoints[0]), np.array(b.fm.cutpoints[0]), rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(np.array(a.fm.V), np.array(b.fm.V), rtol=1e-8, atol=1e-8)
+    info = a.latent_info()
+    assert info["sequential_fallbacks"] == 0 and info["chunks"] > 100, info
