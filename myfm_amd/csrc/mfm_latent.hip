@@ -110,31 +110,22 @@ __device__ __forceinline__ double2 lat_record(double pred, double yv, int n_clas
 
 struct LatRow {  // what a walker keeps of its row
   double s, o, sh, c;  // E / T: z = X s + o, a = (c - (z - sh)^2) / 2;  N: o = mu
-  double tol;          // relative half-width of the band decided by the exact expression
-  int kind;            // 0 N, 1 E, 2 T
+  bool isN, isE, wide;  // wide: E with alpha* >= 1000 -- the shortcut 1 / alpha* = alpha* - mu loses too many digits: always exact
 };
+// (selects only, no branches: the walkers of a wave are in different regimes at every step)
 __device__ __forceinline__ LatRow lat_derive(double A, double B) {
   LatRow r;
-  if (B != B) {
-    r.kind = 0;
-    r.o = A;
-    r.s = r.sh = r.c = 0.0;
-    r.tol = 0.0;
-  } else if (A > B) {
-    r.kind = 1;
-    r.s = A - B;  // = 1 / alpha* up to rounding ((sqrt(mu^2 + 4) - mu) / 2); the band absorbs the difference
-    r.o = B;
-    r.sh = A;
-    r.c = 0.0;
-    r.tol = A < 1e3 ? 1e-9 : __builtin_inf();
-  } else {
-    r.kind = 2;
-    r.s = B - A;
-    r.o = A;
-    r.sh = 0.0;
-    r.c = (A <= 0.0 && B >= 0.0) ? 0.0 : (B < 0.0 ? B * B : A * A);
-    r.tol = 1e-9;
-  }
+  r.isN = B != B;
+  r.isE = A > B;  // (false for NaN)
+  const double d = B - A;
+  r.o = r.isE ? B : A;
+  r.s = r.isE ? -d : d;  // E: alpha* - mu = 1 / alpha* up to rounding ((sqrt(mu^2 + 4) - mu) / 2): the band absorbs the difference
+  r.sh = r.isE ? A : 0.0;
+  // two-sided: 0 when the interval holds 0, else the square of the bound next to 0 (util.hpp:48-55) = max(a, 0)^2 + min(b, 0)^2
+  const double ap = fmax(A, 0.0), bn = fmin(B, 0.0);
+  const double cc = __builtin_fma(ap, ap, bn * bn);
+  r.c = (r.isN | r.isE) ? 0.0 : cc;
+  r.wide = r.isE & !(A < 1e3);
   return r;
 }
 
@@ -143,7 +134,7 @@ struct LatQuad {
 };
 
 // u2 < rho by the reference's own expressions (util.hpp:29-35, :46-59)
-__device__ __noinline__ bool lat_accept_exact(double A, double B, double u1, double nl1, double u2) {
+__device__ __forceinline__ bool lat_accept_exact(double A, double B, double u1, double nl1, double u2) {
   double rho;
   if (A > B) {
     const double z = nl1 / A + B;
@@ -168,19 +159,22 @@ __device__ __forceinline__ double lat_u2(const uint32_t *__restrict__ raw, uint6
 // does row (A, B) accept quad j?
 __device__ __forceinline__ bool lat_accept(const LatRow &r, double A, double B, const LatQuad &q, const uint32_t *__restrict__ raw,
                                            uint64_t mask, uint64_t p0, int64_t j) {
-  if (r.kind == 0) return (q.n1 > r.o) || (q.n2 > r.o);
-  const double X = r.kind == 1 ? q.nl1 : q.u1;
-  const double z = X * r.s + r.o;
+  const double X = r.isE ? q.nl1 : q.u1;
+  const double z = __builtin_fma(X, r.s, r.o);
   const double d = z - r.sh;
-  const double a = (r.c - d * d) * 0.5;
+  const double a = __builtin_fma(-d, d, r.c) * 0.5;
   const double diff = q.l2 - a;
-  if (fabs(diff) > r.tol * (1.0 + fabs(a))) return diff < 0.0;  // (NaN: inf - inf -> the exact expression)
-  return lat_accept_exact(A, B, q.u1, q.nl1, lat_u2(raw, mask, p0, j));
+  const bool accN = (q.n1 > r.o) | (q.n2 > r.o);
+  bool acc = r.isN ? accN : diff < 0.0;
+  // inside the band (or NaN: inf - inf) the reference's own expression decides -- one lane in 10^8 steps
+  const bool band = !r.isN & (!(fabs(diff) > __builtin_fma(fabs(a), 1e-9, 1e-9)) | r.wide);
+  if (band) acc = lat_accept_exact(A, B, q.u1, q.nl1, lat_u2(raw, mask, p0, j));
+  return acc;
 }
 // the accepted value (util.hpp:21-23, :29, :45)
 __device__ __forceinline__ double lat_value(const LatRow &r, double A, double B, const LatQuad &q) {
-  if (r.kind == 0) return q.n1 > r.o ? q.n1 : q.n2;
-  if (r.kind == 1) return q.nl1 / A + B;
+  if (r.isN) return q.n1 > r.o ? q.n1 : q.n2;
+  if (r.isE) return q.nl1 / A + B;
   return q.u1 * (B - A) + A;
 }
 __device__ __forceinline__ LatQuad lat_load_quad(const double *__restrict__ qt, int64_t j) {
@@ -393,27 +387,53 @@ __global__ __launch_bounds__(1024) void k_lat_windows(const double *__restrict__
 }
 
 // ---- a walker's R steps -------------------------------------------------------------------------------
+// The quads of a round are the same for every walker of the chunk (wave-uniform addresses: scalar loads); they are fetched four
+// steps ahead of their use. A walker keeps the records of the next three rows in registers: the load issued when a row is accepted
+// is not needed before the third acceptance after it.
 struct LatWalker {
   int32_t t;
-  double2 r, nx;  // records of row t and row t + 1
+  double2 r, n1, n2, n3;  // records of rows t, t + 1, t + 2, t + 3
   LatRow w;
 };
 __device__ __forceinline__ void lat_walker_load(LatWalker &k, const double2 *__restrict__ rec, int64_t n) {
   k.r = rec[k.t];
-  k.nx = rec[min((int64_t)k.t + 1, n)];
+  k.n1 = rec[min((int64_t)k.t + 1, n)];
+  k.n2 = rec[min((int64_t)k.t + 2, n)];
+  k.n3 = rec[min((int64_t)k.t + 3, n)];
   k.w = lat_derive(k.r.x, k.r.y);
 }
+__device__ __forceinline__ void lat_step(LatWalker &k, const double2 *__restrict__ rec, int64_t n, const LatQuad &q, int64_t j,
+                                         const uint32_t *__restrict__ raw, uint64_t mask, uint64_t p0) {
+  if (lat_accept(k.w, k.r.x, k.r.y, q, raw, mask, p0, j)) {
+    k.t++;
+    k.r = k.n1;
+    k.n1 = k.n2;
+    k.n2 = k.n3;
+    k.n3 = rec[min((int64_t)k.t + 3, n)];
+    k.w = lat_derive(k.r.x, k.r.y);
+  }
+}
+// (the quad table is padded by LAT_QPAD records: the look-ahead of the last round reads past the last quad)
+constexpr int LAT_QPAD = 40;
 __device__ __forceinline__ void lat_walk(LatWalker &k, const double2 *__restrict__ rec, int64_t n, const double *__restrict__ qt,
                                          int64_t j0, int R, const uint32_t *__restrict__ raw, uint64_t mask, uint64_t p0) {
-  for (int s = 0; s < R; s++) {
-    const LatQuad q = lat_load_quad(qt, j0 + s);  // (wave-uniform address)
-    if (lat_accept(k.w, k.r.x, k.r.y, q, raw, mask, p0, j0 + s)) {
-      k.t++;
-      k.r = k.nx;
-      k.w = lat_derive(k.r.x, k.r.y);
-      k.nx = rec[min((int64_t)k.t + 1, n)];
-    }
+  LatQuad q0 = lat_load_quad(qt, j0), q1 = lat_load_quad(qt, j0 + 1), q2 = lat_load_quad(qt, j0 + 2), q3 = lat_load_quad(qt, j0 + 3);
+  int s = 0;
+  for (; s + 4 <= R; s += 4) {
+    const LatQuad a0 = lat_load_quad(qt, j0 + s + 4), a1 = lat_load_quad(qt, j0 + s + 5), a2 = lat_load_quad(qt, j0 + s + 6),
+                  a3 = lat_load_quad(qt, j0 + s + 7);
+    lat_step(k, rec, n, q0, j0 + s, raw, mask, p0);
+    lat_step(k, rec, n, q1, j0 + s + 1, raw, mask, p0);
+    lat_step(k, rec, n, q2, j0 + s + 2, raw, mask, p0);
+    lat_step(k, rec, n, q3, j0 + s + 3, raw, mask, p0);
+    q0 = a0;
+    q1 = a1;
+    q2 = a2;
+    q3 = a3;
   }
+  if (s < R) lat_step(k, rec, n, q0, j0 + s, raw, mask, p0);
+  if (s + 1 < R) lat_step(k, rec, n, q1, j0 + s + 1, raw, mask, p0);
+  if (s + 2 < R) lat_step(k, rec, n, q2, j0 + s + 2, raw, mask, p0);
 }
 
 // every live walker of every chunk: R quads from quad c Lq + done. grid (tiles, C)
@@ -501,8 +521,27 @@ __global__ __launch_bounds__(1024) void k_lat_compact(const int32_t *__restrict_
 
 // ---- the rest of a chunk in one launch: a workgroup per chunk, a walker per thread -------------------------------------
 // Waves work on their own 64 walkers without workgroup barriers: after every round a wave merges the walkers that met among its own
-// (sorted, so a compare with the lane below) through a private LDS strip; at every sub-chunk boundary the workgroup gathers all
-// walkers, merges across the wave borders, writes the snapshot and hands the survivors out again (full waves first).
+// (sorted, so a compare with the lane below); at every sub-chunk boundary the workgroup gathers all walkers, merges across the wave
+// borders, writes the snapshot and hands the survivors out again (full waves first).
+//
+// Memory never sits on the path of a step:
+//  * rows. A walker reads its rows in order, one per acceptance, each a dependent 16-byte gather. Every lane keeps the records of
+//    rows t + 1 .. t + 8 in a private LDS ring (slot = row & 7). Steps run in groups of four: at the start of a group the lane
+//    requests the rows the ring will miss after it (it holds rows up to hi - 1 >= t + 4, a group accepts at most four: rows
+//    hi .. t + 8, at most four 16-byte loads), at the end of the group it stores them into the ring.
+//  * quads. The 16 quads of a segment (640 bytes, the same for every walker of the chunk) are read by broadcast from a per-wave LDS
+//    strip; the next segment's strip is requested at the start of a segment and stored (other buffer) at its end. (Scalar loads
+//    would do for a wave-uniform address -- but SMEM returns out of order: with one in flight every wait for an LDS read becomes
+//    lgkmcnt(0) and pays the scalar load's latency at every step.)
+// The loads are inline asm, their results pass through the `s_waitcnt` that ends the group / segment: nothing is in flight across a
+// loop back-edge, where the register allocator may copy registers.
+typedef double lat_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lat_d2v lat_asm_load(const double2 *p) {
+  lat_d2v v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__ rec, const double *__restrict__ qt,
                                                      const uint32_t *__restrict__ raw, uint64_t mask,
@@ -513,9 +552,14 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
                                                      int2 *__restrict__ snap, int64_t *__restrict__ snap_idx,
                                                      int32_t *__restrict__ snap_cnt, LatStatus *__restrict__ st) {
   constexpr int NW = NT / 64;
-  __shared__ int s_t[2][NT], s_f[2][NT];
-  __shared__ double2 s_r[2][NT], s_n[2][NT];
-  __shared__ int s_cnt[NW];
+  constexpr int QS = 16;                     // quads per segment
+  extern __shared__ double2 lat_lds[];
+  double2 *ring = lat_lds;                   // [8][NT]
+  int *s_t0 = (int *)(lat_lds + 8 * NT);     // [NT] x 2: t / first_in of the gather
+  int *s_f0 = s_t0 + NT;
+  int *s_cnt = s_f0 + NT;                    // [16]
+  double *strips = (double *)(s_cnt + 16);   // [NW][2][QS * LAT_QW]
+  int *s_t1 = (int *)ring, *s_f1 = s_t1 + NT;  // second stage of the redistribution: the ring is refilled after it anyway
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint64_t p0 = rs->p_cons;
   const int64_t J0 = (int64_t)c * Lq;
@@ -527,54 +571,106 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
   const int64_t off = list_off[c];
   int64_t sp = done0 >= subq ? snap_pos[c] : snap_off[c];
   const int64_t sp_end = snap_off[c + 1];
-  // this wave's walkers: lanes [0, wl)
+  const double2 *rec_end = rec + n;  // the record after the last row: accepts nothing
   int wl = max(0, min(64, nl - wid * 64));
-  LatWalker k;
-  int f = 0;
-  k.t = 0;
+  int32_t t = (int32_t)n, f = 0, hi = 0;
+  double2 r;
+  LatRow w;
   if (lane < wl) {
-    k.t = scur[off + tid];
+    t = scur[off + tid];
     f = sfin[off + tid];
   }
-  k.t = lane < wl ? k.t : (int32_t)n;
-  lat_walker_load(k, rec, n);
-  int done = done0;
+  // (re)start of a lane's row supply: the current record and the ring's rows t + 1 .. t + 8 by plain loads
+  auto prime = [&]() {
+    r = rec[t];
+#pragma unroll
+    for (int k = 1; k <= 8; k++) ring[(size_t)((t + k) & 7) * NT + tid] = rec[min((int64_t)t + k, n)];
+    hi = t + 9;
+    w = lat_derive(r.x, r.y);
+  };
+  prime();
+  double *strip0 = strips + (size_t)wid * (2 * QS * LAT_QW);
+  auto quad_addr = [&](int64_t j) { return (const double2 *)(qt + (size_t)j * LAT_QW) + (lane < QS * LAT_QW / 2 ? lane : 0); };
+  int done = done0, buf = 0;
+  bool strip_ready = false;  // strips[buf] holds the quads of the segment that starts at `done`
   while (done < (int)Lq) {
     const int to_boundary = subq - (done % subq);
     const int Rr = min(R, to_boundary);
     if (wl > 0) {
-      lat_walk(k, rec, n, qt, J0 + done, Rr, raw, mask, p0);
-      // merge inside the wave
-      const int prev = __shfl_up(k.t, 1, 64);
-      const bool keep = lane < wl && (lane == 0 || k.t != prev);
+      for (int seg = 0; seg < Rr; seg += QS) {
+        const int S = min(QS, Rr - seg);
+        const int64_t j0 = J0 + done + seg;
+        double *strip = strip0 + buf * (QS * LAT_QW);
+        if (!strip_ready) {
+          lat_d2v q = lat_asm_load(quad_addr(j0));
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(q) : : "memory");
+          if (lane < QS * LAT_QW / 2) ((double2 *)strip)[lane] = make_double2(q.x, q.y);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        lat_d2v qnext = lat_asm_load(quad_addr(j0 + QS));  // (the table is padded: the last look-ahead stays inside it)
+        for (int k0 = 0; k0 < S; k0 += 4) {
+          // rows the ring will miss after this group
+          const int m = t + 9 - hi;  // 0 .. 4
+          lat_d2v l0 = lat_asm_load(m > 0 ? rec + min((int64_t)hi, n) : rec_end);
+          lat_d2v l1 = lat_asm_load(m > 1 ? rec + min((int64_t)hi + 1, n) : rec_end);
+          lat_d2v l2 = lat_asm_load(m > 2 ? rec + min((int64_t)hi + 2, n) : rec_end);
+          lat_d2v l3 = lat_asm_load(m > 3 ? rec + min((int64_t)hi + 3, n) : rec_end);
+          const int ke = min(4, S - k0);
+          for (int k = 0; k < ke; k++) {
+            const double *qp = strip + (k0 + k) * LAT_QW;
+            LatQuad q;
+            q.u1 = qp[0];
+            q.l2 = qp[1];
+            q.nl1 = qp[2];
+            q.n1 = qp[3];
+            q.n2 = qp[4];
+            const double2 nx = ring[(size_t)((t + 1) & 7) * NT + tid];
+            const bool acc = lat_accept(w, r.x, r.y, q, raw, mask, p0, j0 + k0 + k);
+            t += acc ? 1 : 0;
+            r.x = acc ? nx.x : r.x;
+            r.y = acc ? nx.y : r.y;
+            w = lat_derive(r.x, r.y);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(qnext) : : "memory");
+          if (m > 0) ring[(size_t)(hi & 7) * NT + tid] = make_double2(l0.x, l0.y);
+          if (m > 1) ring[(size_t)((hi + 1) & 7) * NT + tid] = make_double2(l1.x, l1.y);
+          if (m > 2) ring[(size_t)((hi + 2) & 7) * NT + tid] = make_double2(l2.x, l2.y);
+          if (m > 3) ring[(size_t)((hi + 3) & 7) * NT + tid] = make_double2(l3.x, l3.y);
+          hi += m;
+        }
+        // the next segment's quads into the other strip
+        buf ^= 1;
+        if (lane < QS * LAT_QW / 2) ((double2 *)(strip0 + buf * (QS * LAT_QW)))[lane] = make_double2(qnext.x, qnext.y);
+        strip_ready = S == QS;  // (a short segment ends at a boundary of the round: the next one starts elsewhere)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      // merge inside the wave: the walkers are sorted, a walker that met the one below it is dropped
+      const int prev = __shfl_up(t, 1, 64);
+      const bool keep = lane < wl && (lane == 0 || t != prev);
       const unsigned long long b = __ballot(keep);
       const int cnt = __popcll(b);
       if (cnt != wl) {
-        const int r = __popcll(b & ((1ull << lane) - 1ull));
+        const int rk = __popcll(b & ((1ull << lane) - 1ull));
         const int base = wid * 64;
         if (keep) {
-          s_t[0][base + r] = k.t;
-          s_f[0][base + r] = f;
-          s_r[0][base + r] = k.r;
-          s_n[0][base + r] = k.nx;
+          s_t0[base + rk] = t;
+          s_f0[base + rk] = f;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         wl = cnt;
-        if (lane < wl) {
-          k.t = s_t[0][base + lane];
-          f = s_f[0][base + lane];
-          k.r = s_r[0][base + lane];
-          k.nx = s_n[0][base + lane];
-        } else {
-          k.t = (int32_t)n;
-          k.r = rec[n];
-          k.nx = k.r;
-        }
-        k.w = lat_derive(k.r.x, k.r.y);
+        t = lane < wl ? s_t0[base + lane] : (int32_t)n;
+        f = lane < wl ? s_f0[base + lane] : 0;
         __builtin_amdgcn_wave_barrier();
+        prime();
       }
+    } else {
+      strip_ready = false;
     }
     done += Rr;
     if (done % subq == 0) {
@@ -583,46 +679,39 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
       if (lane == 0) s_cnt[wid] = wl;
       __syncthreads();
       int before = 0, tot = 0;
-      for (int w = 0; w < NW; w++) {
-        const int cw = s_cnt[w];
-        if (w < wid) before += cw;
+      for (int k = 0; k < NW; k++) {
+        const int cw = s_cnt[k];
+        if (k < wid) before += cw;
         tot += cw;
       }
       if (lane < wl) {
-        s_t[0][before + lane] = k.t;
-        s_f[0][before + lane] = f;
-        s_r[0][before + lane] = k.r;
-        s_n[0][before + lane] = k.nx;
+        s_t0[before + lane] = t;
+        s_f0[before + lane] = f;
       }
       __syncthreads();
       bool keep = false;
       int t2 = 0, f2 = 0;
-      double2 r2 = make_double2(0, 0), n2 = r2;
       if (tid < tot) {
-        t2 = s_t[0][tid];
-        keep = tid == 0 || t2 != s_t[0][tid - 1];
-        f2 = s_f[0][tid];
-        r2 = s_r[0][tid];
-        n2 = s_n[0][tid];
+        t2 = s_t0[tid];
+        keep = tid == 0 || t2 != s_t0[tid - 1];
+        f2 = s_f0[tid];
       }
       const unsigned long long b = __ballot(keep);
       __syncthreads();
       if (lane == 0) s_cnt[wid] = __popcll(b);
       __syncthreads();
       int before2 = 0, tot2 = 0;
-      for (int w = 0; w < NW; w++) {
-        const int cw = s_cnt[w];
-        if (w < wid) before2 += cw;
+      for (int k = 0; k < NW; k++) {
+        const int cw = s_cnt[k];
+        if (k < wid) before2 += cw;
         tot2 += cw;
       }
       const int sk = done / subq - 1;
       if (keep) {
-        const int r = before2 + __popcll(b & ((1ull << lane) - 1ull));
-        s_t[1][r] = t2;
-        s_f[1][r] = f2;
-        s_r[1][r] = r2;
-        s_n[1][r] = n2;
-        if (sp + r < sp_end) snap[sp + r] = make_int2(f2, t2);
+        const int rk = before2 + __popcll(b & ((1ull << lane) - 1ull));
+        s_t1[rk] = t2;  // (in the ring's memory: every lane is past its last ring read, and refills the ring below)
+        s_f1[rk] = f2;
+        if (sp + rk < sp_end) snap[sp + rk] = make_int2(f2, t2);
       }
       if (tid == 0) {
         if (sp + tot2 > sp_end) lat_fail(st, 2, c);
@@ -633,18 +722,10 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
       __syncthreads();
       nl = tot2;
       wl = max(0, min(64, nl - wid * 64));
-      if (lane < wl) {
-        k.t = s_t[1][tid];
-        f = s_f[1][tid];
-        k.r = s_r[1][tid];
-        k.nx = s_n[1][tid];
-      } else {
-        k.t = (int32_t)n;
-        k.r = rec[n];
-        k.nx = k.r;
-      }
-      k.w = lat_derive(k.r.x, k.r.y);
+      t = lane < wl ? s_t1[tid] : (int32_t)n;
+      f = lane < wl ? s_f1[tid] : 0;
       __syncthreads();
+      prime();
     }
   }
 }
@@ -863,7 +944,7 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
   const int64_t nb = (n + LAT_RB - 1) / LAT_RB;
   const int64_t list_cap = (int64_t)C * Wmax;
   const int64_t snap_cap = (int64_t)C * (lat_snap_cap(Wmax, nsub, Lq, subq) + 1);
-  Impl::ensure(m.qt, (size_t)nq * LAT_QW);
+  Impl::ensure(m.qt, (size_t)(nq + LAT_QPAD) * LAT_QW);
   Impl::ensure(m.win_lo, (size_t)C);
   Impl::ensure(m.win_hi, (size_t)C);
   Impl::ensure(m.live, (size_t)C);
@@ -921,7 +1002,16 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
   }
   const int rounds_done = round, handover = done;
   if (done < Lq) {
-    hipLaunchKernelGGL((k_lat_resident<LAT_RES_NT>), dim3((unsigned)C), dim3(LAT_RES_NT), 0, s, m.rec.p, m.qt.p, job.raw, job.mask,
+    const size_t lds = (size_t)8 * LAT_RES_NT * sizeof(double2) + (size_t)(2 * LAT_RES_NT + 16) * sizeof(int) +
+                       (size_t)(LAT_RES_NT / 64) * 2 * 16 * LAT_QW * sizeof(double);
+    {
+      static DeviceOnce raised;
+      if (raised.need()) {
+        MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_lat_resident<LAT_RES_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised.mark();
+      }
+    }
+    hipLaunchKernelGGL((k_lat_resident<LAT_RES_NT>), dim3((unsigned)C), dim3(LAT_RES_NT), lds, s, m.rec.p, m.qt.p, job.raw, job.mask,
                        job.state, n, Lq, done, R, subq, nsub, m.live.p, m.list_off.p, sc, sf, m.snap_off.p, m.snap_pos.p, m.snap.p,
                        m.snap_idx.p, m.snap_cnt.p, m.status.p);
   }
