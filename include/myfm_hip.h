@@ -280,13 +280,15 @@ int mfm_rng_get_z(mfm_ctx *ctx, double *zw, double *zv);
  * (csrc/mfm_latent.hip). No set may be in flight (acquire what was prefetched first); the next mfm_rng_prefetch starts where
  * the draw ended. *status: 0 = done. Otherwise NOTHING was drawn or consumed (e still holds the scores) and the caller makes
  * the draws sequentially through mfm_rng_host_read / mfm_rng_host_advance: 1 = the true path left a chunk's window of
- * candidate rows (probability ~1e-6 per call), 2 / 3 = scratch space, 4 = more engine outputs needed than prepared.
+ * candidate rows even at +-6.5 sigma (probability ~1e-8 per call), 2 / 3 = scratch space, 4 = more engine outputs needed than
+ * prepared, 5 = a score more than 1000 standard deviations on the wrong side of its class.
  * mfm_update_e_classification_exact = FM::predict_score_write_target + the draws (the exact twin of
  * mfm_update_e_classification); mfm_oprobit_sample_z_exact = sample_z_given_cutpoint for one cutpoint group on the current e. */
 int mfm_update_e_classification_exact(mfm_ctx *ctx, int32_t *status);
 int mfm_oprobit_sample_z_exact(mfm_ctx *ctx, int32_t group, const double *gamma, int32_t *status);
-/* diagnostics of the last exact draw: {status, chunks, sub-chunks per chunk, quads per chunk, quads consumed, walkers started} */
-int mfm_latent_stats(mfm_ctx *ctx, int64_t *out6);
+/* diagnostics of the last exact draw: {status, chunks, sub-chunks per chunk, quads per chunk, quads consumed, walkers started,
+ * attempts (2: the first attempt's windows of +-4 sigma missed the path, the second's +-6.5 sigma held it), reserved} */
+int mfm_latent_stats(mfm_ctx *ctx, int64_t *out8);
 /* The host's window into the device stream: out[0..n) = the engine outputs (tempered, as std::mt19937::operator() returns them)
  * number offset .. offset + n - 1 counted from the stream's position; mfm_rng_host_advance moves the position by `words` outputs.
  * For the few draws the host makes itself between two sets (the cutpoint sampler's Metropolis step, OProbitSampler.hpp:55-72,

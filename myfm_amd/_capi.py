@@ -410,9 +410,9 @@ class Context:
         return st.value
 
     def latent_stats(self):
-        out = np.zeros(6, dtype=np.int64)
+        out = np.zeros(8, dtype=np.int64)
         self._ck(lib().mfm_latent_stats(self.h, _p(out)))
-        return dict(zip(("status", "chunks", "subs", "lq", "quads", "walkers"), (int(v) for v in out)))
+        return dict(zip(("status", "chunks", "subs", "lq", "quads", "walkers", "attempts"), (int(v) for v in out)))
 
     def rng_host_read(self, offset, n):
         out = np.empty(max(int(n), 1), dtype=np.uint32)

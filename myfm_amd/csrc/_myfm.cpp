@@ -1725,7 +1725,7 @@ struct GibbsSession {
   }
   // latent mode "exact": geometry of the last parallel draw and how many draws took the sequential loop instead
   py::dict latent_info() {
-    int64_t v[6] = {0, 0, 0, 0, 0, 0};
+    int64_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     ck(trainer->ctx, mfm_latent_stats(trainer->ctx, v));
     int64_t fb = trainer->exact_fallbacks;
     for (auto &cs : trainer->cutpoint_sampler) fb += cs.exact_fallbacks;
@@ -1737,6 +1737,7 @@ struct GibbsSession {
     d["quads_per_chunk"] = v[3];
     d["quads_consumed"] = v[4];
     d["walkers_started"] = v[5];
+    d["attempts"] = v[6];
     d["sequential_fallbacks"] = fb;
     return d;
   }

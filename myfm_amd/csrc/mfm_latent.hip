@@ -4,7 +4,8 @@
 //   k_lat_rows     per row of the group: the standardised truncation bounds as a 16-byte record, the acceptance probability p of
 //                  one quad (closed form) -> expected quads 1/p and variance (1 - p)/p^2, block sums
 //   k_lat_scan     prefix sums of the blocks (expected position of every 1024-th row, its variance)
-//   k_lat_quads    per quad j: (u1, log u2, -log u1, the polar pair's two normals) from the ring of MT19937 outputs
+//   k_lat_quads    per quad j: (u1, -log u1 - 1, log u2, the larger of the polar pair's two normals) for the decisions and
+//                  (first normal, -log u1) for the accepted values, from the ring of MT19937 outputs
 //   k_lat_windows  per chunk c of Lq quads: the rows [lo, hi] that can be in service at quad c Lq (mean +- k sigma)
 //   k_lat_round    every live walker of every chunk walks R quads: t += A(t, j)
 //   k_lat_compact  per chunk: walkers that met (equal t, they are sorted) are merged; at sub-chunk boundaries the list
@@ -32,7 +33,7 @@ namespace {
 constexpr int LAT_RB = 1024;     // rows per block of the row pass
 constexpr int LAT_TILE = 256;    // walkers per workgroup of k_lat_round
 constexpr int LAT_RES_NT = 512;  // threads (= walkers at most) of the resident kernel
-constexpr int LAT_QW = 5;        // doubles per quad record
+constexpr int LAT_QW = 4;        // doubles per quad record of the flows
 
 struct LatStatus {
   int32_t fail;        // first failure code (0: none)
@@ -108,32 +109,44 @@ __device__ __forceinline__ double2 lat_record(double pred, double yv, int n_clas
   return make_double2(alpha, mu);
 }
 
-struct LatRow {  // what a walker keeps of its row
-  double s, o, sh, c;  // E / T: z = X s + o, a = (c - (z - sh)^2) / 2;  N: o = mu
-  bool isN, isE, wide;  // wide: E with alpha* >= 1000 -- the shortcut 1 / alpha* = alpha* - mu loses too many digits: always exact
+// ---- the walkers' form of a row and of a quad ---------------------------------------------------------------------------
+// A walker decides "does my row accept this quad" ~10^10 times per draw of 5 10^7 rows: the decision is ONE straight-line expression
+// for all three regimes, on a 16-byte row record (wA, wB) and a 32-byte quad record (xT, xE, l2, m):
+//   N  (wA, wB) = (mu, NaN)            accepted  <=>  m > mu,                        m = max of the polar pair's two normals (NaN: no pair)
+//   T  (wA, wB) = (a, b)               accepted  <=>  l2 < (c - (a + (b - a) xT)^2) / 2,   c = max(a, 0)^2 + min(b, 0)^2 (util.hpp:48-55)
+//   E  (wA, wB) = (-0.0, alpha* - mu)  accepted  <=>  l2 < -((alpha* - mu) xE)^2 / 2,      xE = -log(u1) - 1
+// E is T's formula with a = -0 (c = 0): z - alpha* = -log(u1) / alpha* + mu - alpha* = (alpha* - mu)(-log(u1) - 1) because
+// 1 / alpha* = alpha* - mu = (sqrt(mu^2 + 4) - mu) / 2 -- an identity of real numbers: in doubles the two sides differ by
+// ~1e-16 alpha*^2 relative, which the band below absorbs (rows with alpha* > 1000, scores a thousand standard deviations on the
+// wrong side of their class, send the whole draw to the sequential loop). A two-sided row whose lower bound is exactly -0.0 is
+// stored with +0.0. l2 = log u2: u2 < exp(x) <=> log u2 < x. Within a relative band of 4e-9 around equality (and for inf - inf) the
+// reference's own expression decides (lat_accept_exact: exp, the division, the original record).
+struct LatQ {
+  double xT, xE, l2, m;
 };
-// (selects only, no branches: the walkers of a wave are in different regimes at every step)
-__device__ __forceinline__ LatRow lat_derive(double A, double B) {
-  LatRow r;
-  r.isN = B != B;
-  r.isE = A > B;  // (false for NaN)
-  const double d = B - A;
-  r.o = r.isE ? B : A;
-  r.s = r.isE ? -d : d;  // E: alpha* - mu = 1 / alpha* up to rounding ((sqrt(mu^2 + 4) - mu) / 2): the band absorbs the difference
-  r.sh = r.isE ? A : 0.0;
-  // two-sided: 0 when the interval holds 0, else the square of the bound next to 0 (util.hpp:48-55) = max(a, 0)^2 + min(b, 0)^2
-  const double ap = fmax(A, 0.0), bn = fmin(B, 0.0);
-  const double cc = __builtin_fma(ap, ap, bn * bn);
-  r.c = (r.isN | r.isE) ? 0.0 : cc;
-  r.wide = r.isE & !(A < 1e3);
-  return r;
+__device__ __forceinline__ bool lat_decide(double wA, double wB, const LatQ &q, bool &band) {
+  const bool isN = wB != wB;
+  const bool isE = __double_as_longlong(wA) == (long long)0x8000000000000000ull;
+  const double X = isE ? q.xE : q.xT;
+  const double w = wB - wA;
+  const double zz = __builtin_fma(w, X, wA);
+  const double ap = fmax(wA, 0.0), bn = fmin(wB, 0.0);
+  const double c = __builtin_fma(ap, ap, bn * bn);
+  const double arg = 0.5 * __builtin_fma(-zz, zz, c);
+  const double diff = q.l2 - arg;
+  band = !isN & !(fabs(diff) > __builtin_fma(fabs(arg), 4e-9, 4e-9));
+  return isN ? (q.m > wA) : (diff < 0.0);
+}
+__device__ __forceinline__ double2 lat_walker_record(double A, double B, bool *too_wide) {
+  if (B != B) return make_double2(A, B);
+  if (A > B) {
+    if (!(A < 1e3)) *too_wide = true;
+    return make_double2(-0.0, A - B);
+  }
+  return make_double2(A == 0.0 ? 0.0 : A, B);
 }
 
-struct LatQuad {
-  double u1, l2, nl1, n1, n2;
-};
-
-// u2 < rho by the reference's own expressions (util.hpp:29-35, :46-59)
+// u2 < rho by the reference's own expressions (util.hpp:29-35, :46-59) on the ORIGINAL record (A, B)
 __device__ __forceinline__ bool lat_accept_exact(double A, double B, double u1, double nl1, double u2) {
   double rho;
   if (A > B) {
@@ -150,49 +163,48 @@ __device__ __forceinline__ bool lat_accept_exact(double A, double B, double u1, 
   }
   return u2 < rho;
 }
-
 __device__ __forceinline__ double lat_u2(const uint32_t *__restrict__ raw, uint64_t mask, uint64_t p0, int64_t j) {
   const uint64_t b = p0 + 4ull * (uint64_t)j;
   return canonical(mt_temper(raw[(b + 2) & mask]), mt_temper(raw[(b + 3) & mask]));
 }
-
-// does row (A, B) accept quad j?
-__device__ __forceinline__ bool lat_accept(const LatRow &r, double A, double B, const LatQuad &q, const uint32_t *__restrict__ raw,
-                                           uint64_t mask, uint64_t p0, int64_t j) {
-  const double X = r.isE ? q.nl1 : q.u1;
-  const double z = __builtin_fma(X, r.s, r.o);
-  const double d = z - r.sh;
-  const double a = __builtin_fma(-d, d, r.c) * 0.5;
-  const double diff = q.l2 - a;
-  const bool accN = (q.n1 > r.o) | (q.n2 > r.o);
-  bool acc = r.isN ? accN : diff < 0.0;
-  // inside the band (or NaN: inf - inf) the reference's own expression decides -- one lane in 10^8 steps
-  const bool band = !r.isN & (!(fabs(diff) > __builtin_fma(fabs(a), 1e-9, 1e-9)) | r.wide);
-  if (band) acc = lat_accept_exact(A, B, q.u1, q.nl1, lat_u2(raw, mask, p0, j));
+// what every pass needs to decide one (row, quad) pair, the band included
+struct LatCtx {
+  const double2 *__restrict__ rec;   // original records (exact path, values)
+  const double2 *__restrict__ qx;    // per quad (n1, -log u1)
+  const uint32_t *__restrict__ raw;
+  uint64_t mask, p0;
+};
+__device__ __forceinline__ bool lat_accept(const LatCtx &cx, int32_t t, double wA, double wB, const LatQ &q, int64_t j) {
+  bool band;
+  bool acc = lat_decide(wA, wB, q, band);
+  if (band) {  // one lane in 10^8 steps
+    const double2 ab = cx.rec[t];
+    acc = lat_accept_exact(ab.x, ab.y, q.xT, cx.qx[j].y, lat_u2(cx.raw, cx.mask, cx.p0, j));
+  }
   return acc;
 }
-// the accepted value (util.hpp:21-23, :29, :45)
-__device__ __forceinline__ double lat_value(const LatRow &r, double A, double B, const LatQuad &q) {
-  if (r.isN) return q.n1 > r.o ? q.n1 : q.n2;
-  if (r.isE) return q.nl1 / A + B;
-  return q.u1 * (B - A) + A;
+// the accepted value (util.hpp:21-23, :29, :45) from the original record; n1 / nl1 = the quad's first normal / -log u1
+__device__ __forceinline__ double lat_value(double A, double B, const LatQ &q, double n1, double nl1) {
+  if (B != B) return n1 > A ? n1 : q.m;  // (the first normal when it passes, else the second -- which then is the larger one)
+  if (A > B) return nl1 / A + B;
+  return q.xT * (B - A) + A;
 }
-__device__ __forceinline__ LatQuad lat_load_quad(const double *__restrict__ qt, int64_t j) {
+__device__ __forceinline__ LatQ lat_load_quad(const double *__restrict__ qt, int64_t j) {
   const double *p = qt + (size_t)j * LAT_QW;
-  LatQuad q;
-  q.u1 = p[0];
-  q.l2 = p[1];
-  q.nl1 = p[2];
-  q.n1 = p[3];
-  q.n2 = p[4];
+  LatQ q;
+  q.xT = p[0];
+  q.xE = p[1];
+  q.l2 = p[2];
+  q.m = p[3];
   return q;
 }
 
 // ---- row pass ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lat_rows(const int32_t *__restrict__ rows, const double2 *__restrict__ eq,
                                                   const double *__restrict__ y, int64_t n, int n_class,
-                                                  const double *__restrict__ gamma, double2 *__restrict__ rec, float *__restrict__ mf,
-                                                  double *__restrict__ blkM, double *__restrict__ blkV) {
+                                                  const double *__restrict__ gamma, double2 *__restrict__ rec,
+                                                  double2 *__restrict__ wrec, float *__restrict__ mf, double *__restrict__ blkM,
+                                                  double *__restrict__ blkV, int32_t *__restrict__ bad) {
   __shared__ double s_m[4], s_v[4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   double sm = 0.0, sv = 0.0;
@@ -204,13 +216,16 @@ __global__ __launch_bounds__(256) void k_lat_rows(const int32_t *__restrict__ ro
       int sgn;
       const double2 ab = lat_record(eq[t].x, y[t], n_class, gamma, &sgn);
       rec[i] = ab;
+      bool wide = false;
+      wrec[i] = lat_walker_record(ab.x, ab.y, &wide);
+      if (wide) *bad = 1;
       const double p = lat_accept_prob(ab.x, ab.y);
       const double m = 1.0 / p;
       mf[i] = (float)m;
       sm += m;
       sv += (1.0 - p) * m * m;
     } else if (i == n) {
-      rec[i] = make_double2(__builtin_inf(), __builtin_nan(""));  // the row after the last one accepts nothing
+      rec[i] = wrec[i] = make_double2(__builtin_inf(), __builtin_nan(""));  // the row after the last one accepts nothing
     }
   }
   for (int d = 32; d > 0; d >>= 1) {
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(1024) void k_lat_scan(const double *__restrict__ bl
 
 // ---- quad table ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lat_quads(const RngState *__restrict__ rs, const uint32_t *__restrict__ raw, uint64_t mask,
-                                                   int64_t nq, double *__restrict__ qt) {
+                                                   int64_t nq, double *__restrict__ qt, double2 *__restrict__ qx) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= nq) return;
   const uint64_t b = rs->p_cons + 4ull * (uint64_t)j;
@@ -293,12 +308,13 @@ __global__ __launch_bounds__(256) void k_lat_quads(const RngState *__restrict__ 
     n1 = (yy * mult) * 1.0 + 0.0;
     n2 = (x * mult) * 1.0 + 0.0;
   }
+  const double nl1 = -log(u1);
   double *p = qt + (size_t)j * LAT_QW;
   p[0] = u1;
-  p[1] = log(u2);
-  p[2] = -log(u1);
-  p[3] = n1;
-  p[4] = n2;
+  p[1] = nl1 - 1.0;
+  p[2] = log(u2);
+  p[3] = n1 > n2 ? n1 : n2;  // (NaN when there is no pair)
+  qx[j] = make_double2(n1, nl1);
 }
 
 // snapshot entries a chunk with W entering rows may write: its walkers at every sub-chunk boundary, about K W / sqrt(quads walked) with
@@ -392,52 +408,50 @@ __global__ __launch_bounds__(1024) void k_lat_windows(const double *__restrict__
 // is not needed before the third acceptance after it.
 struct LatWalker {
   int32_t t;
-  double2 r, n1, n2, n3;  // records of rows t, t + 1, t + 2, t + 3
-  LatRow w;
+  double2 r, n1, n2, n3;  // walker records of rows t, t + 1, t + 2, t + 3
 };
-__device__ __forceinline__ void lat_walker_load(LatWalker &k, const double2 *__restrict__ rec, int64_t n) {
-  k.r = rec[k.t];
-  k.n1 = rec[min((int64_t)k.t + 1, n)];
-  k.n2 = rec[min((int64_t)k.t + 2, n)];
-  k.n3 = rec[min((int64_t)k.t + 3, n)];
-  k.w = lat_derive(k.r.x, k.r.y);
+__device__ __forceinline__ void lat_walker_load(LatWalker &k, const double2 *__restrict__ wrec, int64_t n) {
+  k.r = wrec[k.t];
+  k.n1 = wrec[min((int64_t)k.t + 1, n)];
+  k.n2 = wrec[min((int64_t)k.t + 2, n)];
+  k.n3 = wrec[min((int64_t)k.t + 3, n)];
 }
-__device__ __forceinline__ void lat_step(LatWalker &k, const double2 *__restrict__ rec, int64_t n, const LatQuad &q, int64_t j,
-                                         const uint32_t *__restrict__ raw, uint64_t mask, uint64_t p0) {
-  if (lat_accept(k.w, k.r.x, k.r.y, q, raw, mask, p0, j)) {
+__device__ __forceinline__ void lat_step(LatWalker &k, const double2 *__restrict__ wrec, int64_t n, const LatQ &q, int64_t j,
+                                         const LatCtx &cx) {
+  if (lat_accept(cx, k.t, k.r.x, k.r.y, q, j)) {
     k.t++;
     k.r = k.n1;
     k.n1 = k.n2;
     k.n2 = k.n3;
-    k.n3 = rec[min((int64_t)k.t + 3, n)];
-    k.w = lat_derive(k.r.x, k.r.y);
+    k.n3 = wrec[min((int64_t)k.t + 3, n)];
   }
 }
-// (the quad table is padded by LAT_QPAD records: the look-ahead of the last round reads past the last quad)
+// (the quad tables are padded by LAT_QPAD records: the look-ahead of the last round reads past the last quad)
 constexpr int LAT_QPAD = 40;
-__device__ __forceinline__ void lat_walk(LatWalker &k, const double2 *__restrict__ rec, int64_t n, const double *__restrict__ qt,
-                                         int64_t j0, int R, const uint32_t *__restrict__ raw, uint64_t mask, uint64_t p0) {
-  LatQuad q0 = lat_load_quad(qt, j0), q1 = lat_load_quad(qt, j0 + 1), q2 = lat_load_quad(qt, j0 + 2), q3 = lat_load_quad(qt, j0 + 3);
+__device__ __forceinline__ void lat_walk(LatWalker &k, const double2 *__restrict__ wrec, int64_t n, const double *__restrict__ qt,
+                                         int64_t j0, int R, const LatCtx &cx) {
+  LatQ q0 = lat_load_quad(qt, j0), q1 = lat_load_quad(qt, j0 + 1), q2 = lat_load_quad(qt, j0 + 2), q3 = lat_load_quad(qt, j0 + 3);
   int s = 0;
   for (; s + 4 <= R; s += 4) {
-    const LatQuad a0 = lat_load_quad(qt, j0 + s + 4), a1 = lat_load_quad(qt, j0 + s + 5), a2 = lat_load_quad(qt, j0 + s + 6),
-                  a3 = lat_load_quad(qt, j0 + s + 7);
-    lat_step(k, rec, n, q0, j0 + s, raw, mask, p0);
-    lat_step(k, rec, n, q1, j0 + s + 1, raw, mask, p0);
-    lat_step(k, rec, n, q2, j0 + s + 2, raw, mask, p0);
-    lat_step(k, rec, n, q3, j0 + s + 3, raw, mask, p0);
+    const LatQ a0 = lat_load_quad(qt, j0 + s + 4), a1 = lat_load_quad(qt, j0 + s + 5), a2 = lat_load_quad(qt, j0 + s + 6),
+               a3 = lat_load_quad(qt, j0 + s + 7);
+    lat_step(k, wrec, n, q0, j0 + s, cx);
+    lat_step(k, wrec, n, q1, j0 + s + 1, cx);
+    lat_step(k, wrec, n, q2, j0 + s + 2, cx);
+    lat_step(k, wrec, n, q3, j0 + s + 3, cx);
     q0 = a0;
     q1 = a1;
     q2 = a2;
     q3 = a3;
   }
-  if (s < R) lat_step(k, rec, n, q0, j0 + s, raw, mask, p0);
-  if (s + 1 < R) lat_step(k, rec, n, q1, j0 + s + 1, raw, mask, p0);
-  if (s + 2 < R) lat_step(k, rec, n, q2, j0 + s + 2, raw, mask, p0);
+  if (s < R) lat_step(k, wrec, n, q0, j0 + s, cx);
+  if (s + 1 < R) lat_step(k, wrec, n, q1, j0 + s + 1, cx);
+  if (s + 2 < R) lat_step(k, wrec, n, q2, j0 + s + 2, cx);
 }
 
 // every live walker of every chunk: R quads from quad c Lq + done. grid (tiles, C)
-__global__ __launch_bounds__(LAT_TILE) void k_lat_round(const double2 *__restrict__ rec, const double *__restrict__ qt,
+__global__ __launch_bounds__(LAT_TILE) void k_lat_round(const double2 *__restrict__ rec, const double2 *__restrict__ wrec,
+                                                        const double *__restrict__ qt, const double2 *__restrict__ qx,
                                                         const uint32_t *__restrict__ raw, uint64_t mask,
                                                         const RngState *__restrict__ rs, int64_t n, int64_t Lq, int done, int R,
                                                         const int32_t *__restrict__ win_lo, const int32_t *__restrict__ live,
@@ -445,11 +459,12 @@ __global__ __launch_bounds__(LAT_TILE) void k_lat_round(const double2 *__restric
   const int c = blockIdx.y;
   const int i = blockIdx.x * LAT_TILE + threadIdx.x;
   if (i >= live[c]) return;
+  const LatCtx cx{rec, qx, raw, mask, rs->p_cons};
   LatWalker k;
   int32_t *pc = cur + list_off[c] + i;
   k.t = first ? win_lo[c] + i : *pc;
-  lat_walker_load(k, rec, n);
-  lat_walk(k, rec, n, qt, (int64_t)c * Lq + done, R, raw, mask, rs->p_cons);
+  lat_walker_load(k, wrec, n);
+  lat_walk(k, wrec, n, qt, (int64_t)c * Lq + done, R, cx);
   *pc = k.t;
 }
 
@@ -543,7 +558,8 @@ __device__ __forceinline__ lat_d2v lat_asm_load(const double2 *p) {
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__ rec, const double *__restrict__ qt,
+__global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__ rec, const double2 *__restrict__ wrec,
+                                                     const double *__restrict__ qt, const double2 *__restrict__ qx,
                                                      const uint32_t *__restrict__ raw, uint64_t mask,
                                                      const RngState *__restrict__ rs, int64_t n, int64_t Lq, int done0, int R, int subq,
                                                      int nsub, const int32_t *__restrict__ live, const int64_t *__restrict__ list_off,
@@ -561,7 +577,7 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
   double *strips = (double *)(s_cnt + 16);   // [NW][2][QS * LAT_QW]
   int *s_t1 = (int *)ring, *s_f1 = s_t1 + NT;  // second stage of the redistribution: the ring is refilled after it anyway
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint64_t p0 = rs->p_cons;
+  const LatCtx cx{rec, qx, raw, mask, rs->p_cons};
   const int64_t J0 = (int64_t)c * Lq;
   int nl = live[c];
   if (nl > NT) {
@@ -571,22 +587,20 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
   const int64_t off = list_off[c];
   int64_t sp = done0 >= subq ? snap_pos[c] : snap_off[c];
   const int64_t sp_end = snap_off[c + 1];
-  const double2 *rec_end = rec + n;  // the record after the last row: accepts nothing
+  const double2 *rec_end = wrec + n;  // the record after the last row: accepts nothing
   int wl = max(0, min(64, nl - wid * 64));
   int32_t t = (int32_t)n, f = 0, hi = 0;
   double2 r;
-  LatRow w;
   if (lane < wl) {
     t = scur[off + tid];
     f = sfin[off + tid];
   }
   // (re)start of a lane's row supply: the current record and the ring's rows t + 1 .. t + 8 by plain loads
   auto prime = [&]() {
-    r = rec[t];
+    r = wrec[t];
 #pragma unroll
-    for (int k = 1; k <= 8; k++) ring[(size_t)((t + k) & 7) * NT + tid] = rec[min((int64_t)t + k, n)];
+    for (int k = 1; k <= 8; k++) ring[(size_t)((t + k) & 7) * NT + tid] = wrec[min((int64_t)t + k, n)];
     hi = t + 9;
-    w = lat_derive(r.x, r.y);
   };
   prime();
   double *strip0 = strips + (size_t)wid * (2 * QS * LAT_QW);
@@ -613,25 +627,20 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
         for (int k0 = 0; k0 < S; k0 += 4) {
           // rows the ring will miss after this group
           const int m = t + 9 - hi;  // 0 .. 4
-          lat_d2v l0 = lat_asm_load(m > 0 ? rec + min((int64_t)hi, n) : rec_end);
-          lat_d2v l1 = lat_asm_load(m > 1 ? rec + min((int64_t)hi + 1, n) : rec_end);
-          lat_d2v l2 = lat_asm_load(m > 2 ? rec + min((int64_t)hi + 2, n) : rec_end);
-          lat_d2v l3 = lat_asm_load(m > 3 ? rec + min((int64_t)hi + 3, n) : rec_end);
+          lat_d2v l0 = lat_asm_load(m > 0 ? wrec + min((int64_t)hi, n) : rec_end);
+          lat_d2v l1 = lat_asm_load(m > 1 ? wrec + min((int64_t)hi + 1, n) : rec_end);
+          lat_d2v l2 = lat_asm_load(m > 2 ? wrec + min((int64_t)hi + 2, n) : rec_end);
+          lat_d2v l3 = lat_asm_load(m > 3 ? wrec + min((int64_t)hi + 3, n) : rec_end);
           const int ke = min(4, S - k0);
           for (int k = 0; k < ke; k++) {
-            const double *qp = strip + (k0 + k) * LAT_QW;
-            LatQuad q;
-            q.u1 = qp[0];
-            q.l2 = qp[1];
-            q.nl1 = qp[2];
-            q.n1 = qp[3];
-            q.n2 = qp[4];
+            const double2 *qp = (const double2 *)(strip + (k0 + k) * LAT_QW);
+            const double2 qa = qp[0], qb = qp[1];
+            const LatQ q{qa.x, qa.y, qb.x, qb.y};
             const double2 nx = ring[(size_t)((t + 1) & 7) * NT + tid];
-            const bool acc = lat_accept(w, r.x, r.y, q, raw, mask, p0, j0 + k0 + k);
+            const bool acc = lat_accept(cx, t, r.x, r.y, q, j0 + k0 + k);
             t += acc ? 1 : 0;
             r.x = acc ? nx.x : r.x;
             r.y = acc ? nx.y : r.y;
-            w = lat_derive(r.x, r.y);
           }
           asm volatile("s_waitcnt vmcnt(0)" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(qnext) : : "memory");
           if (m > 0) ring[(size_t)(hi & 7) * NT + tid] = make_double2(l0.x, l0.y);
@@ -764,7 +773,8 @@ __global__ __launch_bounds__(256) void k_lat_resolve(int C, int nsub, int n, con
 }
 
 // ---- final pass: the one true path, a thread per sub-chunk ---------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_lat_final(const double2 *__restrict__ rec, const double *__restrict__ qt,
+__global__ __launch_bounds__(64) void k_lat_final(const double2 *__restrict__ rec, const double2 *__restrict__ wrec,
+                                                  const double *__restrict__ qt, const double2 *__restrict__ qx,
                                                   const uint32_t *__restrict__ raw, uint64_t mask, RngState *__restrict__ rs, int64_t n,
                                                   int64_t Lq, int subq, int nsub, int C, const int32_t *__restrict__ Tc,
                                                   const int2 *__restrict__ snap, const int64_t *__restrict__ snap_idx,
@@ -790,14 +800,15 @@ __global__ __launch_bounds__(64) void k_lat_final(const double2 *__restrict__ re
     t = snap[sp + lo].y;
   }
   if (t >= n) return;
-  const uint64_t p0 = rs->p_cons;
+  const LatCtx cx{rec, qx, raw, mask, rs->p_cons};
   const int64_t j0 = (int64_t)c * Lq + (int64_t)ks * subq;
-  double2 r = rec[t];
-  LatRow w = lat_derive(r.x, r.y);
+  double2 r = wrec[t];
+  LatQ q = lat_load_quad(qt, j0);
   for (int s = 0; s < subq; s++) {
-    const LatQuad q = lat_load_quad(qt, j0 + s);
-    if (lat_accept(w, r.x, r.y, q, raw, mask, p0, j0 + s)) {
-      const double val = lat_value(w, r.x, r.y, q);
+    const LatQ qn = lat_load_quad(qt, j0 + s + 1);  // (one step ahead; the tables are padded)
+    if (lat_accept(cx, t, r.x, r.y, q, j0 + s)) {
+      const double2 ab = rec[t], x = qx[j0 + s];
+      const double val = lat_value(ab.x, ab.y, q, x.x, x.y);
       const int64_t row = rows ? (int64_t)rows[t] : (int64_t)t;
       const double pred = eq[row].x;
       // the side of a one-sided draw (right truncation = -left(-mu)); z = 1 * draw + score, e = score - z
@@ -814,9 +825,9 @@ __global__ __launch_bounds__(64) void k_lat_final(const double2 *__restrict__ re
         st->end_quads = j0 + s + 1;
         return;
       }
-      r = rec[t];
-      w = lat_derive(r.x, r.y);
+      r = wrec[t];
     }
+    q = qn;
   }
 }
 
@@ -841,21 +852,23 @@ static int env_int(const char *name, int dflt) {
 }  // namespace
 
 struct LatentEngine::Impl {
-  DevBuf<double2> rec;
+  DevBuf<double2> rec, wrec, qx;
   DevBuf<float> mf;
   DevBuf<double> blkM, blkV, PM, PV, qt;
-  DevBuf<int32_t> win_lo, win_hi, live, cur0, fin0, cur1, fin1, snap_cnt, Tc, max_live;
+  DevBuf<int32_t> win_lo, win_hi, live, cur0, fin0, cur1, fin1, snap_cnt, Tc, max_live, bad;
   DevBuf<int64_t> list_off, snap_off, snap_pos, snap_idx;
   DevBuf<int2> snap;
   DevBuf<LatStatus> status;
   DevBuf<uint64_t> pos;
   LatStatus *h_status = nullptr;  // pinned
   uint64_t *h_pos = nullptr;
-  int32_t *h_max = nullptr;
-  double ksig = 5.0;
+  int32_t *h_max = nullptr;       // [0] largest list of a round, [1] the row pass's "too wide" flag
+  double ksig = 4.0, ksig_retry = 6.5;
   // geometry of the prepared draw
-  int64_t n = -1, Lq = 0, Wmax = 0;
+  int64_t n = -1, Lq = 0;
   int C = 0, nsub = 0, subq = 0;
+  double sd = 0;
+  bool too_wide = false;
   ~Impl() {
     if (h_status) (void)hipHostFree(h_status);
     if (h_pos) (void)hipHostFree(h_pos);
@@ -865,6 +878,7 @@ struct LatentEngine::Impl {
   static void ensure(DevBuf<T> &b, size_t count) {
     if (b.n < count) b.alloc(count + count / 8 + 16);
   }
+  int64_t wmax(double k) const { return std::min<int64_t>(n + 1, (int64_t)(2.0 * k * sd) + 8); }
 };
 
 LatentEngine::LatentEngine() : im(new Impl()) {}
@@ -879,33 +893,42 @@ void LatentEngine::prepare(const LatentJob &job, LatentPrep *prep) {
   if (!m.h_status) {
     MFM_HIP_CHECK(hipHostMalloc((void **)&m.h_status, sizeof(LatStatus), hipHostMallocDefault));
     MFM_HIP_CHECK(hipHostMalloc((void **)&m.h_pos, 2 * sizeof(uint64_t), hipHostMallocDefault));
-    MFM_HIP_CHECK(hipHostMalloc((void **)&m.h_max, sizeof(int32_t), hipHostMallocDefault));
+    MFM_HIP_CHECK(hipHostMalloc((void **)&m.h_max, 2 * sizeof(int32_t), hipHostMallocDefault));
     m.status.alloc(1);
     m.pos.alloc(2);
     m.max_live.alloc(LAT_MAX_ROUNDS);
+    m.bad.alloc(1);
   }
-  m.ksig = env_double("MFM_LAT_KSIGMA", 5.0);
+  // windows of +- 4 sigma: one draw in ~30 has a chunk whose window misses the path (511 chunks x 6.3e-5); it is then repeated with
+  // +- 6.5 sigma (nothing was written), and only if that misses too (1e-8) the caller's sequential loop runs
+  m.ksig = env_double("MFM_LAT_KSIGMA", 4.0);
+  m.ksig_retry = std::max(m.ksig, env_double("MFM_LAT_KSIGMA_RETRY", 6.5));
   const int64_t n = job.n, nb = (n + LAT_RB - 1) / LAT_RB;
   // (the block that holds row n writes the record of "the row after the last one": one more block when n fills its blocks)
   const int64_t grid = (n + 1 + LAT_RB - 1) / LAT_RB;
   Impl::ensure(m.rec, (size_t)n + 1);
+  Impl::ensure(m.wrec, (size_t)n + 1);
   Impl::ensure(m.mf, (size_t)n + 1);
   Impl::ensure(m.blkM, (size_t)grid);
   Impl::ensure(m.blkV, (size_t)grid);
   Impl::ensure(m.PM, (size_t)nb + 1);
   Impl::ensure(m.PV, (size_t)nb + 1);
+  MFM_HIP_CHECK(hipMemsetAsync(m.bad.p, 0, sizeof(int32_t), s));
   hipLaunchKernelGGL(k_lat_rows, dim3((unsigned)grid), dim3(256), 0, s, job.rows, job.eq, job.y, n, job.n_class, job.gamma, m.rec.p,
-                     m.mf.p, m.blkM.p, m.blkV.p);
+                     m.wrec.p, m.mf.p, m.blkM.p, m.blkV.p, m.bad.p);
   hipLaunchKernelGGL(k_lat_scan, dim3(1), dim3(1024), 0, s, m.blkM.p, m.blkV.p, nb, m.PM.p, m.PV.p, m.status.p, job.state, m.pos.p);
   MFM_HIP_CHECK(hipGetLastError());
   MFM_HIP_CHECK(hipMemcpyAsync(m.h_status, m.status.p, sizeof(LatStatus), hipMemcpyDeviceToHost, s));
   MFM_HIP_CHECK(hipMemcpyAsync(m.h_pos, m.pos.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipMemcpyAsync(m.h_max + 1, m.bad.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MFM_HIP_CHECK(hipStreamSynchronize(s));
   prep->mean_quads = m.h_status->total_m;
   prep->var_quads = m.h_status->total_v;
   prep->p_cons = m.h_pos[0];
   prep->p_gen = m.h_pos[1];
-  const double cap = prep->mean_quads + (m.ksig + 1.0) * std::sqrt(prep->var_quads) + 256.0;
+  m.too_wide = m.h_max[1] != 0;
+  m.sd = std::sqrt(prep->var_quads);
+  const double cap = prep->mean_quads + (m.ksig_retry + 1.0) * m.sd + 256.0;
   // (a row whose bounds are NaN, or whose acceptance probability is ~0, never accepts: the reference would spin for ever)
   if (!(cap == cap) || cap > 64.0 * (double)n + 1e6)
     throw Error(MFM_ERR_RUNTIME, "exact latent draws: a score is not finite, or a truncation region has (almost) no mass");
@@ -913,14 +936,13 @@ void LatentEngine::prepare(const LatentJob &job, LatentPrep *prep) {
   m.subq = std::max(64, env_int("MFM_LAT_SUBQ", 512) / 64 * 64);
   const int target_chunks = std::max(1, env_int("MFM_LAT_CHUNKS", 512));
   int64_t Lq = ((int64_t)cap + target_chunks - 1) / target_chunks;
-  Lq = std::max<int64_t>(Lq, env_int("MFM_LAT_MIN_LQ", 4096));
+  Lq = std::max<int64_t>(Lq, env_int("MFM_LAT_MIN_LQ", 1024));
   Lq = (Lq + m.subq - 1) / m.subq * m.subq;
   if (Lq > 0x3fffffff) throw Error(MFM_ERR_RUNTIME, "exact latent draws: chunk too long");
   m.Lq = Lq;
   m.C = (int)(((int64_t)cap + Lq - 1) / Lq);
   m.nsub = (int)(Lq / m.subq);
   m.n = n;
-  m.Wmax = std::min<int64_t>(n + 1, (int64_t)(2.0 * m.ksig * std::sqrt(prep->var_quads)) + 8);
   prep->q_cap = (int64_t)m.C * Lq;
 }
 
@@ -934,17 +956,21 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
     return 0;
   }
   if (n != m.n) throw Error(MFM_ERR_RUNTIME, "exact latent draws: run() without the matching prepare()");
+  if (m.too_wide) {  // a row a thousand standard deviations on the wrong side of its class: the walkers' shortcut does not hold
+    S.status = 5;
+    if (stats) *stats = S;
+    return 5;
+  }
   const bool timing = std::getenv("MFM_LATENT_TIMING") != nullptr;
   hipEvent_t ev[4];
   if (timing)
     for (auto &e : ev) MFM_HIP_CHECK(hipEventCreate(&e));
   const int subq = m.subq, C = m.C, nsub = m.nsub;
-  const int64_t Lq = m.Lq, nq = prep.q_cap, Wmax = m.Wmax;
-  const int R = std::max(1, std::min(subq, env_int("MFM_LAT_ROUND", 16)));
+  const int64_t Lq = m.Lq, nq = prep.q_cap;
+  const int R = std::max(4, std::min(subq, env_int("MFM_LAT_ROUND", 16)) / 4 * 4);
   const int64_t nb = (n + LAT_RB - 1) / LAT_RB;
-  const int64_t list_cap = (int64_t)C * Wmax;
-  const int64_t snap_cap = (int64_t)C * (lat_snap_cap(Wmax, nsub, Lq, subq) + 1);
   Impl::ensure(m.qt, (size_t)(nq + LAT_QPAD) * LAT_QW);
+  Impl::ensure(m.qx, (size_t)(nq + LAT_QPAD));
   Impl::ensure(m.win_lo, (size_t)C);
   Impl::ensure(m.win_hi, (size_t)C);
   Impl::ensure(m.live, (size_t)C);
@@ -954,84 +980,96 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
   Impl::ensure(m.snap_idx, (size_t)C * nsub);
   Impl::ensure(m.snap_cnt, (size_t)C * nsub);
   Impl::ensure(m.Tc, (size_t)C + 1);
-  Impl::ensure(m.cur0, (size_t)list_cap);
-  Impl::ensure(m.fin0, (size_t)list_cap);
-  Impl::ensure(m.cur1, (size_t)list_cap);
-  Impl::ensure(m.fin1, (size_t)list_cap);
-  Impl::ensure(m.snap, (size_t)snap_cap);
 
-  MFM_HIP_CHECK(hipMemsetAsync(m.max_live.p, 0, sizeof(int32_t) * LAT_MAX_ROUNDS, s));
   if (timing) MFM_HIP_CHECK(hipEventRecord(ev[0], s));
-  hipLaunchKernelGGL(k_lat_quads, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, job.state, job.raw, job.mask, nq, m.qt.p);
-  hipLaunchKernelGGL(k_lat_windows, dim3(1), dim3(1024), 0, s, m.PM.p, m.PV.p, m.mf.p, n, nb, C, Lq, subq, m.ksig, m.win_lo.p,
-                     m.win_hi.p, m.list_off.p, m.snap_off.p, m.live.p, list_cap, snap_cap, m.status.p);
+  hipLaunchKernelGGL(k_lat_quads, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, job.state, job.raw, job.mask, nq, m.qt.p, m.qx.p);
   if (timing) MFM_HIP_CHECK(hipEventRecord(ev[1], s));
-  // Rounds over all chunks' walkers as grid-wide launches (16, 16, 32, ... quads up to the first sub-chunk boundary, then a sub-chunk
-  // per round) while some chunk still has more walkers than a workgroup of the resident kernel; the host reads the largest list back
-  // after every round (4 bytes) to size the next launch and to decide the hand-over.
-  int done = 0, round = 0;
-  bool first = true;
-  int32_t *sc = m.cur0.p, *sf = m.fin0.p, *dc = m.cur1.p, *df = m.fin1.p;
-  int64_t max_live = Wmax;
-  int Rr = R;
-  const bool no_resident = std::getenv("MFM_LAT_NO_RESIDENT") != nullptr;
-  while (done < Lq) {
-    if (!first && max_live <= LAT_RES_NT && !no_resident) break;
-    if (round >= LAT_MAX_ROUNDS) throw Error(MFM_ERR_RUNTIME, "exact latent draws: too many rounds");
-    int step = (int)std::min<int64_t>(Rr, Lq - done);
-    if (done % subq + step > subq) step = subq - done % subq;
-    const unsigned tiles = (unsigned)((max_live + LAT_TILE - 1) / LAT_TILE);
-    hipLaunchKernelGGL(k_lat_round, dim3(tiles, (unsigned)C), dim3(LAT_TILE), 0, s, m.rec.p, m.qt.p, job.raw, job.mask, job.state, n, Lq,
-                       done, step, m.win_lo.p, m.live.p, m.list_off.p, sc, first ? 1 : 0);
-    done += step;
-    const int snap_k = done % subq == 0 ? done / subq - 1 : -1;
-    hipLaunchKernelGGL(k_lat_compact, dim3((unsigned)C), dim3(1024), 0, s, m.win_lo.p, m.live.p, m.list_off.p, sc, sf, dc, df,
-                       first ? 1 : 0, snap_k, nsub, m.snap_off.p, m.snap_pos.p, m.snap.p, m.snap_idx.p, m.snap_cnt.p,
-                       m.max_live.p + round, m.status.p);
-    MFM_HIP_CHECK(hipMemcpyAsync(m.h_max, m.max_live.p + round, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    MFM_HIP_CHECK(hipStreamSynchronize(s));
-    max_live = *m.h_max;
-    round++;
-    std::swap(sc, dc);
-    std::swap(sf, df);
-    first = false;
-    if (done >= subq)
-      Rr = subq;
-    else if (done >= 2 * Rr)
-      Rr = std::min(subq, 2 * Rr);
-  }
-  const int rounds_done = round, handover = done;
-  if (done < Lq) {
-    const size_t lds = (size_t)8 * LAT_RES_NT * sizeof(double2) + (size_t)(2 * LAT_RES_NT + 16) * sizeof(int) +
-                       (size_t)(LAT_RES_NT / 64) * 2 * 16 * LAT_QW * sizeof(double);
-    {
-      static DeviceOnce raised;
-      if (raised.need()) {
-        MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_lat_resident<LAT_RES_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        raised.mark();
-      }
+  int rounds_done = 0, handover = 0, attempts = 0;
+  int64_t max_live = 0;
+  for (double ksig : {m.ksig, m.ksig_retry}) {
+    attempts++;
+    const int64_t Wmax = m.wmax(ksig);
+    const int64_t list_cap = (int64_t)C * Wmax;
+    const int64_t snap_cap = (int64_t)C * (lat_snap_cap(Wmax, nsub, Lq, subq) + 1);
+    Impl::ensure(m.cur0, (size_t)list_cap);
+    Impl::ensure(m.fin0, (size_t)list_cap);
+    Impl::ensure(m.cur1, (size_t)list_cap);
+    Impl::ensure(m.fin1, (size_t)list_cap);
+    Impl::ensure(m.snap, (size_t)snap_cap);
+    MFM_HIP_CHECK(hipMemsetAsync(m.max_live.p, 0, sizeof(int32_t) * LAT_MAX_ROUNDS, s));
+    MFM_HIP_CHECK(hipMemsetAsync(m.status.p, 0, 2 * sizeof(int32_t), s));  // (fail, fail_chunk)
+    hipLaunchKernelGGL(k_lat_windows, dim3(1), dim3(1024), 0, s, m.PM.p, m.PV.p, m.mf.p, n, nb, C, Lq, subq, ksig, m.win_lo.p,
+                       m.win_hi.p, m.list_off.p, m.snap_off.p, m.live.p, list_cap, snap_cap, m.status.p);
+    // Rounds over all chunks' walkers as grid-wide launches (16, 16, 32, ... quads up to the first sub-chunk boundary, then a
+    // sub-chunk per round) while some chunk still has more walkers than a workgroup of the resident kernel; the host reads the
+    // largest list back after every round (4 bytes) to size the next launch and to decide the hand-over.
+    int done = 0, round = 0;
+    bool first = true;
+    int32_t *sc = m.cur0.p, *sf = m.fin0.p, *dc = m.cur1.p, *df = m.fin1.p;
+    max_live = Wmax;
+    int Rr = R;
+    const bool no_resident = std::getenv("MFM_LAT_NO_RESIDENT") != nullptr;
+    while (done < Lq) {
+      if (!first && max_live <= LAT_RES_NT && !no_resident) break;
+      if (round >= LAT_MAX_ROUNDS) throw Error(MFM_ERR_RUNTIME, "exact latent draws: too many rounds");
+      int step = (int)std::min<int64_t>(Rr, Lq - done);
+      if (done % subq + step > subq) step = subq - done % subq;
+      const unsigned tiles = (unsigned)((max_live + LAT_TILE - 1) / LAT_TILE);
+      hipLaunchKernelGGL(k_lat_round, dim3(tiles, (unsigned)C), dim3(LAT_TILE), 0, s, m.rec.p, m.wrec.p, m.qt.p, m.qx.p, job.raw, job.mask,
+                         job.state, n, Lq, done, step, m.win_lo.p, m.live.p, m.list_off.p, sc, first ? 1 : 0);
+      done += step;
+      const int snap_k = done % subq == 0 ? done / subq - 1 : -1;
+      hipLaunchKernelGGL(k_lat_compact, dim3((unsigned)C), dim3(1024), 0, s, m.win_lo.p, m.live.p, m.list_off.p, sc, sf, dc, df,
+                         first ? 1 : 0, snap_k, nsub, m.snap_off.p, m.snap_pos.p, m.snap.p, m.snap_idx.p, m.snap_cnt.p,
+                         m.max_live.p + round, m.status.p);
+      MFM_HIP_CHECK(hipMemcpyAsync(m.h_max, m.max_live.p + round, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      MFM_HIP_CHECK(hipStreamSynchronize(s));
+      max_live = m.h_max[0];
+      round++;
+      std::swap(sc, dc);
+      std::swap(sf, df);
+      first = false;
+      if (done >= subq)
+        Rr = subq;
+      else if (done >= 2 * Rr)
+        Rr = std::min(subq, 2 * Rr);
     }
-    hipLaunchKernelGGL((k_lat_resident<LAT_RES_NT>), dim3((unsigned)C), dim3(LAT_RES_NT), lds, s, m.rec.p, m.qt.p, job.raw, job.mask,
-                       job.state, n, Lq, done, R, subq, nsub, m.live.p, m.list_off.p, sc, sf, m.snap_off.p, m.snap_pos.p, m.snap.p,
-                       m.snap_idx.p, m.snap_cnt.p, m.status.p);
+    rounds_done = round;
+    handover = done;
+    if (done < Lq) {
+      const size_t lds = (size_t)8 * LAT_RES_NT * sizeof(double2) + (size_t)(2 * LAT_RES_NT + 16) * sizeof(int) +
+                         (size_t)(LAT_RES_NT / 64) * 2 * 16 * LAT_QW * sizeof(double);
+      {
+        static DeviceOnce raised;
+        if (raised.need()) {
+          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_lat_resident<LAT_RES_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          raised.mark();
+        }
+      }
+      hipLaunchKernelGGL((k_lat_resident<LAT_RES_NT>), dim3((unsigned)C), dim3(LAT_RES_NT), lds, s, m.rec.p, m.wrec.p, m.qt.p, m.qx.p,
+                         job.raw, job.mask, job.state, n, Lq, done, R, subq, nsub, m.live.p, m.list_off.p, sc, sf, m.snap_off.p,
+                         m.snap_pos.p, m.snap.p, m.snap_idx.p, m.snap_cnt.p, m.status.p);
+    }
+    if (timing && attempts == 1) MFM_HIP_CHECK(hipEventRecord(ev[2], s));
+    hipLaunchKernelGGL(k_lat_resolve, dim3(1), dim3(256), 0, s, C, nsub, (int)n, m.win_lo.p, m.win_hi.p, m.snap.p, m.snap_idx.p,
+                       m.snap_cnt.p, m.Tc.p, m.status.p);
+    hipLaunchKernelGGL(k_lat_final, dim3((unsigned)(((int64_t)C * nsub + 63) / 64)), dim3(64), 0, s, m.rec.p, m.wrec.p, m.qt.p, m.qx.p,
+                       job.raw, job.mask, job.state, n, Lq, subq, nsub, C, m.Tc.p, m.snap.p, m.snap_idx.p, m.snap_cnt.p, job.rows, job.eq,
+                       job.y, job.n_class, m.status.p);
+    hipLaunchKernelGGL(k_lat_commit, dim3(1), dim3(1), 0, s, job.state, m.status.p);
+    if (timing && attempts == 1) MFM_HIP_CHECK(hipEventRecord(ev[3], s));
+    MFM_HIP_CHECK(hipGetLastError());
+    MFM_HIP_CHECK(hipMemcpyAsync(m.h_status, m.status.p, sizeof(LatStatus), hipMemcpyDeviceToHost, s));
+    MFM_HIP_CHECK(hipStreamSynchronize(s));
+    if (m.h_status->fail != 1 || ksig >= m.ksig_retry) break;  // (only a missed window is worth a second look)
   }
-  if (timing) MFM_HIP_CHECK(hipEventRecord(ev[2], s));
-  hipLaunchKernelGGL(k_lat_resolve, dim3(1), dim3(256), 0, s, C, nsub, (int)n, m.win_lo.p, m.win_hi.p, m.snap.p, m.snap_idx.p,
-                     m.snap_cnt.p, m.Tc.p, m.status.p);
-  hipLaunchKernelGGL(k_lat_final, dim3((unsigned)(((int64_t)C * nsub + 63) / 64)), dim3(64), 0, s, m.rec.p, m.qt.p, job.raw, job.mask,
-                     job.state, n, Lq, subq, nsub, C, m.Tc.p, m.snap.p, m.snap_idx.p, m.snap_cnt.p, job.rows, job.eq, job.y, job.n_class,
-                     m.status.p);
-  hipLaunchKernelGGL(k_lat_commit, dim3(1), dim3(1), 0, s, job.state, m.status.p);
-  if (timing) MFM_HIP_CHECK(hipEventRecord(ev[3], s));
-  MFM_HIP_CHECK(hipGetLastError());
-  MFM_HIP_CHECK(hipMemcpyAsync(m.h_status, m.status.p, sizeof(LatStatus), hipMemcpyDeviceToHost, s));
-  MFM_HIP_CHECK(hipStreamSynchronize(s));
   S.status = m.h_status->fail;
   S.chunks = C;
   S.subs = nsub;
   S.lq = Lq;
   S.quads_used = m.h_status->end_quads;
   S.walkers = m.h_status->walkers;
+  S.attempts = attempts;
   if (timing) {
     float a = 0, b = 0, c2 = 0;
     (void)hipEventElapsedTime(&a, ev[0], ev[1]);
@@ -1042,9 +1080,10 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
     S.ms_final = c2;
     std::fprintf(stderr,
                  "[latent] n %lld quads %lld (cap %lld) chunks %d x %lld (sub %d) walkers %lld, %d rounds then resident from quad %d "
-                 "(largest list %lld), status %d (chunk %d) | quads+windows %.3f ms, flows %.3f ms, resolve+final %.3f ms\n",
+                 "(largest list %lld), %d attempt(s), status %d (chunk %d) | first attempt: quads %.3f ms, windows+flows %.3f ms, "
+                 "resolve+final %.3f ms\n",
                  (long long)n, (long long)S.quads_used, (long long)prep.q_cap, C, (long long)Lq, subq, (long long)S.walkers, rounds_done,
-                 handover, (long long)max_live, S.status, m.h_status->fail_chunk, a, b, c2);
+                 handover, (long long)max_live, attempts, S.status, m.h_status->fail_chunk, a, b, c2);
     for (auto &e : ev) (void)hipEventDestroy(e);
   }
   if (stats) *stats = S;

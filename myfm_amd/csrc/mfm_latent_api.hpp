@@ -43,8 +43,8 @@ struct LatentPrep {
 };
 
 struct LatentStats {
-  int32_t status = 0;  // 0 ok; 1 window missed the path; 2 snapshot space; 3 walker space; 4 q_cap too small; 5 bad input
-  int32_t chunks = 0, subs = 0;
+  int32_t status = 0;  // 0 ok; 1 window missed the path; 2 snapshot space; 3 walker space; 4 q_cap too small; 5 a row too far out
+  int32_t chunks = 0, subs = 0, attempts = 0;  // attempts: 2 = the first one's windows missed the path, the wider ones held it
   int64_t quads_used = 0;   // quads consumed (4 engine outputs each)
   int64_t walkers = 0;      // walkers the flows started with (sum of the windows)
   int64_t lq = 0;

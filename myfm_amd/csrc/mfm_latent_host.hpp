@@ -137,15 +137,17 @@ int mfm_oprobit_sample_z_exact(mfm_ctx *ctx, int32_t group, const double *gamma,
   MFM_CATCH(ctx)
 }
 
-int mfm_latent_stats(mfm_ctx *ctx, int64_t *out6) {
+int mfm_latent_stats(mfm_ctx *ctx, int64_t *out8) {
   MFM_TRY(ctx)
   const LatentStats &s = ctx->latent_stats;
-  out6[0] = s.status;
-  out6[1] = s.chunks;
-  out6[2] = s.subs;
-  out6[3] = s.lq;
-  out6[4] = s.quads_used;
-  out6[5] = s.walkers;
+  out8[0] = s.status;
+  out8[1] = s.chunks;
+  out8[2] = s.subs;
+  out8[3] = s.lq;
+  out8[4] = s.quads_used;
+  out8[5] = s.walkers;
+  out8[6] = s.attempts;
+  out8[7] = 0;
   MFM_CATCH(ctx)
 }
 
