@@ -557,7 +557,115 @@ __device__ __forceinline__ lat_d2v lat_asm_load(const double2 *p) {
   return v;
 }
 
-template <int NT>
+// a lane's walker and its row supply
+struct LatLane {
+  int32_t t, hi;  // current row; rows below hi are in the ring or requested
+  double2 r;      // walker record of row t
+};
+// (re)start of a lane's row supply: the current record and the ring's rows t + 1 .. t + RING by plain loads
+template <int NT, int RING>
+__device__ __forceinline__ void lat_prime(LatLane &L, double2 *ring, int tid, const double2 *__restrict__ wrec, int64_t n) {
+  L.r = wrec[L.t];
+#pragma unroll
+  for (int k = 1; k <= RING; k++) ring[(size_t)((L.t + k) & (RING - 1)) * NT + tid] = wrec[min((int64_t)L.t + k, n)];
+  L.hi = L.t + RING + 1;
+  // (the compiler's own wait for these loads belongs HERE: placed at the first use of r -- inside the step loop -- it would also wait,
+  //  at every step, for the asm loads the group has just issued)
+  asm volatile("" : "+v"(L.r.x), "+v"(L.r.y) : : "memory");
+}
+// `steps` quads from quad j0 for the 64 walkers of a wave. strip0: the wave's two LDS strips of QS quads; buf / strip_ready: which
+// of them holds the quads from j0 on (a caller that continues where the last call ended keeps them).
+constexpr int LAT_QS = 16;  // quads per segment
+template <int NT, int RING>
+__device__ __forceinline__ void lat_walk_wave(LatLane &L, double2 *ring, double *strip0, int &buf, bool &strip_ready, int tid, int lane,
+                                              const double2 *__restrict__ wrec, int64_t n, const double *__restrict__ qt, int64_t jstart,
+                                              int steps, const LatCtx &cx) {
+  constexpr int G = RING / 2, QS = LAT_QS;
+  const double2 *rec_end = wrec + n;  // the record after the last row: accepts nothing
+  for (int seg = 0; seg < steps; seg += QS) {
+    const int S = min(QS, steps - seg);
+    const int64_t j0 = jstart + seg;
+    double *strip = strip0 + buf * (QS * LAT_QW);
+    const double2 *qsrc = (const double2 *)(qt + (size_t)j0 * LAT_QW) + (lane < QS * LAT_QW / 2 ? lane : 0);
+    if (!strip_ready) {
+      lat_d2v q = lat_asm_load(qsrc);
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(q) : : "memory");
+      if (lane < QS * LAT_QW / 2) ((double2 *)strip)[lane] = make_double2(q.x, q.y);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    lat_d2v qnext = lat_asm_load(qsrc + QS * LAT_QW / 2);  // (the table is padded: the last look-ahead stays inside it)
+    for (int k0 = 0; k0 < S; k0 += G) {
+      // rows the ring will miss after this group: hi .. t + RING (it holds rows up to hi - 1 >= t + G)
+      const int m = L.t + RING + 1 - L.hi;  // 0 .. G
+      lat_d2v l[G];
+#pragma unroll
+      for (int k = 0; k < G; k++) l[k] = lat_asm_load(m > k ? wrec + min((int64_t)L.hi + k, n) : rec_end);
+      const int ke = min(G, S - k0);
+      for (int k = 0; k < ke; k++) {
+        const double2 *qp = (const double2 *)(strip + (k0 + k) * LAT_QW);
+        const double2 qa = qp[0], qb = qp[1];
+        const LatQ q{qa.x, qa.y, qb.x, qb.y};
+        const double2 nx = ring[(size_t)((L.t + 1) & (RING - 1)) * NT + tid];
+        const bool acc = lat_accept(cx, L.t, L.r.x, L.r.y, q, j0 + k0 + k);
+        L.t += acc ? 1 : 0;
+        L.r.x = acc ? nx.x : L.r.x;
+        L.r.y = acc ? nx.y : L.r.y;
+      }
+      if (G == 4)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(qnext) : : "memory");
+      else if (G == 2)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(l[0]), "+v"(l[1]), "+v"(qnext) : : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(l[0]), "+v"(l[1]), "+v"(l[2 % G]), "+v"(l[3 % G]), "+v"(l[4 % G]), "+v"(l[5 % G]), "+v"(l[6 % G]), "+v"(l[7 % G]),
+                       "+v"(qnext)
+                     :
+                     : "memory");
+#pragma unroll
+      for (int k = 0; k < G; k++)
+        if (m > k) ring[(size_t)((L.hi + k) & (RING - 1)) * NT + tid] = make_double2(l[k].x, l[k].y);
+      L.hi += m;
+    }
+    // the next segment's quads into the other strip
+    buf ^= 1;
+    if (lane < QS * LAT_QW / 2) ((double2 *)(strip0 + buf * (QS * LAT_QW)))[lane] = make_double2(qnext.x, qnext.y);
+    strip_ready = S == QS;  // (a short segment ends where the caller's round ends: the next one starts elsewhere)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// every live walker of every chunk: `R` quads from quad c Lq + done, a walker per thread, on the row supply above. grid (tiles, C)
+template <int NT, int RING>
+__global__ __launch_bounds__(NT) void k_lat_round_ring(const double2 *__restrict__ rec, const double2 *__restrict__ wrec,
+                                                       const double *__restrict__ qt, const double2 *__restrict__ qx,
+                                                       const uint32_t *__restrict__ raw, uint64_t mask,
+                                                       const RngState *__restrict__ rs, int64_t n, int64_t Lq, int done, int R,
+                                                       const int32_t *__restrict__ win_lo, const int32_t *__restrict__ live,
+                                                       const int64_t *__restrict__ list_off, int32_t *cur, int first) {
+  extern __shared__ double2 lat_lds[];
+  double2 *ring = lat_lds;                         // [RING][NT]
+  double *strips = (double *)(lat_lds + RING * NT);  // [NT / 64][2][QS * LAT_QW]
+  const int c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int i = blockIdx.x * NT + tid;
+  const int nl = live[c];
+  if (blockIdx.x * NT + wid * 64 >= nl) return;  // (a whole wave past the list)
+  const LatCtx cx{rec, qx, raw, mask, rs->p_cons};
+  int32_t *pc = cur + list_off[c] + i;
+  LatLane L;
+  L.t = i < nl ? (first ? win_lo[c] + i : *pc) : (int32_t)n;
+  lat_prime<NT, RING>(L, ring, tid, wrec, n);
+  int buf = 0;
+  bool ready = false;
+  lat_walk_wave<NT, RING>(L, ring, strips + (size_t)wid * (2 * LAT_QS * LAT_QW), buf, ready, tid, lane, wrec, n, qt, (int64_t)c * Lq + done, R,
+                          cx);
+  if (i < nl) *pc = L.t;
+}
+
+template <int NT, int RING>
 __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__ rec, const double2 *__restrict__ wrec,
                                                      const double *__restrict__ qt, const double2 *__restrict__ qx,
                                                      const uint32_t *__restrict__ raw, uint64_t mask,
@@ -568,10 +676,10 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
                                                      int2 *__restrict__ snap, int64_t *__restrict__ snap_idx,
                                                      int32_t *__restrict__ snap_cnt, LatStatus *__restrict__ st) {
   constexpr int NW = NT / 64;
-  constexpr int QS = 16;                     // quads per segment
+  constexpr int QS = LAT_QS;
   extern __shared__ double2 lat_lds[];
-  double2 *ring = lat_lds;                   // [8][NT]
-  int *s_t0 = (int *)(lat_lds + 8 * NT);     // [NT] x 2: t / first_in of the gather
+  double2 *ring = lat_lds;                   // [RING][NT]
+  int *s_t0 = (int *)(lat_lds + RING * NT);  // [NT] x 2: t / first_in of the gather
   int *s_f0 = s_t0 + NT;
   int *s_cnt = s_f0 + NT;                    // [16]
   double *strips = (double *)(s_cnt + 16);   // [NW][2][QS * LAT_QW]
@@ -587,96 +695,43 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
   const int64_t off = list_off[c];
   int64_t sp = done0 >= subq ? snap_pos[c] : snap_off[c];
   const int64_t sp_end = snap_off[c + 1];
-  const double2 *rec_end = wrec + n;  // the record after the last row: accepts nothing
   int wl = max(0, min(64, nl - wid * 64));
-  int32_t t = (int32_t)n, f = 0, hi = 0;
-  double2 r;
+  LatLane L;
+  L.t = (int32_t)n;
+  int32_t f = 0;
   if (lane < wl) {
-    t = scur[off + tid];
+    L.t = scur[off + tid];
     f = sfin[off + tid];
   }
-  // (re)start of a lane's row supply: the current record and the ring's rows t + 1 .. t + 8 by plain loads
-  auto prime = [&]() {
-    r = wrec[t];
-#pragma unroll
-    for (int k = 1; k <= 8; k++) ring[(size_t)((t + k) & 7) * NT + tid] = wrec[min((int64_t)t + k, n)];
-    hi = t + 9;
-  };
-  prime();
+  lat_prime<NT, RING>(L, ring, tid, wrec, n);
   double *strip0 = strips + (size_t)wid * (2 * QS * LAT_QW);
-  auto quad_addr = [&](int64_t j) { return (const double2 *)(qt + (size_t)j * LAT_QW) + (lane < QS * LAT_QW / 2 ? lane : 0); };
   int done = done0, buf = 0;
   bool strip_ready = false;  // strips[buf] holds the quads of the segment that starts at `done`
   while (done < (int)Lq) {
     const int to_boundary = subq - (done % subq);
     const int Rr = min(R, to_boundary);
     if (wl > 0) {
-      for (int seg = 0; seg < Rr; seg += QS) {
-        const int S = min(QS, Rr - seg);
-        const int64_t j0 = J0 + done + seg;
-        double *strip = strip0 + buf * (QS * LAT_QW);
-        if (!strip_ready) {
-          lat_d2v q = lat_asm_load(quad_addr(j0));
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(q) : : "memory");
-          if (lane < QS * LAT_QW / 2) ((double2 *)strip)[lane] = make_double2(q.x, q.y);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        lat_d2v qnext = lat_asm_load(quad_addr(j0 + QS));  // (the table is padded: the last look-ahead stays inside it)
-        for (int k0 = 0; k0 < S; k0 += 4) {
-          // rows the ring will miss after this group
-          const int m = t + 9 - hi;  // 0 .. 4
-          lat_d2v l0 = lat_asm_load(m > 0 ? wrec + min((int64_t)hi, n) : rec_end);
-          lat_d2v l1 = lat_asm_load(m > 1 ? wrec + min((int64_t)hi + 1, n) : rec_end);
-          lat_d2v l2 = lat_asm_load(m > 2 ? wrec + min((int64_t)hi + 2, n) : rec_end);
-          lat_d2v l3 = lat_asm_load(m > 3 ? wrec + min((int64_t)hi + 3, n) : rec_end);
-          const int ke = min(4, S - k0);
-          for (int k = 0; k < ke; k++) {
-            const double2 *qp = (const double2 *)(strip + (k0 + k) * LAT_QW);
-            const double2 qa = qp[0], qb = qp[1];
-            const LatQ q{qa.x, qa.y, qb.x, qb.y};
-            const double2 nx = ring[(size_t)((t + 1) & 7) * NT + tid];
-            const bool acc = lat_accept(cx, t, r.x, r.y, q, j0 + k0 + k);
-            t += acc ? 1 : 0;
-            r.x = acc ? nx.x : r.x;
-            r.y = acc ? nx.y : r.y;
-          }
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(qnext) : : "memory");
-          if (m > 0) ring[(size_t)(hi & 7) * NT + tid] = make_double2(l0.x, l0.y);
-          if (m > 1) ring[(size_t)((hi + 1) & 7) * NT + tid] = make_double2(l1.x, l1.y);
-          if (m > 2) ring[(size_t)((hi + 2) & 7) * NT + tid] = make_double2(l2.x, l2.y);
-          if (m > 3) ring[(size_t)((hi + 3) & 7) * NT + tid] = make_double2(l3.x, l3.y);
-          hi += m;
-        }
-        // the next segment's quads into the other strip
-        buf ^= 1;
-        if (lane < QS * LAT_QW / 2) ((double2 *)(strip0 + buf * (QS * LAT_QW)))[lane] = make_double2(qnext.x, qnext.y);
-        strip_ready = S == QS;  // (a short segment ends at a boundary of the round: the next one starts elsewhere)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
+      lat_walk_wave<NT, RING>(L, ring, strip0, buf, strip_ready, tid, lane, wrec, n, qt, J0 + done, Rr, cx);
       // merge inside the wave: the walkers are sorted, a walker that met the one below it is dropped
-      const int prev = __shfl_up(t, 1, 64);
-      const bool keep = lane < wl && (lane == 0 || t != prev);
+      const int prev = __shfl_up(L.t, 1, 64);
+      const bool keep = lane < wl && (lane == 0 || L.t != prev);
       const unsigned long long b = __ballot(keep);
       const int cnt = __popcll(b);
       if (cnt != wl) {
         const int rk = __popcll(b & ((1ull << lane) - 1ull));
         const int base = wid * 64;
         if (keep) {
-          s_t0[base + rk] = t;
+          s_t0[base + rk] = L.t;
           s_f0[base + rk] = f;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         wl = cnt;
-        t = lane < wl ? s_t0[base + lane] : (int32_t)n;
+        L.t = lane < wl ? s_t0[base + lane] : (int32_t)n;
         f = lane < wl ? s_f0[base + lane] : 0;
         __builtin_amdgcn_wave_barrier();
-        prime();
+        lat_prime<NT, RING>(L, ring, tid, wrec, n);
       }
     } else {
       strip_ready = false;
@@ -694,7 +749,7 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
         tot += cw;
       }
       if (lane < wl) {
-        s_t0[before + lane] = t;
+        s_t0[before + lane] = L.t;
         s_f0[before + lane] = f;
       }
       __syncthreads();
@@ -731,10 +786,10 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
       __syncthreads();
       nl = tot2;
       wl = max(0, min(64, nl - wid * 64));
-      t = lane < wl ? s_t1[tid] : (int32_t)n;
+      L.t = lane < wl ? s_t1[tid] : (int32_t)n;
       f = lane < wl ? s_f1[tid] : 0;
       __syncthreads();
-      prime();
+      lat_prime<NT, RING>(L, ring, tid, wrec, n);
     }
   }
 }
@@ -1009,14 +1064,23 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
     max_live = Wmax;
     int Rr = R;
     const bool no_resident = std::getenv("MFM_LAT_NO_RESIDENT") != nullptr;
+    const bool plain_rounds = std::getenv("MFM_LAT_PLAIN_ROUNDS") != nullptr;
+    const int res_nt = env_int("MFM_LAT_RES_NT", LAT_RES_NT) >= 512 ? 512 : 256;
+    const int ring = env_int("MFM_LAT_RING", 8) >= 16 ? 16 : 8;
     while (done < Lq) {
-      if (!first && max_live <= LAT_RES_NT && !no_resident) break;
+      if (!first && max_live <= res_nt && !no_resident) break;
       if (round >= LAT_MAX_ROUNDS) throw Error(MFM_ERR_RUNTIME, "exact latent draws: too many rounds");
       int step = (int)std::min<int64_t>(Rr, Lq - done);
       if (done % subq + step > subq) step = subq - done % subq;
       const unsigned tiles = (unsigned)((max_live + LAT_TILE - 1) / LAT_TILE);
-      hipLaunchKernelGGL(k_lat_round, dim3(tiles, (unsigned)C), dim3(LAT_TILE), 0, s, m.rec.p, m.wrec.p, m.qt.p, m.qx.p, job.raw, job.mask,
-                         job.state, n, Lq, done, step, m.win_lo.p, m.live.p, m.list_off.p, sc, first ? 1 : 0);
+      if (plain_rounds) {
+        hipLaunchKernelGGL(k_lat_round, dim3(tiles, (unsigned)C), dim3(LAT_TILE), 0, s, m.rec.p, m.wrec.p, m.qt.p, m.qx.p, job.raw, job.mask,
+                           job.state, n, Lq, done, step, m.win_lo.p, m.live.p, m.list_off.p, sc, first ? 1 : 0);
+      } else {
+        const size_t lds_r = (size_t)8 * LAT_TILE * sizeof(double2) + (size_t)(LAT_TILE / 64) * 2 * LAT_QS * LAT_QW * sizeof(double);
+        hipLaunchKernelGGL((k_lat_round_ring<LAT_TILE, 8>), dim3(tiles, (unsigned)C), dim3(LAT_TILE), lds_r, s, m.rec.p, m.wrec.p, m.qt.p,
+                           m.qx.p, job.raw, job.mask, job.state, n, Lq, done, step, m.win_lo.p, m.live.p, m.list_off.p, sc, first ? 1 : 0);
+      }
       done += step;
       const int snap_k = done % subq == 0 ? done / subq - 1 : -1;
       hipLaunchKernelGGL(k_lat_compact, dim3((unsigned)C), dim3(1024), 0, s, m.win_lo.p, m.live.p, m.list_off.p, sc, sf, dc, df,
@@ -1037,18 +1101,22 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
     rounds_done = round;
     handover = done;
     if (done < Lq) {
-      const size_t lds = (size_t)8 * LAT_RES_NT * sizeof(double2) + (size_t)(2 * LAT_RES_NT + 16) * sizeof(int) +
-                         (size_t)(LAT_RES_NT / 64) * 2 * 16 * LAT_QW * sizeof(double);
+      const size_t lds = (size_t)ring * res_nt * sizeof(double2) + (size_t)(2 * res_nt + 16) * sizeof(int) +
+                         (size_t)(res_nt / 64) * 2 * LAT_QS * LAT_QW * sizeof(double);
       {
         static DeviceOnce raised;
         if (raised.need()) {
-          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_lat_resident<LAT_RES_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_lat_resident<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_lat_resident<512, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_lat_resident<256, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
           raised.mark();
         }
       }
-      hipLaunchKernelGGL((k_lat_resident<LAT_RES_NT>), dim3((unsigned)C), dim3(LAT_RES_NT), lds, s, m.rec.p, m.wrec.p, m.qt.p, m.qx.p,
-                         job.raw, job.mask, job.state, n, Lq, done, R, subq, nsub, m.live.p, m.list_off.p, sc, sf, m.snap_off.p,
-                         m.snap_pos.p, m.snap.p, m.snap_idx.p, m.snap_cnt.p, m.status.p);
+      auto kern = res_nt == 512 ? (ring == 16 ? k_lat_resident<512, 16> : k_lat_resident<512, 8>)
+                                : (ring == 16 ? k_lat_resident<256, 16> : k_lat_resident<256, 8>);
+      hipLaunchKernelGGL(kern, dim3((unsigned)C), dim3(res_nt), lds, s, m.rec.p, m.wrec.p, m.qt.p, m.qx.p, job.raw, job.mask, job.state, n,
+                         Lq, done, R, subq, nsub, m.live.p, m.list_off.p, sc, sf, m.snap_off.p, m.snap_pos.p, m.snap.p, m.snap_idx.p,
+                         m.snap_cnt.p, m.status.p);
     }
     if (timing && attempts == 1) MFM_HIP_CHECK(hipEventRecord(ev[2], s));
     hipLaunchKernelGGL(k_lat_resolve, dim3(1), dim3(256), 0, s, C, nsub, (int)n, m.win_lo.p, m.win_hi.p, m.snap.p, m.snap_idx.p,
