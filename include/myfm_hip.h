@@ -285,6 +285,10 @@ int mfm_rng_get_z(mfm_ctx *ctx, double *zw, double *zv);
  * mfm_update_e_classification_exact = FM::predict_score_write_target + the draws (the exact twin of
  * mfm_update_e_classification); mfm_oprobit_sample_z_exact = sample_z_given_cutpoint for one cutpoint group on the current e. */
 int mfm_update_e_classification_exact(mfm_ctx *ctx, int32_t *status);
+/* The order in which mfm_update_e_classification_exact serves the rows (FMTrainer.hpp:500 walks the caller's rows 0 .. N - 1): entry i =
+ * the row of this table that is the caller's row i, for a caller that handed the rows over in another order (sorted for the device
+ * paths). n = 0: the table's own order. (Ordered probit: the group's row list of mfm_oprobit_add_group is that order.)              */
+int mfm_set_latent_order(mfm_ctx *ctx, const int64_t *rows, int64_t n);
 int mfm_oprobit_sample_z_exact(mfm_ctx *ctx, int32_t group, const double *gamma, int32_t *status);
 /* diagnostics of the last exact draw: {status, chunks, sub-chunks per chunk, quads per chunk, quads consumed, walkers started,
  * attempts (2: the first attempt's windows of +-4 sigma missed the path, the second's +-6.5 sigma held it), reserved} */

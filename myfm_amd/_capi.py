@@ -32,7 +32,7 @@ SYMBOLS = [
     "mfm_comm_stats", "mfm_comm_info", "mfm_store_create", "mfm_store_destroy", "mfm_store_last_error", "mfm_store_size", "mfm_store_push_ctx",
     "mfm_store_push_host", "mfm_store_get", "mfm_design_predict_store", "mfm_store_reserve", "mfm_cs_plan_selftest",
     "mfm_regression_iteration_ready", "mfm_regression_iteration",
-    "mfm_update_e_classification_exact", "mfm_oprobit_sample_z_exact", "mfm_latent_stats", "mfm_rng_host_read", "mfm_rng_host_advance",
+    "mfm_update_e_classification_exact", "mfm_oprobit_sample_z_exact", "mfm_latent_stats", "mfm_rng_host_read", "mfm_rng_host_advance", "mfm_set_latent_order",
 ]
 
 _lib = None
@@ -126,6 +126,7 @@ def lib():
     L.mfm_update_e_classification_exact.argtypes = [vp, C.POINTER(i32)]
     L.mfm_oprobit_sample_z_exact.argtypes = [vp, i32, P, C.POINTER(i32)]
     L.mfm_latent_stats.argtypes = [vp, P]
+    L.mfm_set_latent_order.argtypes = [vp, P, i64]
     L.mfm_rng_host_read.argtypes = [vp, u64, i64, P]
     L.mfm_rng_host_advance.argtypes = [vp, u64]
     L.mfm_design_score_ctx.argtypes = [vp, vp, P]

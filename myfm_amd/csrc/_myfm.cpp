@@ -167,7 +167,12 @@ struct FMLearningConfig {
   // regression and the latent draws consume ITS stream in the reference's order, evaluated in parallel on the device
   // (csrc/mfm_latent.hpp: coalescing flows) -- the same chain as mode 1 draw for draw. set_exact_latent_draws(true) selects
   // mode 2 (MYFM_AMD_EXACT_ON_HOST=1: mode 1).
-  int latent_mode = 0;
+  int latent_mode = 2;
+  // latent_order (ConfigBuilder.set_latent_row_order; classification, modes "exact" / "host"): the rows in the order in which the
+  // reference draws their latent z -- entry i = the row of THIS table that is the caller's row i. Empty: the table's own order.
+  // (MyFM*.fit sorts the rows for the device paths and passes the inverse permutation here; ordered probit carries the same
+  // information in its cutpoint groups' row lists.)
+  vector<int64_t> latent_order;
   bool host_rng() const { return latent_mode == 1 || std::getenv("MYFM_AMD_HOST_RNG") != nullptr; }
   bool exact_dev() const { return latent_mode == 2 && !host_rng() && task_type != TaskType::REGRESSION; }
 
@@ -206,8 +211,10 @@ struct ConfigBuilder {
   vector<size_t> group_index;
   Real cutpoint_scale = 10;
   CutpointGroupType cutpoint_groups;
-  bool exact_latent_draws = false;  // (see FMLearningConfig::exact_latent_draws)
+  bool exact_latent_draws = true;   // (see FMLearningConfig::exact_latent_draws)
   int latent_mode = -1;             // -1: follows exact_latent_draws
+  vector<int64_t> latent_order;
+  ConfigBuilder &set_latent_row_order(const vector<int64_t> &a) { latent_order = a; return *this; }
 
   ConfigBuilder &set_exact_latent_draws(bool a) { exact_latent_draws = a; return *this; }
   ConfigBuilder &set_latent_mode(const std::string &m) {
@@ -237,6 +244,7 @@ struct ConfigBuilder {
                        n_kept_samples, cutpoint_scale, cutpoint_groups);
     c.exact_latent_draws = exact_latent_draws;
     c.latent_mode = latent_mode >= 0 ? latent_mode : (exact_latent_draws ? (std::getenv("MYFM_AMD_EXACT_ON_HOST") ? 1 : 2) : 0);
+    c.latent_order = latent_order;
     return c;
   }
 };
@@ -1147,6 +1155,19 @@ struct FMTrainer {
   }
   FMTrainer(const FMTrainer &) = delete;
   bool comm_active() const { return !comm_id.empty() || (allreduce.ptr() != nullptr && !allreduce.is_none()); }
+  // before the device is built: the exact latent draws walk ONE stream over ALL rows in order -- a row-sharded fit keeps the
+  // per-row Philox streams (which do not depend on the sharding)
+  void resolve_latent_mode() {
+    if (cfg.latent_mode == 2 && comm_active()) cfg.latent_mode = 0;
+    if (!cfg.latent_order.empty()) {
+      if ((int64_t)cfg.latent_order.size() != N) throw std::invalid_argument("latent row order must list every row once");
+      vector<bool> seen((size_t)N, false);
+      for (auto r : cfg.latent_order) {
+        if (r < 0 || r >= N || seen[(size_t)r]) throw std::invalid_argument("latent row order must list every row once");
+        seen[(size_t)r] = true;
+      }
+    }
+  }
 
   // BaseFMTrainer.hpp:107-115
   FM create_FM(int rank, Real init_std) {
@@ -1188,6 +1209,8 @@ struct FMTrainer {
     lap("mfm_set_groups");
     ck(ctx, mfm_finalize(ctx, rank));
     lap("mfm_finalize");
+    if (!cfg.latent_order.empty() && cfg.task_type == TaskType::CLASSIFICATION)
+      ck(ctx, mfm_set_latent_order(ctx, cfg.latent_order.data(), (int64_t)cfg.latent_order.size()));
     // regression: update_e recomputes the residual after every update_V (:494), nothing reads it in between
     if (cfg.task_type == TaskType::REGRESSION && !std::getenv("MYFM_AMD_KEEP_RESIDUAL")) ck(ctx, mfm_set_residual_policy(ctx, 1));
   }
@@ -1504,7 +1527,9 @@ struct FMTrainer {
         } else {
           eng.host = &gen_;
         }
-        for (int64_t t = 0; t < N; t++) {
+        const bool ordered_rows = !cfg.latent_order.empty();
+        for (int64_t i = 0; i < N; i++) {
+          const int64_t t = ordered_rows ? cfg.latent_order[(size_t)i] : i;
           const Real pred = e[(size_t)t];
           const Real n = y[(size_t)t] > 0 ? host_tn_left(eng, pred, (Real)1, (Real)0) : host_tn_right(eng, pred, (Real)1, (Real)0);
           e[(size_t)t] -= n;
@@ -1535,6 +1560,7 @@ struct FMTrainer {
       FM &fm, Hyper &hyper, const std::function<bool(int, FM *, Hyper *, LearningHistory *)> &cb) {
     std::pair<Predictor, LearningHistory> result{Predictor((size_t)fm.n_factors, dim_all, cfg.task_type), LearningHistory()};
     SetupLap lap("learn_with_callback");
+    resolve_latent_mode();
     build_device(fm.n_factors);
     lap("build_device (set_main, blocks, finalize)");
     if (peer_connect.ptr() != nullptr && !peer_connect.is_none()) {  // row-sharded persistent sweep: the ranks' exchange buffers
@@ -1672,6 +1698,7 @@ struct GibbsSession {
     fm = trainer->create_FM((int)n_factor, init_std);
     hyper = trainer->create_Hyper((size_t)fm.n_factors);
     lap("create_FM / create_Hyper");
+    trainer->resolve_latent_mode();
     trainer->build_device(fm.n_factors);
     lap("build_device (set_main, blocks, finalize)");
     trainer->upload(fm);
@@ -1808,6 +1835,14 @@ PYBIND11_MODULE(_myfm, m) {
       .def("set_cutpoint_scale", &ConfigBuilder::set_cutpoint_scale)
       .def("set_exact_latent_draws", &ConfigBuilder::set_exact_latent_draws, py::return_value_policy::reference_internal)
       .def("set_latent_mode", &ConfigBuilder::set_latent_mode, py::return_value_policy::reference_internal)
+      .def("set_latent_row_order",
+           [](ConfigBuilder &b, const py::object &o) -> ConfigBuilder & {
+             auto arr = py::array_t<int64_t, py::array::c_style | py::array::forcecast>::ensure(o);
+             if (!arr || arr.ndim() != 1) throw std::invalid_argument("latent row order must be a 1-d integer array");
+             b.latent_order.assign(arr.data(), arr.data() + arr.size());
+             return b;
+           },
+           py::return_value_policy::reference_internal)
       .def("set_cutpoint_groups",
            // [(n_class, row indices)]: the reference's list-of-lists (declare_module.hpp:139-156), and numpy index arrays
            // without a per-element Python conversion (5e7 rows at config 5)

@@ -288,6 +288,7 @@ struct mfm_ctx {
   // exact latent draws of classification / ordered probit on the device stream (mfm_latent.hip)
   std::unique_ptr<LatentEngine> latent;
   LatentStats latent_stats;
+  DevBuf<int32_t> latent_order;  // classification: the rows in the reference's draw order (empty: the table's own order)
 
   // ordered probit groups
   struct OGroup {

@@ -111,13 +111,33 @@ static int latent_exact_run(mfm_ctx *ctx, int64_t n, const int32_t *rows, int n_
 
 extern "C" {
 
+int mfm_set_latent_order(mfm_ctx *ctx, const int64_t *rows, int64_t n) {
+  MFM_TRY(ctx)
+  ctx->need_final();
+  if (n == 0) {
+    ctx->latent_order.release();
+    return MFM_OK;
+  }
+  if (n != ctx->N) throw Error(MFM_ERR_INVALID, "the latent row order must list every row once");
+  std::vector<int32_t> r32((size_t)n);
+  std::vector<uint8_t> seen((size_t)n, 0);
+  for (int64_t i = 0; i < n; i++) {
+    if (rows[i] < 0 || rows[i] >= n || seen[(size_t)rows[i]]) throw Error(MFM_ERR_INVALID, "the latent row order must list every row once");
+    seen[(size_t)rows[i]] = 1;
+    r32[(size_t)i] = (int32_t)rows[i];
+  }
+  MFM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->latent_order.upload(r32);
+  MFM_CATCH(ctx)
+}
+
 int mfm_update_e_classification_exact(mfm_ctx *ctx, int32_t *status) {
   MFM_TRY(ctx)
   ctx->need_final();
   if (ctx->comm.active()) throw Error(MFM_ERR_RUNTIME, "exact latent draws are not available on row-sharded fits");
   score_train(ctx, false);
   int32_t st = 0;
-  if (ctx->N) latent_exact_run(ctx, ctx->N, nullptr, 0, nullptr, &st);
+  if (ctx->N) latent_exact_run(ctx, ctx->N, ctx->latent_order.p, 0, nullptr, &st);
   if (status) *status = st;
   MFM_CATCH(ctx)
 }

@@ -3,6 +3,7 @@ MyFMOrderedProbit surface of the reference (src/myfm/base.py:70-399, src/myfm/gi
 written against ``myfm_amd._myfm``. Same constructor / fit / predict arguments, defaults and
 error behaviour; numpy-2 safe.
 """
+import os
 from collections import OrderedDict
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -91,13 +92,15 @@ class MyFMGibbsBase:
         reg_0: float = 1.0,
         fit_w0: bool = True,
         fit_linear: bool = True,
-        exact_latent_draws: bool = False,
+        exact_latent_draws: bool = True,
     ):
-        # exact_latent_draws (not in the reference, which has one generator and nothing to choose): keep the sampler's
-        # std::mt19937 on the host for the whole fit, so that under the same seed EVERY draw is the reference's own -- in
-        # particular the latent draws of MyFMClassifier / MyFMOrderedProbit, which the default device path takes from per-row
-        # Philox streams (same law, other numbers: posterior means agree with the reference's chain only statistically).
-        # Slower (the variates are generated by one host thread and uploaded per sweep) and the rows stay in the caller's order.
+        # exact_latent_draws (not in the reference, which has one generator and nothing to choose). True (default): under the same
+        # seed EVERY draw is the reference's own -- also the latent draws of MyFMClassifier / MyFMOrderedProbit, which the reference
+        # makes row after row inside rejection loops on its one std::mt19937: they are evaluated in parallel on the device from that
+        # same stream (csrc/mfm_latent.hip), in the caller's row order whatever order the device paths keep the rows in. False: the
+        # latent draws come from per-row Philox streams instead (same law, other numbers: posterior means agree with the reference's
+        # chain only statistically) -- 1.15x faster at 5 10^7 rows, 5x at 10^7 rows of a two-field table. Regression chains are the
+        # reference's draw for draw either way. Row-sharded fits always use the per-row streams.
         self.exact_latent_draws = bool(exact_latent_draws)
         self.rank = rank
         self.init_stdev = init_stdev
@@ -206,15 +209,23 @@ class MyFMGibbsBase:
         # The sampler does not depend on the order of the training rows (every conditional is a sum over rows), the
         # device path does: a table sorted by its first one-hot field runs the fused passes. Rows that
         # arrive in another order are sorted by the first stored column here, together with y and the relation maps.
-        perm = None if self.exact_latent_draws else _device_row_order(X)  # (exact draws follow the caller's row order)
+        perm = _device_row_order(X)
         if perm is not None:
             ptr, idx, val = _myfm.permute_csr_rows(X.indptr, X.indices, X.data, perm)
             X = sps.csr_matrix((val, idx, ptr), shape=X.shape)
             y = np.asarray(y)[perm]
             X_rel = [RelationBlock(r.original_to_block_array[perm], r.data) for r in X_rel]
+            if self.exact_latent_draws and self._task_type != TaskType.REGRESSION:
+                # the latent draws are made in the CALLER's row order (FMTrainer.hpp:500, OProbitSampler.hpp:243): the sorted
+                # table's row that is the caller's row i
+                inv = np.empty(perm.shape[0], dtype=np.int64)
+                inv[perm] = np.arange(perm.shape[0], dtype=np.int64)
+                if self._task_type == TaskType.ORDERED:
+                    config_builder.set_cutpoint_groups([(int(np.asarray(y).max()) + 1, inv)])
+                else:
+                    config_builder.set_latent_row_order(inv)
         config_builder.set_task_type(self._task_type)
-        if self.exact_latent_draws:
-            config_builder.set_exact_latent_draws(True)
+        config_builder.set_exact_latent_draws(self.exact_latent_draws and not os.environ.get("MYFM_AMD_PHILOX_LATENT"))
         config = config_builder.build()
 
         if callback is None:

@@ -221,3 +221,41 @@ def test_exact_equals_host_mode_on_two_million_rows(mods):
         np.testing.assert_allclose(np.array(a.fm.V), np.array(b.fm.V), rtol=1e-8, atol=1e-8)
     info = a.latent_info()
     assert info["sequential_fallbacks"] == 0 and info["chunks"] > 100, info
+
+
+@pytest.mark.parametrize("task", ["classification", "ordered"])
+def test_estimators_default_is_the_reference_chain_on_unsorted_rows(mods, oracle, task):
+    """MyFMClassifier / MyFMOrderedProbit as a user calls them (no switch): rows arrive UNSORTED, fit() sorts them for the device paths
+    and hands the caller's order to the latent draws -- kept samples, hyper-parameters (and cutpoints) are the oracle's for the
+    caller's table and seed."""
+    from myfm_amd import MyFMClassifier, MyFMOrderedProbit
+
+    n = 20000
+    X, score, shapes = ds.onehot_mf(n, 300, 100, seed=11, sort_by_user=False)
+    gi = ds.group_index_from_shapes(shapes)
+    n_iter, rank = 4, 3
+    if task == "classification":
+        y = (score - np.median(score)) > 0
+        fm = MyFMClassifier(rank, random_seed=7)
+        fm.fit(X, y, n_iter=n_iter, n_kept_samples=n_iter, group_shapes=shapes)
+        samples, hypers, _, _ = _oracle_chain(oracle, X, np.where(y, 1.0, -1.0), [], n_iter, rank=rank, group_index=gi,
+                                              task=oracle.CLASSIFICATION, seed=7)
+        _assert_chain(fm.predictor_, fm.history_, samples, hypers)
+    else:
+        sc = (score - score.mean()) / score.std()
+        y = np.zeros(n)
+        for c in (-0.9, -0.2, 0.4, 1.1):
+            y += sc > c
+        fm = MyFMOrderedProbit(rank, random_seed=7)
+        fm.fit(X, y, n_iter=n_iter, n_kept_samples=n_iter, group_shapes=shapes)
+        groups = [(5, np.arange(n))]
+        samples, hypers, cuts, t = _oracle_chain(oracle, X, y, [], n_iter, n_groups_cut=1, rank=rank, group_index=gi, task=oracle.ORDERED,
+                                                 cutpoint_groups=groups, seed=7)
+        _assert_chain(fm.predictor_, fm.history_, samples, hypers)
+        for f, cut in zip(fm.predictor_.samples, cuts):
+            np.testing.assert_allclose(f.cutpoints[0], cut[0], rtol=1e-7, atol=1e-7)
+    # the opt-out gives another chain of the same law
+    est = MyFMClassifier if task == "classification" else MyFMOrderedProbit
+    fm2 = est(rank, random_seed=7, exact_latent_draws=False)
+    fm2.fit(X, y, n_iter=n_iter, n_kept_samples=n_iter, group_shapes=shapes)
+    assert not np.allclose(fm2.V_samples[-1], fm.V_samples[-1], rtol=1e-7, atol=1e-7)

@@ -114,7 +114,7 @@ def test_ordered_probit_chain_draw_for_draw(mods, oracle, monkeypatch, design):
 def test_exact_latent_draws_is_a_supported_option(mods, oracle, monkeypatch):
     """The same mode without the environment switch: `MyFMClassifier(..., exact_latent_draws=True)` (the estimator keeps the
     caller's row order and sets `ConfigBuilder.set_exact_latent_draws`) reproduces the oracle's probit chain draw for draw on
-    rows that arrive UNSORTED; the default (device latent stream) gives another chain of the same law."""
+    rows that arrive UNSORTED; the opt-out (per-row Philox streams) gives another chain of the same law."""
     from myfm_amd import MyFMClassifier
 
     monkeypatch.delenv("MYFM_AMD_HOST_RNG", raising=False)
@@ -128,7 +128,7 @@ def test_exact_latent_draws_is_a_supported_option(mods, oracle, monkeypatch):
     samples, hypers, _, _ = _oracle_chain(oracle, X, np.where(y, 1.0, -1.0), [], n_iter, rank=rank, group_index=gi,
                                           task=oracle.CLASSIFICATION, seed=7)
     _assert_chain(fm.predictor_, fm.history_, samples, hypers)
-    fm2 = MyFMClassifier(rank, random_seed=7)
+    fm2 = MyFMClassifier(rank, random_seed=7, exact_latent_draws=False)
     fm2.fit(X, y, n_iter=n_iter, n_kept_samples=n_iter, group_shapes=shapes)
     assert not np.allclose(fm2.V_samples[-1], fm.V_samples[-1], rtol=1e-7, atol=1e-7)
     p1, p2 = fm.predict_proba(X[:2000]), fm2.predict_proba(X[:2000])
