@@ -165,7 +165,21 @@ def other_configs(budget_s):
             ("configs[3]", ["--config", "4", "--steps", "40", "--warmup", "5", "--cpu-seconds", "3"]),
             ("configs[4] at scale 0.1", ["--config", "5", "--scale", "0.1", "--steps", "6", "--warmup", "2", "--cpu-seconds", "1"]),
             # ... and at its own size, N = 50 M rows (one CPU-oracle iteration there is ~130 s: profiles/r03_e_bench_config5_full_cpu.json)
-            ("configs[4] at full size", ["--config", "5", "--scale", "1.0", "--steps", "5", "--warmup", "2", "--cpu-seconds", "0"])]
+            # -- the default latent mode ("exact": the reference's own stream, draw for draw) and the per-row Philox streams
+            ("configs[4] at full size", ["--config", "5", "--scale", "1.0", "--steps", "5", "--warmup", "2", "--cpu-seconds", "0"]),
+            ("configs[4] at full size, latent=philox", ["--config", "5", "--scale", "1.0", "--steps", "5", "--warmup", "2", "--cpu-seconds", "0",
+                                                        "--latent", "philox"]),
+            # the task types BASELINE.md 1 quotes next to regression (examples/ml-100k.ipynb: classification 48.85 it/s, ordered probit
+            # 20.40 it/s on the reference's CPU): configs[1]'s and configs[2]'s designs with those targets, both latent modes
+            ("tasks: classification, configs[1] shape", ["--config", "2", "--task", "classification", "--steps", "200", "--warmup", "10", "--cpu-seconds", "3"]),
+            ("tasks: classification, configs[1] shape, latent=philox", ["--config", "2", "--task", "classification", "--latent", "philox", "--steps", "300",
+                                                                        "--warmup", "20", "--cpu-seconds", "0"]),
+            ("tasks: ordered probit, configs[1] shape", ["--config", "2", "--task", "ordered", "--steps", "200", "--warmup", "10", "--cpu-seconds", "3"]),
+            ("tasks: ordered probit, configs[1] shape, latent=philox", ["--config", "2", "--task", "ordered", "--latent", "philox", "--steps", "300",
+                                                                        "--warmup", "20", "--cpu-seconds", "0"]),
+            ("tasks: classification, configs[2] shape", ["--config", "3", "--task", "classification", "--steps", "30", "--warmup", "3", "--cpu-seconds", "0"]),
+            ("tasks: classification, configs[2] shape, latent=philox", ["--config", "3", "--task", "classification", "--latent", "philox", "--steps", "60",
+                                                                        "--warmup", "5", "--cpu-seconds", "0"])]
     t_all = time.time()
     for name, args in runs:
         if time.time() - t_all > budget_s:
@@ -180,7 +194,8 @@ def other_configs(budget_s):
             continue
         d = json.loads(line[-1])
         cpu = d.get("cpu_baseline") or {}
-        out[name] = {"workload": d["config"]["workload"], "it_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+        out[name] = {"workload": d["config"]["workload"], "task": d["config"].get("task"), "latent": d["config"].get("latent"),
+                     "it_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                      "cpu_it_per_s": cpu.get("value"), "cpu_iterations": cpu.get("iterations"), "cpu_pinned": cpu.get("pinned_to_one_core"),
                      "setup_s": d["config"]["setup_s"], "wall_s": round(time.time() - t0, 1)}
     return out
@@ -445,6 +460,7 @@ def main():
             assert torch.equal(v, allv[0]), ("replicas diverged (64-bit digests of w0, w, V and the hyper-parameters)", [x.tolist() for x in allv])
 
     plan_flags = int(sess.plan_flags())
+    latent_info = dict(sess.latent_info()) if hasattr(sess, "latent_info") else {}
     rccl_ranks, rccl_path = sess.comm_info() if sharded else (0, "")
     # Weak-scaling leg (N > 1, config 3): the table grows with the GPUs -- rank r holds ~a.rows rows of ONE user-sorted table of
     # world * a.rows rows over the same users / items (myfm_amd/utils/synthetic.py::movielens_like_shard). Reported as an extra field;
@@ -622,6 +638,10 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": W["name"], "task": W["task"],
+            # how the latent z of classification / ordered probit are drawn: "exact" = from the reference's own random
+            # stream, draw for draw, in parallel on the device; "philox" = per-row counter-based streams; "host" = the host loop
+            "latent": latent_info.get("mode") if W["task"] != "regression" else None,
+            "latent_draw": latent_info if W["task"] != "regression" else None,
             "rows": N, "nnz": nnz, "features": D, "main_features": D0, "rank": K, "groups": int(max(gi)) + 1,
             "relation_blocks": [{"rows": int(B.shape[0]), "features": int(B.shape[1]), "nnz": int(B.nnz)} for _, B in blocks],
             "parallelism": parallelism,
@@ -645,7 +665,7 @@ def main():
     if weak:
         out["weak_scaling"] = weak
     if a.config == 3 and world == 1 and not a.no_other_configs and not force_sharded:
-        out["other_configs"] = other_configs(budget_s=100.0)
+        out["other_configs"] = other_configs(budget_s=300.0)
     if sharded:
         out["config"]["allreduce_calls_per_step"] = round(calls / a.steps, 1)
         out["config"]["allreduce_bytes_per_step"] = round(8.0 * doubles / a.steps)

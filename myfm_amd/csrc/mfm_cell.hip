@@ -1085,7 +1085,8 @@ __global__ __launch_bounds__(CELL_NT) void k_cell_pass(CellPassArgs a) {
     for (int i = tid; i < n; i += CELL_NT) d[i] = a.DP[o + i];
   }
   int *turn = (int *)(lds + a.ldsTurn);
-  const int nacc = (FT == CELL_U ? nu : (FT == CELL_C ? a.card[a.sF] : 0)) * NS;
+  const int nval = FT == CELL_U ? nu : (FT == CELL_C ? a.card[a.sF] : 0);  // index values of the statistics field in this group
+  const int nacc = nval * NS;
   if (FT == CELL_U || FT == CELL_C) {
     for (int i = tid; i < nacc; i += CELL_NT) lds[a.ldsAcc + i] = 0.0;
     if (tid == 0) *turn = 0;
@@ -1214,8 +1215,8 @@ __global__ __launch_bounds__(CELL_NT) void k_cell_pass(CellPassArgs a) {
       for (int k = 0; k < CELL_R; k++)
         if (valid[k]) {
 #pragma unroll
-          for (int j = 0; j < NS; j++)
-            __hip_atomic_fetch_add(&acc[idxF[k] * NS + j], v[k][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (int j = 0; j < NS; j++)  // (one table per sum: a wave's 64 adds of sum j spread over 16 bank pairs, not 4 as [index][sum])
+            __hip_atomic_fetch_add(&acc[j * nval + idxF[k]], v[k][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) __hip_atomic_store(turn, my + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1267,10 +1268,10 @@ __global__ __launch_bounds__(CELL_NT) void k_cell_pass(CellPassArgs a) {
     if (FT == CELL_U) {
       // a group's U values are its own: the sums are complete
       for (int i = tid; i < nacc; i += CELL_NT)
-        if (u0 + i / NS < a.n_out) a.out[(int64_t)(u0 + i / NS) * a.out_stride + (i % NS)] = acc[i];
+        if (u0 + i / NS < a.n_out) a.out[(int64_t)(u0 + i / NS) * a.out_stride + (i % NS)] = acc[(i % NS) * nval + i / NS];
     } else {
       double *o = a.out + (int64_t)g * nacc;
-      for (int i = tid; i < nacc; i += CELL_NT) o[i] = acc[i];
+      for (int i = tid; i < nacc; i += CELL_NT) o[i] = acc[(i % NS) * nval + i / NS];
     }
   }
 }
