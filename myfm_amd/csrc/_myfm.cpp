@@ -1383,7 +1383,10 @@ struct FMTrainer {
     // shorten the iteration (config 3: 335-338 against 338 it/s). What fills the 0.29 ms between two launches is the random
     // stream, not the host: the evaluation of a set's 2.6 M sweep normals runs starved beside the launch on the CUs it leaves free,
     // and the set's single-workgroup draw kernels (0.26 ms in a row) then take the whole gap.
-    static const bool host_hypers = std::getenv("MYFM_AMD_DEVICE_HYPERS") == nullptr;
+    static const bool host_hypers = [] {  // (default since round 6: the device form; MYFM_AMD_DEVICE_HYPERS=0 keeps the host in the loop)
+      const char *e = std::getenv("MYFM_AMD_DEVICE_HYPERS");
+      return e != nullptr && std::atoi(e) == 0;
+    }();
     if (!host_hypers && device_rng && cfg.task_type == TaskType::REGRESSION && cfg.fit_linear && dim_all && Kf > 0 && !comm_active() &&
         mfm_regression_iteration_ready(ctx) == 1) {
       mfm_hyper_prior pr;
@@ -1582,7 +1585,8 @@ struct FMTrainer {
     // kept samples stay on the GPU (device-to-device copy on the training stream, no host transfer inside the loop);
     // MYFM_AMD_HOST_SAMPLES=1 or a store that does not fit: plain host copies as before
     std::shared_ptr<DeviceStore> store;
-    if (cfg.n_kept_samples > 0 && !std::getenv("MYFM_AMD_HOST_SAMPLES") && !comm_active())
+    // (row-sharded fits too: the model is replicated, every rank keeps its own copy of the samples on its device)
+    if (cfg.n_kept_samples > 0 && !std::getenv("MYFM_AMD_HOST_SAMPLES"))
     {
       store = std::make_shared<DeviceStore>((int64_t)dim_all, fm.n_factors);
       if (mfm_store_reserve(store->st, cfg.n_kept_samples) != MFM_OK) store.reset();  // (does not fit: host copies)
@@ -2003,7 +2007,26 @@ PYBIND11_MODULE(_myfm, m) {
                         return r;
                       }));
 
-  m.def("create_train_fm", &create_train_fm, "create and train fm.", py::return_value_policy::move);
+  // The callback is called after every iteration (FMTrainer.hpp:78-83) -- unless the callable carries an integer attribute
+  // `myfm_every` (the estimators set it on the reference's DEFAULT callback, which only acts every `callback_default_freq`
+  // iterations, base.py:179-205): then only on iterations 0, every, 2 every, ... and the last one, and the other iterations never
+  // leave the C++ loop.
+  m.def(
+      "create_train_fm",
+      [](size_t n_factor, Real init_std, const py::object &X, const py::object &relations, const py::object &y, int random_seed,
+         FMLearningConfig &config, py::object cb) {
+        int every = 1;
+        if (py::hasattr(cb, "myfm_every")) every = std::max(1, cb.attr("myfm_every").cast<int>());
+        auto f = cb.cast<std::function<bool(int, FM *, Hyper *, LearningHistory *)>>();
+        if (every == 1) return create_train_fm(n_factor, init_std, X, relations, y, random_seed, config, f);
+        const int n_iter = config.n_iter;
+        return create_train_fm(n_factor, init_std, X, relations, y, random_seed, config,
+                               [f, every, n_iter](int it, FM *fm, Hyper *hy, LearningHistory *h) {
+                                 if (it % every != 0 && it != n_iter - 1) return false;
+                                 return f(it, fm, hy, h);
+                               });
+      },
+      "create and train fm.", py::return_value_policy::move);
 
   // extensions beyond the reference's surface (bench / tests)
   py::class_<GibbsSession>(m, "GibbsSession")

@@ -591,6 +591,7 @@ struct DevBlock {
     dev_view.n_cols = Db;
     dev_view.ell = (int)X.ell_width;
     plan_V.dev_csc = plan_W.dev_csc = (B > 0 && nnz > 0 && !std::getenv("MFM_HOST_LEVELS")) ? &dev_view : nullptr;
+    plan_V.block_plan = plan_W.block_plan = true;
     plan_V.build(Xt, PBlockV::R_W16, PBlockV::R_WG, coop_capacity<PBlockV>());
     lap("plan_V");
     plan_W.build(Xt, PBlockW::R_W16, PBlockW::R_WG, coop_capacity<PBlockW>(), false, false,

@@ -109,6 +109,9 @@ template <bool LDS>
 __device__ __forceinline__ void cs_wait(const void *w, long long target, int *error, bool &dead) {
   if (dead || target <= 0) return;
   unsigned spins = 0;
+  // (the bound is wall-clock time on the constant 100 MHz counter, 20 s: on a GPU shared with other work a partner workgroup may be
+  //  scheduled late -- that is a slow sweep, not a failed one)
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
   for (;;) {
     long long v;
     if (LDS)
@@ -118,7 +121,7 @@ __device__ __forceinline__ void cs_wait(const void *w, long long target, int *er
     if (v >= target) break;
     __builtin_amdgcn_s_sleep(1);
     if ((++spins & 1023u) == 0u) {
-      if (spins > (1u << 23) || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+      if (__builtin_amdgcn_s_memrealtime() - t_start > 2000000000ull || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         dead = true;
         break;
@@ -270,13 +273,15 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
           // both Y wavefronts of the step's pair have staged it (a COUNT of arrivals would not do: a fast wavefront runs ahead)
           if (!dead) {
             unsigned spins = 0;
+            const unsigned long long t_poll = __builtin_amdgcn_s_memrealtime();  // (20 s on the 100 MHz counter, as cs_wait)
             for (;;) {
               const int y0 = __hip_atomic_load(&y_steps[(s & 1) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               const int y1 = __hip_atomic_load(&y_steps[(s & 1) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               if (min(y0, y1) >= s + 1) break;
               __builtin_amdgcn_s_sleep(1);
               if ((++spins & 1023u) == 0u) {
-                if (spins > (1u << 23) || __hip_atomic_load(g.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                if (__builtin_amdgcn_s_memrealtime() - t_poll > 2000000000ull ||
+                    __hip_atomic_load(g.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                   __hip_atomic_store(g.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   dead = true;
                   break;
@@ -513,6 +518,7 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
         // behind the wait for the slots below)
         if (!dead) {
           unsigned spins = 0;
+          const unsigned long long t_poll = __builtin_amdgcn_s_memrealtime();
           for (;;) {
             bool ok = true;
             for (int p = lane; p < NB * 2; p += WAVE)  // (the two S wavefronts of every range that took step s)
@@ -521,7 +527,8 @@ __global__ __launch_bounds__(CS_NT) void k_cs_stream(SweepArgs a, CsArgs g) {
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 1023u) == 0u) {
-              if (spins > (1u << 23) || __hip_atomic_load(g.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+              if (__builtin_amdgcn_s_memrealtime() - t_poll > 2000000000ull ||
+                  __hip_atomic_load(g.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                 __hip_atomic_store(g.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 dead = true;
                 break;

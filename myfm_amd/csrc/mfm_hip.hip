@@ -91,6 +91,13 @@ struct ResidentBudget {
         fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC | O_NOFOLLOW);
       if (fd < 0) {
         why = "the lock file of this GPU's persistent sweeps cannot be opened (" + path + ": " + std::strerror(errno) + ")";
+        static std::atomic<bool> warned{false};
+        if (!warned.exchange(true))  // (once per process: the fit still runs, on the per-factor passes)
+          std::fprintf(stderr,
+                       "myfm_amd: %s -- the persistent sweep is not used (slower per-factor passes instead). Point MFM_LOCK_DIR at a "
+                       "writable directory shared by the users of this GPU, or set MFM_RES_NO_PROCESS_LOCK=1 if no other process "
+                       "runs fits on it.\n",
+                       why.c_str());
         return false;
       }
       if (::flock(fd, LOCK_EX | LOCK_NB) != 0) {

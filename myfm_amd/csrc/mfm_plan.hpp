@@ -1587,6 +1587,7 @@ struct StepPlan {
 
   int tile_bits = 0;     // > 0: scattered levels use the row-tile path with tiles of 2^tile_bits rows
   bool sharded = false;  // row-sharded multi-GPU mode: no chains (every column needs an all-reduce), no coop
+  bool block_plan = false;  // the plan of a relation block: only those launch the streamed chain (run_plan_t, PBlockV / PBlockW)
 
   // Row-sharded mode: the schedule must be the same on every rank, so it is computed on the GLOBAL design
   // by the caller and handed in; here it is only checked against the local rows.
@@ -1673,7 +1674,10 @@ struct StepPlan {
         s.chain.desc.upload(d.data(), d.size());
       }
       // state too large for the LDS chain of any policy: also keep the conflict-batched form
-      const bool stream_allowed = !std::getenv("MFM_NO_CB_STREAM") && !std::getenv("MFM_NO_CB_PERSIST") && !std::getenv("MFM_NO_CHAIN_GRID");
+      // (a main-table plan never launches the stream: building it, and skipping the conflict batches for it, would leave a long main
+      //  chain to the single-workgroup kernel)
+      const bool stream_allowed =
+          block_plan && !std::getenv("MFM_NO_CB_STREAM") && !std::getenv("MFM_NO_CB_PERSIST") && !std::getenv("MFM_NO_CHAIN_GRID");
       auto try_stream = [&]() {
         CsStreamInfo ci;
         s.chain.stream = cs_stream_build(csc, run, &ci);

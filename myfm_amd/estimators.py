@@ -68,11 +68,11 @@ class _ProgressBar:
         if self.bar is not None:
             self.bar.close()
 
-    def update(self, message):
+    def update(self, message, n=1):
         if self.bar is not None:
             if message is not None:
                 self.bar.set_description(message)
-            self.bar.update(1)
+            self.bar.update(n)
 
 
 class MyFMGibbsBase:
@@ -215,7 +215,7 @@ class MyFMGibbsBase:
             X = sps.csr_matrix((val, idx, ptr), shape=X.shape)
             y = np.asarray(y)[perm]
             X_rel = [RelationBlock(r.original_to_block_array[perm], r.data) for r in X_rel]
-            if self.exact_latent_draws and self._task_type != TaskType.REGRESSION:
+            if self._task_type != TaskType.REGRESSION:
                 # the latent draws are made in the CALLER's row order (FMTrainer.hpp:500, OProbitSampler.hpp:243): the sorted
                 # table's row that is the caller's row i
                 inv = np.empty(perm.shape[0], dtype=np.int64)
@@ -228,15 +228,23 @@ class MyFMGibbsBase:
         config_builder.set_exact_latent_draws(self.exact_latent_draws and not os.environ.get("MYFM_AMD_PHILOX_LATENT"))
         config = config_builder.build()
 
-        if callback is None:
+        default_callback = callback is None
+        if default_callback:
             callback = self._default_callback(callback_default_freq, do_test, X_test, X_rel_test, y_test)
 
         with _ProgressBar(n_iter) as bar:
+            seen = [0]
 
             def wrapped(i, fm, hyper, history) -> bool:
                 should_stop, message = callback(i, fm, hyper, history)
-                bar.update(message)
+                bar.update(message, i + 1 - seen[0])
+                seen[0] = i + 1
                 return bool(should_stop)
+
+            if default_callback:
+                # the default callback only acts every `callback_default_freq` iterations (base.py:179-205): the trainer calls into
+                # Python on those (and the last one) only -- the iterations in between never leave the C++ loop
+                wrapped.myfm_every = max(1, int(callback_default_freq))
 
             from . import distributed as _dist
 

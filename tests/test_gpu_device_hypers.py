@@ -1,4 +1,4 @@
-"""mfm_regression_iteration (MYFM_AMD_DEVICE_HYPERS=1): a regression chain on the persistent sweep draws its hyper-parameters on
+"""mfm_regression_iteration (the default; MYFM_AMD_DEVICE_HYPERS=0 switches it off): a regression chain on the persistent sweep draws its hyper-parameters on
 the device and enqueues a whole iteration at once. The chain must not depend on it: the default form (statistics read back, draws
 on the host, mfm_sweep_wV) gives the same kept samples and the same hyper-parameter trajectory, bit for bit."""
 import os
@@ -32,9 +32,9 @@ def _run(tmp_path, name, fit_w0, host):
     env = dict(os.environ)
     env["MFM_RES_MIN_ROWS"] = "0"  # (a small two-field table takes the persistent sweep)
     env.pop("MFM_PLAN_CHECK", None)  # (checker mode keeps update_e on the row-order scorer: no slot-order sums, no device iteration)
-    env.pop("MYFM_AMD_DEVICE_HYPERS", None)
-    if not host:
-        env["MYFM_AMD_DEVICE_HYPERS"] = "1"
+    env.pop("MYFM_AMD_DEVICE_HYPERS", None)  # (the device form is the default)
+    if host:
+        env["MYFM_AMD_DEVICE_HYPERS"] = "0"
     out = str(tmp_path / (name + ".npz"))
     r = subprocess.run([sys.executable, "-c", SCRIPT, out, "1" if fit_w0 else "0"], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=600)
