@@ -34,6 +34,7 @@ constexpr int LAT_RB = 1024;     // rows per block of the row pass
 constexpr int LAT_TILE = 256;    // walkers per workgroup of k_lat_round
 constexpr int LAT_RES_NT = 512;  // threads (= walkers at most) of the resident kernel
 constexpr int LAT_QW = 4;        // doubles per quad record of the flows
+constexpr int LAT_RPAD = 16;     // records after the last row that accept nothing (a walker requests up to 8 consecutive records)
 
 struct LatStatus {
   int32_t fail;        // first failure code (0: none)
@@ -224,8 +225,8 @@ __global__ __launch_bounds__(256) void k_lat_rows(const int32_t *__restrict__ ro
       mf[i] = (float)m;
       sm += m;
       sv += (1.0 - p) * m * m;
-    } else if (i == n) {
-      rec[i] = wrec[i] = make_double2(__builtin_inf(), __builtin_nan(""));  // the row after the last one accepts nothing
+    } else if (i < n + LAT_RPAD) {
+      rec[i] = wrec[i] = make_double2(__builtin_inf(), __builtin_nan(""));  // the rows after the last one accept nothing
     }
   }
   for (int d = 32; d > 0; d >>= 1) {
@@ -556,6 +557,12 @@ __device__ __forceinline__ lat_d2v lat_asm_load(const double2 *p) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
+template <int OFF>
+__device__ __forceinline__ lat_d2v lat_asm_load_off(const double2 *p) {  // (the 16-byte record at byte offset OFF: same address register)
+  lat_d2v v;
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF) : "memory");
+  return v;
+}
 
 // a lane's walker and its row supply
 struct LatLane {
@@ -581,7 +588,6 @@ __device__ __forceinline__ void lat_walk_wave(LatLane &L, double2 *ring, double 
                                               const double2 *__restrict__ wrec, int64_t n, const double *__restrict__ qt, int64_t jstart,
                                               int steps, const LatCtx &cx) {
   constexpr int G = RING / 2, QS = LAT_QS;
-  const double2 *rec_end = wrec + n;  // the record after the last row: accepts nothing
   for (int seg = 0; seg < steps; seg += QS) {
     const int S = min(QS, steps - seg);
     const int64_t j0 = jstart + seg;
@@ -597,13 +603,25 @@ __device__ __forceinline__ void lat_walk_wave(LatLane &L, double2 *ring, double 
     }
     lat_d2v qnext = lat_asm_load(qsrc + QS * LAT_QW / 2);  // (the table is padded: the last look-ahead stays inside it)
     for (int k0 = 0; k0 < S; k0 += G) {
-      // rows the ring will miss after this group: hi .. t + RING (it holds rows up to hi - 1 >= t + G)
+      // rows the ring will miss after this group: hi .. t + RING (it holds rows up to hi - 1 >= t + G). All G records from hi on are
+      // requested -- one address, consecutive 16-byte records (the walker records are padded by LAT_RPAD rows that accept nothing) --,
+      // the first m of them are stored
       const int m = L.t + RING + 1 - L.hi;  // 0 .. G
+      const double2 *src = wrec + min((int64_t)L.hi, n);
       lat_d2v l[G];
-#pragma unroll
-      for (int k = 0; k < G; k++) l[k] = lat_asm_load(m > k ? wrec + min((int64_t)L.hi + k, n) : rec_end);
-      const int ke = min(G, S - k0);
-      for (int k = 0; k < ke; k++) {
+      l[0] = lat_asm_load_off<0>(src);
+      l[1] = lat_asm_load_off<16>(src);
+      if (G > 2) {
+        l[2 % G] = lat_asm_load_off<32>(src);
+        l[3 % G] = lat_asm_load_off<48>(src);
+      }
+      if (G > 4) {
+        l[4 % G] = lat_asm_load_off<64>(src);
+        l[5 % G] = lat_asm_load_off<80>(src);
+        l[6 % G] = lat_asm_load_off<96>(src);
+        l[7 % G] = lat_asm_load_off<112>(src);
+      }
+      auto one_step = [&](int k) {
         const double2 *qp = (const double2 *)(strip + (k0 + k) * LAT_QW);
         const double2 qa = qp[0], qb = qp[1];
         const LatQ q{qa.x, qa.y, qb.x, qb.y};
@@ -612,6 +630,13 @@ __device__ __forceinline__ void lat_walk_wave(LatLane &L, double2 *ring, double 
         L.t += acc ? 1 : 0;
         L.r.x = acc ? nx.x : L.r.x;
         L.r.y = acc ? nx.y : L.r.y;
+      };
+      if (S == QS) {  // (the usual segment: the group's steps as one basic block)
+#pragma unroll
+        for (int k = 0; k < G; k++) one_step(k);
+      } else {
+        const int ke = min(G, S - k0);
+        for (int k = 0; k < ke; k++) one_step(k);
       }
       if (G == 4)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(qnext) : : "memory");
@@ -695,13 +720,20 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
   const int64_t off = list_off[c];
   int64_t sp = done0 >= subq ? snap_pos[c] : snap_off[c];
   const int64_t sp_end = snap_off[c + 1];
-  int wl = max(0, min(64, nl - wid * 64));
+  // the walkers fill the waves one after the other (wave w: walkers [64 w, 64 w + wl)): the kernel is bound by instruction issue -- eight
+  // quarter-filled waves were 20 % slower than two full ones (HISTORY.md, round 6)
+  auto deal = [&](int total, int &w0) {
+    w0 = wid * 64;
+    return max(0, min(64, total - wid * 64));
+  };
+  int w0 = 0;
+  int wl = deal(nl, w0);
   LatLane L;
   L.t = (int32_t)n;
   int32_t f = 0;
   if (lane < wl) {
-    L.t = scur[off + tid];
-    f = sfin[off + tid];
+    L.t = scur[off + w0 + lane];
+    f = sfin[off + w0 + lane];
   }
   lat_prime<NT, RING>(L, ring, tid, wrec, n);
   double *strip0 = strips + (size_t)wid * (2 * QS * LAT_QW);
@@ -785,9 +817,9 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
       sp += tot2;
       __syncthreads();
       nl = tot2;
-      wl = max(0, min(64, nl - wid * 64));
-      L.t = lane < wl ? s_t1[tid] : (int32_t)n;
-      f = lane < wl ? s_f1[tid] : 0;
+      wl = deal(nl, w0);
+      L.t = lane < wl ? s_t1[w0 + lane] : (int32_t)n;
+      f = lane < wl ? s_f1[w0 + lane] : 0;
       __syncthreads();
       lat_prime<NT, RING>(L, ring, tid, wrec, n);
     }
@@ -960,10 +992,10 @@ void LatentEngine::prepare(const LatentJob &job, LatentPrep *prep) {
   m.ksig_retry = std::max(m.ksig, env_double("MFM_LAT_KSIGMA_RETRY", 6.5));
   const int64_t n = job.n, nb = (n + LAT_RB - 1) / LAT_RB;
   // (the block that holds row n writes the record of "the row after the last one": one more block when n fills its blocks)
-  const int64_t grid = (n + 1 + LAT_RB - 1) / LAT_RB;
-  Impl::ensure(m.rec, (size_t)n + 1);
-  Impl::ensure(m.wrec, (size_t)n + 1);
-  Impl::ensure(m.mf, (size_t)n + 1);
+  const int64_t grid = (n + LAT_RPAD + LAT_RB - 1) / LAT_RB;
+  Impl::ensure(m.rec, (size_t)n + LAT_RPAD);
+  Impl::ensure(m.wrec, (size_t)n + LAT_RPAD);
+  Impl::ensure(m.mf, (size_t)n + LAT_RPAD);
   Impl::ensure(m.blkM, (size_t)grid);
   Impl::ensure(m.blkV, (size_t)grid);
   Impl::ensure(m.PM, (size_t)nb + 1);
