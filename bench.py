@@ -166,7 +166,7 @@ def other_configs(budget_s):
             ("configs[4] at scale 0.1", ["--config", "5", "--scale", "0.1", "--steps", "6", "--warmup", "2", "--cpu-seconds", "1"]),
             # ... and at its own size, N = 50 M rows (one CPU-oracle iteration there is ~130 s: profiles/r03_e_bench_config5_full_cpu.json)
             # -- the default latent mode ("exact": the reference's own stream, draw for draw) and the per-row Philox streams
-            ("configs[4] at full size", ["--config", "5", "--scale", "1.0", "--steps", "5", "--warmup", "2", "--cpu-seconds", "0"]),
+            ("configs[4] at full size", ["--config", "5", "--scale", "1.0", "--steps", "5", "--warmup", "2", "--cpu-seconds", "0", "--kernel-timing"]),
             ("configs[4] at full size, latent=philox", ["--config", "5", "--scale", "1.0", "--steps", "5", "--warmup", "2", "--cpu-seconds", "0",
                                                         "--latent", "philox"]),
             # the task types BASELINE.md 1 quotes next to regression (examples/ml-100k.ipynb: classification 48.85 it/s, ordered probit
@@ -186,8 +186,10 @@ def other_configs(budget_s):
             out[name] = {"skipped": "time budget"}
             continue
         t0 = time.time()
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--fit-iters", "0", "--no-other-configs",
-                            "--no-kernel-timing"] + args, capture_output=True, text=True, cwd=ROOT)
+        timing_args = [] if "--kernel-timing" in args else ["--no-kernel-timing"]
+        args = [x for x in args if x != "--kernel-timing"]
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--fit-iters", "0", "--no-other-configs"] + timing_args + args,
+                           capture_output=True, text=True, cwd=ROOT)
         line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
         if r.returncode != 0 or not line:
             out[name] = {"error": (r.stderr or r.stdout)[-300:]}
@@ -198,6 +200,10 @@ def other_configs(budget_s):
                      "it_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                      "cpu_it_per_s": cpu.get("value"), "cpu_iterations": cpu.get("iterations"), "cpu_pinned": cpu.get("pinned_to_one_core"),
                      "setup_s": d["config"]["setup_s"], "wall_s": round(time.time() - t0, 1)}
+        if d.get("roofline"):  # (the legs run with kernel timing: dominant class, time per chain column, the passes' HBM fractions)
+            rf = d["roofline"]
+            out[name]["roofline"] = {k: rf.get(k) for k in ("kernel", "avg_launch_us", "achieved", "frac", "unit", "kernel_ms_per_step",
+                                                            "chain_us_per_column", "chain_columns_per_step", "by_kernel_hbm")}
     return out
 
 
@@ -558,7 +564,18 @@ def main():
             "kernel_ms_per_step": round(sum(v[0] for v in breakdown.values()), 3),
             "by_kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])},
             "by_kernel_note": "per-class times from 3 diagnostic steps with every launch bracketed (outside the timed region)",
+            # every class on its own algorithmic bytes (the same accounting as `achieved`), from the diagnostic steps
+            "by_kernel_hbm": {k: {"ms_per_step": round(v[0], 3), "launches_per_step": round(v[1], 1),
+                                  "alg_gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 and v[2] > 0 else None,
+                                  "frac": round(v[2] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[0] > 0 and v[2] > 0 else None}
+                              for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][0])[:8]},
         }
+        if blocks and "block_sweep" in breakdown:
+            # the block-feature chains are sequential in the column order (FMTrainer.hpp:276-302, :419-470): their figure of merit is time
+            # per column, not bandwidth
+            n_cols_iter = sum(int(B.shape[1]) for _, B in blocks) * (K + 1)
+            roofline["chain_us_per_column"] = round(breakdown["block_sweep"][0] * 1e3 / max(n_cols_iter, 1), 3)
+            roofline["chain_columns_per_step"] = n_cols_iter
         # second bound of the same kernel: VALU instruction issue. One wave-instruction per CU and clock is the machine's rate
         # (4 SIMDs x 16 lanes, wave64); the instruction count per launch comes from this round's committed SQ-counter pass of the
         # same workload (rocprofv3 --pmc SQ_INSTS_VALU ..., profiles/r04_sq_counters_config3.*), the launch time is live
@@ -664,11 +681,29 @@ def main():
         out["speedup_vs_cpu_baseline"] = round(it_per_s / cpu["value"], 1)
     if weak:
         out["weak_scaling"] = weak
+        # (top level, so that a first N > 1 curve reads without digging: `value` is the STRONG-scaling rate of one chain over the same
+        #  10 M rows; the weak-scaling leg is one chain over N x 10 M rows)
+        out["weak_scaling_it_per_s"] = weak["it_per_s"]
+        out["weak_scaling_row_iterations_per_s"] = weak["row_iterations_per_s"]
     if a.config == 3 and world == 1 and not a.no_other_configs and not force_sharded:
         out["other_configs"] = other_configs(budget_s=300.0)
     if sharded:
         out["config"]["allreduce_calls_per_step"] = round(calls / a.steps, 1)
         out["config"]["allreduce_bytes_per_step"] = round(8.0 * doubles / a.steps)
+        out["allreduce_calls_per_step"] = out["config"]["allreduce_calls_per_step"]
+        out["allreduce_bytes_per_step"] = out["config"]["allreduce_bytes_per_step"]
+        # what DESIGN.md 7 budgets for this run (NO multi-GPU curve had been measured when it was written: times from 1-GPU phase stamps,
+        # xGMI hop assumed 3-5 us) -- printed beside the measurement so that a first curve explains itself
+        if a.config == 3 and not blocks:
+            budget = {1: (2.95, 2.95), 2: (2.4, 2.6), 4: (2.0, 2.15), 8: (1.7, 1.9)} if peer_live else \
+                     {1: (2.95, 2.95), 2: (2.2, 2.4), 4: (2.0, 2.2), 8: (1.9, 2.1)}
+            lo_ms, hi_ms = budget.get(world, (None, None))
+            out["design_budget"] = {
+                "source": "DESIGN.md section 7, config 3 strong scaling (%s)" % ("in-launch exchange" if peer_live else "per-factor passes, one all-reduce per factor"),
+                "expected_ms_per_step": [lo_ms, hi_ms], "expected_it_per_s": [round(1e3 / hi_ms, 1), round(1e3 / lo_ms, 1)] if lo_ms else None,
+                "measured_ms_per_step": round(elapsed / a.steps * 1e3, 3),
+                "note": "strong scaling of ONE latency-bound chain is poor by design (1.3-1.8x at 8 GPUs): N GPUs are better spent on N "
+                        "chains; sharding is what makes tables beyond one GPU possible -- see weak_scaling_it_per_s"}
         out["config"]["per_rank"] = per_rank  # [{rank, rows, allreduce_calls_per_step, allreduce_bytes_per_step}]: every rank's own count
         out["config"]["rows_this_rank"] = hi - lo
         # evidence that the collective spans the ranks: ncclCommCount of the communicator libmyfm_hip.so opened itself, and the

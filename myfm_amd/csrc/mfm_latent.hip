@@ -30,7 +30,7 @@ namespace mfm {
 
 namespace {
 
-constexpr int LAT_RB = 1024;     // rows per block of the row pass
+constexpr int LAT_RB = 256;      // rows per block of the row pass (its sums anchor the windows: a search ends with a scan of <= LAT_RB rows)
 constexpr int LAT_TILE = 256;    // walkers per workgroup of k_lat_round
 constexpr int LAT_RES_NT = 512;  // threads (= walkers at most) of the resident kernel
 constexpr int LAT_QW = 4;        // doubles per quad record of the flows
@@ -827,31 +827,66 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
 }
 
 // ---- resolution: T(c + 1) = map_c(T(c)) -------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lat_resolve(int C, int nsub, int n, const int32_t *__restrict__ win_lo,
-                                                     const int32_t *__restrict__ win_hi, const int2 *__restrict__ snap,
-                                                     const int64_t *__restrict__ snap_idx, const int32_t *__restrict__ snap_cnt,
-                                                     int32_t *__restrict__ Tc, LatStatus *__restrict__ st) {
+// One workgroup walks the chunks in order. A chunk's final list (a few dozen ... a few hundred entries) is requested one chunk ahead
+// and searched in LDS: the serial loop never waits for global memory (a dependent global round trip per chunk and level made this
+// launch the longest of the draw after the flows: ~8 us x 511 chunks).
+constexpr int LAT_RESOLVE_NT = 512;
+__global__ __launch_bounds__(LAT_RESOLVE_NT) void k_lat_resolve(int C, int nsub, int n, const int32_t *__restrict__ win_lo,
+                                                                const int32_t *__restrict__ win_hi, const int2 *__restrict__ snap,
+                                                                const int64_t *__restrict__ snap_idx, const int32_t *__restrict__ snap_cnt,
+                                                                int32_t *__restrict__ Tc, LatStatus *__restrict__ st) {
+  constexpr int NT = LAT_RESOLVE_NT;
+  __shared__ int s_fin[NT + 1];
   __shared__ int s_T;
   const int tid = threadIdx.x;
   if (st->fail != 0) return;
+  auto meta = [&](int c, int64_t &sp, int &cnt, int &lo, int &hi) {
+    sp = snap_idx[(size_t)c * nsub + nsub - 1];
+    cnt = snap_cnt[(size_t)c * nsub + nsub - 1];
+    lo = win_lo[c];
+    hi = win_hi[c];
+  };
+  int64_t sp, sp_n = 0;
+  int cnt, lo, hi, cnt_n = 0, lo_n = 0, hi_n = 0;
+  meta(0, sp, cnt, lo, hi);
+  int2 e = tid < cnt ? snap[sp + tid] : make_int2(0x7fffffff, 0), e_n = e;
+  if (C > 1) meta(1, sp_n, cnt_n, lo_n, hi_n);
   int T = 0;
   for (int c = 0; c < C; c++) {
+    // the next chunk's list and the metadata of the one after it: in flight while this chunk is searched
+    if (c + 1 < C) e_n = tid < cnt_n ? snap[sp_n + tid] : make_int2(0x7fffffff, 0);
+    int64_t sp_nn = 0;
+    int cnt_nn = 0, lo_nn = 0, hi_nn = 0;
+    if (c + 2 < C) meta(c + 2, sp_nn, cnt_nn, lo_nn, hi_nn);
     if (tid == 0) Tc[c] = T;
-    if (T < win_lo[c] || T > win_hi[c]) {
+    if (T < lo || T > hi) {
       if (tid == 0) lat_fail(st, 1, c);
       return;
     }
-    const int64_t sp = snap_idx[(size_t)c * nsub + nsub - 1];
-    const int cnt = snap_cnt[(size_t)c * nsub + nsub - 1];
-    for (int i = tid; i < cnt; i += 256) {
-      const int2 e = snap[sp + i];
-      const bool last = i + 1 == cnt;
-      const int fn = last ? 0x7fffffff : snap[sp + i + 1].x;
-      if (e.x <= T && (last || fn > T)) s_T = e.y;
+    if (cnt <= NT) {
+      s_fin[tid] = e.x;
+      if (tid == 0) s_fin[NT] = 0x7fffffff;
+      __syncthreads();
+      if (tid < cnt && e.x <= T && (tid + 1 == cnt || s_fin[tid + 1] > T)) s_T = e.y;
+    } else {  // (a list longer than the workgroup: straight from global memory)
+      for (int i = tid; i < cnt; i += NT) {
+        const int2 g = snap[sp + i];
+        const bool last = i + 1 == cnt;
+        if (g.x <= T && (last || snap[sp + i + 1].x > T)) s_T = g.y;
+      }
     }
     __syncthreads();
     T = s_T;
     __syncthreads();
+    e = e_n;
+    sp = sp_n;
+    cnt = cnt_n;
+    lo = lo_n;
+    hi = hi_n;
+    sp_n = sp_nn;
+    cnt_n = cnt_nn;
+    lo_n = lo_nn;
+    hi_n = hi_nn;
   }
   if (tid == 0) {
     Tc[C] = T;
@@ -1020,10 +1055,12 @@ void LatentEngine::prepare(const LatentJob &job, LatentPrep *prep) {
   if (!(cap == cap) || cap > 64.0 * (double)n + 1e6)
     throw Error(MFM_ERR_RUNTIME, "exact latent draws: a score is not finite, or a truncation region has (almost) no mass");
   // geometry: C chunks of Lq quads, sub-chunks of subq quads
-  m.subq = std::max(64, env_int("MFM_LAT_SUBQ", 512) / 64 * 64);
   const int target_chunks = std::max(1, env_int("MFM_LAT_CHUNKS", 512));
   int64_t Lq = ((int64_t)cap + target_chunks - 1) / target_chunks;
   Lq = std::max<int64_t>(Lq, env_int("MFM_LAT_MIN_LQ", 1024));
+  // sub-chunks of 512 quads; short chunks (small tables) 128: the final pass walks a sub-chunk sequentially, ~1.5 us per quad when
+  // nothing else hides the latency
+  m.subq = std::max(64, env_int("MFM_LAT_SUBQ", Lq >= 8192 ? 512 : 128) / 64 * 64);
   Lq = (Lq + m.subq - 1) / m.subq * m.subq;
   if (Lq > 0x3fffffff) throw Error(MFM_ERR_RUNTIME, "exact latent draws: chunk too long");
   m.Lq = Lq;
@@ -1151,7 +1188,7 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
                          m.snap_cnt.p, m.status.p);
     }
     if (timing && attempts == 1) MFM_HIP_CHECK(hipEventRecord(ev[2], s));
-    hipLaunchKernelGGL(k_lat_resolve, dim3(1), dim3(256), 0, s, C, nsub, (int)n, m.win_lo.p, m.win_hi.p, m.snap.p, m.snap_idx.p,
+    hipLaunchKernelGGL(k_lat_resolve, dim3(1), dim3(LAT_RESOLVE_NT), 0, s, C, nsub, (int)n, m.win_lo.p, m.win_hi.p, m.snap.p, m.snap_idx.p,
                        m.snap_cnt.p, m.Tc.p, m.status.p);
     hipLaunchKernelGGL(k_lat_final, dim3((unsigned)(((int64_t)C * nsub + 63) / 64)), dim3(64), 0, s, m.rec.p, m.wrec.p, m.qt.p, m.qx.p,
                        job.raw, job.mask, job.state, n, Lq, subq, nsub, C, m.Tc.p, m.snap.p, m.snap_idx.p, m.snap_cnt.p, job.rows, job.eq,
@@ -1183,7 +1220,7 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
                  "(largest list %lld), %d attempt(s), status %d (chunk %d) | first attempt: quads %.3f ms, windows+flows %.3f ms, "
                  "resolve+final %.3f ms\n",
                  (long long)n, (long long)S.quads_used, (long long)prep.q_cap, C, (long long)Lq, subq, (long long)S.walkers, rounds_done,
-                 handover, (long long)max_live, attempts, S.status, m.h_status->fail_chunk, a, b, c2);
+                 handover, (long long)max_live, attempts, S.status, S.status ? m.h_status->fail_chunk : -1, a, b, c2);
     for (auto &e : ev) (void)hipEventDestroy(e);
   }
   if (stats) *stats = S;
