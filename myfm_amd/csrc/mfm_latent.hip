@@ -7,7 +7,7 @@
 //   k_lat_quads    per quad j: (u1, -log u1 - 1, log u2, the larger of the polar pair's two normals) for the decisions and
 //                  (first normal, -log u1) for the accepted values, from the ring of MT19937 outputs
 //   k_lat_windows  per chunk c of Lq quads: the rows [lo, hi] that can be in service at quad c Lq (mean +- k sigma)
-//   k_lat_round    every live walker of every chunk walks R quads: t += A(t, j)
+//   k_lat_round_ring  every live walker of every chunk walks R quads: t += A(t, j)
 //   k_lat_compact  per chunk: walkers that met (equal t, they are sorted) are merged; at sub-chunk boundaries the list
 //                  (first entering row of the merged range, current row) is kept as a snapshot
 //   k_lat_resident the same two steps for the rest of the chunk in one launch once a chunk's walkers fit a workgroup
@@ -31,7 +31,7 @@ namespace mfm {
 namespace {
 
 constexpr int LAT_RB = 256;      // rows per block of the row pass (its sums anchor the windows: a search ends with a scan of <= LAT_RB rows)
-constexpr int LAT_TILE = 256;    // walkers per workgroup of k_lat_round
+constexpr int LAT_TILE = 256;    // walkers per workgroup of k_lat_round_ring
 constexpr int LAT_RES_NT = 512;  // threads (= walkers at most) of the resident kernel
 constexpr int LAT_QW = 4;        // doubles per quad record of the flows
 constexpr int LAT_RPAD = 16;     // records after the last row that accept nothing (a walker requests up to 8 consecutive records)
@@ -403,71 +403,8 @@ __global__ __launch_bounds__(1024) void k_lat_windows(const double *__restrict__
   }
 }
 
-// ---- a walker's R steps -------------------------------------------------------------------------------
-// The quads of a round are the same for every walker of the chunk (wave-uniform addresses: scalar loads); they are fetched four
-// steps ahead of their use. A walker keeps the records of the next three rows in registers: the load issued when a row is accepted
-// is not needed before the third acceptance after it.
-struct LatWalker {
-  int32_t t;
-  double2 r, n1, n2, n3;  // walker records of rows t, t + 1, t + 2, t + 3
-};
-__device__ __forceinline__ void lat_walker_load(LatWalker &k, const double2 *__restrict__ wrec, int64_t n) {
-  k.r = wrec[k.t];
-  k.n1 = wrec[min((int64_t)k.t + 1, n)];
-  k.n2 = wrec[min((int64_t)k.t + 2, n)];
-  k.n3 = wrec[min((int64_t)k.t + 3, n)];
-}
-__device__ __forceinline__ void lat_step(LatWalker &k, const double2 *__restrict__ wrec, int64_t n, const LatQ &q, int64_t j,
-                                         const LatCtx &cx) {
-  if (lat_accept(cx, k.t, k.r.x, k.r.y, q, j)) {
-    k.t++;
-    k.r = k.n1;
-    k.n1 = k.n2;
-    k.n2 = k.n3;
-    k.n3 = wrec[min((int64_t)k.t + 3, n)];
-  }
-}
-// (the quad tables are padded by LAT_QPAD records: the look-ahead of the last round reads past the last quad)
+// (the quad tables are padded by LAT_QPAD records: the look-ahead of the last segment reads past the last quad)
 constexpr int LAT_QPAD = 40;
-__device__ __forceinline__ void lat_walk(LatWalker &k, const double2 *__restrict__ wrec, int64_t n, const double *__restrict__ qt,
-                                         int64_t j0, int R, const LatCtx &cx) {
-  LatQ q0 = lat_load_quad(qt, j0), q1 = lat_load_quad(qt, j0 + 1), q2 = lat_load_quad(qt, j0 + 2), q3 = lat_load_quad(qt, j0 + 3);
-  int s = 0;
-  for (; s + 4 <= R; s += 4) {
-    const LatQ a0 = lat_load_quad(qt, j0 + s + 4), a1 = lat_load_quad(qt, j0 + s + 5), a2 = lat_load_quad(qt, j0 + s + 6),
-               a3 = lat_load_quad(qt, j0 + s + 7);
-    lat_step(k, wrec, n, q0, j0 + s, cx);
-    lat_step(k, wrec, n, q1, j0 + s + 1, cx);
-    lat_step(k, wrec, n, q2, j0 + s + 2, cx);
-    lat_step(k, wrec, n, q3, j0 + s + 3, cx);
-    q0 = a0;
-    q1 = a1;
-    q2 = a2;
-    q3 = a3;
-  }
-  if (s < R) lat_step(k, wrec, n, q0, j0 + s, cx);
-  if (s + 1 < R) lat_step(k, wrec, n, q1, j0 + s + 1, cx);
-  if (s + 2 < R) lat_step(k, wrec, n, q2, j0 + s + 2, cx);
-}
-
-// every live walker of every chunk: R quads from quad c Lq + done. grid (tiles, C)
-__global__ __launch_bounds__(LAT_TILE) void k_lat_round(const double2 *__restrict__ rec, const double2 *__restrict__ wrec,
-                                                        const double *__restrict__ qt, const double2 *__restrict__ qx,
-                                                        const uint32_t *__restrict__ raw, uint64_t mask,
-                                                        const RngState *__restrict__ rs, int64_t n, int64_t Lq, int done, int R,
-                                                        const int32_t *__restrict__ win_lo, const int32_t *__restrict__ live,
-                                                        const int64_t *__restrict__ list_off, int32_t *cur, int first) {
-  const int c = blockIdx.y;
-  const int i = blockIdx.x * LAT_TILE + threadIdx.x;
-  if (i >= live[c]) return;
-  const LatCtx cx{rec, qx, raw, mask, rs->p_cons};
-  LatWalker k;
-  int32_t *pc = cur + list_off[c] + i;
-  k.t = first ? win_lo[c] + i : *pc;
-  lat_walker_load(k, wrec, n);
-  lat_walk(k, wrec, n, qt, (int64_t)c * Lq + done, R, cx);
-  *pc = k.t;
-}
 
 // per chunk: merge the walkers that met, compact (src -> dst), optionally keep the list as snapshot `snap_k`
 __global__ __launch_bounds__(1024) void k_lat_compact(const int32_t *__restrict__ win_lo, int32_t *__restrict__ live,
@@ -925,31 +862,52 @@ __global__ __launch_bounds__(64) void k_lat_final(const double2 *__restrict__ re
   const LatCtx cx{rec, qx, raw, mask, rs->p_cons};
   const int64_t j0 = (int64_t)c * Lq + (int64_t)ks * subq;
   double2 r = wrec[t];
-  LatQ q = lat_load_quad(qt, j0);
-  for (int s = 0; s < subq; s++) {
-    const LatQ qn = lat_load_quad(qt, j0 + s + 1);  // (one step ahead; the tables are padded)
-    if (lat_accept(cx, t, r.x, r.y, q, j0 + s)) {
-      const double2 ab = rec[t], x = qx[j0 + s];
-      const double val = lat_value(ab.x, ab.y, q, x.x, x.y);
-      const int64_t row = rows ? (int64_t)rows[t] : (int64_t)t;
-      const double pred = eq[row].x;
-      // the side of a one-sided draw (right truncation = -left(-mu)); z = 1 * draw + score, e = score - z
-      int sgn = 1;
-      if (n_class == 0)
-        sgn = y[row] > 0 ? 1 : -1;
-      else if ((int)y[row] == 0)
-        sgn = -1;
-      const double draw = sgn > 0 ? val : -val;
-      const double z = 1.0 * draw + pred;
-      eq[row].x = pred - z;
-      t++;
-      if (t >= n) {
-        st->end_quads = j0 + s + 1;
-        return;
-      }
-      r = wrec[t];
+  // four quads at a time: a thread's 128 bytes of decisions' records are one cache line (its neighbours work 16 KB away: a line fetched
+  // for one step would be gone from the caches before the next), the next four are requested before these are worked on
+  const double4 *qt4 = (const double4 *)qt;
+  double4 qc[4], qn[4];
+  double2 xc[4], xn[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    qc[k] = qt4[j0 + k];
+    xc[k] = qx[j0 + k];
+  }
+  for (int s = 0; s < subq; s += 4) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {  // (the tables are padded: the look-ahead of the last block stays inside them)
+      qn[k] = qt4[j0 + s + 4 + k];
+      xn[k] = qx[j0 + s + 4 + k];
     }
-    q = qn;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const LatQ q{qc[k].x, qc[k].y, qc[k].z, qc[k].w};
+      if (lat_accept(cx, t, r.x, r.y, q, j0 + s + k)) {
+        const double2 ab = rec[t];
+        const double val = lat_value(ab.x, ab.y, q, xc[k].x, xc[k].y);
+        const int64_t row = rows ? (int64_t)rows[t] : (int64_t)t;
+        const double pred = eq[row].x;
+        // the side of a one-sided draw (right truncation = -left(-mu)); z = 1 * draw + score, e = score - z
+        int sgn = 1;
+        if (n_class == 0)
+          sgn = y[row] > 0 ? 1 : -1;
+        else if ((int)y[row] == 0)
+          sgn = -1;
+        const double draw = sgn > 0 ? val : -val;
+        const double z = 1.0 * draw + pred;
+        eq[row].x = pred - z;
+        t++;
+        if (t >= n) {
+          st->end_quads = j0 + s + k + 1;
+          return;
+        }
+        r = wrec[t];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      qc[k] = qn[k];
+      xc[k] = xn[k];
+    }
   }
 }
 
@@ -1133,19 +1091,14 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
     max_live = Wmax;
     int Rr = R;
     const bool no_resident = std::getenv("MFM_LAT_NO_RESIDENT") != nullptr;
-    const bool plain_rounds = std::getenv("MFM_LAT_PLAIN_ROUNDS") != nullptr;
-    const int res_nt = env_int("MFM_LAT_RES_NT", LAT_RES_NT) >= 512 ? 512 : 256;
-    const int ring = env_int("MFM_LAT_RING", 8) >= 16 ? 16 : 8;
+    constexpr int res_nt = LAT_RES_NT;
     while (done < Lq) {
       if (!first && max_live <= res_nt && !no_resident) break;
       if (round >= LAT_MAX_ROUNDS) throw Error(MFM_ERR_RUNTIME, "exact latent draws: too many rounds");
       int step = (int)std::min<int64_t>(Rr, Lq - done);
       if (done % subq + step > subq) step = subq - done % subq;
       const unsigned tiles = (unsigned)((max_live + LAT_TILE - 1) / LAT_TILE);
-      if (plain_rounds) {
-        hipLaunchKernelGGL(k_lat_round, dim3(tiles, (unsigned)C), dim3(LAT_TILE), 0, s, m.rec.p, m.wrec.p, m.qt.p, m.qx.p, job.raw, job.mask,
-                           job.state, n, Lq, done, step, m.win_lo.p, m.live.p, m.list_off.p, sc, first ? 1 : 0);
-      } else {
+      {
         const size_t lds_r = (size_t)8 * LAT_TILE * sizeof(double2) + (size_t)(LAT_TILE / 64) * 2 * LAT_QS * LAT_QW * sizeof(double);
         hipLaunchKernelGGL((k_lat_round_ring<LAT_TILE, 8>), dim3(tiles, (unsigned)C), dim3(LAT_TILE), lds_r, s, m.rec.p, m.wrec.p, m.qt.p,
                            m.qx.p, job.raw, job.mask, job.state, n, Lq, done, step, m.win_lo.p, m.live.p, m.list_off.p, sc, first ? 1 : 0);
@@ -1170,22 +1123,18 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
     rounds_done = round;
     handover = done;
     if (done < Lq) {
-      const size_t lds = (size_t)ring * res_nt * sizeof(double2) + (size_t)(2 * res_nt + 16) * sizeof(int) +
+      const size_t lds = (size_t)8 * res_nt * sizeof(double2) + (size_t)(2 * res_nt + 16) * sizeof(int) +
                          (size_t)(res_nt / 64) * 2 * LAT_QS * LAT_QW * sizeof(double);
       {
         static DeviceOnce raised;
         if (raised.need()) {
-          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_lat_resident<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_lat_resident<512, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_lat_resident<256, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_lat_resident<LAT_RES_NT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
           raised.mark();
         }
       }
-      auto kern = res_nt == 512 ? (ring == 16 ? k_lat_resident<512, 16> : k_lat_resident<512, 8>)
-                                : (ring == 16 ? k_lat_resident<256, 16> : k_lat_resident<256, 8>);
-      hipLaunchKernelGGL(kern, dim3((unsigned)C), dim3(res_nt), lds, s, m.rec.p, m.wrec.p, m.qt.p, m.qx.p, job.raw, job.mask, job.state, n,
-                         Lq, done, R, subq, nsub, m.live.p, m.list_off.p, sc, sf, m.snap_off.p, m.snap_pos.p, m.snap.p, m.snap_idx.p,
-                         m.snap_cnt.p, m.status.p);
+      hipLaunchKernelGGL((k_lat_resident<LAT_RES_NT, 8>), dim3((unsigned)C), dim3(res_nt), lds, s, m.rec.p, m.wrec.p, m.qt.p, m.qx.p, job.raw,
+                         job.mask, job.state, n, Lq, done, R, subq, nsub, m.live.p, m.list_off.p, sc, sf, m.snap_off.p, m.snap_pos.p,
+                         m.snap.p, m.snap_idx.p, m.snap_cnt.p, m.status.p);
     }
     if (timing && attempts == 1) MFM_HIP_CHECK(hipEventRecord(ev[2], s));
     hipLaunchKernelGGL(k_lat_resolve, dim3(1), dim3(LAT_RESOLVE_NT), 0, s, C, nsub, (int)n, m.win_lo.p, m.win_hi.p, m.snap.p, m.snap_idx.p,
