@@ -501,30 +501,39 @@ __device__ __forceinline__ lat_d2v lat_asm_load_off(const double2 *p) {  // (the
   return v;
 }
 
-// a lane's walker and its row supply
+// a walker and its row supply
 struct LatLane {
   int32_t t, hi;  // current row; rows below hi are in the ring or requested
   double2 r;      // walker record of row t
 };
+// A lane carries WW walkers (consecutive ones of the sorted list): their steps are independent dependency chains the SIMD can
+// interleave, and the step's quad is read once for all of them. Walker w of thread tid owns column tid * WW + w of the ring
+// ([RING][NT * WW] records).
 // (re)start of a lane's row supply: the current record and the ring's rows t + 1 .. t + RING by plain loads
-template <int NT, int RING>
-__device__ __forceinline__ void lat_prime(LatLane &L, double2 *ring, int tid, const double2 *__restrict__ wrec, int64_t n) {
-  L.r = wrec[L.t];
+template <int NT, int RING, int WW>
+__device__ __forceinline__ void lat_prime(LatLane (&L)[WW], double2 *ring, int tid, const double2 *__restrict__ wrec, int64_t n) {
 #pragma unroll
-  for (int k = 1; k <= RING; k++) ring[(size_t)((L.t + k) & (RING - 1)) * NT + tid] = wrec[min((int64_t)L.t + k, n)];
-  L.hi = L.t + RING + 1;
+  for (int w = 0; w < WW; w++) {
+    L[w].r = wrec[L[w].t];
+#pragma unroll
+    for (int k = 1; k <= RING; k++)
+      ring[(size_t)((L[w].t + k) & (RING - 1)) * (NT * WW) + tid * WW + w] = wrec[min((int64_t)L[w].t + k, n)];
+    L[w].hi = L[w].t + RING + 1;
+  }
   // (the compiler's own wait for these loads belongs HERE: placed at the first use of r -- inside the step loop -- it would also wait,
   //  at every step, for the asm loads the group has just issued)
-  asm volatile("" : "+v"(L.r.x), "+v"(L.r.y) : : "memory");
+#pragma unroll
+  for (int w = 0; w < WW; w++) asm volatile("" : "+v"(L[w].r.x), "+v"(L[w].r.y) : : "memory");
 }
-// `steps` quads from quad j0 for the 64 walkers of a wave. strip0: the wave's two LDS strips of QS quads; buf / strip_ready: which
-// of them holds the quads from j0 on (a caller that continues where the last call ended keeps them).
+// `steps` quads from quad j0 for the 64 * WW walkers of a wave. strip0: the wave's two LDS strips of QS quads; buf / strip_ready:
+// which of them holds the quads from j0 on (a caller that continues where the last call ended keeps them).
 constexpr int LAT_QS = 16;  // quads per segment
-template <int NT, int RING>
-__device__ __forceinline__ void lat_walk_wave(LatLane &L, double2 *ring, double *strip0, int &buf, bool &strip_ready, int tid, int lane,
-                                              const double2 *__restrict__ wrec, int64_t n, const double *__restrict__ qt, int64_t jstart,
-                                              int steps, const LatCtx &cx) {
-  constexpr int G = RING / 2, QS = LAT_QS;
+template <int NT, int RING, int WW>
+__device__ __forceinline__ void lat_walk_wave(LatLane (&L)[WW], double2 *ring, double *strip0, int &buf, bool &strip_ready, int tid,
+                                              int lane, const double2 *__restrict__ wrec, int64_t n, const double *__restrict__ qt,
+                                              int64_t jstart, int steps, const LatCtx &cx) {
+  constexpr int G = RING / 2, QS = LAT_QS, NC = NT * WW;
+  static_assert(G == 4, "groups of four steps");
   for (int seg = 0; seg < steps; seg += QS) {
     const int S = min(QS, steps - seg);
     const int64_t j0 = jstart + seg;
@@ -543,30 +552,29 @@ __device__ __forceinline__ void lat_walk_wave(LatLane &L, double2 *ring, double 
       // rows the ring will miss after this group: hi .. t + RING (it holds rows up to hi - 1 >= t + G). All G records from hi on are
       // requested -- one address, consecutive 16-byte records (the walker records are padded by LAT_RPAD rows that accept nothing) --,
       // the first m of them are stored
-      const int m = L.t + RING + 1 - L.hi;  // 0 .. G
-      const double2 *src = wrec + min((int64_t)L.hi, n);
-      lat_d2v l[G];
-      l[0] = lat_asm_load_off<0>(src);
-      l[1] = lat_asm_load_off<16>(src);
-      if (G > 2) {
-        l[2 % G] = lat_asm_load_off<32>(src);
-        l[3 % G] = lat_asm_load_off<48>(src);
-      }
-      if (G > 4) {
-        l[4 % G] = lat_asm_load_off<64>(src);
-        l[5 % G] = lat_asm_load_off<80>(src);
-        l[6 % G] = lat_asm_load_off<96>(src);
-        l[7 % G] = lat_asm_load_off<112>(src);
+      int m[WW];
+      lat_d2v l[WW][G];
+#pragma unroll
+      for (int w = 0; w < WW; w++) {
+        m[w] = L[w].t + RING + 1 - L[w].hi;  // 0 .. G
+        const double2 *src = wrec + min((int64_t)L[w].hi, n);
+        l[w][0] = lat_asm_load_off<0>(src);
+        l[w][1] = lat_asm_load_off<16>(src);
+        l[w][2] = lat_asm_load_off<32>(src);
+        l[w][3] = lat_asm_load_off<48>(src);
       }
       auto one_step = [&](int k) {
         const double2 *qp = (const double2 *)(strip + (k0 + k) * LAT_QW);
         const double2 qa = qp[0], qb = qp[1];
         const LatQ q{qa.x, qa.y, qb.x, qb.y};
-        const double2 nx = ring[(size_t)((L.t + 1) & (RING - 1)) * NT + tid];
-        const bool acc = lat_accept(cx, L.t, L.r.x, L.r.y, q, j0 + k0 + k);
-        L.t += acc ? 1 : 0;
-        L.r.x = acc ? nx.x : L.r.x;
-        L.r.y = acc ? nx.y : L.r.y;
+#pragma unroll
+        for (int w = 0; w < WW; w++) {
+          const double2 nx = ring[(size_t)((L[w].t + 1) & (RING - 1)) * NC + tid * WW + w];
+          const bool acc = lat_accept(cx, L[w].t, L[w].r.x, L[w].r.y, q, j0 + k0 + k);
+          L[w].t += acc ? 1 : 0;
+          L[w].r.x = acc ? nx.x : L[w].r.x;
+          L[w].r.y = acc ? nx.y : L[w].r.y;
+        }
       };
       if (S == QS) {  // (the usual segment: the group's steps as one basic block)
 #pragma unroll
@@ -575,20 +583,16 @@ __device__ __forceinline__ void lat_walk_wave(LatLane &L, double2 *ring, double 
         const int ke = min(G, S - k0);
         for (int k = 0; k < ke; k++) one_step(k);
       }
-      if (G == 4)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(qnext) : : "memory");
-      else if (G == 2)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(l[0]), "+v"(l[1]), "+v"(qnext) : : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(l[0]), "+v"(l[1]), "+v"(l[2 % G]), "+v"(l[3 % G]), "+v"(l[4 % G]), "+v"(l[5 % G]), "+v"(l[6 % G]), "+v"(l[7 % G]),
-                       "+v"(qnext)
-                     :
-                     : "memory");
 #pragma unroll
-      for (int k = 0; k < G; k++)
-        if (m > k) ring[(size_t)((L.hi + k) & (RING - 1)) * NT + tid] = make_double2(l[k].x, l[k].y);
-      L.hi += m;
+      for (int w = 0; w < WW; w++)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(l[w][0]), "+v"(l[w][1]), "+v"(l[w][2]), "+v"(l[w][3]), "+v"(qnext) : : "memory");
+#pragma unroll
+      for (int w = 0; w < WW; w++) {
+#pragma unroll
+        for (int k = 0; k < G; k++)
+          if (m[w] > k) ring[(size_t)((L[w].hi + k) & (RING - 1)) * NC + tid * WW + w] = make_double2(l[w][k].x, l[w][k].y);
+        L[w].hi += m[w];
+      }
     }
     // the next segment's quads into the other strip
     buf ^= 1;
@@ -617,17 +621,18 @@ __global__ __launch_bounds__(NT) void k_lat_round_ring(const double2 *__restrict
   if (blockIdx.x * NT + wid * 64 >= nl) return;  // (a whole wave past the list)
   const LatCtx cx{rec, qx, raw, mask, rs->p_cons};
   int32_t *pc = cur + list_off[c] + i;
-  LatLane L;
-  L.t = i < nl ? (first ? win_lo[c] + i : *pc) : (int32_t)n;
-  lat_prime<NT, RING>(L, ring, tid, wrec, n);
+  LatLane L[1];
+  L[0].t = i < nl ? (first ? win_lo[c] + i : *pc) : (int32_t)n;
+  lat_prime<NT, RING, 1>(L, ring, tid, wrec, n);
   int buf = 0;
   bool ready = false;
-  lat_walk_wave<NT, RING>(L, ring, strips + (size_t)wid * (2 * LAT_QS * LAT_QW), buf, ready, tid, lane, wrec, n, qt, (int64_t)c * Lq + done, R,
-                          cx);
-  if (i < nl) *pc = L.t;
+  lat_walk_wave<NT, RING, 1>(L, ring, strips + (size_t)wid * (2 * LAT_QS * LAT_QW), buf, ready, tid, lane, wrec, n, qt,
+                             (int64_t)c * Lq + done, R, cx);
+  if (i < nl) *pc = L[0].t;
 }
 
-template <int NT, int RING>
+// the rest of a chunk in one launch: NT threads, WW walkers each (<= NT * WW walkers)
+template <int NT, int RING, int WW>
 __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__ rec, const double2 *__restrict__ wrec,
                                                      const double *__restrict__ qt, const double2 *__restrict__ qx,
                                                      const uint32_t *__restrict__ raw, uint64_t mask,
@@ -637,70 +642,97 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
                                                      const int64_t *__restrict__ snap_off, const int64_t *__restrict__ snap_pos,
                                                      int2 *__restrict__ snap, int64_t *__restrict__ snap_idx,
                                                      int32_t *__restrict__ snap_cnt, LatStatus *__restrict__ st) {
-  constexpr int NW = NT / 64;
+  constexpr int NW = NT / 64, NC = NT * WW, WPW = 64 * WW;  // waves, walkers of the workgroup, walkers of a wave
   constexpr int QS = LAT_QS;
   extern __shared__ double2 lat_lds[];
-  double2 *ring = lat_lds;                   // [RING][NT]
-  int *s_t0 = (int *)(lat_lds + RING * NT);  // [NT] x 2: t / first_in of the gather
-  int *s_f0 = s_t0 + NT;
-  int *s_cnt = s_f0 + NT;                    // [16]
+  double2 *ring = lat_lds;                   // [RING][NC]
+  int *s_t0 = (int *)(lat_lds + RING * NC);  // [NC] x 2: t / first_in of the gather
+  int *s_f0 = s_t0 + NC;
+  int *s_cnt = s_f0 + NC;                    // [16]
   double *strips = (double *)(s_cnt + 16);   // [NW][2][QS * LAT_QW]
-  int *s_t1 = (int *)ring, *s_f1 = s_t1 + NT;  // second stage of the redistribution: the ring is refilled after it anyway
+  int *s_t1 = (int *)ring, *s_f1 = s_t1 + NC;  // second stage of the redistribution: the ring is refilled after it anyway
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const LatCtx cx{rec, qx, raw, mask, rs->p_cons};
   const int64_t J0 = (int64_t)c * Lq;
   int nl = live[c];
-  if (nl > NT) {
+  if (nl > NC) {
     if (tid == 0) lat_fail(st, 3, c);
     return;
   }
   const int64_t off = list_off[c];
   int64_t sp = done0 >= subq ? snap_pos[c] : snap_off[c];
   const int64_t sp_end = snap_off[c + 1];
-  // the walkers fill the waves one after the other (wave w: walkers [64 w, 64 w + wl)): the kernel is bound by instruction issue -- eight
-  // quarter-filled waves were 20 % slower than two full ones (HISTORY.md, round 6)
-  auto deal = [&](int total, int &w0) {
-    w0 = wid * 64;
-    return max(0, min(64, total - wid * 64));
-  };
-  int w0 = 0;
-  int wl = deal(nl, w0);
-  LatLane L;
-  L.t = (int32_t)n;
-  int32_t f = 0;
-  if (lane < wl) {
-    L.t = scur[off + w0 + lane];
-    f = sfin[off + w0 + lane];
+  // the walkers fill the waves one after the other (wave w: walkers [WPW w, WPW w + wl), lane l: walkers WW l .. WW l + WW - 1 of
+  // them): the kernel is bound by instruction issue -- eight quarter-filled waves were 20 % slower than two full ones
+  const int w0 = wid * WPW;
+  int wl = max(0, min(WPW, nl - w0));
+  LatLane L[WW];
+  int32_t f[WW];
+#pragma unroll
+  for (int w = 0; w < WW; w++) {
+    const int wi = lane * WW + w;
+    L[w].t = wi < wl ? scur[off + w0 + wi] : (int32_t)n;
+    f[w] = wi < wl ? sfin[off + w0 + wi] : 0;
   }
-  lat_prime<NT, RING>(L, ring, tid, wrec, n);
+  lat_prime<NT, RING, WW>(L, ring, tid, wrec, n);
   double *strip0 = strips + (size_t)wid * (2 * QS * LAT_QW);
   int done = done0, buf = 0;
   bool strip_ready = false;  // strips[buf] holds the quads of the segment that starts at `done`
+  // survivors among the first `cnt_in` entries of a sorted list held WW per lane: keep[w], rank[w] (order of the list), their number
+  auto survivors = [&](const int (&tt)[WW], int prev_first, int cnt_in, bool (&keep)[WW], int (&rank)[WW]) {
+    unsigned long long bal[WW];
+#pragma unroll
+    for (int w = 0; w < WW; w++) {
+      const int wi = lane * WW + w;
+      int prev = w == 0 ? __shfl_up(tt[WW - 1], 1, 64) : tt[w - 1];
+      if (w == 0 && lane == 0) prev = prev_first;
+      keep[w] = wi < cnt_in && tt[w] != prev;
+      bal[w] = __ballot(keep[w]);
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < WW; w++) {
+      before += __popcll(bal[w] & lt);
+      tot += __popcll(bal[w]);
+    }
+#pragma unroll
+    for (int w = 0; w < WW; w++) {
+      rank[w] = before;
+      before += keep[w] ? 1 : 0;
+    }
+    return tot;
+  };
   while (done < (int)Lq) {
     const int to_boundary = subq - (done % subq);
     const int Rr = min(R, to_boundary);
     if (wl > 0) {
-      lat_walk_wave<NT, RING>(L, ring, strip0, buf, strip_ready, tid, lane, wrec, n, qt, J0 + done, Rr, cx);
+      lat_walk_wave<NT, RING, WW>(L, ring, strip0, buf, strip_ready, tid, lane, wrec, n, qt, J0 + done, Rr, cx);
       // merge inside the wave: the walkers are sorted, a walker that met the one below it is dropped
-      const int prev = __shfl_up(L.t, 1, 64);
-      const bool keep = lane < wl && (lane == 0 || L.t != prev);
-      const unsigned long long b = __ballot(keep);
-      const int cnt = __popcll(b);
+      int tt[WW], rank[WW];
+      bool keep[WW];
+#pragma unroll
+      for (int w = 0; w < WW; w++) tt[w] = L[w].t;
+      const int cnt = survivors(tt, -1, wl, keep, rank);
       if (cnt != wl) {
-        const int rk = __popcll(b & ((1ull << lane) - 1ull));
-        const int base = wid * 64;
-        if (keep) {
-          s_t0[base + rk] = L.t;
-          s_f0[base + rk] = f;
-        }
+#pragma unroll
+        for (int w = 0; w < WW; w++)
+          if (keep[w]) {
+            s_t0[w0 + rank[w]] = L[w].t;
+            s_f0[w0 + rank[w]] = f[w];
+          }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         wl = cnt;
-        L.t = lane < wl ? s_t0[base + lane] : (int32_t)n;
-        f = lane < wl ? s_f0[base + lane] : 0;
+#pragma unroll
+        for (int w = 0; w < WW; w++) {
+          const int wi = lane * WW + w;
+          L[w].t = wi < wl ? s_t0[w0 + wi] : (int32_t)n;
+          f[w] = wi < wl ? s_f0[w0 + wi] : 0;
+        }
         __builtin_amdgcn_wave_barrier();
-        lat_prime<NT, RING>(L, ring, tid, wrec, n);
+        lat_prime<NT, RING, WW>(L, ring, tid, wrec, n);
       }
     } else {
       strip_ready = false;
@@ -717,21 +749,29 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
         if (k < wid) before += cw;
         tot += cw;
       }
-      if (lane < wl) {
-        s_t0[before + lane] = L.t;
-        s_f0[before + lane] = f;
+#pragma unroll
+      for (int w = 0; w < WW; w++) {
+        const int wi = lane * WW + w;
+        if (wi < wl) {
+          s_t0[before + wi] = L[w].t;
+          s_f0[before + wi] = f[w];
+        }
       }
       __syncthreads();
-      bool keep = false;
-      int t2 = 0, f2 = 0;
-      if (tid < tot) {
-        t2 = s_t0[tid];
-        keep = tid == 0 || t2 != s_t0[tid - 1];
-        f2 = s_f0[tid];
+      // thread tid looks at entries WW tid .. WW tid + WW - 1 of the gathered list
+      int t2[WW], f2[WW], rank2[WW];
+      bool keep2[WW];
+#pragma unroll
+      for (int w = 0; w < WW; w++) {
+        const int idx = tid * WW + w;
+        t2[w] = idx < tot ? s_t0[idx] : 0;
+        f2[w] = idx < tot ? s_f0[idx] : 0;
       }
-      const unsigned long long b = __ballot(keep);
+      const int prev_first = (tid > 0 && tid * WW - 1 < tot) ? s_t0[tid * WW - 1] : -1;  // (lane 0 of a wave: the entry before its first)
+      const int cnt_wave = max(0, min(WPW, tot - wid * WPW));
+      const int kept = survivors(t2, prev_first, cnt_wave, keep2, rank2);
       __syncthreads();
-      if (lane == 0) s_cnt[wid] = __popcll(b);
+      if (lane == 0) s_cnt[wid] = kept;
       __syncthreads();
       int before2 = 0, tot2 = 0;
       for (int k = 0; k < NW; k++) {
@@ -740,12 +780,14 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
         tot2 += cw;
       }
       const int sk = done / subq - 1;
-      if (keep) {
-        const int rk = before2 + __popcll(b & ((1ull << lane) - 1ull));
-        s_t1[rk] = t2;  // (in the ring's memory: every lane is past its last ring read, and refills the ring below)
-        s_f1[rk] = f2;
-        if (sp + rk < sp_end) snap[sp + rk] = make_int2(f2, t2);
-      }
+#pragma unroll
+      for (int w = 0; w < WW; w++)
+        if (keep2[w]) {
+          const int rk = before2 + rank2[w];
+          s_t1[rk] = t2[w];  // (in the ring's memory: every lane is past its last ring read, and refills the ring below)
+          s_f1[rk] = f2[w];
+          if (sp + rk < sp_end) snap[sp + rk] = make_int2(f2[w], t2[w]);
+        }
       if (tid == 0) {
         if (sp + tot2 > sp_end) lat_fail(st, 2, c);
         snap_idx[(size_t)c * nsub + sk] = sp;
@@ -754,11 +796,15 @@ __global__ __launch_bounds__(NT) void k_lat_resident(const double2 *__restrict__
       sp += tot2;
       __syncthreads();
       nl = tot2;
-      wl = deal(nl, w0);
-      L.t = lane < wl ? s_t1[w0 + lane] : (int32_t)n;
-      f = lane < wl ? s_f1[w0 + lane] : 0;
+      wl = max(0, min(WPW, nl - w0));
+#pragma unroll
+      for (int w = 0; w < WW; w++) {
+        const int wi = lane * WW + w;
+        L[w].t = wi < wl ? s_t1[w0 + wi] : (int32_t)n;
+        f[w] = wi < wl ? s_f1[w0 + wi] : 0;
+      }
       __syncthreads();
-      lat_prime<NT, RING>(L, ring, tid, wrec, n);
+      lat_prime<NT, RING, WW>(L, ring, tid, wrec, n);
     }
   }
 }
@@ -1123,16 +1169,19 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
     rounds_done = round;
     handover = done;
     if (done < Lq) {
-      const size_t lds = (size_t)8 * res_nt * sizeof(double2) + (size_t)(2 * res_nt + 16) * sizeof(int) +
-                         (size_t)(res_nt / 64) * 2 * LAT_QS * LAT_QW * sizeof(double);
+      // one walker per lane, 512 threads (the kernel is written for WW walkers per lane: with two, at 256 threads, the independent
+      // chains of a lane did not overlap -- 57 against 40 ms at config 5 --, HISTORY.md round 6)
+      constexpr int nt = LAT_RES_NT;
+      const size_t lds = (size_t)8 * nt * sizeof(double2) + (size_t)(2 * nt + 16) * sizeof(int) +
+                         (size_t)(nt / 64) * 2 * LAT_QS * LAT_QW * sizeof(double);
       {
         static DeviceOnce raised;
         if (raised.need()) {
-          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_lat_resident<LAT_RES_NT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+          MFM_HIP_CHECK(hipFuncSetAttribute((const void *)k_lat_resident<LAT_RES_NT, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
           raised.mark();
         }
       }
-      hipLaunchKernelGGL((k_lat_resident<LAT_RES_NT, 8>), dim3((unsigned)C), dim3(res_nt), lds, s, m.rec.p, m.wrec.p, m.qt.p, m.qx.p, job.raw,
+      hipLaunchKernelGGL((k_lat_resident<LAT_RES_NT, 8, 1>), dim3((unsigned)C), dim3(nt), lds, s, m.rec.p, m.wrec.p, m.qt.p, m.qx.p, job.raw,
                          job.mask, job.state, n, Lq, done, R, subq, nsub, m.live.p, m.list_off.p, sc, sf, m.snap_off.p, m.snap_pos.p,
                          m.snap.p, m.snap_idx.p, m.snap_cnt.p, m.status.p);
     }
