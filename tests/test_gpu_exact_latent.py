@@ -259,3 +259,50 @@ def test_estimators_default_is_the_reference_chain_on_unsorted_rows(mods, oracle
     fm2 = est(rank, random_seed=7, exact_latent_draws=False)
     fm2.fit(X, y, n_iter=n_iter, n_kept_samples=n_iter, group_shapes=shapes)
     assert not np.allclose(fm2.V_samples[-1], fm.V_samples[-1], rtol=1e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", ["two_classes", "seven_rows", "rank_zero", "one_class_missing", "wide_middle"])
+def test_small_and_degenerate_ordered_designs(mods, oracle, case):
+    """corner cases of the exact latent draws through the boundary: 2 classes (no two-sided row at all), a table of 7 rows (one
+    chunk, one walker), rank 0 (tests/oprobit/test_oprobit_1dim.py:24 in the reference), a class nobody belongs to, a middle class
+    that holds 98 % of the rows (cutpoints far apart: the uniform proposal is accepted one time in three, the draw consumes twice
+    the engine outputs the generator was sized for -- the ring of outputs grows on the fly)"""
+    _myfm, _ = mods
+    rns = np.random.RandomState(3)
+    if case == "seven_rows":
+        n, n_u, n_i = 7, 3, 2
+    else:
+        n, n_u, n_i = 3000, 40, 25
+    X, score, shapes = ds.onehot_mf(n, n_u, n_i, seed=21, sort_by_user=True)
+    score = (score - score.mean()) / (score.std() + 1e-12) + 0.3 * rns.normal(size=n)
+    if case == "two_classes":
+        y = (score > 0.1).astype(np.float64)
+        n_class = 2
+    elif case == "wide_middle":
+        y = np.ones(n)
+        y[score < np.quantile(score, 0.01)] = 0.0
+        y[score > np.quantile(score, 0.99)] = 2.0
+        n_class = 3
+    elif case == "one_class_missing":
+        y = np.zeros(n)
+        for c in (-0.5, 0.5):
+            y += score > c
+        y[y == 1] = 2.0  # classes 0 and 2 of {0, 1, 2, 3}: class 1 and class 3 are empty
+        n_class = 4
+    else:
+        y = np.zeros(n)
+        for c in (-0.6, 0.0, 0.7):
+            y += score > c
+        n_class = 4
+    rank = 0 if case == "rank_zero" else 2
+    groups = [(n_class, np.arange(n))]
+    gi = ds.group_index_from_shapes(shapes)
+    n_iter = 4
+    cfg = _config(_myfm, gi, n_iter, "ordered", cutpoint_groups=groups)
+    predictor, history = _myfm.create_train_fm(rank, 0.1, X, [], y, 42, cfg, lambda *a: False)
+    samples, hypers, cuts, t = _oracle_chain(oracle, X, y, [], n_iter, n_groups_cut=1, rank=rank, group_index=gi, task=oracle.ORDERED,
+                                             cutpoint_groups=groups)
+    _assert_chain(predictor, history, samples, hypers)
+    for fm, cut in zip(predictor.samples, cuts):
+        np.testing.assert_allclose(fm.cutpoints[0], cut[0], rtol=1e-7, atol=1e-7)
+    assert list(history.n_mh_accept) == [t.mh_accept(0)]
