@@ -306,3 +306,48 @@ def test_small_and_degenerate_ordered_designs(mods, oracle, case):
     for fm, cut in zip(predictor.samples, cuts):
         np.testing.assert_allclose(fm.cutpoints[0], cut[0], rtol=1e-7, atol=1e-7)
     assert list(history.n_mh_accept) == [t.mh_accept(0)]
+
+
+def test_c_abi_classification_draw_and_refusal(oracle):
+    """The entry points themselves, through ctypes: `mfm_update_e_classification_exact` makes the draws of the oracle's `update_e`
+    (FMTrainer.hpp:498-512) from the same engine state and leaves the stream where the oracle's generator stands; with a row whose
+    score lies 5000 standard deviations on the wrong side of its class (alpha* > 1000: outside what the walkers' single decision
+    formula covers) it returns status 5 and has neither drawn nor consumed anything -- the same call after the weights are put
+    back makes the same draws."""
+    from myfm_amd import _capi
+
+    n, K = 40000, 4
+    X, score, shapes = ds.onehot_mf(n, 500, 200, seed=12, sort_by_user=True)
+    y = np.where(score > np.median(score), 1.0, -1.0)
+    t = oracle.OracleTrainer(X, y, rank=K, seed=5, task=oracle.CLASSIFICATION)
+    for _ in range(2):
+        t.step()
+    w0, w, V = t.fm()
+    st, pos = t.rng_state()
+    c = _capi.Context(X, y, rank=K)
+    c.rng_seed_mt19937(st, pos)
+    c.rng_set_program([(0, 0, 4, 0, 0.0), (2, 0, n, 0, 0.0)])  # (MFM_RNG_LATENT: the draws of n rows per iteration)
+    ahead = c.rng_host_read(0, 8)
+
+    # a row far out: user 0 carries y = +1 somewhere; push that user's weight to -5000
+    far = w.copy()
+    u0 = int(X[np.flatnonzero(y > 0)[0]].indices[0])
+    far[u0] = -5000.0
+    c.set_state(w0, far, V)
+    assert c.update_e_classification_exact() == 5
+    assert c.latent_stats()["status"] == 5
+    np.testing.assert_array_equal(c.rng_host_read(0, 8), ahead)
+
+    c.set_state(w0, w, V)
+    assert c.update_e_classification_exact() == 0
+    info = c.latent_stats()
+    assert info["status"] == 0 and info["quads"] >= n
+    e = c.get_e()
+    t.substep(8)
+    np.testing.assert_allclose(e, t.e(n), rtol=1e-9, atol=1e-9)
+    # the stream: 4 engine outputs per quad were consumed, the next ones are the oracle generator's next ones
+    st2, pos2 = t.rng_state()
+    bg = np.random.MT19937()
+    bg.state = {"bit_generator": "MT19937", "state": {"key": st2, "pos": pos2}}
+    np.testing.assert_array_equal(c.rng_host_read(0, 8), bg.random_raw(8).astype(np.uint32))
+    c.close()
