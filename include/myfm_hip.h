@@ -200,6 +200,9 @@ int mfm_sweep_wV(mfm_ctx *ctx, double alpha, double e_shift, const double *lambd
  *   prior: alpha_0, beta_0, gamma_0, mu_0, reg_0 of FMLearningConfig, n_total = training rows, fit_w0; n_in_group: [G] features
  *   per group. In: *w0, mu_w, mu_V = the current values. Out: this iteration's draws (the call returns when they have arrived,
  *   i.e. early in the iteration's device work: w / V / e are still being swept, like after mfm_sweep_wV).
+ *   Errors raised ON the device by this iteration's own launches (a co-residency time-out of the persistent sweep, an exhausted
+ *   random stream) cannot be known when the call returns: they are returned by the NEXT call that waits for the stream -- the next
+ *   mfm_regression_iteration, mfm_get_state, mfm_synchronize -- and always before a model leaves the device.
  * mfm_regression_iteration_ready: 1 when the context can do this now (finalized two-field table on the persistent sweep, one GPU,
  * the residual in the sweep's slot order with its sums from the last mfm_update_e_regression, a device random stream programmed
  * as above); else 0 and the caller runs the iteration step by step. */
