@@ -246,11 +246,13 @@ int mfm_oprobit_sample_z(mfm_ctx *ctx, int32_t group, const double *gamma, uint6
  *     gamma_distribution(shape, scale) (FMTrainer.hpp:142-143, :164-165; multiply by scale);
  *     dest 0 = "hyper" variates returned to the host in program order, 1 = z of mfm_sweep_w (D),
  *     2 = z of mfm_sweep_V (K * D, factor-major);
- *   - mfm_rng_prefetch: start producing a further iteration's variates on a side stream, behind everything
- *     enqueued on the ctx stream so far. Sets are produced in iteration order; up to two may be in flight
- *     besides the acquired one (the trainer requests the set of iteration t + 2 right after the latent
- *     sweep of iteration t: the generator then runs next to update_e and the start of iteration t + 1,
- *     never beside the persistent sweep, which leaves it no CU);
+ *   - mfm_rng_prefetch: start producing a further iteration's variates on a side stream. Sets are produced in
+ *     iteration order; up to two may be in flight besides the acquired one (the trainer requests the set of
+ *     iteration t + 2 right after the latent sweep of iteration t is enqueued). Where the persistent sweep fills the
+ *     device, a set with another one ahead of it is produced in two parts: its single-workgroup kernels (generator,
+ *     hyper draws, the linear term's normals) right away, beside the sweep; its whole-GPU evaluation of the K D
+ *     sweep normals with the NEXT mfm_rng_prefetch (or the mfm_rng_acquire that needs it), behind everything
+ *     enqueued on the ctx stream by then -- between two sweeps, not starved beside one;
  *   - mfm_rng_acquire: wait for the oldest prefetched set, copy its hyper variates to the host and
  *     make its z buffers the ones mfm_sweep_w / mfm_sweep_V use when called with z == NULL.      */
 #define MFM_RNG_NORMALS 0

@@ -263,6 +263,8 @@ struct mfm_ctx {
     } slot[3];
     static constexpr int N_SLOTS = 3;
     hipEvent_t gate = nullptr;  // recorded on the main stream at every prefetch: the side stream starts behind it
+    // a set whose wide evaluation has not been enqueued yet (mfm_rng_prefetch): its slot, the op to go on with; -1: none
+    int pending_slot = -1, pending_op = 0;
     // latent mode "exact": the main stream moved the stream's position (mfm_latent_host.hpp); the next set starts behind that
     bool latent_pending = false;
     hipEvent_t latent_ev = nullptr;
@@ -275,6 +277,7 @@ struct mfm_ctx {
     DevBuf<unsigned long long> masks;
     DevBuf<int> counts;
     DevBuf<NormScratch> nscratch;
+    static constexpr int64_t WIDE_COUNT = 262144;  // NORMALS ops beyond this many draws: "wide" (mfm_rng_prefetch)
     static int64_t attempts_for(int64_t count) {
       double a = (double)count * (4.0 / 3.14159265358979) * 1.01 + 8.0 * std::sqrt((double)count + 1.0) + 4096.0;
       int64_t n = (int64_t)a;
@@ -2118,6 +2121,8 @@ static bool regression_iteration_ready(mfm_ctx *c) {
   return true;
 }
 
+static void rng_finish_pending(mfm_ctx *ctx, bool gated);  // (with mfm_rng_prefetch, below)
+
 int mfm_regression_iteration_ready(mfm_ctx *ctx) { return regression_iteration_ready(ctx) ? 1 : 0; }
 
 int mfm_regression_iteration(mfm_ctx *ctx, const mfm_hyper_prior *prior, const double *n_in_group, double *alpha, double *w0,
@@ -2147,6 +2152,7 @@ int mfm_regression_iteration(mfm_ctx *ctx, const mfm_hyper_prior *prior, const d
     MFM_HIP_CHECK(hipEventRecord(prev.free_ev, s));
     prev.free_valid = true;
   }
+  if (r.pending_slot == (int)(r.acquired % mfm_ctx::RngEngine::N_SLOTS)) rng_finish_pending(ctx, false);
   auto &sl = r.slot[r.acquired % mfm_ctx::RngEngine::N_SLOTS];
   MFM_HIP_CHECK(hipStreamWaitEvent(s, sl.ready, 0));
   r.current = (int)(r.acquired % mfm_ctx::RngEngine::N_SLOTS);
@@ -2468,6 +2474,7 @@ int mfm_rng_seed_mt19937(mfm_ctx *ctx, const uint32_t *state624, int32_t positio
   r.seeded = true;
   r.produced = r.acquired = 0;
   r.current = -1;
+  r.pending_slot = -1;
   for (auto &sl : r.slot) sl.free_valid = false;
   MFM_CATCH(ctx)
 }
@@ -2577,18 +2584,83 @@ int mfm_rng_set_program(mfm_ctx *ctx, const mfm_rng_op *ops, int32_t n_ops) {
   MFM_CATCH(ctx)
 }
 
+// the ops [first, n_ops) of a set on the side stream, then the set's read-back and its ready event. stop_at_wide: stop in front of the
+// first whole-GPU evaluation and return its index (the caller finishes the set later); otherwise n_ops.
+static int rng_enqueue_ops(mfm_ctx *ctx, mfm_ctx::RngEngine::Slot &sl, int first, bool stop_at_wide) {
+  auto &r = ctx->rng;
+  hipStream_t s = r.stream;
+  // small ops (hyper draws) run in one sequential workgroup; big NORMALS ops on the whole GPU
+  int i = first;
+  while (i < r.n_ops) {
+    int j = i;
+    while (j < r.n_ops && !(r.h_ops[j].kind == MFM_RNG_NORMALS && r.h_ops[j].count > 16384)) j++;
+    if (j > i)
+      hipLaunchKernelGGL(k_rng_consume, dim3(1), dim3(RNG_CONSUME_THREADS), 0, s, r.state.p, r.raw.p, r.mask, r.ops.p, i, j,
+                         sl.hv.p, sl.zw.p, sl.zv.p);
+    if (j < r.n_ops) {
+      const RngOp &o = r.h_ops[j];
+      if (stop_at_wide && o.count > mfm_ctx::RngEngine::WIDE_COUNT) {
+        MFM_HIP_CHECK(hipGetLastError());
+        return j;
+      }
+      const int64_t A = mfm_ctx::RngEngine::attempts_for(o.count);
+      const int n_chunks = (int)(A / NORM_CHUNK);
+      double *dst = (o.dest == 0 ? sl.hv.p : (o.dest == 1 ? sl.zw.p : sl.zv.p)) + o.offset;
+      hipLaunchKernelGGL(k_norm_eval, dim3(n_chunks), dim3(256), 0, s, r.state.p, r.raw.p, r.mask, r.cand.p, r.masks.p,
+                         r.counts.p);
+      hipLaunchKernelGGL(k_norm_scan, dim3(1), dim3(1024), 0, s, r.state.p, r.counts.p, n_chunks, o.count, r.nscratch.p);
+      hipLaunchKernelGGL(k_norm_scatter, dim3(n_chunks), dim3(256), 0, s, r.state.p, r.cand.p, r.masks.p, r.counts.p, o.count,
+                         r.nscratch.p, dst);
+      j++;
+    }
+    i = j;
+  }
+  MFM_HIP_CHECK(hipGetLastError());
+  if (r.n_hv)
+    MFM_HIP_CHECK(hipMemcpyAsync(sl.h_hv, sl.hv.p, (size_t)r.n_hv * sizeof(double), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipMemcpyAsync(sl.h_hv + r.n_hv, r.state.p, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+  MFM_HIP_CHECK(hipEventRecord(sl.ready, s));
+  return r.n_ops;
+}
+
+// the rest of the set mfm_rng_prefetch left unfinished: its whole-GPU evaluation(s), behind everything enqueued on the main stream so
+// far when `gated`
+static void rng_finish_pending(mfm_ctx *ctx, bool gated) {
+  auto &r = ctx->rng;
+  if (r.pending_slot < 0) return;
+  if (gated) {
+    if (!r.gate) MFM_HIP_CHECK(hipEventCreateWithFlags(&r.gate, hipEventDisableTiming));
+    MFM_HIP_CHECK(hipEventRecord(r.gate, ctx->stream));
+    MFM_HIP_CHECK(hipStreamWaitEvent(r.stream, r.gate, 0));
+  }
+  const int slot = r.pending_slot;
+  r.pending_slot = -1;
+  rng_enqueue_ops(ctx, r.slot[slot], r.pending_op, false);
+}
+
 int mfm_rng_prefetch(mfm_ctx *ctx) {
   MFM_TRY(ctx)
   auto &r = ctx->rng;
   if (!r.programmed) throw Error(MFM_ERR_RUNTIME, "mfm_rng_set_program has not been called");
   // three slots: the acquired set stays valid until the next acquire, so at most two further sets may be in flight (three
-  // before the first acquire). The trainer keeps two ahead: the set of iteration t + 2 is requested right after the latent
-  // sweep of iteration t is enqueued and starts when that sweep ends (the gate below) -- the persistent sweep occupies every
-  // CU, nothing of the side stream can run beside it, and a generator workgroup still running when it is launched delays
-  // all of its workgroups; the generator has the rest of iteration t and the start of iteration t + 1, and the set
-  // iteration t + 1 needs at its very start was finished one iteration earlier.
+  // before the first acquire). The trainer keeps two ahead: the set of iteration t + 2 is requested right after the persistent
+  // sweep of iteration t is enqueued.
+  //
+  // Where that sweep fills the device, what runs beside it matters. A set is a chain of single-workgroup kernels (the generator's
+  // eight workgroups, the hyper draws, the linear term's normals: ~0.26 ms in a row) and one whole-GPU evaluation (the K D sweep
+  // normals: 60 us + scan + scatter on a free device -- but 2.5 ms, starved on the eight CUs the sweep leaves free, when it starts
+  // beside it, and the sweep itself 2.5 % slower). So the set is produced in two parts: the narrow chain of set t + 2 right away --
+  // beside sweep t, where it disturbs nobody --, its wide evaluation only with the NEXT request, behind sweep t + 1: between two
+  // sweeps, next to update_e, finished ~0.1 ms into a ~0.2 ms gap and in time for sweep t + 2. (One gate in front of the whole set
+  // -- rounds 4 and 5 -- put the narrow chain into the gap and the wide evaluation beside the next sweep.)
   if (r.produced - r.acquired >= (r.current >= 0 ? mfm_ctx::RngEngine::N_SLOTS - 1 : mfm_ctx::RngEngine::N_SLOTS))
     throw Error(MFM_ERR_RUNTIME, "every random set is in use (one acquired, the others in flight): acquire the next one first");
+  static const bool no_gate = std::getenv("MFM_RES_NO_GATE") != nullptr;  // (experiments with CUs left free by MFM_RES_CUS)
+  static const bool one_part = std::getenv("MFM_RNG_ONE_PART") != nullptr;  // (the whole set behind one gate, as before round 6)
+  // (the gate only where the persistent sweep fills the device: a small table's launch leaves most CUs free, and there the
+  //  generator should run beside it -- ML-100k shape: 2700 it/s gated, 3000 not)
+  const bool gated = ctx->res.ready && ctx->res_fills_device && !no_gate;
+  rng_finish_pending(ctx, gated);
   auto &sl = r.slot[r.produced % mfm_ctx::RngEngine::N_SLOTS];
   hipStream_t s = r.stream;
   {  // (timing experiment, wrong results: after the first sets nothing is generated any more -- what the iteration costs without the
@@ -2600,10 +2672,9 @@ int mfm_rng_prefetch(mfm_ctx *ctx) {
       return MFM_OK;
     }
   }
-  // (the gate only where the persistent sweep fills the device: a small table's launch leaves most CUs free, and there the
-  //  generator should run beside it -- ML-100k shape: 2700 it/s gated, 3000 not)
-  static const bool no_gate = std::getenv("MFM_RES_NO_GATE") != nullptr;  // (experiments with CUs left free by MFM_RES_CUS)
-  if (ctx->res.ready && ctx->res_fills_device && !no_gate) {
+  // two parts only with another finished set ahead of this one (the set is then not needed before the request after this one)
+  const bool two_parts = gated && !one_part && r.produced - r.acquired >= 1;
+  if (gated && !two_parts) {
     if (!r.gate) MFM_HIP_CHECK(hipEventCreateWithFlags(&r.gate, hipEventDisableTiming));
     MFM_HIP_CHECK(hipEventRecord(r.gate, ctx->stream));
     MFM_HIP_CHECK(hipStreamWaitEvent(s, r.gate, 0));
@@ -2631,33 +2702,12 @@ int mfm_rng_prefetch(mfm_ctx *ctx) {
   } else {
     hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(MT_GEN_THREADS), 0, s, r.state.p, r.raw.p, r.mask, r.need);
   }
-  // small ops (hyper draws) run in one sequential workgroup; big NORMALS ops on the whole GPU
-  int i = 0;
-  while (i < r.n_ops) {
-    int j = i;
-    while (j < r.n_ops && !(r.h_ops[j].kind == MFM_RNG_NORMALS && r.h_ops[j].count > 16384)) j++;
-    if (j > i)
-      hipLaunchKernelGGL(k_rng_consume, dim3(1), dim3(RNG_CONSUME_THREADS), 0, s, r.state.p, r.raw.p, r.mask, r.ops.p, i, j,
-                         sl.hv.p, sl.zw.p, sl.zv.p);
-    if (j < r.n_ops) {
-      const RngOp &o = r.h_ops[j];
-      const int64_t A = mfm_ctx::RngEngine::attempts_for(o.count);
-      const int n_chunks = (int)(A / NORM_CHUNK);
-      double *dst = (o.dest == 0 ? sl.hv.p : (o.dest == 1 ? sl.zw.p : sl.zv.p)) + o.offset;
-      hipLaunchKernelGGL(k_norm_eval, dim3(n_chunks), dim3(256), 0, s, r.state.p, r.raw.p, r.mask, r.cand.p, r.masks.p,
-                         r.counts.p);
-      hipLaunchKernelGGL(k_norm_scan, dim3(1), dim3(1024), 0, s, r.state.p, r.counts.p, n_chunks, o.count, r.nscratch.p);
-      hipLaunchKernelGGL(k_norm_scatter, dim3(n_chunks), dim3(256), 0, s, r.state.p, r.cand.p, r.masks.p, r.counts.p, o.count,
-                         r.nscratch.p, dst);
-      j++;
-    }
-    i = j;
+  const int slot_idx = (int)(r.produced % mfm_ctx::RngEngine::N_SLOTS);
+  const int next_op = rng_enqueue_ops(ctx, sl, 0, two_parts);
+  if (next_op < r.n_ops) {
+    r.pending_slot = slot_idx;
+    r.pending_op = next_op;
   }
-  MFM_HIP_CHECK(hipGetLastError());
-  if (r.n_hv)
-    MFM_HIP_CHECK(hipMemcpyAsync(sl.h_hv, sl.hv.p, (size_t)r.n_hv * sizeof(double), hipMemcpyDeviceToHost, s));
-  MFM_HIP_CHECK(hipMemcpyAsync(sl.h_hv + r.n_hv, r.state.p, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-  MFM_HIP_CHECK(hipEventRecord(sl.ready, s));
   r.produced++;
   MFM_CATCH(ctx)
 }
@@ -2673,6 +2723,7 @@ int mfm_rng_acquire(mfm_ctx *ctx, double *hyper_variates, int64_t n_hyper_variat
     MFM_HIP_CHECK(hipEventRecord(prev.free_ev, ctx->stream));
     prev.free_valid = true;
   }
+  if (r.pending_slot == (int)(r.acquired % mfm_ctx::RngEngine::N_SLOTS)) rng_finish_pending(ctx, false);
   auto &sl = r.slot[r.acquired % mfm_ctx::RngEngine::N_SLOTS];
   MFM_HIP_CHECK(hipEventSynchronize(sl.ready));
   RngState hdr;
