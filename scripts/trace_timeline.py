@@ -9,7 +9,11 @@ tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('
 kd = [t for t in tabs if "kernel_dispatch" in t and "rocpd" in t][0]
 sym = [t for t in tabs if "kernel_symbol" in t and "rocpd" in t][0]
 cols = [r[1] for r in c.execute("pragma table_info(%s)" % kd)]
-rows = list(c.execute("select s.kernel_name, d.start, d.end from %s d join %s s on d.kernel_id = s.id order by d.start" % (kd, sym)))
+gcol = [x for x in cols if x in ("grid_size_x", "grid_x", "grid_size")]
+gsel = ("d.%s" % gcol[0]) if gcol else "0"
+qcol = [x for x in cols if x in ("queue_id", "stream_id")]
+qsel = ("d.%s" % qcol[0]) if qcol else "0"
+rows = list(c.execute("select s.kernel_name, d.start, d.end, %s, %s from %s d join %s s on d.kernel_id = s.id order by d.start" % (gsel, qsel, kd, sym)))
 marks = [i for i, r in enumerate(rows) if marker in r[0]]
 a, b = marks[-2], marks[-1]
 t0 = rows[a][1]
@@ -17,7 +21,7 @@ prev_end = rows[a][2]
 busy = 0
 print("iteration: %d dispatches, %.1f us wall" % (b - a, (rows[b][1] - t0) / 1e3))
 agg = {}
-for name, st, en in rows[a + 1:b + 1]:
+for name, st, en, _g, _q in rows[a + 1:b + 1]:
     short = name.split("(")[0].replace("void ", "").replace("mfm::", "")[:40]
     gap = (st - prev_end) / 1e3
     agg.setdefault(short, [0, 0.0, 0.0])
@@ -30,6 +34,7 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-42s %6d %10.1f %12.1f" % (k, v[0], v[1], v[2]))
 if "-v" in sys.argv:
     prev_end = rows[a][2]
-    for name, st, en in rows[a + 1:b + 1]:
-        print("%10.1f %8.1f gap %7.1f  %s" % ((st - t0) / 1e3, (en - st) / 1e3, (st - prev_end) / 1e3, name.split("(")[0][-50:]))
+    print("columns of the dispatch table:", cols)
+    for name, st, en, g, q in rows[a + 1:b + 1]:
+        print("%10.1f %8.1f gap %7.1f grid %8s q %4s  %s" % ((st - t0) / 1e3, (en - st) / 1e3, (st - prev_end) / 1e3, g, q, name.split("(")[0][-44:]))
         prev_end = max(prev_end, en)
