@@ -2646,13 +2646,15 @@ int mfm_rng_prefetch(mfm_ctx *ctx) {
   // before the first acquire). The trainer keeps two ahead: the set of iteration t + 2 is requested right after the persistent
   // sweep of iteration t is enqueued.
   //
-  // Where that sweep fills the device, what runs beside it matters. A set is a chain of single-workgroup kernels (the generator's
-  // eight workgroups, the hyper draws, the linear term's normals: ~0.26 ms in a row) and one whole-GPU evaluation (the K D sweep
-  // normals: 60 us + scan + scatter on a free device -- but 2.5 ms, starved on the eight CUs the sweep leaves free, when it starts
-  // beside it, and the sweep itself 2.5 % slower). So the set is produced in two parts: the narrow chain of set t + 2 right away --
-  // beside sweep t, where it disturbs nobody --, its wide evaluation only with the NEXT request, behind sweep t + 1: between two
-  // sweeps, next to update_e, finished ~0.1 ms into a ~0.2 ms gap and in time for sweep t + 2. (One gate in front of the whole set
-  // -- rounds 4 and 5 -- put the narrow chain into the gap and the wide evaluation beside the next sweep.)
+  // Where that sweep fills the device, the order on the side stream matters: a kernel of more than one workgroup that is dispatched
+  // while the sweep runs does not move until the sweep ends (per-dispatch timelines, profiles/r06_q_timeline_config3_*.txt), and
+  // holds up the stream behind it. A set is a chain of narrow kernels (the generator, the hyper draws, the linear term's normals:
+  // ~0.26 ms in a row) and one whole-GPU evaluation (the K D sweep normals: 27 us + scan + scatter on a free device). With one gate in
+  // front of the whole set (rounds 4 and 5) the narrow chain filled the gap between two sweeps and the wide evaluation was
+  // dispatched into the next sweep: stuck for its 2.6 ms, the sweep 2.4 % slower. So the set is produced in two parts: the narrow
+  // chain of set t + 2 with this request, its wide evaluation only with the NEXT one, behind sweep t + 1 -- every gap then starts
+  // with a wide evaluation at full width (done ~0.1 ms into a ~0.28 ms gap, in time for sweep t + 2), followed by the next set's
+  // narrow chain, of which only the last single-workgroup kernel overlaps the next sweep's start.
   if (r.produced - r.acquired >= (r.current >= 0 ? mfm_ctx::RngEngine::N_SLOTS - 1 : mfm_ctx::RngEngine::N_SLOTS))
     throw Error(MFM_ERR_RUNTIME, "every random set is in use (one acquired, the others in flight): acquire the next one first");
   static const bool no_gate = std::getenv("MFM_RES_NO_GATE") != nullptr;  // (experiments with CUs left free by MFM_RES_CUS)
