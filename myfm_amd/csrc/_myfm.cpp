@@ -778,6 +778,21 @@ static Real host_tn_right(Gen &gen, Real mean, Real sd, Real mu_plus) {         
   return mean + sd * host_tn_right(gen, (mu_plus - mean) / sd);
 }
 
+// the parallel evaluation of the exact latent draws refused a draw (status of mfm_*_exact): said once per process -- the draws are
+// the same, but a sequential loop over N rows on the host is ~10x slower than the device path, and nobody should have to guess why
+static void warn_sequential_latent(int32_t status) {
+  static bool said = false;
+  if (said) return;
+  said = true;
+  static const char *why[] = {"", "the draw's path left the prepared windows", "scratch space (snapshots)", "scratch space (walkers)",
+                              "more engine outputs needed than prepared",
+                              "a score lies more than 1000 standard deviations on the wrong side of its class"};
+  std::fprintf(stderr,
+               "myfm_amd: exact latent draws: the parallel evaluation refused a draw (status %d: %s); it is made row by row on the "
+               "host from the same stream (same draws, slower). GibbsSession.latent_info() counts these.\n",
+               (int)status, status >= 1 && status <= 5 ? why[status] : "?");
+}
+
 struct OprobitSampler {
   mfm_ctx *ctx;
   int group;  // device-side cutpoint group
@@ -990,6 +1005,7 @@ struct OprobitSampler {
       ck(ctx, mfm_oprobit_sample_z_exact(ctx, group, gamma_now.data(), &st));
       if (st == 0) return;
       exact_fallbacks++;  // nothing was drawn or consumed: the same draws row after row, below, from the same stream position
+      warn_sequential_latent(st);
     } else if (!host_rows) {  // per-row Philox streams on the device
       ck(ctx, mfm_oprobit_sample_z(ctx, group, gamma_now.data(), seed, draw));
       return;
@@ -1516,7 +1532,10 @@ struct FMTrainer {
       int32_t st = 1;
       if (exact) {  // FMTrainer.hpp:498-512 on the device stream, evaluated in parallel (csrc/mfm_latent.hip)
         ck(ctx, mfm_update_e_classification_exact(ctx, &st));
-        if (st != 0) exact_fallbacks++;  // (nothing drawn or consumed, e holds the scores: row by row below)
+        if (st != 0) {  // (nothing drawn or consumed, e holds the scores: row by row below)
+          exact_fallbacks++;
+          warn_sequential_latent(st);
+        }
       }
       if (exact && st == 0) {
       } else if (cfg.host_rng() || exact) {  // FMTrainer.hpp:498-512 row by row, on the trainer's generator / the device stream
