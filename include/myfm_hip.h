@@ -296,7 +296,7 @@ int mfm_update_e_classification_exact(mfm_ctx *ctx, int32_t *status);
 int mfm_set_latent_order(mfm_ctx *ctx, const int64_t *rows, int64_t n);
 int mfm_oprobit_sample_z_exact(mfm_ctx *ctx, int32_t group, const double *gamma, int32_t *status);
 /* diagnostics of the last exact draw: {status, chunks, sub-chunks per chunk, quads per chunk, quads consumed, walkers started,
- * attempts (2: the first attempt's windows of +-4 sigma missed the path, the second's +-6.5 sigma held it), reserved} */
+ * attempts (2: the first attempt's windows of +-3.5 sigma missed the path, the second's +-6.5 sigma held it), reserved} */
 int mfm_latent_stats(mfm_ctx *ctx, int64_t *out8);
 /* The host's window into the device stream: out[0..n) = the engine outputs (tempered, as std::mt19937::operator() returns them)
  * number offset .. offset + n - 1 counted from the stream's position; mfm_rng_host_advance moves the position by `words` outputs.

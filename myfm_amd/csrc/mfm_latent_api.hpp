@@ -11,7 +11,7 @@
 // So the whole draw is ONE monotone lattice path over (row t, quad j): t += A(t, j), j += 1, where A depends on row t and quad
 // j only. Paths started at different rows of the same quad never cross and coincide for ever once they meet. mfm_latent.hip
 // cuts the quad axis into chunks, walks for every chunk ALL entering rows of a window that contains the true one with
-// probability 1 - 1e-6 (the walkers merge as they meet: "coalescing flows"), composes the chunks' maps, and re-walks the one
+// probability ~1 - 2e-5 (the walkers merge as they meet: "coalescing flows"), composes the chunks' maps, and re-walks the one
 // true path of every 1/C-th of a chunk in parallel to write the draws. Same draws, same engine consumption as the sequential
 // loop; when a window misses (or scratch overflows) nothing is consumed or written and the caller takes the sequential path.
 #pragma once

@@ -163,7 +163,7 @@ def test_every_geometry_gives_the_same_draws(mods, oracle, monkeypatch, env):
 @pytest.mark.parametrize("retry", ["0.02", "6.5"])
 def test_a_missed_window_falls_back_to_the_same_draws(mods, oracle, monkeypatch, retry):
     """windows of +-0.02 sigma cannot hold the path: the parallel evaluation reports it without having drawn or consumed anything.
-    retry 6.5: the second attempt with windows of +-6.5 sigma holds it (what happens to one draw in ~30 with the default +-4 sigma);
+    retry 6.5: the second attempt with windows of +-6.5 sigma holds it (what happens to one draw in ~100 with the default +-3.5 sigma);
     retry 0.02: the second attempt misses too and the sequential loop makes the same draws from the same stream position (the host's
     window into the device stream)."""
     _myfm, _ = mods
