@@ -292,14 +292,8 @@ __global__ __launch_bounds__(1024) void k_lat_scan(const double *__restrict__ bl
 }
 
 // ---- quad table ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lat_quads(const RngState *__restrict__ rs, const uint32_t *__restrict__ raw, uint64_t mask,
-                                                   int64_t nq, double *__restrict__ qt, double2 *__restrict__ qx) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= nq) return;
-  const uint64_t b = rs->p_cons + 4ull * (uint64_t)j;
-  const uint32_t w0 = mt_temper(raw[(b + 0) & mask]), w1 = mt_temper(raw[(b + 1) & mask]);
-  const uint32_t w2 = mt_temper(raw[(b + 2) & mask]), w3 = mt_temper(raw[(b + 3) & mask]);
-  const double u1 = canonical(w0, w1), u2 = canonical(w2, w3);
+// the quad of two canonical variates (u1, u2): what a walker looks at (LatQ) and what only the accepted value needs (n1, -log u1)
+__device__ __forceinline__ LatQ lat_make_quad(double u1, double u2, double *n1_out, double *nl1_out) {
   // Marsaglia polar attempt of normal_distribution (random.tcc:1811-1826): returns y * mult first, keeps x * mult
   const double x = 2.0 * u1 - 1.0, yy = 2.0 * u2 - 1.0;
   const double r2 = x * x + yy * yy;
@@ -310,12 +304,168 @@ __global__ __launch_bounds__(256) void k_lat_quads(const RngState *__restrict__ 
     n2 = (x * mult) * 1.0 + 0.0;
   }
   const double nl1 = -log(u1);
-  double *p = qt + (size_t)j * LAT_QW;
-  p[0] = u1;
-  p[1] = nl1 - 1.0;
-  p[2] = log(u2);
-  p[3] = n1 > n2 ? n1 : n2;  // (NaN when there is no pair)
-  qx[j] = make_double2(n1, nl1);
+  LatQ q;
+  q.xT = u1;
+  q.xE = nl1 - 1.0;
+  q.l2 = log(u2);
+  q.m = n1 > n2 ? n1 : n2;  // (NaN when there is no pair)
+  *n1_out = n1;
+  *nl1_out = nl1;
+  return q;
+}
+
+// ---- the windows' control variate ---------------------------------------------------------------------------------------
+// How far the draw has come after J quads is a sum of J accept / reject decisions; the a-priori windows treat it as a sum of
+// independent Bernoulli variables with the rows' own probabilities. But every quad is known before the walk, and much of a
+// decision is the QUAD's doing (one polar attempt in five has no pair at all: no one-sided row accepts it). With
+//   a(u1, u2) = the fraction of the rows that accept the quad (u1, u2),
+// tabulated on a G x G grid over the unit square from a sample of S rows at the cells' centres, the sum over the quads before J of
+// tab[cell(quad)] - mean(tab) estimates "accepts so far minus expected" -- its own expectation is EXACTLY zero whatever the table
+// holds ((u1, u2) is uniform on the square, the cells have equal area): it can be a better or a worse predictor, never a biased one.
+// The first attempt's windows are shifted by it and narrowed to the spread it leaves: rho = residual / Bernoulli variance, the
+// sample rows weighted by the quads the path spends on them (1 / p), estimated on the same grid (0.33 for probit classification at
+// config 3's shape -- measured on the resolved paths: 0.4 --, 0.55-0.7 for five-class ordered probit). A window that misses the path
+// is noticed as before; the second attempt uses the plain windows. Used for probit classification draws of 2^20 rows and more (the
+// table, its statistics and the chunk sums cost ~0.15 ms there): walkers 3.8 M -> 2.5 M at config 3's shape, 62.5 -> 68 it/s, second
+// attempts 3 in 402 draws as without it (scripts/r06_lat_cv.sh).
+constexpr int LAT_CV_G = 128, LAT_CV_S = 256;
+struct LatCv {
+  double mean, rho;  // mean of the table; variance ratio the first attempt's windows use
+  double rho_est;    // ... as estimated
+};
+// one thread per cell: its centre's quad (kept for the statistics pass) and the fraction of the sample that accepts it
+__global__ __launch_bounds__(256) void k_lat_cv_table(const double2 *__restrict__ wrec, int64_t n, float *__restrict__ tab,
+                                                      LatQ *__restrict__ cellq) {
+  __shared__ double2 s_rec[LAT_CV_S];
+  const int S = (int)min((int64_t)LAT_CV_S, n);
+  const int64_t stride = n / S;
+  for (int k = threadIdx.x; k < S; k += 256) s_rec[k] = wrec[(int64_t)k * stride + stride / 2];
+  __syncthreads();
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  const int i = cell / LAT_CV_G, j = cell % LAT_CV_G;
+  double n1, nl1;
+  const LatQ q = lat_make_quad((i + 0.5) / LAT_CV_G, (j + 0.5) / LAT_CV_G, &n1, &nl1);
+  cellq[cell] = q;
+  int acc = 0;
+  for (int k = 0; k < S; k++) {
+    bool band;
+    acc += lat_decide(s_rec[k].x, s_rec[k].y, q, band) ? 1 : 0;
+  }
+  tab[cell] = (float)acc / (float)S;
+}
+// one workgroup per sample row: its acceptance probability on the grid and what the table leaves of its variance
+__global__ __launch_bounds__(256) void k_lat_cv_stats(const double2 *__restrict__ wrec, int64_t n, const float *__restrict__ tab,
+                                                      const LatQ *__restrict__ cellq, double *__restrict__ row_r,
+                                                      double *__restrict__ row_v, LatCv *__restrict__ cv) {
+  __shared__ double s_a[256], s_b[256];
+  constexpr int NC = LAT_CV_G * LAT_CV_G;
+  const int tid = threadIdx.x;
+  const int S = (int)min((int64_t)LAT_CV_S, n);
+  const int64_t stride = n / S;
+  auto reduce2 = [&](double &a, double &b) {  // (fixed tree: the same numbers in every workgroup and every run)
+    s_a[tid] = a;
+    s_b[tid] = b;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+      if (tid < d) {
+        s_a[tid] += s_a[tid + d];
+        s_b[tid] += s_b[tid + d];
+      }
+      __syncthreads();
+    }
+    a = s_a[0];
+    b = s_b[0];
+    __syncthreads();
+  };
+  double tm = 0.0, dummy = 0.0;
+  for (int c = tid; c < NC; c += 256) tm += (double)tab[c];
+  reduce2(tm, dummy);
+  const double tbar = tm / NC;
+  if (blockIdx.x == 0 && tid == 0) cv->mean = tbar;
+  const double2 r = wrec[(int64_t)blockIdx.x * stride + stride / 2];
+  double cnt = 0.0, d2 = 0.0;
+  for (int c = tid; c < NC; c += 256) {
+    bool band;
+    const double a = lat_decide(r.x, r.y, cellq[c], band) ? 1.0 : 0.0;
+    const double d = a - (double)tab[c];
+    cnt += a;
+    d2 += d * d;
+  }
+  reduce2(cnt, d2);
+  if (tid == 0) {
+    const double p = cnt / NC;
+    const double wgt = 1.0 / fmax(p, 0.02);  // (the path spends 1 / p quads on the row)
+    row_v[blockIdx.x] = wgt * p * (1.0 - p);
+    row_r[blockIdx.x] = wgt * fmax(0.0, d2 / NC - (p - tbar) * (p - tbar));
+  }
+}
+__global__ __launch_bounds__(256) void k_lat_cv_rho(const double *__restrict__ row_r, const double *__restrict__ row_v, int64_t n,
+                                                    double safety, LatCv *__restrict__ cv) {
+  __shared__ double s_a[256], s_b[256];
+  const int tid = threadIdx.x;
+  const int S = (int)min((int64_t)LAT_CV_S, n);
+  s_a[tid] = tid < S ? row_r[tid] : 0.0;
+  s_b[tid] = tid < S ? row_v[tid] : 0.0;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (tid < d) {
+      s_a[tid] += s_a[tid + d];
+      s_b[tid] += s_b[tid + d];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double est = s_b[0] > 0.0 ? s_a[0] / s_b[0] : 1.0;
+    cv->rho_est = est;
+    cv->rho = fmin(1.0, safety * est + 0.02);  // (never wider than a priori)
+  }
+}
+// the table's sum over a chunk's quads, from the waves' sums (k_lat_quads): fixed order
+__global__ __launch_bounds__(256) void k_lat_cv_chunks(const double *__restrict__ wavecv, int64_t waves_per_chunk, int64_t n_waves,
+                                                       double *__restrict__ cvsum) {
+  __shared__ double s_a[256];
+  const int tid = threadIdx.x;
+  const int64_t w0 = (int64_t)blockIdx.x * waves_per_chunk, w1 = min(n_waves, w0 + waves_per_chunk);
+  double a = 0.0;
+  for (int64_t w = w0 + tid; w < w1; w += 256) a += wavecv[w];
+  s_a[tid] = a;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (tid < d) s_a[tid] += s_a[tid + d];
+    __syncthreads();
+  }
+  if (tid == 0) cvsum[blockIdx.x] = s_a[0];
+}
+
+// ---- quad table ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lat_quads(const RngState *__restrict__ rs, const uint32_t *__restrict__ raw, uint64_t mask,
+                                                   int64_t nq, double *__restrict__ qt, double2 *__restrict__ qx,
+                                                   const float *__restrict__ cvtab, const LatCv *__restrict__ cv,
+                                                   double *__restrict__ wavecv) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double dv = 0.0;
+  if (j < nq) {
+    const uint64_t b = rs->p_cons + 4ull * (uint64_t)j;
+    const uint32_t w0 = mt_temper(raw[(b + 0) & mask]), w1 = mt_temper(raw[(b + 1) & mask]);
+    const uint32_t w2 = mt_temper(raw[(b + 2) & mask]), w3 = mt_temper(raw[(b + 3) & mask]);
+    const double u1 = canonical(w0, w1), u2 = canonical(w2, w3);
+    double n1, nl1;
+    const LatQ q = lat_make_quad(u1, u2, &n1, &nl1);
+    double *p = qt + (size_t)j * LAT_QW;
+    p[0] = q.xT;
+    p[1] = q.xE;
+    p[2] = q.l2;
+    p[3] = q.m;
+    qx[j] = make_double2(n1, nl1);
+    if (cvtab) {
+      const int ci = min(LAT_CV_G - 1, (int)(u1 * LAT_CV_G)), cj = min(LAT_CV_G - 1, (int)(u2 * LAT_CV_G));
+      dv = (double)cvtab[ci * LAT_CV_G + cj] - cv->mean;
+    }
+  }
+  if (!cvtab) return;
+  // (a wave's 64 quads lie in one chunk: chunks are multiples of 64 quads)
+  for (int d = 32; d > 0; d >>= 1) dv += __shfl_down(dv, d, 64);
+  if ((threadIdx.x & 63) == 0) wavecv[j >> 6] = dv;
 }
 
 // snapshot entries a chunk with W entering rows may write: its walkers at every sub-chunk boundary, about K W / sqrt(quads walked) with
@@ -349,12 +499,23 @@ __global__ __launch_bounds__(1024) void k_lat_windows(const double *__restrict__
                                                       int subq, double ksig, int32_t *__restrict__ win_lo, int32_t *__restrict__ win_hi,
                                                       int64_t *__restrict__ list_off, int64_t *__restrict__ snap_off,
                                                       int32_t *__restrict__ live, int64_t list_cap, int64_t snap_cap,
-                                                      LatStatus *__restrict__ st) {
+                                                      LatStatus *__restrict__ st, const double *__restrict__ cvsum,
+                                                      double *__restrict__ cvcum, const LatCv *__restrict__ cv) {
   __shared__ int64_t s_w[1024], s_s[1024];
   const int tid = threadIdx.x;
   const int nsub = (int)(Lq / subq);
   const int per = (C + 1023) / 1024;
   const int c0 = min(C, tid * per), c1 = min(C, c0 + per);
+  // control variate (cv != null: the first attempt): accepts beyond the expected number in the quads before every chunk
+  if (cv && tid == 0) {
+    double acc = 0.0;
+    for (int c = 0; c < C; c++) {
+      cvcum[c] = acc;
+      acc += cvsum[c];
+    }
+  }
+  __syncthreads();
+  const double srho = cv ? sqrt(cv->rho) : 1.0;
   int64_t sw = 0, ss = 0;
   for (int c = c0; c < c1; c++) {
     int64_t lo = 0, hi = 0;
@@ -362,9 +523,12 @@ __global__ __launch_bounds__(1024) void k_lat_windows(const double *__restrict__
       const double J = (double)c * (double)Lq;
       const int64_t ts = lat_find_row(PM, mf, n, nb, J);
       const int64_t b = min(nb - 1, ts / LAT_RB);
-      const double sd = sqrt(PV[b + 1]);
-      lo = max((int64_t)0, lat_find_row(PM, mf, n, nb, J - ksig * sd) - 2);
-      hi = min(n, lat_find_row(PM, mf, n, nb, J + ksig * sd) + 2);
+      const double sd = sqrt(PV[b + 1]) * srho;
+      const int64_t shift = cv ? (int64_t)llrint(cvcum[c]) : 0;
+      lo = min(n, max((int64_t)0, lat_find_row(PM, mf, n, nb, J - ksig * sd) - 2 + shift));
+      // (a window that reaches "all rows served" keeps that end where it is: a draw that is over by this chunk enters it at row n)
+      const int64_t hi0 = min(n, lat_find_row(PM, mf, n, nb, J + ksig * sd) + 2);
+      hi = max(lo, hi0 == n ? n : min(n, hi0 + shift));
     }
     win_lo[c] = (int32_t)lo;
     win_hi[c] = (int32_t)hi;
@@ -986,6 +1150,11 @@ struct LatentEngine::Impl {
   DevBuf<int2> snap;
   DevBuf<LatStatus> status;
   DevBuf<uint64_t> pos;
+  // the windows' control variate
+  DevBuf<float> cvtab;
+  DevBuf<LatQ> cvq;
+  DevBuf<double> cvsum, cvcum, cvrow, wavecv;
+  DevBuf<LatCv> cv;
   LatStatus *h_status = nullptr;  // pinned
   uint64_t *h_pos = nullptr;
   int32_t *h_max = nullptr;       // [0] largest list of a round, [1] the row pass's "too wide" flag
@@ -1112,7 +1281,30 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
   Impl::ensure(m.Tc, (size_t)C + 1);
 
   if (timing) MFM_HIP_CHECK(hipEventRecord(ev[0], s));
-  hipLaunchKernelGGL(k_lat_quads, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, job.state, job.raw, job.mask, nq, m.qt.p, m.qx.p);
+  // (probit classification only: there the quads decide two thirds of the variance; for ordered probit -- two-sided rows, whose
+  //  decisions depend on their own interval -- a third, which pays for the table and no more: 56.7 -> 56.2 ... 57.8 it/s at config 3's
+  //  shape, 2.437 -> 2.432 ... 2.439 at config 5, against 62.5 -> 68.3 ... 69.4 for classification)
+  const bool use_cv = job.n_class == 0 && n >= env_int("MFM_LAT_CV_MIN_ROWS", 1 << 20) && std::getenv("MFM_LAT_NO_CV") == nullptr;
+  const int64_t n_waves = (nq + 63) / 64;
+  if (use_cv) {
+    constexpr int NC = LAT_CV_G * LAT_CV_G;
+    Impl::ensure(m.cvtab, (size_t)NC);
+    Impl::ensure(m.cvq, (size_t)NC);
+    Impl::ensure(m.cvrow, (size_t)2 * LAT_CV_S);
+    Impl::ensure(m.cvsum, (size_t)C + 1);
+    Impl::ensure(m.cvcum, (size_t)C + 1);
+    Impl::ensure(m.wavecv, (size_t)n_waves + 4);
+    if (!m.cv.p) m.cv.alloc(1);
+    const int S = (int)std::min<int64_t>(LAT_CV_S, n);
+    hipLaunchKernelGGL(k_lat_cv_table, dim3(NC / 256), dim3(256), 0, s, m.wrec.p, n, m.cvtab.p, m.cvq.p);
+    hipLaunchKernelGGL(k_lat_cv_stats, dim3((unsigned)S), dim3(256), 0, s, m.wrec.p, n, m.cvtab.p, m.cvq.p, m.cvrow.p,
+                       m.cvrow.p + LAT_CV_S, m.cv.p);
+    hipLaunchKernelGGL(k_lat_cv_rho, dim3(1), dim3(256), 0, s, m.cvrow.p, m.cvrow.p + LAT_CV_S, n, env_double("MFM_LAT_CV_SAFETY", 1.15),
+                       m.cv.p);
+  }
+  hipLaunchKernelGGL(k_lat_quads, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, job.state, job.raw, job.mask, nq, m.qt.p, m.qx.p,
+                     use_cv ? m.cvtab.p : (const float *)nullptr, m.cv.p, m.wavecv.p);
+  if (use_cv) hipLaunchKernelGGL(k_lat_cv_chunks, dim3((unsigned)C), dim3(256), 0, s, m.wavecv.p, Lq / 64, n_waves, m.cvsum.p);
   if (timing) MFM_HIP_CHECK(hipEventRecord(ev[1], s));
   int rounds_done = 0, handover = 0, attempts = 0;
   int64_t max_live = 0;
@@ -1128,8 +1320,11 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
     Impl::ensure(m.snap, (size_t)snap_cap);
     MFM_HIP_CHECK(hipMemsetAsync(m.max_live.p, 0, sizeof(int32_t) * LAT_MAX_ROUNDS, s));
     MFM_HIP_CHECK(hipMemsetAsync(m.status.p, 0, 2 * sizeof(int32_t), s));  // (fail, fail_chunk)
+    // (first attempt: windows shifted by the control variate and narrowed to what it leaves; second: the plain a-priori windows)
+    const bool cv_now = use_cv && attempts == 1;
     hipLaunchKernelGGL(k_lat_windows, dim3(1), dim3(1024), 0, s, m.PM.p, m.PV.p, m.mf.p, n, nb, C, Lq, subq, ksig, m.win_lo.p,
-                       m.win_hi.p, m.list_off.p, m.snap_off.p, m.live.p, list_cap, snap_cap, m.status.p);
+                       m.win_hi.p, m.list_off.p, m.snap_off.p, m.live.p, list_cap, snap_cap, m.status.p, m.cvsum.p, m.cvcum.p,
+                       cv_now ? m.cv.p : (const LatCv *)nullptr);
     // Rounds over all chunks' walkers as grid-wide launches (16, 16, 32, ... quads up to the first sub-chunk boundary, then a
     // sub-chunk per round) while some chunk still has more walkers than a workgroup of the resident kernel; the host reads the
     // largest list back after every round (4 bytes) to size the next launch and to decide the hand-over.
@@ -1198,7 +1393,43 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
     MFM_HIP_CHECK(hipGetLastError());
     MFM_HIP_CHECK(hipMemcpyAsync(m.h_status, m.status.p, sizeof(LatStatus), hipMemcpyDeviceToHost, s));
     MFM_HIP_CHECK(hipStreamSynchronize(s));
+    if (m.h_status->fail == 1 && use_cv && std::getenv("MFM_LAT_CV_DEBUG")) {
+      const int fc = m.h_status->fail_chunk;
+      int32_t t = 0, l = 0, h = 0;
+      double cum = 0;
+      MFM_HIP_CHECK(hipMemcpy(&t, m.Tc.p + fc, sizeof(int32_t), hipMemcpyDeviceToHost));
+      MFM_HIP_CHECK(hipMemcpy(&l, m.win_lo.p + fc, sizeof(int32_t), hipMemcpyDeviceToHost));
+      MFM_HIP_CHECK(hipMemcpy(&h, m.win_hi.p + fc, sizeof(int32_t), hipMemcpyDeviceToHost));
+      MFM_HIP_CHECK(hipMemcpy(&cum, m.cvcum.p + fc, sizeof(double), hipMemcpyDeviceToHost));
+      std::fprintf(stderr, "[latent cv] attempt %d missed at chunk %d of %d: entering row %d, window [%d, %d] (shift %.1f)\n", attempts, fc, C, t, l, h, cum);
+    }
     if (m.h_status->fail != 1 || ksig >= m.ksig_retry) break;  // (only a missed window is worth a second look)
+  }
+  if (use_cv && std::getenv("MFM_LAT_CV_DEBUG")) {  // how well the control variate tracks the path (chunk by chunk)
+    std::vector<int32_t> tc((size_t)C + 1), lo((size_t)C), hi((size_t)C);
+    std::vector<double> cum((size_t)C + 1);
+    MFM_HIP_CHECK(hipMemcpy(tc.data(), m.Tc.p, sizeof(int32_t) * ((size_t)C + 1), hipMemcpyDeviceToHost));
+    MFM_HIP_CHECK(hipMemcpy(lo.data(), m.win_lo.p, sizeof(int32_t) * (size_t)C, hipMemcpyDeviceToHost));
+    MFM_HIP_CHECK(hipMemcpy(hi.data(), m.win_hi.p, sizeof(int32_t) * (size_t)C, hipMemcpyDeviceToHost));
+    MFM_HIP_CHECK(hipMemcpy(cum.data(), m.cvcum.p, sizeof(double) * (size_t)C, hipMemcpyDeviceToHost));
+    const bool shifted = attempts == 1;
+    double sxx = 0, syy = 0, sxy = 0, sx = 0, sy = 0;
+    int cnt = 0;
+    for (int c = 1; c < C; c++) {
+      if (tc[c] >= n) break;
+      const double mid = 0.5 * ((double)lo[c] + hi[c]) - (shifted ? std::llrint(cum[c]) : 0);  // a-priori centre
+      const double d = (double)tc[c] - mid, v = cum[c];
+      sx += d; sy += v; sxx += d * d; syy += v * v; sxy += d * v;
+      cnt++;
+    }
+    if (cnt > 2) {
+      const double mx = sx / cnt, my = sy / cnt;
+      const double vx = sxx / cnt - mx * mx, vy = syy / cnt - my * my, cxy = sxy / cnt - mx * my;
+      std::fprintf(stderr, "[latent cv] chunks %d attempts %d: rms deviation from the a-priori centre %.1f, rms control variate %.1f, correlation %.3f, "
+                   "rms of (deviation - cv) %.1f; last chunk: deviation %.1f cv %.1f\n", cnt, attempts, std::sqrt(sxx / cnt), std::sqrt(syy / cnt),
+                   cxy / std::sqrt(vx * vy + 1e-300), std::sqrt((sxx - 2 * sxy + syy) / cnt),
+                   (double)tc[cnt] - (0.5 * ((double)lo[cnt] + hi[cnt]) - (shifted ? std::llrint(cum[cnt]) : 0)), cum[cnt]);
+    }
   }
   S.status = m.h_status->fail;
   S.chunks = C;
@@ -1215,12 +1446,15 @@ int LatentEngine::run(const LatentJob &job, const LatentPrep &prep, LatentStats 
     S.ms_quads = a;
     S.ms_flow = b;
     S.ms_final = c2;
+    LatCv hcv{0.0, 1.0, 1.0};
+    if (use_cv) MFM_HIP_CHECK(hipMemcpy(&hcv, m.cv.p, sizeof(LatCv), hipMemcpyDeviceToHost));
     std::fprintf(stderr,
                  "[latent] n %lld quads %lld (cap %lld) chunks %d x %lld (sub %d) walkers %lld, %d rounds then resident from quad %d "
-                 "(largest list %lld), %d attempt(s), status %d (chunk %d) | first attempt: quads %.3f ms, windows+flows %.3f ms, "
-                 "resolve+final %.3f ms\n",
+                 "(largest list %lld), %d attempt(s), status %d (chunk %d), variance ratio %.3f (used %.3f) | first attempt: quads + "
+                 "table %.3f ms, windows+flows %.3f ms, resolve+final %.3f ms\n",
                  (long long)n, (long long)S.quads_used, (long long)prep.q_cap, C, (long long)Lq, subq, (long long)S.walkers, rounds_done,
-                 handover, (long long)max_live, attempts, S.status, S.status ? m.h_status->fail_chunk : -1, a, b, c2);
+                 handover, (long long)max_live, attempts, S.status, S.status ? m.h_status->fail_chunk : -1, hcv.rho_est, hcv.rho, a, b,
+                 c2);
     for (auto &e : ev) (void)hipEventDestroy(e);
   }
   if (stats) *stats = S;
